@@ -1,0 +1,47 @@
+"""Seeded synthetic Gaussian sets with the statistics of the reference's decoder output
+(/root/reference/lightning/network.py:323,372-375,689-693)."""
+from __future__ import annotations
+
+import math
+
+import torch
+
+
+def make_scene(n: int, seed: int, sh_degree: int = 3, sigma0=(0.0052, 0.00065), device="cpu"):
+    """Raw (pre-activation) attributes exactly as `Renderer.render_img` receives them
+    (lightning/renderer.py:209-230): centers (N,3), shs (N,M,3), opacity logits (N,1),
+    log-scales (N,3), raw quaternions (N,4).  `sigma0` may be one value or a tuple that
+    is mixed in equal parts (C2: 50/50 coarse-like / densified-like)."""
+    g = torch.Generator().manual_seed(seed)
+    if not isinstance(sigma0, (tuple, list)):
+        sigma0 = (sigma0,)
+    centers = torch.rand(n, 3, generator=g) - 0.5
+    logs = torch.empty(n, 3)
+    per = (n + len(sigma0) - 1) // len(sigma0)
+    for k, s0 in enumerate(sigma0):
+        lo, hi = k * per, min(n, (k + 1) * per)
+        if hi > lo:
+            logs[lo:hi] = math.log(s0) + 0.3 * torch.randn(hi - lo, 3, generator=g)
+    rots = torch.randn(n, 4, generator=g)
+    opac = -2.18 + 1.5 * torch.randn(n, 1, generator=g)
+    m = (sh_degree + 1) ** 2
+    shs = torch.empty(n, m, 3)
+    shs[:, 0] = torch.randn(n, 3, generator=g)
+    if m > 1:
+        shs[:, 1:] = 0.1 * torch.randn(n, m - 1, 3, generator=g)
+    perm = torch.randperm(n, generator=g)  # interleave the sigma0 populations
+    out = dict(centers=centers[perm], shs=shs[perm], opacity=opac[perm], scales=logs[perm],
+               rotations=rots[perm])
+    return {k: v.contiguous().to(device) for k, v in out.items()}
+
+
+def make_targets(n_views: int, h: int, w: int, seed: int, device="cpu"):
+    g = torch.Generator().manual_seed(seed + 7919)
+    return torch.rand(n_views, h, w, 3, generator=g).to(device)
+
+
+def view_loss(out: dict, target: torch.Tensor, prex: str = "") -> torch.Tensor:
+    """SURVEY §8d loss: MSE(clamp(image), target) + 0.1 mean(depth) + 0.1 mean(alpha) —
+    exercises the colour, depth and alpha gradient paths (network.py:746-752 keeps all three)."""
+    return (((out[f"image{prex}"] - target) ** 2).mean() + 0.1 * out[f"depth{prex}"].mean()
+            + 0.1 * out[f"acc_map{prex}"].mean())
