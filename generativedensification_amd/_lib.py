@@ -1,0 +1,116 @@
+"""ctypes binding of libgdr_hip.so (C ABI: include/gdr.h).
+
+The HIP library is the product; there is NO CPU fallback: if the shared object is
+missing or a call fails, we raise.  `torch` must be imported before the library is
+loaded so that both share one HIP runtime (libamdhip64.so.7, matched by SONAME).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (loads the HIP runtime first — see module docstring)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libgdr_hip.so")
+
+GDR_OK = 0
+GDR_ERR_WORKSPACE = -4
+
+
+class GdrSettings(C.Structure):
+    _fields_ = [("image_height", C.c_int32), ("image_width", C.c_int32), ("tanfovx", C.c_float),
+                ("tanfovy", C.c_float), ("scale_modifier", C.c_float), ("sh_degree", C.c_int32),
+                ("prefiltered", C.c_int32), ("debug", C.c_int32), ("bg", C.c_void_p),
+                ("viewmatrix", C.c_void_p), ("projmatrix", C.c_void_p), ("campos", C.c_void_p)]
+
+
+class GdrInputs(C.Structure):
+    _fields_ = [("N", C.c_int32), ("M", C.c_int32), ("means3D", C.c_void_p), ("opacities", C.c_void_p),
+                ("shs", C.c_void_p), ("colors_precomp", C.c_void_p), ("scales", C.c_void_p),
+                ("rotations", C.c_void_p), ("cov3D_precomp", C.c_void_p)]
+
+
+class GdrGeom(C.Structure):
+    _fields_ = [("depths", C.c_void_p), ("xy", C.c_void_p), ("conic_opacity", C.c_void_p),
+                ("rgb", C.c_void_p), ("cov3D", C.c_void_p), ("rect", C.c_void_p),
+                ("tiles_touched", C.c_void_p), ("clamped", C.c_void_p), ("block_sums", C.c_void_p),
+                ("num_rendered", C.c_void_p)]
+
+
+class GdrBinning(C.Structure):
+    _fields_ = [("keys", C.c_void_p * 2), ("values", C.c_void_p * 2), ("hist", C.c_void_p),
+                ("sorted", C.c_int32), ("reserved", C.c_int32)]
+
+
+class GdrImage(C.Structure):
+    _fields_ = [("ranges", C.c_void_p), ("n_contrib", C.c_void_p), ("final_T", C.c_void_p)]
+
+
+class GdrOutputs(C.Structure):
+    _fields_ = [("color", C.c_void_p), ("depth", C.c_void_p), ("alpha", C.c_void_p),
+                ("radii", C.c_void_p)]
+
+
+class GdrGradInputs(C.Structure):
+    _fields_ = [("dL_dcolor", C.c_void_p), ("dL_ddepth", C.c_void_p), ("dL_dalpha", C.c_void_p)]
+
+
+class GdrGradOutputs(C.Structure):
+    _fields_ = [("dL_dmeans3D", C.c_void_p), ("dL_dmeans2D", C.c_void_p), ("dL_dshs", C.c_void_p),
+                ("dL_dcolors", C.c_void_p), ("dL_dopacities", C.c_void_p), ("dL_dscales", C.c_void_p),
+                ("dL_drotations", C.c_void_p), ("dL_dcov3D", C.c_void_p), ("scratch", C.c_void_p)]
+
+
+# every symbol include/gdr.h declares, with its prototype
+_PROTOS = {
+    "gdr_abi_version": (C.c_int, []),
+    "gdr_last_error": (C.c_char_p, []),
+    "gdr_geom_bytes": (C.c_size_t, [C.c_int32]),
+    "gdr_binning_bytes": (C.c_size_t, [C.c_uint64]),
+    "gdr_image_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
+    "gdr_geom_carve": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(GdrGeom)]),
+    "gdr_binning_carve": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(GdrBinning)]),
+    "gdr_image_carve": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(GdrImage)]),
+    "gdr_preprocess_forward": (C.c_int, [C.POINTER(GdrSettings), C.POINTER(GdrInputs), C.POINTER(GdrGeom),
+                                         C.c_void_p, C.POINTER(C.c_uint32), C.c_void_p]),
+    "gdr_render_forward": (C.c_int, [C.POINTER(GdrSettings), C.POINTER(GdrInputs), C.POINTER(GdrGeom),
+                                     C.POINTER(GdrBinning), C.POINTER(GdrImage), C.c_uint64,
+                                     C.POINTER(GdrOutputs), C.c_void_p]),
+    "gdr_forward": (C.c_int, [C.POINTER(GdrSettings), C.POINTER(GdrInputs), C.POINTER(GdrGeom),
+                              C.POINTER(GdrBinning), C.POINTER(GdrImage), C.c_uint64,
+                              C.POINTER(GdrOutputs), C.POINTER(C.c_uint32), C.c_void_p]),
+    "gdr_backward": (C.c_int, [C.POINTER(GdrSettings), C.POINTER(GdrInputs), C.POINTER(GdrGeom),
+                               C.POINTER(GdrBinning), C.POINTER(GdrImage), C.c_uint64, C.c_void_p,
+                               C.POINTER(GdrGradInputs), C.POINTER(GdrGradOutputs), C.c_void_p]),
+    "gdr_mark_visible": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+}
+EXPORTED_SYMBOLS = tuple(_PROTOS)
+
+_lib = None
+
+
+def load():
+    """Load libgdr_hip.so (built in-tree by __graft_entry__.build() / csrc/Makefile)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: the HIP rasterizer is not built. Run "
+                "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C "
+                "generativedensification_amd/csrc`). There is no CPU fallback.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in _PROTOS.items():
+            fn = getattr(lib, name)  # AttributeError if the symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+        if lib.gdr_abi_version() != 1:
+            raise RuntimeError("libgdr_hip.so ABI version mismatch")
+        _lib = lib
+    return _lib
+
+
+def check(rc: int, what: str):
+    if rc != GDR_OK:
+        msg = load().gdr_last_error()
+        raise RuntimeError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")

@@ -1,0 +1,252 @@
+// api.hip — the C ABI of libgdr_hip.so (include/gdr.h): argument checking, workspace
+// carving and stage sequencing.  Host code only; all kernels live in preprocess.hip,
+// binning.hip and render.hip.  Nothing here allocates device memory or keeps state.
+#include <stdio.h>
+#include <string.h>
+
+#include "gdr_common.h"
+
+namespace gdr {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* what, hipError_t e) {
+    snprintf(g_err, sizeof(g_err), "%s: %s (%d)", what, e == hipSuccess ? "" : hipGetErrorString(e), (int)e);
+}
+
+static inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+
+struct Carver {
+    char* base;
+    size_t off = 0;
+    explicit Carver(void* b) : base((char*)b) {}
+    template <typename T>
+    T* take(size_t count) {
+        T* p = base ? (T*)(base + off) : nullptr;
+        off = align_up(off + count * sizeof(T));
+        return p;
+    }
+};
+
+static size_t carve_geom(void* base, int64_t N, gdr_geom* g) {
+    Carver c(base);
+    gdr_geom t;
+    const size_t n = (size_t)(N > 0 ? N : 1);
+    t.depths = c.take<float>(n);
+    t.xy = c.take<float>(2 * n);
+    t.conic_opacity = c.take<float>(4 * n);
+    t.rgb = c.take<float>(4 * n);
+    t.cov3D = c.take<float>(6 * n);
+    t.rect = c.take<int32_t>(4 * n);
+    t.tiles_touched = c.take<uint32_t>(n);
+    t.clamped = c.take<uint8_t>(n);
+    t.block_sums = c.take<uint32_t>((n + GDR_BLOCK - 1) / GDR_BLOCK + 1);
+    t.num_rendered = c.take<uint32_t>(1);
+    if (g) *g = t;
+    return c.off;
+}
+
+static size_t carve_binning(void* base, uint64_t D, gdr_binning* b) {
+    Carver c(base);
+    gdr_binning t;
+    const size_t d = (size_t)(D > 0 ? D : 1);
+    t.keys[0] = c.take<uint64_t>(d);
+    t.keys[1] = c.take<uint64_t>(d);
+    t.values[0] = c.take<uint32_t>(d);
+    t.values[1] = c.take<uint32_t>(d);
+    t.hist = c.take<uint32_t>(sort_hist_bytes(D) / sizeof(uint32_t));
+    t.sorted = 0;
+    t.reserved = 0;
+    if (b) *b = t;
+    return c.off;
+}
+
+static size_t carve_image(void* base, int H, int W, gdr_image* im) {
+    Carver c(base);
+    gdr_image t;
+    const size_t tiles = (size_t)tile_grid_x(W) * tile_grid_y(H);
+    const size_t P = (size_t)H * W;
+    t.ranges = c.take<uint32_t>(2 * (tiles ? tiles : 1));
+    t.n_contrib = c.take<uint32_t>(P ? P : 1);
+    t.final_T = c.take<float>(P ? P : 1);
+    if (im) *im = t;
+    return c.off;
+}
+
+static int check_common(const gdr_settings* s, const gdr_inputs* in) {
+    if (!s || !in) { set_error("NULL settings/inputs", hipSuccess); return GDR_ERR_INVALID_ARG; }
+    if (in->N < 0 || s->image_height <= 0 || s->image_width <= 0) {
+        set_error("negative N or empty image", hipSuccess);
+        return GDR_ERR_INVALID_ARG;
+    }
+    if (!s->bg || !s->viewmatrix || !s->projmatrix) {
+        set_error("bg/viewmatrix/projmatrix must be device pointers", hipSuccess);
+        return GDR_ERR_INVALID_ARG;
+    }
+    if (in->N > 0) {
+        if (!in->means3D || !in->opacities) { set_error("means3D/opacities NULL", hipSuccess); return GDR_ERR_INVALID_ARG; }
+        if ((in->shs != nullptr) == (in->colors_precomp != nullptr)) {
+            set_error("provide exactly one of shs / colors_precomp", hipSuccess);
+            return GDR_ERR_INVALID_ARG;
+        }
+        const bool sr = in->scales && in->rotations;
+        if (sr == (in->cov3D_precomp != nullptr) || ((in->scales != nullptr) != (in->rotations != nullptr))) {
+            set_error("provide exactly one of (scales, rotations) / cov3D_precomp", hipSuccess);
+            return GDR_ERR_INVALID_ARG;
+        }
+        if (in->shs) {
+            if (s->sh_degree < 0 || s->sh_degree > 3) { set_error("sh_degree must be 0..3", hipSuccess); return GDR_ERR_UNSUPPORTED; }
+            if (in->M < (s->sh_degree + 1) * (s->sh_degree + 1)) { set_error("M < (sh_degree+1)^2", hipSuccess); return GDR_ERR_INVALID_ARG; }
+            if (!s->campos) { set_error("campos NULL", hipSuccess); return GDR_ERR_INVALID_ARG; }
+        }
+    }
+    return GDR_OK;
+}
+
+static int hip_fail(const char* what, hipError_t e) {
+    set_error(what, e);
+    return GDR_ERR_HIP;
+}
+
+static int debug_sync(const gdr_settings* s, const char* what, hipStream_t st) {
+    if (!s->debug) return GDR_OK;
+    hipError_t e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return hip_fail(what, e);
+    return GDR_OK;
+}
+
+}  // namespace gdr
+
+using namespace gdr;
+
+extern "C" {
+
+int gdr_abi_version(void) { return GDR_ABI_VERSION; }
+const char* gdr_last_error(void) { return g_err; }
+
+size_t gdr_geom_bytes(int32_t N) { return carve_geom(nullptr, N, nullptr); }
+size_t gdr_binning_bytes(uint64_t D) { return carve_binning(nullptr, D, nullptr); }
+size_t gdr_image_bytes(int32_t H, int32_t W) { return carve_image(nullptr, H, W, nullptr); }
+
+int gdr_geom_carve(void* base, int32_t N, gdr_geom* out) {
+    if (!base || !out || ((uintptr_t)base & 255u)) { set_error("geom base NULL/unaligned", hipSuccess); return GDR_ERR_INVALID_ARG; }
+    carve_geom(base, N, out);
+    return GDR_OK;
+}
+int gdr_binning_carve(void* base, uint64_t D, gdr_binning* out) {
+    if (!base || !out || ((uintptr_t)base & 255u)) { set_error("binning base NULL/unaligned", hipSuccess); return GDR_ERR_INVALID_ARG; }
+    carve_binning(base, D, out);
+    return GDR_OK;
+}
+int gdr_image_carve(void* base, int32_t H, int32_t W, gdr_image* out) {
+    if (!base || !out || ((uintptr_t)base & 255u)) { set_error("image base NULL/unaligned", hipSuccess); return GDR_ERR_INVALID_ARG; }
+    carve_image(base, H, W, out);
+    return GDR_OK;
+}
+
+int gdr_preprocess_forward(const gdr_settings* s, const gdr_inputs* in, const gdr_geom* geom,
+                           int32_t* radii, uint32_t* num_rendered_host, void* stream) {
+    int rc = check_common(s, in);
+    if (rc) return rc;
+    if (!geom || (in->N > 0 && !radii)) { set_error("geom/radii NULL", hipSuccess); return GDR_ERR_INVALID_ARG; }
+    const int tiles = tile_grid_x(s->image_width) * tile_grid_y(s->image_height);
+    if (key_bits(tiles) > 64) { set_error("image too large", hipSuccess); return GDR_ERR_UNSUPPORTED; }
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = launch_preprocess_fwd(s, in, geom, radii, st);
+    if (e != hipSuccess) return hip_fail("preprocess_fwd", e);
+    if ((rc = debug_sync(s, "preprocess_fwd", st))) return rc;
+    e = launch_scan_block_sums(geom, in->N, st);
+    if (e != hipSuccess) return hip_fail("scan_block_sums", e);
+    if ((rc = debug_sync(s, "scan_block_sums", st))) return rc;
+    if (num_rendered_host) {
+        e = hipMemcpyAsync(num_rendered_host, geom->num_rendered, sizeof(uint32_t), hipMemcpyDeviceToHost, st);
+        if (e != hipSuccess) return hip_fail("memcpy num_rendered", e);
+        e = hipStreamSynchronize(st);
+        if (e != hipSuccess) return hip_fail("sync num_rendered", e);
+    }
+    return GDR_OK;
+}
+
+int gdr_render_forward(const gdr_settings* s, const gdr_inputs* in, const gdr_geom* geom,
+                       gdr_binning* bin, const gdr_image* img, uint64_t D, const gdr_outputs* out,
+                       void* stream) {
+    int rc = check_common(s, in);
+    if (rc) return rc;
+    if (!geom || !bin || !img || !out || !out->color || !out->depth || !out->alpha || !out->radii) {
+        set_error("render_forward: NULL argument", hipSuccess);
+        return GDR_ERR_INVALID_ARG;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int W = s->image_width, H = s->image_height;
+    const int tiles = tile_grid_x(W) * tile_grid_y(H);
+    hipError_t e = launch_duplicate(geom, in->N, W, H, out->radii, bin->keys[0], bin->values[0], D, st);
+    if (e != hipSuccess) return hip_fail("duplicate", e);
+    if ((rc = debug_sync(s, "duplicate", st))) return rc;
+    e = launch_sort(bin, D, key_bits(tiles), st);
+    if (e != hipSuccess) return hip_fail("sort", e);
+    if ((rc = debug_sync(s, "sort", st))) return rc;
+    e = launch_ranges(bin, D, img, tiles, st);
+    if (e != hipSuccess) return hip_fail("ranges", e);
+    if ((rc = debug_sync(s, "ranges", st))) return rc;
+    e = launch_render_fwd(s, geom, bin, img, out, st);
+    if (e != hipSuccess) return hip_fail("render_fwd", e);
+    if ((rc = debug_sync(s, "render_fwd", st))) return rc;
+    return GDR_OK;
+}
+
+int gdr_forward(const gdr_settings* s, const gdr_inputs* in, const gdr_geom* geom, gdr_binning* bin,
+                const gdr_image* img, uint64_t D_cap, const gdr_outputs* out,
+                uint32_t* num_rendered_host, void* stream) {
+    if (!out || !num_rendered_host) { set_error("gdr_forward: NULL out/num_rendered_host", hipSuccess); return GDR_ERR_INVALID_ARG; }
+    int rc = gdr_preprocess_forward(s, in, geom, out->radii, num_rendered_host, stream);
+    if (rc) return rc;
+    if ((uint64_t)*num_rendered_host > D_cap) {
+        set_error("binning workspace too small for num_rendered", hipSuccess);
+        return GDR_ERR_WORKSPACE;
+    }
+    return gdr_render_forward(s, in, geom, bin, img, *num_rendered_host, out, stream);
+}
+
+int gdr_backward(const gdr_settings* s, const gdr_inputs* in, const gdr_geom* geom,
+                 const gdr_binning* bin, const gdr_image* img, uint64_t D, const int32_t* radii,
+                 const gdr_grad_inputs* gin, const gdr_grad_outputs* gout, void* stream) {
+    (void)D;
+    int rc = check_common(s, in);
+    if (rc) return rc;
+    if (!geom || !bin || !img || !gin || !gout || !gin->dL_dcolor || !gout->dL_dmeans3D ||
+        !gout->dL_dmeans2D || !gout->dL_dopacities || !gout->scratch || (in->N > 0 && !radii)) {
+        set_error("backward: NULL argument", hipSuccess);
+        return GDR_ERR_INVALID_ARG;
+    }
+    if (in->shs && !gout->dL_dshs) { set_error("backward: dL_dshs NULL", hipSuccess); return GDR_ERR_INVALID_ARG; }
+    if (in->colors_precomp && !gout->dL_dcolors) { set_error("backward: dL_dcolors NULL", hipSuccess); return GDR_ERR_INVALID_ARG; }
+    if (in->cov3D_precomp ? !gout->dL_dcov3D : (!gout->dL_dscales || !gout->dL_drotations)) {
+        set_error("backward: covariance gradient buffers NULL", hipSuccess);
+        return GDR_ERR_INVALID_ARG;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const size_t N = (size_t)in->N;
+    if (N == 0) return GDR_OK;
+    hipError_t e = hipMemsetAsync(gout->dL_dmeans2D, 0, N * 4 * sizeof(float), st);
+    if (e == hipSuccess) e = hipMemsetAsync(gout->scratch, 0, N * 8 * sizeof(float), st);
+    if (e == hipSuccess) e = hipMemsetAsync(gout->dL_dopacities, 0, N * sizeof(float), st);
+    if (e != hipSuccess) return hip_fail("memset grads", e);
+    e = launch_render_bwd(s, geom, bin, img, gin, gout, st);
+    if (e != hipSuccess) return hip_fail("render_bwd", e);
+    if ((rc = debug_sync(s, "render_bwd", st))) return rc;
+    e = launch_preprocess_bwd(s, in, geom, radii, gout, st);
+    if (e != hipSuccess) return hip_fail("preprocess_bwd", e);
+    if ((rc = debug_sync(s, "preprocess_bwd", st))) return rc;
+    return GDR_OK;
+}
+
+int gdr_mark_visible(int32_t N, const float* means3D, const float* viewmatrix,
+                     const float* projmatrix, uint8_t* present, void* stream) {
+    (void)projmatrix;
+    if (N < 0 || (N > 0 && (!means3D || !viewmatrix || !present))) { set_error("mark_visible: bad argument", hipSuccess); return GDR_ERR_INVALID_ARG; }
+    hipError_t e = launch_mark_visible(N, means3D, viewmatrix, present, (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail("mark_visible", e);
+    return GDR_OK;
+}
+
+}  // extern "C"

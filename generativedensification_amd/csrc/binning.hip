@@ -1,0 +1,288 @@
+// binning.hip — K2..K5 of the rasterizer for gfx950 (integer / byte work, HBM-bound).
+//   K2  exclusive scan of the per-block sums of tiles_touched (the per-Gaussian part of
+//       the scan is recomputed inside K3 from tiles_touched, so no N-long offsets array
+//       is ever written or read)
+//   K3  duplicate_with_keys: key = (tile << 32) | float_bits(depth), value = Gaussian id
+//   K4  stable LSD radix sort of the D (u64 key, u32 value) pairs on the low
+//       32 + ceil(log2(tiles)) bits, 8 bits per pass: histogram / row scan / scatter
+//   K5  identify_tile_ranges
+// Behaviour: SURVEY.md Appendix A.2.  Equal keys keep emission order (ascending Gaussian
+// index), exactly like the reference's CUB DeviceRadixSort, so the sorted list is
+// bit-identical to oracle_bin() in oracle/gdr_oracle.c.
+//
+// CDNA4 notes: wave = 64, so the in-wave stable ranking uses 64-bit ballots (one per
+// digit bit) instead of 32-wide match_any; LDS holds one 256-bin counter row per wave.
+#include "gdr_common.h"
+
+namespace gdr {
+
+namespace {
+
+__device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
+__device__ __forceinline__ uint64_t lanemask_lt() { return (1ull << lane_id()) - 1ull; }
+
+// inclusive wave scan (uint32) via cross-lane shuffles
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        uint32_t t = __shfl_up(v, off, 64);
+        if ((int)lane_id() >= off) v += t;
+    }
+    return v;
+}
+
+// Block-wide exclusive scan of one value per thread (GDR_BLOCK threads). Returns the
+// exclusive prefix; *total receives the block sum.  `lds` needs >= 8 uint32.
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* lds, uint32_t* total) {
+    const uint32_t incl = wave_incl_scan(v);
+    const uint32_t w = threadIdx.x >> 6;
+    if (lane_id() == 63) lds[w] = incl;
+    __syncthreads();
+    uint32_t base = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < GDR_BLOCK / GDR_WAVE; ++k)
+        if (k < w) base += lds[k];
+    if (total) *total = lds[0] + lds[1] + lds[2] + lds[3];
+    __syncthreads();
+    return base + incl - v;
+}
+
+// ---------------------------------------------------------------------------------
+// K2: single workgroup, exclusive scan of block_sums[0..nb) in place;
+//     block_sums[nb] = num_rendered[0] = total.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(GDR_BLOCK) void scan_block_sums_kernel(uint32_t* __restrict__ block_sums,
+                                                                     int nb,
+                                                                     uint32_t* __restrict__ num_rendered) {
+    __shared__ uint32_t lds[8];
+    uint32_t carry = 0;
+    for (int base = 0; base < nb; base += GDR_BLOCK) {
+        const int i = base + (int)threadIdx.x;
+        const uint32_t v = i < nb ? block_sums[i] : 0u;
+        uint32_t tot;
+        const uint32_t ex = block_excl_scan(v, lds, &tot);
+        if (i < nb) block_sums[i] = carry + ex;
+        carry += tot;
+    }
+    if (threadIdx.x == 0) {
+        block_sums[nb] = carry;
+        *num_rendered = carry;
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// K3
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(GDR_BLOCK) void duplicate_kernel(
+    int N, int gx, const int32_t* __restrict__ radii, const float* __restrict__ depths,
+    const int4* __restrict__ rect, const uint32_t* __restrict__ tiles_touched,
+    const uint32_t* __restrict__ block_offsets, uint64_t* __restrict__ keys,
+    uint32_t* __restrict__ vals, uint64_t D) {
+    __shared__ uint32_t lds[8];
+    const int i = blockIdx.x * GDR_BLOCK + threadIdx.x;
+    const uint32_t t = i < N ? tiles_touched[i] : 0u;
+    uint32_t off = block_offsets[blockIdx.x] + block_excl_scan(t, lds, nullptr);
+    if (t == 0 || radii[i] <= 0) return;
+    const int4 r = rect[i];
+    const uint64_t dbits = (uint64_t)__float_as_uint(depths[i]);
+    for (int y = r.y; y < r.w; ++y)
+        for (int x = r.x; x < r.z; ++x) {
+            if (off < D) {  // capacity guard: never write past the caller's buffers
+                keys[off] = ((uint64_t)(uint32_t)(y * gx + x) << 32) | dbits;
+                vals[off] = (uint32_t)i;
+            }
+            ++off;
+        }
+}
+
+// ---------------------------------------------------------------------------------
+// K4: one radix pass = histogram -> row scan -> scatter.
+// hist layout: hist[digit * nblk + blk]; totals[digit] after it (GDR_RADIX entries).
+// Key order inside a workgroup tile: (wave, round, lane) == ascending index => stable.
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t tile_index(uint32_t blk, uint32_t wave, int round) {
+    return (uint64_t)blk * GDR_SORT_TILE + (uint64_t)wave * (GDR_WAVE * GDR_SORT_ITEMS) +
+           (uint64_t)round * GDR_WAVE + lane_id();
+}
+
+__global__ __launch_bounds__(GDR_BLOCK) void sort_hist_kernel(const uint64_t* __restrict__ keys,
+                                                               uint64_t D, int shift, uint32_t nblk,
+                                                               uint32_t* __restrict__ hist) {
+    __shared__ uint32_t cnt[GDR_BLOCK / GDR_WAVE][GDR_RADIX];
+    for (int k = threadIdx.x; k < (GDR_BLOCK / GDR_WAVE) * GDR_RADIX; k += GDR_BLOCK)
+        (&cnt[0][0])[k] = 0;
+    __syncthreads();
+    const uint32_t w = threadIdx.x >> 6;
+#pragma unroll 4
+    for (int j = 0; j < GDR_SORT_ITEMS; ++j) {
+        const uint64_t idx = tile_index(blockIdx.x, w, j);
+        if (idx < D) {
+            const uint32_t d = (uint32_t)(keys[idx] >> shift) & (GDR_RADIX - 1);
+            atomicAdd(&cnt[w][d], 1u);
+        }
+    }
+    __syncthreads();
+    const uint32_t d = threadIdx.x;  // GDR_BLOCK == GDR_RADIX
+    hist[(uint64_t)d * nblk + blockIdx.x] = cnt[0][d] + cnt[1][d] + cnt[2][d] + cnt[3][d];
+}
+
+// one workgroup per digit: exclusive scan of its row of nblk per-block counts.
+__global__ __launch_bounds__(GDR_BLOCK) void sort_rowscan_kernel(uint32_t* __restrict__ hist,
+                                                                  uint32_t nblk,
+                                                                  uint32_t* __restrict__ totals) {
+    __shared__ uint32_t lds[8];
+    uint32_t* row = hist + (uint64_t)blockIdx.x * nblk;
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < nblk; base += GDR_BLOCK) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t v = i < nblk ? row[i] : 0u;
+        uint32_t tot;
+        const uint32_t ex = block_excl_scan(v, lds, &tot);
+        if (i < nblk) row[i] = carry + ex;
+        carry += tot;
+    }
+    if (threadIdx.x == 0) totals[blockIdx.x] = carry;
+}
+
+__global__ __launch_bounds__(GDR_BLOCK) void sort_scatter_kernel(
+    const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+    uint64_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, uint64_t D, int shift,
+    uint32_t nblk, const uint32_t* __restrict__ hist, const uint32_t* __restrict__ totals) {
+    __shared__ uint32_t cnt[GDR_BLOCK / GDR_WAVE][GDR_RADIX];
+    __shared__ uint32_t lds[8];
+    for (int k = threadIdx.x; k < (GDR_BLOCK / GDR_WAVE) * GDR_RADIX; k += GDR_BLOCK)
+        (&cnt[0][0])[k] = 0;
+    // global base of digit d = exclusive scan of the digit totals
+    const uint32_t digit_base = block_excl_scan(totals[threadIdx.x], lds, nullptr);  // includes a barrier
+
+    const uint32_t w = threadIdx.x >> 6;
+    uint64_t key[GDR_SORT_ITEMS];
+    uint32_t val[GDR_SORT_ITEMS];
+    uint32_t rank[GDR_SORT_ITEMS];
+#pragma unroll
+    for (int j = 0; j < GDR_SORT_ITEMS; ++j) {
+        const uint64_t idx = tile_index(blockIdx.x, w, j);
+        const bool valid = idx < D;
+        key[j] = valid ? keys_in[idx] : ~0ull;
+        val[j] = valid ? vals_in[idx] : 0u;
+    }
+#pragma unroll
+    for (int j = 0; j < GDR_SORT_ITEMS; ++j) {
+        const uint64_t idx = tile_index(blockIdx.x, w, j);
+        const bool valid = idx < D;
+        const uint32_t d = (uint32_t)(key[j] >> shift) & (GDR_RADIX - 1);
+        // lanes of this wave holding the same digit (64-wide match via one ballot per bit)
+        uint64_t m = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < GDR_RADIX_BITS; ++b) {
+            const uint64_t bal = __ballot((d >> b) & 1u);
+            m &= ((d >> b) & 1u) ? bal : ~bal;
+        }
+        uint32_t prior = 0;
+        if (valid) prior = cnt[w][d];
+        const uint32_t below = (uint32_t)__popcll(m & lanemask_lt());
+        rank[j] = prior + below;
+        // the highest lane of each group publishes the new count (all reads above are done:
+        // a wave's DS operations execute in order)
+        if (valid && (m >> lane_id()) == 1ull) cnt[w][d] = prior + below + 1u;
+    }
+    __syncthreads();
+    {   // per-digit: turn per-wave counts into global start positions
+        const uint32_t d = threadIdx.x;
+        uint32_t base = digit_base + hist[(uint64_t)d * nblk + blockIdx.x];
+#pragma unroll
+        for (int k = 0; k < GDR_BLOCK / GDR_WAVE; ++k) {
+            const uint32_t c = cnt[k][d];
+            cnt[k][d] = base;
+            base += c;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < GDR_SORT_ITEMS; ++j) {
+        const uint64_t idx = tile_index(blockIdx.x, w, j);
+        if (idx < D) {
+            const uint32_t d = (uint32_t)(key[j] >> shift) & (GDR_RADIX - 1);
+            const uint32_t pos = cnt[w][d] + rank[j];
+            keys_out[pos] = key[j];
+            vals_out[pos] = val[j];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// K5
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(GDR_BLOCK) void ranges_kernel(const uint64_t* __restrict__ keys, uint64_t D,
+                                                            uint2* __restrict__ ranges) {
+    const uint64_t e = (uint64_t)blockIdx.x * GDR_BLOCK + threadIdx.x;
+    if (e >= D) return;
+    const uint32_t t = (uint32_t)(keys[e] >> 32);
+    if (e == 0) {
+        ranges[t].x = 0;
+    } else {
+        const uint32_t tp = (uint32_t)(keys[e - 1] >> 32);
+        if (tp != t) {
+            ranges[tp].y = (uint32_t)e;
+            ranges[t].x = (uint32_t)e;
+        }
+    }
+    if (e == D - 1) ranges[t].y = (uint32_t)D;
+}
+
+}  // namespace
+
+size_t sort_hist_bytes(uint64_t D) {
+    const uint64_t nblk = (D + GDR_SORT_TILE - 1) / GDR_SORT_TILE;
+    return (size_t)((nblk > 0 ? nblk : 1) * GDR_RADIX + GDR_RADIX) * sizeof(uint32_t);
+}
+
+hipError_t launch_scan_block_sums(const gdr_geom* g, int N, hipStream_t st) {
+    const int nb = div_up(N, GDR_BLOCK);
+    hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(GDR_BLOCK), 0, st, g->block_sums, nb,
+                       g->num_rendered);
+    return hipGetLastError();
+}
+
+hipError_t launch_duplicate(const gdr_geom* g, int N, int W, int H, const int32_t* radii,
+                            uint64_t* keys, uint32_t* vals, uint64_t D, hipStream_t st) {
+    (void)H;
+    if (N == 0) return hipSuccess;
+    hipLaunchKernelGGL(duplicate_kernel, dim3(div_up(N, GDR_BLOCK)), dim3(GDR_BLOCK), 0, st, N,
+                       tile_grid_x(W), radii, g->depths, (const int4*)g->rect, g->tiles_touched,
+                       g->block_sums, keys, vals, D);
+    return hipGetLastError();
+}
+
+hipError_t launch_sort(gdr_binning* bin, uint64_t D, int nbits, hipStream_t st) {
+    bin->sorted = 0;
+    if (D == 0) return hipSuccess;
+    const uint32_t nblk = (uint32_t)((D + GDR_SORT_TILE - 1) / GDR_SORT_TILE);
+    uint32_t* hist = bin->hist;
+    uint32_t* totals = bin->hist + (uint64_t)nblk * GDR_RADIX;
+    int cur = 0;
+    for (int shift = 0; shift < nbits; shift += GDR_RADIX_BITS) {
+        hipLaunchKernelGGL(sort_hist_kernel, dim3(nblk), dim3(GDR_BLOCK), 0, st, bin->keys[cur], D,
+                           shift, nblk, hist);
+        hipLaunchKernelGGL(sort_rowscan_kernel, dim3(GDR_RADIX), dim3(GDR_BLOCK), 0, st, hist, nblk,
+                           totals);
+        hipLaunchKernelGGL(sort_scatter_kernel, dim3(nblk), dim3(GDR_BLOCK), 0, st, bin->keys[cur],
+                           bin->values[cur], bin->keys[cur ^ 1], bin->values[cur ^ 1], D, shift,
+                           nblk, hist, totals);
+        cur ^= 1;
+    }
+    bin->sorted = cur;
+    return hipGetLastError();
+}
+
+hipError_t launch_ranges(const gdr_binning* bin, uint64_t D, const gdr_image* img, int tiles,
+                         hipStream_t st) {
+    hipError_t e = hipMemsetAsync(img->ranges, 0, (size_t)tiles * 2 * sizeof(uint32_t), st);
+    if (e != hipSuccess) return e;
+    if (D == 0) return hipSuccess;
+    hipLaunchKernelGGL(ranges_kernel, dim3(div_up((int64_t)D, GDR_BLOCK)), dim3(GDR_BLOCK), 0, st,
+                       bin->keys[bin->sorted], D, (uint2*)img->ranges);
+    return hipGetLastError();
+}
+
+}  // namespace gdr

@@ -1,0 +1,61 @@
+// gdr_common.h — shared declarations of the gfx950 rasterizer kernels (internal).
+// Public ABI: include/gdr.h.  Everything here is CDNA4-only: wave = 64 lanes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/gdr.h"
+
+#define GDR_WAVE 64
+#define GDR_BLOCK 256          // threads per workgroup (4 waves) everywhere
+#define GDR_TILE_PIX (GDR_TILE * GDR_TILE)
+
+// radix sort geometry (binning.hip)
+#define GDR_SORT_ITEMS 16                               // keys per thread
+#define GDR_SORT_TILE (GDR_BLOCK * GDR_SORT_ITEMS)      // keys per workgroup
+#define GDR_RADIX_BITS 8
+#define GDR_RADIX (1 << GDR_RADIX_BITS)
+
+namespace gdr {
+
+struct View {  // camera constants, loaded once per kernel from device memory
+    float view[16];
+    float proj[16];
+    float campos[3];
+};
+
+void set_error(const char* what, hipError_t e);
+
+static inline int div_up(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+static inline int tile_grid_x(int W) { return (W + GDR_TILE - 1) / GDR_TILE; }
+static inline int tile_grid_y(int H) { return (H + GDR_TILE - 1) / GDR_TILE; }
+
+// number of key bits that must be sorted: 32 depth bits + bits of (tiles-1)
+static inline int key_bits(int tiles) {
+    int b = 0;
+    while ((1u << b) < (unsigned)tiles) ++b;
+    return 32 + b;
+}
+
+// ---- launchers (one per translation unit) ----------------------------------------
+hipError_t launch_preprocess_fwd(const gdr_settings* s, const gdr_inputs* in, const gdr_geom* g,
+                                 int32_t* radii, hipStream_t st);
+hipError_t launch_preprocess_bwd(const gdr_settings* s, const gdr_inputs* in, const gdr_geom* g,
+                                 const int32_t* radii, const gdr_grad_outputs* go, hipStream_t st);
+hipError_t launch_mark_visible(int N, const float* means3D, const float* view, uint8_t* present,
+                               hipStream_t st);
+hipError_t launch_scan_block_sums(const gdr_geom* g, int N, hipStream_t st);
+hipError_t launch_duplicate(const gdr_geom* g, int N, int W, int H, const int32_t* radii,
+                            uint64_t* keys, uint32_t* vals, uint64_t D, hipStream_t st);
+hipError_t launch_sort(gdr_binning* bin, uint64_t D, int nbits, hipStream_t st);
+hipError_t launch_ranges(const gdr_binning* bin, uint64_t D, const gdr_image* img, int tiles,
+                         hipStream_t st);
+hipError_t launch_render_fwd(const gdr_settings* s, const gdr_geom* g, const gdr_binning* bin,
+                             const gdr_image* img, const gdr_outputs* out, hipStream_t st);
+hipError_t launch_render_bwd(const gdr_settings* s, const gdr_geom* g, const gdr_binning* bin,
+                             const gdr_image* img, const gdr_grad_inputs* gi,
+                             const gdr_grad_outputs* go, hipStream_t st);
+
+size_t sort_hist_bytes(uint64_t D);
+
+}  // namespace gdr

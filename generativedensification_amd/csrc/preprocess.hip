@@ -1,0 +1,540 @@
+// preprocess.hip — per-Gaussian stages of the rasterizer for gfx950.
+//   K1  preprocess forward : project, EWA 2D covariance, conic, radius, tile rect,
+//                            SH -> RGB, block partial sums of tiles_touched
+//   K8/K9 preprocess backward: conic/mean2D/colour/depth partials -> means3D, SH,
+//                            scales, rotations (or cov3D)
+//   K10 mark_visible
+// Behaviour: SURVEY.md Appendix A.1 / A.5 (the un-vendored CUDA rasterizer the reference
+// installs from third_party/diff-gaussian-rasterization, /root/reference/.gitmodules:1-3).
+//
+// This translation unit is compiled with -ffp-contract=off and IEEE divide/sqrt: every
+// float operation rounds exactly once, in the order written, so that radii, tile rects,
+// depth key bits and therefore the whole sorted (tile,depth) list are bit-identical to
+// the CPU oracle (oracle/gdr_oracle.c, built with the same contraction setting).
+// These kernels are HBM-bound (236 B read + ~90 B written per Gaussian at SH degree 3);
+// the extra VALU ops from not fusing multiply-adds are hidden behind memory.
+#include "gdr_common.h"
+
+#pragma clang fp contract(off)
+
+namespace gdr {
+
+namespace {
+
+#define SH_C2_0 1.0925484305920792f
+#define SH_C2_1 -1.0925484305920792f
+#define SH_C2_2 0.31539156525252005f
+#define SH_C2_3 -1.0925484305920792f
+#define SH_C2_4 0.5462742152960396f
+#define SH_C3_0 -0.5900435899266435f
+#define SH_C3_1 2.890611442640554f
+#define SH_C3_2 -0.4570457994644658f
+#define SH_C3_3 0.3731763325901154f
+#define SH_C3_4 -0.4570457994644658f
+#define SH_C3_5 1.445305721320277f
+#define SH_C3_6 -0.5900435899266435f
+#define SH_C0 0.28209479177387814f
+#define SH_C1 0.4886025119029199f
+
+struct Cam {
+    float v[16];
+    float p[16];
+    float c[3];
+};
+
+__device__ __forceinline__ void load_cam(Cam& cam, const float* __restrict__ view,
+                                         const float* __restrict__ proj,
+                                         const float* __restrict__ campos) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { cam.v[k] = view[k]; cam.p[k] = proj[k]; }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) cam.c[k] = campos ? campos[k] : 0.f;
+}
+
+// SH basis values b_k(x,y,z); expression trees identical to oracle sh_basis().
+template <int DEG>
+__device__ __forceinline__ void sh_basis(float x, float y, float z, float* b) {
+    b[0] = SH_C0;
+    if (DEG >= 1) {
+        b[1] = -SH_C1 * y;
+        b[2] = SH_C1 * z;
+        b[3] = -SH_C1 * x;
+    }
+    if (DEG >= 2) {
+        float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+        b[4] = SH_C2_0 * xy;
+        b[5] = SH_C2_1 * yz;
+        b[6] = SH_C2_2 * (2.f * zz - xx - yy);
+        b[7] = SH_C2_3 * xz;
+        b[8] = SH_C2_4 * (xx - yy);
+        if (DEG >= 3) {
+            b[9] = SH_C3_0 * y * (3.f * xx - yy);
+            b[10] = SH_C3_1 * xy * z;
+            b[11] = SH_C3_2 * y * (4.f * zz - xx - yy);
+            b[12] = SH_C3_3 * z * (2.f * zz - 3.f * xx - 3.f * yy);
+            b[13] = SH_C3_4 * x * (4.f * zz - xx - yy);
+            b[14] = SH_C3_5 * z * (xx - yy);
+            b[15] = SH_C3_6 * x * (xx - 3.f * yy);
+        }
+    }
+}
+
+template <int DEG>
+__device__ __forceinline__ void sh_basis_grad(float x, float y, float z, float* bx, float* by,
+                                              float* bz) {
+    constexpr int NB = (DEG + 1) * (DEG + 1);
+#pragma unroll
+    for (int k = 0; k < NB; ++k) bx[k] = by[k] = bz[k] = 0.f;
+    if (DEG >= 1) {
+        by[1] = -SH_C1;
+        bz[2] = SH_C1;
+        bx[3] = -SH_C1;
+    }
+    if (DEG >= 2) {
+        float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+        bx[4] = SH_C2_0 * y; by[4] = SH_C2_0 * x;
+        by[5] = SH_C2_1 * z; bz[5] = SH_C2_1 * y;
+        bx[6] = SH_C2_2 * (-2.f * x); by[6] = SH_C2_2 * (-2.f * y); bz[6] = SH_C2_2 * (4.f * z);
+        bx[7] = SH_C2_3 * z; bz[7] = SH_C2_3 * x;
+        bx[8] = SH_C2_4 * (2.f * x); by[8] = SH_C2_4 * (-2.f * y);
+        if (DEG >= 3) {
+            bx[9] = SH_C3_0 * (6.f * xy); by[9] = SH_C3_0 * (3.f * xx - 3.f * yy);
+            bx[10] = SH_C3_1 * yz; by[10] = SH_C3_1 * xz; bz[10] = SH_C3_1 * xy;
+            bx[11] = SH_C3_2 * (-2.f * xy); by[11] = SH_C3_2 * (4.f * zz - xx - 3.f * yy); bz[11] = SH_C3_2 * (8.f * yz);
+            bx[12] = SH_C3_3 * (-6.f * xz); by[12] = SH_C3_3 * (-6.f * yz); bz[12] = SH_C3_3 * (6.f * zz - 3.f * xx - 3.f * yy);
+            bx[13] = SH_C3_4 * (4.f * zz - 3.f * xx - yy); by[13] = SH_C3_4 * (-2.f * xy); bz[13] = SH_C3_4 * (8.f * xz);
+            bx[14] = SH_C3_5 * (2.f * xz); by[14] = SH_C3_5 * (-2.f * yz); bz[14] = SH_C3_5 * (xx - yy);
+            bx[15] = SH_C3_6 * (3.f * xx - 3.f * yy); by[15] = SH_C3_6 * (-6.f * xy);
+        }
+    }
+}
+
+__device__ __forceinline__ void quat_to_R(float r, float x, float y, float z, float* R) {
+    R[0] = 1.f - 2.f * (y * y + z * z);
+    R[1] = 2.f * (x * y - r * z);
+    R[2] = 2.f * (x * z + r * y);
+    R[3] = 2.f * (x * y + r * z);
+    R[4] = 1.f - 2.f * (x * x + z * z);
+    R[5] = 2.f * (y * z - r * x);
+    R[6] = 2.f * (x * z - r * y);
+    R[7] = 2.f * (y * z + r * x);
+    R[8] = 1.f - 2.f * (x * x + y * y);
+}
+
+// EWA projection pieces shared by forward and backward (Appendix A.1-4).
+struct Ewa {
+    float tx, ty, tz, xmul, ymul;
+    float A0[3], A1[3], v0[3], v1[3];
+    float a, b, c;
+};
+
+__device__ __forceinline__ void ewa(const Cam& cam, float pvx, float pvy, float pvz,
+                                    const float* c6, float focal_x, float focal_y, float tanx,
+                                    float tany, Ewa& e) {
+    const float limx = 1.3f * tanx, limy = 1.3f * tany;
+    float txtz = pvx / pvz, tytz = pvy / pvz;
+    e.tz = pvz;
+    e.tx = fminf(limx, fmaxf(-limx, txtz)) * pvz;
+    e.ty = fminf(limy, fmaxf(-limy, tytz)) * pvz;
+    e.xmul = (txtz < -limx || txtz > limx) ? 0.f : 1.f;
+    e.ymul = (tytz < -limy || tytz > limy) ? 0.f : 1.f;
+    float J00 = focal_x / pvz, J02 = -(focal_x * e.tx) / (pvz * pvz);
+    float J11 = focal_y / pvz, J12 = -(focal_y * e.ty) / (pvz * pvz);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        e.A0[k] = J00 * cam.v[4 * k + 0] + J02 * cam.v[4 * k + 2];
+        e.A1[k] = J11 * cam.v[4 * k + 1] + J12 * cam.v[4 * k + 2];
+    }
+    const float S[9] = {c6[0], c6[1], c6[2], c6[1], c6[3], c6[4], c6[2], c6[4], c6[5]};
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        e.v0[r] = (S[3 * r] * e.A0[0] + S[3 * r + 1] * e.A0[1]) + S[3 * r + 2] * e.A0[2];
+        e.v1[r] = (S[3 * r] * e.A1[0] + S[3 * r + 1] * e.A1[1]) + S[3 * r + 2] * e.A1[2];
+    }
+    e.a = ((e.A0[0] * e.v0[0] + e.A0[1] * e.v0[1]) + e.A0[2] * e.v0[2]) + 0.3f;
+    e.b = (e.A0[0] * e.v1[0] + e.A0[1] * e.v1[1]) + e.A0[2] * e.v1[2];
+    e.c = ((e.A1[0] * e.v1[0] + e.A1[1] * e.v1[1]) + e.A1[2] * e.v1[2]) + 0.3f;
+}
+
+// ---------------------------------------------------------------------------------
+// K1
+// ---------------------------------------------------------------------------------
+template <int DEG>
+__global__ __launch_bounds__(GDR_BLOCK) void preprocess_fwd_kernel(
+    int N, int M, const float* __restrict__ means3D, const float* __restrict__ scales,
+    float scale_modifier, const float* __restrict__ rotations, const float* __restrict__ opacities,
+    const float* __restrict__ shs, const float* __restrict__ colors_precomp,
+    const float* __restrict__ cov3D_precomp, const float* __restrict__ view,
+    const float* __restrict__ proj, const float* __restrict__ campos, int W, int H, float tanx,
+    float tany, float focal_x, float focal_y, int32_t* __restrict__ radii, float* __restrict__ g_depths,
+    float2* __restrict__ g_xy, float4* __restrict__ g_conic_opacity, float4* __restrict__ g_rgb,
+    float* __restrict__ g_cov3D, int4* __restrict__ g_rect, uint32_t* __restrict__ g_tiles,
+    uint8_t* __restrict__ g_clamped, uint32_t* __restrict__ block_sums) {
+    Cam cam;
+    load_cam(cam, view, proj, campos);
+    const int i = blockIdx.x * GDR_BLOCK + threadIdx.x;
+    const int gx = (W + GDR_TILE - 1) / GDR_TILE, gy = (H + GDR_TILE - 1) / GDR_TILE;
+
+    uint32_t tiles = 0;
+    if (i < N) {
+        int rad = 0;
+        float depth = 0.f;
+        float2 pxy = make_float2(0.f, 0.f);
+        float4 con_o = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 rgbd = make_float4(0.f, 0.f, 0.f, 0.f);
+        int4 rect = make_int4(0, 0, 0, 0);
+        uint32_t clampbits = 0;
+        float c6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+        const float px_ = means3D[3 * i], py_ = means3D[3 * i + 1], pz_ = means3D[3 * i + 2];
+        const float pvx = cam.v[0] * px_ + cam.v[4] * py_ + cam.v[8] * pz_ + cam.v[12];
+        const float pvy = cam.v[1] * px_ + cam.v[5] * py_ + cam.v[9] * pz_ + cam.v[13];
+        const float pvz = cam.v[2] * px_ + cam.v[6] * py_ + cam.v[10] * pz_ + cam.v[14];
+        bool ok = pvz > 0.2f;  // near cull (A.1-1); no x/y frustum test when prefiltered=False
+        if (ok) {
+            const float phx = cam.p[0] * px_ + cam.p[4] * py_ + cam.p[8] * pz_ + cam.p[12];
+            const float phy = cam.p[1] * px_ + cam.p[5] * py_ + cam.p[9] * pz_ + cam.p[13];
+            const float phw = cam.p[3] * px_ + cam.p[7] * py_ + cam.p[11] * pz_ + cam.p[15];
+            const float p_w = 1.0f / (phw + 0.0000001f);
+            const float ppx = phx * p_w, ppy = phy * p_w;
+
+            if (cov3D_precomp) {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) c6[k] = cov3D_precomp[6 * i + k];
+            } else {
+                const float4 q = reinterpret_cast<const float4*>(rotations)[i];
+                float R[9], Mm[9];
+                quat_to_R(q.x, q.y, q.z, q.w, R);
+                const float s[3] = {scale_modifier * scales[3 * i], scale_modifier * scales[3 * i + 1],
+                                    scale_modifier * scales[3 * i + 2]};
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) Mm[r * 3 + k] = R[r * 3 + k] * s[k];
+#define SIG(a_, b_) ((Mm[a_ * 3 + 0] * Mm[b_ * 3 + 0] + Mm[a_ * 3 + 1] * Mm[b_ * 3 + 1]) + Mm[a_ * 3 + 2] * Mm[b_ * 3 + 2])
+                c6[0] = SIG(0, 0); c6[1] = SIG(0, 1); c6[2] = SIG(0, 2);
+                c6[3] = SIG(1, 1); c6[4] = SIG(1, 2); c6[5] = SIG(2, 2);
+#undef SIG
+            }
+            Ewa e;
+            ewa(cam, pvx, pvy, pvz, c6, focal_x, focal_y, tanx, tany, e);
+            const float det = e.a * e.c - e.b * e.b;
+            ok = det != 0.f;
+            if (ok) {
+                const float det_inv = 1.f / det;
+                const float mid = 0.5f * (e.a + e.c);
+                const float disc = sqrtf(fmaxf(0.1f, mid * mid - det));
+                const float lambda1 = mid + disc, lambda2 = mid - disc;
+                const float my_radius = ceilf(3.f * sqrtf(fmaxf(lambda1, lambda2)));
+                const float sx = ((ppx + 1.0f) * (float)W - 1.0f) * 0.5f;
+                const float sy = ((ppy + 1.0f) * (float)H - 1.0f) * 0.5f;
+                const int r_i = (int)my_radius;
+                const float rf = (float)r_i;
+                rect.x = min(gx, max(0, (int)((sx - rf) / (float)GDR_TILE)));
+                rect.y = min(gy, max(0, (int)((sy - rf) / (float)GDR_TILE)));
+                rect.z = min(gx, max(0, (int)((sx + rf + (float)(GDR_TILE - 1)) / (float)GDR_TILE)));
+                rect.w = min(gy, max(0, (int)((sy + rf + (float)(GDR_TILE - 1)) / (float)GDR_TILE)));
+                tiles = (uint32_t)((rect.z - rect.x) * (rect.w - rect.y));
+                ok = tiles != 0;
+                if (ok) {
+                    rad = r_i;
+                    depth = pvz;
+                    pxy = make_float2(sx, sy);
+                    con_o = make_float4(e.c * det_inv, -e.b * det_inv, e.a * det_inv, opacities[i]);
+                    if (colors_precomp) {
+                        rgbd.x = colors_precomp[3 * i];
+                        rgbd.y = colors_precomp[3 * i + 1];
+                        rgbd.z = colors_precomp[3 * i + 2];
+                    } else {
+                        float dx = px_ - cam.c[0], dy = py_ - cam.c[1], dz = pz_ - cam.c[2];
+                        const float inv = 1.f / sqrtf((dx * dx + dy * dy) + dz * dz);
+                        dx *= inv; dy *= inv; dz *= inv;
+                        constexpr int NB = (DEG + 1) * (DEG + 1);
+                        float bk[NB];
+                        sh_basis<DEG>(dx, dy, dz, bk);
+                        const float* sh = shs + (size_t)i * M * 3;
+                        float acc[3];
+#pragma unroll
+                        for (int ch = 0; ch < 3; ++ch) acc[ch] = bk[0] * sh[ch];
+#pragma unroll
+                        for (int k = 1; k < NB; ++k)
+#pragma unroll
+                            for (int ch = 0; ch < 3; ++ch) acc[ch] = acc[ch] + bk[k] * sh[3 * k + ch];
+#pragma unroll
+                        for (int ch = 0; ch < 3; ++ch) {
+                            acc[ch] = acc[ch] + 0.5f;
+                            if (acc[ch] < 0.f) clampbits |= (1u << ch);
+                            acc[ch] = fmaxf(acc[ch], 0.f);
+                        }
+                        rgbd.x = acc[0]; rgbd.y = acc[1]; rgbd.z = acc[2];
+                    }
+                    rgbd.w = depth;
+                } else {
+                    rect = make_int4(0, 0, 0, 0);
+                }
+            }
+            if (!ok) { tiles = 0; }
+        }
+        radii[i] = rad;
+        g_depths[i] = depth;
+        g_xy[i] = pxy;
+        g_conic_opacity[i] = con_o;
+        g_rgb[i] = rgbd;
+        if (!cov3D_precomp) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) g_cov3D[6 * i + k] = c6[k];
+        }
+        g_rect[i] = rect;
+        g_tiles[i] = tiles;
+        g_clamped[i] = (uint8_t)clampbits;
+    }
+    // block partial sum of tiles_touched -> block_sums[blockIdx.x] (feeds the scan, K2)
+    uint32_t v = tiles;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    __shared__ uint32_t wsum[GDR_BLOCK / GDR_WAVE];
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// ---------------------------------------------------------------------------------
+// K8 + K9 fused: one pass over the Gaussians.
+// scratch layout per Gaussian (8 floats): dL/dconic.x, .y, .z (true partials), dL/ddepth,
+//                                         dL/dcolour r, g, b, pad
+// ---------------------------------------------------------------------------------
+template <int DEG>
+__global__ __launch_bounds__(GDR_BLOCK) void preprocess_bwd_kernel(
+    int N, int M, const float* __restrict__ means3D, const int32_t* __restrict__ radii,
+    const float* __restrict__ shs, const uint8_t* __restrict__ g_clamped,
+    const float* __restrict__ scales, const float* __restrict__ rotations, float scale_modifier,
+    const float* __restrict__ cov3D, int cov_precomp, int colors_precomp,
+    const float* __restrict__ view, const float* __restrict__ proj,
+    const float* __restrict__ campos, int W, int H, float tanx, float tany, float focal_x,
+    float focal_y, const float4* __restrict__ dL_dmean2D, const float4* __restrict__ scratch,
+    float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dcov3D, float* __restrict__ dL_dsh,
+    float* __restrict__ dL_dcolors, float* __restrict__ dL_dscale, float4* __restrict__ dL_drot) {
+    Cam cam;
+    load_cam(cam, view, proj, campos);
+    const int i = blockIdx.x * GDR_BLOCK + threadIdx.x;
+    if (i >= N) return;
+    constexpr int NB = (DEG + 1) * (DEG + 1);
+    const bool vis = radii[i] > 0;
+    float dmean[3] = {0.f, 0.f, 0.f};
+    float dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float dscale[3] = {0.f, 0.f, 0.f};
+    float4 drot = make_float4(0.f, 0.f, 0.f, 0.f);
+    float* dsh = dL_dsh ? dL_dsh + (size_t)i * M * 3 : nullptr;
+
+    if (vis) {
+        const float px_ = means3D[3 * i], py_ = means3D[3 * i + 1], pz_ = means3D[3 * i + 2];
+        const float4 gconic = scratch[2 * i];      // conic.xyz, ddepth
+        const float4 gcolor = scratch[2 * i + 1];  // rgb, pad
+        const float4 g2 = dL_dmean2D[i];
+        float c6[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) c6[k] = cov3D[6 * i + k];
+
+        const float pvx = cam.v[0] * px_ + cam.v[4] * py_ + cam.v[8] * pz_ + cam.v[12];
+        const float pvy = cam.v[1] * px_ + cam.v[5] * py_ + cam.v[9] * pz_ + cam.v[13];
+        const float pvz = cam.v[2] * px_ + cam.v[6] * py_ + cam.v[10] * pz_ + cam.v[14];
+        Ewa e;
+        ewa(cam, pvx, pvy, pvz, c6, focal_x, focal_y, tanx, tany, e);
+        const float a = e.a, b = e.b, c = e.c;
+        const float det = a * c - b * b;
+        float dL_da = 0.f, dL_db = 0.f, dL_dc = 0.f;
+        if (det * det != 0.f) {
+            const float d2 = 1.f / (det * det);
+            dL_da = d2 * (-c * c * gconic.x + b * c * gconic.y - b * b * gconic.z);
+            dL_db = d2 * (2.f * b * c * gconic.x - (a * c + b * b) * gconic.y + 2.f * a * b * gconic.z);
+            dL_dc = d2 * (-b * b * gconic.x + a * b * gconic.y - a * a * gconic.z);
+            const float* A0 = e.A0;
+            const float* A1 = e.A1;
+            dcov[0] = A0[0] * A0[0] * dL_da + A0[0] * A1[0] * dL_db + A1[0] * A1[0] * dL_dc;
+            dcov[3] = A0[1] * A0[1] * dL_da + A0[1] * A1[1] * dL_db + A1[1] * A1[1] * dL_dc;
+            dcov[5] = A0[2] * A0[2] * dL_da + A0[2] * A1[2] * dL_db + A1[2] * A1[2] * dL_dc;
+            dcov[1] = 2.f * A0[0] * A0[1] * dL_da + (A0[0] * A1[1] + A0[1] * A1[0]) * dL_db + 2.f * A1[0] * A1[1] * dL_dc;
+            dcov[2] = 2.f * A0[0] * A0[2] * dL_da + (A0[0] * A1[2] + A0[2] * A1[0]) * dL_db + 2.f * A1[0] * A1[2] * dL_dc;
+            dcov[4] = 2.f * A0[1] * A0[2] * dL_da + (A0[1] * A1[2] + A0[2] * A1[1]) * dL_db + 2.f * A1[1] * A1[2] * dL_dc;
+        }
+        float dJ00 = 0.f, dJ02 = 0.f, dJ11 = 0.f, dJ12 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float dA0 = 2.f * dL_da * e.v0[k] + dL_db * e.v1[k];
+            const float dA1 = 2.f * dL_dc * e.v1[k] + dL_db * e.v0[k];
+            dJ00 += dA0 * cam.v[4 * k + 0];
+            dJ02 += dA0 * cam.v[4 * k + 2];
+            dJ11 += dA1 * cam.v[4 * k + 1];
+            dJ12 += dA1 * cam.v[4 * k + 2];
+        }
+        const float tz1 = 1.f / e.tz, tz2 = tz1 * tz1, tz3 = tz2 * tz1;
+        const float dtx = e.xmul * (-focal_x * tz2 * dJ02);
+        const float dty = e.ymul * (-focal_y * tz2 * dJ12);
+        const float dtz = -focal_x * tz2 * dJ00 - focal_y * tz2 * dJ11 +
+                          (2.f * focal_x * e.tx) * tz3 * dJ02 + (2.f * focal_y * e.ty) * tz3 * dJ12;
+        // projection of the mean (A.5-ii) and depth path (A.5-iii)
+        const float mhx = cam.p[0] * px_ + cam.p[4] * py_ + cam.p[8] * pz_ + cam.p[12];
+        const float mhy = cam.p[1] * px_ + cam.p[5] * py_ + cam.p[9] * pz_ + cam.p[13];
+        const float mhw = cam.p[3] * px_ + cam.p[7] * py_ + cam.p[11] * pz_ + cam.p[15];
+        const float m_w = 1.f / (mhw + 0.0000001f);
+        const float mul1 = mhx * m_w * m_w, mul2 = mhy * m_w * m_w;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            dmean[k] = cam.v[4 * k + 0] * dtx + cam.v[4 * k + 1] * dty + cam.v[4 * k + 2] * dtz;
+            dmean[k] += (cam.p[4 * k + 0] * m_w - cam.p[4 * k + 3] * mul1) * g2.x +
+                        (cam.p[4 * k + 1] * m_w - cam.p[4 * k + 3] * mul2) * g2.y;
+            dmean[k] += cam.v[4 * k + 2] * gconic.w;
+        }
+        // SH backward (A.5-iv)
+        if (!colors_precomp) {
+            float dx = px_ - cam.c[0], dy = py_ - cam.c[1], dz = pz_ - cam.c[2];
+            const float inv = 1.f / sqrtf((dx * dx + dy * dy) + dz * dz);
+            const float ux = dx * inv, uy = dy * inv, uz = dz * inv;
+            float bk[NB], bx[NB], by[NB], bz[NB];
+            sh_basis<DEG>(ux, uy, uz, bk);
+            sh_basis_grad<DEG>(ux, uy, uz, bx, by, bz);
+            const uint32_t cl = g_clamped[i];
+            const float g[3] = {(cl & 1u) ? 0.f : gcolor.x, (cl & 2u) ? 0.f : gcolor.y,
+                                (cl & 4u) ? 0.f : gcolor.z};
+            const float* sh = shs + (size_t)i * M * 3;
+            float ddx = 0.f, ddy = 0.f, ddz = 0.f;
+#pragma unroll
+            for (int k = 0; k < NB; ++k) {
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) {
+                    const float sg = sh[3 * k + ch] * g[ch];
+                    dsh[3 * k + ch] = bk[k] * g[ch];
+                    ddx += bx[k] * sg;
+                    ddy += by[k] * sg;
+                    ddz += bz[k] * sg;
+                }
+            }
+            for (int k = NB; k < M; ++k)
+                for (int ch = 0; ch < 3; ++ch) dsh[3 * k + ch] = 0.f;
+            const float dot = ux * ddx + uy * ddy + uz * ddz;
+            dmean[0] += (ddx - ux * dot) * inv;
+            dmean[1] += (ddy - uy * dot) * inv;
+            dmean[2] += (ddz - uz * dot) * inv;
+        } else if (dL_dcolors) {
+            dL_dcolors[3 * i] = gcolor.x;
+            dL_dcolors[3 * i + 1] = gcolor.y;
+            dL_dcolors[3 * i + 2] = gcolor.z;
+        }
+        // cov3D -> scale / quaternion (A.5-v)
+        if (!cov_precomp) {
+            const float4 q = reinterpret_cast<const float4*>(rotations)[i];
+            float R[9];
+            quat_to_R(q.x, q.y, q.z, q.w, R);
+            const float s[3] = {scale_modifier * scales[3 * i], scale_modifier * scales[3 * i + 1],
+                                scale_modifier * scales[3 * i + 2]};
+            const float Gs[9] = {dcov[0], 0.5f * dcov[1], 0.5f * dcov[2], 0.5f * dcov[1], dcov[3],
+                                 0.5f * dcov[4], 0.5f * dcov[2], 0.5f * dcov[4], dcov[5]};
+            float dR[9];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                float ds = 0.f;
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    float acc = 0.f;
+#pragma unroll
+                    for (int l = 0; l < 3; ++l) acc += Gs[3 * r + l] * (R[3 * l + k] * s[k]);
+                    const float dM = 2.f * acc;
+                    ds += R[3 * r + k] * dM;
+                    dR[3 * r + k] = s[k] * dM;
+                }
+                dscale[k] = scale_modifier * ds;
+            }
+            const float qr = q.x, qx = q.y, qy = q.z, qz = q.w;
+#define G_(r_, c_) dR[3 * (r_) + (c_)]
+            drot.x = 2.f * (-qz * G_(0, 1) + qy * G_(0, 2) + qz * G_(1, 0) - qx * G_(1, 2) - qy * G_(2, 0) + qx * G_(2, 1));
+            drot.y = 2.f * (qy * G_(0, 1) + qz * G_(0, 2) + qy * G_(1, 0) - 2.f * qx * G_(1, 1) - qr * G_(1, 2) + qz * G_(2, 0) + qr * G_(2, 1) - 2.f * qx * G_(2, 2));
+            drot.z = 2.f * (-2.f * qy * G_(0, 0) + qx * G_(0, 1) + qr * G_(0, 2) + qx * G_(1, 0) + qz * G_(1, 2) - qr * G_(2, 0) + qz * G_(2, 1) - 2.f * qy * G_(2, 2));
+            drot.w = 2.f * (-2.f * qz * G_(0, 0) - qr * G_(0, 1) + qx * G_(0, 2) + qr * G_(1, 0) - 2.f * qz * G_(1, 1) + qy * G_(1, 2) + qx * G_(2, 0) + qy * G_(2, 1));
+#undef G_
+        }
+    } else {
+        if (dsh)
+            for (int k = 0; k < 3 * M; ++k) dsh[k] = 0.f;
+        if (colors_precomp && dL_dcolors) {
+            dL_dcolors[3 * i] = 0.f; dL_dcolors[3 * i + 1] = 0.f; dL_dcolors[3 * i + 2] = 0.f;
+        }
+    }
+    dL_dmeans3D[3 * i] = dmean[0];
+    dL_dmeans3D[3 * i + 1] = dmean[1];
+    dL_dmeans3D[3 * i + 2] = dmean[2];
+    if (cov_precomp) {
+        if (dL_dcov3D)
+#pragma unroll
+            for (int k = 0; k < 6; ++k) dL_dcov3D[6 * i + k] = dcov[k];
+    } else {
+        dL_dscale[3 * i] = dscale[0];
+        dL_dscale[3 * i + 1] = dscale[1];
+        dL_dscale[3 * i + 2] = dscale[2];
+        dL_drot[i] = drot;
+    }
+}
+
+__global__ __launch_bounds__(GDR_BLOCK) void mark_visible_kernel(int N, const float* __restrict__ means3D,
+                                                                  const float* __restrict__ view,
+                                                                  uint8_t* __restrict__ present) {
+    const int i = blockIdx.x * GDR_BLOCK + threadIdx.x;
+    if (i >= N) return;
+    const float z = view[2] * means3D[3 * i] + view[6] * means3D[3 * i + 1] + view[10] * means3D[3 * i + 2] + view[14];
+    present[i] = z > 0.2f ? 1 : 0;
+}
+
+}  // namespace
+
+#define LAUNCH_DEG(KERNEL, deg, grid, st, ...)                                              \
+    switch (deg) {                                                                          \
+        case 0: hipLaunchKernelGGL(KERNEL<0>, dim3(grid), dim3(GDR_BLOCK), 0, st, __VA_ARGS__); break; \
+        case 1: hipLaunchKernelGGL(KERNEL<1>, dim3(grid), dim3(GDR_BLOCK), 0, st, __VA_ARGS__); break; \
+        case 2: hipLaunchKernelGGL(KERNEL<2>, dim3(grid), dim3(GDR_BLOCK), 0, st, __VA_ARGS__); break; \
+        default: hipLaunchKernelGGL(KERNEL<3>, dim3(grid), dim3(GDR_BLOCK), 0, st, __VA_ARGS__); break; \
+    }
+
+hipError_t launch_preprocess_fwd(const gdr_settings* s, const gdr_inputs* in, const gdr_geom* g,
+                                 int32_t* radii, hipStream_t st) {
+    const int N = in->N;
+    if (N == 0) return hipSuccess;
+    const int W = s->image_width, H = s->image_height;
+    const float focal_x = (float)W / (2.f * s->tanfovx), focal_y = (float)H / (2.f * s->tanfovy);
+    const int grid = div_up(N, GDR_BLOCK);
+    const int deg = in->shs ? s->sh_degree : 0;
+    LAUNCH_DEG(preprocess_fwd_kernel, deg, grid, st, N, in->M, in->means3D, in->scales,
+               s->scale_modifier, in->rotations, in->opacities, in->shs, in->colors_precomp,
+               in->cov3D_precomp, s->viewmatrix, s->projmatrix, s->campos, W, H, s->tanfovx,
+               s->tanfovy, focal_x, focal_y, radii, g->depths, (float2*)g->xy,
+               (float4*)g->conic_opacity, (float4*)g->rgb, g->cov3D, (int4*)g->rect,
+               g->tiles_touched, g->clamped, g->block_sums);
+    return hipGetLastError();
+}
+
+hipError_t launch_preprocess_bwd(const gdr_settings* s, const gdr_inputs* in, const gdr_geom* g,
+                                 const int32_t* radii, const gdr_grad_outputs* go, hipStream_t st) {
+    const int N = in->N;
+    if (N == 0) return hipSuccess;
+    const int W = s->image_width, H = s->image_height;
+    const float focal_x = (float)W / (2.f * s->tanfovx), focal_y = (float)H / (2.f * s->tanfovy);
+    const int grid = div_up(N, GDR_BLOCK);
+    const int deg = in->shs ? s->sh_degree : 0;
+    const float* cov3D = in->cov3D_precomp ? in->cov3D_precomp : g->cov3D;
+    LAUNCH_DEG(preprocess_bwd_kernel, deg, grid, st, N, in->M, in->means3D, radii, in->shs,
+               g->clamped, in->scales, in->rotations, s->scale_modifier, cov3D,
+               in->cov3D_precomp ? 1 : 0, in->colors_precomp ? 1 : 0, s->viewmatrix,
+               s->projmatrix, s->campos, W, H, s->tanfovx, s->tanfovy, focal_x, focal_y,
+               (const float4*)go->dL_dmeans2D, (const float4*)go->scratch, go->dL_dmeans3D,
+               go->dL_dcov3D, go->dL_dshs, go->dL_dcolors, go->dL_dscales,
+               (float4*)go->dL_drotations);
+    return hipGetLastError();
+}
+
+hipError_t launch_mark_visible(int N, const float* means3D, const float* view, uint8_t* present,
+                               hipStream_t st) {
+    if (N == 0) return hipSuccess;
+    hipLaunchKernelGGL(mark_visible_kernel, dim3(div_up(N, GDR_BLOCK)), dim3(GDR_BLOCK), 0, st, N,
+                       means3D, view, present);
+    return hipGetLastError();
+}
+
+}  // namespace gdr

@@ -1,0 +1,274 @@
+"""Python boundary of the MI355X rasterizer — same surface as the reference's
+`diff_gaussian_rasterization` package (imported at /root/reference/lightning/renderer.py:10-13
+and .../point_decoder/layers/gaussian_renderer.py:14):
+
+    GaussianRasterizationSettings   12-field NamedTuple, built by keyword (renderer.py:111-124)
+    GaussianRasterizer(nn.Module)   forward(means3D, means2D, opacities, shs=, colors_precomp=,
+                                    scales=, rotations=, cov3D_precomp=)
+                                    -> (color(3,H,W), radii(N) int32, depth(1,H,W), alpha(1,H,W))
+                                    (renderer.py:250-259)
+    rasterize_gaussians(...)        functional form (BASELINE.json north_star names it)
+    GaussianRasterizer.markVisible  upstream API, unused by the reference
+
+Host code is Python on PyTorch-ROCm (tensors, streams); all arithmetic is in
+libgdr_hip.so, reached through the C ABI in include/gdr.h via ctypes.  There is no CPU
+path: non-HIP tensors raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import NamedTuple, Optional
+
+import torch
+from torch import nn
+
+from . import _lib as L
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None or t.numel() == 0 else C.c_void_p(t.data_ptr())
+
+
+def _f32(t: torch.Tensor, dev) -> torch.Tensor:
+    if t.device != dev:
+        t = t.to(dev)
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def _require_hip(t: torch.Tensor, name: str):
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"diff_gaussian_rasterization (MI355X build): `{name}` is on {t.device}; this "
+            "rasterizer runs only on ROCm/HIP device tensors and has no CPU fallback.")
+
+
+class _State:
+    """Typed views of the three workspaces of one forward call (kept for backward and
+    exposed to the parity tests)."""
+
+    __slots__ = ("N", "M", "H", "W", "D", "geom_buf", "bin_buf", "img_buf", "geom", "bin", "img")
+
+    def _view(self, buf, ptr, dtype, count):
+        off = ptr - buf.data_ptr()
+        nbytes = count * torch.empty(0, dtype=dtype).element_size()
+        return buf[off:off + nbytes].view(dtype)
+
+    def tensors(self) -> dict:
+        N, D, H, W = max(self.N, 1), self.D, self.H, self.W
+        g, b, im = self.geom, self.bin, self.img
+        gb, bb, ib = self.geom_buf, self.bin_buf, self.img_buf
+        tiles = ((W + 15) // 16) * ((H + 15) // 16)
+        s = b.sorted
+        out = dict(
+            depths=self._view(gb, g.depths, torch.float32, N),
+            xy=self._view(gb, g.xy, torch.float32, 2 * N).view(N, 2),
+            conic_opacity=self._view(gb, g.conic_opacity, torch.float32, 4 * N).view(N, 4),
+            rgb=self._view(gb, g.rgb, torch.float32, 4 * N).view(N, 4),
+            cov3D=self._view(gb, g.cov3D, torch.float32, 6 * N).view(N, 6),
+            rect=self._view(gb, g.rect, torch.int32, 4 * N).view(N, 4),
+            tiles_touched=self._view(gb, g.tiles_touched, torch.int32, N),
+            clamped=self._view(gb, g.clamped, torch.uint8, N),
+            ranges=self._view(ib, im.ranges, torch.int32, 2 * tiles).view(tiles, 2),
+            n_contrib=self._view(ib, im.n_contrib, torch.int32, H * W).view(H, W),
+            final_T=self._view(ib, im.final_T, torch.float32, H * W).view(H, W),
+            num_rendered=D,
+        )
+        if D > 0:
+            out["keys_sorted"] = self._view(bb, b.keys[s], torch.int64, D)
+            out["point_list"] = self._view(bb, b.values[s], torch.int32, D)
+        else:
+            out["keys_sorted"] = torch.empty(0, dtype=torch.int64, device=gb.device)
+            out["point_list"] = torch.empty(0, dtype=torch.int32, device=gb.device)
+        return out
+
+
+def _settings_struct(rs: GaussianRasterizationSettings, dev, keep: list) -> L.GdrSettings:
+    bg = _f32(rs.bg, dev)
+    view = _f32(rs.viewmatrix, dev)
+    proj = _f32(rs.projmatrix, dev)
+    campos = _f32(rs.campos, dev)
+    keep += [bg, view, proj, campos]
+    return L.GdrSettings(int(rs.image_height), int(rs.image_width), float(rs.tanfovx), float(rs.tanfovy),
+                         float(rs.scale_modifier), int(rs.sh_degree), int(bool(rs.prefiltered)),
+                         int(bool(rs.debug)), bg.data_ptr(), view.data_ptr(), proj.data_ptr(),
+                         campos.data_ptr())
+
+
+def _inputs_struct(N, M, means3D, opacities, sh, colors_precomp, scales, rotations, cov3Ds) -> L.GdrInputs:
+    return L.GdrInputs(N, M, _ptr(means3D), _ptr(opacities), _ptr(sh), _ptr(colors_precomp), _ptr(scales),
+                       _ptr(rotations), _ptr(cov3Ds))
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def forward_raw(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                raster_settings):
+    """Un-differentiated forward. Returns (color, radii, depth, alpha, state, keep)."""
+    lib = L.load()
+    _require_hip(means3D, "means3D")
+    dev = means3D.device
+    means3D = _f32(means3D, dev)
+    opacities = _f32(opacities, dev)
+    sh = _f32(sh, dev)
+    colors_precomp = _f32(colors_precomp, dev)
+    scales = _f32(scales, dev)
+    rotations = _f32(rotations, dev)
+    cov3Ds_precomp = _f32(cov3Ds_precomp, dev)
+    N = int(means3D.shape[0])
+    M = int(sh.shape[1]) if sh.numel() else 0
+    H, W = int(raster_settings.image_height), int(raster_settings.image_width)
+    if opacities.numel() != N:
+        raise RuntimeError("opacities must have N elements")
+    keep = [means3D, opacities, sh, colors_precomp, scales, rotations, cov3Ds_precomp]
+    with torch.cuda.device(dev):
+        s = _settings_struct(raster_settings, dev, keep)
+        inp = _inputs_struct(N, M, means3D, opacities, sh, colors_precomp, scales, rotations, cov3Ds_precomp)
+        st = _State()
+        st.N, st.M, st.H, st.W = N, M, H, W
+        u8 = dict(dtype=torch.uint8, device=dev)
+        st.geom_buf = torch.empty(lib.gdr_geom_bytes(N), **u8)
+        st.img_buf = torch.empty(lib.gdr_image_bytes(H, W), **u8)
+        st.geom, st.bin, st.img = L.GdrGeom(), L.GdrBinning(), L.GdrImage()
+        L.check(lib.gdr_geom_carve(st.geom_buf.data_ptr(), N, C.byref(st.geom)), "gdr_geom_carve")
+        L.check(lib.gdr_image_carve(st.img_buf.data_ptr(), H, W, C.byref(st.img)), "gdr_image_carve")
+        f32 = dict(dtype=torch.float32, device=dev)
+        color = torch.empty(3, H, W, **f32)
+        depth = torch.empty(1, H, W, **f32)
+        alpha = torch.empty(1, H, W, **f32)
+        radii = torch.empty(N, dtype=torch.int32, device=dev)
+        stream = _stream()
+        d_host = C.c_uint32(0)
+        L.check(lib.gdr_preprocess_forward(C.byref(s), C.byref(inp), C.byref(st.geom), _ptr(radii),
+                                           C.byref(d_host), stream), "gdr_preprocess_forward")
+        st.D = int(d_host.value)
+        st.bin_buf = torch.empty(lib.gdr_binning_bytes(st.D), **u8)
+        L.check(lib.gdr_binning_carve(st.bin_buf.data_ptr(), st.D, C.byref(st.bin)), "gdr_binning_carve")
+        out = L.GdrOutputs(color.data_ptr(), depth.data_ptr(), alpha.data_ptr(), _ptr(radii))
+        L.check(lib.gdr_render_forward(C.byref(s), C.byref(inp), C.byref(st.geom), C.byref(st.bin),
+                                       C.byref(st.img), st.D, C.byref(out), stream), "gdr_render_forward")
+    return color, radii, depth, alpha, st, keep
+
+
+def backward_raw(st: _State, keep, raster_settings, radii, grad_color, grad_depth, grad_alpha):
+    """Returns dict of gradients (all fp32, on the inputs' device)."""
+    lib = L.load()
+    means3D, opacities, sh, colors_precomp, scales, rotations, cov3Ds_precomp = keep[:7]
+    dev = means3D.device
+    N, M = st.N, st.M
+    f32 = dict(dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        keep2: list = []
+        s = _settings_struct(raster_settings, dev, keep2)
+        inp = _inputs_struct(N, M, means3D, opacities, sh, colors_precomp, scales, rotations, cov3Ds_precomp)
+        gc = _f32(grad_color, dev)
+        gd = None if grad_depth is None else _f32(grad_depth, dev)
+        ga = None if grad_alpha is None else _f32(grad_alpha, dev)
+        use_sh, use_cov = sh.numel() > 0, cov3Ds_precomp.numel() > 0
+        g = dict(
+            means3D=torch.empty(N, 3, **f32), means2D=torch.empty(N, 4, **f32),
+            shs=torch.empty(N, M, 3, **f32) if use_sh else None,
+            colors_precomp=None if use_sh else torch.empty(N, 3, **f32),
+            opacities=torch.empty(N, 1, **f32),
+            scales=None if use_cov else torch.empty(N, 3, **f32),
+            rotations=None if use_cov else torch.empty(N, 4, **f32),
+            cov3D_precomp=torch.empty(N, 6, **f32) if use_cov else None)
+        scratch = torch.empty(max(N, 1) * 8, **f32)
+        gin = L.GdrGradInputs(gc.data_ptr(), _ptr(gd), _ptr(ga))
+        gout = L.GdrGradOutputs(_ptr(g["means3D"]), _ptr(g["means2D"]), _ptr(g["shs"]),
+                                _ptr(g["colors_precomp"]), _ptr(g["opacities"]), _ptr(g["scales"]),
+                                _ptr(g["rotations"]), _ptr(g["cov3D_precomp"]), scratch.data_ptr())
+        L.check(lib.gdr_backward(C.byref(s), C.byref(inp), C.byref(st.geom), C.byref(st.bin),
+                                 C.byref(st.img), st.D, _ptr(radii), C.byref(gin), C.byref(gout),
+                                 _stream()), "gdr_backward")
+    return g
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+                cov3Ds_precomp, raster_settings):
+        color, radii, depth, alpha, st, keep = forward_raw(
+            means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings)
+        ctx.raster_settings = raster_settings
+        ctx.state = st
+        ctx.keep = keep
+        ctx.radii = radii
+        ctx.means2D_shape = tuple(means2D.shape)
+        ctx.in_dtypes = tuple(t.dtype for t in (means3D, means2D, sh, colors_precomp, opacities, scales,
+                                                rotations, cov3Ds_precomp))
+        ctx.mark_non_differentiable(radii)
+        return color, radii, depth, alpha
+
+    @staticmethod
+    def backward(ctx, grad_color, grad_radii, grad_depth, grad_alpha):
+        g = backward_raw(ctx.state, ctx.keep, ctx.raster_settings, ctx.radii, grad_color, grad_depth,
+                         grad_alpha)
+        gm2 = g["means2D"]
+        cols = ctx.means2D_shape[1] if len(ctx.means2D_shape) == 2 else 4
+        if cols == 4:
+            pass
+        elif cols == 3:  # legacy caller (point_decoder/layers/gaussian_renderer.py): xy signed, z = 0
+            gm2 = torch.cat([gm2[:, :2], torch.zeros_like(gm2[:, :1])], dim=1)
+        else:
+            gm2 = gm2[:, :cols].contiguous()
+        grads = [g["means3D"], gm2, g["shs"], g["colors_precomp"], g["opacities"], g["scales"],
+                 g["rotations"], g["cov3D_precomp"]]
+        grads = [None if t is None else (t if t.dtype == dt else t.to(dt)) for t, dt in zip(grads, ctx.in_dtypes)]
+        return (*grads, None)
+
+
+def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+                        cov3Ds_precomp, raster_settings):
+    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+                                     cov3Ds_precomp, raster_settings)
+
+
+class GaussianRasterizer(nn.Module):
+    def __init__(self, raster_settings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions):
+        lib = L.load()
+        _require_hip(positions, "positions")
+        rs = self.raster_settings
+        with torch.no_grad(), torch.cuda.device(positions.device):
+            p = _f32(positions, positions.device)
+            view = _f32(rs.viewmatrix, p.device)
+            proj = _f32(rs.projmatrix, p.device)
+            out = torch.empty(p.shape[0], dtype=torch.uint8, device=p.device)
+            L.check(lib.gdr_mark_visible(int(p.shape[0]), _ptr(p), view.data_ptr(), proj.data_ptr(),
+                                         _ptr(out), _stream()), "gdr_mark_visible")
+        return out.bool()
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None,
+                rotations=None, cov3D_precomp=None):
+        if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+            raise Exception("Please provide excatly one of either SHs or precomputed colors!")
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or (
+                (scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
+        e = torch.empty(0, dtype=torch.float32, device=means3D.device)
+        return rasterize_gaussians(
+            means3D, means2D, e if shs is None else shs, e if colors_precomp is None else colors_precomp,
+            opacities, e if scales is None else scales, e if rotations is None else rotations,
+            e if cov3D_precomp is None else cov3D_precomp, self.raster_settings)

@@ -1,0 +1,79 @@
+"""Host-side render adaptor — counterpart of the reference's `Renderer`
+(/root/reference/lightning/renderer.py:78-272) for boxes where /root/reference does not
+exist (the GPU box).  Same method names, argument meaning and return dict, so callers
+written against the reference (`network.py:836,854,971`) read the same:
+
+    render_img(cam, rays, centers, shs, opacity, scales, rotations, device,
+               cov3D_precomp=None, prex='', screenspace_points=None)
+      -> {f"image{prex}": (H,W,3) clamped to [0,1], f"depth{prex}": (H,W,1), f"acc_map{prex}": (H,W)}
+
+Steps mirrored (renderer.py:224-268): sigmoid(opacity), exp(scales), normalize(rotations);
+a (N,4) zero "screen-space points" carrier that receives the mean2D gradient (columns 2-3:
+AbsGS |.| sums, consumed at network.py:876-878); rasterizer call; clamp; CHW->HWC views.
+Pinned against the real class by tests/golden/render_img_*.npz.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+from torch import nn
+
+from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+
+
+class Renderer(nn.Module):
+    def __init__(self, sh_degree: int = 3, white_background: bool = True, radius: float = 1):
+        super().__init__()
+        self.sh_degree = sh_degree
+        self.white_background = white_background
+        self.radius = radius
+        self.scaling_activation = torch.exp
+        self.opacity_activation = torch.sigmoid
+        self.rotation_activation = torch.nn.functional.normalize
+        self.bg_color = torch.tensor([1, 1, 1] if white_background else [0, 0, 0], dtype=torch.float32)
+
+    def set_bg_color(self, bg):
+        self.bg_color = bg
+
+    def set_rasterizer(self, viewpoint_camera, scaling_modifier: float = 1.0, device="cuda"):
+        settings = GaussianRasterizationSettings(
+            image_height=int(viewpoint_camera.image_height),
+            image_width=int(viewpoint_camera.image_width),
+            tanfovx=math.tan(viewpoint_camera.FoVx * 0.5),
+            tanfovy=math.tan(viewpoint_camera.FoVy * 0.5),
+            bg=self.bg_color.to(device),
+            scale_modifier=scaling_modifier,
+            viewmatrix=viewpoint_camera.world_view_transform,
+            projmatrix=viewpoint_camera.full_proj_transform,
+            sh_degree=self.sh_degree,
+            campos=viewpoint_camera.camera_center,
+            prefiltered=False,
+            debug=False,
+        )
+        return GaussianRasterizer(raster_settings=settings)
+
+    def render_img(self, cam, rays, centers, shs, opacity, scales, rotations, device,
+                   cov3D_precomp=None, prex="", screenspace_points=None):
+        rasterizer = self.set_rasterizer(cam, device=device)
+        opacity = self.opacity_activation(opacity)
+        if scales is not None:
+            scales = self.scaling_activation(scales)
+        if rotations is not None:
+            rotations = self.rotation_activation(rotations)
+        if screenspace_points is None:
+            screenspace_points = torch.zeros((centers.shape[0], 4), dtype=centers.dtype,
+                                             requires_grad=True, device=device) + 0
+        try:
+            screenspace_points.retain_grad()
+        except Exception:
+            pass
+        image, radii, depth, alpha = rasterizer(
+            means3D=centers, means2D=screenspace_points, shs=shs, opacities=opacity, scales=scales,
+            rotations=rotations, cov3D_precomp=cov3D_precomp)
+        image = image.clamp(0, 1)
+        return {
+            f"image{prex}": image.permute(1, 2, 0),
+            f"depth{prex}": depth.permute(1, 2, 0),
+            f"acc_map{prex}": alpha.squeeze(0),
+        }

@@ -1,0 +1,191 @@
+/*
+ * include/gdr.h — C ABI of libgdr_hip.so, the MI355X (gfx950) differentiable
+ * Gaussian-splatting rasterizer for the Generative Densification render path.
+ *
+ * This is the drop-in boundary: the entry points below are what a binding of the
+ * reference's rasterizer extension would call.  The reference reaches its CUDA
+ * extension through the Python package `diff_gaussian_rasterization`
+ *   - import:            /root/reference/lightning/renderer.py:10-13
+ *                        /root/reference/lightning/point_decoder/layers/gaussian_renderer.py:14
+ *   - settings record:   /root/reference/lightning/renderer.py:111-124 (12 fields)
+ *   - forward call:      /root/reference/lightning/renderer.py:250-259
+ *                        (-> color(3,H,W), radii(N), depth(1,H,W), alpha(1,H,W))
+ *   - backward contract: /root/reference/lightning/network.py:867-878
+ *                        ((N,4) means2D gradient, |.|-accumulated in columns 2-3)
+ * whose native half (`_C.rasterize_gaussians`, `_C.rasterize_gaussians_backward`,
+ * `_C.mark_visible`; un-vendored submodule, /root/reference/.gitmodules:1-3) is what
+ * these functions replace.  See INTEGRATION.md for the reference-side stub.
+ *
+ * Conventions
+ *   - plain C: pointers + sizes, no torch / HIP types in any signature
+ *     (`stream` is a hipStream_t passed as void*; NULL = the null stream);
+ *   - every pointer is a DEVICE pointer to fp32/int32 data unless it says "host";
+ *   - matrices are 16 contiguous floats in the reference's row-vector convention
+ *     (/root/reference/lightning/utils.py:37-47): p_view = [p,1] @ viewmatrix;
+ *   - the caller owns every buffer; the library allocates nothing and keeps no
+ *     state => re-entrant, thread-safe for distinct workspaces, one call per stream;
+ *   - all work is enqueued on `stream`; the only host synchronisation is the
+ *     optional read-back of num_rendered in gdr_preprocess_forward;
+ *   - return value: 0 = GDR_OK, negative = error (never throws across the ABI).
+ */
+#ifndef GDR_H
+#define GDR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GDR_ABI_VERSION 1
+
+#define GDR_OK 0
+#define GDR_ERR_INVALID_ARG (-1)  /* NULL / inconsistent arguments                     */
+#define GDR_ERR_HIP (-2)          /* a HIP call failed: see gdr_last_error()           */
+#define GDR_ERR_UNSUPPORTED (-3)  /* sh_degree > 3, image too large for the key layout */
+#define GDR_ERR_WORKSPACE (-4)    /* caller workspace smaller than required            */
+
+#define GDR_TILE 16 /* tile edge in pixels (BLOCK_X = BLOCK_Y = 16) */
+
+/* The 12 fields of GaussianRasterizationSettings (renderer.py:111-124), flattened.
+ * bg / viewmatrix / projmatrix / campos stay device tensors exactly as the caller
+ * holds them (no host copies, no sync). */
+typedef struct gdr_settings {
+    int32_t image_height;
+    int32_t image_width;
+    float tanfovx;
+    float tanfovy;
+    float scale_modifier;
+    int32_t sh_degree;   /* active degree, 0..3 */
+    int32_t prefiltered; /* accepted, unused (reference always passes False) */
+    int32_t debug;       /* !=0: synchronise + check after every kernel */
+    const float* bg;         /* (3)  */
+    const float* viewmatrix; /* (16) */
+    const float* projmatrix; /* (16) */
+    const float* campos;     /* (3)  */
+} gdr_settings;
+
+/* Per-Gaussian inputs of GaussianRasterizer.forward (renderer.py:250-259).
+ * Exactly one of shs / colors_precomp and one of (scales, rotations) / cov3D_precomp
+ * is non-NULL. */
+typedef struct gdr_inputs {
+    int32_t N;                   /* number of Gaussians */
+    int32_t M;                   /* SH coefficients per Gaussian stored in `shs` (>= (deg+1)^2) */
+    const float* means3D;        /* (N,3) */
+    const float* opacities;      /* (N)   activated, [0,1] */
+    const float* shs;            /* (N,M,3) or NULL */
+    const float* colors_precomp; /* (N,3)   or NULL */
+    const float* scales;         /* (N,3)   or NULL, activated */
+    const float* rotations;      /* (N,4)   or NULL, (r,x,y,z), used as given */
+    const float* cov3D_precomp;  /* (N,6)   or NULL */
+} gdr_inputs;
+
+/* Geometry state written by the forward and re-read by the backward
+ * (upstream "geomBuffer").  Carved from one caller allocation by gdr_geom_carve. */
+typedef struct gdr_geom {
+    float* depths;           /* (N)   camera-space z                         */
+    float* xy;               /* (N,2) pixel-space mean                       */
+    float* conic_opacity;    /* (N,4) inverse 2D cov (xx,xy,yy) + opacity    */
+    float* rgb;              /* (N,4) SH colour (3) + pad                    */
+    float* cov3D;            /* (N,6)                                        */
+    int32_t* rect;           /* (N,4) tile rect minx,miny,maxx,maxy          */
+    uint32_t* tiles_touched; /* (N)                                          */
+    uint8_t* clamped;        /* (N)   bit ch set <=> colour channel clamped  */
+    uint32_t* block_sums;    /* (ceil(N/256)+1) scan scratch                 */
+    uint32_t* num_rendered;  /* (1)   D = sum tiles_touched                  */
+} gdr_geom;
+
+/* Binning state (upstream "binningBuffer"): D (key,value) pairs, double-buffered. */
+typedef struct gdr_binning {
+    uint64_t* keys[2];   /* (D) (tile << 32) | float_bits(depth)            */
+    uint32_t* values[2]; /* (D) Gaussian index                              */
+    uint32_t* hist;      /* radix-sort scratch                              */
+    int32_t sorted;      /* which of the two buffers holds the sorted list  */
+    int32_t reserved;
+} gdr_binning;
+
+/* Image state (upstream "imgBuffer"). */
+typedef struct gdr_image {
+    uint32_t* ranges;    /* (tiles,2) [first,last) into the sorted list     */
+    uint32_t* n_contrib; /* (H*W) 1-based index of the last contributor     */
+    float* final_T;      /* (H*W) transmittance after the last contributor  */
+} gdr_image;
+
+typedef struct gdr_outputs {
+    float* color;   /* (3,H,W) */
+    float* depth;   /* (1,H,W) sum_i w_i z_i (not normalised) */
+    float* alpha;   /* (1,H,W) sum_i w_i = 1 - T_final        */
+    int32_t* radii; /* (N)     0 = culled                     */
+} gdr_outputs;
+
+typedef struct gdr_grad_inputs {
+    const float* dL_dcolor; /* (3,H,W) */
+    const float* dL_ddepth; /* (H,W) or NULL (= zeros) */
+    const float* dL_dalpha; /* (H,W) or NULL (= zeros) */
+} gdr_grad_inputs;
+
+/* Gradient outputs; every buffer is fully written (zeros for culled Gaussians), the
+ * caller does not need to clear anything.  dL_dmeans2D is (N,4): columns 0-1 the signed
+ * NDC-space gradient, columns 2-3 the sum over pixels of its absolute per-pixel terms
+ * (network.py:876-878).  scratch: (N*8) floats used for conic/depth partials. */
+typedef struct gdr_grad_outputs {
+    float* dL_dmeans3D;   /* (N,3) */
+    float* dL_dmeans2D;   /* (N,4) */
+    float* dL_dshs;       /* (N,M,3) or NULL when colors_precomp was used */
+    float* dL_dcolors;    /* (N,3)  or NULL when shs was used (then taken from scratch) */
+    float* dL_dopacities; /* (N)   */
+    float* dL_dscales;    /* (N,3) or NULL when cov3D_precomp was used */
+    float* dL_drotations; /* (N,4) or NULL when cov3D_precomp was used */
+    float* dL_dcov3D;     /* (N,6) or NULL when scales/rotations were used */
+    float* scratch;       /* (N*8) floats, contents undefined on return */
+} gdr_grad_outputs;
+
+/* ---- sizes and carving ---------------------------------------------------------- */
+int gdr_abi_version(void);
+const char* gdr_last_error(void); /* thread-local, host string */
+
+size_t gdr_geom_bytes(int32_t N);
+size_t gdr_binning_bytes(uint64_t D);
+size_t gdr_image_bytes(int32_t H, int32_t W);
+/* base must be 256-byte aligned and at least gdr_*_bytes(...) long. */
+int gdr_geom_carve(void* base, int32_t N, gdr_geom* out);
+int gdr_binning_carve(void* base, uint64_t D, gdr_binning* out);
+int gdr_image_carve(void* base, int32_t H, int32_t W, gdr_image* out);
+
+/* ---- forward ---------------------------------------------------------------------
+ * Stage 1 (K1 + K2): per-Gaussian projection, EWA covariance, SH colour, tile rect,
+ * and the scan total.  radii is written here.  If num_rendered_host != NULL the
+ * stream is synchronised and D is returned through it (the one host read the
+ * upstream extension also performs); otherwise D stays in geom->num_rendered. */
+int gdr_preprocess_forward(const gdr_settings* s, const gdr_inputs* in, const gdr_geom* geom,
+                           int32_t* radii, uint32_t* num_rendered_host, void* stream);
+
+/* Stage 2 (K3..K6): duplicate with keys, radix sort on (tile, depth), tile ranges,
+ * per-tile alpha-composited render.  D is the capacity of `bin` and must be >= the
+ * value stage 1 produced.  bin->sorted is set. */
+int gdr_render_forward(const gdr_settings* s, const gdr_inputs* in, const gdr_geom* geom,
+                       gdr_binning* bin, const gdr_image* img, uint64_t D,
+                       const gdr_outputs* out, void* stream);
+
+/* Stages 1+2 with a caller-provided binning capacity D_cap.  Synchronises once to
+ * read D; returns GDR_ERR_WORKSPACE (and *num_rendered_host = required D) if
+ * D > D_cap, in which case only stage 1 has run. */
+int gdr_forward(const gdr_settings* s, const gdr_inputs* in, const gdr_geom* geom,
+                gdr_binning* bin, const gdr_image* img, uint64_t D_cap, const gdr_outputs* out,
+                uint32_t* num_rendered_host, void* stream);
+
+/* ---- backward (K7 + K8/K9) -------------------------------------------------------- */
+int gdr_backward(const gdr_settings* s, const gdr_inputs* in, const gdr_geom* geom,
+                 const gdr_binning* bin, const gdr_image* img, uint64_t D,
+                 const int32_t* radii, const gdr_grad_inputs* gin, const gdr_grad_outputs* gout,
+                 void* stream);
+
+/* ---- K10: visibility mask (upstream markVisible; unused by the reference) -------- */
+int gdr_mark_visible(int32_t N, const float* means3D, const float* viewmatrix,
+                     const float* projmatrix, uint8_t* present, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GDR_H */

@@ -1,0 +1,128 @@
+"""Shared helpers of the parity tests: build a seeded case, run it through the oracle
+(checker) and through the HIP product path, compare."""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+
+from generativedensification_amd.camera import orbit_cameras
+from generativedensification_amd.synthetic import make_scene
+from oracle.gdr_oracle import Oracle, Settings
+
+FOV = 0.75
+
+
+def make_case(N, H, W, seed, deg=3, sigma0=(0.0052, 0.00065), cam_index=1, n_cams=4, bg=(1.0, 1.0, 1.0),
+              scale_modifier=1.0, colors_precomp=False, cov_precomp=False):
+    sc = make_scene(N, seed, sh_degree=deg, sigma0=sigma0)
+    cam = orbit_cameras(n_cams, W, H)[cam_index]
+    case = dict(
+        N=N, H=H, W=W, deg=deg,
+        means3D=sc["centers"].contiguous(),
+        opacities=torch.sigmoid(sc["opacity"]).contiguous(),
+        shs=None if colors_precomp else sc["shs"].contiguous(),
+        colors_precomp=torch.sigmoid(sc["shs"][:, 0, :]).contiguous() if colors_precomp else None,
+        scales=torch.exp(sc["scales"]).contiguous(),
+        rotations=torch.nn.functional.normalize(sc["rotations"]).contiguous(),
+        cov3D_precomp=None,
+        view=cam.world_view_transform.contiguous(), proj=cam.full_proj_transform.contiguous(),
+        campos=cam.camera_center.contiguous(), bg=torch.tensor(bg, dtype=torch.float32),
+        tanfovx=math.tan(FOV * 0.5), tanfovy=math.tan(FOV * 0.5), scale_modifier=scale_modifier,
+    )
+    if cov_precomp:
+        o = Oracle("f32")
+        tmp = o.forward(case["means3D"].numpy(), case["opacities"].numpy(), settings_np(case),
+                        shs=None if colors_precomp else case["shs"].numpy(),
+                        colors_precomp=case["colors_precomp"].numpy() if colors_precomp else None,
+                        scales=case["scales"].numpy(), rotations=case["rotations"].numpy())
+        # covariance of every Gaussian (also the culled ones): recompute densely in torch
+        from oracle.torch_ref import quat_to_R
+        R = quat_to_R(case["rotations"])
+        Mm = R * (scale_modifier * case["scales"])[:, None, :]
+        S = Mm @ Mm.transpose(1, 2)
+        case["cov3D_precomp"] = torch.stack([S[:, 0, 0], S[:, 0, 1], S[:, 0, 2], S[:, 1, 1], S[:, 1, 2], S[:, 2, 2]], 1).contiguous()
+        case["scales"] = None
+        case["rotations"] = None
+        del tmp
+    return case
+
+
+def settings_np(case) -> Settings:
+    return Settings(case["H"], case["W"], case["tanfovx"], case["tanfovy"], case["bg"].numpy(),
+                    case["scale_modifier"], case["view"].numpy(), case["proj"].numpy(), case["deg"],
+                    case["campos"].numpy(), False, False)
+
+
+def _np(t):
+    return None if t is None else t.detach().cpu().numpy()
+
+
+def run_oracle(case, precision="f32", grads=None, nthreads=1):
+    o = Oracle(precision, nthreads=nthreads)
+    out = o.forward(_np(case["means3D"]), _np(case["opacities"]), settings_np(case), shs=_np(case["shs"]),
+                    colors_precomp=_np(case["colors_precomp"]), scales=_np(case["scales"]),
+                    rotations=_np(case["rotations"]), cov3D_precomp=_np(case["cov3D_precomp"]))
+    g = None
+    if grads is not None:
+        g = o.backward(out, _np(grads[0]), _np(grads[1]), _np(grads[2]))
+    return out, g
+
+
+def settings_torch(case, dev):
+    from generativedensification_amd.rasterizer import GaussianRasterizationSettings
+
+    return GaussianRasterizationSettings(
+        image_height=case["H"], image_width=case["W"], tanfovx=case["tanfovx"], tanfovy=case["tanfovy"],
+        bg=case["bg"].to(dev), scale_modifier=case["scale_modifier"], viewmatrix=case["view"].to(dev),
+        projmatrix=case["proj"].to(dev), sh_degree=case["deg"], campos=case["campos"].to(dev),
+        prefiltered=False, debug=False)
+
+
+def run_hip(case, grads=None, dev="cuda:0"):
+    """Through the product C ABI (generativedensification_amd.rasterizer -> libgdr_hip.so)."""
+    from generativedensification_amd import rasterizer as R
+
+    dev = torch.device(dev)
+    rs = settings_torch(case, dev)
+    e = torch.empty(0, device=dev)
+    t = lambda k: e if case[k] is None else case[k].to(dev)
+    color, radii, depth, alpha, st, keep = R.forward_raw(
+        t("means3D"), t("shs"), t("colors_precomp"), t("opacities"), t("scales"), t("rotations"),
+        t("cov3D_precomp"), rs)
+    torch.cuda.synchronize()
+    out = {k: (v.cpu().numpy() if isinstance(v, torch.Tensor) else v) for k, v in st.tensors().items()}
+    out.update(color=color.cpu().numpy(), radii=radii.cpu().numpy(), depth=depth.cpu().numpy(),
+               alpha=alpha.cpu().numpy())
+    g = None
+    if grads is not None:
+        gg = R.backward_raw(st, keep, rs, radii, grads[0].to(dev), grads[1].to(dev), grads[2].to(dev))
+        torch.cuda.synchronize()
+        g = {k: (None if v is None else v.cpu().numpy()) for k, v in gg.items()}
+    return out, g
+
+
+def rand_grads(case, seed=123):
+    g = torch.Generator().manual_seed(seed)
+    H, W = case["H"], case["W"]
+    return (torch.randn(3, H, W, generator=g), torch.randn(1, H, W, generator=g),
+            torch.randn(1, H, W, generator=g))
+
+
+def rel_inf(a, b):
+    """||a-b||_inf / max(||b||_inf, tiny)."""
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)) if a.size else 0.0
+
+
+def outlier_fraction(a, b, rtol=1e-4, atol=1e-4):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return float((np.abs(a - b) > atol + rtol * np.abs(b)).mean()) if a.size else 0.0
+
+
+def psnr(a, b):
+    mse = float(((np.asarray(a, np.float64) - np.asarray(b, np.float64)) ** 2).mean())
+    return 10 * math.log10(1.0 / max(mse, 1e-30))
