@@ -172,7 +172,7 @@ int gdr_render_forward(const gdr_settings* s, const gdr_inputs* in, const gdr_ge
                        void* stream) {
     int rc = check_common(s, in);
     if (rc) return rc;
-    if (!geom || !bin || !img || !out || !out->color || !out->depth || !out->alpha || !out->radii) {
+    if (!geom || !bin || !img || !out || !out->color || !out->depth || !out->alpha || (in->N > 0 && !out->radii)) {
         set_error("render_forward: NULL argument", hipSuccess);
         return GDR_ERR_INVALID_ARG;
     }

@@ -87,7 +87,8 @@ __global__ __launch_bounds__(GDR_BLOCK) void render_fwd_kernel(
 
     for (int r = 0; r < rounds; ++r, todo -= GDR_BLOCK) {
         // workgroup-level early out: all four waves saturated
-        if (lane_id() == 0) s_done[wave] = (__ballot(!done) == 0ull) ? 1 : 0;
+        const bool wave_done = __ballot(!done) == 0ull;  // evaluated by all 64 lanes
+        if (lane_id() == 0) s_done[wave] = wave_done ? 1 : 0;
         __syncthreads();
         if (s_done[0] + s_done[1] + s_done[2] + s_done[3] == GDR_BLOCK / GDR_WAVE) break;
         const int progress = r * GDR_BLOCK + (int)threadIdx.x;
