@@ -1,0 +1,258 @@
+#!/usr/bin/env python
+"""bench.py — views/sec forward+backward @ 800x800 of the Gaussian-splatting render path
+(BASELINE.json `metric`), on N GPUs of one node, one rank per GPU.
+
+    python bench.py [--gpus N --steps K --warmup W]          (N>1: launched by torch.distributed.run)
+
+A "step" = one pass of the hot path over one batch: every view of this rank's shard is
+rendered through the reference boundary (`Renderer.render_img` -> `GaussianRasterizer`,
+lightning/renderer.py:209-272 semantics) and back-propagated (MSE + 0.1 mean(depth) + 0.1
+mean(alpha)) into the Gaussian attributes; per-view losses are all-gathered
+(RCCL over xGMI).  Weak scaling: views_per_gpu is fixed, the Gaussians are replicated.
+
+Workload (config.workload):
+  c4  (default) BASELINE.json configs[3] per-GPU share: 2M densified-like Gaussians
+      (sigma0 = 0.00065), 4 views/GPU at 800x800, SH degree 3 — the configuration the
+      metric's target (">= 2M Gaussians ... >= 120 views/s on 1 x MI355X") is quoted on.
+  c2  BASELINE.json configs[1]: 200k Gaussians (50/50 sigma0 mix), 4 views 800x800.
+
+Prints ONE JSON line (rank 0) with the contract fields plus `roofline` (dominant kernel,
+HIP-event timed on the launch stream in a second pass of the same K steps) and
+`cpu_baseline` (the oracle's C restatement on the host cores, bounded sample, rank 0,
+N=1 only).  Inputs are resident in HBM before the timed region starts.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s achievable
+
+WORKLOADS = {
+    "c4": dict(n=2_000_000, sigma0=(0.00065,), seed=3, views_per_gpu=4, h=800, w=800, deg=3,
+               desc="BASELINE configs[3] per-GPU share: 2M densified-like Gaussians, 4 views/GPU 800x800, SH3, fwd+bwd"),
+    "c2": dict(n=200_000, sigma0=(0.0052, 0.00065), seed=1, views_per_gpu=4, h=800, w=800, deg=3,
+               desc="BASELINE configs[1]: 200k Gaussians (50/50 sigma0 mix), 4 views 800x800, SH3, fwd+bwd"),
+}
+
+
+def algorithmic_bytes(n, d, p, m, tiles):
+    """Per-kernel ALGORITHMIC HBM bytes per launch (stated in DESIGN.md).
+    A = input attribute bytes / Gaussian, S = saved state, G = partial grads, K = key+value."""
+    A = 12 + 12 + 16 + 4 + 12 * m
+    S, G, K = 75, 52, 12
+    bits = 32 + max(1, math.ceil(math.log2(max(tiles, 2))))
+    passes = (bits + 7) // 8
+    return dict(
+        preprocess_fwd=n * (A + S),
+        scan_block_sums=n * 8 // 256,
+        duplicate_with_keys=n * 20 + d * K,
+        sort_hist=d * 8,                # per pass
+        sort_rowscan=0,
+        sort_scatter=d * 2 * K,         # per pass
+        tile_ranges=d * 8,
+        render_fwd=d * 44 + p * 28,
+        render_bwd=d * (44 + G) + p * 28,
+        preprocess_bwd=n * (A + S + G) + n * (A + 16),
+        _passes=passes,
+        _bytes_view=n * (A + S) + n * 28 + d * K + d * (8 + passes * 2 * K) + d * 8 + d * 44 + p * 28
+        + d * (44 + G) + p * 28 + n * (A + S + G) + n * (A + 16),
+    )
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c4", choices=sorted(WORKLOADS))
+    ap.add_argument("--n", type=int, default=0, help="override the number of Gaussians")
+    ap.add_argument("--views-per-gpu", type=int, default=0)
+    ap.add_argument("--grad-allreduce", action="store_true",
+                    help="also sum the Gaussian attribute grads over ranks each step (SURVEY §8e)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--traffic-bytes", type=float, default=None,
+                    help="HBM bytes per launch of the dominant kernel from a rocprofv3 --pmc run (profiles/)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU (no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    from generativedensification_amd import _lib as L
+    from generativedensification_amd.camera import orbit_cameras
+    from generativedensification_amd.multiview import (allreduce_gaussian_grads, gather_view_losses,
+                                                       shard_views)
+    from generativedensification_amd.renderer import Renderer
+    from generativedensification_amd.synthetic import make_scene, make_targets, view_loss
+
+    wl = dict(WORKLOADS[args.workload])
+    if args.n:
+        wl["n"] = args.n
+    if args.views_per_gpu:
+        wl["views_per_gpu"] = args.views_per_gpu
+    n, h, w, deg, vpg = wl["n"], wl["h"], wl["w"], wl["deg"], wl["views_per_gpu"]
+    total_views = vpg * world
+    scene = make_scene(n, wl["seed"], sh_degree=deg, sigma0=wl["sigma0"], device=dev)
+    params = {k: v.requires_grad_(True) for k, v in scene.items()}
+    all_cams = orbit_cameras(total_views, w, h, device=dev)
+    mine = shard_views(total_views, rank, world)
+    cams = [all_cams[i] for i in mine]
+    targets = make_targets(total_views, h, w, wl["seed"])[list(mine)].to(dev)
+    renderer = Renderer(sh_degree=deg, white_background=True)
+    renderer.set_bg_color(torch.ones(3, device=dev))
+    plist = list(params.values())
+    L.load()
+
+    def step():
+        for p in plist:
+            p.grad = None
+        losses = []
+        for j, cam in enumerate(cams):
+            out = renderer.render_img(cam, None, params["centers"], params["shs"], params["opacity"],
+                                      params["scales"], params["rotations"], dev)
+            loss = view_loss(out, targets[j])
+            loss.backward()
+            losses.append(loss.detach())
+        all_losses = gather_view_losses(torch.stack(losses), total_views)
+        if args.grad_allreduce:
+            allreduce_gaussian_grads(plist)
+        return all_losses
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        last_losses = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    views_per_sec = total_views * args.steps / elapsed
+    ms_per_step = 1e3 * elapsed / args.steps
+
+    # ---- D (num_rendered) per view, measured ----------------------------------------
+    from generativedensification_amd import rasterizer as R
+    d_views = []
+    with torch.no_grad():
+        for cam in cams:
+            rs = renderer.set_rasterizer(cam, device=dev).raster_settings
+            e = torch.empty(0, device=dev)
+            _, _, _, _, st, _ = R.forward_raw(params["centers"].detach(), params["shs"].detach(), e,
+                                              torch.sigmoid(params["opacity"].detach()),
+                                              torch.exp(params["scales"].detach()),
+                                              torch.nn.functional.normalize(params["rotations"].detach()), e, rs)
+            d_views.append(st.D)
+            del st
+    d_mean = sum(d_views) / len(d_views)
+    tiles = ((w + 15) // 16) * ((h + 15) // 16)
+    m = (deg + 1) ** 2
+    alg = algorithmic_bytes(n, d_mean, h * w, m, tiles)
+
+    # ---- roofline: per-kernel HIP-event timing, second pass of the same K steps -----------
+    roofline = None
+    kernels = {}
+    if not args.no_roofline:
+        L.profile_enable(True)
+        L.profile_collect(reset=True)
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        prof = L.profile_collect(reset=True)
+        L.profile_enable(False)
+        for name, (ms, cnt) in prof.items():
+            if cnt:
+                kernels[name] = dict(avg_us=round(1e3 * ms / cnt, 2), launches=cnt, total_ms=round(ms, 3))
+        if kernels:
+            dom = max(kernels, key=lambda k: kernels[k]["total_ms"])
+            avg_s = kernels[dom]["avg_us"] * 1e-6
+            achieved = alg[dom] / avg_s / 1e9
+            roofline = dict(bound="hbm", kernel=dom, achieved=round(achieved, 1), peak=HBM_PEAK_GBS,
+                            unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4),
+                            traffic=args.traffic_bytes, alg_bytes_per_launch=int(alg[dom]),
+                            avg_launch_us=kernels[dom]["avg_us"],
+                            path_bytes_view=int(alg["_bytes_view"]),
+                            path_frac=round(views_per_sec / world * alg["_bytes_view"] / 1e9 / HBM_PEAK_GBS, 4))
+
+    # ---- CPU baseline: oracle (C restatement, OpenMP) on a bounded sample ------------------
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        import numpy as np
+        from oracle.gdr_oracle import Oracle, Settings
+
+        cores = os.cpu_count() or 1
+        o = Oracle("f32", nthreads=cores)
+        cam = cams[0]
+        s = Settings(h, w, math.tan(0.375), math.tan(0.375), np.ones(3, np.float32), 1.0,
+                     cam.world_view_transform.cpu().numpy(), cam.full_proj_transform.cpu().numpy(), deg,
+                     cam.camera_center.cpu().numpy())
+        n_s = n  # bounded sample: 1 of the rank's views, full Gaussian set (~6 s on 8 cores)
+        c = {k: v.detach()[:n_s].cpu() for k, v in params.items()}
+        op = torch.sigmoid(c["opacity"]).numpy()
+        sc = torch.exp(c["scales"]).numpy()
+        ro = torch.nn.functional.normalize(c["rotations"]).numpy()
+        g = np.random.default_rng(0)
+        gc = g.standard_normal((3, h, w), dtype=np.float32)
+        gd = g.standard_normal((1, h, w), dtype=np.float32)
+        ga = g.standard_normal((1, h, w), dtype=np.float32)
+        tc0 = time.perf_counter()
+        reps = 0
+        while True:
+            ctx = o.forward(c["centers"].numpy(), op, s, shs=c["shs"].numpy(), scales=sc, rotations=ro)
+            o.backward(ctx, gc, gd, ga)
+            reps += 1
+            if time.perf_counter() - tc0 > 10.0 or reps >= 5:
+                break
+        tc = (time.perf_counter() - tc0) / reps
+        cpu_baseline = dict(value=round(1.0 / tc * (n_s / n), 4), unit="views/s", cores=cores, kind="port",
+                            sample=f"oracle C restatement (OpenMP, {cores} threads), {reps} x fwd+bwd of 1 view {h}x{w}, "
+                                   f"all {n} Gaussians ({tc:.2f} s each)")
+
+    if rank == 0:
+        out = {
+            "metric": "views/sec fwd+bwd @ 800x800", "value": round(views_per_sec, 2), "unit": "views/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic (seeded random Gaussians with the decoder's statistics, random targets)",
+            "config": {"workload": f"{args.workload}: {wl['desc']}", "n_gaussians": n,
+                       "views_per_gpu": vpg, "image": [h, w], "sh_degree": deg,
+                       "num_rendered_per_view": int(d_mean), "parallelism": f"view-sharded x{world}",
+                       "grad_allreduce": bool(args.grad_allreduce)},
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "kernels": kernels,
+            "loss_mean": float(last_losses.mean()),
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

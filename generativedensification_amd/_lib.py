@@ -83,6 +83,10 @@ _PROTOS = {
     "gdr_backward": (C.c_int, [C.POINTER(GdrSettings), C.POINTER(GdrInputs), C.POINTER(GdrGeom),
                                C.POINTER(GdrBinning), C.POINTER(GdrImage), C.c_uint64, C.c_void_p,
                                C.POINTER(GdrGradInputs), C.POINTER(GdrGradOutputs), C.c_void_p]),
+    "gdr_profile_enable": (C.c_int, [C.c_int]),
+    "gdr_profile_collect": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int32, C.c_int32]),
+    "gdr_kernel_count": (C.c_int, []),
+    "gdr_kernel_name": (C.c_char_p, [C.c_int32]),
     "gdr_mark_visible": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
 }
 EXPORTED_SYMBOLS = tuple(_PROTOS)
@@ -114,3 +118,17 @@ def check(rc: int, what: str):
     if rc != GDR_OK:
         msg = load().gdr_last_error()
         raise RuntimeError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")
+
+
+def profile_enable(on: bool):
+    check(load().gdr_profile_enable(int(on)), "gdr_profile_enable")
+
+
+def profile_collect(reset: bool = True) -> dict:
+    """{kernel name: (total ms, launches)} since the last reset (waits for pending events)."""
+    lib = load()
+    n = lib.gdr_kernel_count()
+    ms = (C.c_double * n)()
+    cnt = (C.c_uint64 * n)()
+    check(lib.gdr_profile_collect(ms, cnt, n, int(reset)), "gdr_profile_collect")
+    return {lib.gdr_kernel_name(k).decode(): (float(ms[k]), int(cnt[k])) for k in range(n)}

@@ -4,6 +4,9 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <mutex>
+#include <vector>
+
 #include "gdr_common.h"
 
 namespace gdr {
@@ -12,6 +15,38 @@ static thread_local char g_err[512] = "";
 
 void set_error(const char* what, hipError_t e) {
     snprintf(g_err, sizeof(g_err), "%s: %s (%d)", what, e == hipSuccess ? "" : hipGetErrorString(e), (int)e);
+}
+
+// ---- opt-in per-kernel timing (process-wide; used by bench.py for the roofline) --------
+struct ProfRec { int id; hipEvent_t a, b; };
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_prof_pending;
+static std::vector<hipEvent_t> g_prof_pool;
+static double g_prof_ms[GDR_K_COUNT];
+static uint64_t g_prof_cnt[GDR_K_COUNT];
+static hipEvent_t g_prof_open = nullptr;
+static std::mutex g_prof_mu;
+
+static hipEvent_t prof_event() {
+    if (!g_prof_pool.empty()) { hipEvent_t e = g_prof_pool.back(); g_prof_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+void prof_begin(int id, hipStream_t st) {
+    (void)id;
+    if (!g_prof_on) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_open = prof_event();
+    (void)hipEventRecord(g_prof_open, st);
+}
+void prof_end(int id, hipStream_t st) {
+    if (!g_prof_on) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    hipEvent_t b = prof_event();
+    (void)hipEventRecord(b, st);
+    g_prof_pending.push_back({id, g_prof_open, b});
+    g_prof_open = nullptr;
 }
 
 static inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
@@ -239,6 +274,42 @@ int gdr_backward(const gdr_settings* s, const gdr_inputs* in, const gdr_geom* ge
     if ((rc = debug_sync(s, "preprocess_bwd", st))) return rc;
     return GDR_OK;
 }
+
+int gdr_profile_enable(int on) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_on = on != 0;
+    return GDR_OK;
+}
+
+int gdr_profile_collect(double* ms_total, uint64_t* launches, int32_t n, int32_t reset) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (auto& r : g_prof_pending) {
+        float ms = 0.f;
+        hipError_t e = hipEventSynchronize(r.b);
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, r.a, r.b);
+        if (e != hipSuccess) return hip_fail("profile_collect", e);
+        g_prof_ms[r.id] += ms;
+        g_prof_cnt[r.id] += 1;
+        g_prof_pool.push_back(r.a);
+        g_prof_pool.push_back(r.b);
+    }
+    g_prof_pending.clear();
+    for (int k = 0; k < n && k < GDR_K_COUNT; ++k) {
+        if (ms_total) ms_total[k] = g_prof_ms[k];
+        if (launches) launches[k] = g_prof_cnt[k];
+    }
+    if (reset)
+        for (int k = 0; k < GDR_K_COUNT; ++k) { g_prof_ms[k] = 0; g_prof_cnt[k] = 0; }
+    return GDR_OK;
+}
+
+const char* gdr_kernel_name(int32_t id) {
+    static const char* names[GDR_K_COUNT] = {"preprocess_fwd", "scan_block_sums", "duplicate_with_keys",
+        "sort_hist", "sort_rowscan", "sort_scatter", "tile_ranges", "render_fwd", "render_bwd",
+        "preprocess_bwd", "mark_visible"};
+    return (id >= 0 && id < GDR_K_COUNT) ? names[id] : "";
+}
+int gdr_kernel_count(void) { return GDR_K_COUNT; }
 
 int gdr_mark_visible(int32_t N, const float* means3D, const float* viewmatrix,
                      const float* projmatrix, uint8_t* present, void* stream) {

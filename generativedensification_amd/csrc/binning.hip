@@ -239,7 +239,7 @@ size_t sort_hist_bytes(uint64_t D) {
 
 hipError_t launch_scan_block_sums(const gdr_geom* g, int N, hipStream_t st) {
     const int nb = div_up(N, GDR_BLOCK);
-    hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(GDR_BLOCK), 0, st, g->block_sums, nb,
+    GDR_LAUNCH(GDR_K_SCAN, scan_block_sums_kernel, dim3(1), dim3(GDR_BLOCK), st, g->block_sums, nb,
                        g->num_rendered);
     return hipGetLastError();
 }
@@ -248,7 +248,7 @@ hipError_t launch_duplicate(const gdr_geom* g, int N, int W, int H, const int32_
                             uint64_t* keys, uint32_t* vals, uint64_t D, hipStream_t st) {
     (void)H;
     if (N == 0) return hipSuccess;
-    hipLaunchKernelGGL(duplicate_kernel, dim3(div_up(N, GDR_BLOCK)), dim3(GDR_BLOCK), 0, st, N,
+    GDR_LAUNCH(GDR_K_DUPLICATE, duplicate_kernel, dim3(div_up(N, GDR_BLOCK)), dim3(GDR_BLOCK), st, N,
                        tile_grid_x(W), radii, g->depths, (const int4*)g->rect, g->tiles_touched,
                        g->block_sums, keys, vals, D);
     return hipGetLastError();
@@ -262,11 +262,11 @@ hipError_t launch_sort(gdr_binning* bin, uint64_t D, int nbits, hipStream_t st) 
     uint32_t* totals = bin->hist + (uint64_t)nblk * GDR_RADIX;
     int cur = 0;
     for (int shift = 0; shift < nbits; shift += GDR_RADIX_BITS) {
-        hipLaunchKernelGGL(sort_hist_kernel, dim3(nblk), dim3(GDR_BLOCK), 0, st, bin->keys[cur], D,
+        GDR_LAUNCH(GDR_K_SORT_HIST, sort_hist_kernel, dim3(nblk), dim3(GDR_BLOCK), st, bin->keys[cur], D,
                            shift, nblk, hist);
-        hipLaunchKernelGGL(sort_rowscan_kernel, dim3(GDR_RADIX), dim3(GDR_BLOCK), 0, st, hist, nblk,
+        GDR_LAUNCH(GDR_K_SORT_ROWSCAN, sort_rowscan_kernel, dim3(GDR_RADIX), dim3(GDR_BLOCK), st, hist, nblk,
                            totals);
-        hipLaunchKernelGGL(sort_scatter_kernel, dim3(nblk), dim3(GDR_BLOCK), 0, st, bin->keys[cur],
+        GDR_LAUNCH(GDR_K_SORT_SCATTER, sort_scatter_kernel, dim3(nblk), dim3(GDR_BLOCK), st, bin->keys[cur],
                            bin->values[cur], bin->keys[cur ^ 1], bin->values[cur ^ 1], D, shift,
                            nblk, hist, totals);
         cur ^= 1;
@@ -280,7 +280,7 @@ hipError_t launch_ranges(const gdr_binning* bin, uint64_t D, const gdr_image* im
     hipError_t e = hipMemsetAsync(img->ranges, 0, (size_t)tiles * 2 * sizeof(uint32_t), st);
     if (e != hipSuccess) return e;
     if (D == 0) return hipSuccess;
-    hipLaunchKernelGGL(ranges_kernel, dim3(div_up((int64_t)D, GDR_BLOCK)), dim3(GDR_BLOCK), 0, st,
+    GDR_LAUNCH(GDR_K_RANGES, ranges_kernel, dim3(div_up((int64_t)D, GDR_BLOCK)), dim3(GDR_BLOCK), st,
                        bin->keys[bin->sorted], D, (uint2*)img->ranges);
     return hipGetLastError();
 }

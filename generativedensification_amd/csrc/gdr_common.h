@@ -16,7 +16,34 @@
 #define GDR_RADIX_BITS 8
 #define GDR_RADIX (1 << GDR_RADIX_BITS)
 
+// kernel ids for the opt-in per-kernel timing (gdr_profile_*, include/gdr.h)
+enum {
+    GDR_K_PREPROCESS_FWD = 0,
+    GDR_K_SCAN,
+    GDR_K_DUPLICATE,
+    GDR_K_SORT_HIST,
+    GDR_K_SORT_ROWSCAN,
+    GDR_K_SORT_SCATTER,
+    GDR_K_RANGES,
+    GDR_K_RENDER_FWD,
+    GDR_K_RENDER_BWD,
+    GDR_K_PREPROCESS_BWD,
+    GDR_K_MARK_VISIBLE,
+    GDR_K_COUNT
+};
+
 namespace gdr {
+
+// no-ops unless gdr_profile_enable(1) was called: bracket one launch with HIP events on `st`
+void prof_begin(int kernel_id, hipStream_t st);
+void prof_end(int kernel_id, hipStream_t st);
+
+#define GDR_LAUNCH(KID, KERNEL, GRID, BLOCK, ST, ...)                     \
+    do {                                                                  \
+        ::gdr::prof_begin(KID, ST);                                       \
+        hipLaunchKernelGGL(KERNEL, GRID, BLOCK, 0, ST, __VA_ARGS__);      \
+        ::gdr::prof_end(KID, ST);                                         \
+    } while (0)
 
 struct View {  // camera constants, loaded once per kernel from device memory
     float view[16];

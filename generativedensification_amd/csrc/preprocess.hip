@@ -485,12 +485,12 @@ __global__ __launch_bounds__(GDR_BLOCK) void mark_visible_kernel(int N, const fl
 
 }  // namespace
 
-#define LAUNCH_DEG(KERNEL, deg, grid, st, ...)                                              \
+#define LAUNCH_DEG(KID, KERNEL, deg, grid, st, ...)                                          \
     switch (deg) {                                                                          \
-        case 0: hipLaunchKernelGGL(KERNEL<0>, dim3(grid), dim3(GDR_BLOCK), 0, st, __VA_ARGS__); break; \
-        case 1: hipLaunchKernelGGL(KERNEL<1>, dim3(grid), dim3(GDR_BLOCK), 0, st, __VA_ARGS__); break; \
-        case 2: hipLaunchKernelGGL(KERNEL<2>, dim3(grid), dim3(GDR_BLOCK), 0, st, __VA_ARGS__); break; \
-        default: hipLaunchKernelGGL(KERNEL<3>, dim3(grid), dim3(GDR_BLOCK), 0, st, __VA_ARGS__); break; \
+        case 0: GDR_LAUNCH(KID, KERNEL<0>, dim3(grid), dim3(GDR_BLOCK), st, __VA_ARGS__); break; \
+        case 1: GDR_LAUNCH(KID, KERNEL<1>, dim3(grid), dim3(GDR_BLOCK), st, __VA_ARGS__); break; \
+        case 2: GDR_LAUNCH(KID, KERNEL<2>, dim3(grid), dim3(GDR_BLOCK), st, __VA_ARGS__); break; \
+        default: GDR_LAUNCH(KID, KERNEL<3>, dim3(grid), dim3(GDR_BLOCK), st, __VA_ARGS__); break; \
     }
 
 hipError_t launch_preprocess_fwd(const gdr_settings* s, const gdr_inputs* in, const gdr_geom* g,
@@ -501,7 +501,7 @@ hipError_t launch_preprocess_fwd(const gdr_settings* s, const gdr_inputs* in, co
     const float focal_x = (float)W / (2.f * s->tanfovx), focal_y = (float)H / (2.f * s->tanfovy);
     const int grid = div_up(N, GDR_BLOCK);
     const int deg = in->shs ? s->sh_degree : 0;
-    LAUNCH_DEG(preprocess_fwd_kernel, deg, grid, st, N, in->M, in->means3D, in->scales,
+    LAUNCH_DEG(GDR_K_PREPROCESS_FWD, preprocess_fwd_kernel, deg, grid, st, N, in->M, in->means3D, in->scales,
                s->scale_modifier, in->rotations, in->opacities, in->shs, in->colors_precomp,
                in->cov3D_precomp, s->viewmatrix, s->projmatrix, s->campos, W, H, s->tanfovx,
                s->tanfovy, focal_x, focal_y, radii, g->depths, (float2*)g->xy,
@@ -519,7 +519,7 @@ hipError_t launch_preprocess_bwd(const gdr_settings* s, const gdr_inputs* in, co
     const int grid = div_up(N, GDR_BLOCK);
     const int deg = in->shs ? s->sh_degree : 0;
     const float* cov3D = in->cov3D_precomp ? in->cov3D_precomp : g->cov3D;
-    LAUNCH_DEG(preprocess_bwd_kernel, deg, grid, st, N, in->M, in->means3D, radii, in->shs,
+    LAUNCH_DEG(GDR_K_PREPROCESS_BWD, preprocess_bwd_kernel, deg, grid, st, N, in->M, in->means3D, radii, in->shs,
                g->clamped, in->scales, in->rotations, s->scale_modifier, cov3D,
                in->cov3D_precomp ? 1 : 0, in->colors_precomp ? 1 : 0, s->viewmatrix,
                s->projmatrix, s->campos, W, H, s->tanfovx, s->tanfovy, focal_x, focal_y,
@@ -532,7 +532,7 @@ hipError_t launch_preprocess_bwd(const gdr_settings* s, const gdr_inputs* in, co
 hipError_t launch_mark_visible(int N, const float* means3D, const float* view, uint8_t* present,
                                hipStream_t st) {
     if (N == 0) return hipSuccess;
-    hipLaunchKernelGGL(mark_visible_kernel, dim3(div_up(N, GDR_BLOCK)), dim3(GDR_BLOCK), 0, st, N,
+    GDR_LAUNCH(GDR_K_MARK_VISIBLE, mark_visible_kernel, dim3(div_up(N, GDR_BLOCK)), dim3(GDR_BLOCK), st, N,
                        means3D, view, present);
     return hipGetLastError();
 }

@@ -283,7 +283,7 @@ hipError_t launch_render_fwd(const gdr_settings* s, const gdr_geom* g, const gdr
     const int W = s->image_width, H = s->image_height;
     const int gx = tile_grid_x(W), gy = tile_grid_y(H);
     const int ntiles = gx * gy;
-    hipLaunchKernelGGL(render_fwd_kernel, dim3(ntiles), dim3(GDR_BLOCK), 0, st,
+    GDR_LAUNCH(GDR_K_RENDER_FWD, render_fwd_kernel, dim3(ntiles), dim3(GDR_BLOCK), st,
                        (const uint2*)img->ranges, bin->values[bin->sorted], W, H, gx, ntiles,
                        (const float2*)g->xy, (const float4*)g->conic_opacity, (const float4*)g->rgb,
                        s->bg, img->final_T, img->n_contrib, out->color, out->depth, out->alpha);
@@ -296,7 +296,7 @@ hipError_t launch_render_bwd(const gdr_settings* s, const gdr_geom* g, const gdr
     const int W = s->image_width, H = s->image_height;
     const int gx = tile_grid_x(W), gy = tile_grid_y(H);
     const int ntiles = gx * gy;
-    hipLaunchKernelGGL(render_bwd_kernel, dim3(ntiles), dim3(GDR_BLOCK), 0, st,
+    GDR_LAUNCH(GDR_K_RENDER_BWD, render_bwd_kernel, dim3(ntiles), dim3(GDR_BLOCK), st,
                        (const uint2*)img->ranges, bin->values[bin->sorted], W, H, gx, ntiles, s->bg,
                        (const float2*)g->xy, (const float4*)g->conic_opacity, (const float4*)g->rgb,
                        img->final_T, img->n_contrib, gi->dL_dcolor, gi->dL_ddepth, gi->dL_dalpha,

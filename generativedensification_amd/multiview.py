@@ -1,0 +1,82 @@
+"""View-sharded rendering of one Gaussian set.
+
+The reference renders target views in a serial Python loop per sample
+(/root/reference/lightning/network.py:826-838, 848-856, 964-972) and shards only by
+scene (DDP, train_lightning.py:71-75).  Views are independent given the Gaussians, so
+here rank g of G renders views [g*V/G, (g+1)*V/G): no data-path collective; the only
+exchange is an all-gather of the V per-view losses (V floats over RCCL/xGMI; gloo on
+CPU in tests) and, for a real training step on shared Gaussians, a sum of the packed
+attribute gradients (`allreduce_gaussian_grads`).
+"""
+from __future__ import annotations
+
+from typing import Callable, Sequence
+
+import torch
+import torch.distributed as dist
+
+
+def shard_views(n_views: int, rank: int, world: int) -> range:
+    """Contiguous block partition; the first (n_views % world) ranks get one extra view."""
+    base, extra = divmod(n_views, world)
+    lo = rank * base + min(rank, extra)
+    return range(lo, lo + base + (1 if rank < extra else 0))
+
+
+def render_views(renderer, cams: Sequence, bg_colors, gaussians: dict, device, prex: str = "",
+                 screenspace_points=None):
+    """One `render_img` per camera (same call the reference loop makes); bg_colors may be
+    None (keep the renderer's), one tensor, or one per view (network.py:829-830)."""
+    outs = []
+    for j, cam in enumerate(cams):
+        if bg_colors is not None:
+            renderer.set_bg_color(bg_colors[j] if isinstance(bg_colors, (list, tuple)) else bg_colors)
+        outs.append(renderer.render_img(cam, None, gaussians["centers"], gaussians["shs"], gaussians["opacity"],
+                                        gaussians["scales"], gaussians["rotations"], device, prex=prex,
+                                        screenspace_points=screenspace_points))
+    return outs
+
+
+def gather_view_losses(local_losses: torch.Tensor, n_views: int | None = None) -> torch.Tensor:
+    """All-gather of per-view scalar losses in global view order.  Uneven shards are padded
+    to the largest shard with NaN and stripped again."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return local_losses
+    world = dist.get_world_size()
+    n_local = torch.tensor([local_losses.numel()], device=local_losses.device, dtype=torch.int64)
+    if n_views is None:
+        sizes = [torch.zeros_like(n_local) for _ in range(world)]
+        dist.all_gather(sizes, n_local)
+        sizes = [int(s) for s in sizes]
+    else:
+        sizes = [len(shard_views(n_views, r, world)) for r in range(world)]
+    m = max(sizes)
+    pad = torch.full((m,), float("nan"), device=local_losses.device, dtype=local_losses.dtype)
+    pad[: local_losses.numel()] = local_losses
+    out = torch.empty(world * m, device=local_losses.device, dtype=local_losses.dtype)
+    dist.all_gather_into_tensor(out, pad)
+    return torch.cat([out[r * m: r * m + sizes[r]] for r in range(world)])
+
+
+def allreduce_gaussian_grads(params: Sequence[torch.Tensor]) -> None:
+    """Sum the per-Gaussian attribute gradients over ranks: one packed buffer
+    (236 B/Gaussian at SH degree 3) moved as reduce-scatter + all-gather so that all
+    7 xGMI links of a GPU carry 1/G of it each, instead of a per-tensor ring all-reduce."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return
+    world = dist.get_world_size()
+    grads = [p.grad for p in params if p.grad is not None]
+    if not grads:
+        return
+    flat = torch.cat([g.reshape(-1) for g in grads])
+    n = flat.numel()
+    padded = (n + world - 1) // world * world
+    if padded != n:
+        flat = torch.cat([flat, flat.new_zeros(padded - n)])
+    shard = torch.empty(padded // world, device=flat.device, dtype=flat.dtype)
+    dist.reduce_scatter_tensor(shard, flat, op=dist.ReduceOp.SUM)
+    dist.all_gather_into_tensor(flat, shard)
+    off = 0
+    for g in grads:
+        g.copy_(flat[off: off + g.numel()].view_as(g))
+        off += g.numel()

@@ -185,6 +185,16 @@ int gdr_backward(const gdr_settings* s, const gdr_inputs* in, const gdr_geom* ge
 int gdr_mark_visible(int32_t N, const float* means3D, const float* viewmatrix,
                      const float* projmatrix, uint8_t* present, void* stream);
 
+/* ---- opt-in per-kernel timing (measurement aid, bench.py `roofline`) -----------------
+ * When enabled every kernel launch is bracketed by two HIP events recorded on the SAME
+ * stream the kernel runs on; gdr_profile_collect waits for them and returns, per kernel id
+ * (0 <= id < gdr_kernel_count(), names from gdr_kernel_name), the summed elapsed ms and the
+ * launch count since the last reset.  Process-wide switch; off by default (no events). */
+int gdr_profile_enable(int on);
+int gdr_profile_collect(double* ms_total, uint64_t* launches, int32_t n, int32_t reset);
+int gdr_kernel_count(void);
+const char* gdr_kernel_name(int32_t id);
+
 #ifdef __cplusplus
 }
 #endif

@@ -170,10 +170,14 @@ void oracle_preprocess_fwd(int N, int deg, int M, const real* means3D, const rea
                            const real* view, const real* proj, const real* campos, int W, int H,
                            real tan_fovx, real tan_fovy, int prefiltered, int32_t* radii, real* xy,
                            real* depths, real* cov3D, real* rgb, real* conic_opacity,
-                           uint32_t* tiles_touched, int32_t* rect, uint8_t* clamped) {
+                           uint32_t* tiles_touched, int32_t* rect, uint8_t* clamped, int nthreads) {
+    (void)nthreads;
     (void)prefiltered; /* A.1-1: no x/y frustum test when prefiltered=False (always, renderer.py:122) */
     const int gx = (W + BLOCK_X - 1) / BLOCK_X, gy = (H + BLOCK_Y - 1) / BLOCK_Y;
     const real focal_x = (real)W / (RC(2) * tan_fovx), focal_y = (real)H / (RC(2) * tan_fovy);
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(nthreads > 0 ? nthreads : 1)
+#endif
     for (int i = 0; i < N; ++i) {
         radii[i] = 0;
         tiles_touched[i] = 0;

@@ -132,7 +132,8 @@ class Oracle:
             self.creal(float(s.scale_modifier)), _p(ro), _p(opac), _p(shs_a), _p(cp), _p(c3),
             _p(view), _p(proj), _p(campos), C.c_int(W), C.c_int(H), self.creal(float(s.tanfovx)),
             self.creal(float(s.tanfovy)), C.c_int(int(bool(s.prefiltered))), _p(radii), _p(xy),
-            _p(depths), _p(cov3D), _p(rgb), _p(conic_opacity), _p(tiles), _p(rect), _p(clamped))
+            _p(depths), _p(cov3D), _p(rgb), _p(conic_opacity), _p(tiles), _p(rect), _p(clamped),
+            C.c_int(self.nthreads))
         if c3 is not None:
             cov3D = c3
         offsets = np.zeros(N, np.uint32)
