@@ -18,6 +18,8 @@
 //     skipped with a single ballot; |.| of the mean2D terms is taken per pixel BEFORE
 //     the cross-lane reduction (AbsGS semantics).
 //   * blockIdx -> tile mapping is XCD-aware (consecutive tiles share an XCD's L2).
+#include <stdlib.h>
+
 #include "gdr_common.h"
 
 namespace gdr {
@@ -276,13 +278,336 @@ __global__ __launch_bounds__(GDR_BLOCK) void render_bwd_kernel(
     }
 }
 
+
+// =================================================================================
+// v2 kernels: sub-tile culling.  Each wave owns an 8x8 pixel sub-tile of the 16x16 tile.
+// While a 256-entry slice of the tile's sorted list sits in LDS, every lane tests ONE
+// entry's alpha >= 1/255 bounding box against the wave's sub-tile (4 ballots cover the
+// slice); only the surviving entries are evaluated, in list order, via a scalar
+// find-first-set loop over the 64-bit masks.  The test is conservative (exact bbox of the
+// alpha >= 1/255 ellipse, widened), so results — including n_contrib, which stays the
+// 1-based position in the FULL tile list — are identical to evaluating every entry.
+// The conic is pre-multiplied by log2(e) when staged so that G = v_exp_f32(power) with no
+// range reduction; forward and backward stage identically => identical skip decisions.
+// The next slice is fetched into registers while the current one is being composited.
+// =================================================================================
+#define GDR_LOG2E 1.4426950408889634f
+#define GDR_LN2 0.6931471805599453f
+
+struct Staged {
+    float2 xy, ext;
+    float4 co, cd;
+};
+
+// conservative half-extent (pixels) of {alpha >= 1/255} for conic (cx,cy,cz) and opacity o
+__device__ __forceinline__ float2 alpha_extent(const float4 co) {
+    const float t = 255.f * co.w;
+    if (!(t > 1.f)) return make_float2(-1.f, -1.f);  // alpha <= o < 1/255 everywhere (also NaN)
+    const float det = co.x * co.z - co.y * co.y;
+    if (!(det > 0.f)) return make_float2(1e30f, 1e30f);  // degenerate: never cull
+    const float tau2 = 2.f * __logf(t) / det;            // 2 ln(255 o) / det(conic)
+    return make_float2(sqrtf(tau2 * co.z) * 1.002f + 0.02f, sqrtf(tau2 * co.x) * 1.002f + 0.02f);
+}
+
+__device__ __forceinline__ Staged stage_entry(float2 xy, float4 co, float4 cd) {
+    Staged s;
+    s.xy = xy;
+    s.ext = alpha_extent(co);
+    s.co = make_float4(co.x * GDR_LOG2E, co.y * GDR_LOG2E, co.z * GDR_LOG2E, co.w);
+    s.cd = cd;
+    return s;
+}
+
+__device__ __forceinline__ uint64_t cull_mask(const float2* s_xy, const float2* s_ext, int e, float X0,
+                                              float X1, float Y0, float Y1) {
+    const float2 m = s_xy[e];
+    const float2 h = s_ext[e];
+    const bool ov = (h.x >= 0.f) && (m.x + h.x >= X0) && (m.x - h.x <= X1) && (m.y + h.y >= Y0) &&
+                    (m.y - h.y <= Y1);
+    return __ballot(ov);
+}
+
+__global__ __launch_bounds__(GDR_BLOCK) void render_fwd_v2_kernel(
+    const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int gx,
+    int ntiles, const float2* __restrict__ xy, const float4* __restrict__ conic_opacity,
+    const float4* __restrict__ rgbd, const float* __restrict__ bg, float* __restrict__ final_T,
+    uint32_t* __restrict__ n_contrib, float* __restrict__ out_color, float* __restrict__ out_depth,
+    float* __restrict__ out_alpha) {
+    __shared__ float2 s_xy[GDR_BLOCK];
+    __shared__ float2 s_ext[GDR_BLOCK];
+    __shared__ float4 s_co[GDR_BLOCK];
+    __shared__ float4 s_cd[GDR_BLOCK];
+    __shared__ int s_done[GDR_BLOCK / GDR_WAVE];
+
+    const uint32_t tile = xcd_remap(blockIdx.x, (uint32_t)ntiles);
+    const int tx = (int)(tile % (uint32_t)gx), ty = (int)(tile / (uint32_t)gx);
+    const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
+    const int sx0 = tx * GDR_TILE + (int)(wave & 1u) * 8, sy0 = ty * GDR_TILE + (int)(wave >> 1) * 8;
+    const int px = sx0 + (int)(lane & 7u), py = sy0 + (int)(lane >> 3);
+    const bool inside = px < W && py < H;
+    const float pxf = (float)px, pyf = (float)py;
+    const float X0 = (float)sx0, X1 = (float)(sx0 + 7), Y0 = (float)sy0, Y1 = (float)(sy0 + 7);
+    const uint2 range = ranges[tile];
+    const int total = (int)(range.y - range.x);
+    const int rounds = (total + GDR_BLOCK - 1) / GDR_BLOCK;
+
+    bool done = !inside;
+    float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f, Wt = 0.f;
+    uint32_t last_contributor = 0;
+
+    float2 r_xy = make_float2(0.f, 0.f);
+    float4 r_co = make_float4(0.f, 0.f, 0.f, 0.f), r_cd = r_co;
+    bool r_valid = (int)threadIdx.x < total;
+    if (r_valid) {
+        const uint32_t id = point_list[range.x + threadIdx.x];
+        r_xy = xy[id]; r_co = conic_opacity[id]; r_cd = rgbd[id];
+    }
+    for (int r = 0; r < rounds; ++r) {
+        const bool wave_done = __ballot(!done) == 0ull;
+        if (lane == 0) s_done[wave] = wave_done ? 1 : 0;
+        __syncthreads();
+        if (s_done[0] + s_done[1] + s_done[2] + s_done[3] == GDR_BLOCK / GDR_WAVE) break;
+        if (r_valid) {
+            const Staged st = stage_entry(r_xy, r_co, r_cd);
+            s_xy[threadIdx.x] = st.xy; s_ext[threadIdx.x] = st.ext;
+            s_co[threadIdx.x] = st.co; s_cd[threadIdx.x] = st.cd;
+        } else {
+            s_ext[threadIdx.x] = make_float2(-1.f, -1.f);
+            s_xy[threadIdx.x] = make_float2(0.f, 0.f);
+        }
+        __syncthreads();
+        {   // prefetch the next slice (lands while this one is composited)
+            const int nxt = (r + 1) * GDR_BLOCK + (int)threadIdx.x;
+            r_valid = nxt < total;
+            if (r_valid) {
+                const uint32_t id = point_list[range.x + nxt];
+                r_xy = xy[id]; r_co = conic_opacity[id]; r_cd = rgbd[id];
+            }
+        }
+        if (wave_done) continue;
+        const uint32_t base = (uint32_t)(r * GDR_BLOCK);
+#pragma unroll 1
+        for (int g = 0; g < GDR_BLOCK / GDR_WAVE; ++g) {
+            uint64_t mask = cull_mask(s_xy, s_ext, g * GDR_WAVE + (int)lane, X0, X1, Y0, Y1);
+            while (mask) {
+                const int e = g * GDR_WAVE + __builtin_ctzll(mask);
+                mask &= mask - 1ull;
+                const float2 m = s_xy[e];
+                const float4 co = s_co[e];
+                const float dx = m.x - pxf, dy = m.y - pyf;
+                const float p2 = gauss_power(dx, dy, co.x, co.y, co.z);
+                const float alpha = fminf(0.99f, co.w * __builtin_amdgcn_exp2f(p2));
+                const bool c = !done && !(p2 > 0.f) && !(alpha < (1.f / 255.f));
+                if (__ballot(c) == 0ull) continue;
+                const float test_T = T * (1.f - alpha);
+                const bool stop = c && (test_T < 0.0001f);
+                done = done || stop;
+                const bool acc = c && !stop;
+                const float4 cd = s_cd[e];
+                const float w = acc ? alpha * T : 0.f;
+                C0 = fmaf(cd.x, w, C0);
+                C1 = fmaf(cd.y, w, C1);
+                C2 = fmaf(cd.z, w, C2);
+                Dp = fmaf(cd.w, w, Dp);
+                Wt += w;
+                T = acc ? test_T : T;
+                last_contributor = acc ? base + (uint32_t)e + 1u : last_contributor;
+                if (__ballot(!done) == 0ull) { mask = 0ull; g = GDR_BLOCK / GDR_WAVE; }
+            }
+        }
+    }
+    if (inside) {
+        const size_t pix = (size_t)py * W + px, P = (size_t)H * W;
+        final_T[pix] = T;
+        n_contrib[pix] = last_contributor;
+        out_color[pix] = fmaf(T, bg[0], C0);
+        out_color[P + pix] = fmaf(T, bg[1], C1);
+        out_color[2 * P + pix] = fmaf(T, bg[2], C2);
+        out_depth[pix] = Dp;
+        out_alpha[pix] = Wt;
+    }
+}
+
+#define GDR_ACC_STRIDE 13  // 12 partial gradients + touched flag; odd stride: conflict-free per-thread rows
+
+__global__ __launch_bounds__(GDR_BLOCK) void render_bwd_v2_kernel(
+    const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int gx,
+    int ntiles, const float* __restrict__ bg, const float2* __restrict__ xy,
+    const float4* __restrict__ conic_opacity, const float4* __restrict__ rgbd,
+    const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
+    const float* __restrict__ dL_dpix, const float* __restrict__ dL_ddepthpix,
+    const float* __restrict__ dL_dalphapix, float* __restrict__ dL_dmean2D,
+    float* __restrict__ scratch, float* __restrict__ dL_dopacity) {
+    __shared__ float2 s_xy[GDR_BLOCK];
+    __shared__ float2 s_ext[GDR_BLOCK];
+    __shared__ float4 s_co[GDR_BLOCK];
+    __shared__ float4 s_cd[GDR_BLOCK];
+    __shared__ uint32_t s_id[GDR_BLOCK];
+    __shared__ float s_acc[GDR_BLOCK * GDR_ACC_STRIDE];
+
+    const uint32_t tile = xcd_remap(blockIdx.x, (uint32_t)ntiles);
+    const int tx = (int)(tile % (uint32_t)gx), ty = (int)(tile / (uint32_t)gx);
+    const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
+    const int sx0 = tx * GDR_TILE + (int)(wave & 1u) * 8, sy0 = ty * GDR_TILE + (int)(wave >> 1) * 8;
+    const int px = sx0 + (int)(lane & 7u), py = sy0 + (int)(lane >> 3);
+    const bool inside = px < W && py < H;
+    const float pxf = (float)px, pyf = (float)py;
+    const float X0 = (float)sx0, X1 = (float)(sx0 + 7), Y0 = (float)sy0, Y1 = (float)(sy0 + 7);
+    const size_t pix = (size_t)py * W + px, P = (size_t)H * W;
+    const uint2 range = ranges[tile];
+    const int total = (int)(range.y - range.x);
+    const int rounds = (total + GDR_BLOCK - 1) / GDR_BLOCK;
+
+    const float T_final = inside ? final_T[pix] : 0.f;
+    float T = T_final;
+    const int last_contributor = inside ? (int)n_contrib[pix] : 0;
+    float gC0 = 0.f, gC1 = 0.f, gC2 = 0.f, gD = 0.f, gA = 0.f;
+    if (inside) {
+        gC0 = dL_dpix[pix]; gC1 = dL_dpix[P + pix]; gC2 = dL_dpix[2 * P + pix];
+        if (dL_ddepthpix) gD = dL_ddepthpix[pix];
+        if (dL_dalphapix) gA = dL_dalphapix[pix];
+    }
+    const float bg_dot = (bg[0] * gC0 + bg[1] * gC1) + bg[2] * gC2;
+    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, accD = 0.f, accA = 0.f;
+    float last_alpha = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f, last_depth = 0.f;
+    // the staged conic is log2(e) x the true one: fold 1/log2(e) = ln 2 into the pixel->NDC factors
+    const float kx = 0.5f * (float)W * GDR_LN2, ky = 0.5f * (float)H * GDR_LN2;
+
+    int wave_last = last_contributor;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) wave_last = max(wave_last, __shfl_xor(wave_last, off, 64));
+
+    for (int k = 0; k < GDR_ACC_STRIDE; ++k) s_acc[threadIdx.x * GDR_ACC_STRIDE + k] = 0.f;
+
+    // slice r holds list positions total-1-(r*256+e), e = 0..255: back to front
+    float2 r_xy = make_float2(0.f, 0.f);
+    float4 r_co = make_float4(0.f, 0.f, 0.f, 0.f), r_cd = r_co;
+    uint32_t r_id = 0;
+    bool r_valid = (int)threadIdx.x < total;
+    if (r_valid) {
+        r_id = point_list[range.y - 1 - threadIdx.x];
+        r_xy = xy[r_id]; r_co = conic_opacity[r_id]; r_cd = rgbd[r_id];
+    }
+    for (int r = 0; r <= rounds; ++r) {
+        __syncthreads();  // every wave finished the previous slice: its accumulators are complete
+        if (r > 0) {      // flush my entry of the previous slice: one coalesced atomic pass
+            float* a = s_acc + threadIdx.x * GDR_ACC_STRIDE;
+            if (a[12] != 0.f) {
+                const uint32_t id = s_id[threadIdx.x];
+                float* m2 = dL_dmean2D + 4 * (size_t)id;
+                float* sc = scratch + 8 * (size_t)id;
+                atomicAdd(m2 + 0, a[0]); atomicAdd(m2 + 1, a[1]); atomicAdd(m2 + 2, a[2]); atomicAdd(m2 + 3, a[3]);
+                atomicAdd(sc + 0, a[4]); atomicAdd(sc + 1, a[5]); atomicAdd(sc + 2, a[6]); atomicAdd(sc + 3, a[7]);
+                atomicAdd(sc + 4, a[8]); atomicAdd(sc + 5, a[9]); atomicAdd(sc + 6, a[10]);
+                atomicAdd(dL_dopacity + id, a[11]);
+#pragma unroll
+                for (int k = 0; k < GDR_ACC_STRIDE; ++k) a[k] = 0.f;
+            }
+        }
+        if (r == rounds) break;
+        if (r_valid) {
+            const Staged st = stage_entry(r_xy, r_co, r_cd);
+            s_xy[threadIdx.x] = st.xy; s_ext[threadIdx.x] = st.ext;
+            s_co[threadIdx.x] = st.co; s_cd[threadIdx.x] = st.cd;
+            s_id[threadIdx.x] = r_id;
+        } else {
+            s_ext[threadIdx.x] = make_float2(-1.f, -1.f);
+            s_xy[threadIdx.x] = make_float2(0.f, 0.f);
+        }
+        __syncthreads();
+        {
+            const int nxt = (r + 1) * GDR_BLOCK + (int)threadIdx.x;
+            r_valid = nxt < total;
+            if (r_valid) {
+                r_id = point_list[range.y - 1 - nxt];
+                r_xy = xy[r_id]; r_co = conic_opacity[r_id]; r_cd = rgbd[r_id];
+            }
+        }
+        // list position of LDS entry e in this slice: pos = top - e
+        const int top = total - 1 - r * GDR_BLOCK;
+        if (top - (GDR_BLOCK - 1) >= wave_last) continue;  // whole slice behind every pixel's last contributor
+#pragma unroll 1
+        for (int g = 0; g < GDR_BLOCK / GDR_WAVE; ++g) {
+            uint64_t mask = cull_mask(s_xy, s_ext, g * GDR_WAVE + (int)lane, X0, X1, Y0, Y1);
+            while (mask) {
+                const int e = g * GDR_WAVE + __builtin_ctzll(mask);
+                mask &= mask - 1ull;
+                const int pos = top - e;
+                const float2 m = s_xy[e];
+                const float4 co = s_co[e];
+                const float dx = m.x - pxf, dy = m.y - pyf;
+                const float p2 = gauss_power(dx, dy, co.x, co.y, co.z);
+                const float G = __builtin_amdgcn_exp2f(p2);
+                const float alpha = fminf(0.99f, co.w * G);
+                const bool hit = (pos < last_contributor) && !(p2 > 0.f) && !(alpha < (1.f / 255.f));
+                if (__ballot(hit) == 0ull) continue;
+                const float4 cd = s_cd[e];
+                const float oma = 1.f - alpha;
+                const float Tn = T / oma;
+                const float w = hit ? alpha * Tn : 0.f;
+                const float n0 = last_alpha * lc0 + (1.f - last_alpha) * acc0;
+                const float n1 = last_alpha * lc1 + (1.f - last_alpha) * acc1;
+                const float n2 = last_alpha * lc2 + (1.f - last_alpha) * acc2;
+                const float nD = last_alpha * last_depth + (1.f - last_alpha) * accD;
+                const float nA = last_alpha + (1.f - last_alpha) * accA;
+                float dL_dalpha = (cd.x - n0) * gC0 + (cd.y - n1) * gC1 + (cd.z - n2) * gC2;
+                dL_dalpha += (cd.w - nD) * gD;
+                dL_dalpha += (1.f - nA) * gA;
+                dL_dalpha *= Tn;
+                dL_dalpha += (-T_final / oma) * bg_dot;
+                dL_dalpha = hit ? dL_dalpha : 0.f;
+                if (hit) {
+                    T = Tn; acc0 = n0; acc1 = n1; acc2 = n2; accD = nD; accA = nA;
+                    lc0 = cd.x; lc1 = cd.y; lc2 = cd.z; last_depth = cd.w; last_alpha = alpha;
+                }
+                const float dL_dG = co.w * dL_dalpha;
+                const float gdx = G * dx, gdy = G * dy;
+                // co.xyz carry the log2(e) factor; kx, ky carry its inverse
+                float v_mx = dL_dG * (-gdx * co.x - gdy * co.y) * kx;
+                float v_my = dL_dG * (-gdy * co.z - gdx * co.y) * ky;
+                float v_ax = fabsf(v_mx), v_ay = fabsf(v_my);
+                float v_cx = -0.5f * gdx * dx * dL_dG;
+                float v_cy = -gdx * dy * dL_dG;
+                float v_cz = -0.5f * gdy * dy * dL_dG;
+                float v_dd = w * gD, v_r = w * gC0, v_g = w * gC1, v_b = w * gC2;
+                float v_o = G * dL_dalpha;
+                v_mx = wave_sum_to_lane63(v_mx); v_my = wave_sum_to_lane63(v_my);
+                v_ax = wave_sum_to_lane63(v_ax); v_ay = wave_sum_to_lane63(v_ay);
+                v_cx = wave_sum_to_lane63(v_cx); v_cy = wave_sum_to_lane63(v_cy);
+                v_cz = wave_sum_to_lane63(v_cz); v_dd = wave_sum_to_lane63(v_dd);
+                v_r = wave_sum_to_lane63(v_r);   v_g = wave_sum_to_lane63(v_g);
+                v_b = wave_sum_to_lane63(v_b);   v_o = wave_sum_to_lane63(v_o);
+                if (lane == 63) {
+                    float* a = s_acc + e * GDR_ACC_STRIDE;
+                    atomicAdd(a + 0, v_mx); atomicAdd(a + 1, v_my); atomicAdd(a + 2, v_ax); atomicAdd(a + 3, v_ay);
+                    atomicAdd(a + 4, v_cx); atomicAdd(a + 5, v_cy); atomicAdd(a + 6, v_cz); atomicAdd(a + 7, v_dd);
+                    atomicAdd(a + 8, v_r);  atomicAdd(a + 9, v_g);  atomicAdd(a + 10, v_b); atomicAdd(a + 11, v_o);
+                    a[12] = 1.f;
+                }
+            }
+        }
+    }
+}
+
 }  // namespace
+
+// GDR_RENDER_V1=1 selects the un-culled reference kernels (A/B measurements only)
+static bool render_v1() {
+    static const bool v = [] { const char* e = getenv("GDR_RENDER_V1"); return e && e[0] == '1'; }();
+    return v;
+}
 
 hipError_t launch_render_fwd(const gdr_settings* s, const gdr_geom* g, const gdr_binning* bin,
                              const gdr_image* img, const gdr_outputs* out, hipStream_t st) {
     const int W = s->image_width, H = s->image_height;
     const int gx = tile_grid_x(W), gy = tile_grid_y(H);
     const int ntiles = gx * gy;
+    if (!render_v1())
+        GDR_LAUNCH(GDR_K_RENDER_FWD, render_fwd_v2_kernel, dim3(ntiles), dim3(GDR_BLOCK), st,
+                   (const uint2*)img->ranges, bin->values[bin->sorted], W, H, gx, ntiles,
+                   (const float2*)g->xy, (const float4*)g->conic_opacity, (const float4*)g->rgb,
+                   s->bg, img->final_T, img->n_contrib, out->color, out->depth, out->alpha);
+    else
     GDR_LAUNCH(GDR_K_RENDER_FWD, render_fwd_kernel, dim3(ntiles), dim3(GDR_BLOCK), st,
                        (const uint2*)img->ranges, bin->values[bin->sorted], W, H, gx, ntiles,
                        (const float2*)g->xy, (const float4*)g->conic_opacity, (const float4*)g->rgb,
@@ -296,6 +621,13 @@ hipError_t launch_render_bwd(const gdr_settings* s, const gdr_geom* g, const gdr
     const int W = s->image_width, H = s->image_height;
     const int gx = tile_grid_x(W), gy = tile_grid_y(H);
     const int ntiles = gx * gy;
+    if (!render_v1())
+        GDR_LAUNCH(GDR_K_RENDER_BWD, render_bwd_v2_kernel, dim3(ntiles), dim3(GDR_BLOCK), st,
+                   (const uint2*)img->ranges, bin->values[bin->sorted], W, H, gx, ntiles, s->bg,
+                   (const float2*)g->xy, (const float4*)g->conic_opacity, (const float4*)g->rgb,
+                   img->final_T, img->n_contrib, gi->dL_dcolor, gi->dL_ddepth, gi->dL_dalpha,
+                   go->dL_dmeans2D, go->scratch, go->dL_dopacities);
+    else
     GDR_LAUNCH(GDR_K_RENDER_BWD, render_bwd_kernel, dim3(ntiles), dim3(GDR_BLOCK), st,
                        (const uint2*)img->ranges, bin->values[bin->sorted], W, H, gx, ntiles, s->bg,
                        (const float2*)g->xy, (const float4*)g->conic_opacity, (const float4*)g->rgb,
