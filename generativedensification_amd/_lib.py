@@ -12,7 +12,8 @@ import os
 import torch  # noqa: F401  (loads the HIP runtime first — see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libgdr_hip.so")
+# GDR_LIB_PATH: developer override (ablation builds); the product default is the in-tree library
+LIB_PATH = os.environ.get("GDR_LIB_PATH") or os.path.join(_HERE, "lib", "libgdr_hip.so")
 
 GDR_OK = 0
 GDR_ERR_WORKSPACE = -4
