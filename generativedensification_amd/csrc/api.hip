@@ -262,10 +262,8 @@ int gdr_backward(const gdr_settings* s, const gdr_inputs* in, const gdr_geom* ge
     hipStream_t st = (hipStream_t)stream;
     const size_t N = (size_t)in->N;
     if (N == 0) return GDR_OK;
-    hipError_t e = hipMemsetAsync(gout->dL_dmeans2D, 0, N * 4 * sizeof(float), st);
-    if (e == hipSuccess) e = hipMemsetAsync(gout->scratch, 0, N * 8 * sizeof(float), st);
-    if (e == hipSuccess) e = hipMemsetAsync(gout->dL_dopacities, 0, N * sizeof(float), st);
-    if (e != hipSuccess) return hip_fail("memset grads", e);
+    hipError_t e = hipMemsetAsync(gout->scratch, 0, N * 16 * sizeof(float), st);
+    if (e != hipSuccess) return hip_fail("memset gradient records", e);
     e = launch_render_bwd(s, geom, bin, img, gin, gout, st);
     if (e != hipSuccess) return hip_fail("render_bwd", e);
     if ((rc = debug_sync(s, "render_bwd", st))) return rc;

@@ -300,8 +300,10 @@ __global__ __launch_bounds__(GDR_BLOCK) void preprocess_fwd_kernel(
 
 // ---------------------------------------------------------------------------------
 // K8 + K9 fused: one pass over the Gaussians.
-// scratch layout per Gaussian (8 floats): dL/dconic.x, .y, .z (true partials), dL/ddepth,
-//                                         dL/dcolour r, g, b, pad
+// grad_rec layout per Gaussian (16 floats = one 64-byte line, accumulated by K7):
+//   [0..3] dL/dmean2D x, y (signed, NDC units), sum|x-term|, sum|y-term|
+//   [4..6] dL/dconic.x, .y, .z (true partials)   [7] dL/ddepth
+//   [8..10] dL/dcolour r, g, b                   [11] dL/dopacity     [12..15] unused
 // ---------------------------------------------------------------------------------
 template <int DEG>
 __global__ __launch_bounds__(GDR_BLOCK) void preprocess_bwd_kernel(
@@ -311,8 +313,8 @@ __global__ __launch_bounds__(GDR_BLOCK) void preprocess_bwd_kernel(
     const float* __restrict__ cov3D, int cov_precomp, int colors_precomp,
     const float* __restrict__ view, const float* __restrict__ proj,
     const float* __restrict__ campos, int W, int H, float tanx, float tany, float focal_x,
-    float focal_y, const float4* __restrict__ dL_dmean2D, const float4* __restrict__ scratch,
-    float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dcov3D, float* __restrict__ dL_dsh,
+    float focal_y, const float4* __restrict__ grad_rec, float4* __restrict__ dL_dmean2D,
+    float* __restrict__ dL_dopacity, float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dcov3D, float* __restrict__ dL_dsh,
     float* __restrict__ dL_dcolors, float* __restrict__ dL_dscale, float4* __restrict__ dL_drot) {
     Cam cam;
     load_cam(cam, view, proj, campos);
@@ -328,9 +330,11 @@ __global__ __launch_bounds__(GDR_BLOCK) void preprocess_bwd_kernel(
 
     if (vis) {
         const float px_ = means3D[3 * i], py_ = means3D[3 * i + 1], pz_ = means3D[3 * i + 2];
-        const float4 gconic = scratch[2 * i];      // conic.xyz, ddepth
-        const float4 gcolor = scratch[2 * i + 1];  // rgb, pad
-        const float4 g2 = dL_dmean2D[i];
+        const float4 g2 = grad_rec[4 * i];          // mean2D x, y, |x|, |y|
+        const float4 gconic = grad_rec[4 * i + 1];  // conic.xyz, ddepth
+        const float4 gcolor = grad_rec[4 * i + 2];  // rgb, opacity
+        dL_dmean2D[i] = g2;
+        dL_dopacity[i] = gcolor.w;
         float c6[6];
 #pragma unroll
         for (int k = 0; k < 6; ++k) c6[k] = cov3D[6 * i + k];
@@ -453,6 +457,8 @@ __global__ __launch_bounds__(GDR_BLOCK) void preprocess_bwd_kernel(
 #undef G_
         }
     } else {
+        dL_dmean2D[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        dL_dopacity[i] = 0.f;
         if (dsh)
             for (int k = 0; k < 3 * M; ++k) dsh[k] = 0.f;
         if (colors_precomp && dL_dcolors) {
@@ -523,7 +529,7 @@ hipError_t launch_preprocess_bwd(const gdr_settings* s, const gdr_inputs* in, co
                g->clamped, in->scales, in->rotations, s->scale_modifier, cov3D,
                in->cov3D_precomp ? 1 : 0, in->colors_precomp ? 1 : 0, s->viewmatrix,
                s->projmatrix, s->campos, W, H, s->tanfovx, s->tanfovy, focal_x, focal_y,
-               (const float4*)go->dL_dmeans2D, (const float4*)go->scratch, go->dL_dmeans3D,
+               (const float4*)go->scratch, (float4*)go->dL_dmeans2D, go->dL_dopacities, go->dL_dmeans3D,
                go->dL_dcov3D, go->dL_dshs, go->dL_dcolors, go->dL_dscales,
                (float4*)go->dL_drotations);
     return hipGetLastError();

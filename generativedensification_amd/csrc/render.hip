@@ -6,17 +6,18 @@
 // /root/reference/lightning/network.py:867-878.
 //
 // CDNA4 mapping (not the 32-wide warp layout of the CUDA lineage):
-//   * one workgroup = one 16x16 tile = 4 wavefronts; wave w owns pixel rows 4w..4w+3;
-//   * the tile's Gaussian slice is staged 256 entries at a time in LDS as three SoA
-//     arrays (xy, conic+opacity, rgb+depth = 40 B/entry) and read back with broadcast
-//     ds_read_b64/b128 (all 64 lanes read the same entry: no bank conflicts);
-//   * early-out is per WAVE via 64-bit ballots: a wave whose 64 pixels are saturated
-//     stops issuing LDS reads; the workgroup stops when all four waves are done;
-//   * backward: the 12 per-Gaussian partial gradients are reduced across the 64 lanes
-//     with DPP row operations (6 steps) and ONE lane issues the global float atomics
-//     (64x fewer atomics than one per pixel); Gaussians no lane of the wave touches are
-//     skipped with a single ballot; |.| of the mean2D terms is taken per pixel BEFORE
-//     the cross-lane reduction (AbsGS semantics).
+//   * one workgroup = one 16x16 tile = 4 wavefronts; a wave owns an 8x8 sub-tile and each
+//     of its four 16-lane DPP rows composites its OWN 4x4 pixel block;
+//   * the tile's Gaussian slice is staged 256 entries at a time in LDS (xy, alpha-extent,
+//     conic*log2e + opacity, rgb + depth = 48 B/entry) while the next slice is already being
+//     fetched into registers; every lane tests ONE staged entry against the four blocks and
+//     four 64-bit ballots give each block its culled sub-list (masks live in SGPRs);
+//   * the inner loop is branch-free/predicated; G = v_exp_f32 on a conic pre-scaled by
+//     log2(e); early-out is per block (row) and per wave via ballots;
+//   * backward: the 12 per-Gaussian partial gradients are reduce-scattered inside each
+//     16-lane row with DPP (45 VALU ops, one total per lane) and published with ONE
+//     global_atomic_add_f32 instruction into a 64-byte per-Gaussian record; |.| of the
+//     mean2D terms is taken per pixel BEFORE the reduction (AbsGS semantics);
 //   * blockIdx -> tile mapping is XCD-aware (consecutive tiles share an XCD's L2).
 #include <stdlib.h>
 
@@ -58,227 +59,6 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v) {
     return v;
 }
 
-// ---------------------------------------------------------------------------------
-// K6
-// ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(GDR_BLOCK) void render_fwd_kernel(
-    const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int gx,
-    int ntiles, const float2* __restrict__ xy, const float4* __restrict__ conic_opacity,
-    const float4* __restrict__ rgbd, const float* __restrict__ bg, float* __restrict__ final_T,
-    uint32_t* __restrict__ n_contrib, float* __restrict__ out_color, float* __restrict__ out_depth,
-    float* __restrict__ out_alpha) {
-    __shared__ float2 s_xy[GDR_BLOCK];
-    __shared__ float4 s_co[GDR_BLOCK];
-    __shared__ float4 s_cd[GDR_BLOCK];
-    __shared__ int s_done[GDR_BLOCK / GDR_WAVE];
-
-    const uint32_t tile = xcd_remap(blockIdx.x, (uint32_t)ntiles);
-    const int tx = (int)(tile % (uint32_t)gx), ty = (int)(tile / (uint32_t)gx);
-    const int px = tx * GDR_TILE + (int)(threadIdx.x & 15u);
-    const int py = ty * GDR_TILE + (int)(threadIdx.x >> 4);
-    const bool inside = px < W && py < H;
-    const float pxf = (float)px, pyf = (float)py;
-    const uint2 range = ranges[tile];
-    int todo = (int)(range.y - range.x);
-    const int rounds = (todo + GDR_BLOCK - 1) / GDR_BLOCK;
-    const uint32_t wave = threadIdx.x >> 6;
-
-    bool done = !inside;
-    float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f, Wt = 0.f;
-    uint32_t contributor = 0, last_contributor = 0;
-
-    for (int r = 0; r < rounds; ++r, todo -= GDR_BLOCK) {
-        // workgroup-level early out: all four waves saturated
-        const bool wave_done = __ballot(!done) == 0ull;  // evaluated by all 64 lanes
-        if (lane_id() == 0) s_done[wave] = wave_done ? 1 : 0;
-        __syncthreads();
-        if (s_done[0] + s_done[1] + s_done[2] + s_done[3] == GDR_BLOCK / GDR_WAVE) break;
-        const int progress = r * GDR_BLOCK + (int)threadIdx.x;
-        if (range.x + progress < range.y) {
-            const uint32_t id = point_list[range.x + progress];
-            s_xy[threadIdx.x] = xy[id];
-            s_co[threadIdx.x] = conic_opacity[id];
-            s_cd[threadIdx.x] = rgbd[id];
-        }
-        __syncthreads();
-        const int cnt = todo < GDR_BLOCK ? todo : GDR_BLOCK;
-        if (__ballot(!done) != 0ull) {  // wave-uniform: this wave still has live pixels
-            for (int j = 0; j < cnt; ++j) {
-                if (__ballot(!done) == 0ull) break;  // per-wave early out
-                contributor++;
-                const float2 m = s_xy[j];
-                const float4 co = s_co[j];
-                const float dx = m.x - pxf, dy = m.y - pyf;
-                const float power = gauss_power(dx, dy, co.x, co.y, co.z);
-                if (done || power > 0.f) continue;
-                const float alpha = fminf(0.99f, co.w * expf(power));
-                if (alpha < (1.f / 255.f)) continue;
-                const float test_T = T * (1.f - alpha);
-                if (test_T < 0.0001f) {
-                    done = true;
-                    continue;
-                }
-                const float4 cd = s_cd[j];
-                const float w = alpha * T;
-                C0 = fmaf(cd.x, w, C0);
-                C1 = fmaf(cd.y, w, C1);
-                C2 = fmaf(cd.z, w, C2);
-                Dp = fmaf(cd.w, w, Dp);
-                Wt += w;
-                T = test_T;
-                last_contributor = contributor;
-            }
-        }
-    }
-    if (inside) {
-        const size_t pix = (size_t)py * W + px, P = (size_t)H * W;
-        final_T[pix] = T;
-        n_contrib[pix] = last_contributor;
-        out_color[pix] = fmaf(T, bg[0], C0);
-        out_color[P + pix] = fmaf(T, bg[1], C1);
-        out_color[2 * P + pix] = fmaf(T, bg[2], C2);
-        out_depth[pix] = Dp;
-        out_alpha[pix] = Wt;
-    }
-}
-
-// ---------------------------------------------------------------------------------
-// K7
-// Accumulators (all pre-zeroed by the launcher):
-//   dL_dmean2D (N) float4 : x, y signed (NDC units), z, w = sum |per-pixel term|
-//   scratch    (N) 2xfloat4: {dconic.x, dconic.y, dconic.z, ddepth}, {dr, dg, db, -}
-//   dL_dopacity(N)
-// ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(GDR_BLOCK) void render_bwd_kernel(
-    const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int gx,
-    int ntiles, const float* __restrict__ bg, const float2* __restrict__ xy,
-    const float4* __restrict__ conic_opacity, const float4* __restrict__ rgbd,
-    const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
-    const float* __restrict__ dL_dpix, const float* __restrict__ dL_ddepthpix,
-    const float* __restrict__ dL_dalphapix, float* __restrict__ dL_dmean2D,
-    float* __restrict__ scratch, float* __restrict__ dL_dopacity) {
-    __shared__ float2 s_xy[GDR_BLOCK];
-    __shared__ float4 s_co[GDR_BLOCK];
-    __shared__ float4 s_cd[GDR_BLOCK];
-    __shared__ uint32_t s_id[GDR_BLOCK];
-
-    const uint32_t tile = xcd_remap(blockIdx.x, (uint32_t)ntiles);
-    const int tx = (int)(tile % (uint32_t)gx), ty = (int)(tile / (uint32_t)gx);
-    const int px = tx * GDR_TILE + (int)(threadIdx.x & 15u);
-    const int py = ty * GDR_TILE + (int)(threadIdx.x >> 4);
-    const bool inside = px < W && py < H;
-    const float pxf = (float)px, pyf = (float)py;
-    const size_t pix = (size_t)py * W + px, P = (size_t)H * W;
-    const uint2 range = ranges[tile];
-    int todo = (int)(range.y - range.x);
-    const int rounds = (todo + GDR_BLOCK - 1) / GDR_BLOCK;
-
-    const float T_final = inside ? final_T[pix] : 0.f;
-    float T = T_final;
-    const int last_contributor = inside ? (int)n_contrib[pix] : 0;
-    int contributor = todo;
-    float gC0 = 0.f, gC1 = 0.f, gC2 = 0.f, gD = 0.f, gA = 0.f;
-    if (inside) {
-        gC0 = dL_dpix[pix];
-        gC1 = dL_dpix[P + pix];
-        gC2 = dL_dpix[2 * P + pix];
-        if (dL_ddepthpix) gD = dL_ddepthpix[pix];
-        if (dL_dalphapix) gA = dL_dalphapix[pix];
-    }
-    const float bg_dot = (bg[0] * gC0 + bg[1] * gC1) + bg[2] * gC2;
-    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, accD = 0.f, accA = 0.f;
-    float last_alpha = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f, last_depth = 0.f;
-    const float ddelx_dx = 0.5f * (float)W, ddely_dy = 0.5f * (float)H;
-
-    // the deepest contributor any pixel of this wave has: entries behind it are skipped
-    int wave_last = last_contributor;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) wave_last = max(wave_last, __shfl_xor(wave_last, off, 64));
-
-    for (int r = 0; r < rounds; ++r, todo -= GDR_BLOCK) {
-        __syncthreads();
-        const int progress = r * GDR_BLOCK + (int)threadIdx.x;
-        if (range.x + progress < range.y) {
-            const uint32_t id = point_list[range.y - progress - 1];
-            s_id[threadIdx.x] = id;
-            s_xy[threadIdx.x] = xy[id];
-            s_co[threadIdx.x] = conic_opacity[id];
-            s_cd[threadIdx.x] = rgbd[id];
-        }
-        __syncthreads();
-        const int cnt = todo < GDR_BLOCK ? todo : GDR_BLOCK;
-        if (contributor - cnt >= wave_last) {  // whole chunk lies behind every pixel's last contributor
-            contributor -= cnt;
-            continue;
-        }
-        for (int j = 0; j < cnt; ++j) {
-            contributor--;
-            const float2 m = s_xy[j];
-            const float4 co = s_co[j];
-            const float dx = m.x - pxf, dy = m.y - pyf;
-            const float power = gauss_power(dx, dy, co.x, co.y, co.z);
-            const float G = expf(power);
-            const float alpha = fminf(0.99f, co.w * G);
-            const bool hit = (contributor < last_contributor) && !(power > 0.f) && !(alpha < (1.f / 255.f));
-            if (__ballot(hit) == 0ull) continue;  // wave-uniform skip
-
-            float v_mx = 0.f, v_my = 0.f, v_ax = 0.f, v_ay = 0.f, v_cx = 0.f, v_cy = 0.f, v_cz = 0.f;
-            float v_dd = 0.f, v_r = 0.f, v_g = 0.f, v_b = 0.f, v_o = 0.f;
-            if (hit) {
-                const float4 cd = s_cd[j];
-                T = T / (1.f - alpha);
-                const float w = alpha * T;
-                acc0 = last_alpha * lc0 + (1.f - last_alpha) * acc0;
-                acc1 = last_alpha * lc1 + (1.f - last_alpha) * acc1;
-                acc2 = last_alpha * lc2 + (1.f - last_alpha) * acc2;
-                lc0 = cd.x; lc1 = cd.y; lc2 = cd.z;
-                float dL_dalpha = (cd.x - acc0) * gC0 + (cd.y - acc1) * gC1 + (cd.z - acc2) * gC2;
-                v_r = w * gC0; v_g = w * gC1; v_b = w * gC2;
-                accD = last_alpha * last_depth + (1.f - last_alpha) * accD;
-                last_depth = cd.w;
-                dL_dalpha += (cd.w - accD) * gD;
-                v_dd = w * gD;
-                accA = last_alpha + (1.f - last_alpha) * accA;
-                dL_dalpha += (1.f - accA) * gA;
-                dL_dalpha *= T;
-                last_alpha = alpha;
-                dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot;
-                const float dL_dG = co.w * dL_dalpha;
-                const float gdx = G * dx, gdy = G * dy;
-                const float dG_ddelx = -gdx * co.x - gdy * co.y;
-                const float dG_ddely = -gdy * co.z - gdx * co.y;
-                v_mx = dL_dG * dG_ddelx * ddelx_dx;
-                v_my = dL_dG * dG_ddely * ddely_dy;
-                v_ax = fabsf(v_mx);
-                v_ay = fabsf(v_my);
-                v_cx = -0.5f * gdx * dx * dL_dG;
-                v_cy = -gdx * dy * dL_dG;
-                v_cz = -0.5f * gdy * dy * dL_dG;
-                v_o = G * dL_dalpha;
-            }
-            v_mx = wave_sum_to_lane63(v_mx); v_my = wave_sum_to_lane63(v_my);
-            v_ax = wave_sum_to_lane63(v_ax); v_ay = wave_sum_to_lane63(v_ay);
-            v_cx = wave_sum_to_lane63(v_cx); v_cy = wave_sum_to_lane63(v_cy);
-            v_cz = wave_sum_to_lane63(v_cz); v_dd = wave_sum_to_lane63(v_dd);
-            v_r = wave_sum_to_lane63(v_r);   v_g = wave_sum_to_lane63(v_g);
-            v_b = wave_sum_to_lane63(v_b);   v_o = wave_sum_to_lane63(v_o);
-            if (lane_id() == 63) {
-                const uint32_t id = s_id[j];
-                float* m2 = dL_dmean2D + 4 * (size_t)id;
-                float* sc = scratch + 8 * (size_t)id;
-                atomicAdd(m2 + 0, v_mx); atomicAdd(m2 + 1, v_my);
-                atomicAdd(m2 + 2, v_ax); atomicAdd(m2 + 3, v_ay);
-                atomicAdd(sc + 0, v_cx); atomicAdd(sc + 1, v_cy);
-                atomicAdd(sc + 2, v_cz); atomicAdd(sc + 3, v_dd);
-                atomicAdd(sc + 4, v_r);  atomicAdd(sc + 5, v_g);
-                atomicAdd(sc + 6, v_b);
-                atomicAdd(dL_dopacity + id, v_o);
-            }
-        }
-    }
-}
-
-
 // =================================================================================
 // v2 kernels: sub-tile culling.  Each wave owns an 8x8 pixel sub-tile of the 16x16 tile.
 // While a 256-entry slice of the tile's sorted list sits in LDS, every lane tests ONE
@@ -318,289 +98,6 @@ __device__ __forceinline__ Staged stage_entry(float2 xy, float4 co, float4 cd) {
     return s;
 }
 
-__device__ __forceinline__ uint64_t cull_mask(const float2* s_xy, const float2* s_ext, int e, float X0,
-                                              float X1, float Y0, float Y1) {
-    const float2 m = s_xy[e];
-    const float2 h = s_ext[e];
-    const bool ov = (h.x >= 0.f) && (m.x + h.x >= X0) && (m.x - h.x <= X1) && (m.y + h.y >= Y0) &&
-                    (m.y - h.y <= Y1);
-    return __ballot(ov);
-}
-
-__global__ __launch_bounds__(GDR_BLOCK) void render_fwd_v2_kernel(
-    const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int gx,
-    int ntiles, const float2* __restrict__ xy, const float4* __restrict__ conic_opacity,
-    const float4* __restrict__ rgbd, const float* __restrict__ bg, float* __restrict__ final_T,
-    uint32_t* __restrict__ n_contrib, float* __restrict__ out_color, float* __restrict__ out_depth,
-    float* __restrict__ out_alpha) {
-    __shared__ float2 s_xy[GDR_BLOCK];
-    __shared__ float2 s_ext[GDR_BLOCK];
-    __shared__ float4 s_co[GDR_BLOCK];
-    __shared__ float4 s_cd[GDR_BLOCK];
-    __shared__ int s_done[GDR_BLOCK / GDR_WAVE];
-
-    const uint32_t tile = xcd_remap(blockIdx.x, (uint32_t)ntiles);
-    const int tx = (int)(tile % (uint32_t)gx), ty = (int)(tile / (uint32_t)gx);
-    const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
-    const int sx0 = tx * GDR_TILE + (int)(wave & 1u) * 8, sy0 = ty * GDR_TILE + (int)(wave >> 1) * 8;
-    const int px = sx0 + (int)(lane & 7u), py = sy0 + (int)(lane >> 3);
-    const bool inside = px < W && py < H;
-    const float pxf = (float)px, pyf = (float)py;
-    const float X0 = (float)sx0, X1 = (float)(sx0 + 7), Y0 = (float)sy0, Y1 = (float)(sy0 + 7);
-    const uint2 range = ranges[tile];
-    const int total = (int)(range.y - range.x);
-    const int rounds = (total + GDR_BLOCK - 1) / GDR_BLOCK;
-
-    bool done = !inside;
-    float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f, Wt = 0.f;
-    uint32_t last_contributor = 0;
-
-    float2 r_xy = make_float2(0.f, 0.f);
-    float4 r_co = make_float4(0.f, 0.f, 0.f, 0.f), r_cd = r_co;
-    bool r_valid = (int)threadIdx.x < total;
-    if (r_valid) {
-        const uint32_t id = point_list[range.x + threadIdx.x];
-        r_xy = xy[id]; r_co = conic_opacity[id]; r_cd = rgbd[id];
-    }
-    for (int r = 0; r < rounds; ++r) {
-        const bool wave_done = __ballot(!done) == 0ull;
-        if (lane == 0) s_done[wave] = wave_done ? 1 : 0;
-        __syncthreads();
-        if (s_done[0] + s_done[1] + s_done[2] + s_done[3] == GDR_BLOCK / GDR_WAVE) break;
-        if (r_valid) {
-            const Staged st = stage_entry(r_xy, r_co, r_cd);
-            s_xy[threadIdx.x] = st.xy; s_ext[threadIdx.x] = st.ext;
-            s_co[threadIdx.x] = st.co; s_cd[threadIdx.x] = st.cd;
-        } else {
-            s_ext[threadIdx.x] = make_float2(-1.f, -1.f);
-            s_xy[threadIdx.x] = make_float2(0.f, 0.f);
-        }
-        __syncthreads();
-        {   // prefetch the next slice (lands while this one is composited)
-            const int nxt = (r + 1) * GDR_BLOCK + (int)threadIdx.x;
-            r_valid = nxt < total;
-            if (r_valid) {
-                const uint32_t id = point_list[range.x + nxt];
-                r_xy = xy[id]; r_co = conic_opacity[id]; r_cd = rgbd[id];
-            }
-        }
-        if (wave_done) continue;
-        const uint32_t base = (uint32_t)(r * GDR_BLOCK);
-#pragma unroll 1
-        for (int g = 0; g < GDR_BLOCK / GDR_WAVE; ++g) {
-            uint64_t mask = cull_mask(s_xy, s_ext, g * GDR_WAVE + (int)lane, X0, X1, Y0, Y1);
-            while (mask) {
-                const int e = g * GDR_WAVE + __builtin_ctzll(mask);
-                mask &= mask - 1ull;
-                const float2 m = s_xy[e];
-                const float4 co = s_co[e];
-                const float dx = m.x - pxf, dy = m.y - pyf;
-                const float p2 = gauss_power(dx, dy, co.x, co.y, co.z);
-                const float alpha = fminf(0.99f, co.w * __builtin_amdgcn_exp2f(p2));
-                const bool c = !done && !(p2 > 0.f) && !(alpha < (1.f / 255.f));
-                if (__ballot(c) == 0ull) continue;
-                const float test_T = T * (1.f - alpha);
-                const bool stop = c && (test_T < 0.0001f);
-                done = done || stop;
-                const bool acc = c && !stop;
-                const float4 cd = s_cd[e];
-                const float w = acc ? alpha * T : 0.f;
-                C0 = fmaf(cd.x, w, C0);
-                C1 = fmaf(cd.y, w, C1);
-                C2 = fmaf(cd.z, w, C2);
-                Dp = fmaf(cd.w, w, Dp);
-                Wt += w;
-                T = acc ? test_T : T;
-                last_contributor = acc ? base + (uint32_t)e + 1u : last_contributor;
-                if (__ballot(!done) == 0ull) { mask = 0ull; g = GDR_BLOCK / GDR_WAVE; }
-            }
-        }
-    }
-    if (inside) {
-        const size_t pix = (size_t)py * W + px, P = (size_t)H * W;
-        final_T[pix] = T;
-        n_contrib[pix] = last_contributor;
-        out_color[pix] = fmaf(T, bg[0], C0);
-        out_color[P + pix] = fmaf(T, bg[1], C1);
-        out_color[2 * P + pix] = fmaf(T, bg[2], C2);
-        out_depth[pix] = Dp;
-        out_alpha[pix] = Wt;
-    }
-}
-
-#ifndef GDR_ABL
-#define GDR_ABL 0
-#endif
-#define GDR_ACC_STRIDE 13  // 12 partial gradients + touched flag; odd stride: conflict-free per-thread rows
-
-__global__ __launch_bounds__(GDR_BLOCK) void render_bwd_v2_kernel(
-    const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int gx,
-    int ntiles, const float* __restrict__ bg, const float2* __restrict__ xy,
-    const float4* __restrict__ conic_opacity, const float4* __restrict__ rgbd,
-    const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
-    const float* __restrict__ dL_dpix, const float* __restrict__ dL_ddepthpix,
-    const float* __restrict__ dL_dalphapix, float* __restrict__ dL_dmean2D,
-    float* __restrict__ scratch, float* __restrict__ dL_dopacity) {
-    __shared__ float2 s_xy[GDR_BLOCK];
-    __shared__ float2 s_ext[GDR_BLOCK];
-    __shared__ float4 s_co[GDR_BLOCK];
-    __shared__ float4 s_cd[GDR_BLOCK];
-    __shared__ uint32_t s_id[GDR_BLOCK];
-    __shared__ float s_acc[GDR_BLOCK * GDR_ACC_STRIDE];
-
-    const uint32_t tile = xcd_remap(blockIdx.x, (uint32_t)ntiles);
-    const int tx = (int)(tile % (uint32_t)gx), ty = (int)(tile / (uint32_t)gx);
-    const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
-    const int sx0 = tx * GDR_TILE + (int)(wave & 1u) * 8, sy0 = ty * GDR_TILE + (int)(wave >> 1) * 8;
-    const int px = sx0 + (int)(lane & 7u), py = sy0 + (int)(lane >> 3);
-    const bool inside = px < W && py < H;
-    const float pxf = (float)px, pyf = (float)py;
-    const float X0 = (float)sx0, X1 = (float)(sx0 + 7), Y0 = (float)sy0, Y1 = (float)(sy0 + 7);
-    const size_t pix = (size_t)py * W + px, P = (size_t)H * W;
-    const uint2 range = ranges[tile];
-    const int total = (int)(range.y - range.x);
-    const int rounds = (total + GDR_BLOCK - 1) / GDR_BLOCK;
-
-    const float T_final = inside ? final_T[pix] : 0.f;
-    float T = T_final;
-    const int last_contributor = inside ? (int)n_contrib[pix] : 0;
-    float gC0 = 0.f, gC1 = 0.f, gC2 = 0.f, gD = 0.f, gA = 0.f;
-    if (inside) {
-        gC0 = dL_dpix[pix]; gC1 = dL_dpix[P + pix]; gC2 = dL_dpix[2 * P + pix];
-        if (dL_ddepthpix) gD = dL_ddepthpix[pix];
-        if (dL_dalphapix) gA = dL_dalphapix[pix];
-    }
-    const float bg_dot = (bg[0] * gC0 + bg[1] * gC1) + bg[2] * gC2;
-    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, accD = 0.f, accA = 0.f;
-    float last_alpha = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f, last_depth = 0.f;
-    // the staged conic is log2(e) x the true one: fold 1/log2(e) = ln 2 into the pixel->NDC factors
-    const float kx = 0.5f * (float)W * GDR_LN2, ky = 0.5f * (float)H * GDR_LN2;
-
-    int wave_last = last_contributor;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) wave_last = max(wave_last, __shfl_xor(wave_last, off, 64));
-
-    for (int k = 0; k < GDR_ACC_STRIDE; ++k) s_acc[threadIdx.x * GDR_ACC_STRIDE + k] = 0.f;
-
-    // slice r holds list positions total-1-(r*256+e), e = 0..255: back to front
-    float2 r_xy = make_float2(0.f, 0.f);
-    float4 r_co = make_float4(0.f, 0.f, 0.f, 0.f), r_cd = r_co;
-    uint32_t r_id = 0;
-    bool r_valid = (int)threadIdx.x < total;
-    if (r_valid) {
-        r_id = point_list[range.y - 1 - threadIdx.x];
-        r_xy = xy[r_id]; r_co = conic_opacity[r_id]; r_cd = rgbd[r_id];
-    }
-    for (int r = 0; r <= rounds; ++r) {
-        __syncthreads();  // every wave finished the previous slice: its accumulators are complete
-        if (r > 0) {      // flush my entry of the previous slice: one coalesced atomic pass
-            float* a = s_acc + threadIdx.x * GDR_ACC_STRIDE;
-            if (a[12] != 0.f) {
-                const uint32_t id = s_id[threadIdx.x];
-                float* m2 = dL_dmean2D + 4 * (size_t)id;
-                float* sc = scratch + 8 * (size_t)id;
-                atomicAdd(m2 + 0, a[0]); atomicAdd(m2 + 1, a[1]); atomicAdd(m2 + 2, a[2]); atomicAdd(m2 + 3, a[3]);
-                atomicAdd(sc + 0, a[4]); atomicAdd(sc + 1, a[5]); atomicAdd(sc + 2, a[6]); atomicAdd(sc + 3, a[7]);
-                atomicAdd(sc + 4, a[8]); atomicAdd(sc + 5, a[9]); atomicAdd(sc + 6, a[10]);
-                atomicAdd(dL_dopacity + id, a[11]);
-#pragma unroll
-                for (int k = 0; k < GDR_ACC_STRIDE; ++k) a[k] = 0.f;
-            }
-        }
-        if (r == rounds) break;
-        if (r_valid) {
-            const Staged st = stage_entry(r_xy, r_co, r_cd);
-            s_xy[threadIdx.x] = st.xy; s_ext[threadIdx.x] = st.ext;
-            s_co[threadIdx.x] = st.co; s_cd[threadIdx.x] = st.cd;
-            s_id[threadIdx.x] = r_id;
-        } else {
-            s_ext[threadIdx.x] = make_float2(-1.f, -1.f);
-            s_xy[threadIdx.x] = make_float2(0.f, 0.f);
-        }
-        __syncthreads();
-        {
-            const int nxt = (r + 1) * GDR_BLOCK + (int)threadIdx.x;
-            r_valid = nxt < total;
-            if (r_valid) {
-                r_id = point_list[range.y - 1 - nxt];
-                r_xy = xy[r_id]; r_co = conic_opacity[r_id]; r_cd = rgbd[r_id];
-            }
-        }
-        // list position of LDS entry e in this slice: pos = top - e
-        const int top = total - 1 - r * GDR_BLOCK;
-        if (top - (GDR_BLOCK - 1) >= wave_last) continue;  // whole slice behind every pixel's last contributor
-#pragma unroll 1
-        for (int g = 0; g < GDR_BLOCK / GDR_WAVE; ++g) {
-            uint64_t mask = cull_mask(s_xy, s_ext, g * GDR_WAVE + (int)lane, X0, X1, Y0, Y1);
-            while (mask) {
-                const int e = g * GDR_WAVE + __builtin_ctzll(mask);
-                mask &= mask - 1ull;
-                const int pos = top - e;
-                const float2 m = s_xy[e];
-                const float4 co = s_co[e];
-                const float dx = m.x - pxf, dy = m.y - pyf;
-                const float p2 = gauss_power(dx, dy, co.x, co.y, co.z);
-                const float G = __builtin_amdgcn_exp2f(p2);
-                const float alpha = fminf(0.99f, co.w * G);
-                const bool hit = (pos < last_contributor) && !(p2 > 0.f) && !(alpha < (1.f / 255.f));
-                if (__ballot(hit) == 0ull) continue;
-                const float4 cd = s_cd[e];
-                const float oma = 1.f - alpha;
-                const float Tn = T / oma;
-                const float w = hit ? alpha * Tn : 0.f;
-                const float n0 = last_alpha * lc0 + (1.f - last_alpha) * acc0;
-                const float n1 = last_alpha * lc1 + (1.f - last_alpha) * acc1;
-                const float n2 = last_alpha * lc2 + (1.f - last_alpha) * acc2;
-                const float nD = last_alpha * last_depth + (1.f - last_alpha) * accD;
-                const float nA = last_alpha + (1.f - last_alpha) * accA;
-                float dL_dalpha = (cd.x - n0) * gC0 + (cd.y - n1) * gC1 + (cd.z - n2) * gC2;
-                dL_dalpha += (cd.w - nD) * gD;
-                dL_dalpha += (1.f - nA) * gA;
-                dL_dalpha *= Tn;
-                dL_dalpha += (-T_final / oma) * bg_dot;
-                dL_dalpha = hit ? dL_dalpha : 0.f;
-                if (hit) {
-                    T = Tn; acc0 = n0; acc1 = n1; acc2 = n2; accD = nD; accA = nA;
-                    lc0 = cd.x; lc1 = cd.y; lc2 = cd.z; last_depth = cd.w; last_alpha = alpha;
-                }
-                const float dL_dG = co.w * dL_dalpha;
-                const float gdx = G * dx, gdy = G * dy;
-                // co.xyz carry the log2(e) factor; kx, ky carry its inverse
-                float v_mx = dL_dG * (-gdx * co.x - gdy * co.y) * kx;
-                float v_my = dL_dG * (-gdy * co.z - gdx * co.y) * ky;
-                float v_ax = fabsf(v_mx), v_ay = fabsf(v_my);
-                float v_cx = -0.5f * gdx * dx * dL_dG;
-                float v_cy = -gdx * dy * dL_dG;
-                float v_cz = -0.5f * gdy * dy * dL_dG;
-                float v_dd = w * gD, v_r = w * gC0, v_g = w * gC1, v_b = w * gC2;
-                float v_o = G * dL_dalpha;
-#if GDR_ABL != 2
-                v_mx = wave_sum_to_lane63(v_mx); v_my = wave_sum_to_lane63(v_my);
-                v_ax = wave_sum_to_lane63(v_ax); v_ay = wave_sum_to_lane63(v_ay);
-                v_cx = wave_sum_to_lane63(v_cx); v_cy = wave_sum_to_lane63(v_cy);
-                v_cz = wave_sum_to_lane63(v_cz); v_dd = wave_sum_to_lane63(v_dd);
-                v_r = wave_sum_to_lane63(v_r);   v_g = wave_sum_to_lane63(v_g);
-                v_b = wave_sum_to_lane63(v_b);   v_o = wave_sum_to_lane63(v_o);
-#endif
-#if GDR_ABL == 1 || GDR_ABL == 3
-                asm volatile("" ::"v"(v_mx), "v"(v_my), "v"(v_ax), "v"(v_ay), "v"(v_cx), "v"(v_cy));
-                asm volatile("" ::"v"(v_cz), "v"(v_dd), "v"(v_r), "v"(v_g), "v"(v_b), "v"(v_o));
-                if (false) {
-#else
-                if (lane == 63) {
-#endif
-                    float* a = s_acc + e * GDR_ACC_STRIDE;
-                    atomicAdd(a + 0, v_mx); atomicAdd(a + 1, v_my); atomicAdd(a + 2, v_ax); atomicAdd(a + 3, v_ay);
-                    atomicAdd(a + 4, v_cx); atomicAdd(a + 5, v_cy); atomicAdd(a + 6, v_cz); atomicAdd(a + 7, v_dd);
-                    atomicAdd(a + 8, v_r);  atomicAdd(a + 9, v_g);  atomicAdd(a + 10, v_b); atomicAdd(a + 11, v_o);
-                    a[12] = 1.f;
-                }
-            }
-        }
-    }
-}
-
-
 // =================================================================================
 // v3 kernels: 4x4-pixel blocks, one per 16-lane DPP row.
 // A wave still owns an 8x8 sub-tile, but each of its four rows of 16 lanes composites
@@ -631,9 +128,37 @@ __device__ __forceinline__ float row_sum(float v) {
     return v;
 }
 
+// Row-local reduce-scatter of 12 per-lane values over the 16 lanes of a DPP row: lane i of the
+// row returns the row total of value i (i < 12; lanes 12..15 return 0).  Four halving
+// exchanges (row_mirror, row_half_mirror, quad reverse, quad xor-1): 45 VALU ops instead of
+// 12 x 4 full reductions, and the totals land one per lane, so ONE atomic instruction
+// publishes all of them.
+__device__ __forceinline__ float row_reduce_scatter12(const float (&v)[12], uint32_t li) {
+    const bool b3 = li & 8u, b2 = li & 4u, b1 = li & 2u, b0 = li & 1u;
+    float u[8], t[4], s2[2];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float hi = (j + 8 < 12) ? v[j + 8] : 0.f;
+        const float keep = b3 ? hi : v[j], send = b3 ? v[j] : hi;
+        u[j] = keep + dpp_get<0x140, 0xf>(send);  // row_mirror: partner 15 - i
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float keep = b2 ? u[j + 4] : u[j], send = b2 ? u[j] : u[j + 4];
+        t[j] = keep + dpp_get<0x141, 0xf>(send);  // row_half_mirror: partner i ^ 7
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const float keep = b1 ? t[j + 2] : t[j], send = b1 ? t[j] : t[j + 2];
+        s2[j] = keep + dpp_get<0x1B, 0xf>(send);  // quad_perm [3,2,1,0]: partner i ^ 3
+    }
+    const float keep = b0 ? s2[1] : s2[0], send = b0 ? s2[0] : s2[1];
+    return keep + dpp_get<0xB1, 0xf>(send);       // quad_perm [1,0,3,2]: partner i ^ 1
+}
+
 #define GDR_ROW_MASK(k) (0xFFFFull << (16 * (k)))
 
-__global__ __launch_bounds__(GDR_BLOCK) void render_fwd_v3_kernel(
+__global__ __launch_bounds__(GDR_BLOCK) void render_fwd_kernel(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int gx,
     int ntiles, const float2* __restrict__ xy, const float4* __restrict__ conic_opacity,
     const float4* __restrict__ rgbd, const float* __restrict__ bg, float* __restrict__ final_T,
@@ -756,20 +281,18 @@ __global__ __launch_bounds__(GDR_BLOCK) void render_fwd_v3_kernel(
     }
 }
 
-__global__ __launch_bounds__(GDR_BLOCK) void render_bwd_v3_kernel(
+__global__ __launch_bounds__(GDR_BLOCK) void render_bwd_kernel(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int gx,
     int ntiles, const float* __restrict__ bg, const float2* __restrict__ xy,
     const float4* __restrict__ conic_opacity, const float4* __restrict__ rgbd,
     const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
     const float* __restrict__ dL_dpix, const float* __restrict__ dL_ddepthpix,
-    const float* __restrict__ dL_dalphapix, float* __restrict__ dL_dmean2D,
-    float* __restrict__ scratch, float* __restrict__ dL_dopacity) {
+    const float* __restrict__ dL_dalphapix, float* __restrict__ grad_rec) {
     __shared__ float2 s_xy[GDR_BLOCK];
     __shared__ float2 s_ext[GDR_BLOCK];
     __shared__ float4 s_co[GDR_BLOCK];
     __shared__ float4 s_cd[GDR_BLOCK];
     __shared__ uint32_t s_id[GDR_BLOCK];
-    __shared__ float s_acc[GDR_BLOCK * GDR_ACC_STRIDE];
 
     const uint32_t tile = xcd_remap(blockIdx.x, (uint32_t)ntiles);
     const int tx = (int)(tile % (uint32_t)gx), ty = (int)(tile / (uint32_t)gx);
@@ -809,7 +332,6 @@ __global__ __launch_bounds__(GDR_BLOCK) void render_bwd_v3_kernel(
     const int rl2 = __builtin_amdgcn_readlane(row_last, 32), rl3 = __builtin_amdgcn_readlane(row_last, 48);
     const int wave_last = max(max(rl0, rl1), max(rl2, rl3));
 
-    for (int k = 0; k < GDR_ACC_STRIDE; ++k) s_acc[threadIdx.x * GDR_ACC_STRIDE + k] = 0.f;
 
     float2 r_xy = make_float2(0.f, 0.f);
     float4 r_co = make_float4(0.f, 0.f, 0.f, 0.f), r_cd = r_co;
@@ -819,23 +341,8 @@ __global__ __launch_bounds__(GDR_BLOCK) void render_bwd_v3_kernel(
         r_id = point_list[range.y - 1 - threadIdx.x];
         r_xy = xy[r_id]; r_co = conic_opacity[r_id]; r_cd = rgbd[r_id];
     }
-    for (int r = 0; r <= rounds; ++r) {
-        __syncthreads();
-        if (r > 0) {
-            float* a = s_acc + threadIdx.x * GDR_ACC_STRIDE;
-            if (a[12] != 0.f) {
-                const uint32_t id = s_id[threadIdx.x];
-                float* m2 = dL_dmean2D + 4 * (size_t)id;
-                float* sc = scratch + 8 * (size_t)id;
-                atomicAdd(m2 + 0, a[0]); atomicAdd(m2 + 1, a[1]); atomicAdd(m2 + 2, a[2]); atomicAdd(m2 + 3, a[3]);
-                atomicAdd(sc + 0, a[4]); atomicAdd(sc + 1, a[5]); atomicAdd(sc + 2, a[6]); atomicAdd(sc + 3, a[7]);
-                atomicAdd(sc + 4, a[8]); atomicAdd(sc + 5, a[9]); atomicAdd(sc + 6, a[10]);
-                atomicAdd(dL_dopacity + id, a[11]);
-#pragma unroll
-                for (int k = 0; k < GDR_ACC_STRIDE; ++k) a[k] = 0.f;
-            }
-        }
-        if (r == rounds) break;
+    for (int r = 0; r < rounds; ++r) {
+        __syncthreads();  // every wave finished reading the previous slice
         if (r_valid) {
             const Staged st = stage_entry(r_xy, r_co, r_cd);
             s_xy[threadIdx.x] = st.xy; s_ext[threadIdx.x] = st.ext;
@@ -918,17 +425,14 @@ __global__ __launch_bounds__(GDR_BLOCK) void render_bwd_v3_kernel(
                 float v_cz = -0.5f * gdy * dy * dL_dG;
                 float v_dd = w * gD, v_r = w * gC0, v_g = w * gC1, v_b = w * gC2;
                 float v_o = G * dL_dalpha;
-                v_mx = row_sum(v_mx); v_my = row_sum(v_my); v_ax = row_sum(v_ax); v_ay = row_sum(v_ay);
-                v_cx = row_sum(v_cx); v_cy = row_sum(v_cy); v_cz = row_sum(v_cz); v_dd = row_sum(v_dd);
-                v_r = row_sum(v_r);   v_g = row_sum(v_g);   v_b = row_sum(v_b);   v_o = row_sum(v_o);
-                // one lane per row that had a hit publishes the row totals
-                if (li == 0 && ((hb >> (16 * row)) & 0xFFFFull) != 0ull) {
-                    float* a = s_acc + e * GDR_ACC_STRIDE;
-                    atomicAdd(a + 0, v_mx); atomicAdd(a + 1, v_my); atomicAdd(a + 2, v_ax); atomicAdd(a + 3, v_ay);
-                    atomicAdd(a + 4, v_cx); atomicAdd(a + 5, v_cy); atomicAdd(a + 6, v_cz); atomicAdd(a + 7, v_dd);
-                    atomicAdd(a + 8, v_r);  atomicAdd(a + 9, v_g);  atomicAdd(a + 10, v_b); atomicAdd(a + 11, v_o);
-                    a[12] = 1.f;
-                }
+                const float vals[12] = {v_mx, v_my, v_ax, v_ay, v_cx, v_cy, v_cz, v_dd, v_r, v_g, v_b, v_o};
+                const float tot = row_reduce_scatter12(vals, li);
+                // lanes 0..12 of every row that had a hit publish the row totals: one DS instruction
+                // lanes 0..11 of every row that had a hit add the row totals to the Gaussian's
+                // 64-byte gradient record: one global_atomic_add_f32 instruction, one cache line
+                // per row (no return value => fire and forget)
+                if (li < 12u && ((hb >> (16 * row)) & 0xFFFFull) != 0ull)
+                    atomicAdd(grad_rec + 16 * (size_t)s_id[e] + li, tot);
             }
         }
     }
@@ -936,33 +440,15 @@ __global__ __launch_bounds__(GDR_BLOCK) void render_bwd_v3_kernel(
 
 }  // namespace
 
-// GDR_RENDER_VARIANT=1|2 selects the older kernels (A/B measurements only); default 3
-static int render_variant() {
-    static const int v = [] { const char* e = getenv("GDR_RENDER_VARIANT"); return e ? atoi(e) : 3; }();
-    return v;
-}
-static bool render_v1() { return render_variant() == 1; }
-
 hipError_t launch_render_fwd(const gdr_settings* s, const gdr_geom* g, const gdr_binning* bin,
                              const gdr_image* img, const gdr_outputs* out, hipStream_t st) {
     const int W = s->image_width, H = s->image_height;
     const int gx = tile_grid_x(W), gy = tile_grid_y(H);
     const int ntiles = gx * gy;
-    if (render_variant() >= 3)
-        GDR_LAUNCH(GDR_K_RENDER_FWD, render_fwd_v3_kernel, dim3(ntiles), dim3(GDR_BLOCK), st,
-                   (const uint2*)img->ranges, bin->values[bin->sorted], W, H, gx, ntiles,
-                   (const float2*)g->xy, (const float4*)g->conic_opacity, (const float4*)g->rgb,
-                   s->bg, img->final_T, img->n_contrib, out->color, out->depth, out->alpha);
-    else if (!render_v1())
-        GDR_LAUNCH(GDR_K_RENDER_FWD, render_fwd_v2_kernel, dim3(ntiles), dim3(GDR_BLOCK), st,
-                   (const uint2*)img->ranges, bin->values[bin->sorted], W, H, gx, ntiles,
-                   (const float2*)g->xy, (const float4*)g->conic_opacity, (const float4*)g->rgb,
-                   s->bg, img->final_T, img->n_contrib, out->color, out->depth, out->alpha);
-    else
     GDR_LAUNCH(GDR_K_RENDER_FWD, render_fwd_kernel, dim3(ntiles), dim3(GDR_BLOCK), st,
-                       (const uint2*)img->ranges, bin->values[bin->sorted], W, H, gx, ntiles,
-                       (const float2*)g->xy, (const float4*)g->conic_opacity, (const float4*)g->rgb,
-                       s->bg, img->final_T, img->n_contrib, out->color, out->depth, out->alpha);
+               (const uint2*)img->ranges, bin->values[bin->sorted], W, H, gx, ntiles,
+               (const float2*)g->xy, (const float4*)g->conic_opacity, (const float4*)g->rgb, s->bg,
+               img->final_T, img->n_contrib, out->color, out->depth, out->alpha);
     return hipGetLastError();
 }
 
@@ -972,24 +458,11 @@ hipError_t launch_render_bwd(const gdr_settings* s, const gdr_geom* g, const gdr
     const int W = s->image_width, H = s->image_height;
     const int gx = tile_grid_x(W), gy = tile_grid_y(H);
     const int ntiles = gx * gy;
-    if (render_variant() >= 3)
-        GDR_LAUNCH(GDR_K_RENDER_BWD, render_bwd_v3_kernel, dim3(ntiles), dim3(GDR_BLOCK), st,
-                   (const uint2*)img->ranges, bin->values[bin->sorted], W, H, gx, ntiles, s->bg,
-                   (const float2*)g->xy, (const float4*)g->conic_opacity, (const float4*)g->rgb,
-                   img->final_T, img->n_contrib, gi->dL_dcolor, gi->dL_ddepth, gi->dL_dalpha,
-                   go->dL_dmeans2D, go->scratch, go->dL_dopacities);
-    else if (!render_v1())
-        GDR_LAUNCH(GDR_K_RENDER_BWD, render_bwd_v2_kernel, dim3(ntiles), dim3(GDR_BLOCK), st,
-                   (const uint2*)img->ranges, bin->values[bin->sorted], W, H, gx, ntiles, s->bg,
-                   (const float2*)g->xy, (const float4*)g->conic_opacity, (const float4*)g->rgb,
-                   img->final_T, img->n_contrib, gi->dL_dcolor, gi->dL_ddepth, gi->dL_dalpha,
-                   go->dL_dmeans2D, go->scratch, go->dL_dopacities);
-    else
     GDR_LAUNCH(GDR_K_RENDER_BWD, render_bwd_kernel, dim3(ntiles), dim3(GDR_BLOCK), st,
-                       (const uint2*)img->ranges, bin->values[bin->sorted], W, H, gx, ntiles, s->bg,
-                       (const float2*)g->xy, (const float4*)g->conic_opacity, (const float4*)g->rgb,
-                       img->final_T, img->n_contrib, gi->dL_dcolor, gi->dL_ddepth, gi->dL_dalpha,
-                       go->dL_dmeans2D, go->scratch, go->dL_dopacities);
+               (const uint2*)img->ranges, bin->values[bin->sorted], W, H, gx, ntiles, s->bg,
+               (const float2*)g->xy, (const float4*)g->conic_opacity, (const float4*)g->rgb,
+               img->final_T, img->n_contrib, gi->dL_dcolor, gi->dL_ddepth, gi->dL_dalpha,
+               go->scratch);
     return hipGetLastError();
 }
 

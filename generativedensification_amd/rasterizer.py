@@ -191,7 +191,7 @@ def backward_raw(st: _State, keep, raster_settings, radii, grad_color, grad_dept
             scales=None if use_cov else torch.empty(N, 3, **f32),
             rotations=None if use_cov else torch.empty(N, 4, **f32),
             cov3D_precomp=torch.empty(N, 6, **f32) if use_cov else None)
-        scratch = torch.empty(max(N, 1) * 8, **f32)
+        scratch = torch.empty(max(N, 1) * 16, **f32)
         gin = L.GdrGradInputs(gc.data_ptr(), _ptr(gd), _ptr(ga))
         gout = L.GdrGradOutputs(_ptr(g["means3D"]), _ptr(g["means2D"]), _ptr(g["shs"]),
                                 _ptr(g["colors_precomp"]), _ptr(g["opacities"]), _ptr(g["scales"]),

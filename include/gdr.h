@@ -128,7 +128,8 @@ typedef struct gdr_grad_inputs {
 /* Gradient outputs; every buffer is fully written (zeros for culled Gaussians), the
  * caller does not need to clear anything.  dL_dmeans2D is (N,4): columns 0-1 the signed
  * NDC-space gradient, columns 2-3 the sum over pixels of its absolute per-pixel terms
- * (network.py:876-878).  scratch: (N*8) floats used for conic/depth partials. */
+ * (network.py:876-878).  scratch: (N*16) floats — one 64-byte gradient record per Gaussian
+ * that K7 accumulates into (mean2D, conic, depth, colour, opacity partials). */
 typedef struct gdr_grad_outputs {
     float* dL_dmeans3D;   /* (N,3) */
     float* dL_dmeans2D;   /* (N,4) */
@@ -138,7 +139,7 @@ typedef struct gdr_grad_outputs {
     float* dL_dscales;    /* (N,3) or NULL when cov3D_precomp was used */
     float* dL_drotations; /* (N,4) or NULL when cov3D_precomp was used */
     float* dL_dcov3D;     /* (N,6) or NULL when scales/rotations were used */
-    float* scratch;       /* (N*8) floats, contents undefined on return */
+    float* scratch;       /* (N*16) floats, 64-byte aligned, contents undefined on return */
 } gdr_grad_outputs;
 
 /* ---- sizes and carving ---------------------------------------------------------- */
