@@ -81,6 +81,10 @@ def main():
     ap.add_argument("--views-per-gpu", type=int, default=0)
     ap.add_argument("--grad-allreduce", action="store_true",
                     help="also sum the Gaussian attribute grads over ranks each step (SURVEY §8e)")
+    ap.add_argument("--per-view", action="store_true",
+                    help="call render_img + backward once per view (the reference's loop) instead of render_views")
+    ap.add_argument("--unfused", action="store_true",
+                    help="torch activations before the rasterizer, op for op as lightning/renderer.py:225-230")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--traffic-bytes", type=float, default=None,
@@ -102,7 +106,7 @@ def main():
     from generativedensification_amd import _lib as L
     from generativedensification_amd.camera import orbit_cameras
     from generativedensification_amd.multiview import (allreduce_gaussian_grads, gather_view_losses,
-                                                       shard_views)
+                                                       render_views, shard_views)
     from generativedensification_amd.renderer import Renderer
     from generativedensification_amd.synthetic import make_scene, make_targets, view_loss
 
@@ -119,7 +123,7 @@ def main():
     mine = shard_views(total_views, rank, world)
     cams = [all_cams[i] for i in mine]
     targets = make_targets(total_views, h, w, wl["seed"])[list(mine)].to(dev)
-    renderer = Renderer(sh_degree=deg, white_background=True)
+    renderer = Renderer(sh_degree=deg, white_background=True, fused=not args.unfused)
     renderer.set_bg_color(torch.ones(3, device=dev))
     plist = list(params.values())
     L.load()
@@ -127,14 +131,21 @@ def main():
     def step():
         for p in plist:
             p.grad = None
-        losses = []
-        for j, cam in enumerate(cams):
-            out = renderer.render_img(cam, None, params["centers"], params["shs"], params["opacity"],
-                                      params["scales"], params["rotations"], dev)
-            loss = view_loss(out, targets[j])
-            loss.backward()
-            losses.append(loss.detach())
-        all_losses = gather_view_losses(torch.stack(losses), total_views)
+        if args.per_view:   # the reference's call pattern: one render_img + backward per view
+            losses = []
+            for j, cam in enumerate(cams):
+                out = renderer.render_img(cam, None, params["centers"], params["shs"], params["opacity"],
+                                          params["scales"], params["rotations"], dev)
+                loss = view_loss(out, targets[j])
+                loss.backward()
+                losses.append(loss.detach())
+            losses = torch.stack(losses)
+        else:               # multi-view entry point: all views of the shard in one rasterizer node
+            outs = render_views(renderer, cams, None, params, dev)
+            lv = torch.stack([view_loss(o, targets[j]) for j, o in enumerate(outs)])
+            lv.sum().backward()
+            losses = lv.detach()
+        all_losses = gather_view_losses(losses, total_views)
         if args.grad_allreduce:
             allreduce_gaussian_grads(plist)
         return all_losses
@@ -245,7 +256,9 @@ def main():
             "config": {"workload": f"{args.workload}: {wl['desc']}", "n_gaussians": n,
                        "views_per_gpu": vpg, "image": [h, w], "sh_degree": deg,
                        "num_rendered_per_view": int(d_mean), "parallelism": f"view-sharded x{world}",
-                       "grad_allreduce": bool(args.grad_allreduce)},
+                       "grad_allreduce": bool(args.grad_allreduce),
+                       "entry": ("render_img per view" if args.per_view else "render_views (all views of the shard, one node)")
+                       + (", torch activations" if args.unfused else ", activations fused into K1/K9")},
             "roofline": roofline, "cpu_baseline": cpu_baseline, "kernels": kernels,
             "loss_mean": float(last_losses.mean()),
         }

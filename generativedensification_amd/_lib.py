@@ -16,6 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GDR_LIB_PATH") or os.path.join(_HERE, "lib", "libgdr_hip.so")
 
 GDR_OK = 0
+GDR_IN_RAW_OPACITY, GDR_IN_RAW_SCALES, GDR_IN_RAW_ROTATIONS = 1, 2, 4
 GDR_ERR_WORKSPACE = -4
 
 
@@ -29,7 +30,8 @@ class GdrSettings(C.Structure):
 class GdrInputs(C.Structure):
     _fields_ = [("N", C.c_int32), ("M", C.c_int32), ("means3D", C.c_void_p), ("opacities", C.c_void_p),
                 ("shs", C.c_void_p), ("colors_precomp", C.c_void_p), ("scales", C.c_void_p),
-                ("rotations", C.c_void_p), ("cov3D_precomp", C.c_void_p)]
+                ("rotations", C.c_void_p), ("cov3D_precomp", C.c_void_p), ("flags", C.c_uint32),
+                ("reserved", C.c_uint32)]
 
 
 class GdrGeom(C.Structure):
@@ -60,7 +62,8 @@ class GdrGradInputs(C.Structure):
 class GdrGradOutputs(C.Structure):
     _fields_ = [("dL_dmeans3D", C.c_void_p), ("dL_dmeans2D", C.c_void_p), ("dL_dshs", C.c_void_p),
                 ("dL_dcolors", C.c_void_p), ("dL_dopacities", C.c_void_p), ("dL_dscales", C.c_void_p),
-                ("dL_drotations", C.c_void_p), ("dL_dcov3D", C.c_void_p), ("scratch", C.c_void_p)]
+                ("dL_drotations", C.c_void_p), ("dL_dcov3D", C.c_void_p), ("scratch", C.c_void_p),
+                ("accumulate", C.c_int32), ("reserved", C.c_int32)]
 
 
 # every symbol include/gdr.h declares, with its prototype
@@ -109,7 +112,7 @@ def load():
             fn = getattr(lib, name)  # AttributeError if the symbol is missing
             fn.restype = res
             fn.argtypes = args
-        if lib.gdr_abi_version() != 1:
+        if lib.gdr_abi_version() != 2:
             raise RuntimeError("libgdr_hip.so ABI version mismatch")
         _lib = lib
     return _lib

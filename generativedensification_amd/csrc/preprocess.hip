@@ -121,6 +121,16 @@ __device__ __forceinline__ void quat_to_R(float r, float x, float y, float z, fl
     R[8] = 1.f - 2.f * (x * x + y * y);
 }
 
+// Activations of the render adaptor (lightning/renderer.py:225-230: sigmoid / exp / F.normalize),
+// optionally folded into K1/K9 (gdr_inputs.flags) so the caller's raw tensors are read once.
+__device__ __forceinline__ float act_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }
+__device__ __forceinline__ float4 act_normalize(float4 q, float* inv_norm) {
+    const float n = sqrtf((q.x * q.x + q.y * q.y) + (q.z * q.z + q.w * q.w));
+    const float inv = 1.f / fmaxf(n, 1e-12f);  // F.normalize(eps=1e-12)
+    *inv_norm = inv;
+    return make_float4(q.x * inv, q.y * inv, q.z * inv, q.w * inv);
+}
+
 // EWA projection pieces shared by forward and backward (Appendix A.1-4).
 struct Ewa {
     float tx, ty, tz, xmul, ymul;
@@ -169,7 +179,7 @@ __global__ __launch_bounds__(GDR_BLOCK) void preprocess_fwd_kernel(
     float tany, float focal_x, float focal_y, int32_t* __restrict__ radii, float* __restrict__ g_depths,
     float2* __restrict__ g_xy, float4* __restrict__ g_conic_opacity, float4* __restrict__ g_rgb,
     float* __restrict__ g_cov3D, int4* __restrict__ g_rect, uint32_t* __restrict__ g_tiles,
-    uint8_t* __restrict__ g_clamped, uint32_t* __restrict__ block_sums) {
+    uint8_t* __restrict__ g_clamped, uint32_t* __restrict__ block_sums, uint32_t flags) {
     Cam cam;
     load_cam(cam, view, proj, campos);
     const int i = blockIdx.x * GDR_BLOCK + threadIdx.x;
@@ -202,11 +212,13 @@ __global__ __launch_bounds__(GDR_BLOCK) void preprocess_fwd_kernel(
 #pragma unroll
                 for (int k = 0; k < 6; ++k) c6[k] = cov3D_precomp[6 * i + k];
             } else {
-                const float4 q = reinterpret_cast<const float4*>(rotations)[i];
+                float4 q = reinterpret_cast<const float4*>(rotations)[i];
+                float sc0 = scales[3 * i], sc1 = scales[3 * i + 1], sc2 = scales[3 * i + 2];
+                if (flags & GDR_IN_RAW_ROTATIONS) { float inv_n; q = act_normalize(q, &inv_n); }
+                if (flags & GDR_IN_RAW_SCALES) { sc0 = expf(sc0); sc1 = expf(sc1); sc2 = expf(sc2); }
                 float R[9], Mm[9];
                 quat_to_R(q.x, q.y, q.z, q.w, R);
-                const float s[3] = {scale_modifier * scales[3 * i], scale_modifier * scales[3 * i + 1],
-                                    scale_modifier * scales[3 * i + 2]};
+                const float s[3] = {scale_modifier * sc0, scale_modifier * sc1, scale_modifier * sc2};
 #pragma unroll
                 for (int r = 0; r < 3; ++r)
 #pragma unroll
@@ -240,7 +252,8 @@ __global__ __launch_bounds__(GDR_BLOCK) void preprocess_fwd_kernel(
                     rad = r_i;
                     depth = pvz;
                     pxy = make_float2(sx, sy);
-                    con_o = make_float4(e.c * det_inv, -e.b * det_inv, e.a * det_inv, opacities[i]);
+                    const float op = (flags & GDR_IN_RAW_OPACITY) ? act_sigmoid(opacities[i]) : opacities[i];
+                    con_o = make_float4(e.c * det_inv, -e.b * det_inv, e.a * det_inv, op);
                     if (colors_precomp) {
                         rgbd.x = colors_precomp[3 * i];
                         rgbd.y = colors_precomp[3 * i + 1];
@@ -315,13 +328,15 @@ __global__ __launch_bounds__(GDR_BLOCK) void preprocess_bwd_kernel(
     const float* __restrict__ campos, int W, int H, float tanx, float tany, float focal_x,
     float focal_y, const float4* __restrict__ grad_rec, float4* __restrict__ dL_dmean2D,
     float* __restrict__ dL_dopacity, float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dcov3D, float* __restrict__ dL_dsh,
-    float* __restrict__ dL_dcolors, float* __restrict__ dL_dscale, float4* __restrict__ dL_drot) {
+    float* __restrict__ dL_dcolors, float* __restrict__ dL_dscale, float4* __restrict__ dL_drot,
+    const float4* __restrict__ g_conic_opacity, uint32_t flags, int accumulate) {
     Cam cam;
     load_cam(cam, view, proj, campos);
     const int i = blockIdx.x * GDR_BLOCK + threadIdx.x;
     if (i >= N) return;
     constexpr int NB = (DEG + 1) * (DEG + 1);
     const bool vis = radii[i] > 0;
+    if (accumulate && !vis) return;  // += 0 everywhere: nothing to do for a culled Gaussian
     float dmean[3] = {0.f, 0.f, 0.f};
     float dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float dscale[3] = {0.f, 0.f, 0.f};
@@ -333,8 +348,21 @@ __global__ __launch_bounds__(GDR_BLOCK) void preprocess_bwd_kernel(
         const float4 g2 = grad_rec[4 * i];          // mean2D x, y, |x|, |y|
         const float4 gconic = grad_rec[4 * i + 1];  // conic.xyz, ddepth
         const float4 gcolor = grad_rec[4 * i + 2];  // rgb, opacity
-        dL_dmean2D[i] = g2;
-        dL_dopacity[i] = gcolor.w;
+        {
+            float dop = gcolor.w;
+            if (flags & GDR_IN_RAW_OPACITY) {  // d sigmoid = o (1 - o), o as stored by K1
+                const float o = g_conic_opacity[i].w;
+                dop = dop * (o * (1.f - o));
+            }
+            if (accumulate) {
+                const float4 old = dL_dmean2D[i];
+                dL_dmean2D[i] = make_float4(old.x + g2.x, old.y + g2.y, old.z + g2.z, old.w + g2.w);
+                dL_dopacity[i] += dop;
+            } else {
+                dL_dmean2D[i] = g2;
+                dL_dopacity[i] = dop;
+            }
+        }
         float c6[6];
 #pragma unroll
         for (int k = 0; k < 6; ++k) c6[k] = cov3D[6 * i + k];
@@ -407,30 +435,58 @@ __global__ __launch_bounds__(GDR_BLOCK) void preprocess_bwd_kernel(
 #pragma unroll
                 for (int ch = 0; ch < 3; ++ch) {
                     const float sg = sh[3 * k + ch] * g[ch];
-                    dsh[3 * k + ch] = bk[k] * g[ch];
                     ddx += bx[k] * sg;
                     ddy += by[k] * sg;
                     ddz += bz[k] * sg;
                 }
             }
-            for (int k = NB; k < M; ++k)
-                for (int ch = 0; ch < 3; ++ch) dsh[3 * k + ch] = 0.f;
+            // dL/dsh[k][ch] = b_k g_ch: written (or added) as whole 16-byte chunks when the SH row
+            // of a Gaussian is 16-byte aligned (M*12 % 16 == 0: deg 1 and 3), else scalar
+            if ((3 * NB) % 4 == 0 && M == NB) {
+                float4* d4 = reinterpret_cast<float4*>(dsh);
+#pragma unroll
+                for (int c = 0; c < (3 * NB) / 4; ++c) {
+                    float4 v = make_float4(bk[(4 * c) / 3] * g[(4 * c) % 3], bk[(4 * c + 1) / 3] * g[(4 * c + 1) % 3],
+                                           bk[(4 * c + 2) / 3] * g[(4 * c + 2) % 3], bk[(4 * c + 3) / 3] * g[(4 * c + 3) % 3]);
+                    if (accumulate) {
+                        const float4 o = d4[c];
+                        v = make_float4(v.x + o.x, v.y + o.y, v.z + o.z, v.w + o.w);
+                    }
+                    d4[c] = v;
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < NB; ++k)
+#pragma unroll
+                    for (int ch = 0; ch < 3; ++ch) {
+                        if (accumulate) dsh[3 * k + ch] += bk[k] * g[ch];
+                        else dsh[3 * k + ch] = bk[k] * g[ch];
+                    }
+                if (!accumulate)
+                    for (int k = NB; k < M; ++k)
+                        for (int ch = 0; ch < 3; ++ch) dsh[3 * k + ch] = 0.f;
+            }
             const float dot = ux * ddx + uy * ddy + uz * ddz;
             dmean[0] += (ddx - ux * dot) * inv;
             dmean[1] += (ddy - uy * dot) * inv;
             dmean[2] += (ddz - uz * dot) * inv;
         } else if (dL_dcolors) {
-            dL_dcolors[3 * i] = gcolor.x;
-            dL_dcolors[3 * i + 1] = gcolor.y;
-            dL_dcolors[3 * i + 2] = gcolor.z;
+            if (accumulate) {
+                dL_dcolors[3 * i] += gcolor.x; dL_dcolors[3 * i + 1] += gcolor.y; dL_dcolors[3 * i + 2] += gcolor.z;
+            } else {
+                dL_dcolors[3 * i] = gcolor.x; dL_dcolors[3 * i + 1] = gcolor.y; dL_dcolors[3 * i + 2] = gcolor.z;
+            }
         }
         // cov3D -> scale / quaternion (A.5-v)
         if (!cov_precomp) {
-            const float4 q = reinterpret_cast<const float4*>(rotations)[i];
+            float4 q = reinterpret_cast<const float4*>(rotations)[i];
+            float sc0 = scales[3 * i], sc1 = scales[3 * i + 1], sc2 = scales[3 * i + 2];
+            float inv_n = 1.f;
+            if (flags & GDR_IN_RAW_ROTATIONS) q = act_normalize(q, &inv_n);
+            if (flags & GDR_IN_RAW_SCALES) { sc0 = expf(sc0); sc1 = expf(sc1); sc2 = expf(sc2); }
             float R[9];
             quat_to_R(q.x, q.y, q.z, q.w, R);
-            const float s[3] = {scale_modifier * scales[3 * i], scale_modifier * scales[3 * i + 1],
-                                scale_modifier * scales[3 * i + 2]};
+            const float s[3] = {scale_modifier * sc0, scale_modifier * sc1, scale_modifier * sc2};
             const float Gs[9] = {dcov[0], 0.5f * dcov[1], 0.5f * dcov[2], 0.5f * dcov[1], dcov[3],
                                  0.5f * dcov[4], 0.5f * dcov[2], 0.5f * dcov[4], dcov[5]};
             float dR[9];
@@ -455,6 +511,14 @@ __global__ __launch_bounds__(GDR_BLOCK) void preprocess_bwd_kernel(
             drot.z = 2.f * (-2.f * qy * G_(0, 0) + qx * G_(0, 1) + qr * G_(0, 2) + qx * G_(1, 0) + qz * G_(1, 2) - qr * G_(2, 0) + qz * G_(2, 1) - 2.f * qy * G_(2, 2));
             drot.w = 2.f * (-2.f * qz * G_(0, 0) - qr * G_(0, 1) + qx * G_(0, 2) + qr * G_(1, 0) - 2.f * qz * G_(1, 1) + qy * G_(1, 2) + qx * G_(2, 0) + qy * G_(2, 1));
 #undef G_
+            if (flags & GDR_IN_RAW_SCALES) {  // d exp = s
+                dscale[0] *= sc0; dscale[1] *= sc1; dscale[2] *= sc2;
+            }
+            if (flags & GDR_IN_RAW_ROTATIONS) {  // d (q/|q|) = (I - q^ q^T) / |q|
+                const float dot = (q.x * drot.x + q.y * drot.y) + (q.z * drot.z + q.w * drot.w);
+                drot = make_float4((drot.x - q.x * dot) * inv_n, (drot.y - q.y * dot) * inv_n,
+                                   (drot.z - q.z * dot) * inv_n, (drot.w - q.w * dot) * inv_n);
+            }
         }
     } else {
         dL_dmean2D[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -464,6 +528,23 @@ __global__ __launch_bounds__(GDR_BLOCK) void preprocess_bwd_kernel(
         if (colors_precomp && dL_dcolors) {
             dL_dcolors[3 * i] = 0.f; dL_dcolors[3 * i + 1] = 0.f; dL_dcolors[3 * i + 2] = 0.f;
         }
+    }
+    if (accumulate) {
+        dL_dmeans3D[3 * i] += dmean[0];
+        dL_dmeans3D[3 * i + 1] += dmean[1];
+        dL_dmeans3D[3 * i + 2] += dmean[2];
+        if (cov_precomp) {
+            if (dL_dcov3D)
+#pragma unroll
+                for (int k = 0; k < 6; ++k) dL_dcov3D[6 * i + k] += dcov[k];
+        } else {
+            dL_dscale[3 * i] += dscale[0];
+            dL_dscale[3 * i + 1] += dscale[1];
+            dL_dscale[3 * i + 2] += dscale[2];
+            const float4 old = dL_drot[i];
+            dL_drot[i] = make_float4(old.x + drot.x, old.y + drot.y, old.z + drot.z, old.w + drot.w);
+        }
+        return;
     }
     dL_dmeans3D[3 * i] = dmean[0];
     dL_dmeans3D[3 * i + 1] = dmean[1];
@@ -512,7 +593,7 @@ hipError_t launch_preprocess_fwd(const gdr_settings* s, const gdr_inputs* in, co
                in->cov3D_precomp, s->viewmatrix, s->projmatrix, s->campos, W, H, s->tanfovx,
                s->tanfovy, focal_x, focal_y, radii, g->depths, (float2*)g->xy,
                (float4*)g->conic_opacity, (float4*)g->rgb, g->cov3D, (int4*)g->rect,
-               g->tiles_touched, g->clamped, g->block_sums);
+               g->tiles_touched, g->clamped, g->block_sums, in->flags);
     return hipGetLastError();
 }
 
@@ -531,7 +612,7 @@ hipError_t launch_preprocess_bwd(const gdr_settings* s, const gdr_inputs* in, co
                s->projmatrix, s->campos, W, H, s->tanfovx, s->tanfovy, focal_x, focal_y,
                (const float4*)go->scratch, (float4*)go->dL_dmeans2D, go->dL_dopacities, go->dL_dmeans3D,
                go->dL_dcov3D, go->dL_dshs, go->dL_dcolors, go->dL_dscales,
-               (float4*)go->dL_drotations);
+               (float4*)go->dL_drotations, (const float4*)g->conic_opacity, in->flags, go->accumulate);
     return hipGetLastError();
 }
 

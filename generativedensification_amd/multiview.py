@@ -27,6 +27,10 @@ def render_views(renderer, cams: Sequence, bg_colors, gaussians: dict, device, p
                  screenspace_points=None):
     """One `render_img` per camera (same call the reference loop makes); bg_colors may be
     None (keep the renderer's), one tensor, or one per view (network.py:829-830)."""
+    if hasattr(renderer, "render_views") and getattr(renderer, "fused", False) and gaussians["centers"].is_cuda:
+        return renderer.render_views(cams, bg_colors, gaussians["centers"], gaussians["shs"], gaussians["opacity"],
+                                     gaussians["scales"], gaussians["rotations"], device, prex=prex,
+                                     screenspace_points=screenspace_points)
     outs = []
     for j, cam in enumerate(cams):
         if bg_colors is not None:

@@ -111,9 +111,9 @@ def _settings_struct(rs: GaussianRasterizationSettings, dev, keep: list) -> L.Gd
                          campos.data_ptr())
 
 
-def _inputs_struct(N, M, means3D, opacities, sh, colors_precomp, scales, rotations, cov3Ds) -> L.GdrInputs:
+def _inputs_struct(N, M, means3D, opacities, sh, colors_precomp, scales, rotations, cov3Ds, flags=0) -> L.GdrInputs:
     return L.GdrInputs(N, M, _ptr(means3D), _ptr(opacities), _ptr(sh), _ptr(colors_precomp), _ptr(scales),
-                       _ptr(rotations), _ptr(cov3Ds))
+                       _ptr(rotations), _ptr(cov3Ds), int(flags), 0)
 
 
 def _stream():
@@ -195,7 +195,7 @@ def backward_raw(st: _State, keep, raster_settings, radii, grad_color, grad_dept
         gin = L.GdrGradInputs(gc.data_ptr(), _ptr(gd), _ptr(ga))
         gout = L.GdrGradOutputs(_ptr(g["means3D"]), _ptr(g["means2D"]), _ptr(g["shs"]),
                                 _ptr(g["colors_precomp"]), _ptr(g["opacities"]), _ptr(g["scales"]),
-                                _ptr(g["rotations"]), _ptr(g["cov3D_precomp"]), scratch.data_ptr())
+                                _ptr(g["rotations"]), _ptr(g["cov3D_precomp"]), scratch.data_ptr(), 0, 0)
         L.check(lib.gdr_backward(C.byref(s), C.byref(inp), C.byref(st.geom), C.byref(st.bin),
                                  C.byref(st.img), st.D, _ptr(radii), C.byref(gin), C.byref(gout),
                                  _stream()), "gdr_backward")
@@ -234,6 +234,112 @@ class _RasterizeGaussians(torch.autograd.Function):
                  g["rotations"], g["cov3D_precomp"]]
         grads = [None if t is None else (t if t.dtype == dt else t.to(dt)) for t, dt in zip(grads, ctx.in_dtypes)]
         return (*grads, None)
+
+
+# --------------------------------------------------------------------------------------------
+# Multi-view fused entry point.  One autograd node renders V views of
+# ONE Gaussian set: the adaptor's activations (sigmoid / exp / normalize, renderer.py:225-230)
+# run inside K1/K9, the V values of num_rendered are read back with ONE host sync, and the
+# per-Gaussian gradients are summed over the views inside K9 (accumulate mode) instead of V
+# separate autograd accumulation passes.  Same arithmetic as V calls of rasterize_gaussians.
+# --------------------------------------------------------------------------------------------
+RAW_ALL = L.GDR_IN_RAW_OPACITY | L.GDR_IN_RAW_SCALES | L.GDR_IN_RAW_ROTATIONS
+
+
+class _RenderViews(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, opacities, scales, rotations, settings_list, flags):
+        lib = L.load()
+        _require_hip(means3D, "means3D")
+        dev = means3D.device
+        in_dtypes = tuple(t.dtype for t in (means3D, means2D, sh, opacities, scales, rotations))
+        means3D, sh = _f32(means3D, dev), _f32(sh, dev)
+        opacities, scales, rotations = _f32(opacities, dev), _f32(scales, dev), _f32(rotations, dev)
+        N, M, V = int(means3D.shape[0]), int(sh.shape[1]), len(settings_list)
+        H, W = int(settings_list[0].image_height), int(settings_list[0].image_width)
+        if any(int(rs.image_height) != H or int(rs.image_width) != W for rs in settings_list):
+            raise RuntimeError("render_views: all views must share one image size")
+        e = torch.empty(0, dtype=torch.float32, device=dev)
+        keep = [means3D, opacities, sh, e, scales, rotations, e]
+        f32, u8 = dict(dtype=torch.float32, device=dev), dict(dtype=torch.uint8, device=dev)
+        colors, depths, alphas = torch.empty(V, 3, H, W, **f32), torch.empty(V, 1, H, W, **f32), torch.empty(V, 1, H, W, **f32)
+        radii = torch.empty(V, N, dtype=torch.int32, device=dev)
+        states, structs = [], []
+        with torch.cuda.device(dev):
+            stream = _stream()
+            inp = _inputs_struct(N, M, means3D, opacities, sh, e, scales, rotations, e, flags)
+            for v, rs in enumerate(settings_list):
+                s = _settings_struct(rs, dev, keep)
+                st = _State()
+                st.N, st.M, st.H, st.W = N, M, H, W
+                st.geom_buf = torch.empty(lib.gdr_geom_bytes(N), **u8)
+                st.img_buf = torch.empty(lib.gdr_image_bytes(H, W), **u8)
+                st.geom, st.bin, st.img = L.GdrGeom(), L.GdrBinning(), L.GdrImage()
+                L.check(lib.gdr_geom_carve(st.geom_buf.data_ptr(), N, C.byref(st.geom)), "gdr_geom_carve")
+                L.check(lib.gdr_image_carve(st.img_buf.data_ptr(), H, W, C.byref(st.img)), "gdr_image_carve")
+                L.check(lib.gdr_preprocess_forward(C.byref(s), C.byref(inp), C.byref(st.geom), _ptr(radii[v]),
+                                                   None, stream), "gdr_preprocess_forward")
+                states.append(st)
+                structs.append(s)
+            # ONE host read-back for all V views
+            d_dev = torch.cat([st._view(st.geom_buf, st.geom.num_rendered, torch.int32, 1) for st in states])
+            d_host = d_dev.cpu().tolist()
+            for v, (st, s) in enumerate(zip(states, structs)):
+                st.D = int(d_host[v]) & 0xFFFFFFFF
+                st.bin_buf = torch.empty(lib.gdr_binning_bytes(st.D), **u8)
+                L.check(lib.gdr_binning_carve(st.bin_buf.data_ptr(), st.D, C.byref(st.bin)), "gdr_binning_carve")
+                out = L.GdrOutputs(colors[v].data_ptr(), depths[v].data_ptr(), alphas[v].data_ptr(), _ptr(radii[v]))
+                L.check(lib.gdr_render_forward(C.byref(s), C.byref(inp), C.byref(st.geom), C.byref(st.bin),
+                                               C.byref(st.img), st.D, C.byref(out), stream), "gdr_render_forward")
+        ctx.states, ctx.keep, ctx.settings_list, ctx.flags = states, keep, settings_list, flags
+        ctx.radii, ctx.in_dtypes, ctx.means2D_shape = radii, in_dtypes, tuple(means2D.shape)
+        ctx.mark_non_differentiable(radii)
+        return colors, radii, depths, alphas
+
+    @staticmethod
+    def backward(ctx, g_colors, g_radii, g_depths, g_alphas):
+        lib = L.load()
+        means3D, opacities, sh, e, scales, rotations, _ = ctx.keep[:7]
+        dev = means3D.device
+        st0 = ctx.states[0]
+        N, M = st0.N, st0.M
+        f32 = dict(dtype=torch.float32, device=dev)
+        g = dict(means3D=torch.empty(N, 3, **f32), means2D=torch.empty(N, 4, **f32), shs=torch.empty(N, M, 3, **f32),
+                 opacities=torch.empty(N, 1, **f32), scales=torch.empty(N, 3, **f32), rotations=torch.empty(N, 4, **f32))
+        scratch = torch.empty(max(N, 1) * 16, **f32)
+        with torch.cuda.device(dev):
+            keep2: list = []
+            stream = _stream()
+            inp = _inputs_struct(N, M, means3D, opacities, sh, e, scales, rotations, e, ctx.flags)
+            for v, (st, rs) in enumerate(zip(ctx.states, ctx.settings_list)):
+                s = _settings_struct(rs, dev, keep2)
+                gc = _f32(g_colors[v], dev)
+                gd = None if g_depths is None else _f32(g_depths[v], dev)
+                ga = None if g_alphas is None else _f32(g_alphas[v], dev)
+                keep2 += [gc, gd, ga]
+                gin = L.GdrGradInputs(gc.data_ptr(), _ptr(gd), _ptr(ga))
+                gout = L.GdrGradOutputs(_ptr(g["means3D"]), _ptr(g["means2D"]), _ptr(g["shs"]), None,
+                                        _ptr(g["opacities"]), _ptr(g["scales"]), _ptr(g["rotations"]), None,
+                                        scratch.data_ptr(), 1 if v > 0 else 0, 0)
+                L.check(lib.gdr_backward(C.byref(s), C.byref(inp), C.byref(st.geom), C.byref(st.bin),
+                                         C.byref(st.img), st.D, _ptr(ctx.radii[v]), C.byref(gin), C.byref(gout),
+                                         stream), "gdr_backward")
+        gm2 = g["means2D"]
+        cols = ctx.means2D_shape[1] if len(ctx.means2D_shape) == 2 else 4
+        if cols == 3:
+            gm2 = torch.cat([gm2[:, :2], torch.zeros_like(gm2[:, :1])], dim=1)
+        elif cols != 4:
+            gm2 = gm2[:, :cols].contiguous()
+        grads = [g["means3D"], gm2, g["shs"], g["opacities"], g["scales"], g["rotations"]]
+        grads = [t if t.dtype == dt else t.to(dt) for t, dt in zip(grads, ctx.in_dtypes)]
+        return (*grads, None, None)
+
+
+def render_views_raw(means3D, means2D, sh, opacities, scales, rotations, settings_list, flags=RAW_ALL):
+    """V views of one Gaussian set in one autograd node.  With flags=RAW_ALL the opacity /
+    scale / rotation tensors are the adaptor's RAW (pre-activation) tensors.
+    Returns (colors (V,3,H,W), radii (V,N) int32, depths (V,1,H,W), alphas (V,1,H,W))."""
+    return _RenderViews.apply(means3D, means2D, sh, opacities, scales, rotations, tuple(settings_list), int(flags))
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,

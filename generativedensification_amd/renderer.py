@@ -19,12 +19,16 @@ import math
 import torch
 from torch import nn
 
-from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer, render_views_raw
 
 
 class Renderer(nn.Module):
-    def __init__(self, sh_degree: int = 3, white_background: bool = True, radius: float = 1):
+    def __init__(self, sh_degree: int = 3, white_background: bool = True, radius: float = 1, fused: bool = True):
         super().__init__()
+        # fused=True: render_img/render_views hand the RAW tensors to the rasterizer, which applies
+        # sigmoid/exp/normalize inside its per-Gaussian kernels (same maths, fewer HBM passes);
+        # fused=False: op-for-op the reference sequence (torch activations, then the rasterizer).
+        self.fused = fused
         self.sh_degree = sh_degree
         self.white_background = white_background
         self.radius = radius
@@ -53,8 +57,36 @@ class Renderer(nn.Module):
         )
         return GaussianRasterizer(raster_settings=settings)
 
+    def render_views(self, cams, bg_colors, centers, shs, opacity, scales, rotations, device, prex="",
+                     screenspace_points=None):
+        """All `cams` of one Gaussian set in ONE rasterizer node (replaces the per-view loops of
+        network.py:826-838 / 848-856 / 964-972 without changing what each view returns).
+        bg_colors: None (keep self.bg_color), one tensor, or one per view (network.py:829-830).
+        Returns a list with the same dict render_img returns for each view."""
+        sets = []
+        for j, cam in enumerate(cams):
+            if bg_colors is not None:
+                self.set_bg_color(bg_colors[j] if isinstance(bg_colors, (list, tuple)) else bg_colors)
+            sets.append(self.set_rasterizer(cam, device=device).raster_settings)
+        if screenspace_points is None:
+            screenspace_points = torch.zeros((centers.shape[0], 4), dtype=centers.dtype,
+                                             requires_grad=True, device=device) + 0
+        try:
+            screenspace_points.retain_grad()
+        except Exception:
+            pass
+        images, radii, depths, alphas = render_views_raw(centers, screenspace_points, shs, opacity, scales,
+                                                         rotations, sets)
+        images = images.clamp(0, 1)
+        return [{f"image{prex}": images[v].permute(1, 2, 0), f"depth{prex}": depths[v].permute(1, 2, 0),
+                 f"acc_map{prex}": alphas[v].squeeze(0)} for v in range(len(sets))]
+
     def render_img(self, cam, rays, centers, shs, opacity, scales, rotations, device,
                    cov3D_precomp=None, prex="", screenspace_points=None):
+        if (self.fused and cov3D_precomp is None and scales is not None and rotations is not None
+                and centers.is_cuda):
+            return self.render_views([cam], None, centers, shs, opacity, scales, rotations, device, prex=prex,
+                                     screenspace_points=screenspace_points)[0]
         rasterizer = self.set_rasterizer(cam, device=device)
         opacity = self.opacity_activation(opacity)
         if scales is not None:

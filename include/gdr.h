@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define GDR_ABI_VERSION 1
+#define GDR_ABI_VERSION 2
 
 #define GDR_OK 0
 #define GDR_ERR_INVALID_ARG (-1)  /* NULL / inconsistent arguments                     */
@@ -79,7 +79,17 @@ typedef struct gdr_inputs {
     const float* scales;         /* (N,3)   or NULL, activated */
     const float* rotations;      /* (N,4)   or NULL, (r,x,y,z), used as given */
     const float* cov3D_precomp;  /* (N,6)   or NULL */
+    uint32_t flags;              /* GDR_IN_RAW_*: fold the adaptor's activations into K1/K9 */
+    uint32_t reserved;
 } gdr_inputs;
+
+/* gdr_inputs.flags — the render adaptor (lightning/renderer.py:225-230) applies sigmoid to the
+ * opacity logits, exp to the log-scales and F.normalize to the quaternions before calling the
+ * rasterizer.  With a flag set the corresponding pointer holds the RAW tensor, the activation
+ * runs inside K1 and its derivative inside K9 (the returned gradient is w.r.t. the raw tensor). */
+#define GDR_IN_RAW_OPACITY 1u
+#define GDR_IN_RAW_SCALES 2u
+#define GDR_IN_RAW_ROTATIONS 4u
 
 /* Geometry state written by the forward and re-read by the backward
  * (upstream "geomBuffer").  Carved from one caller allocation by gdr_geom_carve. */
@@ -140,6 +150,9 @@ typedef struct gdr_grad_outputs {
     float* dL_drotations; /* (N,4) or NULL when cov3D_precomp was used */
     float* dL_dcov3D;     /* (N,6) or NULL when scales/rotations were used */
     float* scratch;       /* (N*16) floats, 64-byte aligned, contents undefined on return */
+    int32_t accumulate;   /* !=0: ADD into the output buffers (sum over views of one Gaussian
+                           * set, network.py:826-838) instead of overwriting them */
+    int32_t reserved;
 } gdr_grad_outputs;
 
 /* ---- sizes and carving ---------------------------------------------------------- */
