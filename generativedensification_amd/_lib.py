@@ -47,7 +47,8 @@ class GdrBinning(C.Structure):
 
 
 class GdrImage(C.Structure):
-    _fields_ = [("ranges", C.c_void_p), ("n_contrib", C.c_void_p), ("final_T", C.c_void_p)]
+    _fields_ = [("ranges", C.c_void_p), ("n_contrib", C.c_void_p), ("final_T", C.c_void_p),
+                ("tile_order", C.c_void_p)]
 
 
 class GdrOutputs(C.Structure):

@@ -29,6 +29,7 @@ enum {
     GDR_K_RENDER_BWD,
     GDR_K_PREPROCESS_BWD,
     GDR_K_MARK_VISIBLE,
+    GDR_K_TILE_ORDER,
     GDR_K_COUNT
 };
 
@@ -77,6 +78,7 @@ hipError_t launch_duplicate(const gdr_geom* g, int N, int W, int H, const int32_
 hipError_t launch_sort(gdr_binning* bin, uint64_t D, int nbits, hipStream_t st);
 hipError_t launch_ranges(const gdr_binning* bin, uint64_t D, const gdr_image* img, int tiles,
                          hipStream_t st);
+hipError_t launch_tile_order(const gdr_image* img, int tiles, hipStream_t st);
 hipError_t launch_render_fwd(const gdr_settings* s, const gdr_geom* g, const gdr_binning* bin,
                              const gdr_image* img, const gdr_outputs* out, hipStream_t st);
 hipError_t launch_render_bwd(const gdr_settings* s, const gdr_geom* g, const gdr_binning* bin,

@@ -120,6 +120,7 @@ typedef struct gdr_image {
     uint32_t* ranges;    /* (tiles,2) [first,last) into the sorted list     */
     uint32_t* n_contrib; /* (H*W) 1-based index of the last contributor     */
     float* final_T;      /* (H*W) transmittance after the last contributor  */
+    uint32_t* tile_order; /* (tiles) tile ids, longest sorted list first (launch order of K6/K7) */
 } gdr_image;
 
 typedef struct gdr_outputs {

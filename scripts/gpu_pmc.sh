@@ -1,0 +1,32 @@
+#!/bin/bash
+# GPU box: rocprofv3 PMC passes (counters only + kernel-trace) on a short bench run; summarised per kernel.
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+mkdir -p gpurun_out
+TAG=${1:-pmc}
+R=$PWD
+ARGS="--steps 1 --warmup 1 --no-cpu-baseline --no-roofline ${BENCH_ARGS}"
+i=0
+for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD" \
+           "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_WR" \
+           "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum"; do
+  i=$((i+1))
+  (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $R/gpurun_out/${TAG}_$i -o p -- python $R/bench.py $ARGS > $R/gpurun_out/${TAG}_$i.log 2>&1)
+done
+python - <<PY
+import csv, glob, collections, json
+out = collections.defaultdict(lambda: collections.defaultdict(float))
+cnt = collections.defaultdict(lambda: collections.defaultdict(int))
+for f in glob.glob("gpurun_out/${TAG}_*/**/*counter_collection.csv", recursive=True):
+    for row in csv.DictReader(open(f)):
+        k = row["Kernel_Name"]
+        if "gdr::" not in k: continue
+        name = k.split("gdr::(anonymous namespace)::")[-1].split("(")[0].split("<")[0]
+        c = row["Counter_Name"]; v = float(row["Counter_Value"])
+        out[name][c] += v; cnt[name][c] += 1
+res = {k: {c: out[k][c] / max(cnt[k][c], 1) for c in out[k]} for k in out}
+res["_launches"] = {k: max(cnt[k].values()) for k in cnt}
+json.dump(res, open("gpurun_out/${TAG}_summary.json", "w"), indent=1)
+for k in res:
+    if k.startswith("_"): continue
+    print(k, {c: (round(v) if v > 100 else round(v, 3)) for c, v in sorted(res[k].items())})
+PY
