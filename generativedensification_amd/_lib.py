@@ -17,6 +17,7 @@ LIB_PATH = os.environ.get("GDR_LIB_PATH") or os.path.join(_HERE, "lib", "libgdr_
 
 GDR_OK = 0
 GDR_IN_RAW_OPACITY, GDR_IN_RAW_SCALES, GDR_IN_RAW_ROTATIONS = 1, 2, 4
+GDR_MAX_VIEWS = 8
 GDR_ERR_WORKSPACE = -4
 
 
@@ -88,6 +89,13 @@ _PROTOS = {
     "gdr_backward": (C.c_int, [C.POINTER(GdrSettings), C.POINTER(GdrInputs), C.POINTER(GdrGeom),
                                C.POINTER(GdrBinning), C.POINTER(GdrImage), C.c_uint64, C.c_void_p,
                                C.POINTER(GdrGradInputs), C.POINTER(GdrGradOutputs), C.c_void_p]),
+    "gdr_preprocess_forward_views": (C.c_int, [C.c_int32, C.POINTER(GdrSettings), C.POINTER(GdrInputs),
+                                               C.POINTER(GdrGeom), C.POINTER(C.c_void_p), C.c_void_p]),
+    "gdr_render_backward": (C.c_int, [C.POINTER(GdrSettings), C.c_int32, C.POINTER(GdrGeom), C.POINTER(GdrBinning),
+                                      C.POINTER(GdrImage), C.POINTER(GdrGradInputs), C.c_void_p, C.c_void_p]),
+    "gdr_preprocess_backward_views": (C.c_int, [C.c_int32, C.POINTER(GdrSettings), C.POINTER(GdrInputs),
+                                                C.POINTER(GdrGeom), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                                C.POINTER(GdrGradOutputs), C.c_void_p]),
     "gdr_profile_enable": (C.c_int, [C.c_int]),
     "gdr_profile_collect": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int32, C.c_int32]),
     "gdr_kernel_count": (C.c_int, []),

@@ -277,6 +277,77 @@ int gdr_backward(const gdr_settings* s, const gdr_inputs* in, const gdr_geom* ge
     return GDR_OK;
 }
 
+int gdr_preprocess_forward_views(int32_t V, const gdr_settings* s, const gdr_inputs* in,
+                                 const gdr_geom* geoms, int32_t* const* radii, void* stream) {
+    if (V < 1 || V > GDR_MAX_VIEWS) { set_error("views: V out of range", hipSuccess); return GDR_ERR_UNSUPPORTED; }
+    if (!s || !in || !geoms || !radii) { set_error("views: NULL argument", hipSuccess); return GDR_ERR_INVALID_ARG; }
+    for (int v = 0; v < V; ++v) {
+        int rc = check_common(&s[v], in);
+        if (rc) return rc;
+        if (s[v].image_width != s[0].image_width || s[v].image_height != s[0].image_height ||
+            s[v].sh_degree != s[0].sh_degree || s[v].scale_modifier != s[0].scale_modifier) {
+            set_error("views: image size / sh_degree / scale_modifier must match", hipSuccess);
+            return GDR_ERR_INVALID_ARG;
+        }
+        if (in->N > 0 && !radii[v]) { set_error("views: radii NULL", hipSuccess); return GDR_ERR_INVALID_ARG; }
+    }
+    if (in->N > 0 && (!in->shs || !in->scales || !in->rotations)) {
+        set_error("views: needs shs + scales + rotations", hipSuccess);
+        return GDR_ERR_UNSUPPORTED;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = launch_preprocess_fwd_views(V, s, in, geoms, radii, st);
+    if (e != hipSuccess) return hip_fail("preprocess_fwd_views", e);
+    for (int v = 0; v < V; ++v) {
+        e = launch_scan_block_sums(&geoms[v], in->N, st);
+        if (e != hipSuccess) return hip_fail("scan_block_sums", e);
+    }
+    return debug_sync(&s[0], "preprocess_fwd_views", st);
+}
+
+int gdr_render_backward(const gdr_settings* s, int32_t N, const gdr_geom* geom, const gdr_binning* bin,
+                        const gdr_image* img, const gdr_grad_inputs* gin, float* grad_rec,
+                        void* stream) {
+    if (!s || !geom || !bin || !img || !gin || !gin->dL_dcolor || (N > 0 && !grad_rec) || !s->bg) {
+        set_error("render_backward: NULL argument", hipSuccess);
+        return GDR_ERR_INVALID_ARG;
+    }
+    if (N <= 0) return GDR_OK;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(grad_rec, 0, (size_t)N * 16 * sizeof(float), st);
+    if (e != hipSuccess) return hip_fail("memset gradient records", e);
+    gdr_grad_outputs go;
+    memset(&go, 0, sizeof(go));
+    go.scratch = grad_rec;
+    e = launch_render_bwd(s, geom, bin, img, gin, &go, st);
+    if (e != hipSuccess) return hip_fail("render_bwd", e);
+    return debug_sync(s, "render_bwd", st);
+}
+
+int gdr_preprocess_backward_views(int32_t V, const gdr_settings* s, const gdr_inputs* in,
+                                  const gdr_geom* geoms, const int32_t* const* radii,
+                                  float* const* grad_recs, const gdr_grad_outputs* gout, void* stream) {
+    if (V < 1 || V > GDR_MAX_VIEWS) { set_error("views: V out of range", hipSuccess); return GDR_ERR_UNSUPPORTED; }
+    if (!s || !in || !geoms || !radii || !grad_recs || !gout || !gout->dL_dmeans3D || !gout->dL_dmeans2D ||
+        !gout->dL_dshs || !gout->dL_dopacities || !gout->dL_dscales || !gout->dL_drotations) {
+        set_error("backward_views: NULL argument", hipSuccess);
+        return GDR_ERR_INVALID_ARG;
+    }
+    for (int v = 0; v < V; ++v) {
+        int rc = check_common(&s[v], in);
+        if (rc) return rc;
+        if (in->N > 0 && (!radii[v] || !grad_recs[v])) { set_error("backward_views: NULL view buffer", hipSuccess); return GDR_ERR_INVALID_ARG; }
+    }
+    if (in->N > 0 && (!in->shs || !in->scales || !in->rotations)) {
+        set_error("views: needs shs + scales + rotations", hipSuccess);
+        return GDR_ERR_UNSUPPORTED;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = launch_preprocess_bwd_views(V, s, in, geoms, radii, grad_recs, gout, st);
+    if (e != hipSuccess) return hip_fail("preprocess_bwd_views", e);
+    return debug_sync(&s[0], "preprocess_bwd_views", st);
+}
+
 int gdr_profile_enable(int on) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     g_prof_on = on != 0;

@@ -70,6 +70,12 @@ hipError_t launch_preprocess_fwd(const gdr_settings* s, const gdr_inputs* in, co
                                  int32_t* radii, hipStream_t st);
 hipError_t launch_preprocess_bwd(const gdr_settings* s, const gdr_inputs* in, const gdr_geom* g,
                                  const int32_t* radii, const gdr_grad_outputs* go, hipStream_t st);
+hipError_t launch_preprocess_fwd_views(int V, const gdr_settings* s, const gdr_inputs* in,
+                                       const gdr_geom* geoms, int32_t* const* radii, hipStream_t st);
+hipError_t launch_preprocess_bwd_views(int V, const gdr_settings* s, const gdr_inputs* in,
+                                       const gdr_geom* geoms, const int32_t* const* radii,
+                                       float* const* grad_recs, const gdr_grad_outputs* go,
+                                       hipStream_t st);
 hipError_t launch_mark_visible(int N, const float* means3D, const float* view, uint8_t* present,
                                hipStream_t st);
 hipError_t launch_scan_block_sums(const gdr_geom* g, int N, hipStream_t st);

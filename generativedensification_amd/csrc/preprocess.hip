@@ -561,6 +561,373 @@ __global__ __launch_bounds__(GDR_BLOCK) void preprocess_bwd_kernel(
     }
 }
 
+
+// =================================================================================
+// Multi-view variants: the callers render V views of ONE Gaussian set back to
+// back (network.py:826-838).  One thread still owns one Gaussian but loops over the views, so
+// the view-independent work is done once: inputs (236 B at SH degree 3) are read once instead
+// of V times, cov3D is computed/stored once, and in the backward the per-view partial
+// gradients are summed in registers and every output is written once (no read-modify-write
+// passes, no V-fold SH gradient traffic).  Per-view arithmetic is expression-for-expression the
+// single-view kernels', so integer intermediates stay bit-identical.
+// =================================================================================
+struct FwdView {
+    const float* view; const float* proj; const float* campos;
+    float tanx, tany, fx, fy;
+    int32_t* radii; float* depths; float2* xy; float4* conic_opacity; float4* rgb; int4* rect;
+    uint32_t* tiles; uint8_t* clamped; uint32_t* block_sums;
+};
+struct FwdViewsArgs { int V; FwdView v[GDR_MAX_VIEWS]; };
+
+template <int DEG>
+__global__ __launch_bounds__(GDR_BLOCK) void preprocess_fwd_views_kernel(
+    int N, int M, const float* __restrict__ means3D, const float* __restrict__ scales,
+    float scale_modifier, const float* __restrict__ rotations, const float* __restrict__ opacities,
+    const float* __restrict__ shs, int W, int H, float* __restrict__ g_cov3D, uint32_t flags,
+    const FwdViewsArgs a) {
+    __shared__ uint32_t wsum[GDR_MAX_VIEWS][GDR_BLOCK / GDR_WAVE];
+    constexpr int NB = (DEG + 1) * (DEG + 1);
+    const int i = blockIdx.x * GDR_BLOCK + threadIdx.x;
+    const int gx = (W + GDR_TILE - 1) / GDR_TILE, gy = (H + GDR_TILE - 1) / GDR_TILE;
+    const bool valid = i < N;
+    float px_ = 0.f, py_ = 0.f, pz_ = 0.f, op = 0.f;
+    float c6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float sh[NB * 3];
+    bool sh_loaded = false;
+    if (valid) {
+        px_ = means3D[3 * i]; py_ = means3D[3 * i + 1]; pz_ = means3D[3 * i + 2];
+        op = (flags & GDR_IN_RAW_OPACITY) ? act_sigmoid(opacities[i]) : opacities[i];
+        float4 q = reinterpret_cast<const float4*>(rotations)[i];
+        float sc0 = scales[3 * i], sc1 = scales[3 * i + 1], sc2 = scales[3 * i + 2];
+        if (flags & GDR_IN_RAW_ROTATIONS) { float inv_n; q = act_normalize(q, &inv_n); }
+        if (flags & GDR_IN_RAW_SCALES) { sc0 = expf(sc0); sc1 = expf(sc1); sc2 = expf(sc2); }
+        float R[9], Mm[9];
+        quat_to_R(q.x, q.y, q.z, q.w, R);
+        const float s[3] = {scale_modifier * sc0, scale_modifier * sc1, scale_modifier * sc2};
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) Mm[r * 3 + k] = R[r * 3 + k] * s[k];
+#define SIG(a_, b_) ((Mm[a_ * 3 + 0] * Mm[b_ * 3 + 0] + Mm[a_ * 3 + 1] * Mm[b_ * 3 + 1]) + Mm[a_ * 3 + 2] * Mm[b_ * 3 + 2])
+        c6[0] = SIG(0, 0); c6[1] = SIG(0, 1); c6[2] = SIG(0, 2);
+        c6[3] = SIG(1, 1); c6[4] = SIG(1, 2); c6[5] = SIG(2, 2);
+#undef SIG
+#pragma unroll
+        for (int k = 0; k < 6; ++k) g_cov3D[6 * i + k] = c6[k];
+    }
+    for (int v = 0; v < a.V; ++v) {
+        const FwdView& fv = a.v[v];
+        Cam cam;
+        load_cam(cam, fv.view, fv.proj, fv.campos);
+        uint32_t tiles = 0;
+        if (valid) {
+            int rad = 0;
+            float depth = 0.f;
+            float2 pxy = make_float2(0.f, 0.f);
+            float4 con_o = make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 rgbd = make_float4(0.f, 0.f, 0.f, 0.f);
+            int4 rect = make_int4(0, 0, 0, 0);
+            uint32_t clampbits = 0;
+            const float pvx = cam.v[0] * px_ + cam.v[4] * py_ + cam.v[8] * pz_ + cam.v[12];
+            const float pvy = cam.v[1] * px_ + cam.v[5] * py_ + cam.v[9] * pz_ + cam.v[13];
+            const float pvz = cam.v[2] * px_ + cam.v[6] * py_ + cam.v[10] * pz_ + cam.v[14];
+            bool ok = pvz > 0.2f;
+            if (ok) {
+                const float phx = cam.p[0] * px_ + cam.p[4] * py_ + cam.p[8] * pz_ + cam.p[12];
+                const float phy = cam.p[1] * px_ + cam.p[5] * py_ + cam.p[9] * pz_ + cam.p[13];
+                const float phw = cam.p[3] * px_ + cam.p[7] * py_ + cam.p[11] * pz_ + cam.p[15];
+                const float p_w = 1.0f / (phw + 0.0000001f);
+                const float ppx = phx * p_w, ppy = phy * p_w;
+                Ewa e;
+                ewa(cam, pvx, pvy, pvz, c6, fv.fx, fv.fy, fv.tanx, fv.tany, e);
+                const float det = e.a * e.c - e.b * e.b;
+                ok = det != 0.f;
+                if (ok) {
+                    const float det_inv = 1.f / det;
+                    const float mid = 0.5f * (e.a + e.c);
+                    const float disc = sqrtf(fmaxf(0.1f, mid * mid - det));
+                    const float lambda1 = mid + disc, lambda2 = mid - disc;
+                    const float my_radius = ceilf(3.f * sqrtf(fmaxf(lambda1, lambda2)));
+                    const float sx = ((ppx + 1.0f) * (float)W - 1.0f) * 0.5f;
+                    const float sy = ((ppy + 1.0f) * (float)H - 1.0f) * 0.5f;
+                    const int r_i = (int)my_radius;
+                    const float rf = (float)r_i;
+                    rect.x = min(gx, max(0, (int)((sx - rf) / (float)GDR_TILE)));
+                    rect.y = min(gy, max(0, (int)((sy - rf) / (float)GDR_TILE)));
+                    rect.z = min(gx, max(0, (int)((sx + rf + (float)(GDR_TILE - 1)) / (float)GDR_TILE)));
+                    rect.w = min(gy, max(0, (int)((sy + rf + (float)(GDR_TILE - 1)) / (float)GDR_TILE)));
+                    tiles = (uint32_t)((rect.z - rect.x) * (rect.w - rect.y));
+                    ok = tiles != 0;
+                    if (ok) {
+                        rad = r_i;
+                        depth = pvz;
+                        pxy = make_float2(sx, sy);
+                        con_o = make_float4(e.c * det_inv, -e.b * det_inv, e.a * det_inv, op);
+                        if (!sh_loaded) {  // first view in which this Gaussian is visible
+                            const float* src = shs + (size_t)i * M * 3;
+                            if ((M * 3) % 4 == 0) {
+#pragma unroll
+                                for (int c = 0; c < (NB * 3) / 4; ++c) {
+                                    const float4 t = reinterpret_cast<const float4*>(src)[c];
+                                    sh[4 * c] = t.x; sh[4 * c + 1] = t.y; sh[4 * c + 2] = t.z; sh[4 * c + 3] = t.w;
+                                }
+#pragma unroll
+                                for (int k = ((NB * 3) / 4) * 4; k < NB * 3; ++k) sh[k] = src[k];
+                            } else {
+#pragma unroll
+                                for (int k = 0; k < NB * 3; ++k) sh[k] = src[k];
+                            }
+                            sh_loaded = true;
+                        }
+                        float dx = px_ - cam.c[0], dy = py_ - cam.c[1], dz = pz_ - cam.c[2];
+                        const float inv = 1.f / sqrtf((dx * dx + dy * dy) + dz * dz);
+                        dx *= inv; dy *= inv; dz *= inv;
+                        float bk[NB];
+                        sh_basis<DEG>(dx, dy, dz, bk);
+                        float acc[3];
+#pragma unroll
+                        for (int ch = 0; ch < 3; ++ch) acc[ch] = bk[0] * sh[ch];
+#pragma unroll
+                        for (int k = 1; k < NB; ++k)
+#pragma unroll
+                            for (int ch = 0; ch < 3; ++ch) acc[ch] = acc[ch] + bk[k] * sh[3 * k + ch];
+#pragma unroll
+                        for (int ch = 0; ch < 3; ++ch) {
+                            acc[ch] = acc[ch] + 0.5f;
+                            if (acc[ch] < 0.f) clampbits |= (1u << ch);
+                            acc[ch] = fmaxf(acc[ch], 0.f);
+                        }
+                        rgbd = make_float4(acc[0], acc[1], acc[2], depth);
+                    } else {
+                        rect = make_int4(0, 0, 0, 0);
+                    }
+                }
+                if (!ok) tiles = 0;
+            }
+            fv.radii[i] = rad;
+            fv.depths[i] = depth;
+            fv.xy[i] = pxy;
+            fv.conic_opacity[i] = con_o;
+            fv.rgb[i] = rgbd;
+            fv.rect[i] = rect;
+            fv.tiles[i] = tiles;
+            fv.clamped[i] = (uint8_t)clampbits;
+        }
+        uint32_t t = tiles;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
+        if ((threadIdx.x & 63) == 0) wsum[v][threadIdx.x >> 6] = t;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < a.V)
+        a.v[threadIdx.x].block_sums[blockIdx.x] =
+            wsum[threadIdx.x][0] + wsum[threadIdx.x][1] + wsum[threadIdx.x][2] + wsum[threadIdx.x][3];
+}
+
+struct BwdView {
+    const float* view; const float* proj; const float* campos;
+    float tanx, tany, fx, fy;
+    const int32_t* radii; const uint8_t* clamped; const float4* grad_rec;
+};
+struct BwdViewsArgs { int V; BwdView v[GDR_MAX_VIEWS]; };
+
+template <int DEG>
+__global__ __launch_bounds__(GDR_BLOCK) void preprocess_bwd_views_kernel(
+    int N, int M, const float* __restrict__ means3D, const float* __restrict__ shs,
+    const float* __restrict__ scales, const float* __restrict__ rotations,
+    const float* __restrict__ opacities, float scale_modifier, const float* __restrict__ cov3D, int W,
+    int H, uint32_t flags, int accumulate, float4* __restrict__ dL_dmean2D,
+    float* __restrict__ dL_dopacity, float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dsh,
+    float* __restrict__ dL_dscale, float4* __restrict__ dL_drot, const BwdViewsArgs a) {
+    constexpr int NB = (DEG + 1) * (DEG + 1);
+    const int i = blockIdx.x * GDR_BLOCK + threadIdx.x;
+    if (i >= N) return;
+    float dmean[3] = {0.f, 0.f, 0.f};
+    float dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float4 dm2 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float dop = 0.f;
+    float dsh[NB * 3];
+#pragma unroll
+    for (int k = 0; k < NB * 3; ++k) dsh[k] = 0.f;
+    bool any_vis = false;
+    const float px_ = means3D[3 * i], py_ = means3D[3 * i + 1], pz_ = means3D[3 * i + 2];
+    float c6[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) c6[k] = cov3D[6 * i + k];
+    const float* sh = shs + (size_t)i * M * 3;
+
+    for (int v = 0; v < a.V; ++v) {
+        const BwdView& bv = a.v[v];
+        if (bv.radii[i] <= 0) continue;
+        any_vis = true;
+        Cam cam;
+        load_cam(cam, bv.view, bv.proj, bv.campos);
+        const float4 g2 = bv.grad_rec[4 * i];
+        const float4 gconic = bv.grad_rec[4 * i + 1];
+        const float4 gcolor = bv.grad_rec[4 * i + 2];
+        dm2 = make_float4(dm2.x + g2.x, dm2.y + g2.y, dm2.z + g2.z, dm2.w + g2.w);
+        dop += gcolor.w;
+        const float pvx = cam.v[0] * px_ + cam.v[4] * py_ + cam.v[8] * pz_ + cam.v[12];
+        const float pvy = cam.v[1] * px_ + cam.v[5] * py_ + cam.v[9] * pz_ + cam.v[13];
+        const float pvz = cam.v[2] * px_ + cam.v[6] * py_ + cam.v[10] * pz_ + cam.v[14];
+        Ewa e;
+        ewa(cam, pvx, pvy, pvz, c6, bv.fx, bv.fy, bv.tanx, bv.tany, e);
+        const float ea = e.a, eb = e.b, ec = e.c;
+        const float det = ea * ec - eb * eb;
+        float dL_da = 0.f, dL_db = 0.f, dL_dc = 0.f;
+        if (det * det != 0.f) {
+            const float d2 = 1.f / (det * det);
+            dL_da = d2 * (-ec * ec * gconic.x + eb * ec * gconic.y - eb * eb * gconic.z);
+            dL_db = d2 * (2.f * eb * ec * gconic.x - (ea * ec + eb * eb) * gconic.y + 2.f * ea * eb * gconic.z);
+            dL_dc = d2 * (-eb * eb * gconic.x + ea * eb * gconic.y - ea * ea * gconic.z);
+            const float* A0 = e.A0;
+            const float* A1 = e.A1;
+            dcov[0] += A0[0] * A0[0] * dL_da + A0[0] * A1[0] * dL_db + A1[0] * A1[0] * dL_dc;
+            dcov[3] += A0[1] * A0[1] * dL_da + A0[1] * A1[1] * dL_db + A1[1] * A1[1] * dL_dc;
+            dcov[5] += A0[2] * A0[2] * dL_da + A0[2] * A1[2] * dL_db + A1[2] * A1[2] * dL_dc;
+            dcov[1] += 2.f * A0[0] * A0[1] * dL_da + (A0[0] * A1[1] + A0[1] * A1[0]) * dL_db + 2.f * A1[0] * A1[1] * dL_dc;
+            dcov[2] += 2.f * A0[0] * A0[2] * dL_da + (A0[0] * A1[2] + A0[2] * A1[0]) * dL_db + 2.f * A1[0] * A1[2] * dL_dc;
+            dcov[4] += 2.f * A0[1] * A0[2] * dL_da + (A0[1] * A1[2] + A0[2] * A1[1]) * dL_db + 2.f * A1[1] * A1[2] * dL_dc;
+        }
+        float dJ00 = 0.f, dJ02 = 0.f, dJ11 = 0.f, dJ12 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float dA0 = 2.f * dL_da * e.v0[k] + dL_db * e.v1[k];
+            const float dA1 = 2.f * dL_dc * e.v1[k] + dL_db * e.v0[k];
+            dJ00 += dA0 * cam.v[4 * k + 0];
+            dJ02 += dA0 * cam.v[4 * k + 2];
+            dJ11 += dA1 * cam.v[4 * k + 1];
+            dJ12 += dA1 * cam.v[4 * k + 2];
+        }
+        const float tz1 = 1.f / e.tz, tz2 = tz1 * tz1, tz3 = tz2 * tz1;
+        const float dtx = e.xmul * (-bv.fx * tz2 * dJ02);
+        const float dty = e.ymul * (-bv.fy * tz2 * dJ12);
+        const float dtz = -bv.fx * tz2 * dJ00 - bv.fy * tz2 * dJ11 + (2.f * bv.fx * e.tx) * tz3 * dJ02 +
+                          (2.f * bv.fy * e.ty) * tz3 * dJ12;
+        const float mhx = cam.p[0] * px_ + cam.p[4] * py_ + cam.p[8] * pz_ + cam.p[12];
+        const float mhy = cam.p[1] * px_ + cam.p[5] * py_ + cam.p[9] * pz_ + cam.p[13];
+        const float mhw = cam.p[3] * px_ + cam.p[7] * py_ + cam.p[11] * pz_ + cam.p[15];
+        const float m_w = 1.f / (mhw + 0.0000001f);
+        const float mul1 = mhx * m_w * m_w, mul2 = mhy * m_w * m_w;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            dmean[k] += cam.v[4 * k + 0] * dtx + cam.v[4 * k + 1] * dty + cam.v[4 * k + 2] * dtz;
+            dmean[k] += (cam.p[4 * k + 0] * m_w - cam.p[4 * k + 3] * mul1) * g2.x +
+                        (cam.p[4 * k + 1] * m_w - cam.p[4 * k + 3] * mul2) * g2.y;
+            dmean[k] += cam.v[4 * k + 2] * gconic.w;
+        }
+        {   // SH backward
+            float dx = px_ - cam.c[0], dy = py_ - cam.c[1], dz = pz_ - cam.c[2];
+            const float inv = 1.f / sqrtf((dx * dx + dy * dy) + dz * dz);
+            const float ux = dx * inv, uy = dy * inv, uz = dz * inv;
+            float bk[NB], bx[NB], by[NB], bz[NB];
+            sh_basis<DEG>(ux, uy, uz, bk);
+            sh_basis_grad<DEG>(ux, uy, uz, bx, by, bz);
+            const uint32_t cl = bv.clamped[i];
+            const float g[3] = {(cl & 1u) ? 0.f : gcolor.x, (cl & 2u) ? 0.f : gcolor.y,
+                                (cl & 4u) ? 0.f : gcolor.z};
+            float ddx = 0.f, ddy = 0.f, ddz = 0.f;
+#pragma unroll
+            for (int k = 0; k < NB; ++k) {
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) {
+                    const float sg = sh[3 * k + ch] * g[ch];
+                    dsh[3 * k + ch] += bk[k] * g[ch];
+                    ddx += bx[k] * sg;
+                    ddy += by[k] * sg;
+                    ddz += bz[k] * sg;
+                }
+            }
+            const float dot = ux * ddx + uy * ddy + uz * ddz;
+            dmean[0] += (ddx - ux * dot) * inv;
+            dmean[1] += (ddy - uy * dot) * inv;
+            dmean[2] += (ddz - uz * dot) * inv;
+        }
+    }
+    if (accumulate && !any_vis) return;
+    float dscale[3] = {0.f, 0.f, 0.f};
+    float4 drot = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (any_vis) {
+        if (flags & GDR_IN_RAW_OPACITY) {
+            const float o = act_sigmoid(opacities[i]);
+            dop = dop * (o * (1.f - o));
+        }
+        float4 q = reinterpret_cast<const float4*>(rotations)[i];
+        float sc0 = scales[3 * i], sc1 = scales[3 * i + 1], sc2 = scales[3 * i + 2];
+        float inv_n = 1.f;
+        if (flags & GDR_IN_RAW_ROTATIONS) q = act_normalize(q, &inv_n);
+        if (flags & GDR_IN_RAW_SCALES) { sc0 = expf(sc0); sc1 = expf(sc1); sc2 = expf(sc2); }
+        float R[9];
+        quat_to_R(q.x, q.y, q.z, q.w, R);
+        const float s[3] = {scale_modifier * sc0, scale_modifier * sc1, scale_modifier * sc2};
+        const float Gs[9] = {dcov[0], 0.5f * dcov[1], 0.5f * dcov[2], 0.5f * dcov[1], dcov[3],
+                             0.5f * dcov[4], 0.5f * dcov[2], 0.5f * dcov[4], dcov[5]};
+        float dR[9];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            float ds = 0.f;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                float acc = 0.f;
+#pragma unroll
+                for (int l = 0; l < 3; ++l) acc += Gs[3 * r + l] * (R[3 * l + k] * s[k]);
+                const float dM = 2.f * acc;
+                ds += R[3 * r + k] * dM;
+                dR[3 * r + k] = s[k] * dM;
+            }
+            dscale[k] = scale_modifier * ds;
+        }
+        const float qr = q.x, qx = q.y, qy = q.z, qz = q.w;
+#define G_(r_, c_) dR[3 * (r_) + (c_)]
+        drot.x = 2.f * (-qz * G_(0, 1) + qy * G_(0, 2) + qz * G_(1, 0) - qx * G_(1, 2) - qy * G_(2, 0) + qx * G_(2, 1));
+        drot.y = 2.f * (qy * G_(0, 1) + qz * G_(0, 2) + qy * G_(1, 0) - 2.f * qx * G_(1, 1) - qr * G_(1, 2) + qz * G_(2, 0) + qr * G_(2, 1) - 2.f * qx * G_(2, 2));
+        drot.z = 2.f * (-2.f * qy * G_(0, 0) + qx * G_(0, 1) + qr * G_(0, 2) + qx * G_(1, 0) + qz * G_(1, 2) - qr * G_(2, 0) + qz * G_(2, 1) - 2.f * qy * G_(2, 2));
+        drot.w = 2.f * (-2.f * qz * G_(0, 0) - qr * G_(0, 1) + qx * G_(0, 2) + qr * G_(1, 0) - 2.f * qz * G_(1, 1) + qy * G_(1, 2) + qx * G_(2, 0) + qy * G_(2, 1));
+#undef G_
+        if (flags & GDR_IN_RAW_SCALES) { dscale[0] *= sc0; dscale[1] *= sc1; dscale[2] *= sc2; }
+        if (flags & GDR_IN_RAW_ROTATIONS) {
+            const float dot = (q.x * drot.x + q.y * drot.y) + (q.z * drot.z + q.w * drot.w);
+            drot = make_float4((drot.x - q.x * dot) * inv_n, (drot.y - q.y * dot) * inv_n,
+                               (drot.z - q.z * dot) * inv_n, (drot.w - q.w * dot) * inv_n);
+        }
+    }
+    float* o_sh = dL_dsh + (size_t)i * M * 3;
+    if (accumulate) {
+        const float4 om = dL_dmean2D[i];
+        dm2 = make_float4(dm2.x + om.x, dm2.y + om.y, dm2.z + om.z, dm2.w + om.w);
+        dop += dL_dopacity[i];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { dmean[k] += dL_dmeans3D[3 * i + k]; dscale[k] += dL_dscale[3 * i + k]; }
+        const float4 orot = dL_drot[i];
+        drot = make_float4(drot.x + orot.x, drot.y + orot.y, drot.z + orot.z, drot.w + orot.w);
+    }
+    dL_dmean2D[i] = dm2;
+    dL_dopacity[i] = dop;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { dL_dmeans3D[3 * i + k] = dmean[k]; dL_dscale[3 * i + k] = dscale[k]; }
+    dL_drot[i] = drot;
+    if ((M * 3) % 4 == 0 && M == NB) {
+        float4* d4 = reinterpret_cast<float4*>(o_sh);
+#pragma unroll
+        for (int c = 0; c < (3 * NB) / 4; ++c) {
+            float4 t = make_float4(dsh[4 * c], dsh[4 * c + 1], dsh[4 * c + 2], dsh[4 * c + 3]);
+            if (accumulate) {
+                const float4 o = d4[c];
+                t = make_float4(t.x + o.x, t.y + o.y, t.z + o.z, t.w + o.w);
+            }
+            d4[c] = t;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < NB * 3; ++k) {
+            if (accumulate) o_sh[k] += dsh[k];
+            else o_sh[k] = dsh[k];
+        }
+        if (!accumulate)
+            for (int k = NB * 3; k < M * 3; ++k) o_sh[k] = 0.f;
+    }
+}
+
 __global__ __launch_bounds__(GDR_BLOCK) void mark_visible_kernel(int N, const float* __restrict__ means3D,
                                                                   const float* __restrict__ view,
                                                                   uint8_t* __restrict__ present) {
@@ -613,6 +980,55 @@ hipError_t launch_preprocess_bwd(const gdr_settings* s, const gdr_inputs* in, co
                (const float4*)go->scratch, (float4*)go->dL_dmeans2D, go->dL_dopacities, go->dL_dmeans3D,
                go->dL_dcov3D, go->dL_dshs, go->dL_dcolors, go->dL_dscales,
                (float4*)go->dL_drotations, (const float4*)g->conic_opacity, in->flags, go->accumulate);
+    return hipGetLastError();
+}
+
+hipError_t launch_preprocess_fwd_views(int V, const gdr_settings* s, const gdr_inputs* in,
+                                       const gdr_geom* geoms, int32_t* const* radii, hipStream_t st) {
+    const int N = in->N;
+    if (N == 0) return hipSuccess;
+    const int W = s[0].image_width, H = s[0].image_height;
+    FwdViewsArgs a;
+    a.V = V;
+    for (int v = 0; v < V; ++v) {
+        FwdView& f = a.v[v];
+        f.view = s[v].viewmatrix; f.proj = s[v].projmatrix; f.campos = s[v].campos;
+        f.tanx = s[v].tanfovx; f.tany = s[v].tanfovy;
+        f.fx = (float)W / (2.f * s[v].tanfovx); f.fy = (float)H / (2.f * s[v].tanfovy);
+        f.radii = radii[v]; f.depths = geoms[v].depths; f.xy = (float2*)geoms[v].xy;
+        f.conic_opacity = (float4*)geoms[v].conic_opacity; f.rgb = (float4*)geoms[v].rgb;
+        f.rect = (int4*)geoms[v].rect; f.tiles = geoms[v].tiles_touched; f.clamped = geoms[v].clamped;
+        f.block_sums = geoms[v].block_sums;
+    }
+    const int grid = div_up(N, GDR_BLOCK);
+    LAUNCH_DEG(GDR_K_PREPROCESS_FWD, preprocess_fwd_views_kernel, s[0].sh_degree, grid, st, N, in->M,
+               in->means3D, in->scales, s[0].scale_modifier, in->rotations, in->opacities, in->shs, W, H,
+               geoms[0].cov3D, in->flags, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_preprocess_bwd_views(int V, const gdr_settings* s, const gdr_inputs* in,
+                                       const gdr_geom* geoms, const int32_t* const* radii,
+                                       float* const* grad_recs, const gdr_grad_outputs* go,
+                                       hipStream_t st) {
+    const int N = in->N;
+    if (N == 0) return hipSuccess;
+    const int W = s[0].image_width, H = s[0].image_height;
+    BwdViewsArgs a;
+    a.V = V;
+    for (int v = 0; v < V; ++v) {
+        BwdView& b = a.v[v];
+        b.view = s[v].viewmatrix; b.proj = s[v].projmatrix; b.campos = s[v].campos;
+        b.tanx = s[v].tanfovx; b.tany = s[v].tanfovy;
+        b.fx = (float)W / (2.f * s[v].tanfovx); b.fy = (float)H / (2.f * s[v].tanfovy);
+        b.radii = radii[v]; b.clamped = geoms[v].clamped; b.grad_rec = (const float4*)grad_recs[v];
+    }
+    const int grid = div_up(N, GDR_BLOCK);
+    LAUNCH_DEG(GDR_K_PREPROCESS_BWD, preprocess_bwd_views_kernel, s[0].sh_degree, grid, st, N, in->M,
+               in->means3D, in->shs, in->scales, in->rotations, in->opacities, s[0].scale_modifier,
+               geoms[0].cov3D, W, H, in->flags, go->accumulate, (float4*)go->dL_dmeans2D,
+               go->dL_dopacities, go->dL_dmeans3D, go->dL_dshs, go->dL_dscales,
+               (float4*)go->dL_drotations, a);
     return hipGetLastError();
 }
 

@@ -264,12 +264,14 @@ class _RenderViews(torch.autograd.Function):
         f32, u8 = dict(dtype=torch.float32, device=dev), dict(dtype=torch.uint8, device=dev)
         colors, depths, alphas = torch.empty(V, 3, H, W, **f32), torch.empty(V, 1, H, W, **f32), torch.empty(V, 1, H, W, **f32)
         radii = torch.empty(V, N, dtype=torch.int32, device=dev)
-        states, structs = [], []
+        states = []
         with torch.cuda.device(dev):
             stream = _stream()
             inp = _inputs_struct(N, M, means3D, opacities, sh, e, scales, rotations, e, flags)
+            s_arr = (L.GdrSettings * V)()
+            g_arr = (L.GdrGeom * V)()
             for v, rs in enumerate(settings_list):
-                s = _settings_struct(rs, dev, keep)
+                s_arr[v] = _settings_struct(rs, dev, keep)
                 st = _State()
                 st.N, st.M, st.H, st.W = N, M, H, W
                 st.geom_buf = torch.empty(lib.gdr_geom_bytes(N), **u8)
@@ -277,19 +279,29 @@ class _RenderViews(torch.autograd.Function):
                 st.geom, st.bin, st.img = L.GdrGeom(), L.GdrBinning(), L.GdrImage()
                 L.check(lib.gdr_geom_carve(st.geom_buf.data_ptr(), N, C.byref(st.geom)), "gdr_geom_carve")
                 L.check(lib.gdr_image_carve(st.img_buf.data_ptr(), H, W, C.byref(st.img)), "gdr_image_carve")
-                L.check(lib.gdr_preprocess_forward(C.byref(s), C.byref(inp), C.byref(st.geom), _ptr(radii[v]),
-                                                   None, stream), "gdr_preprocess_forward")
+                st.geom.cov3D = states[0].geom.cov3D if states else st.geom.cov3D  # view-independent: shared
+                g_arr[v] = st.geom
                 states.append(st)
-                structs.append(s)
+            # K1 for all views in groups of <= GDR_MAX_VIEWS launches (inputs read once per group)
+            for lo in range(0, V, L.GDR_MAX_VIEWS):
+                n = min(L.GDR_MAX_VIEWS, V - lo)
+                r_arr = (C.c_void_p * n)(*[radii[lo + k].data_ptr() if N else None for k in range(n)])
+                sub_s = (L.GdrSettings * n).from_address(C.addressof(s_arr) + lo * C.sizeof(L.GdrSettings))
+                sub_g = (L.GdrGeom * n).from_address(C.addressof(g_arr) + lo * C.sizeof(L.GdrGeom))
+                if lo > 0:  # the shared cov3D of group 0 is what every later stage reads
+                    for k in range(n):
+                        sub_g[k].cov3D = g_arr[0].cov3D
+                L.check(lib.gdr_preprocess_forward_views(n, sub_s, C.byref(inp), sub_g, r_arr, stream),
+                        "gdr_preprocess_forward_views")
             # ONE host read-back for all V views
             d_dev = torch.cat([st._view(st.geom_buf, st.geom.num_rendered, torch.int32, 1) for st in states])
             d_host = d_dev.cpu().tolist()
-            for v, (st, s) in enumerate(zip(states, structs)):
+            for v, st in enumerate(states):
                 st.D = int(d_host[v]) & 0xFFFFFFFF
                 st.bin_buf = torch.empty(lib.gdr_binning_bytes(st.D), **u8)
                 L.check(lib.gdr_binning_carve(st.bin_buf.data_ptr(), st.D, C.byref(st.bin)), "gdr_binning_carve")
                 out = L.GdrOutputs(colors[v].data_ptr(), depths[v].data_ptr(), alphas[v].data_ptr(), _ptr(radii[v]))
-                L.check(lib.gdr_render_forward(C.byref(s), C.byref(inp), C.byref(st.geom), C.byref(st.bin),
+                L.check(lib.gdr_render_forward(C.byref(s_arr[v]), C.byref(inp), C.byref(g_arr[v]), C.byref(st.bin),
                                                C.byref(st.img), st.D, C.byref(out), stream), "gdr_render_forward")
         ctx.states, ctx.keep, ctx.settings_list, ctx.flags = states, keep, settings_list, flags
         ctx.radii, ctx.in_dtypes, ctx.means2D_shape = radii, in_dtypes, tuple(means2D.shape)
@@ -301,29 +313,42 @@ class _RenderViews(torch.autograd.Function):
         lib = L.load()
         means3D, opacities, sh, e, scales, rotations, _ = ctx.keep[:7]
         dev = means3D.device
-        st0 = ctx.states[0]
-        N, M = st0.N, st0.M
+        states = ctx.states
+        N, M, V = states[0].N, states[0].M, len(states)
         f32 = dict(dtype=torch.float32, device=dev)
         g = dict(means3D=torch.empty(N, 3, **f32), means2D=torch.empty(N, 4, **f32), shs=torch.empty(N, M, 3, **f32),
                  opacities=torch.empty(N, 1, **f32), scales=torch.empty(N, 3, **f32), rotations=torch.empty(N, 4, **f32))
-        scratch = torch.empty(max(N, 1) * 16, **f32)
         with torch.cuda.device(dev):
             keep2: list = []
             stream = _stream()
             inp = _inputs_struct(N, M, means3D, opacities, sh, e, scales, rotations, e, ctx.flags)
-            for v, (st, rs) in enumerate(zip(ctx.states, ctx.settings_list)):
-                s = _settings_struct(rs, dev, keep2)
-                gc = _f32(g_colors[v], dev)
-                gd = None if g_depths is None else _f32(g_depths[v], dev)
-                ga = None if g_alphas is None else _f32(g_alphas[v], dev)
-                keep2 += [gc, gd, ga]
-                gin = L.GdrGradInputs(gc.data_ptr(), _ptr(gd), _ptr(ga))
+            for lo in range(0, V, L.GDR_MAX_VIEWS):
+                n = min(L.GDR_MAX_VIEWS, V - lo)
+                recs = torch.empty(n, max(N, 1) * 16, **f32)  # one 64-byte gradient record per Gaussian per view
+                s_arr = (L.GdrSettings * n)()
+                g_arr = (L.GdrGeom * n)()
+                for k in range(n):
+                    v = lo + k
+                    st = states[v]
+                    s_arr[k] = _settings_struct(ctx.settings_list[v], dev, keep2)
+                    g_arr[k] = st.geom
+                    g_arr[k].cov3D = states[0].geom.cov3D
+                    gc = _f32(g_colors[v], dev)
+                    gd = None if g_depths is None else _f32(g_depths[v], dev)
+                    ga = None if g_alphas is None else _f32(g_alphas[v], dev)
+                    keep2 += [gc, gd, ga]
+                    gin = L.GdrGradInputs(gc.data_ptr(), _ptr(gd), _ptr(ga))
+                    L.check(lib.gdr_render_backward(C.byref(s_arr[k]), N, C.byref(g_arr[k]), C.byref(st.bin),
+                                                    C.byref(st.img), C.byref(gin), recs[k].data_ptr(), stream),
+                            "gdr_render_backward")
+                r_arr = (C.c_void_p * n)(*[ctx.radii[lo + k].data_ptr() if N else None for k in range(n)])
+                rec_arr = (C.c_void_p * n)(*[recs[k].data_ptr() for k in range(n)])
                 gout = L.GdrGradOutputs(_ptr(g["means3D"]), _ptr(g["means2D"]), _ptr(g["shs"]), None,
-                                        _ptr(g["opacities"]), _ptr(g["scales"]), _ptr(g["rotations"]), None,
-                                        scratch.data_ptr(), 1 if v > 0 else 0, 0)
-                L.check(lib.gdr_backward(C.byref(s), C.byref(inp), C.byref(st.geom), C.byref(st.bin),
-                                         C.byref(st.img), st.D, _ptr(ctx.radii[v]), C.byref(gin), C.byref(gout),
-                                         stream), "gdr_backward")
+                                        _ptr(g["opacities"]), _ptr(g["scales"]), _ptr(g["rotations"]), None, None,
+                                        1 if lo > 0 else 0, 0)
+                L.check(lib.gdr_preprocess_backward_views(n, s_arr, C.byref(inp), g_arr, r_arr, rec_arr,
+                                                          C.byref(gout), stream), "gdr_preprocess_backward_views")
+                keep2.append(recs)
         gm2 = g["means2D"]
         cols = ctx.means2D_shape[1] if len(ctx.means2D_shape) == 2 else 4
         if cols == 3:

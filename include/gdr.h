@@ -196,6 +196,27 @@ int gdr_backward(const gdr_settings* s, const gdr_inputs* in, const gdr_geom* ge
                  const int32_t* radii, const gdr_grad_inputs* gin, const gdr_grad_outputs* gout,
                  void* stream);
 
+/* ---- multi-view entry points (one Gaussian set, V <= GDR_MAX_VIEWS views of one image size) ----
+ * The callers render all target views of one Gaussian set back to back
+ * (/root/reference/lightning/network.py:826-838, 848-856, 964-972).  These variants do the
+ * view-independent work once: the per-Gaussian inputs are read once for all V views, cov3D is
+ * written once (to geoms[0].cov3D — every geoms[v].cov3D is ignored), and the backward sums the
+ * V per-view partial gradients in registers before writing each output once.
+ * s, geoms: arrays of V structs; radii, grad_recs: arrays of V device pointers (host arrays).
+ * Requires in->shs, in->scales, in->rotations (no colors_precomp / cov3D_precomp).
+ * Sequence: gdr_preprocess_forward_views; read the V values geoms[v].num_rendered;
+ *           per view gdr_render_forward; ...; per view gdr_render_backward (K7 into its own
+ *           N*16-float record); gdr_preprocess_backward_views. */
+#define GDR_MAX_VIEWS 8
+int gdr_preprocess_forward_views(int32_t V, const gdr_settings* s, const gdr_inputs* in,
+                                 const gdr_geom* geoms, int32_t* const* radii, void* stream);
+int gdr_render_backward(const gdr_settings* s, int32_t N, const gdr_geom* geom, const gdr_binning* bin,
+                        const gdr_image* img, const gdr_grad_inputs* gin, float* grad_rec,
+                        void* stream);
+int gdr_preprocess_backward_views(int32_t V, const gdr_settings* s, const gdr_inputs* in,
+                                  const gdr_geom* geoms, const int32_t* const* radii,
+                                  float* const* grad_recs, const gdr_grad_outputs* gout, void* stream);
+
 /* ---- K10: visibility mask (upstream markVisible; unused by the reference) -------- */
 int gdr_mark_visible(int32_t N, const float* means3D, const float* viewmatrix,
                      const float* projmatrix, uint8_t* present, void* stream);

@@ -258,3 +258,28 @@ def test_fused_multiview_entry_matches_per_view_reference_sequence():
     for k in g_ref:
         assert U.rel_inf(g_fus[k], g_ref[k]) < 1e-4, k
     assert g_fus["ssp"].shape == (n, 4) and (g_fus["ssp"][:, 2:] >= 0).all()
+
+
+def test_multiview_kernels_keep_integer_intermediates_bit_exact(oracle_built):
+    """The multi-view K1 (inputs read once for V views) must give the oracle's radii / sorted list per view
+    when fed the same ACTIVATED inputs (flags = 0)."""
+    from generativedensification_amd import rasterizer as R
+    from generativedensification_amd.camera import orbit_cameras
+
+    dev = torch.device("cuda:0")
+    case = U.make_case(20_000, 208, 176, 41, deg=3, sigma0=(0.0052, 0.00065))
+    cams = orbit_cameras(3, 176, 208)
+    sets = []
+    for c in cams:
+        cc = dict(case, view=c.world_view_transform.contiguous(), proj=c.full_proj_transform.contiguous(),
+                  campos=c.camera_center.contiguous())
+        sets.append(cc)
+    t = lambda k: case[k].to(dev)
+    colors, radii, depths, alphas = R.render_views_raw(t("means3D"), torch.zeros(case["N"], 4, device=dev), t("shs"),
+                                                       t("opacities"), t("scales"), t("rotations"),
+                                                       [U.settings_torch(cc, dev) for cc in sets], flags=0)
+    for v, cc in enumerate(sets):
+        o, _ = U.run_oracle(cc, "f32")
+        np.testing.assert_array_equal(radii[v].cpu().numpy(), o["radii"])
+        assert U.outlier_fraction(colors[v].cpu().numpy(), o["color"], 1e-4, 1e-5) < 1e-4
+        assert U.outlier_fraction(depths[v].cpu().numpy(), o["depth"], 1e-4, 1e-5) < 1e-4
