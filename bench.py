@@ -63,6 +63,7 @@ def algorithmic_bytes(n, d, p, m, tiles):
         sort_scatter=d * 2 * K,         # per pass
         tile_ranges=d * 8,
         tile_order=tiles * 12,
+        tile_sort=d * (12 + 12),
         render_fwd=d * 44 + p * 28,
         render_bwd=d * (44 + G) + p * 28,
         preprocess_bwd=n * (A + S + G) + n * (A + 16),

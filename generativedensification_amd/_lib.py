@@ -44,7 +44,7 @@ class GdrGeom(C.Structure):
 
 class GdrBinning(C.Structure):
     _fields_ = [("keys", C.c_void_p * 2), ("values", C.c_void_p * 2), ("hist", C.c_void_p),
-                ("sorted", C.c_int32), ("reserved", C.c_int32)]
+                ("sorted", C.c_int32), ("global_sort", C.c_int32), ("scratch32", C.c_void_p)]
 
 
 class GdrImage(C.Structure):
@@ -121,7 +121,7 @@ def load():
             fn = getattr(lib, name)  # AttributeError if the symbol is missing
             fn.restype = res
             fn.argtypes = args
-        if lib.gdr_abi_version() != 2:
+        if lib.gdr_abi_version() != 3:
             raise RuntimeError("libgdr_hip.so ABI version mismatch")
         _lib = lib
     return _lib

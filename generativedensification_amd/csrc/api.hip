@@ -90,8 +90,9 @@ static size_t carve_binning(void* base, uint64_t D, gdr_binning* b) {
     t.values[0] = c.take<uint32_t>(d);
     t.values[1] = c.take<uint32_t>(d);
     t.hist = c.take<uint32_t>(sort_hist_bytes(D) / sizeof(uint32_t));
+    t.scratch32 = c.take<uint32_t>(2 * d);
     t.sorted = 0;
-    t.reserved = 0;
+    t.global_sort = 0;
     if (b) *b = t;
     return c.off;
 }
@@ -218,12 +219,24 @@ int gdr_render_forward(const gdr_settings* s, const gdr_inputs* in, const gdr_ge
     hipError_t e = launch_duplicate(geom, in->N, W, H, out->radii, bin->keys[0], bin->values[0], D, st);
     if (e != hipSuccess) return hip_fail("duplicate", e);
     if ((rc = debug_sync(s, "duplicate", st))) return rc;
-    e = launch_sort(bin, D, key_bits(tiles), st);
-    if (e != hipSuccess) return hip_fail("sort", e);
-    if ((rc = debug_sync(s, "sort", st))) return rc;
-    e = launch_ranges(bin, D, img, tiles, st);
-    if (e != hipSuccess) return hip_fail("ranges", e);
-    if ((rc = debug_sync(s, "ranges", st))) return rc;
+    if (bin->global_sort) {  // one global stable LSD radix sort over all key bits
+        e = launch_sort(bin, D, key_bits(tiles), st);
+        if (e != hipSuccess) return hip_fail("sort", e);
+        if ((rc = debug_sync(s, "sort", st))) return rc;
+        e = launch_ranges(bin, D, img, tiles, st);
+        if (e != hipSuccess) return hip_fail("ranges", e);
+        if ((rc = debug_sync(s, "ranges", st))) return rc;
+    } else {  // default: stable partition by tile, segments, per-tile LDS depth sort
+        e = launch_sort_tile_bits(bin, D, key_bits(tiles), st);
+        if (e != hipSuccess) return hip_fail("sort_tile_bits", e);
+        if ((rc = debug_sync(s, "sort_tile_bits", st))) return rc;
+        e = launch_ranges(bin, D, img, tiles, st);
+        if (e != hipSuccess) return hip_fail("ranges", e);
+        if ((rc = debug_sync(s, "ranges", st))) return rc;
+        e = launch_tile_sort(bin, img, tiles, D, st);
+        if (e != hipSuccess) return hip_fail("tile_sort", e);
+        if ((rc = debug_sync(s, "tile_sort", st))) return rc;
+    }
     e = launch_tile_order(img, tiles, st);
     if (e != hipSuccess) return hip_fail("tile_order", e);
     if ((rc = debug_sync(s, "tile_order", st))) return rc;
@@ -379,7 +392,7 @@ int gdr_profile_collect(double* ms_total, uint64_t* launches, int32_t n, int32_t
 const char* gdr_kernel_name(int32_t id) {
     static const char* names[GDR_K_COUNT] = {"preprocess_fwd", "scan_block_sums", "duplicate_with_keys",
         "sort_hist", "sort_rowscan", "sort_scatter", "tile_ranges", "render_fwd", "render_bwd",
-        "preprocess_bwd", "mark_visible", "tile_order"};
+        "preprocess_bwd", "mark_visible", "tile_order", "tile_sort"};
     return (id >= 0 && id < GDR_K_COUNT) ? names[id] : "";
 }
 int gdr_kernel_count(void) { return GDR_K_COUNT; }

@@ -230,6 +230,124 @@ __global__ __launch_bounds__(GDR_BLOCK) void ranges_kernel(const uint64_t* __res
     if (e == D - 1) ranges[t].y = (uint32_t)D;
 }
 
+
+// =================================================================================
+// Tile-binned sort (default path).  The sort key is (tile, depth).  Instead of 6 global radix
+// passes over the 12-byte pairs, the pairs are first partitioned by TILE with the stable
+// passes above run on the tile bits only (2 passes at 800x800), K5 reads the tile segments off
+// the partitioned keys, and then ONE workgroup per tile sorts its segment by depth in LDS with
+// a stable 8-bit LSD radix sort on (depth - min depth of the tile): typically 3 passes, no
+// global traffic besides one read and one write of the segment.  Every pass is stable, so ties
+// keep emission order (ascending Gaussian id) exactly like the reference's single global
+// stable sort => bit-identical sorted list.  A segment longer than the LDS capacity is sorted
+// by its workgroup with the same code on the global ping-pong buffers.
+// =================================================================================
+#define GDR_TSORT_LDS_ELEMS 4096  // 16 B per element => 64 KiB (+ counters): 2 workgroups per CU
+
+struct TileSortBufs {
+    uint32_t *kA, *vA, *kB, *vB;
+};
+
+// one stable 8-bit pass over [0,L) from (kA,vA) to (kB,vB); cnt: [4][256] LDS counters
+__device__ __forceinline__ void tile_sort_pass(const TileSortBufs& b, uint32_t L, uint32_t kmin, int shift,
+                                               uint32_t (*cnt)[GDR_RADIX], uint32_t* scan_lds) {
+    const uint32_t w = threadIdx.x >> 6, lane = lane_id();
+    const uint32_t Lw = ((L + 4 * GDR_WAVE - 1) / (4 * GDR_WAVE)) * GDR_WAVE;
+    const uint32_t c0 = min(L, w * Lw), c1 = min(L, c0 + Lw);
+    for (int k = threadIdx.x; k < (GDR_BLOCK / GDR_WAVE) * GDR_RADIX; k += GDR_BLOCK) (&cnt[0][0])[k] = 0;
+    __syncthreads();
+    for (uint32_t i = c0 + lane; i < c1; i += GDR_WAVE)
+        atomicAdd(&cnt[w][((b.kA[i] - kmin) >> shift) & (GDR_RADIX - 1)], 1u);
+    __syncthreads();
+    {
+        const uint32_t d = threadIdx.x;  // GDR_BLOCK == GDR_RADIX
+        const uint32_t n0 = cnt[0][d], n1 = cnt[1][d], n2 = cnt[2][d], n3 = cnt[3][d];
+        const uint32_t base = block_excl_scan(n0 + n1 + n2 + n3, scan_lds, nullptr);
+        cnt[0][d] = base; cnt[1][d] = base + n0; cnt[2][d] = base + n0 + n1; cnt[3][d] = base + n0 + n1 + n2;
+    }
+    __syncthreads();
+    for (uint32_t i0 = c0; i0 < c1; i0 += GDR_WAVE) {
+        const uint32_t i = i0 + lane;
+        const bool valid = i < c1;
+        const uint32_t key = valid ? b.kA[i] : 0u, val = valid ? b.vA[i] : 0u;
+        const uint32_t d = ((key - kmin) >> shift) & (GDR_RADIX - 1);
+        uint64_t m = __ballot(valid);
+#pragma unroll
+        for (int bit = 0; bit < GDR_RADIX_BITS; ++bit) {
+            const uint64_t bal = __ballot((d >> bit) & 1u);
+            m &= ((d >> bit) & 1u) ? bal : ~bal;
+        }
+        uint32_t prior = 0;
+        if (valid) prior = cnt[w][d];
+        const uint32_t below = (uint32_t)__popcll(m & lanemask_lt());
+        if (valid) {
+            b.kB[prior + below] = key;
+            b.vB[prior + below] = val;
+            if ((m >> lane) == 1ull) cnt[w][d] = prior + below + 1u;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();  // (global-memory variant: also the workgroup-scope release/acquire of the stores)
+}
+
+// keys_part: tile-partitioned u64 keys (tile << 32 | depth); vals_part: ids; outputs sorted.
+// scratch32: 2*D uint32 of global scratch (depth keys ping-pong for tiles that do not fit in LDS)
+__global__ __launch_bounds__(GDR_BLOCK) void tile_sort_kernel(const uint2* __restrict__ ranges,
+                                                               const uint64_t* __restrict__ keys_part,
+                                                               uint32_t* __restrict__ vals_part,
+                                                               uint64_t* __restrict__ keys_out,
+                                                               uint32_t* __restrict__ vals_out,
+                                                               uint32_t* __restrict__ scratch32, uint64_t D) {
+    __shared__ uint32_t lds_elems[4 * GDR_TSORT_LDS_ELEMS];
+    __shared__ uint32_t cnt[GDR_BLOCK / GDR_WAVE][GDR_RADIX];
+    __shared__ uint32_t misc[16];
+    const uint32_t tile = blockIdx.x;
+    const uint2 rg = ranges[tile];
+    const uint32_t L = rg.y - rg.x;
+    if (L == 0) return;
+    const uint32_t w = threadIdx.x >> 6, lane = lane_id();
+    const bool in_lds = L <= GDR_TSORT_LDS_ELEMS;
+    TileSortBufs b;
+    if (in_lds) {
+        b.kA = lds_elems; b.vA = lds_elems + GDR_TSORT_LDS_ELEMS;
+        b.kB = lds_elems + 2 * GDR_TSORT_LDS_ELEMS; b.vB = lds_elems + 3 * GDR_TSORT_LDS_ELEMS;
+    } else {  // global ping-pong: this tile's own slices of the scratch / value buffers
+        b.kA = scratch32 + rg.x; b.kB = scratch32 + D + rg.x;
+        b.vA = vals_part + rg.x; b.vB = vals_out + rg.x;
+    }
+    uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
+    for (uint32_t i = threadIdx.x; i < L; i += GDR_BLOCK) {
+        const uint32_t k = (uint32_t)keys_part[rg.x + i];
+        b.kA[i] = k;
+        if (in_lds) b.vA[i] = vals_part[rg.x + i];
+        kmin = min(kmin, k);
+        kmax = max(kmax, k);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, off, 64));
+        kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, off, 64));
+    }
+    if (lane == 0) { misc[8 + w] = kmin; misc[12 + w] = kmax; }
+    __syncthreads();
+    kmin = min(min(misc[8], misc[9]), min(misc[10], misc[11]));
+    kmax = max(max(misc[12], misc[13]), max(misc[14], misc[15]));
+    const uint32_t span = kmax - kmin;
+    const int nbits = span ? 32 - __builtin_clz(span) : 0;
+    for (int shift = 0; shift < nbits; shift += GDR_RADIX_BITS) {
+        if (in_lds) tile_sort_pass(b, L, kmin, shift, cnt, misc);
+        else tile_sort_pass(b, L, kmin, shift, cnt, misc);
+        uint32_t* t = b.kA; b.kA = b.kB; b.kB = t;
+        t = b.vA; b.vA = b.vB; b.vB = t;
+    }
+    for (uint32_t i = threadIdx.x; i < L; i += GDR_BLOCK) {
+        const uint32_t v = b.vA[i];
+        const uint32_t k = b.kA[i];
+        if (in_lds || b.vA != vals_out + rg.x) vals_out[rg.x + i] = v;
+        keys_out[rg.x + i] = ((uint64_t)tile << 32) | (uint64_t)k;
+    }
+}
+
 }  // namespace
 
 size_t sort_hist_bytes(uint64_t D) {
@@ -272,6 +390,37 @@ hipError_t launch_sort(gdr_binning* bin, uint64_t D, int nbits, hipStream_t st) 
         cur ^= 1;
     }
     bin->sorted = cur;
+    return hipGetLastError();
+}
+
+// stable partition of the pairs by tile: the LSD passes restricted to key bits [32, nbits)
+hipError_t launch_sort_tile_bits(gdr_binning* bin, uint64_t D, int nbits, hipStream_t st) {
+    bin->sorted = 0;
+    if (D == 0) return hipSuccess;
+    const uint32_t nblk = (uint32_t)((D + GDR_SORT_TILE - 1) / GDR_SORT_TILE);
+    uint32_t* hist = bin->hist;
+    uint32_t* totals = bin->hist + (uint64_t)nblk * GDR_RADIX;
+    int cur = 0;
+    for (int shift = 32; shift < nbits; shift += GDR_RADIX_BITS) {
+        GDR_LAUNCH(GDR_K_SORT_HIST, sort_hist_kernel, dim3(nblk), dim3(GDR_BLOCK), st, bin->keys[cur], D,
+                   shift, nblk, hist);
+        GDR_LAUNCH(GDR_K_SORT_ROWSCAN, sort_rowscan_kernel, dim3(GDR_RADIX), dim3(GDR_BLOCK), st, hist, nblk,
+                   totals);
+        GDR_LAUNCH(GDR_K_SORT_SCATTER, sort_scatter_kernel, dim3(nblk), dim3(GDR_BLOCK), st, bin->keys[cur],
+                   bin->values[cur], bin->keys[cur ^ 1], bin->values[cur ^ 1], D, shift, nblk, hist, totals);
+        cur ^= 1;
+    }
+    bin->sorted = cur;
+    return hipGetLastError();
+}
+
+// per-tile depth sort; input = buffers [bin->sorted] (tile-partitioned), output = the other pair
+hipError_t launch_tile_sort(gdr_binning* bin, const gdr_image* img, int tiles, uint64_t D, hipStream_t st) {
+    if (D == 0) return hipSuccess;
+    const int in = bin->sorted, out = in ^ 1;
+    GDR_LAUNCH(GDR_K_TILE_SORT, tile_sort_kernel, dim3(tiles), dim3(GDR_BLOCK), st, (const uint2*)img->ranges,
+               bin->keys[in], bin->values[in], bin->keys[out], bin->values[out], bin->scratch32, D);
+    bin->sorted = out;
     return hipGetLastError();
 }
 

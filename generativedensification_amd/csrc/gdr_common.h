@@ -30,6 +30,7 @@ enum {
     GDR_K_PREPROCESS_BWD,
     GDR_K_MARK_VISIBLE,
     GDR_K_TILE_ORDER,
+    GDR_K_TILE_SORT,
     GDR_K_COUNT
 };
 
@@ -79,6 +80,9 @@ hipError_t launch_preprocess_bwd_views(int V, const gdr_settings* s, const gdr_i
 hipError_t launch_mark_visible(int N, const float* means3D, const float* view, uint8_t* present,
                                hipStream_t st);
 hipError_t launch_scan_block_sums(const gdr_geom* g, int N, hipStream_t st);
+// tile-binned sort (binning.hip)
+hipError_t launch_sort_tile_bits(gdr_binning* bin, uint64_t D, int nbits, hipStream_t st);
+hipError_t launch_tile_sort(gdr_binning* bin, const gdr_image* img, int tiles, uint64_t D, hipStream_t st);
 hipError_t launch_duplicate(const gdr_geom* g, int N, int W, int H, const int32_t* radii,
                             uint64_t* keys, uint32_t* vals, uint64_t D, hipStream_t st);
 hipError_t launch_sort(gdr_binning* bin, uint64_t D, int nbits, hipStream_t st);

@@ -116,6 +116,10 @@ def _inputs_struct(N, M, means3D, opacities, sh, colors_precomp, scales, rotatio
                        _ptr(rotations), _ptr(cov3Ds), int(flags), 0)
 
 
+# test / A-B hook: one global radix sort instead of tile partition + per-tile LDS sort
+_FORCE_GLOBAL_SORT = False
+
+
 def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -162,6 +166,7 @@ def forward_raw(means3D, sh, colors_precomp, opacities, scales, rotations, cov3D
         st.D = int(d_host.value)
         st.bin_buf = torch.empty(lib.gdr_binning_bytes(st.D), **u8)
         L.check(lib.gdr_binning_carve(st.bin_buf.data_ptr(), st.D, C.byref(st.bin)), "gdr_binning_carve")
+        st.bin.global_sort = int(_FORCE_GLOBAL_SORT)
         out = L.GdrOutputs(color.data_ptr(), depth.data_ptr(), alpha.data_ptr(), _ptr(radii))
         L.check(lib.gdr_render_forward(C.byref(s), C.byref(inp), C.byref(st.geom), C.byref(st.bin),
                                        C.byref(st.img), st.D, C.byref(out), stream), "gdr_render_forward")
@@ -300,6 +305,7 @@ class _RenderViews(torch.autograd.Function):
                 st.D = int(d_host[v]) & 0xFFFFFFFF
                 st.bin_buf = torch.empty(lib.gdr_binning_bytes(st.D), **u8)
                 L.check(lib.gdr_binning_carve(st.bin_buf.data_ptr(), st.D, C.byref(st.bin)), "gdr_binning_carve")
+                st.bin.global_sort = int(_FORCE_GLOBAL_SORT)
                 out = L.GdrOutputs(colors[v].data_ptr(), depths[v].data_ptr(), alphas[v].data_ptr(), _ptr(radii[v]))
                 L.check(lib.gdr_render_forward(C.byref(s_arr[v]), C.byref(inp), C.byref(g_arr[v]), C.byref(st.bin),
                                                C.byref(st.img), st.D, C.byref(out), stream), "gdr_render_forward")

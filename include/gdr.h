@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define GDR_ABI_VERSION 2
+#define GDR_ABI_VERSION 3
 
 #define GDR_OK 0
 #define GDR_ERR_INVALID_ARG (-1)  /* NULL / inconsistent arguments                     */
@@ -112,7 +112,9 @@ typedef struct gdr_binning {
     uint32_t* values[2]; /* (D) Gaussian index                              */
     uint32_t* hist;      /* radix-sort scratch                              */
     int32_t sorted;      /* which of the two buffers holds the sorted list  */
-    int32_t reserved;
+    int32_t global_sort; /* !=0: one global LSD radix sort over all key bits instead of the default
+                          * tile partition + per-tile LDS depth sort (same result; A/B and tests) */
+    uint32_t* scratch32; /* (2*D) depth-key ping-pong for tile lists that do not fit in LDS */
 } gdr_binning;
 
 /* Image state (upstream "imgBuffer"). */
