@@ -142,11 +142,16 @@ __device__ __forceinline__ void block_masks(const SliceLds& s, int g, float XA, 
     m3 = __ballot(x1 && y1 && a3);
 }
 
-// first set bit (or -1) and clear it: s_ff1_i32_b64 + s_bitset0_b64
-__device__ __forceinline__ int take_bit(uint64_t& m) {
-    const int b = __builtin_ffsll((long long)m) - 1;
-    m &= ~(1ull << (b & 63));
+// Per-LANE mask walk: every lane carries its row's 64-bit sub-list mask in two VGPRs and takes
+// the first set bit (0xFFFFFFFF if none) with VALU ops (v_ffbl_b32 x2).  The scalar unit is
+// shared by the CU's four SIMDs; walking four SGPR masks cost ~25 SALU per iteration.
+__device__ __forceinline__ uint32_t take_bit(uint64_t& m) {
+    const uint32_t b = (uint32_t)(__builtin_ffsll((long long)m) - 1);
+    m &= m - 1ull;
     return b;
+}
+__device__ __forceinline__ uint64_t row_select(uint32_t row, uint64_t m0, uint64_t m1, uint64_t m2, uint64_t m3) {
+    return row == 0 ? m0 : (row == 1 ? m1 : (row == 2 ? m2 : m3));
 }
 
 // ---------------------------------------------------------------------------------
@@ -258,9 +263,8 @@ __global__ __launch_bounds__(GDR_BLOCK) void render_fwd_kernel(
             if ((m0 | m1 | m2 | m3) == 0ull) continue;
             const uint32_t goff = (uint32_t)(g * GDR_WAVE), nulloff = GDR_NULL_ENTRY - goff;
             // software pipeline: entry `e` is loaded one iteration before it is composited
-            int b0 = take_bit(m0), b1 = take_bit(m1), b2 = take_bit(m2), b3 = take_bit(m3);
-            uint32_t es = (uint32_t)(row == 0 ? b0 : (row == 1 ? b1 : (row == 2 ? b2 : b3)));
-            uint32_t e = min(es, nulloff) + goff;  // (uint)-1 -> null entry
+            uint64_t mr = row_select(row, m0, m1, m2, m3);
+            uint32_t e = min(take_bit(mr), nulloff) + goff;  // 0xFFFFFFFF (no entry) -> null entry
             float2 m = lds.xy[e];
             float4 co = lds.co[e], cd = lds.cd[e];
             bool more = true;
@@ -268,10 +272,8 @@ __global__ __launch_bounds__(GDR_BLOCK) void render_fwd_kernel(
                 const uint32_t e_cur = e;
                 const float2 m_cur = m;
                 const float4 co_cur = co, cd_cur = cd;
-                more = (m0 | m1 | m2 | m3) != 0ull;
-                b0 = take_bit(m0); b1 = take_bit(m1); b2 = take_bit(m2); b3 = take_bit(m3);
-                es = (uint32_t)(row == 0 ? b0 : (row == 1 ? b1 : (row == 2 ? b2 : b3)));
-                e = min(es, nulloff) + goff;
+                more = __ballot(mr != 0ull) != 0ull;
+                e = min(take_bit(mr), nulloff) + goff;
                 m = lds.xy[e]; co = lds.co[e]; cd = lds.cd[e];
 
                 const float dx = m_cur.x - pxf, dy = m_cur.y - pyf;
@@ -292,10 +294,7 @@ __global__ __launch_bounds__(GDR_BLOCK) void render_fwd_kernel(
                 last_contributor = (w > 0.f) ? base + e_cur : last_contributor;
                 if (__ballot(stop) != 0ull) {  // rare: some pixel saturated -> retire finished blocks
                     live = __ballot(thr < INFINITY);
-                    if (!(live & GDR_ROW_MASK(0))) m0 = 0ull;
-                    if (!(live & GDR_ROW_MASK(1))) m1 = 0ull;
-                    if (!(live & GDR_ROW_MASK(2))) m2 = 0ull;
-                    if (!(live & GDR_ROW_MASK(3))) m3 = 0ull;
+                    if (((live >> (16 * row)) & 0xFFFFull) == 0ull) mr = 0ull;
                     if (live == 0ull) { more = false; g = GDR_BLOCK / GDR_WAVE; }
                 }
             }
@@ -408,9 +407,8 @@ __global__ __launch_bounds__(GDR_BLOCK) void render_bwd_kernel(
             block_masks(lds, g, XA, YA, mypos < rl0, mypos < rl1, mypos < rl2, mypos < rl3, m0, m1, m2, m3);
             if ((m0 | m1 | m2 | m3) == 0ull) continue;
             const uint32_t goff = (uint32_t)(g * GDR_WAVE), nulloff = GDR_NULL_ENTRY - goff;
-            int b0 = take_bit(m0), b1 = take_bit(m1), b2 = take_bit(m2), b3 = take_bit(m3);
-            uint32_t es = (uint32_t)(row == 0 ? b0 : (row == 1 ? b1 : (row == 2 ? b2 : b3)));
-            uint32_t e = min(es, nulloff) + goff;
+            uint64_t mr = row_select(row, m0, m1, m2, m3);
+            uint32_t e = min(take_bit(mr), nulloff) + goff;
             float2 m = lds.xy[e];
             float4 co = lds.co[e], cd = lds.cd[e];
             bool more = true;
@@ -418,10 +416,8 @@ __global__ __launch_bounds__(GDR_BLOCK) void render_bwd_kernel(
                 const uint32_t e_cur = e;
                 const float2 m_cur = m;
                 const float4 co_cur = co, cd_cur = cd;
-                more = (m0 | m1 | m2 | m3) != 0ull;
-                b0 = take_bit(m0); b1 = take_bit(m1); b2 = take_bit(m2); b3 = take_bit(m3);
-                es = (uint32_t)(row == 0 ? b0 : (row == 1 ? b1 : (row == 2 ? b2 : b3)));
-                e = min(es, nulloff) + goff;
+                more = __ballot(mr != 0ull) != 0ull;
+                e = min(take_bit(mr), nulloff) + goff;
                 m = lds.xy[e]; co = lds.co[e]; cd = lds.cd[e];
 
                 const float dx = m_cur.x - pxf, dy = m_cur.y - pyf;
