@@ -87,6 +87,9 @@ def main():
                     help="call render_img + backward once per view (the reference's loop) instead of render_views")
     ap.add_argument("--unfused", action="store_true",
                     help="torch activations before the rasterizer, op for op as lightning/renderer.py:225-230")
+    ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL on ROCm)")
+    ap.add_argument("--single-device", action="store_true",
+                    help="developer smoke test of the N>1 code path on a 1-GPU box: every rank uses cuda:0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--traffic-bytes", type=float, default=None,
@@ -98,11 +101,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (no CPU fallback for the product path)")
+    if args.single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.dist_backend)
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from generativedensification_amd import _lib as L

@@ -68,9 +68,7 @@ static size_t carve_geom(void* base, int64_t N, gdr_geom* g) {
     gdr_geom t;
     const size_t n = (size_t)(N > 0 ? N : 1);
     t.depths = c.take<float>(n);
-    t.xy = c.take<float>(2 * n);
-    t.conic_opacity = c.take<float>(4 * n);
-    t.rgb = c.take<float>(4 * n);
+    t.rec = c.take<float>(16 * n);
     t.cov3D = c.take<float>(6 * n);
     t.rect = c.take<int32_t>(4 * n);
     t.tiles_touched = c.take<uint32_t>(n);

@@ -131,6 +131,26 @@ __device__ __forceinline__ float4 act_normalize(float4 q, float* inv_norm) {
     return make_float4(q.x * inv, q.y * inv, q.z * inv, q.w * inv);
 }
 
+// conservative half-extent (pixels) of {alpha >= 1/255} for conic (cx,cy,cz) and opacity o:
+// exact bounding box of the ellipse power >= -ln(255 o), widened by 0.2 % + 0.02 px.  K6/K7 only
+// use it to skip entries that would fail the alpha test at every pixel of a 4x4 block.
+__device__ __forceinline__ float2 alpha_extent(const float4 co) {
+    const float t = 255.f * co.w;
+    if (!(t > 1.f)) return make_float2(-1.f, -1.f);  // alpha <= o < 1/255 everywhere (also NaN)
+    const float det = co.x * co.z - co.y * co.y;
+    if (!(det > 0.f)) return make_float2(1e30f, 1e30f);  // degenerate: never cull
+    const float tau2 = 2.f * __logf(t) / det;            // 2 ln(255 o) / det(conic)
+    return make_float2(sqrtf(tau2 * co.z) * 1.002f + 0.02f, sqrtf(tau2 * co.x) * 1.002f + 0.02f);
+}
+__device__ __forceinline__ void write_rec(float4* __restrict__ rec, int i, float2 pxy, float depth, float4 con_o,
+                                          float4 rgbd) {
+    const float2 ext = alpha_extent(con_o);
+    rec[4 * i + 0] = make_float4(pxy.x, pxy.y, depth, 0.f);
+    rec[4 * i + 1] = con_o;
+    rec[4 * i + 2] = rgbd;
+    rec[4 * i + 3] = make_float4(ext.x, ext.y, 0.f, 0.f);
+}
+
 // EWA projection pieces shared by forward and backward (Appendix A.1-4).
 struct Ewa {
     float tx, ty, tz, xmul, ymul;
@@ -177,7 +197,7 @@ __global__ __launch_bounds__(GDR_BLOCK) void preprocess_fwd_kernel(
     const float* __restrict__ cov3D_precomp, const float* __restrict__ view,
     const float* __restrict__ proj, const float* __restrict__ campos, int W, int H, float tanx,
     float tany, float focal_x, float focal_y, int32_t* __restrict__ radii, float* __restrict__ g_depths,
-    float2* __restrict__ g_xy, float4* __restrict__ g_conic_opacity, float4* __restrict__ g_rgb,
+    float4* __restrict__ g_rec,
     float* __restrict__ g_cov3D, int4* __restrict__ g_rect, uint32_t* __restrict__ g_tiles,
     uint8_t* __restrict__ g_clamped, uint32_t* __restrict__ block_sums, uint32_t flags) {
     Cam cam;
@@ -290,9 +310,7 @@ __global__ __launch_bounds__(GDR_BLOCK) void preprocess_fwd_kernel(
         }
         radii[i] = rad;
         g_depths[i] = depth;
-        g_xy[i] = pxy;
-        g_conic_opacity[i] = con_o;
-        g_rgb[i] = rgbd;
+        write_rec(g_rec, i, pxy, depth, con_o, rgbd);
         if (!cov3D_precomp) {
 #pragma unroll
             for (int k = 0; k < 6; ++k) g_cov3D[6 * i + k] = c6[k];
@@ -329,7 +347,7 @@ __global__ __launch_bounds__(GDR_BLOCK) void preprocess_bwd_kernel(
     float focal_y, const float4* __restrict__ grad_rec, float4* __restrict__ dL_dmean2D,
     float* __restrict__ dL_dopacity, float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dcov3D, float* __restrict__ dL_dsh,
     float* __restrict__ dL_dcolors, float* __restrict__ dL_dscale, float4* __restrict__ dL_drot,
-    const float4* __restrict__ g_conic_opacity, uint32_t flags, int accumulate) {
+    const float4* __restrict__ g_rec, uint32_t flags, int accumulate) {
     Cam cam;
     load_cam(cam, view, proj, campos);
     const int i = blockIdx.x * GDR_BLOCK + threadIdx.x;
@@ -351,7 +369,7 @@ __global__ __launch_bounds__(GDR_BLOCK) void preprocess_bwd_kernel(
         {
             float dop = gcolor.w;
             if (flags & GDR_IN_RAW_OPACITY) {  // d sigmoid = o (1 - o), o as stored by K1
-                const float o = g_conic_opacity[i].w;
+                const float o = g_rec[4 * i + 1].w;
                 dop = dop * (o * (1.f - o));
             }
             if (accumulate) {
@@ -574,7 +592,7 @@ __global__ __launch_bounds__(GDR_BLOCK) void preprocess_bwd_kernel(
 struct FwdView {
     const float* view; const float* proj; const float* campos;
     float tanx, tany, fx, fy;
-    int32_t* radii; float* depths; float2* xy; float4* conic_opacity; float4* rgb; int4* rect;
+    int32_t* radii; float* depths; float4* rec; int4* rect;
     uint32_t* tiles; uint8_t* clamped; uint32_t* block_sums;
 };
 struct FwdViewsArgs { int V; FwdView v[GDR_MAX_VIEWS]; };
@@ -706,9 +724,7 @@ __global__ __launch_bounds__(GDR_BLOCK) void preprocess_fwd_views_kernel(
             }
             fv.radii[i] = rad;
             fv.depths[i] = depth;
-            fv.xy[i] = pxy;
-            fv.conic_opacity[i] = con_o;
-            fv.rgb[i] = rgbd;
+            write_rec(fv.rec, i, pxy, depth, con_o, rgbd);
             fv.rect[i] = rect;
             fv.tiles[i] = tiles;
             fv.clamped[i] = (uint8_t)clampbits;
@@ -958,8 +974,7 @@ hipError_t launch_preprocess_fwd(const gdr_settings* s, const gdr_inputs* in, co
     LAUNCH_DEG(GDR_K_PREPROCESS_FWD, preprocess_fwd_kernel, deg, grid, st, N, in->M, in->means3D, in->scales,
                s->scale_modifier, in->rotations, in->opacities, in->shs, in->colors_precomp,
                in->cov3D_precomp, s->viewmatrix, s->projmatrix, s->campos, W, H, s->tanfovx,
-               s->tanfovy, focal_x, focal_y, radii, g->depths, (float2*)g->xy,
-               (float4*)g->conic_opacity, (float4*)g->rgb, g->cov3D, (int4*)g->rect,
+               s->tanfovy, focal_x, focal_y, radii, g->depths, (float4*)g->rec, g->cov3D, (int4*)g->rect,
                g->tiles_touched, g->clamped, g->block_sums, in->flags);
     return hipGetLastError();
 }
@@ -979,7 +994,7 @@ hipError_t launch_preprocess_bwd(const gdr_settings* s, const gdr_inputs* in, co
                s->projmatrix, s->campos, W, H, s->tanfovx, s->tanfovy, focal_x, focal_y,
                (const float4*)go->scratch, (float4*)go->dL_dmeans2D, go->dL_dopacities, go->dL_dmeans3D,
                go->dL_dcov3D, go->dL_dshs, go->dL_dcolors, go->dL_dscales,
-               (float4*)go->dL_drotations, (const float4*)g->conic_opacity, in->flags, go->accumulate);
+               (float4*)go->dL_drotations, (const float4*)g->rec, in->flags, go->accumulate);
     return hipGetLastError();
 }
 
@@ -995,8 +1010,7 @@ hipError_t launch_preprocess_fwd_views(int V, const gdr_settings* s, const gdr_i
         f.view = s[v].viewmatrix; f.proj = s[v].projmatrix; f.campos = s[v].campos;
         f.tanx = s[v].tanfovx; f.tany = s[v].tanfovy;
         f.fx = (float)W / (2.f * s[v].tanfovx); f.fy = (float)H / (2.f * s[v].tanfovy);
-        f.radii = radii[v]; f.depths = geoms[v].depths; f.xy = (float2*)geoms[v].xy;
-        f.conic_opacity = (float4*)geoms[v].conic_opacity; f.rgb = (float4*)geoms[v].rgb;
+        f.radii = radii[v]; f.depths = geoms[v].depths; f.rec = (float4*)geoms[v].rec;
         f.rect = (int4*)geoms[v].rect; f.tiles = geoms[v].tiles_touched; f.clamped = geoms[v].clamped;
         f.block_sums = geoms[v].block_sums;
     }

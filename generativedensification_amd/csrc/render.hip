@@ -10,9 +10,10 @@
 //   * one workgroup = one 16x16 tile = 4 wavefronts; a wave owns an 8x8 sub-tile and each of
 //     its four 16-lane DPP rows composites its OWN 4x4 pixel block against its OWN culled
 //     sub-list, so one wave instruction advances up to four different Gaussians;
-//   * the tile's sorted slice is staged 256 entries at a time in LDS (xy, alpha-extent,
-//     conic*log2e + opacity, rgb + depth = 48 B/entry) while the next slice is already being
-//     fetched into registers; every lane tests ONE staged entry's {alpha >= 1/255} bounding box
+//   * every Gaussian's render attributes live in ONE 64-byte record (xy, conic + opacity,
+//     rgb + depth, alpha-extent; written by K1), so the gather by sorted id touches one cache
+//     line per entry instead of three; the tile's sorted slice is staged 256 entries at a time
+//     in LDS while the next slice is already being fetched into registers; every lane tests ONE staged entry's {alpha >= 1/255} bounding box
 //     against the four blocks and four 64-bit ballots give each block its sub-list (SGPR masks);
 //     the test is conservative, so results (incl. n_contrib = position in the FULL tile list)
 //     are identical to evaluating every entry;
@@ -93,16 +94,6 @@ __device__ __forceinline__ float row_reduce_scatter12(const float (&v)[12], uint
     return keep + dpp_get<0xB1, 0xf>(send);       // quad_perm [1,0,3,2]: partner i ^ 1
 }
 
-// conservative half-extent (pixels) of {alpha >= 1/255} for conic (cx,cy,cz) and opacity o
-__device__ __forceinline__ float2 alpha_extent(const float4 co) {
-    const float t = 255.f * co.w;
-    if (!(t > 1.f)) return make_float2(-1.f, -1.f);  // alpha <= o < 1/255 everywhere (also NaN)
-    const float det = co.x * co.z - co.y * co.y;
-    if (!(det > 0.f)) return make_float2(1e30f, 1e30f);  // degenerate: never cull
-    const float tau2 = 2.f * __logf(t) / det;            // 2 ln(255 o) / det(conic)
-    return make_float2(sqrtf(tau2 * co.z) * 1.002f + 0.02f, sqrtf(tau2 * co.x) * 1.002f + 0.02f);
-}
-
 #define GDR_ROW_MASK(k) (0xFFFFull << (16 * (k)))
 
 // LDS image of one 256-entry slice (+ the null entry)
@@ -113,10 +104,10 @@ struct SliceLds {
     float4 cd[GDR_BLOCK + 1];
 };
 
-__device__ __forceinline__ void stage_write(SliceLds& s, bool valid, float2 xy, float4 co, float4 cd) {
-    if (valid) {
-        s.xy[threadIdx.x] = xy;
-        s.ext[threadIdx.x] = alpha_extent(co);
+__device__ __forceinline__ void stage_write(SliceLds& s, bool valid, float4 xe, float4 co, float4 cd) {
+    if (valid) {  // xe = (x, y, extent_x, extent_y)
+        s.xy[threadIdx.x] = make_float2(xe.x, xe.y);
+        s.ext[threadIdx.x] = make_float2(xe.z, xe.w);
         s.co[threadIdx.x] = make_float4(co.x * GDR_LOG2E, co.y * GDR_LOG2E, co.z * GDR_LOG2E, co.w);
         s.cd[threadIdx.x] = cd;
     } else {
@@ -201,8 +192,7 @@ __global__ __launch_bounds__(GDR_BLOCK) void tile_order_kernel(const uint2* __re
 __global__ __launch_bounds__(GDR_BLOCK) void render_fwd_kernel(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const uint32_t* __restrict__ tile_order, int W, int H, int gx, int ntiles,
-    const float2* __restrict__ xy, const float4* __restrict__ conic_opacity,
-    const float4* __restrict__ rgbd, const float* __restrict__ bg, float* __restrict__ final_T,
+    const float4* __restrict__ rec, const float* __restrict__ bg, float* __restrict__ final_T,
     uint32_t* __restrict__ n_contrib, float* __restrict__ out_color, float* __restrict__ out_depth,
     float* __restrict__ out_alpha) {
     __shared__ SliceLds lds;
@@ -231,26 +221,27 @@ __global__ __launch_bounds__(GDR_BLOCK) void render_fwd_kernel(
     float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f, Wt = 0.f;
     uint32_t last_contributor = 0;
 
-    float2 r_xy = make_float2(0.f, 0.f);
-    float4 r_co = make_float4(0.f, 0.f, 0.f, 0.f), r_cd = r_co;
+    float4 r_xe = make_float4(0.f, 0.f, 0.f, 0.f), r_co = r_xe, r_cd = r_xe;
     bool r_valid = (int)threadIdx.x < total;
     if (r_valid) {
         const uint32_t id = point_list[range.x + threadIdx.x];
-        r_xy = xy[id]; r_co = conic_opacity[id]; r_cd = rgbd[id];
+        { const float4 a0 = rec[4 * (size_t)id], a3 = rec[4 * (size_t)id + 3];
+          r_xe = make_float4(a0.x, a0.y, a3.x, a3.y); r_co = rec[4 * (size_t)id + 1]; r_cd = rec[4 * (size_t)id + 2]; }
     }
     for (int r = 0; r < rounds; ++r) {
         uint64_t live = __ballot(thr < INFINITY);
         if (lane == 0) s_done[wave] = live == 0ull ? 1 : 0;
         __syncthreads();
         if (s_done[0] + s_done[1] + s_done[2] + s_done[3] == GDR_BLOCK / GDR_WAVE) break;
-        stage_write(lds, r_valid, r_xy, r_co, r_cd);
+        stage_write(lds, r_valid, r_xe, r_co, r_cd);
         __syncthreads();
         {   // prefetch the next slice (lands while this one is composited)
             const int nxt = (r + 1) * GDR_BLOCK + (int)threadIdx.x;
             r_valid = nxt < total;
             if (r_valid) {
                 const uint32_t id = point_list[range.x + nxt];
-                r_xy = xy[id]; r_co = conic_opacity[id]; r_cd = rgbd[id];
+                { const float4 a0 = rec[4 * (size_t)id], a3 = rec[4 * (size_t)id + 3];
+          r_xe = make_float4(a0.x, a0.y, a3.x, a3.y); r_co = rec[4 * (size_t)id + 1]; r_cd = rec[4 * (size_t)id + 2]; }
             }
         }
         if (live == 0ull) continue;
@@ -320,9 +311,7 @@ __global__ __launch_bounds__(GDR_BLOCK) void render_fwd_kernel(
 __global__ __launch_bounds__(GDR_BLOCK) void render_bwd_kernel(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const uint32_t* __restrict__ tile_order, int W, int H, int gx, int ntiles,
-    const float* __restrict__ bg, const float2* __restrict__ xy,
-    const float4* __restrict__ conic_opacity, const float4* __restrict__ rgbd,
-    const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
+    const float* __restrict__ bg, const float4* __restrict__ rec, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
     const float* __restrict__ dL_dpix, const float* __restrict__ dL_ddepthpix,
     const float* __restrict__ dL_dalphapix, float* __restrict__ grad_rec) {
     __shared__ SliceLds lds;
@@ -375,17 +364,17 @@ __global__ __launch_bounds__(GDR_BLOCK) void render_bwd_kernel(
     const int wave_last = max(max(rl0, rl1), max(rl2, rl3));
 
     // slice r holds list positions total-1-(r*256+e), e = 0..255: back to front
-    float2 r_xy = make_float2(0.f, 0.f);
-    float4 r_co = make_float4(0.f, 0.f, 0.f, 0.f), r_cd = r_co;
+    float4 r_xe = make_float4(0.f, 0.f, 0.f, 0.f), r_co = r_xe, r_cd = r_xe;
     uint32_t r_id = 0;
     bool r_valid = (int)threadIdx.x < total;
     if (r_valid) {
         r_id = point_list[range.y - 1 - threadIdx.x];
-        r_xy = xy[r_id]; r_co = conic_opacity[r_id]; r_cd = rgbd[r_id];
+        { const float4 a0 = rec[4 * (size_t)r_id], a3 = rec[4 * (size_t)r_id + 3];
+          r_xe = make_float4(a0.x, a0.y, a3.x, a3.y); r_co = rec[4 * (size_t)r_id + 1]; r_cd = rec[4 * (size_t)r_id + 2]; }
     }
     for (int r = 0; r < rounds; ++r) {
         __syncthreads();  // every wave finished reading the previous slice
-        stage_write(lds, r_valid, r_xy, r_co, r_cd);
+        stage_write(lds, r_valid, r_xe, r_co, r_cd);
         if (r_valid) s_id[threadIdx.x] = r_id;
         __syncthreads();
         {
@@ -393,7 +382,8 @@ __global__ __launch_bounds__(GDR_BLOCK) void render_bwd_kernel(
             r_valid = nxt < total;
             if (r_valid) {
                 r_id = point_list[range.y - 1 - nxt];
-                r_xy = xy[r_id]; r_co = conic_opacity[r_id]; r_cd = rgbd[r_id];
+                { const float4 a0 = rec[4 * (size_t)r_id], a3 = rec[4 * (size_t)r_id + 3];
+          r_xe = make_float4(a0.x, a0.y, a3.x, a3.y); r_co = rec[4 * (size_t)r_id + 1]; r_cd = rec[4 * (size_t)r_id + 2]; }
             }
         }
         const int top = total - 1 - r * GDR_BLOCK;  // list position of LDS entry e: top - e
@@ -476,8 +466,7 @@ hipError_t launch_render_fwd(const gdr_settings* s, const gdr_geom* g, const gdr
     const int ntiles = gx * gy;
     GDR_LAUNCH(GDR_K_RENDER_FWD, render_fwd_kernel, dim3(ntiles), dim3(GDR_BLOCK), st,
                (const uint2*)img->ranges, bin->values[bin->sorted], img->tile_order, W, H, gx, ntiles,
-               (const float2*)g->xy, (const float4*)g->conic_opacity, (const float4*)g->rgb, s->bg,
-               img->final_T, img->n_contrib, out->color, out->depth, out->alpha);
+               (const float4*)g->rec, s->bg, img->final_T, img->n_contrib, out->color, out->depth, out->alpha);
     return hipGetLastError();
 }
 
@@ -489,8 +478,7 @@ hipError_t launch_render_bwd(const gdr_settings* s, const gdr_geom* g, const gdr
     const int ntiles = gx * gy;
     GDR_LAUNCH(GDR_K_RENDER_BWD, render_bwd_kernel, dim3(ntiles), dim3(GDR_BLOCK), st,
                (const uint2*)img->ranges, bin->values[bin->sorted], img->tile_order, W, H, gx, ntiles, s->bg,
-               (const float2*)g->xy, (const float4*)g->conic_opacity, (const float4*)g->rgb,
-               img->final_T, img->n_contrib, gi->dL_dcolor, gi->dL_ddepth, gi->dL_dalpha,
+               (const float4*)g->rec, img->final_T, img->n_contrib, gi->dL_dcolor, gi->dL_ddepth, gi->dL_dalpha,
                go->scratch);
     return hipGetLastError();
 }

@@ -78,9 +78,7 @@ class _State:
         s = b.sorted
         out = dict(
             depths=self._view(gb, g.depths, torch.float32, N),
-            xy=self._view(gb, g.xy, torch.float32, 2 * N).view(N, 2),
-            conic_opacity=self._view(gb, g.conic_opacity, torch.float32, 4 * N).view(N, 4),
-            rgb=self._view(gb, g.rgb, torch.float32, 4 * N).view(N, 4),
+            rec=self._view(gb, g.rec, torch.float32, 16 * N).view(N, 16),
             cov3D=self._view(gb, g.cov3D, torch.float32, 6 * N).view(N, 6),
             rect=self._view(gb, g.rect, torch.int32, 4 * N).view(N, 4),
             tiles_touched=self._view(gb, g.tiles_touched, torch.int32, N),
@@ -90,6 +88,7 @@ class _State:
             final_T=self._view(ib, im.final_T, torch.float32, H * W).view(H, W),
             num_rendered=D,
         )
+        out["xy"], out["conic_opacity"], out["rgb"] = out["rec"][:, 0:2], out["rec"][:, 4:8], out["rec"][:, 8:12]
         if D > 0:
             out["keys_sorted"] = self._view(bb, b.keys[s], torch.int64, D)
             out["point_list"] = self._view(bb, b.values[s], torch.int32, D)

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define GDR_ABI_VERSION 3
+#define GDR_ABI_VERSION 4
 
 #define GDR_OK 0
 #define GDR_ERR_INVALID_ARG (-1)  /* NULL / inconsistent arguments                     */
@@ -95,9 +95,12 @@ typedef struct gdr_inputs {
  * (upstream "geomBuffer").  Carved from one caller allocation by gdr_geom_carve. */
 typedef struct gdr_geom {
     float* depths;           /* (N)   camera-space z                         */
-    float* xy;               /* (N,2) pixel-space mean                       */
-    float* conic_opacity;    /* (N,4) inverse 2D cov (xx,xy,yy) + opacity    */
-    float* rgb;              /* (N,4) SH colour (3) + pad                    */
+    float* rec;              /* (N,16) render record, ONE 64-byte line per Gaussian so that
+                              * K6/K7 gather one line instead of three:
+                              *   [0..1] pixel-space mean xy   [2] depth   [3] -
+                              *   [4..6] inverse 2D cov (xx,xy,yy)         [7] opacity
+                              *   [8..10] colour rgb            [11] depth
+                              *   [12..13] half-extent of {alpha >= 1/255} (px; < 0: never)  */
     float* cov3D;            /* (N,6)                                        */
     int32_t* rect;           /* (N,4) tile rect minx,miny,maxx,maxy          */
     uint32_t* tiles_touched; /* (N)                                          */
