@@ -242,7 +242,10 @@ __global__ __launch_bounds__(GDR_BLOCK) void ranges_kernel(const uint64_t* __res
 // stable sort => bit-identical sorted list.  A segment longer than the LDS capacity is sorted
 // by its workgroup with the same code on the global ping-pong buffers.
 // =================================================================================
-#define GDR_TSORT_LDS_ELEMS 4096  // 16 B per element => 64 KiB (+ counters): 2 workgroups per CU
+// two size classes: short lists (<= 4096 entries, 68 KiB of LDS: 2 workgroups per CU) and long
+// lists (<= 8192 entries in LDS, 1 workgroup per CU; longer ones on the global ping-pong buffers)
+#define GDR_TSORT_SMALL 4096
+#define GDR_TSORT_LARGE 8192
 
 struct TileSortBufs {
     uint32_t *kA, *vA, *kB, *vB;
@@ -292,25 +295,26 @@ __device__ __forceinline__ void tile_sort_pass(const TileSortBufs& b, uint32_t L
 
 // keys_part: tile-partitioned u64 keys (tile << 32 | depth); vals_part: ids; outputs sorted.
 // scratch32: 2*D uint32 of global scratch (depth keys ping-pong for tiles that do not fit in LDS)
+template <int CAP, int LMIN>  // handles tiles with LMIN < L (<= CAP in LDS, else global buffers if LMIN > 0)
 __global__ __launch_bounds__(GDR_BLOCK) void tile_sort_kernel(const uint2* __restrict__ ranges,
                                                                const uint64_t* __restrict__ keys_part,
                                                                uint32_t* __restrict__ vals_part,
                                                                uint64_t* __restrict__ keys_out,
                                                                uint32_t* __restrict__ vals_out,
                                                                uint32_t* __restrict__ scratch32, uint64_t D) {
-    __shared__ uint32_t lds_elems[4 * GDR_TSORT_LDS_ELEMS];
+    __shared__ uint32_t lds_elems[4 * CAP];
     __shared__ uint32_t cnt[GDR_BLOCK / GDR_WAVE][GDR_RADIX];
     __shared__ uint32_t misc[16];
     const uint32_t tile = blockIdx.x;
     const uint2 rg = ranges[tile];
     const uint32_t L = rg.y - rg.x;
-    if (L == 0) return;
+    if (L <= (uint32_t)LMIN || (LMIN == 0 && L > (uint32_t)CAP)) return;  // other size class
     const uint32_t w = threadIdx.x >> 6, lane = lane_id();
-    const bool in_lds = L <= GDR_TSORT_LDS_ELEMS;
+    const bool in_lds = L <= (uint32_t)CAP;
     TileSortBufs b;
     if (in_lds) {
-        b.kA = lds_elems; b.vA = lds_elems + GDR_TSORT_LDS_ELEMS;
-        b.kB = lds_elems + 2 * GDR_TSORT_LDS_ELEMS; b.vB = lds_elems + 3 * GDR_TSORT_LDS_ELEMS;
+        b.kA = lds_elems; b.vA = lds_elems + CAP;
+        b.kB = lds_elems + 2 * CAP; b.vB = lds_elems + 3 * CAP;
     } else {  // global ping-pong: this tile's own slices of the scratch / value buffers
         b.kA = scratch32 + rg.x; b.kB = scratch32 + D + rg.x;
         b.vA = vals_part + rg.x; b.vB = vals_out + rg.x;
@@ -418,8 +422,12 @@ hipError_t launch_sort_tile_bits(gdr_binning* bin, uint64_t D, int nbits, hipStr
 hipError_t launch_tile_sort(gdr_binning* bin, const gdr_image* img, int tiles, uint64_t D, hipStream_t st) {
     if (D == 0) return hipSuccess;
     const int in = bin->sorted, out = in ^ 1;
-    GDR_LAUNCH(GDR_K_TILE_SORT, tile_sort_kernel, dim3(tiles), dim3(GDR_BLOCK), st, (const uint2*)img->ranges,
-               bin->keys[in], bin->values[in], bin->keys[out], bin->values[out], bin->scratch32, D);
+    GDR_LAUNCH(GDR_K_TILE_SORT, (tile_sort_kernel<GDR_TSORT_LARGE, GDR_TSORT_SMALL>), dim3(tiles), dim3(GDR_BLOCK),
+               st, (const uint2*)img->ranges, bin->keys[in], bin->values[in], bin->keys[out], bin->values[out],
+               bin->scratch32, D);
+    GDR_LAUNCH(GDR_K_TILE_SORT, (tile_sort_kernel<GDR_TSORT_SMALL, 0>), dim3(tiles), dim3(GDR_BLOCK), st,
+               (const uint2*)img->ranges, bin->keys[in], bin->values[in], bin->keys[out], bin->values[out],
+               bin->scratch32, D);
     bin->sorted = out;
     return hipGetLastError();
 }
