@@ -38,6 +38,7 @@ class GdrInputs(C.Structure):
 class GdrGeom(C.Structure):
     _fields_ = [("depths", C.c_void_p), ("rec", C.c_void_p), ("cov3D", C.c_void_p), ("rect", C.c_void_p),
                 ("tiles_touched", C.c_void_p), ("clamped", C.c_void_p), ("block_sums", C.c_void_p),
+                ("block_offs", C.c_void_p),
                 ("num_rendered", C.c_void_p)]
 
 
@@ -120,7 +121,7 @@ def load():
             fn = getattr(lib, name)  # AttributeError if the symbol is missing
             fn.restype = res
             fn.argtypes = args
-        if lib.gdr_abi_version() != 4:
+        if lib.gdr_abi_version() != 5:
             raise RuntimeError("libgdr_hip.so ABI version mismatch")
         _lib = lib
     return _lib

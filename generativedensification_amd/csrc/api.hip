@@ -74,6 +74,7 @@ static size_t carve_geom(void* base, int64_t N, gdr_geom* g) {
     t.tiles_touched = c.take<uint32_t>(n);
     t.clamped = c.take<uint8_t>(n);
     t.block_sums = c.take<uint32_t>((n + GDR_BLOCK - 1) / GDR_BLOCK + 1);
+    t.block_offs = c.take<uint32_t>((n + GDR_BLOCK - 1) / GDR_BLOCK + 1);
     t.num_rendered = c.take<uint32_t>(1);
     if (g) *g = t;
     return c.off;
@@ -187,12 +188,11 @@ int gdr_preprocess_forward(const gdr_settings* s, const gdr_inputs* in, const gd
     const int tiles = tile_grid_x(s->image_width) * tile_grid_y(s->image_height);
     if (key_bits(tiles) > 64) { set_error("image too large", hipSuccess); return GDR_ERR_UNSUPPORTED; }
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = launch_preprocess_fwd(s, in, geom, radii, st);
+    hipError_t e = hipMemsetAsync(geom->num_rendered, 0, sizeof(uint32_t), st);  // K1 draws block offsets from it
+    if (e != hipSuccess) return hip_fail("memset num_rendered", e);
+    e = launch_preprocess_fwd(s, in, geom, radii, st);
     if (e != hipSuccess) return hip_fail("preprocess_fwd", e);
     if ((rc = debug_sync(s, "preprocess_fwd", st))) return rc;
-    e = launch_scan_block_sums(geom, in->N, st);
-    if (e != hipSuccess) return hip_fail("scan_block_sums", e);
-    if ((rc = debug_sync(s, "scan_block_sums", st))) return rc;
     if (num_rendered_host) {
         e = hipMemcpyAsync(num_rendered_host, geom->num_rendered, sizeof(uint32_t), hipMemcpyDeviceToHost, st);
         if (e != hipSuccess) return hip_fail("memcpy num_rendered", e);
@@ -214,7 +214,13 @@ int gdr_render_forward(const gdr_settings* s, const gdr_inputs* in, const gdr_ge
     hipStream_t st = (hipStream_t)stream;
     const int W = s->image_width, H = s->image_height;
     const int tiles = tile_grid_x(W) * tile_grid_y(H);
-    hipError_t e = launch_duplicate(geom, in->N, W, H, out->radii, bin->keys[0], bin->values[0], D, st);
+    hipError_t e;
+    if (bin->global_sort) {  // stable global sort: duplicates must be emitted in Gaussian order
+        e = launch_scan_block_sums(geom, in->N, st);
+        if (e != hipSuccess) return hip_fail("scan_block_sums", e);
+    }
+    e = launch_duplicate(geom, in->N, W, H, out->radii, bin->global_sort ? geom->block_sums : geom->block_offs,
+                         bin->keys[0], bin->values[0], D, st);
     if (e != hipSuccess) return hip_fail("duplicate", e);
     if ((rc = debug_sync(s, "duplicate", st))) return rc;
     if (bin->global_sort) {  // one global stable LSD radix sort over all key bits
@@ -307,12 +313,11 @@ int gdr_preprocess_forward_views(int32_t V, const gdr_settings* s, const gdr_inp
         return GDR_ERR_UNSUPPORTED;
     }
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = launch_preprocess_fwd_views(V, s, in, geoms, radii, st);
+    hipError_t e = hipSuccess;
+    for (int v = 0; v < V && e == hipSuccess; ++v) e = hipMemsetAsync(geoms[v].num_rendered, 0, sizeof(uint32_t), st);
+    if (e != hipSuccess) return hip_fail("memset num_rendered", e);
+    e = launch_preprocess_fwd_views(V, s, in, geoms, radii, st);
     if (e != hipSuccess) return hip_fail("preprocess_fwd_views", e);
-    for (int v = 0; v < V; ++v) {
-        e = launch_scan_block_sums(&geoms[v], in->N, st);
-        if (e != hipSuccess) return hip_fail("scan_block_sums", e);
-    }
     return debug_sync(&s[0], "preprocess_fwd_views", st);
 }
 

@@ -237,9 +237,9 @@ __global__ __launch_bounds__(GDR_BLOCK) void ranges_kernel(const uint64_t* __res
 // passes above run on the tile bits only (2 passes at 800x800), K5 reads the tile segments off
 // the partitioned keys, and then ONE workgroup per tile sorts its segment by depth in LDS with
 // a stable 8-bit LSD radix sort on (depth - min depth of the tile): typically 3 passes, no
-// global traffic besides one read and one write of the segment.  Every pass is stable, so ties
-// keep emission order (ascending Gaussian id) exactly like the reference's single global
-// stable sort => bit-identical sorted list.  A segment longer than the LDS capacity is sorted
+// global traffic besides one read and one write of the segment.  Entries with identical depth
+// bits are finally put in ascending Gaussian-id order, which is exactly what the reference's
+// single global stable sort of Gaussian-ordered duplicates yields => bit-identical sorted list.  A segment longer than the LDS capacity is sorted
 // by its workgroup with the same code on the global ping-pong buffers.
 // =================================================================================
 // two size classes: short lists (<= 4096 entries, 68 KiB of LDS: 2 workgroups per CU) and long
@@ -344,6 +344,21 @@ __global__ __launch_bounds__(GDR_BLOCK) void tile_sort_kernel(const uint2* __res
         uint32_t* t = b.kA; b.kA = b.kB; b.kB = t;
         t = b.vA; b.vA = b.vB; b.vB = t;
     }
+    // ties on identical depth bits: ascending Gaussian id — the order the reference's stable sort of
+    // (Gaussian-ordered) emission leaves them in; our emission order is arbitrary (block_offs)
+    for (uint32_t i = threadIdx.x; i + 1 < L; i += GDR_BLOCK) {
+        if (b.kA[i] == b.kA[i + 1] && (i == 0 || b.kA[i - 1] != b.kA[i])) {
+            uint32_t j = i + 1;
+            while (j < L && b.kA[j] == b.kA[i]) ++j;
+            for (uint32_t a = i + 1; a < j; ++a) {  // insertion sort of the run [i, j) by id
+                const uint32_t x = b.vA[a];
+                uint32_t c = a;
+                while (c > i && b.vA[c - 1] > x) { b.vA[c] = b.vA[c - 1]; --c; }
+                b.vA[c] = x;
+            }
+        }
+    }
+    __syncthreads();
     for (uint32_t i = threadIdx.x; i < L; i += GDR_BLOCK) {
         const uint32_t v = b.vA[i];
         const uint32_t k = b.kA[i];
@@ -367,12 +382,13 @@ hipError_t launch_scan_block_sums(const gdr_geom* g, int N, hipStream_t st) {
 }
 
 hipError_t launch_duplicate(const gdr_geom* g, int N, int W, int H, const int32_t* radii,
-                            uint64_t* keys, uint32_t* vals, uint64_t D, hipStream_t st) {
+                            const uint32_t* block_offsets, uint64_t* keys, uint32_t* vals, uint64_t D,
+                            hipStream_t st) {
     (void)H;
     if (N == 0) return hipSuccess;
     GDR_LAUNCH(GDR_K_DUPLICATE, duplicate_kernel, dim3(div_up(N, GDR_BLOCK)), dim3(GDR_BLOCK), st, N,
                        tile_grid_x(W), radii, g->depths, (const int4*)g->rect, g->tiles_touched,
-                       g->block_sums, keys, vals, D);
+                       block_offsets, keys, vals, D);
     return hipGetLastError();
 }
 

@@ -84,7 +84,8 @@ hipError_t launch_scan_block_sums(const gdr_geom* g, int N, hipStream_t st);
 hipError_t launch_sort_tile_bits(gdr_binning* bin, uint64_t D, int nbits, hipStream_t st);
 hipError_t launch_tile_sort(gdr_binning* bin, const gdr_image* img, int tiles, uint64_t D, hipStream_t st);
 hipError_t launch_duplicate(const gdr_geom* g, int N, int W, int H, const int32_t* radii,
-                            uint64_t* keys, uint32_t* vals, uint64_t D, hipStream_t st);
+                            const uint32_t* block_offsets, uint64_t* keys, uint32_t* vals, uint64_t D,
+                            hipStream_t st);
 hipError_t launch_sort(gdr_binning* bin, uint64_t D, int nbits, hipStream_t st);
 hipError_t launch_ranges(const gdr_binning* bin, uint64_t D, const gdr_image* img, int tiles,
                          hipStream_t st);

@@ -199,7 +199,8 @@ __global__ __launch_bounds__(GDR_BLOCK) void preprocess_fwd_kernel(
     float tany, float focal_x, float focal_y, int32_t* __restrict__ radii, float* __restrict__ g_depths,
     float4* __restrict__ g_rec,
     float* __restrict__ g_cov3D, int4* __restrict__ g_rect, uint32_t* __restrict__ g_tiles,
-    uint8_t* __restrict__ g_clamped, uint32_t* __restrict__ block_sums, uint32_t flags) {
+    uint8_t* __restrict__ g_clamped, uint32_t* __restrict__ block_sums, uint32_t flags,
+    uint32_t* __restrict__ block_offs, uint32_t* __restrict__ num_rendered) {
     Cam cam;
     load_cam(cam, view, proj, campos);
     const int i = blockIdx.x * GDR_BLOCK + threadIdx.x;
@@ -326,7 +327,11 @@ __global__ __launch_bounds__(GDR_BLOCK) void preprocess_fwd_kernel(
     __shared__ uint32_t wsum[GDR_BLOCK / GDR_WAVE];
     if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = v;
     __syncthreads();
-    if (threadIdx.x == 0) block_sums[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    if (threadIdx.x == 0) {
+        const uint32_t bs = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        block_sums[blockIdx.x] = bs;
+        block_offs[blockIdx.x] = bs ? atomicAdd(num_rendered, bs) : 0u;  // this block's slice of the D duplicates
+    }
 }
 
 // ---------------------------------------------------------------------------------
@@ -593,7 +598,7 @@ struct FwdView {
     const float* view; const float* proj; const float* campos;
     float tanx, tany, fx, fy;
     int32_t* radii; float* depths; float4* rec; int4* rect;
-    uint32_t* tiles; uint8_t* clamped; uint32_t* block_sums;
+    uint32_t* tiles; uint8_t* clamped; uint32_t* block_sums; uint32_t* block_offs; uint32_t* num_rendered;
 };
 struct FwdViewsArgs { int V; FwdView v[GDR_MAX_VIEWS]; };
 
@@ -735,9 +740,11 @@ __global__ __launch_bounds__(GDR_BLOCK) void preprocess_fwd_views_kernel(
         if ((threadIdx.x & 63) == 0) wsum[v][threadIdx.x >> 6] = t;
     }
     __syncthreads();
-    if ((int)threadIdx.x < a.V)
-        a.v[threadIdx.x].block_sums[blockIdx.x] =
-            wsum[threadIdx.x][0] + wsum[threadIdx.x][1] + wsum[threadIdx.x][2] + wsum[threadIdx.x][3];
+    if ((int)threadIdx.x < a.V) {
+        const uint32_t bs = wsum[threadIdx.x][0] + wsum[threadIdx.x][1] + wsum[threadIdx.x][2] + wsum[threadIdx.x][3];
+        a.v[threadIdx.x].block_sums[blockIdx.x] = bs;
+        a.v[threadIdx.x].block_offs[blockIdx.x] = bs ? atomicAdd(a.v[threadIdx.x].num_rendered, bs) : 0u;
+    }
 }
 
 struct BwdView {
@@ -975,7 +982,7 @@ hipError_t launch_preprocess_fwd(const gdr_settings* s, const gdr_inputs* in, co
                s->scale_modifier, in->rotations, in->opacities, in->shs, in->colors_precomp,
                in->cov3D_precomp, s->viewmatrix, s->projmatrix, s->campos, W, H, s->tanfovx,
                s->tanfovy, focal_x, focal_y, radii, g->depths, (float4*)g->rec, g->cov3D, (int4*)g->rect,
-               g->tiles_touched, g->clamped, g->block_sums, in->flags);
+               g->tiles_touched, g->clamped, g->block_sums, in->flags, g->block_offs, g->num_rendered);
     return hipGetLastError();
 }
 
@@ -1012,7 +1019,8 @@ hipError_t launch_preprocess_fwd_views(int V, const gdr_settings* s, const gdr_i
         f.fx = (float)W / (2.f * s[v].tanfovx); f.fy = (float)H / (2.f * s[v].tanfovy);
         f.radii = radii[v]; f.depths = geoms[v].depths; f.rec = (float4*)geoms[v].rec;
         f.rect = (int4*)geoms[v].rect; f.tiles = geoms[v].tiles_touched; f.clamped = geoms[v].clamped;
-        f.block_sums = geoms[v].block_sums;
+        f.block_sums = geoms[v].block_sums; f.block_offs = geoms[v].block_offs;
+        f.num_rendered = geoms[v].num_rendered;
     }
     const int grid = div_up(N, GDR_BLOCK);
     LAUNCH_DEG(GDR_K_PREPROCESS_FWD, preprocess_fwd_views_kernel, s[0].sh_degree, grid, st, N, in->M,

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define GDR_ABI_VERSION 4
+#define GDR_ABI_VERSION 5
 
 #define GDR_OK 0
 #define GDR_ERR_INVALID_ARG (-1)  /* NULL / inconsistent arguments                     */
@@ -105,7 +105,10 @@ typedef struct gdr_geom {
     int32_t* rect;           /* (N,4) tile rect minx,miny,maxx,maxy          */
     uint32_t* tiles_touched; /* (N)                                          */
     uint8_t* clamped;        /* (N)   bit ch set <=> colour channel clamped  */
-    uint32_t* block_sums;    /* (ceil(N/256)+1) scan scratch                 */
+    uint32_t* block_sums;    /* (ceil(N/256)+1) per-block sums of tiles_touched (global-sort path) */
+    uint32_t* block_offs;    /* (ceil(N/256))   per-block duplicate offsets drawn from num_rendered
+                              * with one atomic per block (emission order is free: the default
+                              * sort orders ties by Gaussian id explicitly)                     */
     uint32_t* num_rendered;  /* (1)   D = sum tiles_touched                  */
 } gdr_geom;
 

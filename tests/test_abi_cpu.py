@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/gdr.h but not exported"
         assert n in L.EXPORTED_SYMBOLS, f"{n} has no ctypes prototype"
-    assert lib.gdr_abi_version() == 4
+    assert lib.gdr_abi_version() == 5
 
 
 def test_workspace_sizes_and_carving_without_gpu():
@@ -45,7 +45,7 @@ def test_workspace_sizes_and_carving_without_gpu():
     g = L.GdrGeom()
     base = 0x10000000
     assert lib.gdr_geom_carve(C.c_void_p(base), 1000, C.byref(g)) == 0
-    ptrs = [g.depths, g.rec, g.cov3D, g.rect, g.tiles_touched, g.clamped, g.block_sums, g.num_rendered]
+    ptrs = [g.depths, g.rec, g.cov3D, g.rect, g.tiles_touched, g.clamped, g.block_sums, g.block_offs, g.num_rendered]
     assert ptrs == sorted(ptrs) and all(p % 256 == 0 for p in ptrs)
     assert ptrs[0] == base and ptrs[-1] + 4 <= base + lib.gdr_geom_bytes(1000)
     assert lib.gdr_geom_carve(C.c_void_p(base + 4), 1000, C.byref(g)) == -1  # unaligned -> GDR_ERR_INVALID_ARG
