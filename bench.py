@@ -92,8 +92,9 @@ def main():
                     help="developer smoke test of the N>1 code path on a 1-GPU box: every rank uses cuda:0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--traffic-bytes", type=float, default=None,
-                    help="HBM bytes per launch of the dominant kernel from a rocprofv3 --pmc run (profiles/)")
+    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "pmc_traffic.json"),
+                    help="per-kernel HBM bytes per launch measured with rocprofv3 --pmc (scripts/gpu_pmc.sh); "
+                         "{workload: {kernel: bytes}}; missing file/entry -> traffic null")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -216,9 +217,14 @@ def main():
             dom = max(kernels, key=lambda k: kernels[k]["total_ms"])
             avg_s = kernels[dom]["avg_us"] * 1e-6
             achieved = alg[dom] / avg_s / 1e9
+            traffic = None
+            try:
+                traffic = json.load(open(args.traffic_json)).get(args.workload, {}).get(dom + "_kernel")
+            except Exception:
+                pass
             roofline = dict(bound="hbm", kernel=dom, achieved=round(achieved, 1), peak=HBM_PEAK_GBS,
                             unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4),
-                            traffic=args.traffic_bytes, alg_bytes_per_launch=int(alg[dom]),
+                            traffic=traffic, alg_bytes_per_launch=int(alg[dom]),
                             avg_launch_us=kernels[dom]["avg_us"],
                             path_bytes_view=int(alg["_bytes_view"]),
                             path_frac=round(views_per_sec / world * alg["_bytes_view"] / 1e9 / HBM_PEAK_GBS, 4))

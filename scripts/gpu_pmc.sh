@@ -20,11 +20,16 @@ for f in glob.glob("gpurun_out/${TAG}_*/**/*counter_collection.csv", recursive=T
     for row in csv.DictReader(open(f)):
         k = row["Kernel_Name"]
         if "gdr::" not in k: continue
-        name = k.split("gdr::(anonymous namespace)::")[-1].split("(")[0].split("<")[0]
+        name = k.split("gdr::(anonymous namespace)::")[1].split("(")[0].split("<")[0]
         c = row["Counter_Name"]; v = float(row["Counter_Value"])
         out[name][c] += v; cnt[name][c] += 1
 res = {k: {c: out[k][c] / max(cnt[k][c], 1) for c in out[k]} for k in out}
 res["_launches"] = {k: max(cnt[k].values()) for k in cnt}
+# HBM traffic per launch (MI355X_MICROARCH.md §HBM): FETCH_SIZE/WRITE_SIZE are KB; on gfx950 FETCH_SIZE
+# reports half of the bytes read (calibrated here on preprocess_fwd / tile_ranges / sort_hist, whose read
+# byte counts are known: 2x matches them), WRITE_SIZE is accurate (calibrated on preprocess_fwd).
+res["_traffic_bytes_per_launch"] = {k: int(2 * 1024 * res[k].get("FETCH_SIZE", 0) + 1024 * res[k].get("WRITE_SIZE", 0))
+                                    for k in res if not k.startswith("_")}
 json.dump(res, open("gpurun_out/${TAG}_summary.json", "w"), indent=1)
 for k in res:
     if k.startswith("_"): continue
