@@ -83,6 +83,8 @@ def main():
     ap.add_argument("--views-per-gpu", type=int, default=0)
     ap.add_argument("--grad-allreduce", action="store_true",
                     help="also sum the Gaussian attribute grads over ranks each step (SURVEY §8e)")
+    ap.add_argument("--stacked-loss", action="store_true",
+                    help="take the loss on the view-stacked tensors (measured slower: dim-wise means on strided views)")
     ap.add_argument("--per-view", action="store_true",
                     help="call render_img + backward once per view (the reference's loop) instead of render_views")
     ap.add_argument("--unfused", action="store_true",
@@ -119,7 +121,7 @@ def main():
     from generativedensification_amd.multiview import (allreduce_gaussian_grads, gather_view_losses,
                                                        render_views, shard_views)
     from generativedensification_amd.renderer import Renderer
-    from generativedensification_amd.synthetic import make_scene, make_targets, view_loss
+    from generativedensification_amd.synthetic import make_scene, make_targets, view_loss, views_loss
 
     wl = dict(WORKLOADS[args.workload])
     if args.n:
@@ -134,6 +136,8 @@ def main():
     mine = shard_views(total_views, rank, world)
     cams = [all_cams[i] for i in mine]
     targets = make_targets(total_views, h, w, wl["seed"])[list(mine)].to(dev)
+    # same strides as the HWC views of the rasterizer's CHW images: elementwise kernels stay on the dense path
+    targets = targets.permute(0, 3, 1, 2).contiguous().permute(0, 2, 3, 1)
     renderer = Renderer(sh_degree=deg, white_background=True, fused=not args.unfused)
     renderer.set_bg_color(torch.ones(3, device=dev))
     plist = list(params.values())
@@ -152,8 +156,12 @@ def main():
                 losses.append(loss.detach())
             losses = torch.stack(losses)
         else:               # multi-view entry point: all views of the shard in one rasterizer node
-            outs = render_views(renderer, cams, None, params, dev)
-            lv = torch.stack([view_loss(o, targets[j]) for j, o in enumerate(outs)])
+            if not args.stacked_loss:
+                outs = render_views(renderer, cams, None, params, dev)
+                lv = torch.stack([view_loss(o, targets[j]) for j, o in enumerate(outs)])
+            else:
+                out = render_views(renderer, cams, None, params, dev, stacked=True)
+                lv = views_loss(out, targets)  # (V,) per-view losses on the view-stacked tensors
             lv.sum().backward()
             losses = lv.detach()
         all_losses = gather_view_losses(losses, total_views)

@@ -24,13 +24,13 @@ def shard_views(n_views: int, rank: int, world: int) -> range:
 
 
 def render_views(renderer, cams: Sequence, bg_colors, gaussians: dict, device, prex: str = "",
-                 screenspace_points=None):
+                 screenspace_points=None, stacked: bool = False):
     """One `render_img` per camera (same call the reference loop makes); bg_colors may be
     None (keep the renderer's), one tensor, or one per view (network.py:829-830)."""
     if hasattr(renderer, "render_views") and getattr(renderer, "fused", False) and gaussians["centers"].is_cuda:
         return renderer.render_views(cams, bg_colors, gaussians["centers"], gaussians["shs"], gaussians["opacity"],
                                      gaussians["scales"], gaussians["rotations"], device, prex=prex,
-                                     screenspace_points=screenspace_points)
+                                     screenspace_points=screenspace_points, stacked=stacked)
     outs = []
     for j, cam in enumerate(cams):
         if bg_colors is not None:
@@ -38,6 +38,8 @@ def render_views(renderer, cams: Sequence, bg_colors, gaussians: dict, device, p
         outs.append(renderer.render_img(cam, None, gaussians["centers"], gaussians["shs"], gaussians["opacity"],
                                         gaussians["scales"], gaussians["rotations"], device, prex=prex,
                                         screenspace_points=screenspace_points))
+    if stacked:  # same dict of view-stacked tensors the fused path returns (network.py:840)
+        return {k: torch.stack([o[k] for o in outs]) for k in outs[0]}
     return outs
 
 

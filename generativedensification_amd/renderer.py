@@ -58,11 +58,13 @@ class Renderer(nn.Module):
         return GaussianRasterizer(raster_settings=settings)
 
     def render_views(self, cams, bg_colors, centers, shs, opacity, scales, rotations, device, prex="",
-                     screenspace_points=None):
+                     screenspace_points=None, stacked=False):
         """All `cams` of one Gaussian set in ONE rasterizer node (replaces the per-view loops of
         network.py:826-838 / 848-856 / 964-972 without changing what each view returns).
         bg_colors: None (keep self.bg_color), one tensor, or one per view (network.py:829-830).
-        Returns a list with the same dict render_img returns for each view."""
+        Returns a list with the same dict render_img returns for each view, or with stacked=True ONE
+        dict of view-stacked tensors (image (V,H,W,3), depth (V,H,W,1), acc_map (V,H,W)) — what the
+        callers build anyway with torch.stack (network.py:840, 974-978) before taking the loss."""
         sets = []
         for j, cam in enumerate(cams):
             if bg_colors is not None:
@@ -78,6 +80,9 @@ class Renderer(nn.Module):
         images, radii, depths, alphas = render_views_raw(centers, screenspace_points, shs, opacity, scales,
                                                          rotations, sets)
         images = images.clamp(0, 1)
+        if stacked:
+            return {f"image{prex}": images.permute(0, 2, 3, 1), f"depth{prex}": depths.permute(0, 2, 3, 1),
+                    f"acc_map{prex}": alphas.squeeze(1)}
         return [{f"image{prex}": images[v].permute(1, 2, 0), f"depth{prex}": depths[v].permute(1, 2, 0),
                  f"acc_map{prex}": alphas[v].squeeze(0)} for v in range(len(sets))]
 

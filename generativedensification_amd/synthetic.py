@@ -45,3 +45,10 @@ def view_loss(out: dict, target: torch.Tensor, prex: str = "") -> torch.Tensor:
     exercises the colour, depth and alpha gradient paths (network.py:746-752 keeps all three)."""
     return (((out[f"image{prex}"] - target) ** 2).mean() + 0.1 * out[f"depth{prex}"].mean()
             + 0.1 * out[f"acc_map{prex}"].mean())
+
+
+def views_loss(out: dict, targets: torch.Tensor, prex: str = "") -> torch.Tensor:
+    """Per-view losses (V,) of view-stacked outputs: the same loss as view_loss, evaluated on the stacked
+    tensors the way the reference takes its loss on the concatenated views (network.py:974-978, loss.py:37-48)."""
+    return (((out[f"image{prex}"] - targets) ** 2).mean(dim=(1, 2, 3)) + 0.1 * out[f"depth{prex}"].mean(dim=(1, 2, 3))
+            + 0.1 * out[f"acc_map{prex}"].mean(dim=(1, 2)))
