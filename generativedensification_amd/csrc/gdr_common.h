@@ -47,12 +47,6 @@ void prof_end(int kernel_id, hipStream_t st);
         ::gdr::prof_end(KID, ST);                                         \
     } while (0)
 
-struct View {  // camera constants, loaded once per kernel from device memory
-    float view[16];
-    float proj[16];
-    float campos[3];
-};
-
 void set_error(const char* what, hipError_t e);
 
 static inline int div_up(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

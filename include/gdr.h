@@ -22,8 +22,9 @@
  *   - every pointer is a DEVICE pointer to fp32/int32 data unless it says "host";
  *   - matrices are 16 contiguous floats in the reference's row-vector convention
  *     (/root/reference/lightning/utils.py:37-47): p_view = [p,1] @ viewmatrix;
- *   - the caller owns every buffer; the library allocates nothing and keeps no
- *     state => re-entrant, thread-safe for distinct workspaces, one call per stream;
+ *   - the caller owns every buffer; the library allocates no device memory and keeps no
+ *     state (except the opt-in timing facility at the end of this header) => re-entrant,
+ *     thread-safe for distinct workspaces, one call per stream;
  *   - all work is enqueued on `stream`; the only host synchronisation is the
  *     optional read-back of num_rendered in gdr_preprocess_forward;
  *   - return value: 0 = GDR_OK, negative = error (never throws across the ABI).
