@@ -42,6 +42,9 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s
 WORKLOADS = {
     "c4": dict(n=2_000_000, sigma0=(0.00065,), seed=3, views_per_gpu=4, h=800, w=800, deg=3,
                desc="BASELINE configs[3] per-GPU share: 2M densified-like Gaussians, 4 views/GPU 800x800, SH3, fwd+bwd"),
+    "c3": dict(n=262_144 + 81_600, sigma0=None, seed=2, views_per_gpu=8, h=512, w=512, deg=1,
+               desc="BASELINE configs[2] stand-in: 262144 coarse (sigma0 0.0052) + 81600 fine (0.00065) Gaussians with the "
+                    "statistics of network.py's decoder output, 8 views 512x512, SH1 (configs/base.yaml), fwd+bwd"),
     "c2": dict(n=200_000, sigma0=(0.0052, 0.00065), seed=1, views_per_gpu=4, h=800, w=800, deg=3,
                desc="BASELINE configs[1]: 200k Gaussians (50/50 sigma0 mix), 4 views 800x800, SH3, fwd+bwd"),
 }
@@ -130,7 +133,12 @@ def main():
         wl["views_per_gpu"] = args.views_per_gpu
     n, h, w, deg, vpg = wl["n"], wl["h"], wl["w"], wl["deg"], wl["views_per_gpu"]
     total_views = vpg * world
-    scene = make_scene(n, wl["seed"], sh_degree=deg, sigma0=wl["sigma0"], device=dev)
+    if args.workload == "c3" and not args.n:  # two populations of different size (coarse grid + densified points)
+        a = make_scene(262_144, wl["seed"], sh_degree=deg, sigma0=(0.0052,), device=dev)
+        b = make_scene(81_600, wl["seed"] + 1, sh_degree=deg, sigma0=(0.00065,), device=dev)
+        scene = {k: torch.cat([a[k], b[k]]).contiguous() for k in a}
+    else:
+        scene = make_scene(n, wl["seed"], sh_degree=deg, sigma0=wl["sigma0"] or (0.0052,), device=dev)
     params = {k: v.requires_grad_(True) for k, v in scene.items()}
     all_cams = orbit_cameras(total_views, w, h, device=dev)
     mine = shard_views(total_views, rank, world)

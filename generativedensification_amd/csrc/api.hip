@@ -340,6 +340,20 @@ int gdr_render_backward(const gdr_settings* s, int32_t N, const gdr_geom* geom, 
     return debug_sync(s, "render_bwd", st);
 }
 
+int gdr_render_backward_mean2d(const gdr_settings* s, int32_t N, const gdr_geom* geom,
+                               const gdr_binning* bin, const gdr_image* img, const float* dL_dcolor,
+                               float* dL_dmean2D, void* stream) {
+    if (!s || !geom || !bin || !img || !dL_dcolor || (N > 0 && !dL_dmean2D) || !s->bg) {
+        set_error("render_backward_mean2d: NULL argument", hipSuccess);
+        return GDR_ERR_INVALID_ARG;
+    }
+    if (N <= 0) return GDR_OK;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = launch_render_bwd_mean2d(s, geom, bin, img, dL_dcolor, dL_dmean2D, st);
+    if (e != hipSuccess) return hip_fail("render_bwd_mean2d", e);
+    return debug_sync(s, "render_bwd_mean2d", st);
+}
+
 int gdr_preprocess_backward_views(int32_t V, const gdr_settings* s, const gdr_inputs* in,
                                   const gdr_geom* geoms, const int32_t* const* radii,
                                   float* const* grad_recs, const gdr_grad_outputs* gout, void* stream) {

@@ -86,6 +86,9 @@ hipError_t launch_ranges(const gdr_binning* bin, uint64_t D, const gdr_image* im
 hipError_t launch_tile_order(const gdr_image* img, int tiles, hipStream_t st);
 hipError_t launch_render_fwd(const gdr_settings* s, const gdr_geom* g, const gdr_binning* bin,
                              const gdr_image* img, const gdr_outputs* out, hipStream_t st);
+hipError_t launch_render_bwd_mean2d(const gdr_settings* s, const gdr_geom* g, const gdr_binning* bin,
+                                    const gdr_image* img, const float* dL_dcolor, float* dL_dmean2D,
+                                    hipStream_t st);
 hipError_t launch_render_bwd(const gdr_settings* s, const gdr_geom* g, const gdr_binning* bin,
                              const gdr_image* img, const gdr_grad_inputs* gi,
                              const gdr_grad_outputs* go, hipStream_t st);

@@ -94,6 +94,19 @@ __device__ __forceinline__ float row_reduce_scatter12(const float (&v)[12], uint
     return keep + dpp_get<0xB1, 0xf>(send);       // quad_perm [1,0,3,2]: partner i ^ 1
 }
 
+// 4 values over the 16 lanes of a row: lane i returns the row total of value (i >> 2) & 3
+// (two halving exchanges, then two plain butterfly adds inside the quads)
+__device__ __forceinline__ float row_reduce_scatter4(float v0, float v1, float v2, float v3, uint32_t li) {
+    const bool b3 = li & 8u, b2 = li & 4u;
+    const float k0 = b3 ? v2 : v0, s0 = b3 ? v0 : v2, k1 = b3 ? v3 : v1, s1 = b3 ? v1 : v3;
+    const float u0 = k0 + dpp_get<0x140, 0xf>(s0), u1 = k1 + dpp_get<0x140, 0xf>(s1);  // row_mirror
+    const float k = b2 ? u1 : u0, sd = b2 ? u0 : u1;
+    float t = k + dpp_get<0x141, 0xf>(sd);  // row_half_mirror
+    t += dpp_get<0x1B, 0xf>(t);             // quad reverse
+    t += dpp_get<0xB1, 0xf>(t);             // quad xor-1  -> all 4 lanes of the quad hold the total
+    return t;
+}
+
 #define GDR_ROW_MASK(k) (0xFFFFull << (16 * (k)))
 
 // LDS image of one 256-entry slice (+ the null entry)
@@ -308,6 +321,10 @@ __global__ __launch_bounds__(GDR_BLOCK) void render_fwd_kernel(
 //   [0..3] dL/dmean2D x, y (signed, NDC units), sum|x-term|, sum|y-term|
 //   [4..6] dL/dconic.x, .y, .z   [7] dL/ddepth   [8..10] dL/dcolour   [11] dL/dopacity
 // ---------------------------------------------------------------------------------
+// M2_ONLY: only dL/dmean2D (x, y, |x|, |y|) is produced, accumulated over views straight into an (N,4)
+// buffer — the screen-space gradient the densification step consumes (network.py:865-878); dL/ddepth and
+// dL/dalpha inputs are taken as zero (that call site differentiates an image loss only).
+template <bool M2_ONLY>
 __global__ __launch_bounds__(GDR_BLOCK) void render_bwd_kernel(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const uint32_t* __restrict__ tile_order, int W, int H, int gx, int ntiles,
@@ -343,8 +360,8 @@ __global__ __launch_bounds__(GDR_BLOCK) void render_bwd_kernel(
     float gC0 = 0.f, gC1 = 0.f, gC2 = 0.f, gD = 0.f, gA = 0.f;
     if (inside) {
         gC0 = dL_dpix[pix]; gC1 = dL_dpix[P + pix]; gC2 = dL_dpix[2 * P + pix];
-        if (dL_ddepthpix) gD = dL_ddepthpix[pix];
-        if (dL_dalphapix) gA = dL_dalphapix[pix];
+        if (!M2_ONLY && dL_ddepthpix) gD = dL_ddepthpix[pix];
+        if (!M2_ONLY && dL_dalphapix) gA = dL_dalphapix[pix];
     }
     const float bgT = -T_final * ((bg[0] * gC0 + bg[1] * gC1) + bg[2] * gC2);
     // "behind" state B = colour / depth / coverage composited from everything behind the
@@ -427,16 +444,27 @@ __global__ __launch_bounds__(GDR_BLOCK) void render_bwd_kernel(
                 T = T * r_oma;                                        // transmittance in FRONT of this Gaussian
                 const float w = a * T;
                 const float d0 = cd_cur.x - B0, d1 = cd_cur.y - B1, d2 = cd_cur.z - B2;
-                const float dD = cd_cur.w - BD, dA = 1.f - BA;
-                float dL_dalpha = fmaf(d0, gC0, fmaf(d1, gC1, fmaf(d2, gC2, fmaf(dD, gD, dA * gA))));
+                float dL_dalpha;
+                if (M2_ONLY) {
+                    dL_dalpha = fmaf(d0, gC0, fmaf(d1, gC1, d2 * gC2));
+                } else {
+                    const float dD = cd_cur.w - BD, dA = 1.f - BA;
+                    dL_dalpha = fmaf(d0, gC0, fmaf(d1, gC1, fmaf(d2, gC2, fmaf(dD, gD, dA * gA))));
+                    BD = fmaf(a, dD, BD); BA = fmaf(a, dA, BA);
+                }
                 dL_dalpha = fmaf(dL_dalpha, T, bgT * r_oma) * hm;
                 B0 = fmaf(a, d0, B0); B1 = fmaf(a, d1, B1); B2 = fmaf(a, d2, B2);
-                BD = fmaf(a, dD, BD); BA = fmaf(a, dA, BA);
                 const float dL_dG = co_cur.w * dL_dalpha;
                 const float gdx = G * dx, gdy = G * dy;
                 // co.xyz carry the log2(e) factor; kx, ky carry its inverse
                 const float v_mx = dL_dG * (-gdx * co_cur.x - gdy * co_cur.y) * kx;
                 const float v_my = dL_dG * (-gdy * co_cur.z - gdx * co_cur.y) * ky;
+                if (M2_ONLY) {
+                    const float tot4 = row_reduce_scatter4(v_mx, v_my, fabsf(v_mx), fabsf(v_my), li);
+                    if ((li & 3u) == 0u && ((hb >> (16 * row)) & 0xFFFFull) != 0ull)
+                        atomicAdd(grad_rec + 4 * (size_t)s_id[e_cur] + (li >> 2), tot4);
+                    continue;
+                }
                 const float vals[12] = {v_mx, v_my, fabsf(v_mx), fabsf(v_my),
                                         -0.5f * gdx * dx * dL_dG, -gdx * dy * dL_dG, -0.5f * gdy * dy * dL_dG,
                                         w * gD, w * gC0, w * gC1, w * gC2, G * dL_dalpha};
@@ -476,10 +504,22 @@ hipError_t launch_render_bwd(const gdr_settings* s, const gdr_geom* g, const gdr
     const int W = s->image_width, H = s->image_height;
     const int gx = tile_grid_x(W), gy = tile_grid_y(H);
     const int ntiles = gx * gy;
-    GDR_LAUNCH(GDR_K_RENDER_BWD, render_bwd_kernel, dim3(ntiles), dim3(GDR_BLOCK), st,
+    GDR_LAUNCH(GDR_K_RENDER_BWD, render_bwd_kernel<false>, dim3(ntiles), dim3(GDR_BLOCK), st,
                (const uint2*)img->ranges, bin->values[bin->sorted], img->tile_order, W, H, gx, ntiles, s->bg,
                (const float4*)g->rec, img->final_T, img->n_contrib, gi->dL_dcolor, gi->dL_ddepth, gi->dL_dalpha,
                go->scratch);
+    return hipGetLastError();
+}
+
+hipError_t launch_render_bwd_mean2d(const gdr_settings* s, const gdr_geom* g, const gdr_binning* bin,
+                                    const gdr_image* img, const float* dL_dcolor, float* dL_dmean2D,
+                                    hipStream_t st) {
+    const int W = s->image_width, H = s->image_height;
+    const int gx = tile_grid_x(W), gy = tile_grid_y(H);
+    const int ntiles = gx * gy;
+    GDR_LAUNCH(GDR_K_RENDER_BWD, render_bwd_kernel<true>, dim3(ntiles), dim3(GDR_BLOCK), st,
+               (const uint2*)img->ranges, bin->values[bin->sorted], img->tile_order, W, H, gx, ntiles, s->bg,
+               (const float4*)g->rec, img->final_T, img->n_contrib, dL_dcolor, nullptr, nullptr, dL_dmean2D);
     return hipGetLastError();
 }
 

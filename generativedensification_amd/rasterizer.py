@@ -268,78 +268,86 @@ class _RasterizeGaussians(torch.autograd.Function):
 RAW_ALL = L.GDR_IN_RAW_OPACITY | L.GDR_IN_RAW_SCALES | L.GDR_IN_RAW_ROTATIONS
 
 
+def _forward_views_impl(means3D, means2D, sh, opacities, scales, rotations, settings_list, flags):
+    """K1 for all views (one launch per <= 8 views), ONE host read of the V duplicate counts, then binning +
+    K6 per view.  Returns (colors, radii, depths, alphas, states, keep, in_dtypes)."""
+    lib = L.load()
+    _require_hip(means3D, "means3D")
+    dev = means3D.device
+    in_dtypes = tuple(t.dtype for t in (means3D, means2D, sh, opacities, scales, rotations))
+    means3D, sh = _f32(means3D, dev), _f32(sh, dev)
+    opacities, scales, rotations = _f32(opacities, dev), _f32(scales, dev), _f32(rotations, dev)
+    N, M, V = int(means3D.shape[0]), int(sh.shape[1]), len(settings_list)
+    H, W = int(settings_list[0].image_height), int(settings_list[0].image_width)
+    if any(int(rs.image_height) != H or int(rs.image_width) != W for rs in settings_list):
+        raise RuntimeError("render_views: all views must share one image size")
+    e = torch.empty(0, dtype=torch.float32, device=dev)
+    keep = [means3D, opacities, sh, e, scales, rotations, e]
+    f32, u8 = dict(dtype=torch.float32, device=dev), dict(dtype=torch.uint8, device=dev)
+    colors, depths, alphas = torch.empty(V, 3, H, W, **f32), torch.empty(V, 1, H, W, **f32), torch.empty(V, 1, H, W, **f32)
+    radii = torch.empty(V, N, dtype=torch.int32, device=dev)
+    states = []
+    with torch.cuda.device(dev):
+        stream = _stream()
+        inp = _inputs_struct(N, M, means3D, opacities, sh, e, scales, rotations, e, flags)
+        s_arr = (L.GdrSettings * V)()
+        g_arr = (L.GdrGeom * V)()
+        for v, rs in enumerate(settings_list):
+            s_arr[v] = _settings_struct(rs, dev, keep)
+            st = _State()
+            st.N, st.M, st.H, st.W = N, M, H, W
+            st.geom_buf = torch.empty(lib.gdr_geom_bytes(N), **u8)
+            st.img_buf = torch.empty(lib.gdr_image_bytes(H, W), **u8)
+            st.geom, st.bin, st.img = L.GdrGeom(), L.GdrBinning(), L.GdrImage()
+            L.check(lib.gdr_geom_carve(st.geom_buf.data_ptr(), N, C.byref(st.geom)), "gdr_geom_carve")
+            L.check(lib.gdr_image_carve(st.img_buf.data_ptr(), H, W, C.byref(st.img)), "gdr_image_carve")
+            st.geom.cov3D = states[0].geom.cov3D if states else st.geom.cov3D  # view-independent: shared
+            g_arr[v] = st.geom
+            states.append(st)
+        # K1 for all views in groups of <= GDR_MAX_VIEWS launches (inputs read once per group)
+        for lo in range(0, V, L.GDR_MAX_VIEWS):
+            n = min(L.GDR_MAX_VIEWS, V - lo)
+            r_arr = (C.c_void_p * n)(*[radii[lo + k].data_ptr() if N else None for k in range(n)])
+            sub_s = (L.GdrSettings * n).from_address(C.addressof(s_arr) + lo * C.sizeof(L.GdrSettings))
+            sub_g = (L.GdrGeom * n).from_address(C.addressof(g_arr) + lo * C.sizeof(L.GdrGeom))
+            if lo > 0:  # the shared cov3D of group 0 is what every later stage reads
+                for k in range(n):
+                    sub_g[k].cov3D = g_arr[0].cov3D
+            L.check(lib.gdr_preprocess_forward_views(n, sub_s, C.byref(inp), sub_g, r_arr, stream),
+                    "gdr_preprocess_forward_views")
+        # ONE host read-back for all V views
+        d_dev = torch.cat([st._view(st.geom_buf, st.geom.num_rendered, torch.int32, 1) for st in states])
+        d_host = d_dev.cpu().tolist()
+        for v, st in enumerate(states):
+            st.D = int(d_host[v]) & 0xFFFFFFFF
+            st.bin_buf = torch.empty(lib.gdr_binning_bytes(st.D), **u8)
+            L.check(lib.gdr_binning_carve(st.bin_buf.data_ptr(), st.D, C.byref(st.bin)), "gdr_binning_carve")
+            st.bin.global_sort = int(_FORCE_GLOBAL_SORT)
+        main = torch.cuda.current_stream()
+        side = _view_streams(dev, min(VIEW_STREAMS, V)) if VIEW_STREAMS > 1 and V > 1 else None
+        if side:
+            ready = torch.cuda.Event()
+            ready.record(main)
+            for sd in side:
+                sd.wait_event(ready)
+        for v, st in enumerate(states):
+            sv = C.c_void_p(side[v % len(side)].cuda_stream) if side else stream
+            out = L.GdrOutputs(colors[v].data_ptr(), depths[v].data_ptr(), alphas[v].data_ptr(), _ptr(radii[v]))
+            L.check(lib.gdr_render_forward(C.byref(s_arr[v]), C.byref(inp), C.byref(g_arr[v]), C.byref(st.bin),
+                                           C.byref(st.img), st.D, C.byref(out), sv), "gdr_render_forward")
+        if side:
+            for sd in side:  # the caller's stream continues only after every view is rendered
+                done = torch.cuda.Event()
+                done.record(sd)
+                main.wait_event(done)
+    return colors, radii, depths, alphas, states, keep, in_dtypes
+
+
 class _RenderViews(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, opacities, scales, rotations, settings_list, flags):
-        lib = L.load()
-        _require_hip(means3D, "means3D")
-        dev = means3D.device
-        in_dtypes = tuple(t.dtype for t in (means3D, means2D, sh, opacities, scales, rotations))
-        means3D, sh = _f32(means3D, dev), _f32(sh, dev)
-        opacities, scales, rotations = _f32(opacities, dev), _f32(scales, dev), _f32(rotations, dev)
-        N, M, V = int(means3D.shape[0]), int(sh.shape[1]), len(settings_list)
-        H, W = int(settings_list[0].image_height), int(settings_list[0].image_width)
-        if any(int(rs.image_height) != H or int(rs.image_width) != W for rs in settings_list):
-            raise RuntimeError("render_views: all views must share one image size")
-        e = torch.empty(0, dtype=torch.float32, device=dev)
-        keep = [means3D, opacities, sh, e, scales, rotations, e]
-        f32, u8 = dict(dtype=torch.float32, device=dev), dict(dtype=torch.uint8, device=dev)
-        colors, depths, alphas = torch.empty(V, 3, H, W, **f32), torch.empty(V, 1, H, W, **f32), torch.empty(V, 1, H, W, **f32)
-        radii = torch.empty(V, N, dtype=torch.int32, device=dev)
-        states = []
-        with torch.cuda.device(dev):
-            stream = _stream()
-            inp = _inputs_struct(N, M, means3D, opacities, sh, e, scales, rotations, e, flags)
-            s_arr = (L.GdrSettings * V)()
-            g_arr = (L.GdrGeom * V)()
-            for v, rs in enumerate(settings_list):
-                s_arr[v] = _settings_struct(rs, dev, keep)
-                st = _State()
-                st.N, st.M, st.H, st.W = N, M, H, W
-                st.geom_buf = torch.empty(lib.gdr_geom_bytes(N), **u8)
-                st.img_buf = torch.empty(lib.gdr_image_bytes(H, W), **u8)
-                st.geom, st.bin, st.img = L.GdrGeom(), L.GdrBinning(), L.GdrImage()
-                L.check(lib.gdr_geom_carve(st.geom_buf.data_ptr(), N, C.byref(st.geom)), "gdr_geom_carve")
-                L.check(lib.gdr_image_carve(st.img_buf.data_ptr(), H, W, C.byref(st.img)), "gdr_image_carve")
-                st.geom.cov3D = states[0].geom.cov3D if states else st.geom.cov3D  # view-independent: shared
-                g_arr[v] = st.geom
-                states.append(st)
-            # K1 for all views in groups of <= GDR_MAX_VIEWS launches (inputs read once per group)
-            for lo in range(0, V, L.GDR_MAX_VIEWS):
-                n = min(L.GDR_MAX_VIEWS, V - lo)
-                r_arr = (C.c_void_p * n)(*[radii[lo + k].data_ptr() if N else None for k in range(n)])
-                sub_s = (L.GdrSettings * n).from_address(C.addressof(s_arr) + lo * C.sizeof(L.GdrSettings))
-                sub_g = (L.GdrGeom * n).from_address(C.addressof(g_arr) + lo * C.sizeof(L.GdrGeom))
-                if lo > 0:  # the shared cov3D of group 0 is what every later stage reads
-                    for k in range(n):
-                        sub_g[k].cov3D = g_arr[0].cov3D
-                L.check(lib.gdr_preprocess_forward_views(n, sub_s, C.byref(inp), sub_g, r_arr, stream),
-                        "gdr_preprocess_forward_views")
-            # ONE host read-back for all V views
-            d_dev = torch.cat([st._view(st.geom_buf, st.geom.num_rendered, torch.int32, 1) for st in states])
-            d_host = d_dev.cpu().tolist()
-            for v, st in enumerate(states):
-                st.D = int(d_host[v]) & 0xFFFFFFFF
-                st.bin_buf = torch.empty(lib.gdr_binning_bytes(st.D), **u8)
-                L.check(lib.gdr_binning_carve(st.bin_buf.data_ptr(), st.D, C.byref(st.bin)), "gdr_binning_carve")
-                st.bin.global_sort = int(_FORCE_GLOBAL_SORT)
-            main = torch.cuda.current_stream()
-            side = _view_streams(dev, min(VIEW_STREAMS, V)) if VIEW_STREAMS > 1 and V > 1 else None
-            if side:
-                ready = torch.cuda.Event()
-                ready.record(main)
-                for sd in side:
-                    sd.wait_event(ready)
-            for v, st in enumerate(states):
-                sv = C.c_void_p(side[v % len(side)].cuda_stream) if side else stream
-                out = L.GdrOutputs(colors[v].data_ptr(), depths[v].data_ptr(), alphas[v].data_ptr(), _ptr(radii[v]))
-                L.check(lib.gdr_render_forward(C.byref(s_arr[v]), C.byref(inp), C.byref(g_arr[v]), C.byref(st.bin),
-                                               C.byref(st.img), st.D, C.byref(out), sv), "gdr_render_forward")
-            if side:
-                for sd in side:  # the caller's stream continues only after every view is rendered
-                    done = torch.cuda.Event()
-                    done.record(sd)
-                    main.wait_event(done)
+        colors, radii, depths, alphas, states, keep, in_dtypes = _forward_views_impl(
+            means3D, means2D, sh, opacities, scales, rotations, settings_list, flags)
         ctx.states, ctx.keep, ctx.settings_list, ctx.flags = states, keep, settings_list, flags
         ctx.radii, ctx.in_dtypes, ctx.means2D_shape = radii, in_dtypes, tuple(means2D.shape)
         ctx.mark_non_differentiable(radii)
@@ -420,6 +428,38 @@ def render_views_raw(means3D, means2D, sh, opacities, scales, rotations, setting
     scale / rotation tensors are the adaptor's RAW (pre-activation) tensors.
     Returns (colors (V,3,H,W), radii (V,N) int32, depths (V,1,H,W), alphas (V,1,H,W))."""
     return _RenderViews.apply(means3D, means2D, sh, opacities, scales, rotations, tuple(settings_list), int(flags))
+
+
+def screenspace_absgrad_raw(means3D, sh, opacities, scales, rotations, settings_list, gt_images, flags=RAW_ALL):
+    """SURVEY §8f-2.  What the densification step of the reference computes with
+    `vjp(fn, screenspace_point)` (network.py:843-878): loss = mean over all views and pixels of
+    (clamp(image, 0, 1) - gt)^2 and its gradient w.r.t. the shared (N,4) means2D carrier
+    (columns 0-1 signed, 2-3 sum of |per-pixel terms|) — nothing else.  Forward as usual; the backward is
+    the mean2D-only K7 variant accumulated over the views into ONE (N,4) buffer (no gradient records, no K8/K9).
+    gt_images: (V,3,H,W).  Returns (loss, grad (N,4))."""
+    lib = L.load()
+    with torch.no_grad():
+        dev = means3D.device
+        N = int(means3D.shape[0])
+        dummy = torch.empty(0, 4, device=dev)
+        colors, radii, depths, alphas, states, keep, _ = _forward_views_impl(
+            means3D, dummy, sh, opacities, scales, rotations, tuple(settings_list), int(flags))
+        gt = _f32(gt_images, dev)
+        diff = colors.clamp(0, 1) - gt
+        loss = (diff * diff).mean()
+        dL = diff * ((colors >= 0) & (colors <= 1)) * (2.0 / diff.numel())  # d loss / d image through the clamp
+        grad = torch.zeros(N, 4, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            keep2: list = []
+            stream = _stream()
+            for v, st in enumerate(states):
+                s = _settings_struct(settings_list[v], dev, keep2)
+                g = st.geom
+                g.cov3D = states[0].geom.cov3D
+                L.check(lib.gdr_render_backward_mean2d(C.byref(s), N, C.byref(g), C.byref(st.bin), C.byref(st.img),
+                                                       dL[v].data_ptr(), _ptr(grad), stream),
+                        "gdr_render_backward_mean2d")
+    return loss, grad
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,

@@ -19,7 +19,8 @@ import math
 import torch
 from torch import nn
 
-from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer, render_views_raw
+from .rasterizer import (GaussianRasterizationSettings, GaussianRasterizer, render_views_raw,
+                         screenspace_absgrad_raw)
 
 
 class Renderer(nn.Module):
@@ -85,6 +86,17 @@ class Renderer(nn.Module):
                     f"acc_map{prex}": alphas.squeeze(1)}
         return [{f"image{prex}": images[v].permute(1, 2, 0), f"depth{prex}": depths[v].permute(1, 2, 0),
                  f"acc_map{prex}": alphas[v].squeeze(0)} for v in range(len(sets))]
+
+    def screenspace_absgrad(self, cams, bg_colors, gt_images, centers, shs, opacity, scales, rotations, device):
+        """Image loss and its (N,4) screen-space gradient over `cams` — the quantity the reference obtains with
+        `vjp(fn, screenspace_point)` at network.py:843-878 (fn = MSE of the clamped renders against
+        `gt_images` (V,H,W,3)); only grad[:, 2:4] is consumed there.  Returns (loss, grad)."""
+        sets = []
+        for j, cam in enumerate(cams):
+            if bg_colors is not None:
+                self.set_bg_color(bg_colors[j] if isinstance(bg_colors, (list, tuple)) else bg_colors)
+            sets.append(self.set_rasterizer(cam, device=device).raster_settings)
+        return screenspace_absgrad_raw(centers, shs, opacity, scales, rotations, sets, gt_images.permute(0, 3, 1, 2))
 
     def render_img(self, cam, rays, centers, shs, opacity, scales, rotations, device,
                    cov3D_precomp=None, prex="", screenspace_points=None):

@@ -226,6 +226,15 @@ int gdr_preprocess_backward_views(int32_t V, const gdr_settings* s, const gdr_in
                                   const gdr_geom* geoms, const int32_t* const* radii,
                                   float* const* grad_recs, const gdr_grad_outputs* gout, void* stream);
 
+/* ---- screen-space gradient only ----------------------------------------------
+ * The densification step differentiates an image loss w.r.t. the (N,4) means2D carrier of several
+ * views and uses nothing else (/root/reference/lightning/network.py:865-878).  This K7 variant
+ * ADDS one view's dL/dmean2D (x, y signed; |x|, |y| summed per pixel) into dL_dmean2D (N,4), which the
+ * caller zeroes once before the first view; no per-view records, no K8/K9. */
+int gdr_render_backward_mean2d(const gdr_settings* s, int32_t N, const gdr_geom* geom,
+                               const gdr_binning* bin, const gdr_image* img, const float* dL_dcolor,
+                               float* dL_dmean2D, void* stream);
+
 /* ---- K10: visibility mask (upstream markVisible; unused by the reference) -------- */
 int gdr_mark_visible(int32_t N, const float* means3D, const float* viewmatrix,
                      const float* projmatrix, uint8_t* present, void* stream);

@@ -1,0 +1,27 @@
+import sys, time, torch
+sys.path.insert(0, '.')
+from torch.autograd.functional import vjp
+from generativedensification_amd.camera import orbit_cameras
+from generativedensification_amd.renderer import Renderer
+from generativedensification_amd.synthetic import make_scene, make_targets
+dev = torch.device('cuda:0')
+for n, sig in ((262144, (0.0052,)), (2000000, (0.00065,))):
+    h = w = 512 if n == 262144 else 800
+    sc = {k: v.to(dev) for k, v in make_scene(n, 2, sh_degree=1, sigma0=sig).items()}
+    cams = orbit_cameras(4, w, h, device=dev); gt = make_targets(4, h, w, 2).to(dev)
+    r = Renderer(sh_degree=1); rr = Renderer(sh_degree=1, fused=False)
+    def fn(ssp):
+        imgs = [rr.render_img(c, None, sc['centers'], sc['shs'], sc['opacity'], sc['scales'], sc['rotations'], dev, screenspace_points=ssp)['image'] for c in cams]
+        return ((torch.stack(imgs) - gt) ** 2).mean()
+    def fn2(ssp):
+        outs = r.render_views(cams, None, sc['centers'], sc['shs'], sc['opacity'], sc['scales'], sc['rotations'], dev, screenspace_points=ssp)
+        return ((torch.stack([o['image'] for o in outs]) - gt) ** 2).mean()
+    def t(f, reps=10):
+        for _ in range(3): f()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(reps): f()
+        torch.cuda.synchronize(); return (time.perf_counter() - t0) / reps * 1e3
+    a = t(lambda: vjp(fn, torch.zeros(n, 4, device=dev)))
+    b = t(lambda: vjp(fn2, torch.zeros(n, 4, device=dev)))
+    c = t(lambda: r.screenspace_absgrad(cams, None, gt, sc['centers'], sc['shs'], sc['opacity'], sc['scales'], sc['rotations'], dev))
+    print(f'N={n} {h}x{w} 4 views SH1: vjp(render_img per view) {a:.2f} ms | vjp(render_views) {b:.2f} ms | screenspace_absgrad {c:.2f} ms')

@@ -326,3 +326,41 @@ def test_equal_depth_ties_keep_gaussian_index_order(oracle_built):
     h, _ = U.run_hip(case)
     np.testing.assert_array_equal(h["point_list"].view(np.uint32), o["point_list"])
     np.testing.assert_array_equal(h["keys_sorted"].view(np.uint64), o["keys_sorted"])
+
+
+def test_screenspace_absgrad_entry_matches_vjp_through_the_reference_sequence():
+    """Renderer.screenspace_absgrad (mean2D-only K7, no K8/K9) == vjp of the MSE over 4 views w.r.t. the (N,4)
+    carrier through render_img with torch activations — the computation of network.py:843-878."""
+    from torch.autograd.functional import vjp
+
+    from generativedensification_amd.camera import orbit_cameras
+    from generativedensification_amd.renderer import Renderer
+    from generativedensification_amd.synthetic import make_scene, make_targets
+
+    dev = torch.device("cuda:0")
+    n, h, w, V = 40_000, 224, 192, 4
+    sc = {k: v.to(dev) for k, v in make_scene(n, 91, sh_degree=1, sigma0=(0.0052, 0.01)).items()}
+    cams = orbit_cameras(V, w, h, device=dev)
+    gt = make_targets(V, h, w, 91).to(dev)
+    bgs = [torch.tensor([b, b, b], device=dev) for b in (1.0, 0.5, 0.0, 1.0)]
+    r_ref = Renderer(sh_degree=1, fused=False)
+
+    def fn(ssp):
+        imgs = []
+        for c, b in zip(cams, bgs):
+            r_ref.set_bg_color(b)
+            imgs.append(r_ref.render_img(c, None, sc["centers"], sc["shs"], sc["opacity"], sc["scales"],
+                                         sc["rotations"], dev, screenspace_points=ssp)["image"])
+        return ((torch.stack(imgs) - gt) ** 2).mean()
+
+    loss_ref, grad_ref = vjp(fn, torch.zeros(n, 4, device=dev))
+    loss, grad = Renderer(sh_degree=1).screenspace_absgrad(cams, bgs, gt, sc["centers"], sc["shs"], sc["opacity"],
+                                                           sc["scales"], sc["rotations"], dev)
+    assert abs(float(loss) - float(loss_ref)) <= 1e-5 * abs(float(loss_ref))
+    assert grad.shape == (n, 4) and float(grad[:, 2:].min()) >= 0
+    assert U.rel_inf(grad.cpu().numpy(), grad_ref.cpu().numpy()) < 1e-4
+    # what the caller consumes: the norm of the abs channels, then top-k (network.py:876-893)
+    k = 12_000
+    sel = torch.topk(grad[:, 2:4].norm(dim=-1), k).indices
+    sel_ref = torch.topk(grad_ref[:, 2:4].norm(dim=-1), k).indices
+    assert len(set(sel.tolist()) & set(sel_ref.tolist())) >= k - 5
