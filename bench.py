@@ -67,6 +67,7 @@ def algorithmic_bytes(n, d, p, m, tiles):
         tile_ranges=d * 8,
         tile_order=tiles * 12,
         tile_sort=d * (12 + 12),
+        tile_sort_long=0,
         render_fwd=d * 44 + p * 28,
         render_bwd=d * (44 + G) + p * 28,
         preprocess_bwd=n * (A + S + G) + n * (A + 16),

@@ -237,13 +237,18 @@ int gdr_render_forward(const gdr_settings* s, const gdr_inputs* in, const gdr_ge
         e = launch_ranges(bin, D, img, tiles, st);
         if (e != hipSuccess) return hip_fail("ranges", e);
         if ((rc = debug_sync(s, "ranges", st))) return rc;
+        e = launch_tile_order(img, tiles, st);  // longest list first: launch order of tile_sort, K6, K7
+        if (e != hipSuccess) return hip_fail("tile_order", e);
+        if ((rc = debug_sync(s, "tile_order", st))) return rc;
         e = launch_tile_sort(bin, img, tiles, D, st);
         if (e != hipSuccess) return hip_fail("tile_sort", e);
         if ((rc = debug_sync(s, "tile_sort", st))) return rc;
     }
-    e = launch_tile_order(img, tiles, st);
-    if (e != hipSuccess) return hip_fail("tile_order", e);
-    if ((rc = debug_sync(s, "tile_order", st))) return rc;
+    if (bin->global_sort) {
+        e = launch_tile_order(img, tiles, st);
+        if (e != hipSuccess) return hip_fail("tile_order", e);
+        if ((rc = debug_sync(s, "tile_order", st))) return rc;
+    }
     e = launch_render_fwd(s, geom, bin, img, out, st);
     if (e != hipSuccess) return hip_fail("render_fwd", e);
     if ((rc = debug_sync(s, "render_fwd", st))) return rc;
@@ -409,7 +414,7 @@ int gdr_profile_collect(double* ms_total, uint64_t* launches, int32_t n, int32_t
 const char* gdr_kernel_name(int32_t id) {
     static const char* names[GDR_K_COUNT] = {"preprocess_fwd", "scan_block_sums", "duplicate_with_keys",
         "sort_hist", "sort_rowscan", "sort_scatter", "tile_ranges", "render_fwd", "render_bwd",
-        "preprocess_bwd", "mark_visible", "tile_order", "tile_sort"};
+        "preprocess_bwd", "mark_visible", "tile_order", "tile_sort", "tile_sort_long"};
     return (id >= 0 && id < GDR_K_COUNT) ? names[id] : "";
 }
 int gdr_kernel_count(void) { return GDR_K_COUNT; }

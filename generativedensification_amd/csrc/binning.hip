@@ -242,31 +242,44 @@ __global__ __launch_bounds__(GDR_BLOCK) void ranges_kernel(const uint64_t* __res
 // single global stable sort of Gaussian-ordered duplicates yields => bit-identical sorted list.  A segment longer than the LDS capacity is sorted
 // by its workgroup with the same code on the global ping-pong buffers.
 // =================================================================================
-// two size classes: short lists (<= 4096 entries, 68 KiB of LDS: 2 workgroups per CU) and long
-// lists (<= 8192 entries in LDS, 1 workgroup per CU; longer ones on the global ping-pong buffers)
-#define GDR_TSORT_SMALL 4096
+// three size classes so that LDS footprint (= workgroups per CU) follows the list length:
+//   short  (L <= 2048): 36 KiB, 4 waves, 4 workgroups per CU, one workgroup per tile;
+//   medium (L <= 4096): 68 KiB, 8 waves, 2 per CU   } small grids that walk the tiles longest-first
+//   long   (L <= 8192 in LDS, beyond that on the global ping-pong buffers): 132 KiB, 16 waves, 1 per CU }
+#define GDR_TSORT_SMALL 2048
+#define GDR_TSORT_MEDIUM 4096
 #define GDR_TSORT_LARGE 8192
 
 struct TileSortBufs {
     uint32_t *kA, *vA, *kB, *vB;
 };
 
-// one stable 8-bit pass over [0,L) from (kA,vA) to (kB,vB); cnt: [4][256] LDS counters
+// one stable 8-bit pass over [0,L) from (kA,vA) to (kB,vB); cnt: [NW][256] LDS counters (NW waves)
+template <int NW>
 __device__ __forceinline__ void tile_sort_pass(const TileSortBufs& b, uint32_t L, uint32_t kmin, int shift,
                                                uint32_t (*cnt)[GDR_RADIX], uint32_t* scan_lds) {
     const uint32_t w = threadIdx.x >> 6, lane = lane_id();
-    const uint32_t Lw = ((L + 4 * GDR_WAVE - 1) / (4 * GDR_WAVE)) * GDR_WAVE;
+    const uint32_t Lw = ((L + NW * GDR_WAVE - 1) / (NW * GDR_WAVE)) * GDR_WAVE;
     const uint32_t c0 = min(L, w * Lw), c1 = min(L, c0 + Lw);
-    for (int k = threadIdx.x; k < (GDR_BLOCK / GDR_WAVE) * GDR_RADIX; k += GDR_BLOCK) (&cnt[0][0])[k] = 0;
+    for (int k = threadIdx.x; k < NW * GDR_RADIX; k += NW * GDR_WAVE) (&cnt[0][0])[k] = 0;
     __syncthreads();
     for (uint32_t i = c0 + lane; i < c1; i += GDR_WAVE)
         atomicAdd(&cnt[w][((b.kA[i] - kmin) >> shift) & (GDR_RADIX - 1)], 1u);
     __syncthreads();
-    {
-        const uint32_t d = threadIdx.x;  // GDR_BLOCK == GDR_RADIX
-        const uint32_t n0 = cnt[0][d], n1 = cnt[1][d], n2 = cnt[2][d], n3 = cnt[3][d];
-        const uint32_t base = block_excl_scan(n0 + n1 + n2 + n3, scan_lds, nullptr);
-        cnt[0][d] = base; cnt[1][d] = base + n0; cnt[2][d] = base + n0 + n1; cnt[3][d] = base + n0 + n1 + n2;
+    {   // the first 256 threads own one digit each: per-wave offsets + exclusive scan of the digit totals
+        const uint32_t d = threadIdx.x & (GDR_RADIX - 1);
+        const bool owner = threadIdx.x < GDR_RADIX;
+        uint32_t tot = 0;
+        if (owner)
+            for (int k = 0; k < NW; ++k) tot += cnt[k][d];
+        const uint32_t incl = wave_incl_scan(owner ? tot : 0u);
+        if (owner && lane == 63) scan_lds[w] = incl;
+        __syncthreads();
+        if (owner) {
+            uint32_t base = incl - tot;
+            for (uint32_t k = 0; k < w; ++k) base += scan_lds[k];
+            for (int k = 0; k < NW; ++k) { const uint32_t c = cnt[k][d]; cnt[k][d] = base; base += c; }
+        }
     }
     __syncthreads();
     for (uint32_t i0 = c0; i0 < c1; i0 += GDR_WAVE) {
@@ -295,20 +308,29 @@ __device__ __forceinline__ void tile_sort_pass(const TileSortBufs& b, uint32_t L
 
 // keys_part: tile-partitioned u64 keys (tile << 32 | depth); vals_part: ids; outputs sorted.
 // scratch32: 2*D uint32 of global scratch (depth keys ping-pong for tiles that do not fit in LDS)
-template <int CAP, int LMIN>  // handles tiles with LMIN < L (<= CAP in LDS, else global buffers if LMIN > 0)
-__global__ __launch_bounds__(GDR_BLOCK) void tile_sort_kernel(const uint2* __restrict__ ranges,
+// handles tiles with LMIN < L <= CAP in LDS (TOP: also L > CAP, on the global buffers); NW waves per workgroup
+template <int CAP, int LMIN, int NW, bool TOP>
+__global__ __launch_bounds__(NW * GDR_WAVE) void tile_sort_kernel(const uint2* __restrict__ ranges,
                                                                const uint64_t* __restrict__ keys_part,
                                                                uint32_t* __restrict__ vals_part,
                                                                uint64_t* __restrict__ keys_out,
                                                                uint32_t* __restrict__ vals_out,
-                                                               uint32_t* __restrict__ scratch32, uint64_t D) {
+                                                               uint32_t* __restrict__ scratch32, uint64_t D,
+                                                               const uint32_t* __restrict__ tile_order, int ntiles) {
+    constexpr uint32_t NT = NW * GDR_WAVE;
     __shared__ uint32_t lds_elems[4 * CAP];
-    __shared__ uint32_t cnt[GDR_BLOCK / GDR_WAVE][GDR_RADIX];
-    __shared__ uint32_t misc[16];
-    const uint32_t tile = blockIdx.x;
+    __shared__ uint32_t cnt[NW][GDR_RADIX];
+    __shared__ uint32_t misc[8];
+    __shared__ uint32_t mm[2 * NW];
+    // LMIN > 0 (long-list class): a small grid walks the tiles longest-first (tile_order is sorted by
+    // list length / 16, descending) and stops at the first tile that is clearly in the other class
+    for (uint32_t slot = blockIdx.x; slot < (uint32_t)ntiles; slot += gridDim.x) {
+    const uint32_t tile = LMIN > 0 ? tile_order[slot] : slot;
     const uint2 rg = ranges[tile];
     const uint32_t L = rg.y - rg.x;
-    if (L <= (uint32_t)LMIN || (LMIN == 0 && L > (uint32_t)CAP)) return;  // other size class
+    if (LMIN > 0 && (L >> 4) < ((uint32_t)LMIN >> 4)) return;             // every later tile is shorter
+    if (L <= (uint32_t)LMIN || (!TOP && L > (uint32_t)CAP)) continue;  // other size class
+    __syncthreads();  // LDS reuse across loop iterations
     const uint32_t w = threadIdx.x >> 6, lane = lane_id();
     const bool in_lds = L <= (uint32_t)CAP;
     TileSortBufs b;
@@ -320,7 +342,7 @@ __global__ __launch_bounds__(GDR_BLOCK) void tile_sort_kernel(const uint2* __res
         b.vA = vals_part + rg.x; b.vB = vals_out + rg.x;
     }
     uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
-    for (uint32_t i = threadIdx.x; i < L; i += GDR_BLOCK) {
+    for (uint32_t i = threadIdx.x; i < L; i += NT) {
         const uint32_t k = (uint32_t)keys_part[rg.x + i];
         b.kA[i] = k;
         if (in_lds) b.vA[i] = vals_part[rg.x + i];
@@ -332,21 +354,19 @@ __global__ __launch_bounds__(GDR_BLOCK) void tile_sort_kernel(const uint2* __res
         kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, off, 64));
         kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, off, 64));
     }
-    if (lane == 0) { misc[8 + w] = kmin; misc[12 + w] = kmax; }
+    if (lane == 0) { mm[w] = kmin; mm[NW + w] = kmax; }
     __syncthreads();
-    kmin = min(min(misc[8], misc[9]), min(misc[10], misc[11]));
-    kmax = max(max(misc[12], misc[13]), max(misc[14], misc[15]));
+    for (int k = 0; k < NW; ++k) { kmin = min(kmin, mm[k]); kmax = max(kmax, mm[NW + k]); }
     const uint32_t span = kmax - kmin;
     const int nbits = span ? 32 - __builtin_clz(span) : 0;
     for (int shift = 0; shift < nbits; shift += GDR_RADIX_BITS) {
-        if (in_lds) tile_sort_pass(b, L, kmin, shift, cnt, misc);
-        else tile_sort_pass(b, L, kmin, shift, cnt, misc);
+        tile_sort_pass<NW>(b, L, kmin, shift, cnt, misc);
         uint32_t* t = b.kA; b.kA = b.kB; b.kB = t;
         t = b.vA; b.vA = b.vB; b.vB = t;
     }
     // ties on identical depth bits: ascending Gaussian id — the order the reference's stable sort of
     // (Gaussian-ordered) emission leaves them in; our emission order is arbitrary (block_offs)
-    for (uint32_t i = threadIdx.x; i + 1 < L; i += GDR_BLOCK) {
+    for (uint32_t i = threadIdx.x; i + 1 < L; i += NT) {
         if (b.kA[i] == b.kA[i + 1] && (i == 0 || b.kA[i - 1] != b.kA[i])) {
             uint32_t j = i + 1;
             while (j < L && b.kA[j] == b.kA[i]) ++j;
@@ -359,12 +379,13 @@ __global__ __launch_bounds__(GDR_BLOCK) void tile_sort_kernel(const uint2* __res
         }
     }
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < L; i += GDR_BLOCK) {
+    for (uint32_t i = threadIdx.x; i < L; i += NT) {
         const uint32_t v = b.vA[i];
         const uint32_t k = b.kA[i];
         if (in_lds || b.vA != vals_out + rg.x) vals_out[rg.x + i] = v;
         keys_out[rg.x + i] = ((uint64_t)tile << 32) | (uint64_t)k;
     }
+    }  // slot loop
 }
 
 }  // namespace
@@ -438,12 +459,16 @@ hipError_t launch_sort_tile_bits(gdr_binning* bin, uint64_t D, int nbits, hipStr
 hipError_t launch_tile_sort(gdr_binning* bin, const gdr_image* img, int tiles, uint64_t D, hipStream_t st) {
     if (D == 0) return hipSuccess;
     const int in = bin->sorted, out = in ^ 1;
-    GDR_LAUNCH(GDR_K_TILE_SORT, (tile_sort_kernel<GDR_TSORT_LARGE, GDR_TSORT_SMALL>), dim3(tiles), dim3(GDR_BLOCK),
-               st, (const uint2*)img->ranges, bin->keys[in], bin->values[in], bin->keys[out], bin->values[out],
-               bin->scratch32, D);
-    GDR_LAUNCH(GDR_K_TILE_SORT, (tile_sort_kernel<GDR_TSORT_SMALL, 0>), dim3(tiles), dim3(GDR_BLOCK), st,
+    // long lists: 16 waves per workgroup (1 per CU) so that the few heavy tiles finish quickly
+    GDR_LAUNCH(GDR_K_TILE_SORT_LONG, (tile_sort_kernel<GDR_TSORT_LARGE, GDR_TSORT_MEDIUM, 16, true>),
+               dim3(tiles < 128 ? tiles : 128), dim3(16 * GDR_WAVE), st, (const uint2*)img->ranges, bin->keys[in],
+               bin->values[in], bin->keys[out], bin->values[out], bin->scratch32, D, img->tile_order, tiles);
+    GDR_LAUNCH(GDR_K_TILE_SORT_LONG, (tile_sort_kernel<GDR_TSORT_MEDIUM, GDR_TSORT_SMALL, 8, false>),
+               dim3(tiles < 512 ? tiles : 512), dim3(8 * GDR_WAVE), st, (const uint2*)img->ranges, bin->keys[in],
+               bin->values[in], bin->keys[out], bin->values[out], bin->scratch32, D, img->tile_order, tiles);
+    GDR_LAUNCH(GDR_K_TILE_SORT, (tile_sort_kernel<GDR_TSORT_SMALL, 0, 4, false>), dim3(tiles), dim3(GDR_BLOCK), st,
                (const uint2*)img->ranges, bin->keys[in], bin->values[in], bin->keys[out], bin->values[out],
-               bin->scratch32, D);
+               bin->scratch32, D, img->tile_order, tiles);
     bin->sorted = out;
     return hipGetLastError();
 }

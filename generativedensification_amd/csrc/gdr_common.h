@@ -31,6 +31,7 @@ enum {
     GDR_K_MARK_VISIBLE,
     GDR_K_TILE_ORDER,
     GDR_K_TILE_SORT,
+    GDR_K_TILE_SORT_LONG,
     GDR_K_COUNT
 };
 
