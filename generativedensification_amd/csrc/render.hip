@@ -109,6 +109,12 @@ __device__ __forceinline__ float row_reduce_scatter4(float v0, float v1, float v
 
 #define GDR_ROW_MASK(k) (0xFFFFull << (16 * (k)))
 
+struct Entry {  // one staged list entry, in registers
+    uint32_t e;
+    float2 m;
+    float4 co, cd;
+};
+
 // LDS image of one 256-entry slice (+ the null entry)
 struct SliceLds {
     float2 xy[GDR_BLOCK + 1];
@@ -266,23 +272,18 @@ __global__ __launch_bounds__(GDR_BLOCK) void render_fwd_kernel(
                         (live & GDR_ROW_MASK(2)) != 0ull, (live & GDR_ROW_MASK(3)) != 0ull, m0, m1, m2, m3);
             if ((m0 | m1 | m2 | m3) == 0ull) continue;
             const uint32_t goff = (uint32_t)(g * GDR_WAVE), nulloff = GDR_NULL_ENTRY - goff;
-            // software pipeline: entry `e` is loaded one iteration before it is composited
+            // software pipeline, unrolled by two (ping-pong registers instead of copies): entry A is
+            // composited while B's LDS reads are in flight, and vice versa
             uint64_t mr = row_select(row, m0, m1, m2, m3);
-            uint32_t e = min(take_bit(mr), nulloff) + goff;  // 0xFFFFFFFF (no entry) -> null entry
-            float2 m = lds.xy[e];
-            float4 co = lds.co[e], cd = lds.cd[e];
-            bool more = true;
-            while (more) {
-                const uint32_t e_cur = e;
-                const float2 m_cur = m;
-                const float4 co_cur = co, cd_cur = cd;
-                more = __ballot(mr != 0ull) != 0ull;
-                e = min(take_bit(mr), nulloff) + goff;
-                m = lds.xy[e]; co = lds.co[e]; cd = lds.cd[e];
-
-                const float dx = m_cur.x - pxf, dy = m_cur.y - pyf;
-                const float p2 = gauss_power(dx, dy, co_cur.x, co_cur.y, co_cur.z);
-                float alpha = fminf(0.99f, co_cur.w * __builtin_amdgcn_exp2f(p2));
+            bool abort = false;
+            auto fetch = [&](Entry& en) {
+                en.e = min(take_bit(mr), nulloff) + goff;  // 0xFFFFFFFF (no entry) -> null entry
+                en.m = lds.xy[en.e]; en.co = lds.co[en.e]; en.cd = lds.cd[en.e];
+            };
+            auto composite = [&](const Entry& en) {
+                const float dx = en.m.x - pxf, dy = en.m.y - pyf;
+                const float p2 = gauss_power(dx, dy, en.co.x, en.co.y, en.co.z);
+                float alpha = fminf(0.99f, en.co.w * __builtin_amdgcn_exp2f(p2));
                 alpha = (p2 > 0.f) ? 0.f : alpha;        // reference skips power > 0
                 const float a_c = (alpha >= thr) ? alpha : 0.f;
                 const float T_new = fmaf(-a_c, T, T);     // T (1 - alpha); == T when a_c == 0
@@ -290,18 +291,31 @@ __global__ __launch_bounds__(GDR_BLOCK) void render_fwd_kernel(
                 const float w = stop ? 0.f : a_c * T;
                 T = stop ? T : T_new;
                 thr = stop ? INFINITY : thr;
-                C0 = fmaf(cd_cur.x, w, C0);
-                C1 = fmaf(cd_cur.y, w, C1);
-                C2 = fmaf(cd_cur.z, w, C2);
-                Dp = fmaf(cd_cur.w, w, Dp);
+                C0 = fmaf(en.cd.x, w, C0);
+                C1 = fmaf(en.cd.y, w, C1);
+                C2 = fmaf(en.cd.z, w, C2);
+                Dp = fmaf(en.cd.w, w, Dp);
                 Wt += w;
-                last_contributor = (w > 0.f) ? base + e_cur : last_contributor;
+                last_contributor = (w > 0.f) ? base + en.e : last_contributor;
                 if (__ballot(stop) != 0ull) {  // rare: some pixel saturated -> retire finished blocks
                     live = __ballot(thr < INFINITY);
                     if (((live >> (16 * row)) & 0xFFFFull) == 0ull) mr = 0ull;
-                    if (live == 0ull) { more = false; g = GDR_BLOCK / GDR_WAVE; }
+                    if (live == 0ull) abort = true;
                 }
+            };
+            Entry A, B;
+            fetch(A);
+            for (;;) {
+                const bool moreA = __ballot(mr != 0ull) != 0ull;
+                fetch(B);
+                composite(A);
+                if (!moreA || abort) break;
+                const bool moreB = __ballot(mr != 0ull) != 0ull;
+                fetch(A);
+                composite(B);
+                if (!moreB || abort) break;
             }
+            if (abort) g = GDR_BLOCK / GDR_WAVE;
         }
     }
     if (inside) {
@@ -415,55 +429,48 @@ __global__ __launch_bounds__(GDR_BLOCK) void render_bwd_kernel(
             if ((m0 | m1 | m2 | m3) == 0ull) continue;
             const uint32_t goff = (uint32_t)(g * GDR_WAVE), nulloff = GDR_NULL_ENTRY - goff;
             uint64_t mr = row_select(row, m0, m1, m2, m3);
-            uint32_t e = min(take_bit(mr), nulloff) + goff;
-            float2 m = lds.xy[e];
-            float4 co = lds.co[e], cd = lds.cd[e];
-            bool more = true;
-            while (more) {
-                const uint32_t e_cur = e;
-                const float2 m_cur = m;
-                const float4 co_cur = co, cd_cur = cd;
-                more = __ballot(mr != 0ull) != 0ull;
-                e = min(take_bit(mr), nulloff) + goff;
-                m = lds.xy[e]; co = lds.co[e]; cd = lds.cd[e];
-
-                const float dx = m_cur.x - pxf, dy = m_cur.y - pyf;
-                const float p2 = gauss_power(dx, dy, co_cur.x, co_cur.y, co_cur.z);
+            auto fetch = [&](Entry& en) {
+                en.e = min(take_bit(mr), nulloff) + goff;
+                en.m = lds.xy[en.e]; en.co = lds.co[en.e]; en.cd = lds.cd[en.e];
+            };
+            auto accumulate = [&](const Entry& en) {
+                const float dx = en.m.x - pxf, dy = en.m.y - pyf;
+                const float p2 = gauss_power(dx, dy, en.co.x, en.co.y, en.co.z);
                 const float G = __builtin_amdgcn_exp2f(p2);
-                float alpha = fminf(0.99f, co_cur.w * G);
+                float alpha = fminf(0.99f, en.co.w * G);
                 alpha = (p2 > 0.f) ? 0.f : alpha;
                 // contributes iff it did in the forward: alpha >= 1/255 and position < last_contributor
                 // (the null entry has opacity 0 -> alpha 0)
-                const float lim = (top - (int)e_cur < last_contributor) ? GDR_ALPHA_MIN : INFINITY;
+                const float lim = (top - (int)en.e < last_contributor) ? GDR_ALPHA_MIN : INFINITY;
                 const bool hit = alpha >= lim;
                 const uint64_t hb = __ballot(hit);
-                if (hb == 0ull) continue;
+                if (hb == 0ull) return;
                 const float a = hit ? alpha : 0.f;
                 const float hm = hit ? 1.f : 0.f;
                 const float r_oma = __builtin_amdgcn_rcpf(1.f - a);  // == 1 when a == 0
                 T = T * r_oma;                                        // transmittance in FRONT of this Gaussian
                 const float w = a * T;
-                const float d0 = cd_cur.x - B0, d1 = cd_cur.y - B1, d2 = cd_cur.z - B2;
+                const float d0 = en.cd.x - B0, d1 = en.cd.y - B1, d2 = en.cd.z - B2;
                 float dL_dalpha;
                 if (M2_ONLY) {
                     dL_dalpha = fmaf(d0, gC0, fmaf(d1, gC1, d2 * gC2));
                 } else {
-                    const float dD = cd_cur.w - BD, dA = 1.f - BA;
+                    const float dD = en.cd.w - BD, dA = 1.f - BA;
                     dL_dalpha = fmaf(d0, gC0, fmaf(d1, gC1, fmaf(d2, gC2, fmaf(dD, gD, dA * gA))));
                     BD = fmaf(a, dD, BD); BA = fmaf(a, dA, BA);
                 }
                 dL_dalpha = fmaf(dL_dalpha, T, bgT * r_oma) * hm;
                 B0 = fmaf(a, d0, B0); B1 = fmaf(a, d1, B1); B2 = fmaf(a, d2, B2);
-                const float dL_dG = co_cur.w * dL_dalpha;
+                const float dL_dG = en.co.w * dL_dalpha;
                 const float gdx = G * dx, gdy = G * dy;
                 // co.xyz carry the log2(e) factor; kx, ky carry its inverse
-                const float v_mx = dL_dG * (-gdx * co_cur.x - gdy * co_cur.y) * kx;
-                const float v_my = dL_dG * (-gdy * co_cur.z - gdx * co_cur.y) * ky;
+                const float v_mx = dL_dG * (-gdx * en.co.x - gdy * en.co.y) * kx;
+                const float v_my = dL_dG * (-gdy * en.co.z - gdx * en.co.y) * ky;
                 if (M2_ONLY) {
                     const float tot4 = row_reduce_scatter4(v_mx, v_my, fabsf(v_mx), fabsf(v_my), li);
                     if ((li & 3u) == 0u && ((hb >> (16 * row)) & 0xFFFFull) != 0ull)
-                        atomicAdd(grad_rec + 4 * (size_t)s_id[e_cur] + (li >> 2), tot4);
-                    continue;
+                        atomicAdd(grad_rec + 4 * (size_t)s_id[en.e] + (li >> 2), tot4);
+                    return;
                 }
                 const float vals[12] = {v_mx, v_my, fabsf(v_mx), fabsf(v_my),
                                         -0.5f * gdx * dx * dL_dG, -gdx * dy * dL_dG, -0.5f * gdy * dy * dL_dG,
@@ -473,7 +480,19 @@ __global__ __launch_bounds__(GDR_BLOCK) void render_bwd_kernel(
                 // 64-byte gradient record: one global_atomic_add_f32 instruction, one cache line
                 // per row (no return value => fire and forget)
                 if (li < 12u && ((hb >> (16 * row)) & 0xFFFFull) != 0ull)
-                    atomicAdd(grad_rec + 16 * (size_t)s_id[e_cur] + li, tot);
+                    atomicAdd(grad_rec + 16 * (size_t)s_id[en.e] + li, tot);
+            };
+            Entry A, B;  // unrolled by two: ping-pong registers instead of copies
+            fetch(A);
+            for (;;) {
+                const bool moreA = __ballot(mr != 0ull) != 0ull;
+                fetch(B);
+                accumulate(A);
+                if (!moreA) break;
+                const bool moreB = __ballot(mr != 0ull) != 0ull;
+                fetch(A);
+                accumulate(B);
+                if (!moreB) break;
             }
         }
     }
