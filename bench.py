@@ -115,7 +115,10 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.dist_backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            try:
+                dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+            except TypeError:  # older torch: no device_id argument
+                dist.init_process_group("nccl")
         else:
             dist.init_process_group(args.dist_backend)
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
