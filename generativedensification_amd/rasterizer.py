@@ -284,7 +284,11 @@ def _forward_views_impl(means3D, means2D, sh, opacities, scales, rotations, sett
     e = torch.empty(0, dtype=torch.float32, device=dev)
     keep = [means3D, opacities, sh, e, scales, rotations, e]
     f32, u8 = dict(dtype=torch.float32, device=dev), dict(dtype=torch.uint8, device=dev)
-    colors, depths, alphas = torch.empty(V, 3, H, W, **f32), torch.empty(V, 1, H, W, **f32), torch.empty(V, 1, H, W, **f32)
+    # one tensor per view (not slices of a stacked buffer): a per-view loss then back-propagates straight into
+    # that view's gradient, without autograd's select-backward zero-fill + add of the whole stack per view
+    colors = [torch.empty(3, H, W, **f32) for _ in range(V)]
+    depths = [torch.empty(1, H, W, **f32) for _ in range(V)]
+    alphas = [torch.empty(1, H, W, **f32) for _ in range(V)]
     radii = torch.empty(V, N, dtype=torch.int32, device=dev)
     states = []
     with torch.cuda.device(dev):
@@ -351,15 +355,17 @@ class _RenderViews(torch.autograd.Function):
         ctx.states, ctx.keep, ctx.settings_list, ctx.flags = states, keep, settings_list, flags
         ctx.radii, ctx.in_dtypes, ctx.means2D_shape = radii, in_dtypes, tuple(means2D.shape)
         ctx.mark_non_differentiable(radii)
-        return colors, radii, depths, alphas
+        return (radii, *colors, *depths, *alphas)
 
     @staticmethod
-    def backward(ctx, g_colors, g_radii, g_depths, g_alphas):
+    def backward(ctx, g_radii, *g_views):
         lib = L.load()
         means3D, opacities, sh, e, scales, rotations, _ = ctx.keep[:7]
         dev = means3D.device
         states = ctx.states
         N, M, V = states[0].N, states[0].M, len(states)
+        H, W = states[0].H, states[0].W
+        g_colors, g_depths, g_alphas = g_views[:V], g_views[V:2 * V], g_views[2 * V:3 * V]
         f32 = dict(dtype=torch.float32, device=dev)
         g = dict(means3D=torch.empty(N, 3, **f32), means2D=torch.empty(N, 4, **f32), shs=torch.empty(N, M, 3, **f32),
                  opacities=torch.empty(N, 1, **f32), scales=torch.empty(N, 3, **f32), rotations=torch.empty(N, 4, **f32))
@@ -377,9 +383,10 @@ class _RenderViews(torch.autograd.Function):
                 grads_in = []
                 for k in range(n):  # torch-side preparation stays on the caller's stream
                     v = lo + k
-                    gc = _f32(g_colors[v], dev)
-                    gd = None if g_depths is None else _f32(g_depths[v], dev)
-                    ga = None if g_alphas is None else _f32(g_alphas[v], dev)
+                    gc = (_f32(g_colors[v], dev) if g_colors[v] is not None
+                          else torch.zeros(3, H, W, dtype=torch.float32, device=dev))
+                    gd = None if g_depths[v] is None else _f32(g_depths[v], dev)
+                    ga = None if g_alphas[v] is None else _f32(g_alphas[v], dev)
                     keep2 += [gc, gd, ga]
                     grads_in.append((gc, gd, ga))
                 if side:
@@ -426,8 +433,11 @@ class _RenderViews(torch.autograd.Function):
 def render_views_raw(means3D, means2D, sh, opacities, scales, rotations, settings_list, flags=RAW_ALL):
     """V views of one Gaussian set in one autograd node.  With flags=RAW_ALL the opacity /
     scale / rotation tensors are the adaptor's RAW (pre-activation) tensors.
-    Returns (colors (V,3,H,W), radii (V,N) int32, depths (V,1,H,W), alphas (V,1,H,W))."""
-    return _RenderViews.apply(means3D, means2D, sh, opacities, scales, rotations, tuple(settings_list), int(flags))
+    Returns (colors, radii (V,N) int32, depths, alphas) with colors / depths / alphas LISTS of V per-view
+    tensors (3,H,W) / (1,H,W) / (1,H,W)."""
+    V = len(settings_list)
+    out = _RenderViews.apply(means3D, means2D, sh, opacities, scales, rotations, tuple(settings_list), int(flags))
+    return list(out[1:1 + V]), out[0], list(out[1 + V:1 + 2 * V]), list(out[1 + 2 * V:1 + 3 * V])
 
 
 def screenspace_absgrad_raw(means3D, sh, opacities, scales, rotations, settings_list, gt_images, flags=RAW_ALL):
@@ -444,6 +454,7 @@ def screenspace_absgrad_raw(means3D, sh, opacities, scales, rotations, settings_
         dummy = torch.empty(0, 4, device=dev)
         colors, radii, depths, alphas, states, keep, _ = _forward_views_impl(
             means3D, dummy, sh, opacities, scales, rotations, tuple(settings_list), int(flags))
+        colors = torch.stack(colors)
         gt = _f32(gt_images, dev)
         diff = colors.clamp(0, 1) - gt
         loss = (diff * diff).mean()

@@ -80,12 +80,11 @@ class Renderer(nn.Module):
             pass
         images, radii, depths, alphas = render_views_raw(centers, screenspace_points, shs, opacity, scales,
                                                          rotations, sets)
-        images = images.clamp(0, 1)
-        if stacked:
-            return {f"image{prex}": images.permute(0, 2, 3, 1), f"depth{prex}": depths.permute(0, 2, 3, 1),
-                    f"acc_map{prex}": alphas.squeeze(1)}
-        return [{f"image{prex}": images[v].permute(1, 2, 0), f"depth{prex}": depths[v].permute(1, 2, 0),
+        outs = [{f"image{prex}": images[v].clamp(0, 1).permute(1, 2, 0), f"depth{prex}": depths[v].permute(1, 2, 0),
                  f"acc_map{prex}": alphas[v].squeeze(0)} for v in range(len(sets))]
+        if stacked:
+            return {k: torch.stack([o[k] for o in outs]) for k in outs[0]}
+        return outs
 
     def screenspace_absgrad(self, cams, bg_colors, gt_images, centers, shs, opacity, scales, rotations, device):
         """Image loss and its (N,4) screen-space gradient over `cams` — the quantity the reference obtains with

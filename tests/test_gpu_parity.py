@@ -281,6 +281,7 @@ def test_multiview_kernels_keep_integer_intermediates_bit_exact(oracle_built):
     for v, cc in enumerate(sets):
         o, _ = U.run_oracle(cc, "f32")
         np.testing.assert_array_equal(radii[v].cpu().numpy(), o["radii"])
+        assert colors[v].shape == (3, 208, 176) and depths[v].shape == (1, 208, 176)
         assert U.outlier_fraction(colors[v].cpu().numpy(), o["color"], 1e-4, 1e-5) < 1e-4
         assert U.outlier_fraction(depths[v].cpu().numpy(), o["depth"], 1e-4, 1e-5) < 1e-4
 
