@@ -87,6 +87,9 @@ def main():
     ap.add_argument("--views-per-gpu", type=int, default=0)
     ap.add_argument("--grad-allreduce", action="store_true",
                     help="also sum the Gaussian attribute grads over ranks each step (SURVEY §8e)")
+    ap.add_argument("--torch-loss", action="store_true",
+                    help="take the loss with torch ops on the clamped HWC dicts (default: the fused HIP loss kernel, "
+                         "same value and gradients, generativedensification_amd/losses.py)")
     ap.add_argument("--stacked-loss", action="store_true",
                     help="take the loss on the view-stacked tensors (measured slower: dim-wise means on strided views)")
     ap.add_argument("--per-view", action="store_true",
@@ -128,6 +131,7 @@ def main():
     from generativedensification_amd.multiview import (allreduce_gaussian_grads, gather_view_losses,
                                                        render_views, shard_views)
     from generativedensification_amd.renderer import Renderer
+    from generativedensification_amd.losses import view_loss_fused
     from generativedensification_amd.synthetic import make_scene, make_targets, view_loss, views_loss
 
     wl = dict(WORKLOADS[args.workload])
@@ -149,7 +153,8 @@ def main():
     cams = [all_cams[i] for i in mine]
     targets = make_targets(total_views, h, w, wl["seed"])[list(mine)].to(dev)
     # same strides as the HWC views of the rasterizer's CHW images: elementwise kernels stay on the dense path
-    targets = targets.permute(0, 3, 1, 2).contiguous().permute(0, 2, 3, 1)
+    targets_chw = targets.permute(0, 3, 1, 2).contiguous()
+    targets = targets_chw.permute(0, 2, 3, 1)
     renderer = Renderer(sh_degree=deg, white_background=True, fused=not args.unfused)
     renderer.set_bg_color(torch.ones(3, device=dev))
     plist = list(params.values())
@@ -168,7 +173,11 @@ def main():
                 losses.append(loss.detach())
             losses = torch.stack(losses)
         else:               # multi-view entry point: all views of the shard in one rasterizer node
-            if not args.stacked_loss:
+            if not (args.stacked_loss or args.torch_loss or args.unfused):
+                outs = render_views(renderer, cams, None, params, dev, raw=True)
+                lv = torch.stack([view_loss_fused(o["color"], o["depth"], o["alpha"], targets_chw[j])
+                                  for j, o in enumerate(outs)])
+            elif not args.stacked_loss:
                 outs = render_views(renderer, cams, None, params, dev)
                 lv = torch.stack([view_loss(o, targets[j]) for j, o in enumerate(outs)])
             else:
@@ -294,7 +303,9 @@ def main():
                        "num_rendered_per_view": int(d_mean), "parallelism": f"view-sharded x{world}",
                        "grad_allreduce": bool(args.grad_allreduce),
                        "entry": ("render_img per view" if args.per_view else "render_views (all views of the shard, one node)")
-                       + (", torch activations" if args.unfused else ", activations fused into K1/K9")},
+                       + (", torch activations" if args.unfused else ", activations fused into K1/K9"),
+                       "loss": ("torch ops" if (args.per_view or args.stacked_loss or args.torch_loss or args.unfused)
+                                else "fused HIP kernel (clamp+MSE+0.1 mean depth+0.1 mean alpha)")},
             "roofline": roofline, "cpu_baseline": cpu_baseline, "kernels": kernels,
             "loss_mean": float(last_losses.mean()),
         }

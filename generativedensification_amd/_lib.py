@@ -98,6 +98,10 @@ _PROTOS = {
     "gdr_preprocess_backward_views": (C.c_int, [C.c_int32, C.POINTER(GdrSettings), C.POINTER(GdrInputs),
                                                 C.POINTER(GdrGeom), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                                 C.POINTER(GdrGradOutputs), C.c_void_p]),
+    "gdr_view_loss_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float,
+                                        C.c_float, C.c_void_p, C.c_void_p]),
+    "gdr_view_loss_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_void_p,
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gdr_profile_enable": (C.c_int, [C.c_int]),
     "gdr_profile_collect": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int32, C.c_int32]),
     "gdr_kernel_count": (C.c_int, []),

@@ -383,6 +383,23 @@ int gdr_preprocess_backward_views(int32_t V, const gdr_settings* s, const gdr_in
     return debug_sync(&s[0], "preprocess_bwd_views", st);
 }
 
+int gdr_view_loss_forward(const float* color, const float* depth, const float* alpha, const float* target,
+                          int32_t H, int32_t W, float w_depth, float w_alpha, float* loss, void* stream) {
+    if (!color || !depth || !alpha || !target || !loss || H <= 0 || W <= 0) { set_error("view_loss_forward: bad argument", hipSuccess); return GDR_ERR_INVALID_ARG; }
+    hipError_t e = launch_view_loss_fwd(color, depth, alpha, target, H * W, w_depth, w_alpha, loss, (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail("view_loss_fwd", e);
+    return GDR_OK;
+}
+
+int gdr_view_loss_backward(const float* color, const float* target, int32_t H, int32_t W, float w_depth,
+                           float w_alpha, const float* g, float* dL_dcolor, float* dL_ddepth, float* dL_dalpha,
+                           void* stream) {
+    if (!color || !target || !dL_dcolor || !dL_ddepth || !dL_dalpha || H <= 0 || W <= 0) { set_error("view_loss_backward: bad argument", hipSuccess); return GDR_ERR_INVALID_ARG; }
+    hipError_t e = launch_view_loss_bwd(color, target, H * W, w_depth, w_alpha, g, dL_dcolor, dL_ddepth, dL_dalpha, (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail("view_loss_bwd", e);
+    return GDR_OK;
+}
+
 int gdr_profile_enable(int on) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     g_prof_on = on != 0;
@@ -414,7 +431,7 @@ int gdr_profile_collect(double* ms_total, uint64_t* launches, int32_t n, int32_t
 const char* gdr_kernel_name(int32_t id) {
     static const char* names[GDR_K_COUNT] = {"preprocess_fwd", "scan_block_sums", "duplicate_with_keys",
         "sort_hist", "sort_rowscan", "sort_scatter", "tile_ranges", "render_fwd", "render_bwd",
-        "preprocess_bwd", "mark_visible", "tile_order", "tile_sort", "tile_sort_long"};
+        "preprocess_bwd", "mark_visible", "tile_order", "tile_sort", "tile_sort_long", "view_loss"};
     return (id >= 0 && id < GDR_K_COUNT) ? names[id] : "";
 }
 int gdr_kernel_count(void) { return GDR_K_COUNT; }

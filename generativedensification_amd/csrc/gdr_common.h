@@ -32,6 +32,7 @@ enum {
     GDR_K_TILE_ORDER,
     GDR_K_TILE_SORT,
     GDR_K_TILE_SORT_LONG,
+    GDR_K_VIEW_LOSS,
     GDR_K_COUNT
 };
 
@@ -93,6 +94,11 @@ hipError_t launch_render_bwd_mean2d(const gdr_settings* s, const gdr_geom* g, co
 hipError_t launch_render_bwd(const gdr_settings* s, const gdr_geom* g, const gdr_binning* bin,
                              const gdr_image* img, const gdr_grad_inputs* gi,
                              const gdr_grad_outputs* go, hipStream_t st);
+
+hipError_t launch_view_loss_fwd(const float* color, const float* depth, const float* alpha, const float* target,
+                                int P, float w_depth, float w_alpha, float* loss, hipStream_t st);
+hipError_t launch_view_loss_bwd(const float* color, const float* target, int P, float w_depth, float w_alpha,
+                                const float* g, float* d_color, float* d_depth, float* d_alpha, hipStream_t st);
 
 size_t sort_hist_bytes(uint64_t D);
 

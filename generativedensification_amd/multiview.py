@@ -24,13 +24,16 @@ def shard_views(n_views: int, rank: int, world: int) -> range:
 
 
 def render_views(renderer, cams: Sequence, bg_colors, gaussians: dict, device, prex: str = "",
-                 screenspace_points=None, stacked: bool = False):
+                 screenspace_points=None, stacked: bool = False, raw: bool = False):
     """One `render_img` per camera (same call the reference loop makes); bg_colors may be
-    None (keep the renderer's), one tensor, or one per view (network.py:829-830)."""
+    None (keep the renderer's), one tensor, or one per view (network.py:829-830).
+    raw=True (fused renderer only): the rasterizer's own layout, see Renderer.render_views."""
+    if raw and not (hasattr(renderer, "render_views") and getattr(renderer, "fused", False)):
+        raise RuntimeError("raw=True needs the fused HIP renderer")
     if hasattr(renderer, "render_views") and getattr(renderer, "fused", False) and gaussians["centers"].is_cuda:
         return renderer.render_views(cams, bg_colors, gaussians["centers"], gaussians["shs"], gaussians["opacity"],
                                      gaussians["scales"], gaussians["rotations"], device, prex=prex,
-                                     screenspace_points=screenspace_points, stacked=stacked)
+                                     screenspace_points=screenspace_points, stacked=stacked, raw=raw)
     outs = []
     for j, cam in enumerate(cams):
         if bg_colors is not None:

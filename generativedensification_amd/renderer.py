@@ -59,13 +59,15 @@ class Renderer(nn.Module):
         return GaussianRasterizer(raster_settings=settings)
 
     def render_views(self, cams, bg_colors, centers, shs, opacity, scales, rotations, device, prex="",
-                     screenspace_points=None, stacked=False):
+                     screenspace_points=None, stacked=False, raw=False):
         """All `cams` of one Gaussian set in ONE rasterizer node (replaces the per-view loops of
         network.py:826-838 / 848-856 / 964-972 without changing what each view returns).
         bg_colors: None (keep self.bg_color), one tensor, or one per view (network.py:829-830).
         Returns a list with the same dict render_img returns for each view, or with stacked=True ONE
         dict of view-stacked tensors (image (V,H,W,3), depth (V,H,W,1), acc_map (V,H,W)) — what the
-        callers build anyway with torch.stack (network.py:840, 974-978) before taking the loss."""
+        callers build anyway with torch.stack (network.py:840, 974-978) before taking the loss.
+        raw=True: per-view dicts in the rasterizer's own layout instead — color (3,H,W) UNclamped, depth (1,H,W),
+        alpha (1,H,W) — for a loss that folds the clamp in (losses.view_loss_fused)."""
         sets = []
         for j, cam in enumerate(cams):
             if bg_colors is not None:
@@ -80,6 +82,9 @@ class Renderer(nn.Module):
             pass
         images, radii, depths, alphas = render_views_raw(centers, screenspace_points, shs, opacity, scales,
                                                          rotations, sets)
+        if raw:
+            return [{f"color{prex}": images[v], f"depth{prex}": depths[v], f"alpha{prex}": alphas[v]}
+                    for v in range(len(sets))]
         outs = [{f"image{prex}": images[v].clamp(0, 1).permute(1, 2, 0), f"depth{prex}": depths[v].permute(1, 2, 0),
                  f"acc_map{prex}": alphas[v].squeeze(0)} for v in range(len(sets))]
         if stacked:

@@ -235,6 +235,17 @@ int gdr_render_backward_mean2d(const gdr_settings* s, int32_t N, const gdr_geom*
                                const gdr_binning* bin, const gdr_image* img, const float* dL_dcolor,
                                float* dL_dmean2D, void* stream);
 
+/* ---- fused image loss either side of the path ---------------------------------
+ * loss += mean_{c,p}(clamp(color,0,1) - target)^2 + w_depth mean(depth) + w_alpha mean(alpha) for ONE view
+ * (renderer.py:261 clamp, loss.py:37-38 MSE; depth/alpha terms: the measurement loss of SURVEY §8d).
+ * color, target: (3,H,W); depth, alpha: (H,W); loss: device float the caller zeroes (accumulated with one
+ * atomic per workgroup).  backward: g = device pointer to the upstream scalar (NULL = 1). */
+int gdr_view_loss_forward(const float* color, const float* depth, const float* alpha, const float* target,
+                          int32_t H, int32_t W, float w_depth, float w_alpha, float* loss, void* stream);
+int gdr_view_loss_backward(const float* color, const float* target, int32_t H, int32_t W, float w_depth,
+                           float w_alpha, const float* g, float* dL_dcolor, float* dL_ddepth, float* dL_dalpha,
+                           void* stream);
+
 /* ---- K10: visibility mask (upstream markVisible; unused by the reference) -------- */
 int gdr_mark_visible(int32_t N, const float* means3D, const float* viewmatrix,
                      const float* projmatrix, uint8_t* present, void* stream);

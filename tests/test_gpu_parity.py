@@ -365,3 +365,58 @@ def test_screenspace_absgrad_entry_matches_vjp_through_the_reference_sequence():
     sel = torch.topk(grad[:, 2:4].norm(dim=-1), k).indices
     sel_ref = torch.topk(grad_ref[:, 2:4].norm(dim=-1), k).indices
     assert len(set(sel.tolist()) & set(sel_ref.tolist())) >= k - 5
+
+
+def test_fused_view_loss_matches_torch_loss_value_and_gradients():
+    """losses.view_loss_fused (one HIP reduction forward, one elementwise kernel backward) == synthetic.view_loss on
+    the clamped dict (renderer.py:261 clamp + loss.py:37-38 MSE + the §8d depth/alpha means): value to 1e-6
+    relative (fp32 reduction order differs), image-space gradients elementwise to 1e-6, Gaussian gradients to 1e-4."""
+    from generativedensification_amd.camera import orbit_cameras
+    from generativedensification_amd.losses import view_loss_fused
+    from generativedensification_amd.renderer import Renderer
+    from generativedensification_amd.synthetic import make_scene, make_targets, view_loss
+
+    dev = torch.device("cuda:0")
+    n, h, w, V = 20_000, 144, 176, 2
+    sc = make_scene(n, 91, sh_degree=3, sigma0=(0.0052, 0.02))
+    sc["shs"][:, 0] *= 3.0   # push a good share of pixels outside [0,1] so the clamp mask matters
+    cams = orbit_cameras(V, w, h, device=dev)
+    tg = make_targets(V, h, w, 91).to(dev)
+    tg_chw = tg.permute(0, 3, 1, 2).contiguous()
+    r = Renderer(sh_degree=3, fused=True)
+
+    def run(fused_loss):
+        leaves = {k: v.to(dev).clone().requires_grad_(True) for k, v in sc.items()}
+        args = (cams, None, leaves["centers"], leaves["shs"], leaves["opacity"], leaves["scales"], leaves["rotations"], dev)
+        if fused_loss:
+            outs = r.render_views(*args, raw=True)
+            img = [o["color"] for o in outs]
+            lv = torch.stack([view_loss_fused(o["color"], o["depth"], o["alpha"], tg_chw[j]) for j, o in enumerate(outs)])
+        else:
+            outs = r.render_views(*args)
+            img = None
+            lv = torch.stack([view_loss(o, tg[j]) for j, o in enumerate(outs)])
+        # non-unit upstream gradients exercise the device-scalar g of the backward kernel
+        wts = torch.tensor([0.7, 1.9], device=dev)
+        grads = torch.autograd.grad((lv * wts).sum(), list(leaves.values()))
+        return lv.detach().cpu().numpy(), {k: g_.cpu().numpy() for k, g_ in zip(leaves, grads)}, img
+
+    l_ref, g_ref, _ = run(False)
+    l_fus, g_fus, img = run(True)
+    frac_out = float(((img[0] < 0) | (img[0] > 1)).float().mean())
+    assert 0.02 < frac_out < 0.98, frac_out
+    np.testing.assert_allclose(l_fus, l_ref, rtol=2e-6)
+    for k in g_ref:
+        assert U.rel_inf(g_fus[k], g_ref[k]) < 1e-4, k
+
+    # image-space gradients of the loss kernel alone against torch autograd
+    c = (torch.rand(3, h, w, device=dev) * 1.6 - 0.3).requires_grad_(True)
+    d = torch.rand(1, h, w, device=dev).requires_grad_(True)
+    a = torch.rand(1, h, w, device=dev).requires_grad_(True)
+    lf = view_loss_fused(c, d, a, tg_chw[0])
+    gf = torch.autograd.grad(lf * 3.0, [c, d, a])
+    lt = view_loss({"image": c.clamp(0, 1).permute(1, 2, 0), "depth": d.permute(1, 2, 0), "acc_map": a.squeeze(0)}, tg[0])
+    gt = torch.autograd.grad(lt * 3.0, [c, d, a])
+    assert abs(lf.item() - lt.item()) <= 2e-6 * abs(lt.item())
+    for x, y in zip(gf, gt):
+        torch.testing.assert_close(x, y, rtol=1e-6, atol=1e-12)
