@@ -30,11 +30,11 @@ def build(force: bool = False) -> None:
     need = force or not all(
         os.path.exists(os.path.join(_HERE, f"libgdr_oracle_{p}.so")) for p in ("f32", "f64")
     )
-    src = os.path.join(_HERE, "gdr_oracle.c")
+    srcs = [os.path.join(_HERE, f) for f in ("gdr_oracle.c", "gsr_oracle.c", "oracle_common.h")]
     if not need:
         for p in ("f32", "f64"):
             so = os.path.join(_HERE, f"libgdr_oracle_{p}.so")
-            if os.path.getmtime(so) < os.path.getmtime(src):
+            if any(os.path.getmtime(so) < os.path.getmtime(src) for src in srcs):
                 need = True
     if need:
         subprocess.check_call(["make", "-C", _HERE, "-B", "all"], stdout=subprocess.DEVNULL)
