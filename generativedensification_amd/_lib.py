@@ -68,7 +68,31 @@ class GdrGradOutputs(C.Structure):
                 ("accumulate", C.c_int32), ("reserved", C.c_int32)]
 
 
-# every symbol include/gdr.h declares, with its prototype
+class GsrInputs(C.Structure):   # include/gsr.h
+    _fields_ = [("N", C.c_int32), ("M", C.c_int32), ("means3D", C.c_void_p), ("opacities", C.c_void_p),
+                ("shs", C.c_void_p), ("colors_precomp", C.c_void_p), ("scales", C.c_void_p),
+                ("rotations", C.c_void_p), ("transMat_precomp", C.c_void_p), ("flags", C.c_uint32),
+                ("reserved", C.c_uint32)]
+
+
+class GsrOutputs(C.Structure):
+    _fields_ = [("color", C.c_void_p), ("allmap", C.c_void_p), ("radii", C.c_void_p)]
+
+
+class GsrGradInputs(C.Structure):
+    _fields_ = [("dL_dcolor", C.c_void_p), ("dL_dallmap", C.c_void_p)]
+
+
+class GsrGradOutputs(C.Structure):
+    _fields_ = [("dL_dmeans3D", C.c_void_p), ("dL_dmeans2D", C.c_void_p), ("dL_dshs", C.c_void_p),
+                ("dL_dcolors", C.c_void_p), ("dL_dopacities", C.c_void_p), ("dL_dscales", C.c_void_p),
+                ("dL_drotations", C.c_void_p), ("dL_dtransMat", C.c_void_p), ("scratch", C.c_void_p),
+                ("accumulate", C.c_int32), ("reserved", C.c_int32)]
+
+
+GSR_REC_FLOATS, GSR_GRAD_FLOATS = 24, 32
+
+# every symbol include/gdr.h and include/gsr.h declare, with its prototype
 _PROTOS = {
     "gdr_abi_version": (C.c_int, []),
     "gdr_last_error": (C.c_char_p, []),
@@ -107,6 +131,22 @@ _PROTOS = {
     "gdr_kernel_count": (C.c_int, []),
     "gdr_kernel_name": (C.c_char_p, [C.c_int32]),
     "gdr_mark_visible": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    # include/gsr.h — 2DGS surfel path
+    "gsr_geom_bytes": (C.c_size_t, [C.c_int32]),
+    "gsr_image_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
+    "gsr_geom_carve": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(GdrGeom)]),
+    "gsr_image_carve": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(GdrImage)]),
+    "gsr_preprocess_forward": (C.c_int, [C.POINTER(GdrSettings), C.POINTER(GsrInputs), C.POINTER(GdrGeom), C.c_void_p,
+                                         C.POINTER(C.c_uint32), C.c_void_p]),
+    "gsr_render_forward": (C.c_int, [C.POINTER(GdrSettings), C.POINTER(GsrInputs), C.POINTER(GdrGeom),
+                                     C.POINTER(GdrBinning), C.POINTER(GdrImage), C.c_uint64, C.POINTER(GsrOutputs),
+                                     C.c_void_p]),
+    "gsr_forward": (C.c_int, [C.POINTER(GdrSettings), C.POINTER(GsrInputs), C.POINTER(GdrGeom), C.POINTER(GdrBinning),
+                              C.POINTER(GdrImage), C.c_uint64, C.POINTER(GsrOutputs), C.POINTER(C.c_uint32),
+                              C.c_void_p]),
+    "gsr_backward": (C.c_int, [C.POINTER(GdrSettings), C.POINTER(GsrInputs), C.POINTER(GdrGeom), C.POINTER(GdrBinning),
+                               C.POINTER(GdrImage), C.c_uint64, C.c_void_p, C.POINTER(GsrGradInputs),
+                               C.POINTER(GsrGradOutputs), C.c_void_p]),
 }
 EXPORTED_SYMBOLS = tuple(_PROTOS)
 

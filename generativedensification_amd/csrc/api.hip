@@ -446,3 +446,179 @@ int gdr_mark_visible(int32_t N, const float* means3D, const float* viewmatrix,
 }
 
 }  // extern "C"
+
+// =================================================================================
+// 2DGS surfel path (include/gsr.h)
+// =================================================================================
+namespace gdr {
+static size_t carve_surfel_geom(void* base, int64_t N, gdr_geom* g) {
+    Carver c(base);
+    gdr_geom t;
+    const size_t n = (size_t)(N > 0 ? N : 1);
+    t.depths = c.take<float>(n);
+    t.rec = c.take<float>(GSR_REC_FLOATS * n);
+    t.cov3D = nullptr;
+    t.rect = c.take<int32_t>(4 * n);
+    t.tiles_touched = c.take<uint32_t>(n);
+    t.clamped = c.take<uint8_t>(n);
+    t.block_sums = c.take<uint32_t>((n + GDR_BLOCK - 1) / GDR_BLOCK + 1);
+    t.block_offs = c.take<uint32_t>((n + GDR_BLOCK - 1) / GDR_BLOCK + 1);
+    t.num_rendered = c.take<uint32_t>(1);
+    if (g) *g = t;
+    return c.off;
+}
+static size_t carve_surfel_image(void* base, int H, int W, gdr_image* im) {
+    Carver c(base);
+    gdr_image t;
+    const size_t tiles = (size_t)tile_grid_x(W) * tile_grid_y(H);
+    const size_t P = (size_t)H * W;
+    t.ranges = c.take<uint32_t>(2 * (tiles ? tiles : 1));
+    t.n_contrib = c.take<uint32_t>(2 * (P ? P : 1));
+    t.final_T = c.take<float>(3 * (P ? P : 1));
+    t.tile_order = c.take<uint32_t>(tiles ? tiles : 1);
+    if (im) *im = t;
+    return c.off;
+}
+static int check_surfel(const gdr_settings* s, const gsr_inputs* in) {
+    if (!s || !in) { set_error("NULL settings/inputs", hipSuccess); return GDR_ERR_INVALID_ARG; }
+    if (in->N < 0 || s->image_height <= 0 || s->image_width <= 0) { set_error("negative N or empty image", hipSuccess); return GDR_ERR_INVALID_ARG; }
+    if (!s->bg || !s->viewmatrix || !s->projmatrix) { set_error("bg/viewmatrix/projmatrix must be device pointers", hipSuccess); return GDR_ERR_INVALID_ARG; }
+    if (in->N > 0) {
+        if (!in->means3D || !in->opacities) { set_error("means3D/opacities NULL", hipSuccess); return GDR_ERR_INVALID_ARG; }
+        if ((in->shs != nullptr) == (in->colors_precomp != nullptr)) { set_error("provide exactly one of shs / colors_precomp", hipSuccess); return GDR_ERR_INVALID_ARG; }
+        const bool sr = in->scales && in->rotations;
+        if (sr == (in->transMat_precomp != nullptr) || ((in->scales != nullptr) != (in->rotations != nullptr))) {
+            set_error("provide exactly one of (scales, rotations) / transMat_precomp", hipSuccess);
+            return GDR_ERR_INVALID_ARG;
+        }
+        if (in->shs) {
+            if (s->sh_degree < 0 || s->sh_degree > 3) { set_error("sh_degree must be 0..3", hipSuccess); return GDR_ERR_UNSUPPORTED; }
+            if (in->M < (s->sh_degree + 1) * (s->sh_degree + 1)) { set_error("M < (sh_degree+1)^2", hipSuccess); return GDR_ERR_INVALID_ARG; }
+            if (!s->campos) { set_error("campos NULL", hipSuccess); return GDR_ERR_INVALID_ARG; }
+        }
+    }
+    return GDR_OK;
+}
+}  // namespace gdr
+
+extern "C" {
+
+size_t gsr_geom_bytes(int32_t N) { return carve_surfel_geom(nullptr, N, nullptr); }
+size_t gsr_image_bytes(int32_t H, int32_t W) { return carve_surfel_image(nullptr, H, W, nullptr); }
+int gsr_geom_carve(void* base, int32_t N, gdr_geom* out) {
+    if (!base || !out || ((uintptr_t)base & 255u)) { set_error("geom base NULL/unaligned", hipSuccess); return GDR_ERR_INVALID_ARG; }
+    carve_surfel_geom(base, N, out);
+    return GDR_OK;
+}
+int gsr_image_carve(void* base, int32_t H, int32_t W, gdr_image* out) {
+    if (!base || !out || ((uintptr_t)base & 255u)) { set_error("image base NULL/unaligned", hipSuccess); return GDR_ERR_INVALID_ARG; }
+    carve_surfel_image(base, H, W, out);
+    return GDR_OK;
+}
+
+int gsr_preprocess_forward(const gdr_settings* s, const gsr_inputs* in, const gdr_geom* geom, int32_t* radii,
+                           uint32_t* num_rendered_host, void* stream) {
+    int rc = check_surfel(s, in);
+    if (rc) return rc;
+    if (!geom || (in->N > 0 && !radii)) { set_error("geom/radii NULL", hipSuccess); return GDR_ERR_INVALID_ARG; }
+    const int tiles = tile_grid_x(s->image_width) * tile_grid_y(s->image_height);
+    if (key_bits(tiles) > 64) { set_error("image too large", hipSuccess); return GDR_ERR_UNSUPPORTED; }
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(geom->num_rendered, 0, sizeof(uint32_t), st);
+    if (e != hipSuccess) return hip_fail("memset num_rendered", e);
+    e = launch_surfel_preprocess_fwd(s, in, geom, radii, st);
+    if (e != hipSuccess) return hip_fail("surfel_preprocess_fwd", e);
+    if ((rc = debug_sync(s, "surfel_preprocess_fwd", st))) return rc;
+    if (num_rendered_host) {
+        e = hipMemcpyAsync(num_rendered_host, geom->num_rendered, sizeof(uint32_t), hipMemcpyDeviceToHost, st);
+        if (e != hipSuccess) return hip_fail("memcpy num_rendered", e);
+        e = hipStreamSynchronize(st);
+        if (e != hipSuccess) return hip_fail("sync num_rendered", e);
+    }
+    return GDR_OK;
+}
+
+int gsr_render_forward(const gdr_settings* s, const gsr_inputs* in, const gdr_geom* geom, gdr_binning* bin,
+                       const gdr_image* img, uint64_t D, const gsr_outputs* out, void* stream) {
+    int rc = check_surfel(s, in);
+    if (rc) return rc;
+    if (!geom || !bin || !img || !out || !out->color || !out->allmap || (in->N > 0 && !out->radii)) {
+        set_error("surfel render_forward: NULL argument", hipSuccess);
+        return GDR_ERR_INVALID_ARG;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int W = s->image_width, H = s->image_height;
+    const int tiles = tile_grid_x(W) * tile_grid_y(H);
+    hipError_t e;
+    if (bin->global_sort) {
+        e = launch_scan_block_sums(geom, in->N, st);
+        if (e != hipSuccess) return hip_fail("scan_block_sums", e);
+    }
+    e = launch_duplicate(geom, in->N, W, H, out->radii, bin->global_sort ? geom->block_sums : geom->block_offs,
+                         bin->keys[0], bin->values[0], D, st);
+    if (e != hipSuccess) return hip_fail("duplicate", e);
+    if ((rc = debug_sync(s, "duplicate", st))) return rc;
+    if (bin->global_sort) {
+        e = launch_sort(bin, D, key_bits(tiles), st);
+        if (e != hipSuccess) return hip_fail("sort", e);
+        e = launch_ranges(bin, D, img, tiles, st);
+        if (e != hipSuccess) return hip_fail("ranges", e);
+        e = launch_tile_order(img, tiles, st);
+        if (e != hipSuccess) return hip_fail("tile_order", e);
+    } else {
+        e = launch_sort_tile_bits(bin, D, key_bits(tiles), st);
+        if (e != hipSuccess) return hip_fail("sort_tile_bits", e);
+        e = launch_ranges(bin, D, img, tiles, st);
+        if (e != hipSuccess) return hip_fail("ranges", e);
+        e = launch_tile_order(img, tiles, st);
+        if (e != hipSuccess) return hip_fail("tile_order", e);
+        e = launch_tile_sort(bin, img, tiles, D, st);
+        if (e != hipSuccess) return hip_fail("tile_sort", e);
+    }
+    if ((rc = debug_sync(s, "binning", st))) return rc;
+    e = launch_surfel_render_fwd(s, geom, bin, img, out, st);
+    if (e != hipSuccess) return hip_fail("surfel_render_fwd", e);
+    return debug_sync(s, "surfel_render_fwd", st);
+}
+
+int gsr_forward(const gdr_settings* s, const gsr_inputs* in, const gdr_geom* geom, gdr_binning* bin,
+                const gdr_image* img, uint64_t D_cap, const gsr_outputs* out, uint32_t* num_rendered_host,
+                void* stream) {
+    if (!out || !num_rendered_host) { set_error("gsr_forward: NULL out/num_rendered_host", hipSuccess); return GDR_ERR_INVALID_ARG; }
+    int rc = gsr_preprocess_forward(s, in, geom, out->radii, num_rendered_host, stream);
+    if (rc) return rc;
+    if ((uint64_t)*num_rendered_host > D_cap) { set_error("binning workspace too small for num_rendered", hipSuccess); return GDR_ERR_WORKSPACE; }
+    return gsr_render_forward(s, in, geom, bin, img, *num_rendered_host, out, stream);
+}
+
+int gsr_backward(const gdr_settings* s, const gsr_inputs* in, const gdr_geom* geom, const gdr_binning* bin,
+                 const gdr_image* img, uint64_t D, const int32_t* radii, const gsr_grad_inputs* gin,
+                 const gsr_grad_outputs* gout, void* stream) {
+    (void)D;
+    int rc = check_surfel(s, in);
+    if (rc) return rc;
+    if (!geom || !bin || !img || !gin || !gout || !gin->dL_dcolor || !gout->dL_dmeans3D || !gout->dL_dmeans2D ||
+        !gout->dL_dopacities || !gout->scratch || (in->N > 0 && !radii)) {
+        set_error("surfel backward: NULL argument", hipSuccess);
+        return GDR_ERR_INVALID_ARG;
+    }
+    if (in->shs && !gout->dL_dshs) { set_error("surfel backward: dL_dshs NULL", hipSuccess); return GDR_ERR_INVALID_ARG; }
+    if (in->colors_precomp && !gout->dL_dcolors) { set_error("surfel backward: dL_dcolors NULL", hipSuccess); return GDR_ERR_INVALID_ARG; }
+    if (in->transMat_precomp ? !gout->dL_dtransMat : (!gout->dL_dscales || !gout->dL_drotations)) {
+        set_error("surfel backward: scale/rotation/transMat gradient buffers NULL", hipSuccess);
+        return GDR_ERR_INVALID_ARG;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const size_t N = (size_t)in->N;
+    if (N == 0) return GDR_OK;
+    hipError_t e = hipMemsetAsync(gout->scratch, 0, N * GSR_GRAD_FLOATS * sizeof(float), st);
+    if (e != hipSuccess) return hip_fail("memset gradient records", e);
+    e = launch_surfel_render_bwd(s, geom, bin, img, gin, gout->scratch, st);
+    if (e != hipSuccess) return hip_fail("surfel_render_bwd", e);
+    if ((rc = debug_sync(s, "surfel_render_bwd", st))) return rc;
+    e = launch_surfel_preprocess_bwd(s, in, geom, radii, gout, st);
+    if (e != hipSuccess) return hip_fail("surfel_preprocess_bwd", e);
+    return debug_sync(s, "surfel_preprocess_bwd", st);
+}
+
+}  // extern "C"

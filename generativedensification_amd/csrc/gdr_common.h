@@ -5,6 +5,7 @@
 #include <stdint.h>
 
 #include "../../include/gdr.h"
+#include "../../include/gsr.h"
 
 #define GDR_WAVE 64
 #define GDR_BLOCK 256          // threads per workgroup (4 waves) everywhere
@@ -99,6 +100,17 @@ hipError_t launch_view_loss_fwd(const float* color, const float* depth, const fl
                                 int P, float w_depth, float w_alpha, float* loss, hipStream_t st);
 hipError_t launch_view_loss_bwd(const float* color, const float* target, int P, float w_depth, float w_alpha,
                                 const float* g, float* d_color, float* d_depth, float* d_alpha, hipStream_t st);
+
+// 2DGS surfel path (preprocess_surfel.hip, render_surfel.hip)
+hipError_t launch_surfel_preprocess_fwd(const gdr_settings* s, const gsr_inputs* in, const gdr_geom* g,
+                                        int32_t* radii, hipStream_t st);
+hipError_t launch_surfel_preprocess_bwd(const gdr_settings* s, const gsr_inputs* in, const gdr_geom* g,
+                                        const int32_t* radii, const gsr_grad_outputs* go, hipStream_t st);
+hipError_t launch_surfel_render_fwd(const gdr_settings* s, const gdr_geom* g, const gdr_binning* bin,
+                                    const gdr_image* img, const gsr_outputs* out, hipStream_t st);
+hipError_t launch_surfel_render_bwd(const gdr_settings* s, const gdr_geom* g, const gdr_binning* bin,
+                                    const gdr_image* img, const gsr_grad_inputs* gi, float* grad_rec,
+                                    hipStream_t st);
 
 size_t sort_hist_bytes(uint64_t D);
 

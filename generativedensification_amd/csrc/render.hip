@@ -34,24 +34,11 @@
 #include <stdlib.h>
 
 #include "gdr_common.h"
+#include "render_common.h"
 
 namespace gdr {
 
 namespace {
-
-#define GDR_LOG2E 1.4426950408889634f
-#define GDR_LN2 0.6931471805599453f
-#define GDR_ALPHA_MIN (1.f / 255.f)
-#define GDR_NULL_ENTRY GDR_BLOCK  // LDS slot 256: xy = 0, conic = 0, opacity = 0, colour = 0
-
-__device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
-
-// XCD-aware bijective remap of a linear workgroup id (8 XCDs, round-robin dispatch).
-__device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t n) {
-    const uint32_t xcd = b & 7u, q = n >> 3, r = n & 7u;
-    const uint32_t base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    return base + (b >> 3);
-}
 
 // exponent (in log2 units: the conic carries the log2(e) factor) shared by forward and
 // backward: explicit operation order and explicit fused multiply-adds.
@@ -61,53 +48,6 @@ __device__ __forceinline__ float gauss_power(float dx, float dy, float cx, float
     return fmaf(-0.5f, s, -(cy * (dx * dy)));
 }
 
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_get(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
-}
-
-// Row-local reduce-scatter of 12 per-lane values over the 16 lanes of a DPP row: lane i of the
-// row returns the row total of value i (i < 12; lanes 12..15 return 0).  Four halving
-// exchanges (row_mirror, row_half_mirror, quad reverse, quad xor-1): 45 VALU ops instead of
-// 12 x 4 full reductions, and the totals land one per lane, so ONE atomic instruction
-// publishes all of them.
-__device__ __forceinline__ float row_reduce_scatter12(const float (&v)[12], uint32_t li) {
-    const bool b3 = li & 8u, b2 = li & 4u, b1 = li & 2u, b0 = li & 1u;
-    float u[8], t[4], s2[2];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const float hi = (j + 8 < 12) ? v[j + 8] : 0.f;
-        const float keep = b3 ? hi : v[j], send = b3 ? v[j] : hi;
-        u[j] = keep + dpp_get<0x140, 0xf>(send);  // row_mirror: partner 15 - i
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const float keep = b2 ? u[j + 4] : u[j], send = b2 ? u[j] : u[j + 4];
-        t[j] = keep + dpp_get<0x141, 0xf>(send);  // row_half_mirror: partner i ^ 7
-    }
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const float keep = b1 ? t[j + 2] : t[j], send = b1 ? t[j] : t[j + 2];
-        s2[j] = keep + dpp_get<0x1B, 0xf>(send);  // quad_perm [3,2,1,0]: partner i ^ 3
-    }
-    const float keep = b0 ? s2[1] : s2[0], send = b0 ? s2[0] : s2[1];
-    return keep + dpp_get<0xB1, 0xf>(send);       // quad_perm [1,0,3,2]: partner i ^ 1
-}
-
-// 4 values over the 16 lanes of a row: lane i returns the row total of value (i >> 2) & 3
-// (two halving exchanges, then two plain butterfly adds inside the quads)
-__device__ __forceinline__ float row_reduce_scatter4(float v0, float v1, float v2, float v3, uint32_t li) {
-    const bool b3 = li & 8u, b2 = li & 4u;
-    const float k0 = b3 ? v2 : v0, s0 = b3 ? v0 : v2, k1 = b3 ? v3 : v1, s1 = b3 ? v1 : v3;
-    const float u0 = k0 + dpp_get<0x140, 0xf>(s0), u1 = k1 + dpp_get<0x140, 0xf>(s1);  // row_mirror
-    const float k = b2 ? u1 : u0, sd = b2 ? u0 : u1;
-    float t = k + dpp_get<0x141, 0xf>(sd);  // row_half_mirror
-    t += dpp_get<0x1B, 0xf>(t);             // quad reverse
-    t += dpp_get<0xB1, 0xf>(t);             // quad xor-1  -> all 4 lanes of the quad hold the total
-    return t;
-}
-
-#define GDR_ROW_MASK(k) (0xFFFFull << (16 * (k)))
 
 struct Entry {  // one staged list entry, in registers
     uint32_t e;
@@ -150,18 +90,6 @@ __device__ __forceinline__ void block_masks(const SliceLds& s, int g, float XA, 
     m1 = __ballot(x1 && y0 && a1);
     m2 = __ballot(x0 && y1 && a2);
     m3 = __ballot(x1 && y1 && a3);
-}
-
-// Per-LANE mask walk: every lane carries its row's 64-bit sub-list mask in two VGPRs and takes
-// the first set bit (0xFFFFFFFF if none) with VALU ops (v_ffbl_b32 x2).  The scalar unit is
-// shared by the CU's four SIMDs; walking four SGPR masks cost ~25 SALU per iteration.
-__device__ __forceinline__ uint32_t take_bit(uint64_t& m) {
-    const uint32_t b = (uint32_t)(__builtin_ffsll((long long)m) - 1);
-    m &= m - 1ull;
-    return b;
-}
-__device__ __forceinline__ uint64_t row_select(uint32_t row, uint64_t m0, uint64_t m1, uint64_t m2, uint64_t m3) {
-    return row == 0 ? m0 : (row == 1 ? m1 : (row == 2 ? m2 : m3));
 }
 
 // ---------------------------------------------------------------------------------

@@ -1,0 +1,396 @@
+// render_surfel.hip — K6s (per-tile alpha-composited forward) and K7s (per-pixel reverse-order backward) of the
+// 2D-Gaussian (surfel) rasterizer for gfx950 (include/gsr.h): what the reference obtains from
+// `diff_surfel_rasterization` at /root/reference/lightning/renderer_2dgs.py:224-234 (image + the 7-channel allmap
+// sliced at :241-257); arithmetic as restated in oracle/gsr_oracle.c.
+//
+// Same CDNA4 mapping as render.hip (measured there): workgroup = 16x16 tile, wave = 8x8 sub-tile,
+// each 16-lane DPP row composites its OWN 4x4 pixel block against its OWN sub-list — every lane tests one staged
+// surfel's conservative {alpha >= 1/255} box (written by K1s) against the wave's four blocks and four ballots give
+// the per-block masks; idle rows read a null LDS entry (T = 0 -> no intersection); predication by float
+// thresholds; the tile's sorted slice is staged 256 entries at a time while the next one is in flight.
+// Per pixel and surfel: ray-splat intersection (u,v) = cross(x Tw - Tu, y Tw - Tv) dehomogenised (v_rcp_f32),
+// G = v_exp_f32(-0.5 log2e min(u^2+v^2, 2|pix - centre|^2)).  Backward: all "behind" recurrences (colour, depth,
+// coverage, normal and the distortion weight) share the select-free form B <- B + a (c - B); the 20 per-surfel
+// partials are reduce-scattered inside each row (16 + 4 values) and published with two atomic instructions into a
+// 128-byte gradient record.
+#include "gdr_common.h"
+#include "render_common.h"
+#include "../../include/gsr.h"
+
+namespace gdr {
+
+namespace {
+
+#define GSR_NEAR 0.2f
+#define GSR_FAR 100.0f
+#define GSR_FARK (GSR_FAR / (GSR_FAR - GSR_NEAR))
+
+struct SEntry {  // one staged list entry, in registers
+    uint32_t e;
+    float4 tu, tv, tw, nr;  // (Tu, cx) (Tv, cy) (Tw, opacity) (normal, r)
+    float2 gb;
+};
+
+struct SurfelLds {
+    float4 tu[GDR_BLOCK + 1], tv[GDR_BLOCK + 1], tw[GDR_BLOCK + 1], nr[GDR_BLOCK + 1];
+    float2 gb[GDR_BLOCK + 1];
+    float4 box[GDR_BLOCK];  // lo.x, lo.y, hi.x, hi.y
+};
+
+// the 96-byte render record of one surfel is prefetched into six float4 registers (q0..q5) and staged from there
+#define GSR_LOAD_REC(ID)                                                                   \
+    do {                                                                                   \
+        const float4* p_ = rec + 6 * (size_t)(ID);                                         \
+        q0 = p_[0]; q1 = p_[1]; q2 = p_[2]; q3 = p_[3]; q4 = p_[4]; q5 = p_[5];            \
+    } while (0)
+#define GSR_STAGE(VALID)                                                                   \
+    do {                                                                                   \
+        if (VALID) {                                                                       \
+            lds.tu[threadIdx.x] = q0; lds.tv[threadIdx.x] = q1; lds.tw[threadIdx.x] = q2;  \
+            lds.nr[threadIdx.x] = q3; lds.gb[threadIdx.x] = make_float2(q4.x, q4.y);       \
+            lds.box[threadIdx.x] = make_float4(q4.z, q4.w, q5.x, q5.y);                    \
+        } else { /* culled for every block */                                              \
+            lds.box[threadIdx.x] = make_float4(INFINITY, INFINITY, -INFINITY, -INFINITY);  \
+        }                                                                                  \
+    } while (0)
+
+__device__ __forceinline__ void null_entry(SurfelLds& s) {
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    s.tu[GDR_NULL_ENTRY] = z; s.tv[GDR_NULL_ENTRY] = z; s.tw[GDR_NULL_ENTRY] = z; s.nr[GDR_NULL_ENTRY] = z;
+    s.gb[GDR_NULL_ENTRY] = make_float2(0.f, 0.f);
+}
+
+__device__ __forceinline__ void block_masks(const SurfelLds& s, int g, float XA, float YA, bool a0, bool a1, bool a2,
+                                            bool a3, uint64_t& m0, uint64_t& m1, uint64_t& m2, uint64_t& m3) {
+    const float4 b = s.box[g * GDR_WAVE + (int)lane_id()];
+    const bool x0 = b.z >= XA && b.x <= XA + 3.f, x1 = b.z >= XA + 4.f && b.x <= XA + 7.f;
+    const bool y0 = b.w >= YA && b.y <= YA + 3.f, y1 = b.w >= YA + 4.f && b.y <= YA + 7.f;
+    m0 = __ballot(x0 && y0 && a0);
+    m1 = __ballot(x1 && y0 && a1);
+    m2 = __ballot(x0 && y1 && a2);
+    m3 = __ballot(x1 && y1 && a3);
+}
+
+// ray-splat intersection and Gaussian weight of one pixel against one staged surfel
+struct Hit {
+    float kx, ky, kz, lx, ly, lz, rz, sx, sy, dx, dy, depth, G, alpha;
+    bool use3d, geom_ok;
+};
+
+__device__ __forceinline__ void intersect(const SEntry& en, float pxf, float pyf, Hit& h) {
+    h.kx = fmaf(pxf, en.tw.x, -en.tu.x); h.ky = fmaf(pxf, en.tw.y, -en.tu.y); h.kz = fmaf(pxf, en.tw.z, -en.tu.z);
+    h.lx = fmaf(pyf, en.tw.x, -en.tv.x); h.ly = fmaf(pyf, en.tw.y, -en.tv.y); h.lz = fmaf(pyf, en.tw.z, -en.tv.z);
+    const float cx = h.ky * h.lz - h.kz * h.ly, cy = h.kz * h.lx - h.kx * h.lz, cz = h.kx * h.ly - h.ky * h.lx;
+    h.rz = __builtin_amdgcn_rcpf(cz);
+    h.sx = cx * h.rz; h.sy = cy * h.rz;
+    const float rho3d = fmaf(h.sx, h.sx, h.sy * h.sy);
+    h.dx = en.tu.w - pxf; h.dy = en.tv.w - pyf;
+    const float rho2d = 2.f * fmaf(h.dx, h.dx, h.dy * h.dy);
+    h.use3d = rho3d <= rho2d;
+    const float rho = h.use3d ? rho3d : rho2d;
+    h.depth = h.use3d ? fmaf(h.sx, en.tw.x, fmaf(h.sy, en.tw.y, en.tw.z)) : en.tw.z;
+    h.G = __builtin_amdgcn_exp2f((-0.5f * GDR_LOG2E) * rho);
+    h.alpha = fminf(0.99f, en.tw.w * h.G);
+    h.geom_ok = cz != 0.f && h.depth >= GSR_NEAR;  // false for the null entry (cz = 0) and for NaNs
+}
+
+// ---------------------------------------------------------------------------------
+// K6s
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(GDR_BLOCK) void surfel_render_fwd_kernel(
+    const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, const uint32_t* __restrict__ tile_order,
+    int W, int H, int gx, int ntiles, const float4* __restrict__ rec, const float* __restrict__ bg,
+    float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float* __restrict__ out_color,
+    float* __restrict__ out_others) {
+    __shared__ SurfelLds lds;
+    __shared__ int s_done[GDR_BLOCK / GDR_WAVE];
+
+    const uint32_t tile = tile_order ? tile_order[blockIdx.x] : xcd_remap(blockIdx.x, (uint32_t)ntiles);
+    const int tx = (int)(tile % (uint32_t)gx), ty = (int)(tile / (uint32_t)gx);
+    const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
+    const uint32_t row = lane >> 4, li = lane & 15u;
+    const int sx0 = tx * GDR_TILE + (int)(wave & 1u) * 8, sy0 = ty * GDR_TILE + (int)(wave >> 1) * 8;
+    const int px = sx0 + (int)(row & 1u) * 4 + (int)(li & 3u), py = sy0 + (int)(row >> 1) * 4 + (int)(li >> 2);
+    const bool inside = px < W && py < H;
+    const float pxf = (float)px, pyf = (float)py;
+    const float XA = (float)sx0, YA = (float)sy0;
+    const uint2 range = ranges[tile];
+    const int total = (int)(range.y - range.x);
+    const int rounds = (total + GDR_BLOCK - 1) / GDR_BLOCK;
+
+    if (threadIdx.x == 0) null_entry(lds);
+    float thr = inside ? GDR_ALPHA_MIN : INFINITY;
+    float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f, N0 = 0.f, N1 = 0.f, N2 = 0.f;
+    float Dp = 0.f, M1 = 0.f, M2 = 0.f, dist = 0.f, med = 0.f;
+    uint32_t last_contributor = 0, med_contributor = 0;
+
+    float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0, q2 = q0, q3 = q0, q4 = q0, q5 = q0;
+    bool r_valid = (int)threadIdx.x < total;
+    if (r_valid) GSR_LOAD_REC(point_list[range.x + threadIdx.x]);
+    for (int r = 0; r < rounds; ++r) {
+        uint64_t live = __ballot(thr < INFINITY);
+        if (lane == 0) s_done[wave] = live == 0ull ? 1 : 0;
+        __syncthreads();
+        if (s_done[0] + s_done[1] + s_done[2] + s_done[3] == GDR_BLOCK / GDR_WAVE) break;
+        GSR_STAGE(r_valid);
+        __syncthreads();
+        {
+            const int nxt = (r + 1) * GDR_BLOCK + (int)threadIdx.x;
+            r_valid = nxt < total;
+            if (r_valid) GSR_LOAD_REC(point_list[range.x + nxt]);
+        }
+        if (live == 0ull) continue;
+        const uint32_t base = (uint32_t)(r * GDR_BLOCK) + 1u;
+#pragma unroll 1
+        for (int g = 0; g < GDR_BLOCK / GDR_WAVE; ++g) {
+            uint64_t m0, m1, m2, m3;
+            block_masks(lds, g, XA, YA, (live & GDR_ROW_MASK(0)) != 0ull, (live & GDR_ROW_MASK(1)) != 0ull,
+                        (live & GDR_ROW_MASK(2)) != 0ull, (live & GDR_ROW_MASK(3)) != 0ull, m0, m1, m2, m3);
+            if ((m0 | m1 | m2 | m3) == 0ull) continue;
+            const uint32_t goff = (uint32_t)(g * GDR_WAVE), nulloff = GDR_NULL_ENTRY - goff;
+            uint64_t mr = row_select(row, m0, m1, m2, m3);
+            bool abort = false;
+            auto fetch = [&](SEntry& en) {
+                en.e = min(take_bit(mr), nulloff) + goff;
+                en.tu = lds.tu[en.e]; en.tv = lds.tv[en.e]; en.tw = lds.tw[en.e]; en.nr = lds.nr[en.e]; en.gb = lds.gb[en.e];
+            };
+            auto composite = [&](const SEntry& en) {
+                Hit h;
+                intersect(en, pxf, pyf, h);
+                const bool ok = h.geom_ok && h.alpha >= thr;
+                const float a_c = ok ? h.alpha : 0.f;
+                const float depth = ok ? h.depth : 1.f;
+                const float T_new = fmaf(-a_c, T, T);
+                const bool stop = T_new < 0.0001f;
+                const float w = stop ? 0.f : a_c * T;
+                const float A = 1.f - T;
+                const float m = GSR_FARK * (1.f - GSR_NEAR * __builtin_amdgcn_rcpf(depth));
+                const float mm = m * m;
+                dist = fmaf(fmaf(mm, A, M2) - 2.f * m * M1, w, dist);
+                Dp = fmaf(depth, w, Dp);
+                M1 = fmaf(m, w, M1);
+                M2 = fmaf(mm, w, M2);
+                const bool contributes = w > 0.f;
+                const bool is_med = contributes && T > 0.5f;
+                med = is_med ? depth : med;
+                med_contributor = is_med ? base + en.e : med_contributor;
+                N0 = fmaf(en.nr.x, w, N0); N1 = fmaf(en.nr.y, w, N1); N2 = fmaf(en.nr.z, w, N2);
+                C0 = fmaf(en.nr.w, w, C0); C1 = fmaf(en.gb.x, w, C1); C2 = fmaf(en.gb.y, w, C2);
+                T = stop ? T : T_new;
+                thr = stop ? INFINITY : thr;
+                last_contributor = contributes ? base + en.e : last_contributor;
+                if (__ballot(stop) != 0ull) {
+                    live = __ballot(thr < INFINITY);
+                    if (((live >> (16 * row)) & 0xFFFFull) == 0ull) mr = 0ull;
+                    if (live == 0ull) abort = true;
+                }
+            };
+            SEntry A, B;
+            fetch(A);
+            for (;;) {
+                const bool moreA = __ballot(mr != 0ull) != 0ull;
+                fetch(B);
+                composite(A);
+                if (!moreA || abort) break;
+                const bool moreB = __ballot(mr != 0ull) != 0ull;
+                fetch(A);
+                composite(B);
+                if (!moreB || abort) break;
+            }
+            if (abort) g = GDR_BLOCK / GDR_WAVE;
+        }
+    }
+    if (inside) {
+        const size_t pix = (size_t)py * W + px, P = (size_t)H * W;
+        final_T[pix] = T; final_T[P + pix] = M1; final_T[2 * P + pix] = M2;
+        n_contrib[pix] = last_contributor; n_contrib[P + pix] = med_contributor;
+        out_color[pix] = fmaf(T, bg[0], C0);
+        out_color[P + pix] = fmaf(T, bg[1], C1);
+        out_color[2 * P + pix] = fmaf(T, bg[2], C2);
+        out_others[pix] = Dp;
+        out_others[P + pix] = 1.f - T;
+        out_others[2 * P + pix] = N0; out_others[3 * P + pix] = N1; out_others[4 * P + pix] = N2;
+        out_others[5 * P + pix] = med;
+        out_others[6 * P + pix] = dist;
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// K7s.  grad_rec: (N,32) floats, pre-zeroed by the launcher; layout in include/gsr.h.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(GDR_BLOCK) void surfel_render_bwd_kernel(
+    const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, const uint32_t* __restrict__ tile_order,
+    int W, int H, int gx, int ntiles, const float* __restrict__ bg, const float4* __restrict__ rec,
+    const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
+    const float* __restrict__ dL_dothers, float* __restrict__ grad_rec) {
+    __shared__ SurfelLds lds;
+    __shared__ uint32_t s_id[GDR_BLOCK + 1];
+
+    const uint32_t tile = tile_order ? tile_order[blockIdx.x] : xcd_remap(blockIdx.x, (uint32_t)ntiles);
+    const int tx = (int)(tile % (uint32_t)gx), ty = (int)(tile / (uint32_t)gx);
+    const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
+    const uint32_t row = lane >> 4, li = lane & 15u;
+    const int sx0 = tx * GDR_TILE + (int)(wave & 1u) * 8, sy0 = ty * GDR_TILE + (int)(wave >> 1) * 8;
+    const int px = sx0 + (int)(row & 1u) * 4 + (int)(li & 3u), py = sy0 + (int)(row >> 1) * 4 + (int)(li >> 2);
+    const bool inside = px < W && py < H;
+    const float pxf = (float)px, pyf = (float)py;
+    const float XA = (float)sx0, YA = (float)sy0;
+    const size_t pix = (size_t)py * W + px, P = (size_t)H * W;
+    const uint2 range = ranges[tile];
+    const int total = (int)(range.y - range.x);
+    const int rounds = (total + GDR_BLOCK - 1) / GDR_BLOCK;
+
+    if (threadIdx.x == 0) { null_entry(lds); s_id[GDR_NULL_ENTRY] = 0; }
+    const float T_final = inside ? final_T[pix] : 0.f;
+    const float final_D = inside ? final_T[P + pix] : 0.f, final_D2 = inside ? final_T[2 * P + pix] : 0.f;
+    const float final_A = 1.f - T_final;
+    float T = T_final;
+    const int last_contributor = inside ? (int)n_contrib[pix] : 0;
+    const int med_contributor = inside ? (int)n_contrib[P + pix] : 0;
+    float gC0 = 0.f, gC1 = 0.f, gC2 = 0.f, gDepth = 0.f, gAlpha = 0.f, gN0 = 0.f, gN1 = 0.f, gN2 = 0.f, gMed = 0.f, gReg = 0.f;
+    if (inside) {
+        gC0 = dL_dpix[pix]; gC1 = dL_dpix[P + pix]; gC2 = dL_dpix[2 * P + pix];
+        if (dL_dothers) {
+            gDepth = dL_dothers[pix]; gAlpha = dL_dothers[P + pix];
+            gN0 = dL_dothers[2 * P + pix]; gN1 = dL_dothers[3 * P + pix]; gN2 = dL_dothers[4 * P + pix];
+            gMed = dL_dothers[5 * P + pix]; gReg = dL_dothers[6 * P + pix];
+        }
+    }
+    const float bgT = -T_final * ((bg[0] * gC0 + bg[1] * gC1) + bg[2] * gC2);
+    float B0 = 0.f, B1 = 0.f, B2 = 0.f, BD = 0.f, BA = 0.f, BN0 = 0.f, BN1 = 0.f, BN2 = 0.f, BW = 0.f;
+
+    int row_last = last_contributor;
+    row_last = max(row_last, __shfl_xor(row_last, 1, 64));
+    row_last = max(row_last, __shfl_xor(row_last, 2, 64));
+    row_last = max(row_last, __shfl_xor(row_last, 4, 64));
+    row_last = max(row_last, __shfl_xor(row_last, 8, 64));
+    const int rl0 = __builtin_amdgcn_readlane(row_last, 0), rl1 = __builtin_amdgcn_readlane(row_last, 16);
+    const int rl2 = __builtin_amdgcn_readlane(row_last, 32), rl3 = __builtin_amdgcn_readlane(row_last, 48);
+    const int wave_last = max(max(rl0, rl1), max(rl2, rl3));
+
+    float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0, q2 = q0, q3 = q0, q4 = q0, q5 = q0;
+    uint32_t r_id = 0;
+    bool r_valid = (int)threadIdx.x < total;
+    if (r_valid) { r_id = point_list[range.y - 1 - threadIdx.x]; GSR_LOAD_REC(r_id); }
+    for (int r = 0; r < rounds; ++r) {
+        __syncthreads();
+        GSR_STAGE(r_valid);
+        if (r_valid) s_id[threadIdx.x] = r_id;
+        __syncthreads();
+        {
+            const int nxt = (r + 1) * GDR_BLOCK + (int)threadIdx.x;
+            r_valid = nxt < total;
+            if (r_valid) { r_id = point_list[range.y - 1 - nxt]; GSR_LOAD_REC(r_id); }
+        }
+        const int top = total - 1 - r * GDR_BLOCK;  // list position of LDS entry e: top - e
+        if (top - (GDR_BLOCK - 1) >= wave_last) continue;
+#pragma unroll 1
+        for (int g = 0; g < GDR_BLOCK / GDR_WAVE; ++g) {
+            const int gtop = top - g * GDR_WAVE;
+            if (gtop - (GDR_WAVE - 1) >= wave_last) continue;
+            uint64_t m0, m1, m2, m3;
+            const int mypos = gtop - (int)lane;
+            block_masks(lds, g, XA, YA, mypos < rl0, mypos < rl1, mypos < rl2, mypos < rl3, m0, m1, m2, m3);
+            if ((m0 | m1 | m2 | m3) == 0ull) continue;
+            const uint32_t goff = (uint32_t)(g * GDR_WAVE), nulloff = GDR_NULL_ENTRY - goff;
+            uint64_t mr = row_select(row, m0, m1, m2, m3);
+            auto fetch = [&](SEntry& en) {
+                en.e = min(take_bit(mr), nulloff) + goff;
+                en.tu = lds.tu[en.e]; en.tv = lds.tv[en.e]; en.tw = lds.tw[en.e]; en.nr = lds.nr[en.e]; en.gb = lds.gb[en.e];
+            };
+            auto accumulate = [&](const SEntry& en) {
+                Hit h;
+                intersect(en, pxf, pyf, h);
+                const int pos = top - (int)en.e;  // 0-based position in the tile list
+                const float lim = (pos < last_contributor) ? GDR_ALPHA_MIN : INFINITY;
+                const bool hit = h.geom_ok && h.alpha >= lim;
+                const uint64_t hb = __ballot(hit);
+                if (hb == 0ull) return;
+                const float a = hit ? h.alpha : 0.f, hm = hit ? 1.f : 0.f;
+                const float G = hit ? h.G : 0.f, depth = hit ? h.depth : 1.f, rz = hit ? h.rz : 0.f;
+                const bool u3 = hit && h.use3d;
+                const float sx = u3 ? h.sx : 0.f, sy = u3 ? h.sy : 0.f;
+                const float r_oma = __builtin_amdgcn_rcpf(1.f - a);
+                T = T * r_oma;
+                const float w = a * T;
+                const float rd = __builtin_amdgcn_rcpf(depth);
+                const float m_d = GSR_FARK * (1.f - GSR_NEAR * rd);
+                const float dmd_dd = (GSR_FARK * GSR_NEAR) * rd * rd;
+                const float dLw = (fmaf(m_d * m_d, final_A, final_D2) - 2.f * m_d * final_D) * gReg;
+                const float d0 = en.nr.w - B0, d1 = en.gb.x - B1, d2 = en.gb.y - B2;
+                const float dD = depth - BD, dA = 1.f - BA;
+                const float dn0 = en.nr.x - BN0, dn1 = en.nr.y - BN1, dn2 = en.nr.z - BN2;
+                const float dW = dLw - BW;
+                float dL_dalpha = fmaf(d0, gC0, fmaf(d1, gC1, fmaf(d2, gC2, fmaf(dD, gDepth, dA * gAlpha))));
+                dL_dalpha += fmaf(dn0, gN0, fmaf(dn1, gN1, fmaf(dn2, gN2, dW)));
+                B0 = fmaf(a, d0, B0); B1 = fmaf(a, d1, B1); B2 = fmaf(a, d2, B2);
+                BD = fmaf(a, dD, BD); BA = fmaf(a, dA, BA);
+                BN0 = fmaf(a, dn0, BN0); BN1 = fmaf(a, dn1, BN1); BN2 = fmaf(a, dn2, BN2);
+                BW = fmaf(a, dW, BW);
+                dL_dalpha = fmaf(dL_dalpha, T, bgT * r_oma) * hm;
+                float dL_dz = fmaf(2.f * w * (m_d * final_A - final_D) * gReg, dmd_dd, w * gDepth);
+                dL_dz += (hit && pos + 1 == med_contributor) ? gMed : 0.f;
+                const float dL_dG = en.tw.w * dL_dalpha;
+                const float mG = -G * dL_dG;
+                // object-space branch (zero when the screen-space low-pass was taken)
+                const float dsx = u3 ? fmaf(mG, sx, dL_dz * en.tw.x) : 0.f;
+                const float dsy = u3 ? fmaf(mG, sy, dL_dz * en.tw.y) : 0.f;
+                const float px_ = dsx * rz, py_ = dsy * rz, pz_ = -(px_ * sx + py_ * sy);
+                const float dkx = h.ly * pz_ - h.lz * py_, dky = h.lz * px_ - h.lx * pz_, dkz = h.lx * py_ - h.ly * px_;
+                const float dlx = py_ * h.kz - pz_ * h.ky, dly = pz_ * h.kx - px_ * h.kz, dlz = px_ * h.ky - py_ * h.kx;
+                const bool lp = hit && !h.use3d;
+                const float lowx = lp ? mG * 2.f * h.dx : 0.f, lowy = lp ? mG * 2.f * h.dy : 0.f;
+                const float vals[16] = {-dkx, -dky, -dkz, -dlx, -dly, -dlz,
+                                        fmaf(pxf, dkx, fmaf(pyf, dlx, dL_dz * sx)), fmaf(pxf, dky, fmaf(pyf, dly, dL_dz * sy)),
+                                        fmaf(pxf, dkz, fmaf(pyf, dlz, dL_dz)),
+                                        G * dL_dalpha, w * gC0, w * gC1, w * gC2, w * gN0, w * gN1, w * gN2};
+                const float tot = row_reduce_scatter16(vals, li);
+                const float tot4 = row_reduce_scatter4(lowx, lowy, fabsf(dkz), fabsf(dlz), li);
+                if (((hb >> (16 * row)) & 0xFFFFull) != 0ull) {
+                    float* g = grad_rec + GSR_GRAD_FLOATS * (size_t)s_id[en.e];
+                    atomicAdd(g + li, tot);
+                    if ((li & 3u) == 0u) atomicAdd(g + 16 + (li >> 2), tot4);
+                }
+            };
+            SEntry A, B;
+            fetch(A);
+            for (;;) {
+                const bool moreA = __ballot(mr != 0ull) != 0ull;
+                fetch(B);
+                accumulate(A);
+                if (!moreA) break;
+                const bool moreB = __ballot(mr != 0ull) != 0ull;
+                fetch(A);
+                accumulate(B);
+                if (!moreB) break;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+hipError_t launch_surfel_render_fwd(const gdr_settings* s, const gdr_geom* g, const gdr_binning* bin,
+                                    const gdr_image* img, const gsr_outputs* out, hipStream_t st) {
+    const int W = s->image_width, H = s->image_height;
+    const int gx = tile_grid_x(W), gy = tile_grid_y(H);
+    const int ntiles = gx * gy;
+    GDR_LAUNCH(GDR_K_RENDER_FWD, surfel_render_fwd_kernel, dim3(ntiles), dim3(GDR_BLOCK), st, (const uint2*)img->ranges,
+               bin->values[bin->sorted], img->tile_order, W, H, gx, ntiles, (const float4*)g->rec, s->bg, img->final_T,
+               img->n_contrib, out->color, out->allmap);
+    return hipGetLastError();
+}
+
+hipError_t launch_surfel_render_bwd(const gdr_settings* s, const gdr_geom* g, const gdr_binning* bin,
+                                    const gdr_image* img, const gsr_grad_inputs* gi, float* grad_rec,
+                                    hipStream_t st) {
+    const int W = s->image_width, H = s->image_height;
+    const int gx = tile_grid_x(W), gy = tile_grid_y(H);
+    const int ntiles = gx * gy;
+    GDR_LAUNCH(GDR_K_RENDER_BWD, surfel_render_bwd_kernel, dim3(ntiles), dim3(GDR_BLOCK), st, (const uint2*)img->ranges,
+               bin->values[bin->sorted], img->tile_order, W, H, gx, ntiles, s->bg, (const float4*)g->rec, img->final_T,
+               img->n_contrib, gi->dL_dcolor, gi->dL_dallmap, grad_rec);
+    return hipGetLastError();
+}
+
+}  // namespace gdr

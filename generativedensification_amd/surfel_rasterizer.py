@@ -1,0 +1,200 @@
+"""Python boundary of the MI355X 2D-Gaussian (surfel) rasterizer — same surface as the `diff_surfel_rasterization`
+package the reference's 2DGS adaptor imports (/root/reference/lightning/renderer_2dgs.py:7-10):
+
+    GaussianRasterizationSettings   the same 12-field NamedTuple as the 3DGS path (renderer_2dgs.py:111-124)
+    GaussianRasterizer(nn.Module)   forward(means3D, means2D, opacities, shs=, colors_precomp=, scales=, rotations=,
+                                    cov3D_precomp=) -> (color (3,H,W), radii (N) int32, allmap (7,H,W))
+                                    (renderer_2dgs.py:224-234); scales are (N,2); `cov3D_precomp` carries a
+                                    precomputed (N,9) / (N,3,3) splat-to-pixel matrix
+    rasterize_gaussians(...)        functional form
+
+All arithmetic is in libgdr_hip.so (include/gsr.h) through ctypes; there is no CPU path: non-HIP tensors raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+from torch import nn
+
+from . import _lib as L
+from .rasterizer import (GaussianRasterizationSettings, _f32, _ptr, _require_hip, _settings_struct, _State,
+                         _stream)
+from . import rasterizer as _R
+
+
+class _SurfelState(_State):
+    """Typed views of the surfel workspaces (rec is (N,24); n_contrib (2,H,W); final_T (3,H,W))."""
+
+    __slots__ = ()
+
+    def tensors(self) -> dict:
+        N, D, H, W = max(self.N, 1), self.D, self.H, self.W
+        g, b, im = self.geom, self.bin, self.img
+        gb, bb, ib = self.geom_buf, self.bin_buf, self.img_buf
+        tiles = ((W + 15) // 16) * ((H + 15) // 16)
+        rec = self._view(gb, g.rec, torch.float32, L.GSR_REC_FLOATS * N).view(N, L.GSR_REC_FLOATS)
+        out = dict(
+            depths=self._view(gb, g.depths, torch.float32, N), rec=rec,
+            rect=self._view(gb, g.rect, torch.int32, 4 * N).view(N, 4),
+            tiles_touched=self._view(gb, g.tiles_touched, torch.int32, N),
+            clamped=self._view(gb, g.clamped, torch.uint8, N),
+            ranges=self._view(ib, im.ranges, torch.int32, 2 * tiles).view(tiles, 2),
+            n_contrib=self._view(ib, im.n_contrib, torch.int32, 2 * H * W).view(2, H, W),
+            final_T=self._view(ib, im.final_T, torch.float32, 3 * H * W).view(3, H, W),
+            num_rendered=D,
+            transMats=torch.cat([rec[:, 0:3], rec[:, 4:7], rec[:, 8:11]], 1),
+            xy=torch.stack([rec[:, 3], rec[:, 7]], 1),
+            normal_opacity=torch.cat([rec[:, 12:15], rec[:, 11:12]], 1),
+            rgb=rec[:, 15:18], box=rec[:, 18:22])
+        s = b.sorted
+        if D > 0:
+            out["keys_sorted"] = self._view(bb, b.keys[s], torch.int64, D)
+            out["point_list"] = self._view(bb, b.values[s], torch.int32, D)
+        else:
+            out["keys_sorted"] = torch.empty(0, dtype=torch.int64, device=gb.device)
+            out["point_list"] = torch.empty(0, dtype=torch.int32, device=gb.device)
+        return out
+
+
+def _inputs_struct(N, M, means3D, opacities, sh, colors_precomp, scales, rotations, transmat, flags=0) -> L.GsrInputs:
+    return L.GsrInputs(N, M, _ptr(means3D), _ptr(opacities), _ptr(sh), _ptr(colors_precomp), _ptr(scales),
+                       _ptr(rotations), _ptr(transmat), int(flags), 0)
+
+
+def forward_raw(means3D, sh, colors_precomp, opacities, scales, rotations, transMat_precomp, raster_settings, flags=0):
+    """Un-differentiated forward.  Returns (color, radii, allmap, state, keep)."""
+    lib = L.load()
+    _require_hip(means3D, "means3D")
+    dev = means3D.device
+    means3D, opacities, sh = _f32(means3D, dev), _f32(opacities, dev), _f32(sh, dev)
+    colors_precomp, scales, rotations = _f32(colors_precomp, dev), _f32(scales, dev), _f32(rotations, dev)
+    transMat_precomp = _f32(transMat_precomp, dev)
+    N = int(means3D.shape[0])
+    M = int(sh.shape[1]) if sh.numel() else 0
+    H, W = int(raster_settings.image_height), int(raster_settings.image_width)
+    if opacities.numel() != N:
+        raise RuntimeError("opacities must have N elements")
+    if scales.numel() and scales.shape[-1] != 2:
+        raise RuntimeError("diff_surfel_rasterization: scales must be (N,2)")
+    if transMat_precomp.numel() and transMat_precomp.numel() != 9 * N:
+        raise RuntimeError("diff_surfel_rasterization: precomputed transform must be (N,9) or (N,3,3)")
+    keep = [means3D, opacities, sh, colors_precomp, scales, rotations, transMat_precomp, int(flags)]
+    with torch.cuda.device(dev):
+        s = _settings_struct(raster_settings, dev, keep)
+        inp = _inputs_struct(N, M, means3D, opacities, sh, colors_precomp, scales, rotations, transMat_precomp, flags)
+        st = _SurfelState()
+        st.N, st.M, st.H, st.W = N, M, H, W
+        u8 = dict(dtype=torch.uint8, device=dev)
+        st.geom_buf = torch.empty(lib.gsr_geom_bytes(N), **u8)
+        st.img_buf = torch.empty(lib.gsr_image_bytes(H, W), **u8)
+        st.geom, st.bin, st.img = L.GdrGeom(), L.GdrBinning(), L.GdrImage()
+        L.check(lib.gsr_geom_carve(st.geom_buf.data_ptr(), N, C.byref(st.geom)), "gsr_geom_carve")
+        L.check(lib.gsr_image_carve(st.img_buf.data_ptr(), H, W, C.byref(st.img)), "gsr_image_carve")
+        f32 = dict(dtype=torch.float32, device=dev)
+        color = torch.empty(3, H, W, **f32)
+        allmap = torch.empty(7, H, W, **f32)
+        radii = torch.empty(N, dtype=torch.int32, device=dev)
+        stream = _stream()
+        d_host = C.c_uint32(0)
+        L.check(lib.gsr_preprocess_forward(C.byref(s), C.byref(inp), C.byref(st.geom), _ptr(radii), C.byref(d_host),
+                                           stream), "gsr_preprocess_forward")
+        st.D = int(d_host.value)
+        st.bin_buf = torch.empty(lib.gdr_binning_bytes(st.D), **u8)
+        L.check(lib.gdr_binning_carve(st.bin_buf.data_ptr(), st.D, C.byref(st.bin)), "gdr_binning_carve")
+        st.bin.global_sort = int(_R._FORCE_GLOBAL_SORT)
+        out = L.GsrOutputs(color.data_ptr(), allmap.data_ptr(), _ptr(radii))
+        L.check(lib.gsr_render_forward(C.byref(s), C.byref(inp), C.byref(st.geom), C.byref(st.bin), C.byref(st.img),
+                                       st.D, C.byref(out), stream), "gsr_render_forward")
+    return color, radii, allmap, st, keep
+
+
+def backward_raw(st, keep, raster_settings, radii, grad_color, grad_allmap):
+    """Returns dict of gradients (all fp32, on the inputs' device)."""
+    lib = L.load()
+    means3D, opacities, sh, colors_precomp, scales, rotations, transmat, flags = keep[:8]
+    dev = means3D.device
+    N, M = st.N, st.M
+    f32 = dict(dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        keep2: list = []
+        s = _settings_struct(raster_settings, dev, keep2)
+        inp = _inputs_struct(N, M, means3D, opacities, sh, colors_precomp, scales, rotations, transmat, flags)
+        gc = _f32(grad_color, dev)
+        ga = None if grad_allmap is None else _f32(grad_allmap, dev)
+        use_sh, use_tm = sh.numel() > 0, transmat.numel() > 0
+        g = dict(
+            means3D=torch.empty(N, 3, **f32), means2D=torch.empty(N, 4, **f32),
+            shs=torch.empty(N, M, 3, **f32) if use_sh else None,
+            colors_precomp=None if use_sh else torch.empty(N, 3, **f32),
+            opacities=torch.empty(N, 1, **f32),
+            scales=None if use_tm else torch.empty(N, 2, **f32),
+            rotations=None if use_tm else torch.empty(N, 4, **f32),
+            transMat_precomp=torch.empty(N, 9, **f32) if use_tm else None)
+        scratch = torch.empty(max(N, 1) * L.GSR_GRAD_FLOATS, **f32)
+        gin = L.GsrGradInputs(gc.data_ptr(), _ptr(ga))
+        gout = L.GsrGradOutputs(_ptr(g["means3D"]), _ptr(g["means2D"]), _ptr(g["shs"]), _ptr(g["colors_precomp"]),
+                                _ptr(g["opacities"]), _ptr(g["scales"]), _ptr(g["rotations"]),
+                                _ptr(g["transMat_precomp"]), scratch.data_ptr(), 0, 0)
+        L.check(lib.gsr_backward(C.byref(s), C.byref(inp), C.byref(st.geom), C.byref(st.bin), C.byref(st.img), st.D,
+                                 _ptr(radii), C.byref(gin), C.byref(gout), _stream()), "gsr_backward")
+    return g
+
+
+class _RasterizeSurfels(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, transMat_precomp,
+                raster_settings, flags=0):
+        color, radii, allmap, st, keep = forward_raw(means3D, sh, colors_precomp, opacities, scales, rotations,
+                                                     transMat_precomp, raster_settings, flags)
+        ctx.raster_settings, ctx.state, ctx.keep, ctx.radii = raster_settings, st, keep, radii
+        ctx.means2D_shape = tuple(means2D.shape)
+        ctx.tm_shape = tuple(transMat_precomp.shape)
+        ctx.in_dtypes = tuple(t.dtype for t in (means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+                                                transMat_precomp))
+        ctx.mark_non_differentiable(radii)
+        return color, radii, allmap
+
+    @staticmethod
+    def backward(ctx, grad_color, grad_radii, grad_allmap):
+        g = backward_raw(ctx.state, ctx.keep, ctx.raster_settings, ctx.radii, grad_color, grad_allmap)
+        gm2 = g["means2D"]
+        cols = ctx.means2D_shape[1] if len(ctx.means2D_shape) == 2 else 4
+        if cols == 3:  # upstream's (N,3) carrier: xy signal, z = 0
+            gm2 = torch.cat([gm2[:, :2], torch.zeros_like(gm2[:, :1])], dim=1)
+        elif cols != 4:
+            gm2 = gm2[:, :cols].contiguous()
+        gtm = g["transMat_precomp"]
+        if gtm is not None:
+            gtm = gtm.reshape(ctx.tm_shape)
+        grads = [g["means3D"], gm2, g["shs"], g["colors_precomp"], g["opacities"], g["scales"], g["rotations"], gtm]
+        grads = [None if t is None else (t if t.dtype == dt else t.to(dt)) for t, dt in zip(grads, ctx.in_dtypes)]
+        return (*grads, None, None)
+
+
+def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                        raster_settings):
+    return _RasterizeSurfels.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+                                   cov3Ds_precomp, raster_settings)
+
+
+class GaussianRasterizer(nn.Module):
+    def __init__(self, raster_settings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions):
+        return _R.GaussianRasterizer(self.raster_settings).markVisible(positions)
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None):
+        if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+            raise Exception("Please provide excatly one of either SHs or precomputed colors!")
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or (
+                (scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
+        e = torch.empty(0, dtype=torch.float32, device=means3D.device)
+        return rasterize_gaussians(
+            means3D, means2D, e if shs is None else shs, e if colors_precomp is None else colors_precomp, opacities,
+            e if scales is None else scales, e if rotations is None else rotations,
+            e if cov3D_precomp is None else cov3D_precomp, self.raster_settings)

@@ -1,0 +1,103 @@
+/*
+ * include/gsr.h — C ABI of the 2D-Gaussian (surfel) rasterizer in libgdr_hip.so (MI355X, gfx950): the native
+ * half of `diff_surfel_rasterization`, the package /root/reference/lightning/renderer_2dgs.py:7-10 imports
+ * (BASELINE config 5).  What the reference binds:
+ *   - settings record:   /root/reference/lightning/renderer_2dgs.py:111-124 (the same 12 fields as the 3DGS path)
+ *   - forward call:      /root/reference/lightning/renderer_2dgs.py:224-234
+ *                        (-> rendered_image (3,H,W), radii (N), allmap (7,H,W))
+ *   - allmap channels:   /root/reference/lightning/renderer_2dgs.py:241-257  0 expected depth (sum w z), 1 alpha,
+ *                        2-4 normal (view space), 5 median depth, 6 depth distortion
+ *   - inputs:            scales (N,2) (renderer_2dgs.py:92-96), means2D carrier (N,4) (:207-208)
+ * The package itself is in neither .gitmodules nor the tree, so the arithmetic follows the published 2DGS
+ * algorithm as restated in oracle/gsr_oracle.c (PARITY UNPINNED).  Conventions, ownership, error codes and the
+ * stream rule are those of include/gdr.h, whose settings / binning / workspace structs are reused:
+ *   gdr_geom   — `rec` holds 24 floats (96 B) per surfel instead of 16:
+ *                  [0..2] Tu  [3] centre x      [4..6] Tv  [7] centre y     [8..10] Tw  [11] opacity
+ *                  [12..14] normal (view space, facing the camera)  [15] r   [16] g  [17] b
+ *                  [18..19] lower, [20..21] upper corner of a conservative box around {alpha >= 1/255}
+ *                where (Tu, Tv, Tw) are the rows of the splat-to-pixel homography: (u,v,1) . (Tu,Tv,Tw) =
+ *                (x w, y w, w).  `cov3D` is unused.
+ *   gdr_image  — n_contrib is (2,H,W): last contributor, median contributor (1-based, 0 = none);
+ *                final_T is (3,H,W): T, M1 = sum w m, M2 = sum w m^2 (m = normalised depth).
+ * Use gsr_geom_bytes / gsr_image_bytes + gsr_*_carve for these layouts; binning is gdr_binning_bytes / _carve.
+ */
+#ifndef GSR_H
+#define GSR_H
+
+#include "gdr.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GSR_REC_FLOATS 24  /* floats per surfel in gdr_geom.rec          */
+#define GSR_GRAD_FLOATS 32 /* floats per surfel in gsr_grad_outputs.scratch */
+
+/* Per-surfel inputs of GaussianRasterizer.forward (renderer_2dgs.py:224-234).  Exactly one of shs /
+ * colors_precomp and one of (scales, rotations) / transMat_precomp is non-NULL.  flags: GDR_IN_RAW_* of gdr.h
+ * (sigmoid / exp / normalize of renderer_2dgs.py:190-199 folded into the kernels). */
+typedef struct gsr_inputs {
+    int32_t N;
+    int32_t M;                     /* SH coefficients per surfel stored in `shs` (>= (deg+1)^2) */
+    const float* means3D;          /* (N,3) */
+    const float* opacities;        /* (N)   */
+    const float* shs;              /* (N,M,3) or NULL */
+    const float* colors_precomp;   /* (N,3)   or NULL */
+    const float* scales;           /* (N,2)   or NULL */
+    const float* rotations;        /* (N,4)   or NULL, (r,x,y,z) */
+    const float* transMat_precomp; /* (N,9)   or NULL: rows Tu, Tv, Tw (the adaptor's `cov3D_precomp` argument) */
+    uint32_t flags;
+    uint32_t reserved;
+} gsr_inputs;
+
+typedef struct gsr_outputs {
+    float* color;   /* (3,H,W) */
+    float* allmap;  /* (7,H,W) */
+    int32_t* radii; /* (N)     */
+} gsr_outputs;
+
+typedef struct gsr_grad_inputs {
+    const float* dL_dcolor;  /* (3,H,W) */
+    const float* dL_dallmap; /* (7,H,W) or NULL (= zeros) */
+} gsr_grad_inputs;
+
+/* Every buffer is fully written (zeros for culled surfels) unless accumulate != 0.  dL_dmeans2D is (N,4):
+ * columns 0-1 = dL/dTu.z, dL/dTv.z scaled by depth * 0.5 W (resp. H) — the densification signal of the lineage —
+ * columns 2-3 the same with per-pixel |.| accumulation.  scratch: N * GSR_GRAD_FLOATS floats (128-byte records:
+ * [0..8] dL/dT, [9] opacity, [10..12] colour, [13..15] normal, [16..17] low-pass centre, [18..19] |dTu.z|, |dTv.z|). */
+typedef struct gsr_grad_outputs {
+    float* dL_dmeans3D;   /* (N,3) */
+    float* dL_dmeans2D;   /* (N,4) */
+    float* dL_dshs;       /* (N,M,3) or NULL when colors_precomp was used */
+    float* dL_dcolors;    /* (N,3)  or NULL when shs was used */
+    float* dL_dopacities; /* (N)   */
+    float* dL_dscales;    /* (N,2) or NULL when transMat_precomp was used */
+    float* dL_drotations; /* (N,4) or NULL when transMat_precomp was used */
+    float* dL_dtransMat;  /* (N,9) or NULL when scales/rotations were used */
+    float* scratch;       /* (N*32) floats, 128-byte aligned */
+    int32_t accumulate;
+    int32_t reserved;
+} gsr_grad_outputs;
+
+size_t gsr_geom_bytes(int32_t N);
+size_t gsr_image_bytes(int32_t H, int32_t W);
+int gsr_geom_carve(void* base, int32_t N, gdr_geom* out);
+int gsr_image_carve(void* base, int32_t H, int32_t W, gdr_image* out);
+
+/* Stage 1: per-surfel homography, bounding box, SH colour, tile rect, total D (same contract as
+ * gdr_preprocess_forward).  Stage 2: duplicate / sort / ranges (the 3DGS path's kernels) + surfel compositing. */
+int gsr_preprocess_forward(const gdr_settings* s, const gsr_inputs* in, const gdr_geom* geom, int32_t* radii,
+                           uint32_t* num_rendered_host, void* stream);
+int gsr_render_forward(const gdr_settings* s, const gsr_inputs* in, const gdr_geom* geom, gdr_binning* bin,
+                       const gdr_image* img, uint64_t D, const gsr_outputs* out, void* stream);
+int gsr_forward(const gdr_settings* s, const gsr_inputs* in, const gdr_geom* geom, gdr_binning* bin,
+                const gdr_image* img, uint64_t D_cap, const gsr_outputs* out, uint32_t* num_rendered_host,
+                void* stream);
+int gsr_backward(const gdr_settings* s, const gsr_inputs* in, const gdr_geom* geom, const gdr_binning* bin,
+                 const gdr_image* img, uint64_t D, const int32_t* radii, const gsr_grad_inputs* gin,
+                 const gsr_grad_outputs* gout, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSR_H */

@@ -126,3 +126,49 @@ def outlier_fraction(a, b, rtol=1e-4, atol=1e-4):
 def psnr(a, b):
     mse = float(((np.asarray(a, np.float64) - np.asarray(b, np.float64)) ** 2).mean())
     return 10 * math.log10(1.0 / max(mse, 1e-30))
+
+
+# ---- 2DGS surfel path -------------------------------------------------------------------------------------
+def make_surfel_case(N, H, W, seed, **kw):
+    """make_case with (N,2) scales (renderer_2dgs.py:92-96)."""
+    case = make_case(N, H, W, seed, **kw)
+    case["scales"] = case["scales"][:, :2].contiguous()
+    case["transMat_precomp"] = None
+    return case
+
+
+def run_surfel_oracle(case, precision="f32", grads=None, nthreads=1):
+    from oracle.gsr_oracle import SurfelOracle
+
+    o = SurfelOracle(precision, nthreads=nthreads)
+    out = o.forward(_np(case["means3D"]), _np(case["opacities"]), settings_np(case), shs=_np(case["shs"]),
+                    colors_precomp=_np(case["colors_precomp"]), scales=_np(case["scales"]),
+                    rotations=_np(case["rotations"]), transMat_precomp=_np(case.get("transMat_precomp")))
+    g = o.backward(out, _np(grads[0]), _np(grads[1])) if grads is not None else None
+    return out, g
+
+
+def run_surfel_hip(case, grads=None, dev="cuda:0"):
+    """Through the product C ABI (generativedensification_amd.surfel_rasterizer -> libgdr_hip.so, include/gsr.h)."""
+    from generativedensification_amd import surfel_rasterizer as S
+
+    dev = torch.device(dev)
+    rs = settings_torch(case, dev)
+    e = torch.empty(0, device=dev)
+    t = lambda k: e if case.get(k) is None else case[k].to(dev)
+    color, radii, allmap, st, keep = S.forward_raw(t("means3D"), t("shs"), t("colors_precomp"), t("opacities"),
+                                                   t("scales"), t("rotations"), t("transMat_precomp"), rs)
+    torch.cuda.synchronize()
+    out = {k: (v.cpu().numpy() if isinstance(v, torch.Tensor) else v) for k, v in st.tensors().items()}
+    out.update(color=color.cpu().numpy(), radii=radii.cpu().numpy(), allmap=allmap.cpu().numpy())
+    g = None
+    if grads is not None:
+        gg = S.backward_raw(st, keep, rs, radii, grads[0].to(dev), grads[1].to(dev))
+        torch.cuda.synchronize()
+        g = {k: (None if v is None else v.cpu().numpy()) for k, v in gg.items()}
+    return out, g
+
+
+def rand_surfel_grads(case, seed=123):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(3, case["H"], case["W"], generator=g), torch.randn(7, case["H"], case["W"], generator=g)
