@@ -1,0 +1,119 @@
+"""Host-side 2DGS render adaptor — counterpart of the reference's surfel `Renderer`
+(/root/reference/lightning/renderer_2dgs.py:98-283) for boxes where /root/reference does not exist.  Same method
+names, argument meaning and return values:
+
+    render_img(cam, rays, centers, shs, opacity, scales, rotations, device, cov3D_precomp=None, prex='',
+               depth_ratio=0.0, screenspace_points=None)
+      rays is None -> the clamped image (3,H,W)                                            (renderer_2dgs.py:236-238)
+      else         -> {image (H,W,3), depth (H,W,1), acc_map (H,W), rend_normal (H,W,3) world space,
+                       depth_normal (H,W,3) pseudo normal of the depth map x alpha, rend_dist (H,W)}  (:241-278)
+
+Steps mirrored (:190-278): sigmoid(opacity), exp(scales (N,2)), normalize(rotations); (N,4) zero screen-space
+carrier; rasterizer -> (image, radii, allmap); clamp; allmap slicing; normal rotated by world_view[:3,:3].T;
+expected depth = allmap[0] / alpha with nan -> 0; surf_depth = (1-r) expected + r median; pseudo normals from the
+unprojected depth map (central differences, cross product, normalised, zero border) times detached alpha.
+fused=True hands the RAW opacity / scale / rotation tensors to the rasterizer (activations inside K1s/K9s).
+Pinned against the real class by tests/golden/render2dgs_*.npz.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+from torch import nn
+
+from . import _lib as L
+from .rasterizer import GaussianRasterizationSettings
+from .surfel_rasterizer import GaussianRasterizer, _RasterizeSurfels
+
+RAW_ALL = L.GDR_IN_RAW_OPACITY | L.GDR_IN_RAW_SCALES | L.GDR_IN_RAW_ROTATIONS
+
+
+def depths_to_points(rays: torch.Tensor, depthmap: torch.Tensor) -> torch.Tensor:
+    """rays (H,W,6) = origin | direction; point = origin + depth * direction  (renderer_2dgs.py:75-77)."""
+    return rays[..., :3].reshape(-1, 3) + depthmap.reshape(-1, 1) * rays[..., 3:].reshape(-1, 3)
+
+
+def depth_to_normal(rays: torch.Tensor, depth: torch.Tensor):
+    """Pseudo surface normal of a depth map (1,H,W): normalised cross product of the central differences of the
+    unprojected points along rows and columns, zero on the 1-pixel border (renderer_2dgs.py:79-90).
+    Returns (normal (H,W,3), points (H,W,3))."""
+    pts = depths_to_points(rays, depth).reshape(*depth.shape[1:], 3)
+    d_rows = pts[2:, 1:-1] - pts[:-2, 1:-1]
+    d_cols = pts[1:-1, 2:] - pts[1:-1, :-2]
+    inner = torch.nn.functional.normalize(torch.cross(d_rows, d_cols, dim=-1), dim=-1)
+    normal = torch.zeros_like(pts)
+    normal[1:-1, 1:-1, :] = inner
+    return normal, pts
+
+
+class Renderer(nn.Module):
+    def __init__(self, sh_degree: int = 3, white_background: bool = True, radius: float = 1, fused: bool = True):
+        super().__init__()
+        self.fused = fused
+        self.sh_degree = sh_degree
+        self.white_background = white_background
+        self.radius = radius
+        self.scaling_activation = torch.exp
+        self.opacity_activation = torch.sigmoid
+        self.rotation_activation = torch.nn.functional.normalize
+        self.bg_color = torch.tensor([1, 1, 1] if white_background else [0, 0, 0], dtype=torch.float32)
+
+    def set_bg_color(self, bg):
+        self.bg_color = bg
+
+    def get_scaling(self, s):
+        return self.scaling_activation(s)
+
+    def get_rotation(self, r):
+        return self.rotation_activation(r)
+
+    def get_opacity(self, o):
+        return self.opacity_activation(o)
+
+    def set_rasterizer(self, viewpoint_camera, scaling_modifier: float = 1.0, device="cuda"):
+        settings = GaussianRasterizationSettings(
+            image_height=int(viewpoint_camera.image_height), image_width=int(viewpoint_camera.image_width),
+            tanfovx=math.tan(viewpoint_camera.FoVx * 0.5), tanfovy=math.tan(viewpoint_camera.FoVy * 0.5),
+            bg=self.bg_color.to(device), scale_modifier=scaling_modifier,
+            viewmatrix=viewpoint_camera.world_view_transform, projmatrix=viewpoint_camera.full_proj_transform,
+            sh_degree=self.sh_degree, campos=viewpoint_camera.camera_center, prefiltered=False, debug=False)
+        return GaussianRasterizer(raster_settings=settings)
+
+    def render_img(self, cam, rays, centers, shs, opacity, scales, rotations, device, cov3D_precomp=None, prex="",
+                   depth_ratio=0.0, screenspace_points=None):
+        rasterizer = self.set_rasterizer(cam, device=device)
+        if screenspace_points is None:
+            screenspace_points = torch.zeros((centers.shape[0], 4), dtype=centers.dtype, requires_grad=True,
+                                             device=device) + 0
+        try:
+            screenspace_points.retain_grad()
+        except Exception:
+            pass
+        if self.fused and cov3D_precomp is None and scales is not None and rotations is not None and centers.is_cuda:
+            e = torch.empty(0, dtype=torch.float32, device=centers.device)
+            image, radii, allmap = _RasterizeSurfels.apply(centers, screenspace_points, shs, e, opacity, scales,
+                                                           rotations, e, rasterizer.raster_settings, RAW_ALL)
+        else:
+            image, radii, allmap = rasterizer(
+                means3D=centers, means2D=screenspace_points, shs=shs, opacities=self.get_opacity(opacity),
+                scales=None if scales is None else self.get_scaling(scales),
+                rotations=None if rotations is None else self.get_rotation(rotations), cov3D_precomp=cov3D_precomp)
+        image = image.clamp(0, 1)
+        if rays is None:
+            return image
+        alpha = allmap[1:2]
+        normal_world = (allmap[2:5].permute(1, 2, 0) @ cam.world_view_transform[:3, :3].T).permute(2, 0, 1)
+        depth_median = torch.nan_to_num(allmap[5:6], 0, 0)
+        depth_expected = torch.nan_to_num(allmap[0:1] / alpha, 0, 0)
+        surf_depth = depth_expected * (1 - depth_ratio) + depth_ratio * depth_median
+        surf_normal, _ = depth_to_normal(rays, surf_depth)
+        surf_normal = surf_normal.permute(2, 0, 1) * alpha.detach()
+        return {
+            f"image{prex}": image.permute(1, 2, 0),
+            f"depth{prex}": surf_depth.permute(1, 2, 0),
+            f"acc_map{prex}": alpha.squeeze(0),
+            f"rend_normal{prex}": normal_world.permute(1, 2, 0),
+            f"depth_normal{prex}": surf_normal.permute(1, 2, 0),
+            f"rend_dist{prex}": allmap[6:7].squeeze(0),
+        }

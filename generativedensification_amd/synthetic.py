@@ -52,3 +52,15 @@ def views_loss(out: dict, targets: torch.Tensor, prex: str = "") -> torch.Tensor
     tensors the way the reference takes its loss on the concatenated views (network.py:974-978, loss.py:37-48)."""
     return (((out[f"image{prex}"] - targets) ** 2).mean(dim=(1, 2, 3)) + 0.1 * out[f"depth{prex}"].mean(dim=(1, 2, 3))
             + 0.1 * out[f"acc_map{prex}"].mean(dim=(1, 2)))
+
+
+def surfel_loss(out: dict, target: torch.Tensor, prex: str = "") -> torch.Tensor:
+    """Measurement loss of the 2DGS path: the terms the reference's loss takes on the surfel adaptor's dict
+    (lightning/loss.py:37-38 MSE on the clamped image; :49-61 distortion.mean() * 1000 and the normal-consistency
+    term ((1 - <rend_normal, depth_normal>) * acc_map.detach()).mean() * 0.2) plus 0.1 mean(depth) + 0.1 mean(alpha)
+    so that every allmap channel receives a gradient (same role as `view_loss` for the 3DGS path)."""
+    loss = ((out[f"image{prex}"] - target) ** 2).mean()
+    loss = loss + 1000.0 * out[f"rend_dist{prex}"].mean()
+    normal_error = ((1 - (out[f"rend_normal{prex}"] * out[f"depth_normal{prex}"]).sum(dim=-1))
+                    * out[f"acc_map{prex}"].detach()).mean()
+    return loss + 0.2 * normal_error + 0.1 * out[f"depth{prex}"].mean() + 0.1 * out[f"acc_map{prex}"].mean()

@@ -12,9 +12,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _declared_symbols():
-    src = open(os.path.join(ROOT, "include", "gdr.h")).read()
-    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(gdr_[a-z_0-9]+)\s*\(", src)))
+    names = set()
+    for hdr in ("gdr.h", "gsr.h"):   # every header under include/
+        src = open(os.path.join(ROOT, "include", hdr)).read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        names |= set(re.findall(r"\b(g[ds]r_[a-z_0-9]+)\s*\(", src))
+    return sorted(names)
 
 
 def test_library_exports_every_declared_symbol():
@@ -22,9 +25,9 @@ def test_library_exports_every_declared_symbol():
 
     lib = L.load()
     names = _declared_symbols()
-    assert len(names) >= 15
+    assert len(names) >= 23 and "gsr_backward" in names and sorted(os.listdir(os.path.join(ROOT, "include"))) == ["gdr.h", "gsr.h"]
     for n in names:
-        assert hasattr(lib, n), f"{n} declared in include/gdr.h but not exported"
+        assert hasattr(lib, n), f"{n} declared in include/*.h but not exported"
         assert n in L.EXPORTED_SYMBOLS, f"{n} has no ctypes prototype"
     assert lib.gdr_abi_version() == 5
 
@@ -53,6 +56,42 @@ def test_workspace_sizes_and_carving_without_gpu():
     b = L.GdrBinning()
     assert lib.gdr_binning_carve(C.c_void_p(base), 5000, C.byref(b)) == 0
     assert b.keys[1] - b.keys[0] >= 5000 * 8 and b.values[1] - b.values[0] >= 5000 * 4
+
+
+def test_surfel_workspace_sizes_and_errors_without_gpu():
+    from generativedensification_amd import _lib as L
+
+    lib = L.load()
+    assert lib.gsr_geom_bytes(1_000_000) >= 1_000_000 * (4 + 96 + 16 + 4 + 1) and lib.gsr_geom_bytes(1000) % 256 == 0
+    assert lib.gsr_image_bytes(800, 800) >= 2500 * 12 + 640000 * (8 + 12)
+    g, im = L.GdrGeom(), L.GdrImage()
+    base = 0x20000000
+    assert lib.gsr_geom_carve(C.c_void_p(base), 1000, C.byref(g)) == 0 and g.cov3D is None
+    assert g.rect - g.rec >= 1000 * 96
+    assert lib.gsr_image_carve(C.c_void_p(base), 64, 48, C.byref(im)) == 0
+    assert im.final_T - im.n_contrib >= 2 * 64 * 48 * 4 and im.tile_order - im.final_T >= 3 * 64 * 48 * 4
+    assert lib.gsr_geom_carve(C.c_void_p(base + 8), 10, C.byref(g)) == -1
+    s, i = L.GdrSettings(), L.GsrInputs()
+    assert lib.gsr_preprocess_forward(None, None, None, None, None, None) == -1
+    s.image_height, s.image_width = 64, 64
+    assert lib.gsr_preprocess_forward(C.byref(s), C.byref(i), C.byref(g), None, None, None) == -1
+    assert lib.gsr_backward(C.byref(s), C.byref(i), None, None, None, 0, None, None, None, None) == -1
+
+
+def test_surfel_product_path_has_no_cpu_fallback():
+    import diff_surfel_rasterization as D
+
+    rs = D.GaussianRasterizationSettings(image_height=32, image_width=32, tanfovx=0.4, tanfovy=0.4, bg=torch.ones(3),
+                                         scale_modifier=1.0, viewmatrix=torch.eye(4), projmatrix=torch.eye(4),
+                                         sh_degree=0, campos=torch.zeros(3), prefiltered=False, debug=False)
+    r = D.GaussianRasterizer(rs)
+    n = 10
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        r(means3D=torch.zeros(n, 3), means2D=torch.zeros(n, 4), opacities=torch.ones(n, 1), shs=torch.zeros(n, 1, 3),
+          scales=torch.ones(n, 2), rotations=torch.ones(n, 4))
+    with pytest.raises(Exception, match="SHs or precomputed colors"):
+        r(means3D=torch.zeros(n, 3), means2D=torch.zeros(n, 4), opacities=torch.ones(n, 1), scales=torch.ones(n, 2),
+          rotations=torch.ones(n, 4))
 
 
 def test_argument_errors_are_reported_not_thrown():
