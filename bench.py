@@ -47,6 +47,9 @@ WORKLOADS = {
                     "statistics of network.py's decoder output, 8 views 512x512, SH1 (configs/base.yaml), fwd+bwd"),
     "c2": dict(n=200_000, sigma0=(0.0052, 0.00065), seed=1, views_per_gpu=4, h=800, w=800, deg=3,
                desc="BASELINE configs[1]: 200k Gaussians (50/50 sigma0 mix), 4 views 800x800, SH3, fwd+bwd"),
+    "c5": dict(n=500_000, sigma0=(0.0052, 0.00065), seed=5, views_per_gpu=4, h=800, w=800, deg=3, surfel=True,
+               desc="BASELINE configs[4]: 2DGS surfel path (renderer_2dgs.render_img: image + depth/normal/distortion "
+                    "maps), 500k surfels (50/50 sigma0 mix), 4 views 800x800, SH3, fwd+bwd"),
 }
 
 
@@ -75,6 +78,22 @@ def algorithmic_bytes(n, d, p, m, tiles):
         _bytes_view=n * (A + S) + n * 28 + d * K + d * (8 + passes * 2 * K) + d * 8 + d * 44 + p * 28
         + d * (44 + G) + p * 28 + n * (A + S + G) + n * (A + 16),
     )
+
+
+def surfel_algorithmic_bytes(n, d, p, m, tiles):
+    """2DGS path: A = 12 + 8 + 16 + 4 + 12 M input bytes / surfel, S = 96-byte render record + depth, rect, tiles,
+    clamp (25), G = 20 partial gradients (80), K = key + value; per pixel 15 floats out (image 3, allmap 7, final
+    T/M1/M2 3, n_contrib 2) and 15 in (10 gradients + 5 state)."""
+    A = 12 + 8 + 16 + 4 + 12 * m
+    S, G, K = 96 + 25, 80, 12
+    bits = 32 + max(1, math.ceil(math.log2(max(tiles, 2))))
+    passes = (bits + 7) // 8
+    out = algorithmic_bytes(n, d, p, m, tiles)
+    out.update(preprocess_fwd=n * (A + S), render_fwd=d * (4 + 96) + p * 60, render_bwd=d * (4 + 96 + G) + p * 60,
+               preprocess_bwd=n * (A + S + 128) + n * (A + 16), _passes=passes)
+    out["_bytes_view"] = (out["preprocess_fwd"] + n * 28 + d * K + d * (8 + passes * 2 * K) + d * 8 + out["render_fwd"]
+                          + out["render_bwd"] + out["preprocess_bwd"])
+    return out
 
 
 def main():
@@ -147,6 +166,9 @@ def main():
         scene = {k: torch.cat([a[k], b[k]]).contiguous() for k in a}
     else:
         scene = make_scene(n, wl["seed"], sh_degree=deg, sigma0=wl["sigma0"] or (0.0052,), device=dev)
+    surfel = bool(wl.get("surfel"))
+    if surfel:
+        scene["scales"] = scene["scales"][:, :2].contiguous()
     params = {k: v.requires_grad_(True) for k, v in scene.items()}
     all_cams = orbit_cameras(total_views, w, h, device=dev)
     mine = shard_views(total_views, rank, world)
@@ -155,7 +177,15 @@ def main():
     # same strides as the HWC views of the rasterizer's CHW images: elementwise kernels stay on the dense path
     targets_chw = targets.permute(0, 3, 1, 2).contiguous()
     targets = targets_chw.permute(0, 2, 3, 1)
-    renderer = Renderer(sh_degree=deg, white_background=True, fused=not args.unfused)
+    if surfel:
+        from generativedensification_amd.camera import build_rays
+        from generativedensification_amd.renderer_2dgs import Renderer as Renderer2D
+        from generativedensification_amd.synthetic import surfel_loss
+
+        renderer = Renderer2D(sh_degree=deg, white_background=True, fused=not args.unfused)
+        rays = [build_rays(torch.inverse(c.world_view_transform.T.cpu()), 0.75, 0.75, h, w).to(dev) for c in cams]
+    else:
+        renderer = Renderer(sh_degree=deg, white_background=True, fused=not args.unfused)
     renderer.set_bg_color(torch.ones(3, device=dev))
     plist = list(params.values())
     L.load()
@@ -163,7 +193,16 @@ def main():
     def step():
         for p in plist:
             p.grad = None
-        if args.per_view:   # the reference's call pattern: one render_img + backward per view
+        if surfel:          # 2DGS adaptor: one render_img (image + depth/normal/distortion maps) + backward per view
+            losses = []
+            for j, cam in enumerate(cams):
+                out = renderer.render_img(cam, rays[j], params["centers"], params["shs"], params["opacity"],
+                                          params["scales"], params["rotations"], dev)
+                loss = surfel_loss(out, targets[j])
+                loss.backward()
+                losses.append(loss.detach())
+            losses = torch.stack(losses)
+        elif args.per_view:   # the reference's call pattern: one render_img + backward per view
             losses = []
             for j, cam in enumerate(cams):
                 out = renderer.render_img(cam, None, params["centers"], params["shs"], params["opacity"],
@@ -212,21 +251,23 @@ def main():
 
     # ---- D (num_rendered) per view, measured ----------------------------------------
     from generativedensification_amd import rasterizer as R
+    from generativedensification_amd import surfel_rasterizer as SR
     d_views = []
     with torch.no_grad():
         for cam in cams:
             rs = renderer.set_rasterizer(cam, device=dev).raster_settings
             e = torch.empty(0, device=dev)
-            _, _, _, _, st, _ = R.forward_raw(params["centers"].detach(), params["shs"].detach(), e,
-                                              torch.sigmoid(params["opacity"].detach()),
-                                              torch.exp(params["scales"].detach()),
-                                              torch.nn.functional.normalize(params["rotations"].detach()), e, rs)
+            fr = (SR if surfel else R).forward_raw(params["centers"].detach(), params["shs"].detach(), e,
+                                                   torch.sigmoid(params["opacity"].detach()),
+                                                   torch.exp(params["scales"].detach()),
+                                                   torch.nn.functional.normalize(params["rotations"].detach()), e, rs)
+            st = fr[-2]
             d_views.append(st.D)
-            del st
+            del st, fr
     d_mean = sum(d_views) / len(d_views)
     tiles = ((w + 15) // 16) * ((h + 15) // 16)
     m = (deg + 1) ** 2
-    alg = algorithmic_bytes(n, d_mean, h * w, m, tiles)
+    alg = (surfel_algorithmic_bytes if surfel else algorithmic_bytes)(n, d_mean, h * w, m, tiles)
 
     # ---- roofline: per-kernel HIP-event timing, second pass of the same K steps -----------
     roofline = None
@@ -263,9 +304,10 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         import numpy as np
         from oracle.gdr_oracle import Oracle, Settings
+        from oracle.gsr_oracle import SurfelOracle
 
         cores = os.cpu_count() or 1
-        o = Oracle("f32", nthreads=cores)
+        o = (SurfelOracle if surfel else Oracle)("f32", nthreads=cores)
         cam = cams[0]
         s = Settings(h, w, math.tan(0.375), math.tan(0.375), np.ones(3, np.float32), 1.0,
                      cam.world_view_transform.cpu().numpy(), cam.full_proj_transform.cpu().numpy(), deg,
@@ -279,11 +321,12 @@ def main():
         gc = g.standard_normal((3, h, w), dtype=np.float32)
         gd = g.standard_normal((1, h, w), dtype=np.float32)
         ga = g.standard_normal((1, h, w), dtype=np.float32)
+        gm = g.standard_normal((7, h, w), dtype=np.float32)
         tc0 = time.perf_counter()
         reps = 0
         while True:
             ctx = o.forward(c["centers"].numpy(), op, s, shs=c["shs"].numpy(), scales=sc, rotations=ro)
-            o.backward(ctx, gc, gd, ga)
+            o.backward(ctx, gc, gm) if surfel else o.backward(ctx, gc, gd, ga)
             reps += 1
             if time.perf_counter() - tc0 > 10.0 or reps >= 5:
                 break
@@ -302,9 +345,11 @@ def main():
                        "views_per_gpu": vpg, "image": [h, w], "sh_degree": deg,
                        "num_rendered_per_view": int(d_mean), "parallelism": f"view-sharded x{world}",
                        "grad_allreduce": bool(args.grad_allreduce),
-                       "entry": ("render_img per view" if args.per_view else "render_views (all views of the shard, one node)")
+                       "entry": ("renderer_2dgs.render_img per view" if surfel else "render_img per view" if args.per_view
+                                 else "render_views (all views of the shard, one node)")
                        + (", torch activations" if args.unfused else ", activations fused into K1/K9"),
-                       "loss": ("torch ops" if (args.per_view or args.stacked_loss or args.torch_loss or args.unfused)
+                       "loss": ("torch ops (MSE + 1000 distortion + 0.2 normal consistency + 0.1 depth + 0.1 alpha)" if surfel
+                                else "torch ops" if (args.per_view or args.stacked_loss or args.torch_loss or args.unfused)
                                 else "fused HIP kernel (clamp+MSE+0.1 mean depth+0.1 mean alpha)")},
             "roofline": roofline, "cpu_baseline": cpu_baseline, "kernels": kernels,
             "loss_mean": float(last_losses.mean()),
