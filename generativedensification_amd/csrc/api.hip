@@ -431,7 +431,7 @@ int gdr_profile_collect(double* ms_total, uint64_t* launches, int32_t n, int32_t
 const char* gdr_kernel_name(int32_t id) {
     static const char* names[GDR_K_COUNT] = {"preprocess_fwd", "scan_block_sums", "duplicate_with_keys",
         "sort_hist", "sort_rowscan", "sort_scatter", "tile_ranges", "render_fwd", "render_bwd",
-        "preprocess_bwd", "mark_visible", "tile_order", "tile_sort", "tile_sort_long", "view_loss"};
+        "preprocess_bwd", "mark_visible", "tile_order", "tile_sort", "tile_sort_long", "view_loss", "surfel_maps"};
     return (id >= 0 && id < GDR_K_COUNT) ? names[id] : "";
 }
 int gdr_kernel_count(void) { return GDR_K_COUNT; }
@@ -619,6 +619,33 @@ int gsr_backward(const gdr_settings* s, const gsr_inputs* in, const gdr_geom* ge
     e = launch_surfel_preprocess_bwd(s, in, geom, radii, gout, st);
     if (e != hipSuccess) return hip_fail("surfel_preprocess_bwd", e);
     return debug_sync(s, "surfel_preprocess_bwd", st);
+}
+
+int gsr_maps_forward(const float* allmap, const float* rays, const float* viewmatrix, int32_t H, int32_t W,
+                     float depth_ratio, float* depth, float* acc_map, float* rend_normal, float* depth_normal,
+                     float* rend_dist, void* stream) {
+    if (!allmap || !rays || !viewmatrix || !depth || !acc_map || !rend_normal || !depth_normal || !rend_dist || H <= 0 || W <= 0) {
+        set_error("gsr_maps_forward: bad argument", hipSuccess);
+        return GDR_ERR_INVALID_ARG;
+    }
+    hipError_t e = launch_surfel_maps_fwd(allmap, rays, viewmatrix, H, W, depth_ratio, depth, acc_map, rend_normal,
+                                          depth_normal, rend_dist, (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail("surfel_maps_fwd", e);
+    return GDR_OK;
+}
+
+int gsr_maps_backward(const float* allmap, const float* rays, const float* viewmatrix, int32_t H, int32_t W,
+                      float depth_ratio, const float* g_depth, const float* g_acc_map, const float* g_rend_normal,
+                      const float* g_depth_normal, const float* g_rend_dist, float* scratch, float* dL_dallmap,
+                      void* stream) {
+    if (!allmap || !rays || !viewmatrix || !dL_dallmap || (g_depth_normal && !scratch) || H <= 0 || W <= 0) {
+        set_error("gsr_maps_backward: bad argument", hipSuccess);
+        return GDR_ERR_INVALID_ARG;
+    }
+    hipError_t e = launch_surfel_maps_bwd(allmap, rays, viewmatrix, H, W, depth_ratio, g_depth, g_acc_map, g_rend_normal,
+                                          g_depth_normal, g_rend_dist, scratch, dL_dallmap, (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail("surfel_maps_bwd", e);
+    return GDR_OK;
 }
 
 }  // extern "C"

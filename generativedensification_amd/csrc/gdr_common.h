@@ -34,6 +34,7 @@ enum {
     GDR_K_TILE_SORT,
     GDR_K_TILE_SORT_LONG,
     GDR_K_VIEW_LOSS,
+    GDR_K_SURFEL_MAPS,
     GDR_K_COUNT
 };
 
@@ -111,6 +112,13 @@ hipError_t launch_surfel_render_fwd(const gdr_settings* s, const gdr_geom* g, co
 hipError_t launch_surfel_render_bwd(const gdr_settings* s, const gdr_geom* g, const gdr_binning* bin,
                                     const gdr_image* img, const gsr_grad_inputs* gi, float* grad_rec,
                                     hipStream_t st);
+
+hipError_t launch_surfel_maps_fwd(const float* allmap, const float* rays, const float* view, int H, int W, float r,
+                                  float* depth, float* acc, float* rend_normal, float* depth_normal, float* rend_dist,
+                                  hipStream_t st);
+hipError_t launch_surfel_maps_bwd(const float* allmap, const float* rays, const float* view, int H, int W, float r,
+                                  const float* g_depth, const float* g_acc, const float* g_rn, const float* g_dn,
+                                  const float* g_dist, float* scratch, float* dL_dallmap, hipStream_t st);
 
 size_t sort_hist_bytes(uint64_t D);
 

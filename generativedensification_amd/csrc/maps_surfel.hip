@@ -1,0 +1,187 @@
+// maps_surfel.hip — the per-pixel maps the 2DGS adaptor derives from the rasterizer's allmap, fused
+// (/root/reference/lightning/renderer_2dgs.py:241-278, SURVEY §8f-3 "depth_to_normal fused"):
+//   acc_map      = allmap[1]
+//   rend_normal  = allmap[2:5] rotated to world space by world_view[:3,:3]^T                     (:244-246)
+//   surf_depth   = (1 - r) nan0(allmap[0] / alpha) + r nan0(allmap[5])                           (:248-262)
+//   depth_normal = normalize(cross(P(y+1,x) - P(y-1,x), P(y,x+1) - P(y,x-1))) alpha (alpha detached, zero on the
+//                  1-pixel border), P = ray origin + surf_depth * ray direction                   (:75-90, 266-271)
+//   rend_dist    = allmap[6]
+// In torch this is ~45 elementwise / slicing / small-GEMM launches forward and ~90 backward per view over 640k
+// pixels; here one kernel forward and two backward (the stencil's transpose needs the neighbours' partials: pass A
+// stores dL/d(row difference), dL/d(column difference) per pixel, pass B gathers them).  HBM-bound, ~150 B/pixel.
+#include "gdr_common.h"
+
+namespace gdr {
+namespace {
+
+__device__ __forceinline__ float nan0(float v) { return (v != v || v == INFINITY) ? 0.f : v; }  // nan_to_num(x, 0, 0)
+
+struct Maps {
+    const float* allmap; const float* rays; int H, W; float r;
+};
+
+// surf_depth of pixel q and whether its expected-depth quotient is differentiable there
+__device__ __forceinline__ float surf_depth(const Maps& m, int q, size_t P, bool* exp_ok, bool* med_ok) {
+    const float D = m.allmap[q], a = m.allmap[P + q], med = m.allmap[5 * P + q];
+    const float e = D / a;
+    const bool eo = !(e != e) && e != INFINITY, mo = !(med != med) && med != INFINITY;
+    if (exp_ok) *exp_ok = eo;
+    if (med_ok) *med_ok = mo;
+    return (1.f - m.r) * (eo ? e : 0.f) + m.r * (mo ? med : 0.f);
+}
+
+__device__ __forceinline__ void point_at(const Maps& m, int q, size_t P, float* p) {
+    const float sd = surf_depth(m, q, P, nullptr, nullptr);
+    const float* ry = m.rays + 6 * (size_t)q;
+    p[0] = fmaf(sd, ry[3], ry[0]); p[1] = fmaf(sd, ry[4], ry[1]); p[2] = fmaf(sd, ry[5], ry[2]);
+}
+
+struct Stencil { float a[3], b[3], c[3], len; };  // a = row difference, b = column difference, c = a x b
+
+__device__ __forceinline__ void stencil_at(const Maps& m, int y, int x, size_t P, Stencil& s) {
+    float u[3], d[3], l[3], r[3];
+    point_at(m, (y - 1) * m.W + x, P, u); point_at(m, (y + 1) * m.W + x, P, d);
+    point_at(m, y * m.W + x - 1, P, l); point_at(m, y * m.W + x + 1, P, r);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { s.a[k] = d[k] - u[k]; s.b[k] = r[k] - l[k]; }
+    s.c[0] = s.a[1] * s.b[2] - s.a[2] * s.b[1];
+    s.c[1] = s.a[2] * s.b[0] - s.a[0] * s.b[2];
+    s.c[2] = s.a[0] * s.b[1] - s.a[1] * s.b[0];
+    s.len = sqrtf(fmaf(s.c[0], s.c[0], fmaf(s.c[1], s.c[1], s.c[2] * s.c[2])));
+}
+
+__global__ __launch_bounds__(GDR_BLOCK) void surfel_maps_fwd_kernel(Maps m, const float* __restrict__ view,
+                                                                     float* __restrict__ depth, float* __restrict__ acc,
+                                                                     float* __restrict__ rend_normal,
+                                                                     float* __restrict__ depth_normal,
+                                                                     float* __restrict__ rend_dist) {
+    const int q = blockIdx.x * GDR_BLOCK + threadIdx.x;
+    const size_t P = (size_t)m.H * m.W;
+    if (q >= (int)P) return;
+    const int y = q / m.W, x = q - y * m.W;
+    const float a = m.allmap[P + q];
+    depth[q] = surf_depth(m, q, P, nullptr, nullptr);
+    acc[q] = a;
+    rend_dist[q] = m.allmap[6 * P + q];
+    const float n0 = m.allmap[2 * P + q], n1 = m.allmap[3 * P + q], n2 = m.allmap[4 * P + q];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) rend_normal[3 * (size_t)q + j] = fmaf(view[4 * j], n0, fmaf(view[4 * j + 1], n1, view[4 * j + 2] * n2));
+    float dn[3] = {0.f, 0.f, 0.f};
+    if (y >= 1 && y < m.H - 1 && x >= 1 && x < m.W - 1) {
+        Stencil s;
+        stencil_at(m, y, x, P, s);
+        const float inv = a / fmaxf(s.len, 1e-12f);  // F.normalize(eps = 1e-12), times the (detached) alpha
+        dn[0] = s.c[0] * inv; dn[1] = s.c[1] * inv; dn[2] = s.c[2] * inv;
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) depth_normal[3 * (size_t)q + j] = dn[j];
+}
+
+// pass A: per interior pixel, dL/d(row difference) and dL/d(column difference) of its normal -> scratch (6 floats)
+__global__ __launch_bounds__(GDR_BLOCK) void surfel_maps_bwd_a_kernel(Maps m, const float* __restrict__ g_dn,
+                                                                       float* __restrict__ scratch) {
+    const int q = blockIdx.x * GDR_BLOCK + threadIdx.x;
+    const size_t P = (size_t)m.H * m.W;
+    if (q >= (int)P) return;
+    const int y = q / m.W, x = q - y * m.W;
+    float ga[3] = {0.f, 0.f, 0.f}, gb[3] = {0.f, 0.f, 0.f};
+    if (g_dn && y >= 1 && y < m.H - 1 && x >= 1 && x < m.W - 1) {
+        Stencil s;
+        stencil_at(m, y, x, P, s);
+        const float a = m.allmap[P + q];
+        const float g[3] = {g_dn[3 * (size_t)q] * a, g_dn[3 * (size_t)q + 1] * a, g_dn[3 * (size_t)q + 2] * a};
+        float gc[3];
+        if (s.len > 1e-12f) {  // n = c / |c|: dL/dc = (g - n (n.g)) / |c|
+            const float inv = 1.f / s.len;
+            const float n[3] = {s.c[0] * inv, s.c[1] * inv, s.c[2] * inv};
+            const float dot = fmaf(n[0], g[0], fmaf(n[1], g[1], n[2] * g[2]));
+#pragma unroll
+            for (int k = 0; k < 3; ++k) gc[k] = (g[k] - n[k] * dot) * inv;
+        } else {               // clamped denominator: n = c / eps
+#pragma unroll
+            for (int k = 0; k < 3; ++k) gc[k] = g[k] * 1e12f;
+        }
+        // c = a x b: dL/da = b x gc, dL/db = gc x a
+        ga[0] = s.b[1] * gc[2] - s.b[2] * gc[1]; ga[1] = s.b[2] * gc[0] - s.b[0] * gc[2]; ga[2] = s.b[0] * gc[1] - s.b[1] * gc[0];
+        gb[0] = gc[1] * s.a[2] - gc[2] * s.a[1]; gb[1] = gc[2] * s.a[0] - gc[0] * s.a[2]; gb[2] = gc[0] * s.a[1] - gc[1] * s.a[0];
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { scratch[(size_t)k * P + q] = ga[k]; scratch[(size_t)(3 + k) * P + q] = gb[k]; }
+}
+
+// pass B: gather the neighbours' partials into dL/dsurf_depth, then everything into dL/dallmap
+__global__ __launch_bounds__(GDR_BLOCK) void surfel_maps_bwd_b_kernel(Maps m, const float* __restrict__ view,
+                                                                       const float* __restrict__ g_depth,
+                                                                       const float* __restrict__ g_acc,
+                                                                       const float* __restrict__ g_rn,
+                                                                       const float* __restrict__ g_dist,
+                                                                       const float* __restrict__ scratch, int have_dn,
+                                                                       float* __restrict__ dL_dallmap) {
+    const int q = blockIdx.x * GDR_BLOCK + threadIdx.x;
+    const size_t P = (size_t)m.H * m.W;
+    if (q >= (int)P) return;
+    const int y = q / m.W, x = q - y * m.W;
+    float gp[3] = {0.f, 0.f, 0.f};
+    if (have_dn) {
+        const bool xin = x >= 1 && x < m.W - 1, yin = y >= 1 && y < m.H - 1;
+        // q is the lower neighbour of (y-1,x) [+ row term], the upper one of (y+1,x) [-], the right one of (y,x-1)
+        // [+ column term], the left one of (y,x+1) [-]; the source pixel must be interior
+        if (xin && y - 1 >= 1 && y - 1 < m.H - 1)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) gp[k] += scratch[(size_t)k * P + q - m.W];
+        if (xin && y + 1 >= 1 && y + 1 < m.H - 1)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) gp[k] -= scratch[(size_t)k * P + q + m.W];
+        if (yin && x - 1 >= 1 && x - 1 < m.W - 1)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) gp[k] += scratch[(size_t)(3 + k) * P + q - 1];
+        if (yin && x + 1 >= 1 && x + 1 < m.W - 1)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) gp[k] -= scratch[(size_t)(3 + k) * P + q + 1];
+    }
+    const float* ry = m.rays + 6 * (size_t)q;
+    float gsd = fmaf(gp[0], ry[3], fmaf(gp[1], ry[4], gp[2] * ry[5]));
+    if (g_depth) gsd += g_depth[q];
+    bool eo, mo;
+    surf_depth(m, q, P, &eo, &mo);
+    const float D = m.allmap[q], a = m.allmap[P + q];
+    const float ge = eo ? (1.f - m.r) * gsd : 0.f;
+    // an empty pixel (alpha = 0) has no dependence on D or alpha (nan_to_num); torch would hand 0/0 = NaN here
+    const float gD = (eo && a != 0.f) ? ge / a : 0.f;
+    float gA = (eo && a != 0.f) ? -ge * D / (a * a) : 0.f;
+    if (g_acc) gA += g_acc[q];
+    dL_dallmap[q] = gD;
+    dL_dallmap[P + q] = gA;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        float v = 0.f;
+        if (g_rn) v = fmaf(view[i], g_rn[3 * (size_t)q], fmaf(view[4 + i], g_rn[3 * (size_t)q + 1], view[8 + i] * g_rn[3 * (size_t)q + 2]));
+        dL_dallmap[(2 + i) * P + q] = v;
+    }
+    dL_dallmap[5 * P + q] = mo ? m.r * gsd : 0.f;
+    dL_dallmap[6 * P + q] = g_dist ? g_dist[q] : 0.f;
+}
+
+}  // namespace
+
+hipError_t launch_surfel_maps_fwd(const float* allmap, const float* rays, const float* view, int H, int W, float r,
+                                  float* depth, float* acc, float* rend_normal, float* depth_normal, float* rend_dist,
+                                  hipStream_t st) {
+    const Maps m{allmap, rays, H, W, r};
+    GDR_LAUNCH(GDR_K_SURFEL_MAPS, surfel_maps_fwd_kernel, dim3(div_up((int64_t)H * W, GDR_BLOCK)), dim3(GDR_BLOCK), st, m,
+               view, depth, acc, rend_normal, depth_normal, rend_dist);
+    return hipGetLastError();
+}
+
+hipError_t launch_surfel_maps_bwd(const float* allmap, const float* rays, const float* view, int H, int W, float r,
+                                  const float* g_depth, const float* g_acc, const float* g_rn, const float* g_dn,
+                                  const float* g_dist, float* scratch, float* dL_dallmap, hipStream_t st) {
+    const Maps m{allmap, rays, H, W, r};
+    const dim3 grid(div_up((int64_t)H * W, GDR_BLOCK));
+    if (g_dn) GDR_LAUNCH(GDR_K_SURFEL_MAPS, surfel_maps_bwd_a_kernel, grid, dim3(GDR_BLOCK), st, m, g_dn, scratch);
+    GDR_LAUNCH(GDR_K_SURFEL_MAPS, surfel_maps_bwd_b_kernel, grid, dim3(GDR_BLOCK), st, m, view, g_depth, g_acc, g_rn,
+               g_dist, scratch, g_dn ? 1 : 0, dL_dallmap);
+    return hipGetLastError();
+}
+
+}  // namespace gdr

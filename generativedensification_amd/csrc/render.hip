@@ -300,7 +300,7 @@ __global__ __launch_bounds__(GDR_BLOCK) void render_bwd_kernel(
     float T = T_final;
     const int last_contributor = inside ? (int)n_contrib[pix] : 0;
     float gC0 = 0.f, gC1 = 0.f, gC2 = 0.f, gD = 0.f, gA = 0.f;
-    if (inside) {
+    if (inside && last_contributor > 0) {  // a pixel without contributors reads no upstream gradient (NaN-safe)
         gC0 = dL_dpix[pix]; gC1 = dL_dpix[P + pix]; gC2 = dL_dpix[2 * P + pix];
         if (!M2_ONLY && dL_ddepthpix) gD = dL_ddepthpix[pix];
         if (!M2_ONLY && dL_dalphapix) gA = dL_dalphapix[pix];

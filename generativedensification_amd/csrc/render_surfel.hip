@@ -248,7 +248,9 @@ __global__ __launch_bounds__(GDR_BLOCK) void surfel_render_bwd_kernel(
     const int last_contributor = inside ? (int)n_contrib[pix] : 0;
     const int med_contributor = inside ? (int)n_contrib[P + pix] : 0;
     float gC0 = 0.f, gC1 = 0.f, gC2 = 0.f, gDepth = 0.f, gAlpha = 0.f, gN0 = 0.f, gN1 = 0.f, gN2 = 0.f, gMed = 0.f, gReg = 0.f;
-    if (inside) {
+    // a pixel without contributors reads no upstream gradient: the adaptor's torch ops hand NaN (0/0) to the depth
+    // and alpha channels of empty pixels (renderer_2dgs.py:253-254 backward), which must not leak into a row reduction
+    if (inside && last_contributor > 0) {
         gC0 = dL_dpix[pix]; gC1 = dL_dpix[P + pix]; gC2 = dL_dpix[2 * P + pix];
         if (dL_dothers) {
             gDepth = dL_dothers[pix]; gAlpha = dL_dothers[P + pix];

@@ -47,6 +47,51 @@ def depth_to_normal(rays: torch.Tensor, depth: torch.Tensor):
     return normal, pts
 
 
+class _SurfelMaps(torch.autograd.Function):
+    """allmap -> (depth (H,W,1), acc_map (H,W), rend_normal (H,W,3), depth_normal (H,W,3), rend_dist (H,W)) in one HIP
+    kernel forward and two backward (include/gsr.h gsr_maps_*): the lines 241-278 of the reference adaptor."""
+
+    @staticmethod
+    def forward(ctx, allmap, rays, viewmatrix, depth_ratio):
+        import ctypes as C
+
+        lib = L.load()
+        dev = allmap.device
+        allmap = allmap.contiguous()
+        rays = rays.to(device=dev, dtype=torch.float32).contiguous()
+        view = viewmatrix.to(device=dev, dtype=torch.float32).contiguous()
+        H, W = int(allmap.shape[1]), int(allmap.shape[2])
+        f32 = dict(dtype=torch.float32, device=dev)
+        depth, acc = torch.empty(H, W, 1, **f32), torch.empty(H, W, **f32)
+        rn, dn, dist = torch.empty(H, W, 3, **f32), torch.empty(H, W, 3, **f32), torch.empty(H, W, **f32)
+        with torch.cuda.device(dev):
+            L.check(lib.gsr_maps_forward(allmap.data_ptr(), rays.data_ptr(), view.data_ptr(), H, W, float(depth_ratio),
+                                         depth.data_ptr(), acc.data_ptr(), rn.data_ptr(), dn.data_ptr(), dist.data_ptr(),
+                                         C.c_void_p(torch.cuda.current_stream().cuda_stream)), "gsr_maps_forward")
+        ctx.save_for_backward(allmap, rays, view)
+        ctx.depth_ratio = float(depth_ratio)
+        return depth, acc, rn, dn, dist
+
+    @staticmethod
+    def backward(ctx, g_depth, g_acc, g_rn, g_dn, g_dist):
+        import ctypes as C
+
+        lib = L.load()
+        allmap, rays, view = ctx.saved_tensors
+        dev = allmap.device
+        H, W = int(allmap.shape[1]), int(allmap.shape[2])
+        gs = [None if g is None else g.to(torch.float32).contiguous() for g in (g_depth, g_acc, g_rn, g_dn, g_dist)]
+        ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+        out = torch.empty_like(allmap)
+        scratch = torch.empty(6, H, W, dtype=torch.float32, device=dev) if gs[3] is not None else None
+        with torch.cuda.device(dev):
+            L.check(lib.gsr_maps_backward(allmap.data_ptr(), rays.data_ptr(), view.data_ptr(), H, W, ctx.depth_ratio,
+                                          ptr(gs[0]), ptr(gs[1]), ptr(gs[2]), ptr(gs[3]), ptr(gs[4]), ptr(scratch),
+                                          out.data_ptr(), C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                    "gsr_maps_backward")
+        return out, None, None, None
+
+
 class Renderer(nn.Module):
     def __init__(self, sh_degree: int = 3, white_background: bool = True, radius: float = 1, fused: bool = True):
         super().__init__()
@@ -102,6 +147,12 @@ class Renderer(nn.Module):
         image = image.clamp(0, 1)
         if rays is None:
             return image
+        if self.fused and allmap.is_cuda:   # lines 241-278 of the reference adaptor in one kernel (same dict)
+            depth, acc, rend_normal, depth_normal, rend_dist = _SurfelMaps.apply(allmap, rays, cam.world_view_transform,
+                                                                                 float(depth_ratio))
+            return {f"image{prex}": image.permute(1, 2, 0), f"depth{prex}": depth, f"acc_map{prex}": acc,
+                    f"rend_normal{prex}": rend_normal, f"depth_normal{prex}": depth_normal,
+                    f"rend_dist{prex}": rend_dist}
         alpha = allmap[1:2]
         normal_world = (allmap[2:5].permute(1, 2, 0) @ cam.world_view_transform[:3, :3].T).permute(2, 0, 1)
         depth_median = torch.nan_to_num(allmap[5:6], 0, 0)

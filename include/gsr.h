@@ -97,6 +97,21 @@ int gsr_backward(const gdr_settings* s, const gsr_inputs* in, const gdr_geom* ge
                  const gdr_image* img, uint64_t D, const int32_t* radii, const gsr_grad_inputs* gin,
                  const gsr_grad_outputs* gout, void* stream);
 
+/* ---- the adaptor's per-pixel maps, fused (renderer_2dgs.py:241-278; SURVEY §8f-3 "depth_to_normal fused") ------
+ * forward:  allmap (7,H,W), rays (H,W,6) = origin | direction (dataLoader/utils.py:21-34), viewmatrix (16),
+ *           depth_ratio r  ->  depth (H,W,1) = (1-r) nan0(allmap[0]/alpha) + r nan0(allmap[5]); acc_map (H,W) = alpha;
+ *           rend_normal (H,W,3) = allmap[2:5] rotated to world space; depth_normal (H,W,3) = unit normal of the
+ *           unprojected depth map (central differences, zero border) times alpha; rend_dist (H,W) = allmap[6].
+ * backward: upstream gradients of the five maps (any may be NULL = zeros; alpha is detached inside depth_normal as in
+ *           the reference) -> dL_dallmap (7,H,W), fully written.  scratch: 6*H*W floats (needed iff g_depth_normal). */
+int gsr_maps_forward(const float* allmap, const float* rays, const float* viewmatrix, int32_t H, int32_t W,
+                     float depth_ratio, float* depth, float* acc_map, float* rend_normal, float* depth_normal,
+                     float* rend_dist, void* stream);
+int gsr_maps_backward(const float* allmap, const float* rays, const float* viewmatrix, int32_t H, int32_t W,
+                      float depth_ratio, const float* g_depth, const float* g_acc_map, const float* g_rend_normal,
+                      const float* g_depth_normal, const float* g_rend_dist, float* scratch, float* dL_dallmap,
+                      void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -187,3 +187,102 @@ def test_product_2dgs_renderer_on_gpu_matches_golden_render_img(name, fused):
         ref = g[f"grad_{k}"]
         assert U.outlier_fraction(gr.cpu().numpy(), ref, 1e-2, 1e-3 * np.abs(ref).max()) < 1e-2, k
     assert grads[-1].shape == (int(g["n"]), 4) and float(grads[-1][:, 2:].min()) >= 0.0
+
+
+def test_fused_surfel_maps_match_the_torch_adaptor_ops():
+    """gsr_maps_forward/backward (one kernel forward, two backward) == the adaptor's torch sequence (renderer_2dgs.py:
+    241-278) on random allmaps incl. empty pixels (alpha = 0 -> depth 0, zero gradient), both depth ratios."""
+    from generativedensification_amd.camera import build_rays, look_at_c2w, MiniCam
+    from generativedensification_amd.renderer_2dgs import _SurfelMaps, depth_to_normal
+
+    dev = torch.device("cuda:0")
+    H, W = 57, 83
+    c2w = look_at_c2w(torch.tensor([0.9, -1.1, 1.2]))
+    cam = MiniCam(c2w, W, H, torch.tensor(0.75), torch.tensor(0.75), 1.1, 2.7, dev)
+    rays = build_rays(c2w, 0.75, 0.75, H, W).to(dev)
+    g = torch.Generator().manual_seed(5)
+    for ratio in (0.0, 1.0, 0.3):
+        am = torch.rand(7, H, W, generator=g)
+        am[0] = am[1] * (1.5 + am[0])          # expected depth = alpha * z
+        am[5] = 1.5 + am[5]
+        am[2:5] = am[2:5] - 0.5
+        hole = torch.rand(H, W, generator=g) < 0.15
+        am[:, hole] = 0.0                      # empty pixels
+        am = am.to(dev)
+        ups = [torch.randn(s, generator=g).to(dev) for s in ((H, W, 1), (H, W), (H, W, 3), (H, W, 3), (H, W))]
+
+        def torch_ops(a):
+            alpha = a[1:2]
+            nw = (a[2:5].permute(1, 2, 0) @ cam.world_view_transform[:3, :3].T).permute(2, 0, 1)
+            med = torch.nan_to_num(a[5:6], 0, 0)
+            exp = torch.nan_to_num(a[0:1] / alpha, 0, 0)
+            sd = exp * (1 - ratio) + ratio * med
+            sn, _ = depth_to_normal(rays, sd)
+            sn = sn.permute(2, 0, 1) * alpha.detach()
+            return sd.permute(1, 2, 0), alpha.squeeze(0), nw.permute(1, 2, 0), sn.permute(1, 2, 0), a[6]
+
+        a1 = am.clone().requires_grad_(True)
+        ref = torch_ops(a1)
+        a2 = am.clone().requires_grad_(True)
+        got = _SurfelMaps.apply(a2, rays, cam.world_view_transform, ratio)
+        for k, (x, y) in enumerate(zip(got, ref)):
+            assert x.shape == y.shape, k
+            if k == 3:   # unit normal of a RANDOM depth map: a nearly vanishing cross product amplifies rounding
+                assert U.outlier_fraction(x.detach().cpu().numpy(), y.detach().cpu().numpy(), 1e-3, 1e-4) < 2e-3
+            else:
+                torch.testing.assert_close(x, y, rtol=2e-5, atol=2e-6, msg=f"map {k} ratio {ratio}")
+        (g_ref,) = torch.autograd.grad(sum((o * u).sum() for o, u in zip(ref, ups)), a1)
+        (g_got,) = torch.autograd.grad(sum((o * u).sum() for o, u in zip(got, ups)), a2)
+        assert torch.isfinite(g_got).all()
+        # torch hands 0/0 = NaN to allmap[0:2] of empty pixels (nan_to_num's zero gradient divided by alpha = 0); the
+        # fused backward writes the finite part there: 0 for allmap[0], the acc_map gradient for allmap[1]
+        hole_d = hole.to(dev)
+        assert torch.isnan(g_ref[0:2][:, hole_d]).all()
+        assert float(g_got[0][hole_d].abs().max()) == 0.0
+        torch.testing.assert_close(g_got[1][hole_d], ups[1][hole_d])
+        g_ref = torch.where(torch.isnan(g_ref), g_got, g_ref)
+        # a random depth map makes some cross products nearly vanish: 1/|c| amplifies fp32 rounding there
+        scale = float(g_ref.abs().max())
+        assert float((g_got - g_ref).abs().max()) < 2e-3 * scale, ratio
+        assert U.outlier_fraction(g_got.cpu().numpy(), g_ref.cpu().numpy(), 1e-3, 1e-5 * scale) < 1e-3, ratio
+
+
+def test_nan_upstream_gradients_at_empty_pixels_do_not_leak():
+    """The adaptor's torch ops produce NaN gradients for allmap[0:2] at pixels nothing was rendered to (0/0 in the
+    backward of nan_to_num(D / alpha)); K7s / K7 never read upstream gradients of such pixels."""
+    from generativedensification_amd import rasterizer as R3
+    from generativedensification_amd import surfel_rasterizer as S
+
+    dev = torch.device("cuda:0")
+    case = U.make_surfel_case(400, 96, 96, 21, deg=1, sigma0=(0.01,))
+    rs = U.settings_torch(case, dev)
+    e = torch.empty(0, device=dev)
+    t = lambda k: case[k].to(dev)
+    color, radii, allmap, st, keep = S.forward_raw(t("means3D"), t("shs"), e, t("opacities"), t("scales"), t("rotations"), e, rs)
+    empty = st.tensors()["n_contrib"][0] == 0
+    assert 0.2 < float(empty.float().mean()) < 0.999
+    gc, ga = [g.to(dev) for g in U.rand_surfel_grads(case)]
+    clean = S.backward_raw(st, keep, rs, radii, gc, ga)
+    gc2, ga2 = gc.clone(), ga.clone()
+    gc2[:, empty] = float("nan")
+    ga2[:, empty] = float("nan")
+    dirty = S.backward_raw(st, keep, rs, radii, gc2, ga2)
+    for k, v in clean.items():
+        if v is not None:
+            assert torch.isfinite(dirty[k]).all(), k
+            torch.testing.assert_close(dirty[k], v, rtol=1e-5, atol=1e-6 * float(v.abs().max()), msg=k)
+    # same for the 3DGS path
+    case3 = U.make_case(400, 96, 96, 21, deg=1, sigma0=(0.01,))
+    t3 = lambda k: case3[k].to(dev)
+    color, radii, depth, alpha, st, keep = R3.forward_raw(t3("means3D"), t3("shs"), e, t3("opacities"), t3("scales"), t3("rotations"), e, rs)
+    empty = st.tensors()["n_contrib"] == 0
+    g3 = [g.to(dev) for g in U.rand_grads(case3)]
+    clean = R3.backward_raw(st, keep, rs, radii, *g3)
+    g3n = [g.clone() for g in g3]
+    for g in g3n:
+        g[:, empty] = float("nan")
+    dirty = R3.backward_raw(st, keep, rs, radii, *g3n)
+    for k, v in clean.items():
+        if v is not None:
+            assert torch.isfinite(dirty[k]).all(), k
+            torch.testing.assert_close(dirty[k], v, rtol=1e-5, atol=1e-6 * float(v.abs().max()), msg=k)
