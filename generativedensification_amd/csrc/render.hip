@@ -272,7 +272,7 @@ __global__ __launch_bounds__(GDR_BLOCK) void render_bwd_kernel(
     const uint32_t* __restrict__ tile_order, int W, int H, int gx, int ntiles,
     const float* __restrict__ bg, const float4* __restrict__ rec, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
     const float* __restrict__ dL_dpix, const float* __restrict__ dL_ddepthpix,
-    const float* __restrict__ dL_dalphapix, float* __restrict__ grad_rec) {
+    const float* __restrict__ dL_dalphapix, float* __restrict__ grad_rec, int wave_num8) {
     __shared__ SliceLds lds;
     __shared__ uint32_t s_id[GDR_BLOCK + 1];
 
@@ -356,7 +356,8 @@ __global__ __launch_bounds__(GDR_BLOCK) void render_bwd_kernel(
             block_masks(lds, g, XA, YA, mypos < rl0, mypos < rl1, mypos < rl2, mypos < rl3, m0, m1, m2, m3);
             if ((m0 | m1 | m2 | m3) == 0ull) continue;
             const uint32_t goff = (uint32_t)(g * GDR_WAVE), nulloff = GDR_NULL_ENTRY - goff;
-            uint64_t mr = row_select(row, m0, m1, m2, m3);
+            const bool wave_mode = choose_wave_mode(m0, m1, m2, m3, wave_num8);
+            uint64_t mr = wave_mode ? (m0 | m1 | m2 | m3) : row_select(row, m0, m1, m2, m3);
             auto fetch = [&](Entry& en) {
                 en.e = min(take_bit(mr), nulloff) + goff;
                 en.m = lds.xy[en.e]; en.co = lds.co[en.e]; en.cd = lds.cd[en.e];
@@ -395,19 +396,23 @@ __global__ __launch_bounds__(GDR_BLOCK) void render_bwd_kernel(
                 const float v_mx = dL_dG * (-gdx * en.co.x - gdy * en.co.y) * kx;
                 const float v_my = dL_dG * (-gdy * en.co.z - gdx * en.co.y) * ky;
                 if (M2_ONLY) {
-                    const float tot4 = row_reduce_scatter4(v_mx, v_my, fabsf(v_mx), fabsf(v_my), li);
-                    if ((li & 3u) == 0u && ((hb >> (16 * row)) & 0xFFFFull) != 0ull)
+                    float tot4 = row_reduce_scatter4(v_mx, v_my, fabsf(v_mx), fabsf(v_my), li);
+                    bool publish4 = ((hb >> (16 * row)) & 0xFFFFull) != 0ull;
+                    if (wave_mode) { tot4 = wave_rows_sum(tot4); publish4 = row == 0u; }
+                    if ((li & 3u) == 0u && publish4)
                         atomicAdd(grad_rec + 4 * (size_t)s_id[en.e] + (li >> 2), tot4);
                     return;
                 }
                 const float vals[12] = {v_mx, v_my, fabsf(v_mx), fabsf(v_my),
                                         -0.5f * gdx * dx * dL_dG, -gdx * dy * dL_dG, -0.5f * gdy * dy * dL_dG,
                                         w * gD, w * gC0, w * gC1, w * gC2, G * dL_dalpha};
-                const float tot = row_reduce_scatter12(vals, li);
+                float tot = row_reduce_scatter12(vals, li);
+                bool publish = ((hb >> (16 * row)) & 0xFFFFull) != 0ull;
+                if (wave_mode) { tot = wave_rows_sum(tot); publish = row == 0u; }  // lockstep: row 0 publishes
                 // lanes 0..11 of every row that had a hit add the row totals to the Gaussian's
                 // 64-byte gradient record: one global_atomic_add_f32 instruction, one cache line
                 // per row (no return value => fire and forget)
-                if (li < 12u && ((hb >> (16 * row)) & 0xFFFFull) != 0ull)
+                if (li < 12u && publish)
                     atomicAdd(grad_rec + 16 * (size_t)s_id[en.e] + li, tot);
             };
             Entry A, B;  // unrolled by two: ping-pong registers instead of copies
@@ -427,6 +432,14 @@ __global__ __launch_bounds__(GDR_BLOCK) void render_bwd_kernel(
 }
 
 }  // namespace
+
+// lockstep threshold in eighths (render_common.h choose_wave_mode); GDR_WAVE_MODE_NUM8 overrides for A/B runs.
+// Measured on MI355X for this kernel (one 64-byte atomic per row): 10/8 -> C2 K7 196 -> 184 us, C3 282 -> 290 us,
+// C4 unchanged; 12/8 worse everywhere => off by default here (the surfel K7s, two atomics per row, gains 11 %).
+static int wave_mode_num8() {
+    static const int v = [] { const char* e = getenv("GDR_WAVE_MODE_NUM8"); return e ? atoi(e) : 0; }();
+    return v;
+}
 
 hipError_t launch_tile_order(const gdr_image* img, int ntiles, hipStream_t st) {
     GDR_LAUNCH(GDR_K_TILE_ORDER, tile_order_kernel, dim3(1), dim3(GDR_BLOCK), st, (const uint2*)img->ranges,
@@ -454,7 +467,7 @@ hipError_t launch_render_bwd(const gdr_settings* s, const gdr_geom* g, const gdr
     GDR_LAUNCH(GDR_K_RENDER_BWD, render_bwd_kernel<false>, dim3(ntiles), dim3(GDR_BLOCK), st,
                (const uint2*)img->ranges, bin->values[bin->sorted], img->tile_order, W, H, gx, ntiles, s->bg,
                (const float4*)g->rec, img->final_T, img->n_contrib, gi->dL_dcolor, gi->dL_ddepth, gi->dL_dalpha,
-               go->scratch);
+               go->scratch, wave_mode_num8());
     return hipGetLastError();
 }
 
@@ -466,7 +479,7 @@ hipError_t launch_render_bwd_mean2d(const gdr_settings* s, const gdr_geom* g, co
     const int ntiles = gx * gy;
     GDR_LAUNCH(GDR_K_RENDER_BWD, render_bwd_kernel<true>, dim3(ntiles), dim3(GDR_BLOCK), st,
                (const uint2*)img->ranges, bin->values[bin->sorted], img->tile_order, W, H, gx, ntiles, s->bg,
-               (const float4*)g->rec, img->final_T, img->n_contrib, dL_dcolor, nullptr, nullptr, dL_dmean2D);
+               (const float4*)g->rec, img->final_T, img->n_contrib, dL_dcolor, nullptr, nullptr, dL_dmean2D, wave_mode_num8());
     return hipGetLastError();
 }
 

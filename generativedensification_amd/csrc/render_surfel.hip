@@ -13,6 +13,8 @@
 // coverage, normal and the distortion weight) share the select-free form B <- B + a (c - B); the 20 per-surfel
 // partials are reduce-scattered inside each row (16 + 4 values) and published with two atomic instructions into a
 // 128-byte gradient record.
+#include <stdlib.h>
+
 #include "gdr_common.h"
 #include "render_common.h"
 #include "../../include/gsr.h"
@@ -222,7 +224,7 @@ __global__ __launch_bounds__(GDR_BLOCK) void surfel_render_bwd_kernel(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, const uint32_t* __restrict__ tile_order,
     int W, int H, int gx, int ntiles, const float* __restrict__ bg, const float4* __restrict__ rec,
     const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
-    const float* __restrict__ dL_dothers, float* __restrict__ grad_rec) {
+    const float* __restrict__ dL_dothers, float* __restrict__ grad_rec, int wave_num8) {
     __shared__ SurfelLds lds;
     __shared__ uint32_t s_id[GDR_BLOCK + 1];
 
@@ -295,7 +297,8 @@ __global__ __launch_bounds__(GDR_BLOCK) void surfel_render_bwd_kernel(
             block_masks(lds, g, XA, YA, mypos < rl0, mypos < rl1, mypos < rl2, mypos < rl3, m0, m1, m2, m3);
             if ((m0 | m1 | m2 | m3) == 0ull) continue;
             const uint32_t goff = (uint32_t)(g * GDR_WAVE), nulloff = GDR_NULL_ENTRY - goff;
-            uint64_t mr = row_select(row, m0, m1, m2, m3);
+            const bool wave_mode = choose_wave_mode(m0, m1, m2, m3, wave_num8);
+            uint64_t mr = wave_mode ? (m0 | m1 | m2 | m3) : row_select(row, m0, m1, m2, m3);
             auto fetch = [&](SEntry& en) {
                 en.e = min(take_bit(mr), nulloff) + goff;
                 en.tu = lds.tu[en.e]; en.tv = lds.tv[en.e]; en.tw = lds.tw[en.e]; en.nr = lds.nr[en.e]; en.gb = lds.gb[en.e];
@@ -346,9 +349,15 @@ __global__ __launch_bounds__(GDR_BLOCK) void surfel_render_bwd_kernel(
                                         fmaf(pxf, dkx, fmaf(pyf, dlx, dL_dz * sx)), fmaf(pxf, dky, fmaf(pyf, dly, dL_dz * sy)),
                                         fmaf(pxf, dkz, fmaf(pyf, dlz, dL_dz)),
                                         G * dL_dalpha, w * gC0, w * gC1, w * gC2, w * gN0, w * gN1, w * gN2};
-                const float tot = row_reduce_scatter16(vals, li);
-                const float tot4 = row_reduce_scatter4(lowx, lowy, fabsf(dkz), fabsf(dlz), li);
-                if (((hb >> (16 * row)) & 0xFFFFull) != 0ull) {
+                float tot = row_reduce_scatter16(vals, li);
+                float tot4 = row_reduce_scatter4(lowx, lowy, fabsf(dkz), fabsf(dlz), li);
+                bool publish = ((hb >> (16 * row)) & 0xFFFFull) != 0ull;
+                if (wave_mode) {  // all four rows hold the same entry: add the rows, row 0 publishes
+                    tot = wave_rows_sum(tot);
+                    tot4 = wave_rows_sum(tot4);
+                    publish = row == 0u;
+                }
+                if (publish) {
                     float* g = grad_rec + GSR_GRAD_FLOATS * (size_t)s_id[en.e];
                     atomicAdd(g + li, tot);
                     if ((li & 3u) == 0u) atomicAdd(g + 16 + (li >> 2), tot4);
@@ -372,6 +381,13 @@ __global__ __launch_bounds__(GDR_BLOCK) void surfel_render_bwd_kernel(
 
 }  // namespace
 
+// lockstep threshold in eighths (render_common.h choose_wave_mode); GDR_WAVE_MODE_NUM8 overrides for A/B runs.
+// Measured on MI355X, C5 K7s: off 647 us, 9/8 637, 10/8 586, 11/8 578, 12/8 632, 14/8 695.
+static int wave_mode_num8() {
+    static const int v = [] { const char* e = getenv("GDR_WAVE_MODE_NUM8"); return e ? atoi(e) : 11; }();
+    return v;
+}
+
 hipError_t launch_surfel_render_fwd(const gdr_settings* s, const gdr_geom* g, const gdr_binning* bin,
                                     const gdr_image* img, const gsr_outputs* out, hipStream_t st) {
     const int W = s->image_width, H = s->image_height;
@@ -391,7 +407,7 @@ hipError_t launch_surfel_render_bwd(const gdr_settings* s, const gdr_geom* g, co
     const int ntiles = gx * gy;
     GDR_LAUNCH(GDR_K_RENDER_BWD, surfel_render_bwd_kernel, dim3(ntiles), dim3(GDR_BLOCK), st, (const uint2*)img->ranges,
                bin->values[bin->sorted], img->tile_order, W, H, gx, ntiles, s->bg, (const float4*)g->rec, img->final_T,
-               img->n_contrib, gi->dL_dcolor, gi->dL_dallmap, grad_rec);
+               img->n_contrib, gi->dL_dcolor, gi->dL_dallmap, grad_rec, wave_mode_num8());
     return hipGetLastError();
 }
 
