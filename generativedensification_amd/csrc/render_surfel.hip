@@ -121,6 +121,12 @@ __global__ __launch_bounds__(GDR_BLOCK) void surfel_render_fwd_kernel(
     const int rounds = (total + GDR_BLOCK - 1) / GDR_BLOCK;
 
     if (threadIdx.x == 0) null_entry(lds);
+    // The distortion sum_i w_i (m_i^2 A_i + M2_i - 2 m_i M1_i) = sum_{j<i} w_i w_j (m_i - m_j)^2 only depends on
+    // DIFFERENCES of the normalised depth m = far/(far-near) (1 - near/z).  Evaluated with m ~ 0.9 in fp32 it cancels
+    // to ~1e-4 of its terms (the reference's loss weights it by 1000, loss.py:52); here m is taken relative to the
+    // depth of the tile's first surfel, m' = K (1/z_ref - 1/z), the same constant in K6s and K7s, which keeps the
+    // terms at the size of the result.  M1, M2 in final_T are sums of m'.
+    const float r_ref = total > 0 ? __builtin_amdgcn_rcpf(fmaxf(rec[6 * (size_t)point_list[range.x] + 2].z, GSR_NEAR)) : 1.f;
     float thr = inside ? GDR_ALPHA_MIN : INFINITY;
     float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f, N0 = 0.f, N1 = 0.f, N2 = 0.f;
     float Dp = 0.f, M1 = 0.f, M2 = 0.f, dist = 0.f, med = 0.f;
@@ -166,7 +172,7 @@ __global__ __launch_bounds__(GDR_BLOCK) void surfel_render_fwd_kernel(
                 const bool stop = T_new < 0.0001f;
                 const float w = stop ? 0.f : a_c * T;
                 const float A = 1.f - T;
-                const float m = GSR_FARK * (1.f - GSR_NEAR * __builtin_amdgcn_rcpf(depth));
+                const float m = (GSR_FARK * GSR_NEAR) * (r_ref - __builtin_amdgcn_rcpf(depth));
                 const float mm = m * m;
                 dist = fmaf(fmaf(mm, A, M2) - 2.f * m * M1, w, dist);
                 Dp = fmaf(depth, w, Dp);
@@ -243,6 +249,8 @@ __global__ __launch_bounds__(GDR_BLOCK) void surfel_render_bwd_kernel(
     const int rounds = (total + GDR_BLOCK - 1) / GDR_BLOCK;
 
     if (threadIdx.x == 0) { null_entry(lds); s_id[GDR_NULL_ENTRY] = 0; }
+    // reference depth of the shifted normalised depth m' (see K6s): the tile's FIRST list entry
+    const float r_ref = total > 0 ? __builtin_amdgcn_rcpf(fmaxf(rec[6 * (size_t)point_list[range.x] + 2].z, GSR_NEAR)) : 1.f;
     const float T_final = inside ? final_T[pix] : 0.f;
     const float final_D = inside ? final_T[P + pix] : 0.f, final_D2 = inside ? final_T[2 * P + pix] : 0.f;
     const float final_A = 1.f - T_final;
@@ -319,7 +327,7 @@ __global__ __launch_bounds__(GDR_BLOCK) void surfel_render_bwd_kernel(
                 T = T * r_oma;
                 const float w = a * T;
                 const float rd = __builtin_amdgcn_rcpf(depth);
-                const float m_d = GSR_FARK * (1.f - GSR_NEAR * rd);
+                const float m_d = (GSR_FARK * GSR_NEAR) * (r_ref - rd);
                 const float dmd_dd = (GSR_FARK * GSR_NEAR) * rd * rd;
                 const float dLw = (fmaf(m_d * m_d, final_A, final_D2) - 2.f * m_d * final_D) * gReg;
                 const float d0 = en.nr.w - B0, d1 = en.gb.x - B1, d2 = en.gb.y - B2;
