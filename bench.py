@@ -180,6 +180,7 @@ def main():
     if surfel:
         from generativedensification_amd.camera import build_rays
         from generativedensification_amd.renderer_2dgs import Renderer as Renderer2D
+        from generativedensification_amd.losses import surfel_view_loss_fused
         from generativedensification_amd.synthetic import surfel_loss
 
         renderer = Renderer2D(sh_degree=deg, white_background=True, fused=not args.unfused)
@@ -193,7 +194,15 @@ def main():
     def step():
         for p in plist:
             p.grad = None
-        if surfel:          # 2DGS adaptor: one render_img (image + depth/normal/distortion maps) + backward per view
+        if surfel and not (args.per_view or args.torch_loss or args.unfused):
+            # all views of the shard in one surfel node + fused loss kernels (maps never materialised)
+            outs = renderer.render_views(cams, rays, None, params["centers"], params["shs"], params["opacity"],
+                                         params["scales"], params["rotations"], dev, raw=True)
+            lv = torch.stack([surfel_view_loss_fused(o["color"], o["allmap"], rays[j], cams[j].world_view_transform,
+                                                     targets_chw[j]) for j, o in enumerate(outs)])
+            lv.sum().backward()
+            losses = lv.detach()
+        elif surfel:        # 2DGS adaptor: one render_img (image + depth/normal/distortion maps) + backward per view
             losses = []
             for j, cam in enumerate(cams):
                 out = renderer.render_img(cam, rays[j], params["centers"], params["shs"], params["opacity"],
@@ -345,10 +354,13 @@ def main():
                        "views_per_gpu": vpg, "image": [h, w], "sh_degree": deg,
                        "num_rendered_per_view": int(d_mean), "parallelism": f"view-sharded x{world}",
                        "grad_allreduce": bool(args.grad_allreduce),
-                       "entry": ("renderer_2dgs.render_img per view" if surfel else "render_img per view" if args.per_view
+                       "entry": ("renderer_2dgs.render_views (all views of the shard, one node)" if surfel and not (args.per_view or args.torch_loss or args.unfused)
+                                 else "renderer_2dgs.render_img per view" if surfel else "render_img per view" if args.per_view
                                  else "render_views (all views of the shard, one node)")
                        + (", torch activations" if args.unfused else ", activations fused into K1/K9"),
-                       "loss": ("torch ops (MSE + 1000 distortion + 0.2 normal consistency + 0.1 depth + 0.1 alpha)" if surfel
+                       "loss": ("fused HIP kernels (MSE + 1000 distortion + 0.2 normal consistency + 0.1 depth + 0.1 alpha)"
+                                if surfel and not (args.per_view or args.torch_loss or args.unfused)
+                                else "torch ops (MSE + 1000 distortion + 0.2 normal consistency + 0.1 depth + 0.1 alpha)" if surfel
                                 else "torch ops" if (args.per_view or args.stacked_loss or args.torch_loss or args.unfused)
                                 else "fused HIP kernel (clamp+MSE+0.1 mean depth+0.1 mean alpha)")},
             "roofline": roofline, "cpu_baseline": cpu_baseline, "kernels": kernels,

@@ -648,4 +648,31 @@ int gsr_maps_backward(const float* allmap, const float* rays, const float* viewm
     return GDR_OK;
 }
 
+int gsr_view_loss_forward(const float* color, const float* allmap, const float* rays, const float* viewmatrix,
+                          const float* target, int32_t H, int32_t W, float depth_ratio, float w_dist, float w_normal,
+                          float w_depth, float w_alpha, float* loss, void* stream) {
+    if (!color || !allmap || !rays || !viewmatrix || !target || !loss || H <= 0 || W <= 0) {
+        set_error("gsr_view_loss_forward: bad argument", hipSuccess);
+        return GDR_ERR_INVALID_ARG;
+    }
+    hipError_t e = launch_surfel_loss_fwd(color, allmap, rays, viewmatrix, target, H, W, depth_ratio, w_dist, w_normal,
+                                          w_depth, w_alpha, loss, (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail("surfel_loss_fwd", e);
+    return GDR_OK;
+}
+
+int gsr_view_loss_backward(const float* color, const float* allmap, const float* rays, const float* viewmatrix,
+                           const float* target, int32_t H, int32_t W, float depth_ratio, float w_dist, float w_normal,
+                           float w_depth, float w_alpha, const float* g, float* scratch, float* dL_dcolor,
+                           float* dL_dallmap, void* stream) {
+    if (!color || !allmap || !rays || !viewmatrix || !target || !scratch || !dL_dcolor || !dL_dallmap || H <= 0 || W <= 0) {
+        set_error("gsr_view_loss_backward: bad argument", hipSuccess);
+        return GDR_ERR_INVALID_ARG;
+    }
+    hipError_t e = launch_surfel_loss_bwd(color, allmap, rays, viewmatrix, target, H, W, depth_ratio, w_dist, w_normal,
+                                          w_depth, w_alpha, g, scratch, dL_dcolor, dL_dallmap, (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail("surfel_loss_bwd", e);
+    return GDR_OK;
+}
+
 }  // extern "C"

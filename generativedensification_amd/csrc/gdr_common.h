@@ -120,6 +120,14 @@ hipError_t launch_surfel_maps_bwd(const float* allmap, const float* rays, const 
                                   const float* g_depth, const float* g_acc, const float* g_rn, const float* g_dn,
                                   const float* g_dist, float* scratch, float* dL_dallmap, hipStream_t st);
 
+hipError_t launch_surfel_loss_fwd(const float* color, const float* allmap, const float* rays, const float* view,
+                                  const float* target, int H, int W, float r, float w_dist, float w_normal, float w_depth,
+                                  float w_alpha, float* loss, hipStream_t st);
+hipError_t launch_surfel_loss_bwd(const float* color, const float* allmap, const float* rays, const float* view,
+                                  const float* target, int H, int W, float r, float w_dist, float w_normal, float w_depth,
+                                  float w_alpha, const float* g, float* scratch, float* dL_dcolor, float* dL_dallmap,
+                                  hipStream_t st);
+
 size_t sort_hist_bytes(uint64_t D);
 
 }  // namespace gdr

@@ -51,3 +51,49 @@ def view_loss_fused(color_chw: torch.Tensor, depth: torch.Tensor, alpha: torch.T
     if not color_chw.is_cuda:
         raise RuntimeError("view_loss_fused runs on ROCm/HIP tensors only")
     return _ViewLoss.apply(color_chw, depth, alpha, target_chw, w_depth, w_alpha)
+
+
+class _SurfelViewLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, color, allmap, rays, viewmatrix, target_chw, depth_ratio, w_dist, w_normal, w_depth, w_alpha):
+        lib = L.load()
+        dev = color.device
+        color, allmap = color.contiguous(), allmap.contiguous()
+        rays = rays.to(device=dev, dtype=torch.float32).contiguous()
+        view = viewmatrix.to(device=dev, dtype=torch.float32).contiguous()
+        H, W = int(color.shape[-2]), int(color.shape[-1])
+        w = (float(depth_ratio), float(w_dist), float(w_normal), float(w_depth), float(w_alpha))
+        loss = torch.zeros((), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+            L.check(lib.gsr_view_loss_forward(color.data_ptr(), allmap.data_ptr(), rays.data_ptr(), view.data_ptr(),
+                                              target_chw.data_ptr(), H, W, *w, loss.data_ptr(), st), "gsr_view_loss_forward")
+        ctx.save_for_backward(color, allmap, rays, view, target_chw)
+        ctx.w, ctx.hw = w, (H, W)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = L.load()
+        color, allmap, rays, view, target = ctx.saved_tensors
+        H, W = ctx.hw
+        dev = color.device
+        g = g.to(torch.float32).contiguous()
+        dc, da = torch.empty_like(color), torch.empty_like(allmap)
+        scratch = torch.empty(9, H, W, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+            L.check(lib.gsr_view_loss_backward(color.data_ptr(), allmap.data_ptr(), rays.data_ptr(), view.data_ptr(),
+                                               target.data_ptr(), H, W, *ctx.w, g.data_ptr(), scratch.data_ptr(),
+                                               dc.data_ptr(), da.data_ptr(), st), "gsr_view_loss_backward")
+        return dc, da, None, None, None, None, None, None, None, None
+
+
+def surfel_view_loss_fused(color_chw, allmap, rays, viewmatrix, target_chw, depth_ratio=0.0, w_dist=1000.0, w_normal=0.2,
+                           w_depth=0.1, w_alpha=0.1) -> torch.Tensor:
+    """`synthetic.surfel_loss` of the dict the 2DGS adaptor would return for (color, allmap), without materialising the
+    dict: color (3,H,W) UNclamped, allmap (7,H,W), rays (H,W,6), viewmatrix = cam.world_view_transform, target (3,H,W)."""
+    if not color_chw.is_cuda:
+        raise RuntimeError("surfel_view_loss_fused runs on ROCm/HIP tensors only")
+    return _SurfelViewLoss.apply(color_chw, allmap, rays, viewmatrix, target_chw, depth_ratio, w_dist, w_normal, w_depth,
+                                 w_alpha)

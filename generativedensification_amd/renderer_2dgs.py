@@ -24,7 +24,7 @@ from torch import nn
 
 from . import _lib as L
 from .rasterizer import GaussianRasterizationSettings
-from .surfel_rasterizer import GaussianRasterizer, _RasterizeSurfels
+from .surfel_rasterizer import GaussianRasterizer, _RasterizeSurfels, render_surfel_views_raw
 
 RAW_ALL = L.GDR_IN_RAW_OPACITY | L.GDR_IN_RAW_SCALES | L.GDR_IN_RAW_ROTATIONS
 
@@ -124,6 +124,43 @@ class Renderer(nn.Module):
             viewmatrix=viewpoint_camera.world_view_transform, projmatrix=viewpoint_camera.full_proj_transform,
             sh_degree=self.sh_degree, campos=viewpoint_camera.camera_center, prefiltered=False, debug=False)
         return GaussianRasterizer(raster_settings=settings)
+
+    def render_views(self, cams, rays_list, bg_colors, centers, shs, opacity, scales, rotations, device, prex="",
+                     depth_ratio=0.0, screenspace_points=None, raw=False):
+        """All `cams` of one surfel set in ONE rasterizer node (the per-view loops of network.py:826-838 / 964-972 with
+        the 2DGS adaptor): K1s for every view, one read-back of the duplicate counts, gradients summed over the views
+        inside K9s.  Returns the list of dicts render_img(cam, rays, ...) returns, or with raw=True per-view dicts in the
+        rasterizer's own layout {color (3,H,W) UNclamped, allmap (7,H,W)} for a loss that folds the maps in
+        (losses.surfel_view_loss_fused).  bg_colors: None, one tensor, or one per view."""
+        sets = []
+        for j, cam in enumerate(cams):
+            if bg_colors is not None:
+                self.set_bg_color(bg_colors[j] if isinstance(bg_colors, (list, tuple)) else bg_colors)
+            sets.append(self.set_rasterizer(cam, device=device).raster_settings)
+        if screenspace_points is None:
+            screenspace_points = torch.zeros((centers.shape[0], 4), dtype=centers.dtype, requires_grad=True,
+                                             device=device) + 0
+        try:
+            screenspace_points.retain_grad()
+        except Exception:
+            pass
+        if self.fused:
+            colors, radii, allmaps = render_surfel_views_raw(centers, screenspace_points, shs, opacity, scales, rotations,
+                                                             sets, RAW_ALL)
+        else:
+            colors, radii, allmaps = render_surfel_views_raw(
+                centers, screenspace_points, shs, self.get_opacity(opacity), self.get_scaling(scales),
+                self.get_rotation(rotations), sets, 0)
+        if raw:
+            return [{f"color{prex}": c, f"allmap{prex}": a} for c, a in zip(colors, allmaps)]
+        outs = []
+        for v, cam in enumerate(cams):
+            depth, acc, rend_normal, depth_normal, rend_dist = _SurfelMaps.apply(allmaps[v], rays_list[v],
+                                                                                 cam.world_view_transform, float(depth_ratio))
+            outs.append({f"image{prex}": colors[v].clamp(0, 1).permute(1, 2, 0), f"depth{prex}": depth,
+                         f"acc_map{prex}": acc, f"rend_normal{prex}": rend_normal, f"depth_normal{prex}": depth_normal,
+                         f"rend_dist{prex}": rend_dist})
+        return outs
 
     def render_img(self, cam, rays, centers, shs, opacity, scales, rotations, device, cov3D_precomp=None, prex="",
                    depth_ratio=0.0, screenspace_points=None):

@@ -172,6 +172,115 @@ class _RasterizeSurfels(torch.autograd.Function):
         return (*grads, None, None)
 
 
+# --------------------------------------------------------------------------------------------
+# Multi-view node (SURVEY §8f-1 for the surfel path): V views of ONE surfel set in one autograd node — K1s for every
+# view without a host sync, ONE read-back of the V duplicate counts, binning + K6s per view; backward runs K7s + K9s
+# per view with K9s ACCUMULATING into one set of gradient buffers (no autograd accumulation passes).
+# --------------------------------------------------------------------------------------------
+class _RenderSurfelViews(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, opacities, scales, rotations, settings_list, flags):
+        lib = L.load()
+        _require_hip(means3D, "means3D")
+        dev = means3D.device
+        in_dtypes = tuple(t.dtype for t in (means3D, means2D, sh, opacities, scales, rotations))
+        means3D, sh = _f32(means3D, dev), _f32(sh, dev)
+        opacities, scales, rotations = _f32(opacities, dev), _f32(scales, dev), _f32(rotations, dev)
+        N, M, V = int(means3D.shape[0]), int(sh.shape[1]), len(settings_list)
+        H, W = int(settings_list[0].image_height), int(settings_list[0].image_width)
+        if scales.shape[-1] != 2:
+            raise RuntimeError("diff_surfel_rasterization: scales must be (N,2)")
+        e = torch.empty(0, dtype=torch.float32, device=dev)
+        keep = [means3D, opacities, sh, e, scales, rotations, e, int(flags)]
+        f32, u8 = dict(dtype=torch.float32, device=dev), dict(dtype=torch.uint8, device=dev)
+        colors = [torch.empty(3, H, W, **f32) for _ in range(V)]
+        allmaps = [torch.empty(7, H, W, **f32) for _ in range(V)]
+        radii = torch.empty(V, N, dtype=torch.int32, device=dev)
+        states, structs = [], []
+        with torch.cuda.device(dev):
+            stream = _stream()
+            inp = _inputs_struct(N, M, means3D, opacities, sh, e, scales, rotations, e, flags)
+            for v, rs in enumerate(settings_list):
+                s = _settings_struct(rs, dev, keep)
+                st = _SurfelState()
+                st.N, st.M, st.H, st.W = N, M, int(rs.image_height), int(rs.image_width)
+                st.geom_buf = torch.empty(lib.gsr_geom_bytes(N), **u8)
+                st.img_buf = torch.empty(lib.gsr_image_bytes(st.H, st.W), **u8)
+                st.geom, st.bin, st.img = L.GdrGeom(), L.GdrBinning(), L.GdrImage()
+                L.check(lib.gsr_geom_carve(st.geom_buf.data_ptr(), N, C.byref(st.geom)), "gsr_geom_carve")
+                L.check(lib.gsr_image_carve(st.img_buf.data_ptr(), st.H, st.W, C.byref(st.img)), "gsr_image_carve")
+                L.check(lib.gsr_preprocess_forward(C.byref(s), C.byref(inp), C.byref(st.geom), _ptr(radii[v]), None, stream),
+                        "gsr_preprocess_forward")
+                states.append(st)
+                structs.append(s)
+            d_host = torch.cat([st._view(st.geom_buf, st.geom.num_rendered, torch.int32, 1) for st in states]).cpu().tolist()
+            for v, st in enumerate(states):
+                st.D = int(d_host[v]) & 0xFFFFFFFF
+                st.bin_buf = torch.empty(lib.gdr_binning_bytes(st.D), **u8)
+                L.check(lib.gdr_binning_carve(st.bin_buf.data_ptr(), st.D, C.byref(st.bin)), "gdr_binning_carve")
+                st.bin.global_sort = int(_R._FORCE_GLOBAL_SORT)
+                out = L.GsrOutputs(colors[v].data_ptr(), allmaps[v].data_ptr(), _ptr(radii[v]))
+                L.check(lib.gsr_render_forward(C.byref(structs[v]), C.byref(inp), C.byref(st.geom), C.byref(st.bin),
+                                               C.byref(st.img), st.D, C.byref(out), stream), "gsr_render_forward")
+        ctx.states, ctx.keep, ctx.settings_list, ctx.radii, ctx.flags = states, keep, settings_list, radii, int(flags)
+        ctx.means2D_shape, ctx.in_dtypes, ctx.V = tuple(means2D.shape), in_dtypes, V
+        ctx.mark_non_differentiable(radii)
+        return (radii, *colors, *allmaps)
+
+    @staticmethod
+    def backward(ctx, g_radii, *g):
+        lib = L.load()
+        V = ctx.V
+        means3D, opacities, sh, _, scales, rotations, _, flags = ctx.keep[:8]
+        dev = means3D.device
+        N, M = int(means3D.shape[0]), int(sh.shape[1])
+        f32 = dict(dtype=torch.float32, device=dev)
+        out = dict(means3D=torch.empty(N, 3, **f32), means2D=torch.empty(N, 4, **f32), shs=torch.empty(N, M, 3, **f32),
+                   opacities=torch.empty(N, 1, **f32), scales=torch.empty(N, 2, **f32), rotations=torch.empty(N, 4, **f32))
+        scratch = torch.empty(max(N, 1) * L.GSR_GRAD_FLOATS, **f32)
+        e = torch.empty(0, dtype=torch.float32, device=dev)
+        first = True
+        with torch.cuda.device(dev):
+            stream = _stream()
+            inp = _inputs_struct(N, M, means3D, opacities, sh, e, scales, rotations, e, flags)
+            for v in range(V):
+                gc, ga = g[v], g[V + v]
+                if gc is None and ga is None:
+                    continue
+                st = ctx.states[v]
+                gc = torch.zeros(3, st.H, st.W, **f32) if gc is None else _f32(gc, dev)
+                ga = None if ga is None else _f32(ga, dev)
+                keep2: list = []
+                s = _settings_struct(ctx.settings_list[v], dev, keep2)
+                gin = L.GsrGradInputs(gc.data_ptr(), _ptr(ga))
+                gout = L.GsrGradOutputs(_ptr(out["means3D"]), _ptr(out["means2D"]), _ptr(out["shs"]), None,
+                                        _ptr(out["opacities"]), _ptr(out["scales"]), _ptr(out["rotations"]), None,
+                                        scratch.data_ptr(), 0 if first else 1, 0)
+                L.check(lib.gsr_backward(C.byref(s), C.byref(inp), C.byref(st.geom), C.byref(st.bin), C.byref(st.img), st.D,
+                                         _ptr(ctx.radii[v]), C.byref(gin), C.byref(gout), stream), "gsr_backward")
+                first = False
+        if first:
+            for t in out.values():
+                t.zero_()
+        gm2 = out["means2D"]
+        cols = ctx.means2D_shape[1] if len(ctx.means2D_shape) == 2 else 4
+        if cols == 3:
+            gm2 = torch.cat([gm2[:, :2], torch.zeros_like(gm2[:, :1])], dim=1)
+        elif cols != 4:
+            gm2 = gm2[:, :cols].contiguous()
+        grads = [out["means3D"], gm2, out["shs"], out["opacities"], out["scales"], out["rotations"]]
+        grads = [t if t.dtype == dt else t.to(dt) for t, dt in zip(grads, ctx.in_dtypes)]
+        return (*grads, None, None)
+
+
+def render_surfel_views_raw(means3D, means2D, sh, opacities, scales, rotations, settings_list, flags=0):
+    """All views of one surfel set in one node.  opacities / scales (N,2) / rotations are RAW when the matching
+    GDR_IN_RAW_* flag is set.  Returns (colors [V x (3,H,W)], radii (V,N), allmaps [V x (7,H,W)])."""
+    V = len(settings_list)
+    res = _RenderSurfelViews.apply(means3D, means2D, sh, opacities, scales, rotations, list(settings_list), int(flags))
+    return list(res[1:1 + V]), res[0], list(res[1 + V:1 + 2 * V])
+
+
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                         raster_settings):
     return _RasterizeSurfels.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,

@@ -112,6 +112,21 @@ int gsr_maps_backward(const float* allmap, const float* rays, const float* viewm
                       const float* g_depth_normal, const float* g_rend_dist, float* scratch, float* dL_dallmap,
                       void* stream);
 
+/* ---- fused image-space loss of the surfel path ----------------------------------------------------
+ * loss += mean_{c,p}(clamp(color,0,1) - target)^2 + w_dist mean(rend_dist)
+ *       + w_normal mean((1 - <rend_normal, depth_normal>) acc_map.detach()) + w_depth mean(depth) + w_alpha mean(acc_map)
+ * on the maps gsr_maps_forward would produce (never materialised): renderer_2dgs.py:236 clamp, loss.py:37-38 MSE,
+ * loss.py:49-61 distortion (x1000) and normal consistency (x0.2); the depth / alpha means are the measurement loss's
+ * coverage terms.  color, target: (3,H,W); loss: device float the caller zeroes; g: device pointer to the
+ * upstream scalar (NULL = 1); scratch: 9*H*W floats. */
+int gsr_view_loss_forward(const float* color, const float* allmap, const float* rays, const float* viewmatrix,
+                          const float* target, int32_t H, int32_t W, float depth_ratio, float w_dist, float w_normal,
+                          float w_depth, float w_alpha, float* loss, void* stream);
+int gsr_view_loss_backward(const float* color, const float* allmap, const float* rays, const float* viewmatrix,
+                           const float* target, int32_t H, int32_t W, float depth_ratio, float w_dist, float w_normal,
+                           float w_depth, float w_alpha, const float* g, float* scratch, float* dL_dcolor,
+                           float* dL_dallmap, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -290,3 +290,54 @@ def test_nan_upstream_gradients_at_empty_pixels_do_not_leak():
         if v is not None:
             assert torch.isfinite(dirty[k]).all(), k
             torch.testing.assert_close(dirty[k], v, rtol=1e-5, atol=1e-6 * float(v.abs().max()), msg=k)
+
+
+def test_surfel_multiview_node_and_fused_loss_match_the_per_view_sequence():
+    """Renderer2D.render_views (one node, K9s accumulating over views) + losses.surfel_view_loss_fused == the
+    reference's sequence: render_img per view (torch activations) + synthetic.surfel_loss (torch ops) + autograd sum."""
+    from generativedensification_amd.camera import build_rays, orbit_cameras
+    from generativedensification_amd.losses import surfel_view_loss_fused
+    from generativedensification_amd.renderer_2dgs import Renderer
+    from generativedensification_amd.synthetic import make_scene, make_targets, surfel_loss
+
+    dev = torch.device("cuda:0")
+    n, h, w, V = 20_000, 144, 176, 3
+    sc = make_scene(n, 77, sh_degree=3, sigma0=(0.0052, 0.02))
+    sc["scales"] = sc["scales"][:, :2].contiguous()
+    sc["shs"][:, 0] *= 2.0
+    cams = orbit_cameras(V, w, h, device=dev)
+    rays = [build_rays(torch.inverse(c.world_view_transform.T.cpu()), 0.75, 0.75, h, w).to(dev) for c in cams]
+    tg = make_targets(V, h, w, 77).to(dev)
+    tg_chw = tg.permute(0, 3, 1, 2).contiguous()
+    bgs = [torch.tensor(c, device=dev) for c in ([1.0, 1.0, 1.0], [0.5, 0.5, 0.5], [0.0, 0.0, 0.0])]
+    wts = torch.tensor([0.7, 1.9, 1.0], device=dev)
+
+    def run(mode):
+        r = Renderer(sh_degree=3, fused=(mode != "reference"))
+        leaves = {k: v.to(dev).clone().requires_grad_(True) for k, v in sc.items()}
+        ssp = torch.zeros(n, 4, device=dev, requires_grad=True)
+        args = (leaves["centers"], leaves["shs"], leaves["opacity"], leaves["scales"], leaves["rotations"], dev)
+        if mode == "reference":
+            outs = []
+            for c, ry, b in zip(cams, rays, bgs):
+                r.set_bg_color(b)
+                outs.append(r.render_img(c, ry, *args, depth_ratio=0.3, screenspace_points=ssp))
+            lv = torch.stack([surfel_loss(o, tg[j]) for j, o in enumerate(outs)])
+        elif mode == "views":
+            outs = r.render_views(cams, rays, bgs, *args, depth_ratio=0.3, screenspace_points=ssp)
+            lv = torch.stack([surfel_loss(o, tg[j]) for j, o in enumerate(outs)])
+        else:
+            outs = r.render_views(cams, rays, bgs, *args, screenspace_points=ssp, raw=True)
+            lv = torch.stack([surfel_view_loss_fused(o["color"], o["allmap"], rays[j], cams[j].world_view_transform,
+                                                     tg_chw[j], depth_ratio=0.3) for j, o in enumerate(outs)])
+        grads = torch.autograd.grad((lv * wts).sum(), list(leaves.values()) + [ssp])
+        return lv.detach().cpu().numpy(), {k: g_.cpu().numpy() for k, g_ in zip(list(leaves) + ["ssp"], grads)}
+
+    l_ref, g_ref = run("reference")
+    for mode in ("views", "fused_loss"):
+        l, g = run(mode)
+        np.testing.assert_allclose(l, l_ref, rtol=2e-5, err_msg=mode)
+        for k in g_ref:
+            assert U.rel_inf(g[k], g_ref[k]) < 2e-4, (mode, k)
+            assert U.outlier_fraction(g[k], g_ref[k], 1e-3, 1e-5 * np.abs(g_ref[k]).max()) < 1e-3, (mode, k)
+        assert g["ssp"].shape == (n, 4) and (g["ssp"][:, 2:] >= 0).all()
