@@ -150,6 +150,8 @@ _PROTOS = {
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gsr_view_loss_forward": (C.c_int, [C.c_void_p] * 5 + [C.c_int32, C.c_int32] + [C.c_float] * 5 + [C.c_void_p, C.c_void_p]),
     "gsr_view_loss_backward": (C.c_int, [C.c_void_p] * 5 + [C.c_int32, C.c_int32] + [C.c_float] * 5 + [C.c_void_p] * 5),
+    "gsr_knn_cells": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "gsr_knn_mean_dist2": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gsr_backward": (C.c_int, [C.POINTER(GdrSettings), C.POINTER(GsrInputs), C.POINTER(GdrGeom), C.POINTER(GdrBinning),
                                C.POINTER(GdrImage), C.c_uint64, C.c_void_p, C.POINTER(GsrGradInputs),
                                C.POINTER(GsrGradOutputs), C.c_void_p]),

@@ -431,7 +431,7 @@ int gdr_profile_collect(double* ms_total, uint64_t* launches, int32_t n, int32_t
 const char* gdr_kernel_name(int32_t id) {
     static const char* names[GDR_K_COUNT] = {"preprocess_fwd", "scan_block_sums", "duplicate_with_keys",
         "sort_hist", "sort_rowscan", "sort_scatter", "tile_ranges", "render_fwd", "render_bwd",
-        "preprocess_bwd", "mark_visible", "tile_order", "tile_sort", "tile_sort_long", "view_loss", "surfel_maps"};
+        "preprocess_bwd", "mark_visible", "tile_order", "tile_sort", "tile_sort_long", "view_loss", "surfel_maps", "knn"};
     return (id >= 0 && id < GDR_K_COUNT) ? names[id] : "";
 }
 int gdr_kernel_count(void) { return GDR_K_COUNT; }
@@ -672,6 +672,24 @@ int gsr_view_loss_backward(const float* color, const float* allmap, const float*
     hipError_t e = launch_surfel_loss_bwd(color, allmap, rays, viewmatrix, target, H, W, depth_ratio, w_dist, w_normal,
                                           w_depth, w_alpha, g, scratch, dL_dcolor, dL_dallmap, (hipStream_t)stream);
     if (e != hipSuccess) return hip_fail("surfel_loss_bwd", e);
+    return GDR_OK;
+}
+
+int gsr_knn_cells(const float* points, int32_t N, const float* bbox, int32_t G, int32_t* cell, void* stream) {
+    if (N < 0 || G < 1 || G > 1024 || (N > 0 && (!points || !bbox || !cell))) { set_error("gsr_knn_cells: bad argument", hipSuccess); return GDR_ERR_INVALID_ARG; }
+    hipError_t e = launch_knn_cells(points, N, bbox, G, cell, (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail("knn_cells", e);
+    return GDR_OK;
+}
+
+int gsr_knn_mean_dist2(const float* points_sorted, int32_t N, const float* bbox, int32_t G, const int32_t* cell_start,
+                       float* out, void* stream) {
+    if (N < 0 || G < 1 || G > 1024 || (N > 0 && (!points_sorted || !bbox || !cell_start || !out))) {
+        set_error("gsr_knn_mean_dist2: bad argument", hipSuccess);
+        return GDR_ERR_INVALID_ARG;
+    }
+    hipError_t e = launch_knn_mean_dist2(points_sorted, N, bbox, G, cell_start, out, (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail("knn_mean_dist2", e);
     return GDR_OK;
 }
 

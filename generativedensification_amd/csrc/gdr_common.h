@@ -35,6 +35,7 @@ enum {
     GDR_K_TILE_SORT_LONG,
     GDR_K_VIEW_LOSS,
     GDR_K_SURFEL_MAPS,
+    GDR_K_KNN,
     GDR_K_COUNT
 };
 
@@ -127,6 +128,10 @@ hipError_t launch_surfel_loss_bwd(const float* color, const float* allmap, const
                                   const float* target, int H, int W, float r, float w_dist, float w_normal, float w_depth,
                                   float w_alpha, const float* g, float* scratch, float* dL_dcolor, float* dL_dallmap,
                                   hipStream_t st);
+
+hipError_t launch_knn_cells(const float* pts, int N, const float* bbox, int G, int32_t* cell, hipStream_t st);
+hipError_t launch_knn_mean_dist2(const float* pts_sorted, int N, const float* bbox, int G, const int32_t* cell_start,
+                                 float* out, hipStream_t st);
 
 size_t sort_hist_bytes(uint64_t D);
 

@@ -47,6 +47,15 @@ def depth_to_normal(rays: torch.Tensor, depth: torch.Tensor):
     return normal, pts
 
 
+@torch.no_grad()
+def _activation_scale(x: torch.Tensor) -> torch.Tensor:
+    """Initial isotropic surfel scale (N,2) = distance-scale of the 3 nearest neighbours: sqrt(clamp_min(distCUDA2(x),
+    1e-7)) repeated on both axes (renderer_2dgs.py:92-96)."""
+    from .knn import dist2
+
+    return torch.sqrt(torch.clamp_min(dist2(x), 0.0000001))[..., None].repeat(1, 2)
+
+
 class _SurfelMaps(torch.autograd.Function):
     """allmap -> (depth (H,W,1), acc_map (H,W), rend_normal (H,W,3), depth_normal (H,W,3), rend_dist (H,W)) in one HIP
     kernel forward and two backward (include/gsr.h gsr_maps_*): the lines 241-278 of the reference adaptor."""

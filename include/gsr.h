@@ -127,6 +127,17 @@ int gsr_view_loss_backward(const float* color, const float* allmap, const float*
                            float w_depth, float w_alpha, const float* g, float* scratch, float* dL_dcolor,
                            float* dL_dallmap, void* stream);
 
+/* ---- simple_knn._C.distCUDA2 (renderer_2dgs.py:11,92-96) -----------------------------------------
+ * out[i] = mean of the squared distances from point i to its three nearest OTHER points (fp32).  Two stages around
+ * host plumbing (sort by cell, cell populations -> exclusive prefix):
+ *   gsr_knn_cells:      cell[i] = (cz*G + cy)*G + cx of point i in the G^3 grid over bbox (device float[6]: min, max)
+ *   gsr_knn_mean_dist2: points_sorted = the points in ascending cell order, cell_start = (G^3 + 1) exclusive prefix;
+ *                       out is in the SAME (sorted) order.  Exact (growing cubic shells until the third best is closer
+ *                       than the searched cube's nearest face). */
+int gsr_knn_cells(const float* points, int32_t N, const float* bbox, int32_t G, int32_t* cell, void* stream);
+int gsr_knn_mean_dist2(const float* points_sorted, int32_t N, const float* bbox, int32_t G, const int32_t* cell_start,
+                       float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -489,3 +489,27 @@ void oracle_surfel_preprocess_bwd(int N, int deg, int M, const real* means3D, co
         for (int k = 0; k < 3; ++k) dL_dmeans3D[3 * i + k] = dmean[k];
     }
 }
+
+/* ------------------------------------------------------------------------- */
+/* simple_knn.distCUDA2 (renderer_2dgs.py:11,92-96): brute-force restatement.  out[i] = (d1 + d2 + d3) / 3 with d_k   */
+/* the squared distances of the three nearest OTHER points (by index), +inf terms when fewer than four points exist.   */
+/* ------------------------------------------------------------------------- */
+void oracle_knn_mean_dist2(int N, const real* pts, real* out, int nthreads) {
+    (void)nthreads;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(nthreads > 0 ? nthreads : 1)
+#endif
+    for (int i = 0; i < N; ++i) {
+        real b0 = (real)INFINITY, b1 = (real)INFINITY, b2 = (real)INFINITY;
+        const real px = pts[3 * i], py = pts[3 * i + 1], pz = pts[3 * i + 2];
+        for (int j = 0; j < N; ++j) {
+            if (j == i) continue;
+            const real dx = pts[3 * j] - px, dy = pts[3 * j + 1] - py, dz = pts[3 * j + 2] - pz;
+            real d = dx * dx + dy * dy + dz * dz;
+            if (d < b0) { real t = b0; b0 = d; d = t; }
+            if (d < b1) { real t = b1; b1 = d; d = t; }
+            if (d < b2) b2 = d;
+        }
+        out[i] = (b0 + b1 + b2) / RC(3);
+    }
+}

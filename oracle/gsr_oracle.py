@@ -199,19 +199,24 @@ def make_surfel_standin_module(precision: str = "f32") -> types.ModuleType:
 
 
 def make_simple_knn_stub():
-    """`simple_knn` + `simple_knn._C` with distCUDA2 = mean squared distance to the 3 nearest neighbours (the
-    published meaning; O(N^2) numpy, small N only) — renderer_2dgs.py:11,94 imports it at module import."""
+    """`simple_knn` + `simple_knn._C` with distCUDA2 = the brute-force oracle (CPU tensors, small N) —
+    renderer_2dgs.py:11 imports it at module import."""
     import torch
 
     def distCUDA2(x):
-        a = x.detach().cpu().double().numpy()
-        d2 = ((a[:, None, :] - a[None, :, :]) ** 2).sum(-1)
-        np.fill_diagonal(d2, np.inf)
-        k = min(3, max(a.shape[0] - 1, 1))
-        return torch.from_numpy(np.sort(d2, axis=1)[:, :k].mean(1)).to(x.dtype)
+        return torch.from_numpy(knn_mean_dist2(x.detach().cpu().numpy(), "f32")).to(x.dtype)
 
     pkg = types.ModuleType("simple_knn")
     sub = types.ModuleType("simple_knn._C")
     sub.distCUDA2 = distCUDA2
     pkg._C = sub
     return pkg, sub
+
+
+def knn_mean_dist2(points, precision: str = "f32", nthreads: int = 1) -> np.ndarray:
+    """Brute-force restatement of simple_knn.distCUDA2 (oracle_knn_mean_dist2 in gsr_oracle.c)."""
+    o = SurfelOracle(precision, nthreads)
+    pts = o._a(points, (-1, 3))
+    out = np.zeros(pts.shape[0], o.rt)
+    o.lib.oracle_knn_mean_dist2(C.c_int(pts.shape[0]), _p(pts), _p(out), C.c_int(o.nthreads))
+    return out

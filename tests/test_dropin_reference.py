@@ -94,13 +94,22 @@ def _cleanup_2dgs(saved):
 
 
 def test_reference_2dgs_adaptor_imports_against_product_package_and_fails_loudly_on_cpu():
+    """No stand-ins at all: lightning/renderer_2dgs.py imports the PRODUCT `diff_surfel_rasterization` and the PRODUCT
+    `simple_knn._C.distCUDA2` (both HIP only)."""
     saved = sys.modules.pop("diff_surfel_rasterization", None)
+    for k in [k for k in sys.modules if k.startswith("simple_knn")]:
+        del sys.modules[k]
     import diff_surfel_rasterization as D  # the PRODUCT package (HIP only)
 
     assert not getattr(D, "__oracle_standin__", False)
     sys.path.insert(0, REF)
     try:
-        ref_2dgs, ref_utils = _import_ref_2dgs()
+        ref_2dgs, ref_utils = _fresh_import("lightning.renderer_2dgs"), _fresh_import("lightning.utils")
+        from generativedensification_amd.knn import dist2
+
+        assert ref_2dgs.distCUDA2 is dist2
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            ref_2dgs._activation_scale(torch.zeros(8, 3))
         assert ref_2dgs.GaussianRasterizer is D.GaussianRasterizer
         c2w = torch.eye(4)
         c2w[2, 3] = -2.0

@@ -341,3 +341,37 @@ def test_surfel_multiview_node_and_fused_loss_match_the_per_view_sequence():
             assert U.rel_inf(g[k], g_ref[k]) < 2e-4, (mode, k)
             assert U.outlier_fraction(g[k], g_ref[k], 1e-3, 1e-5 * np.abs(g_ref[k]).max()) < 1e-3, (mode, k)
         assert g["ssp"].shape == (n, 4) and (g["ssp"][:, 2:] >= 0).all()
+
+
+@pytest.mark.parametrize("kind,N", [("uniform", 50_000), ("clustered", 30_000), ("plane", 20_000), ("tiny", 5), ("three", 3)])
+def test_simple_knn_distcuda2_matches_brute_force(oracle_built, kind, N):
+    """simple_knn._C.distCUDA2 (HIP grid search, csrc/knn.hip) == the brute-force oracle: exact neighbours, fp32
+    rounding only (1e-5 relative)."""
+    from oracle.gsr_oracle import knn_mean_dist2
+    from simple_knn._C import distCUDA2
+
+    g = torch.Generator().manual_seed(N)
+    if kind == "uniform":
+        pts = torch.rand(N, 3, generator=g) - 0.5
+    elif kind == "clustered":   # two tight clusters far apart + exact duplicates + outliers: stresses the shell bound
+        a = 0.01 * torch.randn(N // 2, 3, generator=g) + torch.tensor([0.4, 0.4, 0.4])
+        b = 0.02 * torch.randn(N // 2 - 10, 3, generator=g) - torch.tensor([0.45, 0.3, 0.1])
+        pts = torch.cat([a, b, a[:5], 3.0 * torch.randn(5, 3, generator=g)])
+    elif kind == "plane":       # degenerate extent along z
+        pts = torch.cat([torch.rand(N, 2, generator=g), torch.zeros(N, 1)], 1)
+    else:
+        pts = torch.rand(N, 3, generator=g)
+    ref = knn_mean_dist2(pts.numpy(), "f64", nthreads=16)
+    got = distCUDA2(pts.to("cuda:0")).cpu().numpy()
+    assert got.shape == (N,) and got.dtype == np.float32
+    if N < 4:
+        assert np.isinf(got).all() and np.isinf(ref).all()
+        return
+    np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-12)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        distCUDA2(pts)
+    from generativedensification_amd.renderer_2dgs import _activation_scale
+
+    sc = _activation_scale(pts.to("cuda:0"))   # renderer_2dgs.py:92-96
+    assert sc.shape == (N, 2)
+    np.testing.assert_allclose(sc[:, 0].cpu().numpy(), np.sqrt(np.maximum(ref, 1e-7)), rtol=1e-5)

@@ -184,3 +184,25 @@ def test_openmp_threads_do_not_change_surfel_results_beyond_rounding(oracle_buil
     b1, b4 = o1.backward(f1, gc, ga), o4.backward(f4, gc, ga)
     for k in ("means3D", "scales", "rotations", "opacities", "shs", "means2D"):
         assert U.rel_inf(b4[k], b1[k]) < 1e-12, k
+
+
+def test_knn_oracle_known_answers(oracle_built):
+    """simple_knn.distCUDA2 restatement: unit lattice (every interior point has six neighbours at distance 1 ->
+    mean 1), coincident points (distance 0 counts), fewer than four points (inf), and a random set vs numpy."""
+    from oracle.gsr_oracle import knn_mean_dist2
+
+    g = np.stack(np.meshgrid(np.arange(5.0), np.arange(5.0), np.arange(5.0), indexing="ij"), -1).reshape(-1, 3)
+    d = knn_mean_dist2(g, "f64")
+    inner = ((g >= 1) & (g <= 3)).all(1)
+    np.testing.assert_allclose(d[inner], 1.0)
+    corner = (g == 0).all(1)
+    np.testing.assert_allclose(d[corner], 1.0)            # three axis neighbours at distance 1
+    pts = np.array([[0, 0, 0], [0, 0, 0], [1, 0, 0], [0, 2, 0], [5, 5, 5.0]])
+    d = knn_mean_dist2(pts, "f64")
+    np.testing.assert_allclose(d[0], (0 + 1 + 4) / 3)
+    np.testing.assert_allclose(d[2], (1 + 1 + 5) / 3)
+    assert np.isinf(knn_mean_dist2(pts[:3], "f64")).all() and knn_mean_dist2(np.zeros((0, 3)), "f32").shape == (0,)
+    r = np.random.default_rng(0).standard_normal((300, 3))
+    d2 = ((r[:, None] - r[None]) ** 2).sum(-1)
+    np.fill_diagonal(d2, np.inf)
+    np.testing.assert_allclose(knn_mean_dist2(r, "f64", nthreads=4), np.sort(d2, 1)[:, :3].mean(1), rtol=1e-12)
