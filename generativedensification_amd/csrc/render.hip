@@ -272,7 +272,7 @@ __global__ __launch_bounds__(GDR_BLOCK) void render_bwd_kernel(
     const uint32_t* __restrict__ tile_order, int W, int H, int gx, int ntiles,
     const float* __restrict__ bg, const float4* __restrict__ rec, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
     const float* __restrict__ dL_dpix, const float* __restrict__ dL_ddepthpix,
-    const float* __restrict__ dL_dalphapix, float* __restrict__ grad_rec, int wave_num8) {
+    const float* __restrict__ dL_dalphapix, float* __restrict__ grad_rec) {
     __shared__ SliceLds lds;
     __shared__ uint32_t s_id[GDR_BLOCK + 1];
 
@@ -347,20 +347,28 @@ __global__ __launch_bounds__(GDR_BLOCK) void render_bwd_kernel(
         }
         const int top = total - 1 - r * GDR_BLOCK;  // list position of LDS entry e: top - e
         if (top - (GDR_BLOCK - 1) >= wave_last) continue;  // whole slice behind every last contributor
-#pragma unroll 1
-        for (int g = 0; g < GDR_BLOCK / GDR_WAVE; ++g) {
+        // Row sub-lists of the slice's four 64-entry groups, one 64-bit mask per group and lane (all 16 lanes of a row
+        // hold the same four masks).  A row walks them back to back at its own pace — rows only re-synchronise at slice
+        // boundaries, so a row whose block has few entries in one group does not wait for the others there.
+        auto group_mask = [&](int g) -> uint64_t {
             const int gtop = top - g * GDR_WAVE;  // position of this group's entry 0
-            if (gtop - (GDR_WAVE - 1) >= wave_last) continue;
+            if (gtop - (GDR_WAVE - 1) >= wave_last) return 0ull;
             uint64_t m0, m1, m2, m3;
             const int mypos = gtop - (int)lane;
             block_masks(lds, g, XA, YA, mypos < rl0, mypos < rl1, mypos < rl2, mypos < rl3, m0, m1, m2, m3);
-            if ((m0 | m1 | m2 | m3) == 0ull) continue;
-            const uint32_t goff = (uint32_t)(g * GDR_WAVE), nulloff = GDR_NULL_ENTRY - goff;
-            const bool wave_mode = choose_wave_mode(m0, m1, m2, m3, wave_num8);
-            uint64_t mr = wave_mode ? (m0 | m1 | m2 | m3) : row_select(row, m0, m1, m2, m3);
-            auto fetch = [&](Entry& en) {
-                en.e = min(take_bit(mr), nulloff) + goff;
+            return row_select(row, m0, m1, m2, m3);
+        };
+        const uint64_t q0 = group_mask(0), q1 = group_mask(1), q2 = group_mask(2), q3 = group_mask(3);
+        if (__ballot((q0 | q1 | q2 | q3) != 0ull) == 0ull) continue;
+        {
+            uint32_t gi = 0u;
+            uint64_t mr = q0;
+            GDR_REFILL(mr, gi, q1, q2, q3);
+            auto fetch = [&](Entry& en) __attribute__((always_inline)) {
+                const uint32_t goff = gi << 6;
+                en.e = min(take_bit(mr), GDR_NULL_ENTRY - goff) + goff;  // 0xFFFFFFFF (no entry) -> null entry
                 en.m = lds.xy[en.e]; en.co = lds.co[en.e]; en.cd = lds.cd[en.e];
+                if (__ballot(mr == 0ull && gi < 3u) != 0ull) GDR_REFILL(mr, gi, q1, q2, q3);
             };
             auto accumulate = [&](const Entry& en) {
                 const float dx = en.m.x - pxf, dy = en.m.y - pyf;
@@ -396,19 +404,16 @@ __global__ __launch_bounds__(GDR_BLOCK) void render_bwd_kernel(
                 const float v_mx = dL_dG * (-gdx * en.co.x - gdy * en.co.y) * kx;
                 const float v_my = dL_dG * (-gdy * en.co.z - gdx * en.co.y) * ky;
                 if (M2_ONLY) {
-                    float tot4 = row_reduce_scatter4(v_mx, v_my, fabsf(v_mx), fabsf(v_my), li);
-                    bool publish4 = ((hb >> (16 * row)) & 0xFFFFull) != 0ull;
-                    if (wave_mode) { tot4 = wave_rows_sum(tot4); publish4 = row == 0u; }
-                    if ((li & 3u) == 0u && publish4)
+                    const float tot4 = row_reduce_scatter4(v_mx, v_my, fabsf(v_mx), fabsf(v_my), li);
+                    if ((li & 3u) == 0u && ((hb >> (16 * row)) & 0xFFFFull) != 0ull)
                         atomicAdd(grad_rec + 4 * (size_t)s_id[en.e] + (li >> 2), tot4);
                     return;
                 }
                 const float vals[12] = {v_mx, v_my, fabsf(v_mx), fabsf(v_my),
                                         -0.5f * gdx * dx * dL_dG, -gdx * dy * dL_dG, -0.5f * gdy * dy * dL_dG,
                                         w * gD, w * gC0, w * gC1, w * gC2, G * dL_dalpha};
-                float tot = row_reduce_scatter12(vals, li);
-                bool publish = ((hb >> (16 * row)) & 0xFFFFull) != 0ull;
-                if (wave_mode) { tot = wave_rows_sum(tot); publish = row == 0u; }  // lockstep: row 0 publishes
+                const float tot = row_reduce_scatter12(vals, li);
+                const bool publish = ((hb >> (16 * row)) & 0xFFFFull) != 0ull;
                 // lanes 0..11 of every row that had a hit add the row totals to the Gaussian's
                 // 64-byte gradient record: one global_atomic_add_f32 instruction, one cache line
                 // per row (no return value => fire and forget)
@@ -432,14 +437,6 @@ __global__ __launch_bounds__(GDR_BLOCK) void render_bwd_kernel(
 }
 
 }  // namespace
-
-// lockstep threshold in eighths (render_common.h choose_wave_mode); GDR_WAVE_MODE_NUM8 overrides for A/B runs.
-// Measured on MI355X for this kernel (one 64-byte atomic per row): 10/8 -> C2 K7 196 -> 184 us, C3 282 -> 290 us,
-// C4 unchanged; 12/8 worse everywhere => off by default here (the surfel K7s, two atomics per row, gains 11 %).
-static int wave_mode_num8() {
-    static const int v = [] { const char* e = getenv("GDR_WAVE_MODE_NUM8"); return e ? atoi(e) : 0; }();
-    return v;
-}
 
 hipError_t launch_tile_order(const gdr_image* img, int ntiles, hipStream_t st) {
     GDR_LAUNCH(GDR_K_TILE_ORDER, tile_order_kernel, dim3(1), dim3(GDR_BLOCK), st, (const uint2*)img->ranges,
@@ -467,7 +464,7 @@ hipError_t launch_render_bwd(const gdr_settings* s, const gdr_geom* g, const gdr
     GDR_LAUNCH(GDR_K_RENDER_BWD, render_bwd_kernel<false>, dim3(ntiles), dim3(GDR_BLOCK), st,
                (const uint2*)img->ranges, bin->values[bin->sorted], img->tile_order, W, H, gx, ntiles, s->bg,
                (const float4*)g->rec, img->final_T, img->n_contrib, gi->dL_dcolor, gi->dL_ddepth, gi->dL_dalpha,
-               go->scratch, wave_mode_num8());
+               go->scratch);
     return hipGetLastError();
 }
 
@@ -479,7 +476,7 @@ hipError_t launch_render_bwd_mean2d(const gdr_settings* s, const gdr_geom* g, co
     const int ntiles = gx * gy;
     GDR_LAUNCH(GDR_K_RENDER_BWD, render_bwd_kernel<true>, dim3(ntiles), dim3(GDR_BLOCK), st,
                (const uint2*)img->ranges, bin->values[bin->sorted], img->tile_order, W, H, gx, ntiles, s->bg,
-               (const float4*)g->rec, img->final_T, img->n_contrib, dL_dcolor, nullptr, nullptr, dL_dmean2D, wave_mode_num8());
+               (const float4*)g->rec, img->final_T, img->n_contrib, dL_dcolor, nullptr, nullptr, dL_dmean2D);
     return hipGetLastError();
 }
 

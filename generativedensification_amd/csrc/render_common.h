@@ -91,29 +91,23 @@ __device__ __forceinline__ float row_reduce_scatter4(float v0, float v1, float v
     return t;
 }
 
-// Sum over the four 16-lane rows of a wave, lane by lane (gfx950 v_permlane16_swap / v_permlane32_swap): every row
-// ends up with row0 + row1 + row2 + row3.
-typedef unsigned gdr_uint2v __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ float wave_rows_sum(float x) {
-    const unsigned u = __float_as_uint(x);
-    const gdr_uint2v r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
-    const float s = __uint_as_float(r.x) + __uint_as_float(r.y);
-    const unsigned v = __float_as_uint(s);
-    const gdr_uint2v q = __builtin_amdgcn_permlane32_swap(v, v, false, false);
-    return __uint_as_float(q.x) + __uint_as_float(q.y);
-}
-
-// Per 64-entry group the wave either lets each row walk its OWN sub-list ("block mode": best when the splats are
-// small, the four lists are nearly disjoint) or lets all four rows walk the UNION in lockstep ("wave mode": best when
-// most entries hit every block — one iteration, one reduction and one atomic per entry instead of up to four).
-// Both keep list order per pixel, so results are identical up to float summation order.  Wave mode is chosen when
-// the union is at most num8/8 times as long as the longest per-row list (launcher parameter, measured).
-__device__ __forceinline__ bool choose_wave_mode(uint64_t m0, uint64_t m1, uint64_t m2, uint64_t m3, int num8) {
-    const int pu = __builtin_popcountll(m0 | m1 | m2 | m3);
-    const int pm = max(max(__builtin_popcountll(m0), __builtin_popcountll(m1)),
-                       max(__builtin_popcountll(m2), __builtin_popcountll(m3)));
-    return pu * 8 <= pm * num8;  // num8 = 0: never
-}
+// Slice-wide row lists.  A 256-entry slice is culled in four 64-entry groups; every lane keeps its row's four 64-bit
+// sub-list masks (q0..q3) and walks them back to back: `mr` = the rest of the current group's mask, `gi` = its index.
+// Rows only re-synchronise at slice boundaries, so a block with few entries in one group does not wait for the other
+// three blocks there (measured: K7 409 -> 381 us at C4, 196 -> 172 us at C2).  GDR_REFILL steps a lane over exhausted
+// groups; the masks are copied to prvalues first — a `c ? q1 : q2` on by-reference lambda captures is an ADDRESS
+// select, which the optimiser turns into an indexed load from a closure kept in scratch memory.
+#define GDR_REFILL(mr, gi, q1, q2, q3)                                           \
+    do {                                                                          \
+        _Pragma("unroll") for (int k_ = 0; k_ < 3; ++k_) {                        \
+            const bool adv_ = (mr) == 0ull && (gi) < 3u;                          \
+            const uint64_t a1_ = (q1), a2_ = (q2), a3_ = (q3);                    \
+            uint64_t nxt_ = (gi) == 0u ? a1_ : a2_;                               \
+            nxt_ = (gi) >= 2u ? a3_ : nxt_;                                       \
+            (mr) = adv_ ? nxt_ : (mr);                                            \
+            (gi) = adv_ ? (gi) + 1u : (gi);                                       \
+        }                                                                         \
+    } while (0)
 
 #define GDR_ROW_MASK(k) (0xFFFFull << (16 * (k)))
 

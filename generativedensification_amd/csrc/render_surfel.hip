@@ -12,7 +12,9 @@
 // G = v_exp_f32(-0.5 log2e min(u^2+v^2, 2|pix - centre|^2)).  Backward: all "behind" recurrences (colour, depth,
 // coverage, normal and the distortion weight) share the select-free form B <- B + a (c - B); the 20 per-surfel
 // partials are reduce-scattered inside each row (16 + 4 values) and published with two atomic instructions into a
-// 128-byte gradient record.
+// 128-byte gradient record; K7s walks slice-wide row lists (render_common.h GDR_REFILL): 647 -> 540 us at C5 (a
+// lockstep variant — all four rows on the union list, rows summed with v_permlane16/32_swap, one atomic per wave —
+// reached 578 us and was dropped for it).
 #include <stdlib.h>
 
 #include "gdr_common.h"
@@ -230,7 +232,7 @@ __global__ __launch_bounds__(GDR_BLOCK) void surfel_render_bwd_kernel(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, const uint32_t* __restrict__ tile_order,
     int W, int H, int gx, int ntiles, const float* __restrict__ bg, const float4* __restrict__ rec,
     const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
-    const float* __restrict__ dL_dothers, float* __restrict__ grad_rec, int wave_num8) {
+    const float* __restrict__ dL_dothers, float* __restrict__ grad_rec) {
     __shared__ SurfelLds lds;
     __shared__ uint32_t s_id[GDR_BLOCK + 1];
 
@@ -296,20 +298,25 @@ __global__ __launch_bounds__(GDR_BLOCK) void surfel_render_bwd_kernel(
         }
         const int top = total - 1 - r * GDR_BLOCK;  // list position of LDS entry e: top - e
         if (top - (GDR_BLOCK - 1) >= wave_last) continue;
-#pragma unroll 1
-        for (int g = 0; g < GDR_BLOCK / GDR_WAVE; ++g) {
-            const int gtop = top - g * GDR_WAVE;
-            if (gtop - (GDR_WAVE - 1) >= wave_last) continue;
+        auto group_mask = [&](int g) -> uint64_t {
+            const int gtop = top - g * GDR_WAVE;  // position of this group's entry 0
+            if (gtop - (GDR_WAVE - 1) >= wave_last) return 0ull;
             uint64_t m0, m1, m2, m3;
             const int mypos = gtop - (int)lane;
             block_masks(lds, g, XA, YA, mypos < rl0, mypos < rl1, mypos < rl2, mypos < rl3, m0, m1, m2, m3);
-            if ((m0 | m1 | m2 | m3) == 0ull) continue;
-            const uint32_t goff = (uint32_t)(g * GDR_WAVE), nulloff = GDR_NULL_ENTRY - goff;
-            const bool wave_mode = choose_wave_mode(m0, m1, m2, m3, wave_num8);
-            uint64_t mr = wave_mode ? (m0 | m1 | m2 | m3) : row_select(row, m0, m1, m2, m3);
-            auto fetch = [&](SEntry& en) {
-                en.e = min(take_bit(mr), nulloff) + goff;
+            return row_select(row, m0, m1, m2, m3);
+        };
+        const uint64_t q0 = group_mask(0), q1 = group_mask(1), q2 = group_mask(2), q3 = group_mask(3);
+        if (__ballot((q0 | q1 | q2 | q3) != 0ull) == 0ull) continue;
+        {
+            uint32_t gi = 0u;
+            uint64_t mr = q0;
+            GDR_REFILL(mr, gi, q1, q2, q3);
+            auto fetch = [&](SEntry& en) __attribute__((always_inline)) {
+                const uint32_t goff = gi << 6;
+                en.e = min(take_bit(mr), GDR_NULL_ENTRY - goff) + goff;
                 en.tu = lds.tu[en.e]; en.tv = lds.tv[en.e]; en.tw = lds.tw[en.e]; en.nr = lds.nr[en.e]; en.gb = lds.gb[en.e];
+                if (__ballot(mr == 0ull && gi < 3u) != 0ull) GDR_REFILL(mr, gi, q1, q2, q3);
             };
             auto accumulate = [&](const SEntry& en) {
                 Hit h;
@@ -357,15 +364,9 @@ __global__ __launch_bounds__(GDR_BLOCK) void surfel_render_bwd_kernel(
                                         fmaf(pxf, dkx, fmaf(pyf, dlx, dL_dz * sx)), fmaf(pxf, dky, fmaf(pyf, dly, dL_dz * sy)),
                                         fmaf(pxf, dkz, fmaf(pyf, dlz, dL_dz)),
                                         G * dL_dalpha, w * gC0, w * gC1, w * gC2, w * gN0, w * gN1, w * gN2};
-                float tot = row_reduce_scatter16(vals, li);
-                float tot4 = row_reduce_scatter4(lowx, lowy, fabsf(dkz), fabsf(dlz), li);
-                bool publish = ((hb >> (16 * row)) & 0xFFFFull) != 0ull;
-                if (wave_mode) {  // all four rows hold the same entry: add the rows, row 0 publishes
-                    tot = wave_rows_sum(tot);
-                    tot4 = wave_rows_sum(tot4);
-                    publish = row == 0u;
-                }
-                if (publish) {
+                const float tot = row_reduce_scatter16(vals, li);
+                const float tot4 = row_reduce_scatter4(lowx, lowy, fabsf(dkz), fabsf(dlz), li);
+                if (((hb >> (16 * row)) & 0xFFFFull) != 0ull) {
                     float* g = grad_rec + GSR_GRAD_FLOATS * (size_t)s_id[en.e];
                     atomicAdd(g + li, tot);
                     if ((li & 3u) == 0u) atomicAdd(g + 16 + (li >> 2), tot4);
@@ -389,13 +390,6 @@ __global__ __launch_bounds__(GDR_BLOCK) void surfel_render_bwd_kernel(
 
 }  // namespace
 
-// lockstep threshold in eighths (render_common.h choose_wave_mode); GDR_WAVE_MODE_NUM8 overrides for A/B runs.
-// Measured on MI355X, C5 K7s: off 647 us, 9/8 637, 10/8 586, 11/8 578, 12/8 632, 14/8 695.
-static int wave_mode_num8() {
-    static const int v = [] { const char* e = getenv("GDR_WAVE_MODE_NUM8"); return e ? atoi(e) : 11; }();
-    return v;
-}
-
 hipError_t launch_surfel_render_fwd(const gdr_settings* s, const gdr_geom* g, const gdr_binning* bin,
                                     const gdr_image* img, const gsr_outputs* out, hipStream_t st) {
     const int W = s->image_width, H = s->image_height;
@@ -415,7 +409,7 @@ hipError_t launch_surfel_render_bwd(const gdr_settings* s, const gdr_geom* g, co
     const int ntiles = gx * gy;
     GDR_LAUNCH(GDR_K_RENDER_BWD, surfel_render_bwd_kernel, dim3(ntiles), dim3(GDR_BLOCK), st, (const uint2*)img->ranges,
                bin->values[bin->sorted], img->tile_order, W, H, gx, ntiles, s->bg, (const float4*)g->rec, img->final_T,
-               img->n_contrib, gi->dL_dcolor, gi->dL_dallmap, grad_rec, wave_mode_num8());
+               img->n_contrib, gi->dL_dcolor, gi->dL_dallmap, grad_rec);
     return hipGetLastError();
 }
 
