@@ -26,25 +26,45 @@ __device__ __forceinline__ float dpp_get(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
 }
 
-// Row-local reduce-scatter of 12 per-lane values over the 16 lanes of a DPP row: lane i of the
-// row returns the row total of value i (i < 12; lanes 12..15 return 0).  Four halving
-// exchanges (row_mirror, row_half_mirror, quad reverse, quad xor-1): 45 VALU ops instead of
-// 12 x 4 full reductions, and the totals land one per lane, so ONE atomic instruction
-// publishes all of them.
+// Row-local reduce-scatter of 12 (16) per-lane values over the 16 lanes of a DPP row: lane i of the row returns the
+// row total of value i (lanes 12..15 of the 12-value form return unused sums).  Four halving exchanges: row_mirror
+// (partner 15 - i), row_half_mirror (i ^ 7), quad reverse (i ^ 3), quad xor-1 — the totals land one per lane, so ONE
+// atomic instruction publishes all of them.  In the first two exchanges the lanes that keep the upper value of a
+// pair are whole 4-lane DPP banks, so each output is two bank-masked v_add_f32_dpp into the same register
+//     a = a + perm(a)   [banks of the lower half, in place]      a = b + perm(b)   [banks of the upper half]
+// (all in place: no temporaries) instead of two v_cndmask + one add; the compiler has no intrinsic for a bank-masked DPP add (update_dpp with a
+// partial bank mask is a v_mov and is not folded), hence the inline asm (29 VALU ops for 12 values instead of 47;
+// K7 381 -> see DESIGN.md).  The last two exchanges split inside a bank and stay select + add.  s_nop 1 on both
+// sides: the hazard recogniser does not look inside inline asm (VALU write -> DPP read needs two wait states).
 __device__ __forceinline__ float row_reduce_scatter12(const float (&v)[12], uint32_t li) {
-    const bool b3 = li & 8u, b2 = li & 4u, b1 = li & 2u, b0 = li & 1u;
-    float u[8], t[4], s2[2];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const float hi = (j + 8 < 12) ? v[j + 8] : 0.f;
-        const float keep = b3 ? hi : v[j], send = b3 ? v[j] : hi;
-        u[j] = keep + dpp_get<0x140, 0xf>(send);  // row_mirror: partner 15 - i
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const float keep = b2 ? u[j + 4] : u[j], send = b2 ? u[j] : u[j + 4];
-        t[j] = keep + dpp_get<0x141, 0xf>(send);  // row_half_mirror: partner i ^ 7
-    }
+    const bool b1 = li & 2u, b0 = li & 1u;
+    float a0 = v[0], a1 = v[1], a2 = v[2], a3 = v[3], a4 = v[4], a5 = v[5], a6 = v[6], a7 = v[7], s2[2];
+    asm(
+        "s_nop 1\n\t"  /* VALU write -> DPP read of the inputs needs 2 wait states */
+        "v_add_f32_dpp %[a0], %[a0], %[a0] row_mirror row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %[a0], %[b0], %[b0] row_mirror row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %[a1], %[a1], %[a1] row_mirror row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %[a1], %[b1], %[b1] row_mirror row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %[a2], %[a2], %[a2] row_mirror row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %[a2], %[b2], %[b2] row_mirror row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %[a3], %[a3], %[a3] row_mirror row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %[a3], %[b3], %[b3] row_mirror row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %[a4], %[a4], %[a4] row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %[a5], %[a5], %[a5] row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %[a6], %[a6], %[a6] row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %[a7], %[a7], %[a7] row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %[a0], %[a0], %[a0] row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %[a0], %[a4], %[a4] row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %[a1], %[a1], %[a1] row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %[a1], %[a5], %[a5] row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %[a2], %[a2], %[a2] row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %[a2], %[a6], %[a6] row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %[a3], %[a3], %[a3] row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %[a3], %[a7], %[a7] row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+        "s_nop 1"      /* ... and so does the compiler-generated DPP read of a0..a3 that follows */
+        : [a0] "+v"(a0), [a1] "+v"(a1), [a2] "+v"(a2), [a3] "+v"(a3), [a4] "+v"(a4), [a5] "+v"(a5), [a6] "+v"(a6), [a7] "+v"(a7)
+        : [b0] "v"(v[8]), [b1] "v"(v[9]), [b2] "v"(v[10]), [b3] "v"(v[11]));
+    const float t[4] = {a0, a1, a2, a3};
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const float keep = b1 ? t[j + 2] : t[j], send = b1 ? t[j] : t[j + 2];
@@ -54,28 +74,46 @@ __device__ __forceinline__ float row_reduce_scatter12(const float (&v)[12], uint
     return keep + dpp_get<0xB1, 0xf>(send);       // quad_perm [1,0,3,2]: partner i ^ 1
 }
 
-// 16 values over the 16 lanes of a row: lane i returns the row total of value i (same four halving
-// exchanges as row_reduce_scatter12 with every slot used).
 __device__ __forceinline__ float row_reduce_scatter16(const float (&v)[16], uint32_t li) {
-    const bool b3 = li & 8u, b2 = li & 4u, b1 = li & 2u, b0 = li & 1u;
-    float u[8], t[4], s2[2];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const float keep = b3 ? v[j + 8] : v[j], send = b3 ? v[j] : v[j + 8];
-        u[j] = keep + dpp_get<0x140, 0xf>(send);
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const float keep = b2 ? u[j + 4] : u[j], send = b2 ? u[j] : u[j + 4];
-        t[j] = keep + dpp_get<0x141, 0xf>(send);
-    }
+    const bool b1 = li & 2u, b0 = li & 1u;
+    float a0 = v[0], a1 = v[1], a2 = v[2], a3 = v[3], a4 = v[4], a5 = v[5], a6 = v[6], a7 = v[7], s2[2];
+    asm(
+        "s_nop 1\n\t"  /* VALU write -> DPP read of the inputs needs 2 wait states */
+        "v_add_f32_dpp %[a0], %[a0], %[a0] row_mirror row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %[a0], %[b0], %[b0] row_mirror row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %[a1], %[a1], %[a1] row_mirror row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %[a1], %[b1], %[b1] row_mirror row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %[a2], %[a2], %[a2] row_mirror row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %[a2], %[b2], %[b2] row_mirror row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %[a3], %[a3], %[a3] row_mirror row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %[a3], %[b3], %[b3] row_mirror row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %[a4], %[a4], %[a4] row_mirror row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %[a4], %[b4], %[b4] row_mirror row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %[a5], %[a5], %[a5] row_mirror row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %[a5], %[b5], %[b5] row_mirror row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %[a6], %[a6], %[a6] row_mirror row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %[a6], %[b6], %[b6] row_mirror row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %[a7], %[a7], %[a7] row_mirror row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %[a7], %[b7], %[b7] row_mirror row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %[a0], %[a0], %[a0] row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %[a0], %[a4], %[a4] row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %[a1], %[a1], %[a1] row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %[a1], %[a5], %[a5] row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %[a2], %[a2], %[a2] row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %[a2], %[a6], %[a6] row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %[a3], %[a3], %[a3] row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %[a3], %[a7], %[a7] row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+        "s_nop 1"      /* ... and so does the compiler-generated DPP read of a0..a3 that follows */
+        : [a0] "+v"(a0), [a1] "+v"(a1), [a2] "+v"(a2), [a3] "+v"(a3), [a4] "+v"(a4), [a5] "+v"(a5), [a6] "+v"(a6), [a7] "+v"(a7)
+        : [b0] "v"(v[8]), [b1] "v"(v[9]), [b2] "v"(v[10]), [b3] "v"(v[11]), [b4] "v"(v[12]), [b5] "v"(v[13]), [b6] "v"(v[14]), [b7] "v"(v[15]));
+    const float t[4] = {a0, a1, a2, a3};
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const float keep = b1 ? t[j + 2] : t[j], send = b1 ? t[j] : t[j + 2];
-        s2[j] = keep + dpp_get<0x1B, 0xf>(send);
+        s2[j] = keep + dpp_get<0x1B, 0xf>(send);  // quad_perm [3,2,1,0]: partner i ^ 3
     }
     const float keep = b0 ? s2[1] : s2[0], send = b0 ? s2[0] : s2[1];
-    return keep + dpp_get<0xB1, 0xf>(send);
+    return keep + dpp_get<0xB1, 0xf>(send);       // quad_perm [1,0,3,2]: partner i ^ 1
 }
 
 // 4 values over the 16 lanes of a row: lane i returns the row total of value (i >> 2) & 3
