@@ -107,6 +107,10 @@ _PROTOS = {
     "gdr_render_forward": (C.c_int, [C.POINTER(GdrSettings), C.POINTER(GdrInputs), C.POINTER(GdrGeom),
                                      C.POINTER(GdrBinning), C.POINTER(GdrImage), C.c_uint64,
                                      C.POINTER(GdrOutputs), C.c_void_p]),
+    "gdr_binning_forward": (C.c_int, [C.POINTER(GdrSettings), C.c_int32, C.POINTER(GdrGeom), C.POINTER(GdrBinning),
+                                      C.POINTER(GdrImage), C.c_uint64, C.c_void_p, C.c_void_p]),
+    "gdr_composite_forward": (C.c_int, [C.POINTER(GdrSettings), C.POINTER(GdrGeom), C.POINTER(GdrBinning),
+                                        C.POINTER(GdrImage), C.POINTER(GdrOutputs), C.c_void_p]),
     "gdr_forward": (C.c_int, [C.POINTER(GdrSettings), C.POINTER(GdrInputs), C.POINTER(GdrGeom),
                               C.POINTER(GdrBinning), C.POINTER(GdrImage), C.c_uint64,
                               C.POINTER(GdrOutputs), C.POINTER(C.c_uint32), C.c_void_p]),
@@ -141,6 +145,8 @@ _PROTOS = {
     "gsr_render_forward": (C.c_int, [C.POINTER(GdrSettings), C.POINTER(GsrInputs), C.POINTER(GdrGeom),
                                      C.POINTER(GdrBinning), C.POINTER(GdrImage), C.c_uint64, C.POINTER(GsrOutputs),
                                      C.c_void_p]),
+    "gsr_composite_forward": (C.c_int, [C.POINTER(GdrSettings), C.POINTER(GdrGeom), C.POINTER(GdrBinning),
+                                        C.POINTER(GdrImage), C.POINTER(GsrOutputs), C.c_void_p]),
     "gsr_forward": (C.c_int, [C.POINTER(GdrSettings), C.POINTER(GsrInputs), C.POINTER(GdrGeom), C.POINTER(GdrBinning),
                               C.POINTER(GdrImage), C.c_uint64, C.POINTER(GsrOutputs), C.POINTER(C.c_uint32),
                               C.c_void_p]),
@@ -175,7 +181,7 @@ def load():
             fn = getattr(lib, name)  # AttributeError if the symbol is missing
             fn.restype = res
             fn.argtypes = args
-        if lib.gdr_abi_version() != 5:
+        if lib.gdr_abi_version() != 6:
             raise RuntimeError("libgdr_hip.so ABI version mismatch")
         _lib = lib
     return _lib

@@ -202,25 +202,20 @@ int gdr_preprocess_forward(const gdr_settings* s, const gdr_inputs* in, const gd
     return GDR_OK;
 }
 
-int gdr_render_forward(const gdr_settings* s, const gdr_inputs* in, const gdr_geom* geom,
-                       gdr_binning* bin, const gdr_image* img, uint64_t D, const gdr_outputs* out,
-                       void* stream) {
-    int rc = check_common(s, in);
-    if (rc) return rc;
-    if (!geom || !bin || !img || !out || !out->color || !out->depth || !out->alpha || (in->N > 0 && !out->radii)) {
-        set_error("render_forward: NULL argument", hipSuccess);
-        return GDR_ERR_INVALID_ARG;
-    }
-    hipStream_t st = (hipStream_t)stream;
+// K3..K5 + tile sort: everything between K1 and K6; shared by the 3DGS and the surfel path (only the geometry's
+// depths / rects / tiles_touched / block offsets and the radii are read)
+static int binning_stage(const gdr_settings* s, int32_t N, const gdr_geom* geom, gdr_binning* bin, const gdr_image* img,
+                         uint64_t D, const int32_t* radii, hipStream_t st) {
+    int rc;
     const int W = s->image_width, H = s->image_height;
     const int tiles = tile_grid_x(W) * tile_grid_y(H);
     hipError_t e;
     if (bin->global_sort) {  // stable global sort: duplicates must be emitted in Gaussian order
-        e = launch_scan_block_sums(geom, in->N, st);
+        e = launch_scan_block_sums(geom, N, st);
         if (e != hipSuccess) return hip_fail("scan_block_sums", e);
     }
-    e = launch_duplicate(geom, in->N, W, H, out->radii, bin->global_sort ? geom->block_sums : geom->block_offs,
-                         bin->keys[0], bin->values[0], D, st);
+    e = launch_duplicate(geom, N, W, H, radii, bin->global_sort ? geom->block_sums : geom->block_offs, bin->keys[0],
+                         bin->values[0], D, st);
     if (e != hipSuccess) return hip_fail("duplicate", e);
     if ((rc = debug_sync(s, "duplicate", st))) return rc;
     if (bin->global_sort) {  // one global stable LSD radix sort over all key bits
@@ -230,6 +225,9 @@ int gdr_render_forward(const gdr_settings* s, const gdr_inputs* in, const gdr_ge
         e = launch_ranges(bin, D, img, tiles, st);
         if (e != hipSuccess) return hip_fail("ranges", e);
         if ((rc = debug_sync(s, "ranges", st))) return rc;
+        e = launch_tile_order(img, tiles, st);
+        if (e != hipSuccess) return hip_fail("tile_order", e);
+        if ((rc = debug_sync(s, "tile_order", st))) return rc;
     } else {  // default: stable partition by tile, segments, per-tile LDS depth sort
         e = launch_sort_tile_bits(bin, D, key_bits(tiles), st);
         if (e != hipSuccess) return hip_fail("sort_tile_bits", e);
@@ -244,15 +242,38 @@ int gdr_render_forward(const gdr_settings* s, const gdr_inputs* in, const gdr_ge
         if (e != hipSuccess) return hip_fail("tile_sort", e);
         if ((rc = debug_sync(s, "tile_sort", st))) return rc;
     }
-    if (bin->global_sort) {
-        e = launch_tile_order(img, tiles, st);
-        if (e != hipSuccess) return hip_fail("tile_order", e);
-        if ((rc = debug_sync(s, "tile_order", st))) return rc;
-    }
-    e = launch_render_fwd(s, geom, bin, img, out, st);
-    if (e != hipSuccess) return hip_fail("render_fwd", e);
-    if ((rc = debug_sync(s, "render_fwd", st))) return rc;
     return GDR_OK;
+}
+
+int gdr_binning_forward(const gdr_settings* s, int32_t N, const gdr_geom* geom, gdr_binning* bin, const gdr_image* img,
+                        uint64_t D, const int32_t* radii, void* stream) {
+    if (!s || !geom || !bin || !img || N < 0 || (N > 0 && !radii)) { set_error("binning_forward: bad argument", hipSuccess); return GDR_ERR_INVALID_ARG; }
+    return binning_stage(s, N, geom, bin, img, D, radii, (hipStream_t)stream);
+}
+
+int gdr_composite_forward(const gdr_settings* s, const gdr_geom* geom, const gdr_binning* bin, const gdr_image* img,
+                          const gdr_outputs* out, void* stream) {
+    if (!s || !geom || !bin || !img || !out || !out->color || !out->depth || !out->alpha) {
+        set_error("composite_forward: NULL argument", hipSuccess);
+        return GDR_ERR_INVALID_ARG;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = launch_render_fwd(s, geom, bin, img, out, st);
+    if (e != hipSuccess) return hip_fail("render_fwd", e);
+    return debug_sync(s, "render_fwd", st);
+}
+
+int gdr_render_forward(const gdr_settings* s, const gdr_inputs* in, const gdr_geom* geom,
+                       gdr_binning* bin, const gdr_image* img, uint64_t D, const gdr_outputs* out,
+                       void* stream) {
+    int rc = check_common(s, in);
+    if (rc) return rc;
+    if (!geom || !bin || !img || !out || !out->color || !out->depth || !out->alpha || (in->N > 0 && !out->radii)) {
+        set_error("render_forward: NULL argument", hipSuccess);
+        return GDR_ERR_INVALID_ARG;
+    }
+    if ((rc = binning_stage(s, in->N, geom, bin, img, D, out->radii, (hipStream_t)stream))) return rc;
+    return gdr_composite_forward(s, geom, bin, img, out, stream);
 }
 
 int gdr_forward(const gdr_settings* s, const gdr_inputs* in, const gdr_geom* geom, gdr_binning* bin,
@@ -538,6 +559,18 @@ int gsr_preprocess_forward(const gdr_settings* s, const gsr_inputs* in, const gd
     return GDR_OK;
 }
 
+int gsr_composite_forward(const gdr_settings* s, const gdr_geom* geom, const gdr_binning* bin, const gdr_image* img,
+                          const gsr_outputs* out, void* stream) {
+    if (!s || !geom || !bin || !img || !out || !out->color || !out->allmap) {
+        set_error("surfel composite_forward: NULL argument", hipSuccess);
+        return GDR_ERR_INVALID_ARG;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = launch_surfel_render_fwd(s, geom, bin, img, out, st);
+    if (e != hipSuccess) return hip_fail("surfel_render_fwd", e);
+    return debug_sync(s, "surfel_render_fwd", st);
+}
+
 int gsr_render_forward(const gdr_settings* s, const gsr_inputs* in, const gdr_geom* geom, gdr_binning* bin,
                        const gdr_image* img, uint64_t D, const gsr_outputs* out, void* stream) {
     int rc = check_surfel(s, in);
@@ -546,39 +579,8 @@ int gsr_render_forward(const gdr_settings* s, const gsr_inputs* in, const gdr_ge
         set_error("surfel render_forward: NULL argument", hipSuccess);
         return GDR_ERR_INVALID_ARG;
     }
-    hipStream_t st = (hipStream_t)stream;
-    const int W = s->image_width, H = s->image_height;
-    const int tiles = tile_grid_x(W) * tile_grid_y(H);
-    hipError_t e;
-    if (bin->global_sort) {
-        e = launch_scan_block_sums(geom, in->N, st);
-        if (e != hipSuccess) return hip_fail("scan_block_sums", e);
-    }
-    e = launch_duplicate(geom, in->N, W, H, out->radii, bin->global_sort ? geom->block_sums : geom->block_offs,
-                         bin->keys[0], bin->values[0], D, st);
-    if (e != hipSuccess) return hip_fail("duplicate", e);
-    if ((rc = debug_sync(s, "duplicate", st))) return rc;
-    if (bin->global_sort) {
-        e = launch_sort(bin, D, key_bits(tiles), st);
-        if (e != hipSuccess) return hip_fail("sort", e);
-        e = launch_ranges(bin, D, img, tiles, st);
-        if (e != hipSuccess) return hip_fail("ranges", e);
-        e = launch_tile_order(img, tiles, st);
-        if (e != hipSuccess) return hip_fail("tile_order", e);
-    } else {
-        e = launch_sort_tile_bits(bin, D, key_bits(tiles), st);
-        if (e != hipSuccess) return hip_fail("sort_tile_bits", e);
-        e = launch_ranges(bin, D, img, tiles, st);
-        if (e != hipSuccess) return hip_fail("ranges", e);
-        e = launch_tile_order(img, tiles, st);
-        if (e != hipSuccess) return hip_fail("tile_order", e);
-        e = launch_tile_sort(bin, img, tiles, D, st);
-        if (e != hipSuccess) return hip_fail("tile_sort", e);
-    }
-    if ((rc = debug_sync(s, "binning", st))) return rc;
-    e = launch_surfel_render_fwd(s, geom, bin, img, out, st);
-    if (e != hipSuccess) return hip_fail("surfel_render_fwd", e);
-    return debug_sync(s, "surfel_render_fwd", st);
+    if ((rc = binning_stage(s, in->N, geom, bin, img, D, out->radii, (hipStream_t)stream))) return rc;
+    return gsr_composite_forward(s, geom, bin, img, out, stream);
 }
 
 int gsr_forward(const gdr_settings* s, const gsr_inputs* in, const gdr_geom* geom, gdr_binning* bin,

@@ -126,6 +126,9 @@ _FORCE_GLOBAL_SORT = False
 import os as _os
 
 VIEW_STREAMS = max(1, int(_os.environ.get("GDR_VIEW_STREAMS", "1")))
+# GDR_BIN_STREAM=1: binning of all views on ONE dedicated side stream, compositing on the caller's stream (see
+# _forward_views_impl); measured in BASELINE.md §4.
+BIN_STREAM = int(_os.environ.get("GDR_BIN_STREAM", "1")) != 0
 _side_streams: dict = {}
 
 
@@ -328,6 +331,28 @@ def _forward_views_impl(means3D, means2D, sh, opacities, scales, rotations, sett
             L.check(lib.gdr_binning_carve(st.bin_buf.data_ptr(), st.D, C.byref(st.bin)), "gdr_binning_carve")
             st.bin.global_sort = int(_FORCE_GLOBAL_SORT)
         main = torch.cuda.current_stream()
+        if BIN_STREAM and V > 1:
+            # Binning of view v+1 (latency-bound: ~10 short kernels with few workgroups) overlaps K6 of view v
+            # (VALU-bound) on a dedicated stream.  The D read-back above synchronised `main`, so every workspace
+            # allocated since then is free of pending work and may be touched by the side stream at once.
+            aux = _view_streams(dev, 1)[0]
+            aux_p = C.c_void_p(aux.cuda_stream)
+            ready = torch.cuda.Event()
+            ready.record(main)
+            aux.wait_event(ready)
+            binned = []
+            for v, st in enumerate(states):
+                L.check(lib.gdr_binning_forward(C.byref(s_arr[v]), N, C.byref(g_arr[v]), C.byref(st.bin), C.byref(st.img),
+                                                st.D, _ptr(radii[v]), aux_p), "gdr_binning_forward")
+                ev = torch.cuda.Event()
+                ev.record(aux)
+                binned.append(ev)
+            for v, st in enumerate(states):
+                main.wait_event(binned[v])
+                out = L.GdrOutputs(colors[v].data_ptr(), depths[v].data_ptr(), alphas[v].data_ptr(), _ptr(radii[v]))
+                L.check(lib.gdr_composite_forward(C.byref(s_arr[v]), C.byref(g_arr[v]), C.byref(st.bin), C.byref(st.img),
+                                                  C.byref(out), stream), "gdr_composite_forward")
+            return colors, radii, depths, alphas, states, keep, in_dtypes
         side = _view_streams(dev, min(VIEW_STREAMS, V)) if VIEW_STREAMS > 1 and V > 1 else None
         if side:
             ready = torch.cuda.Event()

@@ -219,9 +219,30 @@ class _RenderSurfelViews(torch.autograd.Function):
                 st.bin_buf = torch.empty(lib.gdr_binning_bytes(st.D), **u8)
                 L.check(lib.gdr_binning_carve(st.bin_buf.data_ptr(), st.D, C.byref(st.bin)), "gdr_binning_carve")
                 st.bin.global_sort = int(_R._FORCE_GLOBAL_SORT)
-                out = L.GsrOutputs(colors[v].data_ptr(), allmaps[v].data_ptr(), _ptr(radii[v]))
-                L.check(lib.gsr_render_forward(C.byref(structs[v]), C.byref(inp), C.byref(st.geom), C.byref(st.bin),
-                                               C.byref(st.img), st.D, C.byref(out), stream), "gsr_render_forward")
+            if _R.BIN_STREAM and V > 1:   # binning of view v+1 overlaps K6s of view v (rasterizer._forward_views_impl)
+                main = torch.cuda.current_stream()
+                aux = _R._view_streams(dev, 1)[0]
+                aux_p = C.c_void_p(aux.cuda_stream)
+                ready = torch.cuda.Event()
+                ready.record(main)
+                aux.wait_event(ready)
+                binned = []
+                for v, st in enumerate(states):
+                    L.check(lib.gdr_binning_forward(C.byref(structs[v]), N, C.byref(st.geom), C.byref(st.bin),
+                                                    C.byref(st.img), st.D, _ptr(radii[v]), aux_p), "gdr_binning_forward")
+                    ev = torch.cuda.Event()
+                    ev.record(aux)
+                    binned.append(ev)
+                for v, st in enumerate(states):
+                    main.wait_event(binned[v])
+                    out = L.GsrOutputs(colors[v].data_ptr(), allmaps[v].data_ptr(), _ptr(radii[v]))
+                    L.check(lib.gsr_composite_forward(C.byref(structs[v]), C.byref(st.geom), C.byref(st.bin),
+                                                      C.byref(st.img), C.byref(out), stream), "gsr_composite_forward")
+            else:
+                for v, st in enumerate(states):
+                    out = L.GsrOutputs(colors[v].data_ptr(), allmaps[v].data_ptr(), _ptr(radii[v]))
+                    L.check(lib.gsr_render_forward(C.byref(structs[v]), C.byref(inp), C.byref(st.geom), C.byref(st.bin),
+                                                   C.byref(st.img), st.D, C.byref(out), stream), "gsr_render_forward")
         ctx.states, ctx.keep, ctx.settings_list, ctx.radii, ctx.flags = states, keep, settings_list, radii, int(flags)
         ctx.means2D_shape, ctx.in_dtypes, ctx.V = tuple(means2D.shape), in_dtypes, V
         ctx.mark_non_differentiable(radii)

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define GDR_ABI_VERSION 5
+#define GDR_ABI_VERSION 6
 
 #define GDR_OK 0
 #define GDR_ERR_INVALID_ARG (-1)  /* NULL / inconsistent arguments                     */
@@ -191,6 +191,15 @@ int gdr_preprocess_forward(const gdr_settings* s, const gdr_inputs* in, const gd
 int gdr_render_forward(const gdr_settings* s, const gdr_inputs* in, const gdr_geom* geom,
                        gdr_binning* bin, const gdr_image* img, uint64_t D,
                        const gdr_outputs* out, void* stream);
+
+/* The two halves of stage 2, for callers that overlap the binning of one view with the compositing of another on
+ * separate streams (binning is latency-bound with few workgroups, compositing is VALU-bound):
+ * gdr_binning_forward = K3..K5 + tile order + tile sort (also valid for the surfel geometry of gsr.h),
+ * gdr_composite_forward = K6.  gdr_render_forward is exactly one after the other on one stream. */
+int gdr_binning_forward(const gdr_settings* s, int32_t N, const gdr_geom* geom, gdr_binning* bin, const gdr_image* img,
+                        uint64_t D, const int32_t* radii, void* stream);
+int gdr_composite_forward(const gdr_settings* s, const gdr_geom* geom, const gdr_binning* bin, const gdr_image* img,
+                          const gdr_outputs* out, void* stream);
 
 /* Stages 1+2 with a caller-provided binning capacity D_cap.  Synchronises once to
  * read D; returns GDR_ERR_WORKSPACE (and *num_rendered_host = required D) if

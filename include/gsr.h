@@ -90,6 +90,9 @@ int gsr_preprocess_forward(const gdr_settings* s, const gsr_inputs* in, const gd
                            uint32_t* num_rendered_host, void* stream);
 int gsr_render_forward(const gdr_settings* s, const gsr_inputs* in, const gdr_geom* geom, gdr_binning* bin,
                        const gdr_image* img, uint64_t D, const gsr_outputs* out, void* stream);
+/* K6s alone (after gdr_binning_forward on the surfel geometry); see gdr.h for the two-stream use */
+int gsr_composite_forward(const gdr_settings* s, const gdr_geom* geom, const gdr_binning* bin, const gdr_image* img,
+                          const gsr_outputs* out, void* stream);
 int gsr_forward(const gdr_settings* s, const gsr_inputs* in, const gdr_geom* geom, gdr_binning* bin,
                 const gdr_image* img, uint64_t D_cap, const gsr_outputs* out, uint32_t* num_rendered_host,
                 void* stream);
