@@ -126,9 +126,9 @@ _FORCE_GLOBAL_SORT = False
 import os as _os
 
 VIEW_STREAMS = max(1, int(_os.environ.get("GDR_VIEW_STREAMS", "1")))
-# GDR_BIN_STREAM=1: binning of all views on ONE dedicated side stream, compositing on the caller's stream (see
+# GDR_BIN_STREAM=n: binning of the views round-robin on n dedicated side streams, compositing on the caller's stream (see
 # _forward_views_impl); measured in BASELINE.md §4.
-BIN_STREAM = int(_os.environ.get("GDR_BIN_STREAM", "1")) != 0
+BIN_STREAM = max(0, int(_os.environ.get("GDR_BIN_STREAM", "4")))   # number of binning side streams (0 = none; measured 1/2/4)
 _side_streams: dict = {}
 
 
@@ -335,15 +335,16 @@ def _forward_views_impl(means3D, means2D, sh, opacities, scales, rotations, sett
             # Binning of view v+1 (latency-bound: ~10 short kernels with few workgroups) overlaps K6 of view v
             # (VALU-bound) on a dedicated stream.  The D read-back above synchronised `main`, so every workspace
             # allocated since then is free of pending work and may be touched by the side stream at once.
-            aux = _view_streams(dev, 1)[0]
-            aux_p = C.c_void_p(aux.cuda_stream)
+            auxs = _view_streams(dev, min(BIN_STREAM, V))
             ready = torch.cuda.Event()
             ready.record(main)
-            aux.wait_event(ready)
+            for aux in auxs:
+                aux.wait_event(ready)
             binned = []
             for v, st in enumerate(states):
+                aux = auxs[v % len(auxs)]
                 L.check(lib.gdr_binning_forward(C.byref(s_arr[v]), N, C.byref(g_arr[v]), C.byref(st.bin), C.byref(st.img),
-                                                st.D, _ptr(radii[v]), aux_p), "gdr_binning_forward")
+                                                st.D, _ptr(radii[v]), C.c_void_p(aux.cuda_stream)), "gdr_binning_forward")
                 ev = torch.cuda.Event()
                 ev.record(aux)
                 binned.append(ev)

@@ -221,15 +221,17 @@ class _RenderSurfelViews(torch.autograd.Function):
                 st.bin.global_sort = int(_R._FORCE_GLOBAL_SORT)
             if _R.BIN_STREAM and V > 1:   # binning of view v+1 overlaps K6s of view v (rasterizer._forward_views_impl)
                 main = torch.cuda.current_stream()
-                aux = _R._view_streams(dev, 1)[0]
-                aux_p = C.c_void_p(aux.cuda_stream)
+                auxs = _R._view_streams(dev, min(_R.BIN_STREAM, V))
                 ready = torch.cuda.Event()
                 ready.record(main)
-                aux.wait_event(ready)
+                for aux in auxs:
+                    aux.wait_event(ready)
                 binned = []
                 for v, st in enumerate(states):
+                    aux = auxs[v % len(auxs)]
                     L.check(lib.gdr_binning_forward(C.byref(structs[v]), N, C.byref(st.geom), C.byref(st.bin),
-                                                    C.byref(st.img), st.D, _ptr(radii[v]), aux_p), "gdr_binning_forward")
+                                                    C.byref(st.img), st.D, _ptr(radii[v]), C.c_void_p(aux.cuda_stream)),
+                            "gdr_binning_forward")
                     ev = torch.cuda.Event()
                     ev.record(aux)
                     binned.append(ev)
