@@ -13,6 +13,8 @@
 // the CPU oracle (oracle/gdr_oracle.c, built with the same contraction setting).
 // These kernels are HBM-bound (236 B read + ~90 B written per Gaussian at SH degree 3);
 // the extra VALU ops from not fusing multiply-adds are hidden behind memory.
+#include <stdlib.h>
+
 #include "gdr_common.h"
 #include "device_math.h"
 
@@ -645,7 +647,9 @@ struct BwdView {
 };
 struct BwdViewsArgs { int V; BwdView v[GDR_MAX_VIEWS]; };
 
-template <int DEG>
+// STAGED (M == NB and 3 NB a multiple of 4: degrees 1 and 3): SH rows in, SH gradient rows out through LDS with
+// coalesced accesses (device_math.h RowStage)
+template <int DEG, bool STAGED>
 __global__ __launch_bounds__(GDR_BLOCK) void preprocess_bwd_views_kernel(
     int N, int M, const float* __restrict__ means3D, const float* __restrict__ shs,
     const float* __restrict__ scales, const float* __restrict__ rotations,
@@ -654,8 +658,20 @@ __global__ __launch_bounds__(GDR_BLOCK) void preprocess_bwd_views_kernel(
     float* __restrict__ dL_dopacity, float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dsh,
     float* __restrict__ dL_dscale, float4* __restrict__ dL_drot, const BwdViewsArgs a) {
     constexpr int NB = (DEG + 1) * (DEG + 1);
-    const int i = blockIdx.x * GDR_BLOCK + threadIdx.x;
-    if (i >= N) return;
+    constexpr int ROWF = 3 * NB;
+    using RS = RowStage<STAGED ? ROWF : 4>;
+    __shared__ float lds_rows[STAGED ? RS::LDS_FLOATS : 1];
+    const int row0 = blockIdx.x * GDR_BLOCK;
+    const int nrows = min(GDR_BLOCK, N - row0);
+    const int i = row0 + threadIdx.x;
+    if (STAGED) {
+        stage_rows_in<STAGED ? ROWF : 4>(shs, row0, nrows, lds_rows);
+        __syncthreads();
+    }
+    const bool in_range = i < N;
+    if (!STAGED && !in_range) return;
+    float* my_row = lds_rows + (STAGED ? (int)threadIdx.x * RS::STRIDE : 0);
+    if (in_range) {
     float dmean[3] = {0.f, 0.f, 0.f};
     float dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float4 dm2 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -668,7 +684,8 @@ __global__ __launch_bounds__(GDR_BLOCK) void preprocess_bwd_views_kernel(
     float c6[6];
 #pragma unroll
     for (int k = 0; k < 6; ++k) c6[k] = cov3D[6 * i + k];
-    const float* sh = shs + (size_t)i * M * 3;
+    const float* sh_g = shs + (size_t)i * M * 3;
+    auto sh = [&](int idx) -> float { return STAGED ? my_row[idx] : sh_g[idx]; };
 
     for (int v = 0; v < a.V; ++v) {
         const BwdView& bv = a.v[v];
@@ -741,11 +758,22 @@ __global__ __launch_bounds__(GDR_BLOCK) void preprocess_bwd_views_kernel(
             const float g[3] = {(cl & 1u) ? 0.f : gcolor.x, (cl & 2u) ? 0.f : gcolor.y,
                                 (cl & 4u) ? 0.f : gcolor.z};
             float ddx = 0.f, ddy = 0.f, ddz = 0.f;
+            float shr[NB * 3];  // this view's copy of the SH row: 16-byte LDS reads when staged
+            if (STAGED) {
+#pragma unroll
+                for (int c = 0; c < ROWF / 4; ++c) {
+                    const float4 t = *reinterpret_cast<const float4*>(my_row + 4 * c);
+                    shr[4 * c] = t.x; shr[4 * c + 1] = t.y; shr[4 * c + 2] = t.z; shr[4 * c + 3] = t.w;
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < NB * 3; ++k) shr[k] = sh(k);
+            }
 #pragma unroll
             for (int k = 0; k < NB; ++k) {
 #pragma unroll
                 for (int ch = 0; ch < 3; ++ch) {
-                    const float sg = sh[3 * k + ch] * g[ch];
+                    const float sg = shr[3 * k + ch] * g[ch];
                     dsh[3 * k + ch] += bk[k] * g[ch];
                     ddx += bx[k] * sg;
                     ddy += by[k] * sg;
@@ -758,7 +786,7 @@ __global__ __launch_bounds__(GDR_BLOCK) void preprocess_bwd_views_kernel(
             dmean[2] += (ddz - uz * dot) * inv;
         }
     }
-    if (accumulate && !any_vis) return;
+    if (!STAGED && accumulate && !any_vis) return;
     float dscale[3] = {0.f, 0.f, 0.f};
     float4 drot = make_float4(0.f, 0.f, 0.f, 0.f);
     if (any_vis) {
@@ -806,6 +834,9 @@ __global__ __launch_bounds__(GDR_BLOCK) void preprocess_bwd_views_kernel(
         }
     }
     float* o_sh = dL_dsh + (size_t)i * M * 3;
+    if (STAGED && accumulate && !any_vis) {
+        // nothing to add for this Gaussian (zeros go through the staged SH rows below)
+    } else {
     if (accumulate) {
         const float4 om = dL_dmean2D[i];
         dm2 = make_float4(dm2.x + om.x, dm2.y + om.y, dm2.z + om.z, dm2.w + om.w);
@@ -820,7 +851,13 @@ __global__ __launch_bounds__(GDR_BLOCK) void preprocess_bwd_views_kernel(
 #pragma unroll
     for (int k = 0; k < 3; ++k) { dL_dmeans3D[3 * i + k] = dmean[k]; dL_dscale[3 * i + k] = dscale[k]; }
     dL_drot[i] = drot;
-    if ((M * 3) % 4 == 0 && M == NB) {
+    }
+    if (STAGED) {
+        // every lane is past its last read of its SH row (it owns that row exclusively): overwrite it with the gradient
+#pragma unroll
+        for (int c = 0; c < ROWF / 4; ++c)
+            *reinterpret_cast<float4*>(my_row + 4 * c) = make_float4(dsh[4 * c], dsh[4 * c + 1], dsh[4 * c + 2], dsh[4 * c + 3]);
+    } else if ((M * 3) % 4 == 0 && M == NB) {
         float4* d4 = reinterpret_cast<float4*>(o_sh);
 #pragma unroll
         for (int c = 0; c < (3 * NB) / 4; ++c) {
@@ -839,6 +876,11 @@ __global__ __launch_bounds__(GDR_BLOCK) void preprocess_bwd_views_kernel(
         }
         if (!accumulate)
             for (int k = NB * 3; k < M * 3; ++k) o_sh[k] = 0.f;
+    }
+    }  // in_range
+    if (STAGED) {
+        __syncthreads();
+        stage_rows_out<STAGED ? ROWF : 4>(dL_dsh, row0, nrows, lds_rows, accumulate != 0);
     }
 }
 
@@ -937,11 +979,20 @@ hipError_t launch_preprocess_bwd_views(int V, const gdr_settings* s, const gdr_i
         b.radii = radii[v]; b.clamped = geoms[v].clamped; b.grad_rec = (const float4*)grad_recs[v];
     }
     const int grid = div_up(N, GDR_BLOCK);
-    LAUNCH_DEG(GDR_K_PREPROCESS_BWD, preprocess_bwd_views_kernel, s[0].sh_degree, grid, st, N, in->M,
-               in->means3D, in->shs, in->scales, in->rotations, in->opacities, s[0].scale_modifier,
-               geoms[0].cov3D, W, H, in->flags, go->accumulate, (float4*)go->dL_dmeans2D,
-               go->dL_dopacities, go->dL_dmeans3D, go->dL_dshs, go->dL_dscales,
-               (float4*)go->dL_drotations, a);
+#define GDR_K9V(DEG_, ST_)                                                                                  \
+    GDR_LAUNCH(GDR_K_PREPROCESS_BWD, (preprocess_bwd_views_kernel<DEG_, ST_>), dim3(grid), dim3(GDR_BLOCK), st, N,  \
+               in->M, in->means3D, in->shs, in->scales, in->rotations, in->opacities, s[0].scale_modifier,     \
+               geoms[0].cov3D, W, H, in->flags, go->accumulate, (float4*)go->dL_dmeans2D, go->dL_dopacities,   \
+               go->dL_dmeans3D, go->dL_dshs, go->dL_dscales, (float4*)go->dL_drotations, a)
+    const int deg = s[0].sh_degree, nb = (deg + 1) * (deg + 1);
+    const bool staged = in->M == nb && (3 * nb) % 4 == 0 && !getenv("GDR_NO_ROW_STAGE");
+    switch (deg) {
+        case 0: GDR_K9V(0, false); break;
+        case 1: if (staged) GDR_K9V(1, true); else GDR_K9V(1, false); break;
+        case 2: GDR_K9V(2, false); break;
+        default: if (staged) GDR_K9V(3, true); else GDR_K9V(3, false); break;
+    }
+#undef GDR_K9V
     return hipGetLastError();
 }
 
