@@ -220,8 +220,10 @@ __device__ __forceinline__ void put(T* p, T v, int accumulate) {
     *p = accumulate ? *p + v : v;
 }
 
-// K9s.  grad_rec: (N,32) floats accumulated by K7s, see include/gsr.h.
-template <int DEG>
+// K9s.  grad_rec: (N,32) floats accumulated by K7s, see include/gsr.h.  STAGED (M == NB, degrees 1 and 3): SH rows
+// in and SH-gradient rows out (incl. the read-modify-write of accumulate mode) through LDS with coalesced accesses
+// (device_math.h RowStage).
+template <int DEG, bool STAGED>
 __global__ __launch_bounds__(GDR_BLOCK) void surfel_preprocess_bwd_kernel(
     int N, int M, const float* __restrict__ means3D, const int32_t* __restrict__ radii, const float* __restrict__ shs,
     const uint8_t* __restrict__ g_clamped, const float* __restrict__ scales, const float* __restrict__ rotations,
@@ -233,18 +235,37 @@ __global__ __launch_bounds__(GDR_BLOCK) void surfel_preprocess_bwd_kernel(
     float4* __restrict__ dL_drot, uint32_t flags, int accumulate) {
     Cam cam;
     load_cam(cam, view, proj, campos);
-    const int i = blockIdx.x * GDR_BLOCK + threadIdx.x;
-    if (i >= N) return;
     constexpr int NB = (DEG + 1) * (DEG + 1);
+    constexpr int ROWF = 3 * NB;
+    using RS = RowStage<STAGED ? ROWF : 4>;
+    __shared__ float lds_rows[STAGED ? RS::LDS_FLOATS : 1];
+    const int row0 = blockIdx.x * GDR_BLOCK, nrows = min(GDR_BLOCK, N - row0);
+    const int i = row0 + threadIdx.x;
+    float* my_row = lds_rows + (STAGED ? (int)threadIdx.x * RS::STRIDE : 0);
+    if (STAGED) {
+        stage_rows_in<STAGED ? ROWF : 4>(shs, row0, nrows, lds_rows);
+        __syncthreads();
+    }
+    // STAGED: every thread reaches the ONE barrier + staged write-out after body(); its row then holds the SH gradient
+    // (zeros if culled)
+    auto zero_row = [&]() {
+        if (STAGED) {
+#pragma unroll
+            for (int c = 0; c < ROWF / 4; ++c) *reinterpret_cast<float4*>(my_row + 4 * c) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto body = [&]() __attribute__((always_inline)) {
+    if (i >= N) return;
     const bool vis = radii[i] > 0;
-    if (accumulate && !vis) return;
+    if (accumulate && !vis) { zero_row(); return; }
     float* dsh = dL_dsh ? dL_dsh + (size_t)i * M * 3 : nullptr;
     if (!vis) {
+        zero_row();
         dL_dmean2D[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         dL_dopacity[i] = 0.f;
 #pragma unroll
         for (int k = 0; k < 3; ++k) dL_dmeans3D[3 * i + k] = 0.f;
-        if (dsh)
+        if (dsh && !STAGED)
             for (int k = 0; k < 3 * M; ++k) dsh[k] = 0.f;
         if (colors_precomp && dL_dcolors) { dL_dcolors[3 * i] = 0.f; dL_dcolors[3 * i + 1] = 0.f; dL_dcolors[3 * i + 2] = 0.f; }
         if (transmat_precomp) {
@@ -372,7 +393,18 @@ __global__ __launch_bounds__(GDR_BLOCK) void surfel_preprocess_bwd_kernel(
         sh_basis_grad<DEG>(ux, uy, uz, bx, by, bz);
         const uint32_t cl = g_clamped[i];
         const float g[3] = {(cl & 1u) ? 0.f : gcol[0], (cl & 2u) ? 0.f : gcol[1], (cl & 4u) ? 0.f : gcol[2]};
-        const float* sh = shs + (size_t)i * M * 3;
+        const float* sh_g = shs + (size_t)i * M * 3;
+        float sh[NB * 3];
+        if (STAGED) {
+#pragma unroll
+            for (int c = 0; c < ROWF / 4; ++c) {
+                const float4 t = *reinterpret_cast<const float4*>(my_row + 4 * c);
+                sh[4 * c] = t.x; sh[4 * c + 1] = t.y; sh[4 * c + 2] = t.z; sh[4 * c + 3] = t.w;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < NB * 3; ++k) sh[k] = sh_g[k];
+        }
         float ddx = 0.f, ddy = 0.f, ddz = 0.f;
 #pragma unroll
         for (int k = 0; k < NB; ++k) {
@@ -382,7 +414,13 @@ __global__ __launch_bounds__(GDR_BLOCK) void surfel_preprocess_bwd_kernel(
                 ddx += bx[k] * sg; ddy += by[k] * sg; ddz += bz[k] * sg;
             }
         }
-        if ((3 * NB) % 4 == 0 && M == NB) {
+        if (STAGED) {  // the gradient row replaces the SH row this thread owns; written out coalesced after body()
+#pragma unroll
+            for (int c = 0; c < ROWF / 4; ++c)
+                *reinterpret_cast<float4*>(my_row + 4 * c) =
+                    make_float4(bk[(4 * c) / 3] * g[(4 * c) % 3], bk[(4 * c + 1) / 3] * g[(4 * c + 1) % 3],
+                                bk[(4 * c + 2) / 3] * g[(4 * c + 2) % 3], bk[(4 * c + 3) / 3] * g[(4 * c + 3) % 3]);
+        } else if ((3 * NB) % 4 == 0 && M == NB) {
             float4* d4 = reinterpret_cast<float4*>(dsh);
 #pragma unroll
             for (int c = 0; c < (3 * NB) / 4; ++c) {
@@ -413,6 +451,12 @@ __global__ __launch_bounds__(GDR_BLOCK) void surfel_preprocess_bwd_kernel(
     }
 #pragma unroll
     for (int k = 0; k < 3; ++k) put(dL_dmeans3D + 3 * i + k, dmean[k], accumulate);
+    };
+    body();
+    if (STAGED) {
+        __syncthreads();
+        stage_rows_out<STAGED ? ROWF : 4>(dL_dsh, row0, nrows, lds_rows, accumulate != 0);
+    }
 }
 
 #define LAUNCH_DEG_S(KID, KERNEL, deg, grid, st, ...)                                          \
@@ -443,12 +487,22 @@ hipError_t launch_surfel_preprocess_bwd(const gdr_settings* s, const gsr_inputs*
     if (in->N == 0) return hipSuccess;
     const dim3 grid(div_up(in->N, GDR_BLOCK));
     const int deg = in->shs ? s->sh_degree : 0;
-    LAUNCH_DEG_S(GDR_K_PREPROCESS_BWD, surfel_preprocess_bwd_kernel, deg, grid, st, in->N, in->M, in->means3D, radii,
-                 in->shs, g->clamped, in->scales, in->rotations, s->scale_modifier, in->transMat_precomp ? 1 : 0,
-                 in->colors_precomp ? 1 : 0, s->viewmatrix, s->projmatrix, s->campos, s->image_width,
-                 s->image_height, (const float4*)go->scratch, (const float4*)g->rec, (float4*)go->dL_dmeans2D,
-                 go->dL_dopacities, go->dL_dmeans3D, go->dL_dtransMat, go->dL_dshs, go->dL_dcolors, go->dL_dscales,
-                 (float4*)go->dL_drotations, in->flags, go->accumulate);
+#define GSR_K9(DEG_, ST_)                                                                                      \
+    GDR_LAUNCH(GDR_K_PREPROCESS_BWD, (surfel_preprocess_bwd_kernel<DEG_, ST_>), grid, dim3(GDR_BLOCK), st, in->N,      \
+               in->M, in->means3D, radii, in->shs, g->clamped, in->scales, in->rotations, s->scale_modifier,       \
+               in->transMat_precomp ? 1 : 0, in->colors_precomp ? 1 : 0, s->viewmatrix, s->projmatrix, s->campos,  \
+               s->image_width, s->image_height, (const float4*)go->scratch, (const float4*)g->rec,                 \
+               (float4*)go->dL_dmeans2D, go->dL_dopacities, go->dL_dmeans3D, go->dL_dtransMat, go->dL_dshs,        \
+               go->dL_dcolors, go->dL_dscales, (float4*)go->dL_drotations, in->flags, go->accumulate)
+    const int nb = (deg + 1) * (deg + 1);
+    const bool staged = in->shs && in->M == nb && (3 * nb) % 4 == 0;
+    switch (deg) {
+        case 0: GSR_K9(0, false); break;
+        case 1: if (staged) GSR_K9(1, true); else GSR_K9(1, false); break;
+        case 2: GSR_K9(2, false); break;
+        default: if (staged) GSR_K9(3, true); else GSR_K9(3, false); break;
+    }
+#undef GSR_K9
     return hipGetLastError();
 }
 
