@@ -234,7 +234,9 @@ __global__ __launch_bounds__(GDR_BLOCK) void preprocess_fwd_kernel(
 //   [4..6] dL/dconic.x, .y, .z (true partials)   [7] dL/ddepth
 //   [8..10] dL/dcolour r, g, b                   [11] dL/dopacity     [12..15] unused
 // ---------------------------------------------------------------------------------
-template <int DEG>
+// STAGED (shs given, M == NB, degrees 1 and 3): SH rows in / SH-gradient rows out through LDS, coalesced
+// (device_math.h RowStage); one barrier after body() for every thread
+template <int DEG, bool STAGED>
 __global__ __launch_bounds__(GDR_BLOCK) void preprocess_bwd_kernel(
     int N, int M, const float* __restrict__ means3D, const int32_t* __restrict__ radii,
     const float* __restrict__ shs, const uint8_t* __restrict__ g_clamped,
@@ -248,11 +250,27 @@ __global__ __launch_bounds__(GDR_BLOCK) void preprocess_bwd_kernel(
     const float4* __restrict__ g_rec, uint32_t flags, int accumulate) {
     Cam cam;
     load_cam(cam, view, proj, campos);
-    const int i = blockIdx.x * GDR_BLOCK + threadIdx.x;
-    if (i >= N) return;
     constexpr int NB = (DEG + 1) * (DEG + 1);
+    constexpr int ROWF = 3 * NB;
+    using RS = RowStage<STAGED ? ROWF : 4>;
+    __shared__ float lds_rows[STAGED ? RS::LDS_FLOATS : 1];
+    const int row0 = blockIdx.x * GDR_BLOCK, nrows = min(GDR_BLOCK, N - row0);
+    const int i = row0 + threadIdx.x;
+    float* my_row = lds_rows + (STAGED ? (int)threadIdx.x * RS::STRIDE : 0);
+    if (STAGED) {
+        stage_rows_in<STAGED ? ROWF : 4>(shs, row0, nrows, lds_rows);
+        __syncthreads();
+    }
+    auto zero_row = [&]() {
+        if (STAGED) {
+#pragma unroll
+            for (int c = 0; c < ROWF / 4; ++c) *reinterpret_cast<float4*>(my_row + 4 * c) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto body = [&]() __attribute__((always_inline)) {
+    if (i >= N) return;
     const bool vis = radii[i] > 0;
-    if (accumulate && !vis) return;  // += 0 everywhere: nothing to do for a culled Gaussian
+    if (accumulate && !vis) { zero_row(); return; }  // += 0 everywhere: nothing to do for a culled Gaussian
     float dmean[3] = {0.f, 0.f, 0.f};
     float dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float dscale[3] = {0.f, 0.f, 0.f};
@@ -344,7 +362,18 @@ __global__ __launch_bounds__(GDR_BLOCK) void preprocess_bwd_kernel(
             const uint32_t cl = g_clamped[i];
             const float g[3] = {(cl & 1u) ? 0.f : gcolor.x, (cl & 2u) ? 0.f : gcolor.y,
                                 (cl & 4u) ? 0.f : gcolor.z};
-            const float* sh = shs + (size_t)i * M * 3;
+            const float* sh_g = shs + (size_t)i * M * 3;
+            float sh[NB * 3];
+            if (STAGED) {
+#pragma unroll
+                for (int c = 0; c < ROWF / 4; ++c) {
+                    const float4 t = *reinterpret_cast<const float4*>(my_row + 4 * c);
+                    sh[4 * c] = t.x; sh[4 * c + 1] = t.y; sh[4 * c + 2] = t.z; sh[4 * c + 3] = t.w;
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < NB * 3; ++k) sh[k] = sh_g[k];
+            }
             float ddx = 0.f, ddy = 0.f, ddz = 0.f;
 #pragma unroll
             for (int k = 0; k < NB; ++k) {
@@ -358,7 +387,13 @@ __global__ __launch_bounds__(GDR_BLOCK) void preprocess_bwd_kernel(
             }
             // dL/dsh[k][ch] = b_k g_ch: written (or added) as whole 16-byte chunks when the SH row
             // of a Gaussian is 16-byte aligned (M*12 % 16 == 0: deg 1 and 3), else scalar
-            if ((3 * NB) % 4 == 0 && M == NB) {
+            if (STAGED) {  // the gradient row replaces the SH row this thread owns; written out coalesced after body()
+#pragma unroll
+                for (int c = 0; c < ROWF / 4; ++c)
+                    *reinterpret_cast<float4*>(my_row + 4 * c) =
+                        make_float4(bk[(4 * c) / 3] * g[(4 * c) % 3], bk[(4 * c + 1) / 3] * g[(4 * c + 1) % 3],
+                                    bk[(4 * c + 2) / 3] * g[(4 * c + 2) % 3], bk[(4 * c + 3) / 3] * g[(4 * c + 3) % 3]);
+            } else if ((3 * NB) % 4 == 0 && M == NB) {
                 float4* d4 = reinterpret_cast<float4*>(dsh);
 #pragma unroll
                 for (int c = 0; c < (3 * NB) / 4; ++c) {
@@ -439,7 +474,8 @@ __global__ __launch_bounds__(GDR_BLOCK) void preprocess_bwd_kernel(
     } else {
         dL_dmean2D[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         dL_dopacity[i] = 0.f;
-        if (dsh)
+        zero_row();
+        if (dsh && !STAGED)
             for (int k = 0; k < 3 * M; ++k) dsh[k] = 0.f;
         if (colors_precomp && dL_dcolors) {
             dL_dcolors[3 * i] = 0.f; dL_dcolors[3 * i + 1] = 0.f; dL_dcolors[3 * i + 2] = 0.f;
@@ -474,6 +510,12 @@ __global__ __launch_bounds__(GDR_BLOCK) void preprocess_bwd_kernel(
         dL_dscale[3 * i + 1] = dscale[1];
         dL_dscale[3 * i + 2] = dscale[2];
         dL_drot[i] = drot;
+    }
+    };
+    body();
+    if (STAGED) {
+        __syncthreads();
+        stage_rows_out<STAGED ? ROWF : 4>(dL_dsh, row0, nrows, lds_rows, accumulate != 0);
     }
 }
 
@@ -928,13 +970,24 @@ hipError_t launch_preprocess_bwd(const gdr_settings* s, const gdr_inputs* in, co
     const int grid = div_up(N, GDR_BLOCK);
     const int deg = in->shs ? s->sh_degree : 0;
     const float* cov3D = in->cov3D_precomp ? in->cov3D_precomp : g->cov3D;
-    LAUNCH_DEG(GDR_K_PREPROCESS_BWD, preprocess_bwd_kernel, deg, grid, st, N, in->M, in->means3D, radii, in->shs,
-               g->clamped, in->scales, in->rotations, s->scale_modifier, cov3D,
-               in->cov3D_precomp ? 1 : 0, in->colors_precomp ? 1 : 0, s->viewmatrix,
-               s->projmatrix, s->campos, W, H, s->tanfovx, s->tanfovy, focal_x, focal_y,
-               (const float4*)go->scratch, (float4*)go->dL_dmeans2D, go->dL_dopacities, go->dL_dmeans3D,
-               go->dL_dcov3D, go->dL_dshs, go->dL_dcolors, go->dL_dscales,
-               (float4*)go->dL_drotations, (const float4*)g->rec, in->flags, go->accumulate);
+#define GDR_K9(DEG_, ST_) GDR_LAUNCH(GDR_K_PREPROCESS_BWD, (preprocess_bwd_kernel<DEG_, ST_>), dim3(grid), dim3(GDR_BLOCK), st, N, in->M, in->means3D, radii, in->shs, \
+               g->clamped, in->scales, in->rotations, s->scale_modifier, cov3D, \
+               in->cov3D_precomp ? 1 : 0, in->colors_precomp ? 1 : 0, s->viewmatrix, \
+               s->projmatrix, s->campos, W, H, s->tanfovx, s->tanfovy, focal_x, focal_y, \
+               (const float4*)go->scratch, (float4*)go->dL_dmeans2D, go->dL_dopacities, go->dL_dmeans3D, \
+               go->dL_dcov3D, go->dL_dshs, go->dL_dcolors, go->dL_dscales, \
+               (float4*)go->dL_drotations, (const float4*)g->rec, in->flags, go->accumulate)
+    {
+        const int nb_ = (deg + 1) * (deg + 1);
+        const bool staged = in->shs && go->dL_dshs && in->M == nb_ && (3 * nb_) % 4 == 0;
+        switch (deg) {
+            case 0: GDR_K9(0, false); break;
+            case 1: if (staged) GDR_K9(1, true); else GDR_K9(1, false); break;
+            case 2: GDR_K9(2, false); break;
+            default: if (staged) GDR_K9(3, true); else GDR_K9(3, false); break;
+        }
+    }
+#undef GDR_K9
     return hipGetLastError();
 }
 
