@@ -109,6 +109,9 @@ def main():
     ap.add_argument("--torch-loss", action="store_true",
                     help="take the loss with torch ops on the clamped HWC dicts (default: the fused HIP loss kernel, "
                          "same value and gradients, generativedensification_amd/losses.py)")
+    ap.add_argument("--loss-kernels", action="store_true",
+                    help="separate fused loss kernels after K6 / before K7 (losses.view_loss_fused) instead of the loss "
+                         "folded into K6/K7 (default)")
     ap.add_argument("--stacked-loss", action="store_true",
                     help="take the loss on the view-stacked tensors (measured slower: dim-wise means on strided views)")
     ap.add_argument("--per-view", action="store_true",
@@ -221,7 +224,11 @@ def main():
                 losses.append(loss.detach())
             losses = torch.stack(losses)
         else:               # multi-view entry point: all views of the shard in one rasterizer node
-            if not (args.stacked_loss or args.torch_loss or args.unfused):
+            if not (args.stacked_loss or args.torch_loss or args.unfused or args.loss_kernels):
+                # loss folded into K6's epilogue / K7's prologue: no loss kernels, no dL/dimage tensors
+                lv = renderer.render_views_loss(cams, None, targets_chw, params["centers"], params["shs"], params["opacity"],
+                                                params["scales"], params["rotations"], dev)
+            elif not (args.stacked_loss or args.torch_loss or args.unfused):
                 outs = render_views(renderer, cams, None, params, dev, raw=True)
                 lv = torch.stack([view_loss_fused(o["color"], o["depth"], o["alpha"], targets_chw[j])
                                   for j, o in enumerate(outs)])
@@ -362,7 +369,8 @@ def main():
                                 if surfel and not (args.per_view or args.torch_loss or args.unfused)
                                 else "torch ops (MSE + 1000 distortion + 0.2 normal consistency + 0.1 depth + 0.1 alpha)" if surfel
                                 else "torch ops" if (args.per_view or args.stacked_loss or args.torch_loss or args.unfused)
-                                else "fused HIP kernel (clamp+MSE+0.1 mean depth+0.1 mean alpha)")},
+                                else "fused HIP loss kernels (clamp+MSE+0.1 mean depth+0.1 mean alpha)" if args.loss_kernels
+                                else "folded into K6 epilogue / K7 prologue (clamp+MSE+0.1 mean depth+0.1 mean alpha)")},
             "roofline": roofline, "cpu_baseline": cpu_baseline, "kernels": kernels,
             "loss_mean": float(last_losses.mean()),
         }

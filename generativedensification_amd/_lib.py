@@ -111,6 +111,12 @@ _PROTOS = {
                                       C.POINTER(GdrImage), C.c_uint64, C.c_void_p, C.c_void_p]),
     "gdr_composite_forward": (C.c_int, [C.POINTER(GdrSettings), C.POINTER(GdrGeom), C.POINTER(GdrBinning),
                                         C.POINTER(GdrImage), C.POINTER(GdrOutputs), C.c_void_p]),
+    "gdr_composite_forward_loss": (C.c_int, [C.POINTER(GdrSettings), C.POINTER(GdrGeom), C.POINTER(GdrBinning),
+                                             C.POINTER(GdrImage), C.POINTER(GdrOutputs), C.c_void_p, C.c_float, C.c_float,
+                                             C.c_void_p, C.c_void_p]),
+    "gdr_render_backward_loss": (C.c_int, [C.POINTER(GdrSettings), C.c_int32, C.POINTER(GdrGeom), C.POINTER(GdrBinning),
+                                           C.POINTER(GdrImage), C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p,
+                                           C.c_void_p, C.c_void_p]),
     "gdr_forward": (C.c_int, [C.POINTER(GdrSettings), C.POINTER(GdrInputs), C.POINTER(GdrGeom),
                               C.POINTER(GdrBinning), C.POINTER(GdrImage), C.c_uint64,
                               C.POINTER(GdrOutputs), C.POINTER(C.c_uint32), C.c_void_p]),

@@ -263,6 +263,35 @@ int gdr_composite_forward(const gdr_settings* s, const gdr_geom* geom, const gdr
     return debug_sync(s, "render_fwd", st);
 }
 
+int gdr_composite_forward_loss(const gdr_settings* s, const gdr_geom* geom, const gdr_binning* bin, const gdr_image* img,
+                               const gdr_outputs* out, const float* target, float w_depth, float w_alpha, float* loss,
+                               void* stream) {
+    if (!s || !geom || !bin || !img || !out || !out->color || !out->depth || !out->alpha || !target || !loss) {
+        set_error("composite_forward_loss: NULL argument", hipSuccess);
+        return GDR_ERR_INVALID_ARG;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = launch_render_fwd_loss(s, geom, bin, img, out, target, w_depth, w_alpha, loss, st);
+    if (e != hipSuccess) return hip_fail("render_fwd_loss", e);
+    return debug_sync(s, "render_fwd_loss", st);
+}
+
+int gdr_render_backward_loss(const gdr_settings* s, int32_t N, const gdr_geom* geom, const gdr_binning* bin,
+                             const gdr_image* img, const float* color, const float* target, float w_depth, float w_alpha,
+                             const float* g, float* grad_rec, void* stream) {
+    if (!s || !geom || !bin || !img || !color || !target || !g || (N > 0 && !grad_rec) || !s->bg) {
+        set_error("render_backward_loss: NULL argument", hipSuccess);
+        return GDR_ERR_INVALID_ARG;
+    }
+    if (N <= 0) return GDR_OK;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(grad_rec, 0, (size_t)N * 16 * sizeof(float), st);
+    if (e != hipSuccess) return hip_fail("memset gradient records", e);
+    e = launch_render_bwd_loss(s, geom, bin, img, color, target, w_depth, w_alpha, g, grad_rec, st);
+    if (e != hipSuccess) return hip_fail("render_bwd_loss", e);
+    return debug_sync(s, "render_bwd_loss", st);
+}
+
 int gdr_render_forward(const gdr_settings* s, const gdr_inputs* in, const gdr_geom* geom,
                        gdr_binning* bin, const gdr_image* img, uint64_t D, const gdr_outputs* out,
                        void* stream) {

@@ -91,6 +91,12 @@ hipError_t launch_ranges(const gdr_binning* bin, uint64_t D, const gdr_image* im
 hipError_t launch_tile_order(const gdr_image* img, int tiles, hipStream_t st);
 hipError_t launch_render_fwd(const gdr_settings* s, const gdr_geom* g, const gdr_binning* bin,
                              const gdr_image* img, const gdr_outputs* out, hipStream_t st);
+hipError_t launch_render_fwd_loss(const gdr_settings* s, const gdr_geom* g, const gdr_binning* bin,
+                                  const gdr_image* img, const gdr_outputs* out, const float* target, float w_depth,
+                                  float w_alpha, float* loss, hipStream_t st);
+hipError_t launch_render_bwd_loss(const gdr_settings* s, const gdr_geom* g, const gdr_binning* bin,
+                                  const gdr_image* img, const float* color, const float* target, float w_depth,
+                                  float w_alpha, const float* go, float* grad_rec, hipStream_t st);
 hipError_t launch_render_bwd_mean2d(const gdr_settings* s, const gdr_geom* g, const gdr_binning* bin,
                                     const gdr_image* img, const float* dL_dcolor, float* dL_dmean2D,
                                     hipStream_t st);

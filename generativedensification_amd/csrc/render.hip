@@ -136,12 +136,24 @@ __global__ __launch_bounds__(GDR_BLOCK) void tile_order_kernel(const uint2* __re
 // ---------------------------------------------------------------------------------
 // K6
 // ---------------------------------------------------------------------------------
+// LOSS: the image loss of the measurement / training step folded into the epilogue:
+//   loss += mean_{c,p}(clamp(color,0,1) - target)^2 + w_depth mean(depth) + w_alpha mean(alpha)
+// (renderer.py:261 clamp, loss.py:37-38 MSE; depth / alpha means: §8d) — one atomicAdd per tile.
+struct FusedLoss {
+    const float* target;  // (3,H,W)
+    float w_depth, w_alpha;
+    float* loss;          // K6: accumulated (caller zeroes)
+    const float* go;      // K7: upstream scalar gradient (device)
+    const float* color;   // K7: the colour K6 wrote, (3,H,W)
+};
+
+template <bool LOSS>
 __global__ __launch_bounds__(GDR_BLOCK) void render_fwd_kernel(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const uint32_t* __restrict__ tile_order, int W, int H, int gx, int ntiles,
     const float4* __restrict__ rec, const float* __restrict__ bg, float* __restrict__ final_T,
     uint32_t* __restrict__ n_contrib, float* __restrict__ out_color, float* __restrict__ out_depth,
-    float* __restrict__ out_alpha) {
+    float* __restrict__ out_alpha, const FusedLoss fl) {
     __shared__ SliceLds lds;
     __shared__ int s_done[GDR_BLOCK / GDR_WAVE];
 
@@ -256,6 +268,24 @@ __global__ __launch_bounds__(GDR_BLOCK) void render_fwd_kernel(
         out_depth[pix] = Dp;
         out_alpha[pix] = Wt;
     }
+    if (LOSS) {
+        float lp = 0.f;
+        if (inside) {
+            const size_t pix = (size_t)py * W + px, P = (size_t)H * W;
+            const float invp = 1.f / (float)P;
+            const float c0 = fminf(fmaxf(fmaf(T, bg[0], C0), 0.f), 1.f) - fl.target[pix];
+            const float c1 = fminf(fmaxf(fmaf(T, bg[1], C1), 0.f), 1.f) - fl.target[P + pix];
+            const float c2 = fminf(fmaxf(fmaf(T, bg[2], C2), 0.f), 1.f) - fl.target[2 * P + pix];
+            lp = (fmaf(c0, c0, fmaf(c1, c1, c2 * c2)) * (1.f / 3.f) + fl.w_depth * Dp + fl.w_alpha * Wt) * invp;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) lp += __shfl_xor(lp, off, 64);
+        __syncthreads();  // s_done is free again
+        float* wl = reinterpret_cast<float*>(s_done);
+        if (lane == 0) wl[wave] = lp;
+        __syncthreads();
+        if (threadIdx.x == 0) atomicAdd(fl.loss, (wl[0] + wl[1]) + (wl[2] + wl[3]));
+    }
 }
 
 // ---------------------------------------------------------------------------------
@@ -266,13 +296,14 @@ __global__ __launch_bounds__(GDR_BLOCK) void render_fwd_kernel(
 // M2_ONLY: only dL/dmean2D (x, y, |x|, |y|) is produced, accumulated over views straight into an (N,4)
 // buffer — the screen-space gradient the densification step consumes (network.py:865-878); dL/ddepth and
 // dL/dalpha inputs are taken as zero (that call site differentiates an image loss only).
-template <bool M2_ONLY>
+// LOSS: dL/dpixel computed in the prologue from the colour K6 wrote and the target (see FusedLoss) instead of read
+template <bool M2_ONLY, bool LOSS = false>
 __global__ __launch_bounds__(GDR_BLOCK) void render_bwd_kernel(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const uint32_t* __restrict__ tile_order, int W, int H, int gx, int ntiles,
     const float* __restrict__ bg, const float4* __restrict__ rec, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
     const float* __restrict__ dL_dpix, const float* __restrict__ dL_ddepthpix,
-    const float* __restrict__ dL_dalphapix, float* __restrict__ grad_rec) {
+    const float* __restrict__ dL_dalphapix, float* __restrict__ grad_rec, const FusedLoss fl) {
     __shared__ SliceLds lds;
     __shared__ uint32_t s_id[GDR_BLOCK + 1];
 
@@ -300,7 +331,17 @@ __global__ __launch_bounds__(GDR_BLOCK) void render_bwd_kernel(
     float T = T_final;
     const int last_contributor = inside ? (int)n_contrib[pix] : 0;
     float gC0 = 0.f, gC1 = 0.f, gC2 = 0.f, gD = 0.f, gA = 0.f;
-    if (inside && last_contributor > 0) {  // a pixel without contributors reads no upstream gradient (NaN-safe)
+    if (LOSS) {
+        if (inside && last_contributor > 0) {
+            const float go = *fl.go, invp = go / (float)P, k = 2.f * invp * (1.f / 3.f);
+            const float c0 = fl.color[pix], c1 = fl.color[P + pix], c2 = fl.color[2 * P + pix];
+            gC0 = (c0 >= 0.f && c0 <= 1.f) ? k * (c0 - fl.target[pix]) : 0.f;   // clamp passes the gradient inside [0,1]
+            gC1 = (c1 >= 0.f && c1 <= 1.f) ? k * (c1 - fl.target[P + pix]) : 0.f;
+            gC2 = (c2 >= 0.f && c2 <= 1.f) ? k * (c2 - fl.target[2 * P + pix]) : 0.f;
+            gD = fl.w_depth * invp;
+            gA = fl.w_alpha * invp;
+        }
+    } else if (inside && last_contributor > 0) {  // a pixel without contributors reads no upstream gradient (NaN-safe)
         gC0 = dL_dpix[pix]; gC1 = dL_dpix[P + pix]; gC2 = dL_dpix[2 * P + pix];
         if (!M2_ONLY && dL_ddepthpix) gD = dL_ddepthpix[pix];
         if (!M2_ONLY && dL_dalphapix) gA = dL_dalphapix[pix];
@@ -449,9 +490,36 @@ hipError_t launch_render_fwd(const gdr_settings* s, const gdr_geom* g, const gdr
     const int W = s->image_width, H = s->image_height;
     const int gx = tile_grid_x(W), gy = tile_grid_y(H);
     const int ntiles = gx * gy;
-    GDR_LAUNCH(GDR_K_RENDER_FWD, render_fwd_kernel, dim3(ntiles), dim3(GDR_BLOCK), st,
+    GDR_LAUNCH(GDR_K_RENDER_FWD, render_fwd_kernel<false>, dim3(ntiles), dim3(GDR_BLOCK), st,
                (const uint2*)img->ranges, bin->values[bin->sorted], img->tile_order, W, H, gx, ntiles,
-               (const float4*)g->rec, s->bg, img->final_T, img->n_contrib, out->color, out->depth, out->alpha);
+               (const float4*)g->rec, s->bg, img->final_T, img->n_contrib, out->color, out->depth, out->alpha,
+               FusedLoss{});
+    return hipGetLastError();
+}
+
+hipError_t launch_render_fwd_loss(const gdr_settings* s, const gdr_geom* g, const gdr_binning* bin,
+                                  const gdr_image* img, const gdr_outputs* out, const float* target, float w_depth,
+                                  float w_alpha, float* loss, hipStream_t st) {
+    const int W = s->image_width, H = s->image_height;
+    const int gx = tile_grid_x(W), gy = tile_grid_y(H);
+    const int ntiles = gx * gy;
+    const FusedLoss fl{target, w_depth, w_alpha, loss, nullptr, nullptr};
+    GDR_LAUNCH(GDR_K_RENDER_FWD, render_fwd_kernel<true>, dim3(ntiles), dim3(GDR_BLOCK), st,
+               (const uint2*)img->ranges, bin->values[bin->sorted], img->tile_order, W, H, gx, ntiles,
+               (const float4*)g->rec, s->bg, img->final_T, img->n_contrib, out->color, out->depth, out->alpha, fl);
+    return hipGetLastError();
+}
+
+hipError_t launch_render_bwd_loss(const gdr_settings* s, const gdr_geom* g, const gdr_binning* bin,
+                                  const gdr_image* img, const float* color, const float* target, float w_depth,
+                                  float w_alpha, const float* go, float* grad_rec, hipStream_t st) {
+    const int W = s->image_width, H = s->image_height;
+    const int gx = tile_grid_x(W), gy = tile_grid_y(H);
+    const int ntiles = gx * gy;
+    const FusedLoss fl{target, w_depth, w_alpha, nullptr, go, color};
+    GDR_LAUNCH(GDR_K_RENDER_BWD, (render_bwd_kernel<false, true>), dim3(ntiles), dim3(GDR_BLOCK), st,
+               (const uint2*)img->ranges, bin->values[bin->sorted], img->tile_order, W, H, gx, ntiles, s->bg,
+               (const float4*)g->rec, img->final_T, img->n_contrib, nullptr, nullptr, nullptr, grad_rec, fl);
     return hipGetLastError();
 }
 
@@ -464,7 +532,7 @@ hipError_t launch_render_bwd(const gdr_settings* s, const gdr_geom* g, const gdr
     GDR_LAUNCH(GDR_K_RENDER_BWD, render_bwd_kernel<false>, dim3(ntiles), dim3(GDR_BLOCK), st,
                (const uint2*)img->ranges, bin->values[bin->sorted], img->tile_order, W, H, gx, ntiles, s->bg,
                (const float4*)g->rec, img->final_T, img->n_contrib, gi->dL_dcolor, gi->dL_ddepth, gi->dL_dalpha,
-               go->scratch);
+               go->scratch, FusedLoss{});
     return hipGetLastError();
 }
 
@@ -476,7 +544,7 @@ hipError_t launch_render_bwd_mean2d(const gdr_settings* s, const gdr_geom* g, co
     const int ntiles = gx * gy;
     GDR_LAUNCH(GDR_K_RENDER_BWD, render_bwd_kernel<true>, dim3(ntiles), dim3(GDR_BLOCK), st,
                (const uint2*)img->ranges, bin->values[bin->sorted], img->tile_order, W, H, gx, ntiles, s->bg,
-               (const float4*)g->rec, img->final_T, img->n_contrib, dL_dcolor, nullptr, nullptr, dL_dmean2D);
+               (const float4*)g->rec, img->final_T, img->n_contrib, dL_dcolor, nullptr, nullptr, dL_dmean2D, FusedLoss{});
     return hipGetLastError();
 }
 

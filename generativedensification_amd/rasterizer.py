@@ -271,7 +271,7 @@ class _RasterizeGaussians(torch.autograd.Function):
 RAW_ALL = L.GDR_IN_RAW_OPACITY | L.GDR_IN_RAW_SCALES | L.GDR_IN_RAW_ROTATIONS
 
 
-def _forward_views_impl(means3D, means2D, sh, opacities, scales, rotations, settings_list, flags):
+def _forward_views_impl(means3D, means2D, sh, opacities, scales, rotations, settings_list, flags, loss_spec=None):
     """K1 for all views (one launch per <= 8 views), ONE host read of the V duplicate counts, then binning +
     K6 per view.  Returns (colors, radii, depths, alphas, states, keep, in_dtypes)."""
     lib = L.load()
@@ -330,6 +330,19 @@ def _forward_views_impl(means3D, means2D, sh, opacities, scales, rotations, sett
             st.bin_buf = torch.empty(lib.gdr_binning_bytes(st.D), **u8)
             L.check(lib.gdr_binning_carve(st.bin_buf.data_ptr(), st.D, C.byref(st.bin)), "gdr_binning_carve")
             st.bin.global_sort = int(_FORCE_GLOBAL_SORT)
+        def composite(v, sv):  # K6 of view v (with the loss folded into its epilogue when loss_spec is given)
+            st = states[v]
+            out = L.GdrOutputs(colors[v].data_ptr(), depths[v].data_ptr(), alphas[v].data_ptr(), _ptr(radii[v]))
+            if loss_spec is None:
+                L.check(lib.gdr_composite_forward(C.byref(s_arr[v]), C.byref(g_arr[v]), C.byref(st.bin), C.byref(st.img),
+                                                  C.byref(out), sv), "gdr_composite_forward")
+            else:
+                targets, w_depth, w_alpha, losses = loss_spec
+                L.check(lib.gdr_composite_forward_loss(C.byref(s_arr[v]), C.byref(g_arr[v]), C.byref(st.bin),
+                                                       C.byref(st.img), C.byref(out), targets[v].data_ptr(), float(w_depth),
+                                                       float(w_alpha), losses[v:v + 1].data_ptr(), sv),
+                        "gdr_composite_forward_loss")
+
         main = torch.cuda.current_stream()
         if BIN_STREAM and V > 1:
             # Binning of view v+1 (latency-bound: ~10 short kernels with few workgroups) overlaps K6 of view v
@@ -350,9 +363,7 @@ def _forward_views_impl(means3D, means2D, sh, opacities, scales, rotations, sett
                 binned.append(ev)
             for v, st in enumerate(states):
                 main.wait_event(binned[v])
-                out = L.GdrOutputs(colors[v].data_ptr(), depths[v].data_ptr(), alphas[v].data_ptr(), _ptr(radii[v]))
-                L.check(lib.gdr_composite_forward(C.byref(s_arr[v]), C.byref(g_arr[v]), C.byref(st.bin), C.byref(st.img),
-                                                  C.byref(out), stream), "gdr_composite_forward")
+                composite(v, stream)
             return colors, radii, depths, alphas, states, keep, in_dtypes
         side = _view_streams(dev, min(VIEW_STREAMS, V)) if VIEW_STREAMS > 1 and V > 1 else None
         if side:
@@ -362,9 +373,9 @@ def _forward_views_impl(means3D, means2D, sh, opacities, scales, rotations, sett
                 sd.wait_event(ready)
         for v, st in enumerate(states):
             sv = C.c_void_p(side[v % len(side)].cuda_stream) if side else stream
-            out = L.GdrOutputs(colors[v].data_ptr(), depths[v].data_ptr(), alphas[v].data_ptr(), _ptr(radii[v]))
-            L.check(lib.gdr_render_forward(C.byref(s_arr[v]), C.byref(inp), C.byref(g_arr[v]), C.byref(st.bin),
-                                           C.byref(st.img), st.D, C.byref(out), sv), "gdr_render_forward")
+            L.check(lib.gdr_binning_forward(C.byref(s_arr[v]), N, C.byref(g_arr[v]), C.byref(st.bin), C.byref(st.img), st.D,
+                                            _ptr(radii[v]), sv), "gdr_binning_forward")
+            composite(v, sv)
         if side:
             for sd in side:  # the caller's stream continues only after every view is rendered
                 done = torch.cuda.Event()
@@ -454,6 +465,84 @@ class _RenderViews(torch.autograd.Function):
         grads = [g["means3D"], gm2, g["shs"], g["opacities"], g["scales"], g["rotations"]]
         grads = [t if t.dtype == dt else t.to(dt) for t, dt in zip(grads, ctx.in_dtypes)]
         return (*grads, None, None)
+
+
+class _RenderViewsLoss(torch.autograd.Function):
+    """V views of one Gaussian set AND their image losses in one node: K6 accumulates
+    loss_v = mean((clamp(color_v) - target_v)^2) + w_depth mean(depth_v) + w_alpha mean(alpha_v) in its epilogue, K7
+    forms the per-pixel upstream gradients in its prologue — no loss kernels, no dL/dimage tensors, no autograd nodes
+    between the rasterizer and the scalar losses.  Returns (losses (V,), radii (V,N))."""
+
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, opacities, scales, rotations, settings_list, flags, targets, w_depth, w_alpha):
+        dev = means3D.device
+        V = len(settings_list)
+        targets = [t.to(device=dev, dtype=torch.float32).contiguous() for t in targets]
+        losses = torch.zeros(V, dtype=torch.float32, device=dev)
+        colors, radii, depths, alphas, states, keep, in_dtypes = _forward_views_impl(
+            means3D, means2D, sh, opacities, scales, rotations, settings_list, flags,
+            loss_spec=(targets, w_depth, w_alpha, losses))
+        ctx.states, ctx.keep, ctx.settings_list, ctx.flags = states, keep, settings_list, flags
+        ctx.radii, ctx.in_dtypes, ctx.means2D_shape = radii, in_dtypes, tuple(means2D.shape)
+        ctx.colors, ctx.targets, ctx.w = colors, targets, (float(w_depth), float(w_alpha))
+        ctx.mark_non_differentiable(radii)
+        return losses, radii
+
+    @staticmethod
+    def backward(ctx, g_losses, g_radii):
+        lib = L.load()
+        means3D, opacities, sh, e, scales, rotations, _ = ctx.keep[:7]
+        dev = means3D.device
+        states = ctx.states
+        N, M, V = states[0].N, states[0].M, len(states)
+        f32 = dict(dtype=torch.float32, device=dev)
+        g = dict(means3D=torch.empty(N, 3, **f32), means2D=torch.empty(N, 4, **f32), shs=torch.empty(N, M, 3, **f32),
+                 opacities=torch.empty(N, 1, **f32), scales=torch.empty(N, 3, **f32), rotations=torch.empty(N, 4, **f32))
+        go = g_losses.to(torch.float32).contiguous()
+        with torch.cuda.device(dev):
+            keep2: list = []
+            stream = _stream()
+            inp = _inputs_struct(N, M, means3D, opacities, sh, e, scales, rotations, e, ctx.flags)
+            for lo in range(0, V, L.GDR_MAX_VIEWS):
+                n = min(L.GDR_MAX_VIEWS, V - lo)
+                recs = torch.empty(n, max(N, 1) * 16, **f32)
+                s_arr = (L.GdrSettings * n)()
+                g_arr = (L.GdrGeom * n)()
+                for k in range(n):
+                    v = lo + k
+                    st = states[v]
+                    s_arr[k] = _settings_struct(ctx.settings_list[v], dev, keep2)
+                    g_arr[k] = st.geom
+                    g_arr[k].cov3D = states[0].geom.cov3D
+                    L.check(lib.gdr_render_backward_loss(C.byref(s_arr[k]), N, C.byref(g_arr[k]), C.byref(st.bin),
+                                                         C.byref(st.img), ctx.colors[v].data_ptr(), ctx.targets[v].data_ptr(),
+                                                         ctx.w[0], ctx.w[1], go[v:v + 1].data_ptr(), recs[k].data_ptr(),
+                                                         stream), "gdr_render_backward_loss")
+                r_arr = (C.c_void_p * n)(*[ctx.radii[lo + k].data_ptr() if N else None for k in range(n)])
+                rec_arr = (C.c_void_p * n)(*[recs[k].data_ptr() for k in range(n)])
+                gout = L.GdrGradOutputs(_ptr(g["means3D"]), _ptr(g["means2D"]), _ptr(g["shs"]), None,
+                                        _ptr(g["opacities"]), _ptr(g["scales"]), _ptr(g["rotations"]), None, None,
+                                        1 if lo > 0 else 0, 0)
+                L.check(lib.gdr_preprocess_backward_views(n, s_arr, C.byref(inp), g_arr, r_arr, rec_arr,
+                                                          C.byref(gout), stream), "gdr_preprocess_backward_views")
+                keep2.append(recs)
+        gm2 = g["means2D"]
+        cols = ctx.means2D_shape[1] if len(ctx.means2D_shape) == 2 else 4
+        if cols == 3:
+            gm2 = torch.cat([gm2[:, :2], torch.zeros_like(gm2[:, :1])], dim=1)
+        elif cols != 4:
+            gm2 = gm2[:, :cols].contiguous()
+        grads = [g["means3D"], gm2, g["shs"], g["opacities"], g["scales"], g["rotations"]]
+        grads = [t if t.dtype == dt else t.to(dt) for t, dt in zip(grads, ctx.in_dtypes)]
+        return (*grads, None, None, None, None, None)
+
+
+def render_views_loss_raw(means3D, means2D, sh, opacities, scales, rotations, settings_list, targets_chw, w_depth=0.1,
+                          w_alpha=0.1, flags=RAW_ALL):
+    """Per-view losses (V,) of V views of one Gaussian set with the loss folded into K6/K7; targets_chw: V tensors
+    (3,H,W).  Returns (losses, radii)."""
+    return _RenderViewsLoss.apply(means3D, means2D, sh, opacities, scales, rotations, list(settings_list), int(flags),
+                                  list(targets_chw), float(w_depth), float(w_alpha))
 
 
 def render_views_raw(means3D, means2D, sh, opacities, scales, rotations, settings_list, flags=RAW_ALL):

@@ -19,7 +19,7 @@ import math
 import torch
 from torch import nn
 
-from .rasterizer import (GaussianRasterizationSettings, GaussianRasterizer, render_views_raw,
+from .rasterizer import (GaussianRasterizationSettings, GaussianRasterizer, render_views_loss_raw, render_views_raw,
                          screenspace_absgrad_raw)
 
 
@@ -90,6 +90,26 @@ class Renderer(nn.Module):
         if stacked:
             return {k: torch.stack([o[k] for o in outs]) for k in outs[0]}
         return outs
+
+    def render_views_loss(self, cams, bg_colors, targets_chw, centers, shs, opacity, scales, rotations, device,
+                          w_depth=0.1, w_alpha=0.1, screenspace_points=None):
+        """Per-view image losses (V,) of all `cams` with the loss folded into the rasterizer's K6 epilogue / K7 prologue
+        (SURVEY §8f-4): loss_v = mean((clamp(image_v) - target_v)^2) + w_depth mean(depth_v) + w_alpha mean(alpha_v) —
+        `synthetic.view_loss` on render_views' dicts, without materialising dL/dimage.  targets_chw: (V,3,H,W)."""
+        sets = []
+        for j, cam in enumerate(cams):
+            if bg_colors is not None:
+                self.set_bg_color(bg_colors[j] if isinstance(bg_colors, (list, tuple)) else bg_colors)
+            sets.append(self.set_rasterizer(cam, device=device).raster_settings)
+        if screenspace_points is None:
+            screenspace_points = torch.zeros((centers.shape[0], 4), dtype=centers.dtype, requires_grad=True, device=device) + 0
+        try:
+            screenspace_points.retain_grad()
+        except Exception:
+            pass
+        losses, _ = render_views_loss_raw(centers, screenspace_points, shs, opacity, scales, rotations, sets,
+                                          [targets_chw[j] for j in range(len(sets))], w_depth, w_alpha)
+        return losses
 
     def screenspace_absgrad(self, cams, bg_colors, gt_images, centers, shs, opacity, scales, rotations, device):
         """Image loss and its (N,4) screen-space gradient over `cams` — the quantity the reference obtains with

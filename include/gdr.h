@@ -201,6 +201,20 @@ int gdr_binning_forward(const gdr_settings* s, int32_t N, const gdr_geom* geom, 
 int gdr_composite_forward(const gdr_settings* s, const gdr_geom* geom, const gdr_binning* bin, const gdr_image* img,
                           const gdr_outputs* out, void* stream);
 
+/* K6 / K7 with the image loss folded in ("clamp + MSE + per-view loss reduction folded into the K6/K7
+ * epilogue/prologue"; renderer.py:261 clamp, loss.py:37-38 MSE, plus the depth / alpha means of the measurement loss):
+ *   *loss += mean_{c,p}(clamp(color,0,1) - target)^2 + w_depth mean(depth) + w_alpha mean(alpha)
+ * gdr_composite_forward_loss = K6 that also accumulates the view's loss (one atomic per tile; the caller zeroes *loss);
+ * the images are still written.  gdr_render_backward_loss = K7 whose per-pixel upstream gradients are computed from
+ * `color` (what K6 wrote) and `target` times the upstream scalar *g (device) instead of being read — no loss kernels,
+ * no dL/dimage tensors.  target, color: (3,H,W). */
+int gdr_composite_forward_loss(const gdr_settings* s, const gdr_geom* geom, const gdr_binning* bin, const gdr_image* img,
+                               const gdr_outputs* out, const float* target, float w_depth, float w_alpha, float* loss,
+                               void* stream);
+int gdr_render_backward_loss(const gdr_settings* s, int32_t N, const gdr_geom* geom, const gdr_binning* bin,
+                             const gdr_image* img, const float* color, const float* target, float w_depth, float w_alpha,
+                             const float* g, float* grad_rec, void* stream);
+
 /* Stages 1+2 with a caller-provided binning capacity D_cap.  Synchronises once to
  * read D; returns GDR_ERR_WORKSPACE (and *num_rendered_host = required D) if
  * D > D_cap, in which case only stage 1 has run. */

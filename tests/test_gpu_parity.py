@@ -420,3 +420,42 @@ def test_fused_view_loss_matches_torch_loss_value_and_gradients():
     assert abs(lf.item() - lt.item()) <= 2e-6 * abs(lt.item())
     for x, y in zip(gf, gt):
         torch.testing.assert_close(x, y, rtol=1e-6, atol=1e-12)
+
+
+def test_loss_folded_into_k6_k7_matches_the_torch_loss_on_render_views():
+    """Renderer.render_views_loss (K6 epilogue accumulates the loss, K7 prologue forms dL/dpixel) == synthetic.view_loss
+    on render_views' dicts + autograd: values to 2e-6, Gaussian gradients to 1e-4, per-view bg colours, non-unit
+    upstream gradients, a good share of pixels outside [0,1] (clamp mask)."""
+    from generativedensification_amd.camera import orbit_cameras
+    from generativedensification_amd.renderer import Renderer
+    from generativedensification_amd.synthetic import make_scene, make_targets, view_loss
+
+    dev = torch.device("cuda:0")
+    n, h, w, V = 25_000, 150, 200, 3
+    sc = make_scene(n, 93, sh_degree=3, sigma0=(0.0052, 0.02))
+    sc["shs"][:, 0] *= 3.0
+    cams = orbit_cameras(V, w, h, device=dev)
+    tg = make_targets(V, h, w, 93).to(dev)
+    tg_chw = tg.permute(0, 3, 1, 2).contiguous()
+    bgs = [torch.tensor(c, device=dev) for c in ([1.0, 1.0, 1.0], [0.5, 0.5, 0.5], [0.0, 0.0, 0.0])]
+    wts = torch.tensor([0.7, 1.9, 1.0], device=dev)
+    r = Renderer(sh_degree=3, fused=True)
+
+    def run(folded):
+        leaves = {k: v.to(dev).clone().requires_grad_(True) for k, v in sc.items()}
+        ssp = torch.zeros(n, 4, device=dev, requires_grad=True)
+        args = (leaves["centers"], leaves["shs"], leaves["opacity"], leaves["scales"], leaves["rotations"], dev)
+        if folded:
+            lv = r.render_views_loss(cams, bgs, tg_chw, *args, screenspace_points=ssp)
+        else:
+            outs = r.render_views(cams, bgs, *args, screenspace_points=ssp)
+            lv = torch.stack([view_loss(o, tg[j]) for j, o in enumerate(outs)])
+        grads = torch.autograd.grad((lv * wts).sum(), list(leaves.values()) + [ssp])
+        return lv.detach().cpu().numpy(), {k: g_.cpu().numpy() for k, g_ in zip(list(leaves) + ["ssp"], grads)}
+
+    l_ref, g_ref = run(False)
+    l_fold, g_fold = run(True)
+    np.testing.assert_allclose(l_fold, l_ref, rtol=2e-6)
+    for k in g_ref:
+        assert U.rel_inf(g_fold[k], g_ref[k]) < 1e-4, k
+    assert g_fold["ssp"].shape == (n, 4) and (g_fold["ssp"][:, 2:] >= 0).all()
