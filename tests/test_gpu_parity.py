@@ -459,3 +459,51 @@ def test_loss_folded_into_k6_k7_matches_the_torch_loss_on_render_views():
     for k in g_ref:
         assert U.rel_inf(g_fold[k], g_ref[k]) < 1e-4, k
     assert g_fold["ssp"].shape == (n, 4) and (g_fold["ssp"][:, 2:] >= 0).all()
+
+
+@pytest.mark.parametrize("H,W", [(1, 1), (5, 37), (16, 16), (17, 300)])
+def test_tiny_and_odd_image_sizes_both_paths(oracle_built, H, W):
+    """Degenerate image shapes (single pixel, one partial tile, a 19-tile strip) through both rasterizers."""
+    case = U.make_case(300, H, W, 31, deg=2, sigma0=(0.05, 0.3))
+    grads = U.rand_grads(case)
+    hip, hg = U.run_hip(case, grads)
+    ora, _ = U.run_oracle(case, "f32")
+    _, g64 = U.run_oracle(case, "f64", grads)
+    for k in ("radii", "rect", "tiles_touched", "point_list", "ranges"):
+        np.testing.assert_array_equal(np.asarray(hip[k]).astype(np.asarray(ora[k]).dtype).reshape(np.asarray(ora[k]).shape), ora[k], err_msg=k)
+    assert U.outlier_fraction(hip["color"], ora["color"], 1e-4, 1e-4) < 2e-3
+    for k in ("means3D", "shs", "opacities", "scales", "rotations"):
+        assert U.rel_inf(hg[k].reshape(g64[k].shape), g64[k]) < 2e-4, k
+    scase = U.make_surfel_case(300, H, W, 31, deg=2, sigma0=(0.05, 0.3))
+    sg = U.rand_surfel_grads(scase)
+    ship, shg = U.run_surfel_hip(scase, sg)
+    sora, sg32 = U.run_surfel_oracle(scase, "f32", sg)
+    _, sg64 = U.run_surfel_oracle(scase, "f64", sg)
+    for k in ("radii", "rect", "tiles_touched", "point_list", "ranges"):
+        np.testing.assert_array_equal(np.asarray(ship[k]).astype(np.asarray(sora[k]).dtype).reshape(np.asarray(sora[k]).shape), sora[k], err_msg=k)
+    assert U.outlier_fraction(ship["color"], sora["color"], 1e-4, 1e-4) < 2e-3
+    for k in ("means3D", "shs", "opacities", "scales", "rotations"):
+        ref = sg64[k]
+        e_hip, e_o32 = U.rel_inf(shg[k].reshape(ref.shape), ref), U.rel_inf(sg32[k].reshape(ref.shape), ref)
+        assert e_hip <= 2.0 * e_o32 + 2e-4, (k, e_hip, e_o32)
+
+
+def test_one_tile_with_a_very_long_list_takes_the_global_sort_path(oracle_built):
+    """20k Gaussians stacked on one spot: a single tile list far beyond the 8192-entry LDS classes of the per-tile
+    depth sort (tile_sort_long's global ping-pong), equal depths included; sorted list bit-exact, image within tolerance."""
+    case = U.make_case(20_000, 48, 48, 37, deg=0, sigma0=(0.01,))
+    case["means3D"] = (case["means3D"] * 0.02).contiguous()          # all inside one or two tiles at the image centre
+    case["means3D"][::7] = case["means3D"][0]                         # exact depth ties
+    case["opacities"] = (case["opacities"] * 0.02).contiguous()       # keep transmittance alive through the long list
+    grads = U.rand_grads(case)
+    hip, hg = U.run_hip(case, grads)
+    ora, _ = U.run_oracle(case, "f32")
+    lens = ora["ranges"][:, 1].astype(np.int64) - ora["ranges"][:, 0].astype(np.int64)
+    assert lens.max() > 8192
+    np.testing.assert_array_equal(hip["point_list"], ora["point_list"])
+    np.testing.assert_array_equal(hip["ranges"], ora["ranges"])
+    assert U.outlier_fraction(hip["color"], ora["color"], 1e-3, 1e-4) < 1e-3
+    assert float((hip["n_contrib"].astype(np.int64) != ora["n_contrib"]).mean()) < 1e-3
+    _, g64 = U.run_oracle(case, "f64", grads, nthreads=8)
+    for k in ("means3D", "opacities", "scales", "rotations"):
+        assert U.rel_inf(hg[k].reshape(g64[k].shape), g64[k]) < 5e-4, k
