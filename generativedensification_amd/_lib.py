@@ -164,6 +164,13 @@ _PROTOS = {
     "gsr_view_loss_backward": (C.c_int, [C.c_void_p] * 5 + [C.c_int32, C.c_int32] + [C.c_float] * 5 + [C.c_void_p] * 5),
     "gsr_knn_cells": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "gsr_knn_mean_dist2": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gsr_preprocess_forward_views": (C.c_int, [C.c_int32, C.POINTER(GdrSettings), C.POINTER(GsrInputs), C.POINTER(GdrGeom),
+                                               C.POINTER(C.c_void_p), C.c_void_p]),
+    "gsr_render_backward": (C.c_int, [C.POINTER(GdrSettings), C.c_int32, C.POINTER(GdrGeom), C.POINTER(GdrBinning),
+                                      C.POINTER(GdrImage), C.POINTER(GsrGradInputs), C.c_void_p, C.c_void_p]),
+    "gsr_preprocess_backward_views": (C.c_int, [C.c_int32, C.POINTER(GdrSettings), C.POINTER(GsrInputs), C.POINTER(GdrGeom),
+                                                C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(GsrGradOutputs),
+                                                C.c_void_p]),
     "gsr_backward": (C.c_int, [C.POINTER(GdrSettings), C.POINTER(GsrInputs), C.POINTER(GdrGeom), C.POINTER(GdrBinning),
                                C.POINTER(GdrImage), C.c_uint64, C.c_void_p, C.POINTER(GsrGradInputs),
                                C.POINTER(GsrGradOutputs), C.c_void_p]),

@@ -652,6 +652,75 @@ int gsr_backward(const gdr_settings* s, const gsr_inputs* in, const gdr_geom* ge
     return debug_sync(s, "surfel_preprocess_bwd", st);
 }
 
+static int check_surfel_views(int32_t V, const gdr_settings* s, const gsr_inputs* in, const gdr_geom* geoms) {
+    if (V < 1 || V > GDR_MAX_VIEWS) { set_error("surfel views: V out of range", hipSuccess); return GDR_ERR_UNSUPPORTED; }
+    if (!s || !in || !geoms) { set_error("surfel views: NULL argument", hipSuccess); return GDR_ERR_INVALID_ARG; }
+    for (int v = 0; v < V; ++v) {
+        int rc = check_surfel(&s[v], in);
+        if (rc) return rc;
+        if (s[v].image_width != s[0].image_width || s[v].image_height != s[0].image_height ||
+            s[v].sh_degree != s[0].sh_degree || s[v].scale_modifier != s[0].scale_modifier) {
+            set_error("surfel views: image size / sh_degree / scale_modifier must match", hipSuccess);
+            return GDR_ERR_INVALID_ARG;
+        }
+    }
+    if (in->N > 0 && (!in->shs || !in->scales || !in->rotations)) {
+        set_error("surfel views: needs shs + scales + rotations", hipSuccess);
+        return GDR_ERR_UNSUPPORTED;
+    }
+    return GDR_OK;
+}
+
+int gsr_preprocess_forward_views(int32_t V, const gdr_settings* s, const gsr_inputs* in, const gdr_geom* geoms,
+                                 int32_t* const* radii, void* stream) {
+    int rc = check_surfel_views(V, s, in, geoms);
+    if (rc) return rc;
+    if (!radii) { set_error("surfel views: radii NULL", hipSuccess); return GDR_ERR_INVALID_ARG; }
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipSuccess;
+    for (int v = 0; v < V && e == hipSuccess; ++v) e = hipMemsetAsync(geoms[v].num_rendered, 0, sizeof(uint32_t), st);
+    if (e != hipSuccess) return hip_fail("memset num_rendered", e);
+    e = launch_surfel_preprocess_fwd_views(V, s, in, geoms, radii, st);
+    if (e != hipSuccess) return hip_fail("surfel_preprocess_fwd_views", e);
+    return debug_sync(&s[0], "surfel_preprocess_fwd_views", st);
+}
+
+int gsr_render_backward(const gdr_settings* s, int32_t N, const gdr_geom* geom, const gdr_binning* bin,
+                        const gdr_image* img, const gsr_grad_inputs* gin, float* grad_rec, void* stream) {
+    if (!s || !geom || !bin || !img || !gin || !gin->dL_dcolor || (N > 0 && !grad_rec) || !s->bg) {
+        set_error("surfel render_backward: NULL argument", hipSuccess);
+        return GDR_ERR_INVALID_ARG;
+    }
+    if (N <= 0) return GDR_OK;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(grad_rec, 0, (size_t)N * GSR_GRAD_FLOATS * sizeof(float), st);
+    if (e != hipSuccess) return hip_fail("memset gradient records", e);
+    e = launch_surfel_render_bwd(s, geom, bin, img, gin, grad_rec, st);
+    if (e != hipSuccess) return hip_fail("surfel_render_bwd", e);
+    return debug_sync(s, "surfel_render_bwd", st);
+}
+
+int gsr_preprocess_backward_views(int32_t V, const gdr_settings* s, const gsr_inputs* in, const gdr_geom* geoms,
+                                  const int32_t* const* radii, float* const* grad_recs, const gsr_grad_outputs* gout,
+                                  void* stream) {
+    int rc = check_surfel_views(V, s, in, geoms);
+    if (rc) return rc;
+    if (!radii || !grad_recs || !gout || !gout->dL_dmeans3D || !gout->dL_dmeans2D || !gout->dL_dshs ||
+        !gout->dL_dopacities || !gout->dL_dscales || !gout->dL_drotations) {
+        set_error("surfel backward views: NULL argument", hipSuccess);
+        return GDR_ERR_INVALID_ARG;
+    }
+    const int nb = (s[0].sh_degree + 1) * (s[0].sh_degree + 1);
+    if ((3 * nb) % 4 == 0 && in->M != nb) {
+        set_error("surfel backward views: M must equal (sh_degree+1)^2 at degrees 1 and 3", hipSuccess);
+        return GDR_ERR_UNSUPPORTED;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = launch_surfel_preprocess_bwd_views(V, s, in, geoms, radii, grad_recs, gout, st);
+    if (e != hipSuccess) return hip_fail("surfel_preprocess_bwd_views", e);
+    return debug_sync(&s[0], "surfel_preprocess_bwd_views", st);
+}
+
 int gsr_maps_forward(const float* allmap, const float* rays, const float* viewmatrix, int32_t H, int32_t W,
                      float depth_ratio, float* depth, float* acc_map, float* rend_normal, float* depth_normal,
                      float* rend_dist, void* stream) {

@@ -114,6 +114,11 @@ hipError_t launch_surfel_preprocess_fwd(const gdr_settings* s, const gsr_inputs*
                                         int32_t* radii, hipStream_t st);
 hipError_t launch_surfel_preprocess_bwd(const gdr_settings* s, const gsr_inputs* in, const gdr_geom* g,
                                         const int32_t* radii, const gsr_grad_outputs* go, hipStream_t st);
+hipError_t launch_surfel_preprocess_fwd_views(int V, const gdr_settings* s, const gsr_inputs* in, const gdr_geom* geoms,
+                                              int32_t* const* radii, hipStream_t st);
+hipError_t launch_surfel_preprocess_bwd_views(int V, const gdr_settings* s, const gsr_inputs* in, const gdr_geom* geoms,
+                                              const int32_t* const* radii, float* const* grad_recs,
+                                              const gsr_grad_outputs* go, hipStream_t st);
 hipError_t launch_surfel_render_fwd(const gdr_settings* s, const gdr_geom* g, const gdr_binning* bin,
                                     const gdr_image* img, const gsr_outputs* out, hipStream_t st);
 hipError_t launch_surfel_render_bwd(const gdr_settings* s, const gdr_geom* g, const gdr_binning* bin,

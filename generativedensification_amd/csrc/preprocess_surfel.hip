@@ -459,6 +459,362 @@ __global__ __launch_bounds__(GDR_BLOCK) void surfel_preprocess_bwd_kernel(
     }
 }
 
+// =================================================================================
+// Multi-view variants (SURVEY §8f-1 for the surfel path): V views of ONE surfel set per launch.  One thread owns one
+// surfel and loops over the views: position / scales / quaternion / opacity (and their activations, the rotation
+// matrix) are read and computed once, the SH row is loaded once; in the backward the per-view gradients of the three
+// world-space vectors that build T (s_u t_u, s_v t_v, p), of the normal and of the SH block are summed in registers
+// and the scale / quaternion chain runs once.  Per-view arithmetic is expression-for-expression the single-view
+// kernels', so integer intermediates stay bit-identical.
+// =================================================================================
+struct SFwdView {
+    const float* view; const float* proj; const float* campos;
+    int32_t* radii; float* depths; float4* rec; int4* rect; uint32_t* tiles; uint8_t* clamped;
+    uint32_t* block_sums; uint32_t* block_offs; uint32_t* num_rendered;
+};
+struct SFwdViewsArgs { int V; SFwdView v[GDR_MAX_VIEWS]; };
+
+template <int DEG>
+__global__ __launch_bounds__(GDR_BLOCK) void surfel_preprocess_fwd_views_kernel(
+    int N, int M, const float* __restrict__ means3D, const float* __restrict__ scales, float scale_modifier,
+    const float* __restrict__ rotations, const float* __restrict__ opacities, const float* __restrict__ shs, int W, int H,
+    uint32_t flags, const SFwdViewsArgs a) {
+    __shared__ uint32_t wsum[GDR_MAX_VIEWS][GDR_BLOCK / GDR_WAVE];
+    constexpr int NB = (DEG + 1) * (DEG + 1);
+    const int i = blockIdx.x * GDR_BLOCK + threadIdx.x;
+    const int gx = (W + GDR_TILE - 1) / GDR_TILE, gy = (H + GDR_TILE - 1) / GDR_TILE;
+    const bool valid = i < N;
+    float p[3] = {0.f, 0.f, 0.f}, R[9], s0 = 0.f, s1 = 0.f, op = 0.f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) R[k] = 0.f;
+    float sh[NB * 3];
+    bool sh_loaded = false;
+    if (valid) {
+        p[0] = means3D[3 * i]; p[1] = means3D[3 * i + 1]; p[2] = means3D[3 * i + 2];
+        op = (flags & GDR_IN_RAW_OPACITY) ? act_sigmoid(opacities[i]) : opacities[i];
+        float4 q = reinterpret_cast<const float4*>(rotations)[i];
+        float sc0 = scales[2 * i], sc1 = scales[2 * i + 1];
+        if (flags & GDR_IN_RAW_ROTATIONS) { float inv_n; q = act_normalize(q, &inv_n); }
+        if (flags & GDR_IN_RAW_SCALES) { sc0 = expf(sc0); sc1 = expf(sc1); }
+        quat_to_R(q.x, q.y, q.z, q.w, R);
+        s0 = scale_modifier * sc0; s1 = scale_modifier * sc1;
+    }
+    for (int v = 0; v < a.V; ++v) {
+        const SFwdView& fv = a.v[v];
+        uint32_t tiles = 0;
+        if (valid) {
+            Cam cam;
+            load_cam(cam, fv.view, fv.proj, fv.campos);
+            int rad = 0;
+            float depth = 0.f;
+            int4 rect = make_int4(0, 0, 0, 0);
+            uint32_t clampbits = 0;
+            SurfelT T;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) T.Tu[k] = T.Tv[k] = T.Tw[k] = 0.f;
+            float nv[3] = {0.f, 0.f, 0.f}, rgb[3] = {0.f, 0.f, 0.f}, cxy[2] = {0.f, 0.f}, opv = 0.f;
+            float lo[2] = {INFINITY, INFINITY}, hi[2] = {-INFINITY, -INFINITY};
+            const float pvx = cam.v[0] * p[0] + cam.v[4] * p[1] + cam.v[8] * p[2] + cam.v[12];
+            const float pvy = cam.v[1] * p[0] + cam.v[5] * p[1] + cam.v[9] * p[2] + cam.v[13];
+            const float pvz = cam.v[2] * p[0] + cam.v[6] * p[1] + cam.v[10] * p[2] + cam.v[14];
+            bool ok = pvz > 0.2f;
+            if (ok) {
+                SurfelT Tl;
+                surfel_transmat(p, s0, s1, R, cam.p, W, H, Tl);
+                const float n[3] = {(cam.v[0] * R[2] + cam.v[4] * R[5]) + cam.v[8] * R[8],
+                                    (cam.v[1] * R[2] + cam.v[5] * R[5]) + cam.v[9] * R[8],
+                                    (cam.v[2] * R[2] + cam.v[6] * R[5]) + cam.v[10] * R[8]};
+                const float cosv = -((pvx * n[0] + pvy * n[1]) + pvz * n[2]);
+                ok = cosv != 0.f;
+                const float mult = cosv > 0.f ? 1.f : -1.f;
+                const float t0 = 9.f, t2 = -1.f;
+                const float d = (t0 * Tl.Tw[0] * Tl.Tw[0] + t0 * Tl.Tw[1] * Tl.Tw[1]) + t2 * Tl.Tw[2] * Tl.Tw[2];
+                ok = ok && d != 0.f;
+                if (ok) {
+                    const float inv_d = 1.f / d;
+                    const float f0 = t0 * inv_d, f2 = t2 * inv_d;
+                    const float cx = (f0 * Tl.Tu[0] * Tl.Tw[0] + f0 * Tl.Tu[1] * Tl.Tw[1]) + f2 * Tl.Tu[2] * Tl.Tw[2];
+                    const float cy = (f0 * Tl.Tv[0] * Tl.Tw[0] + f0 * Tl.Tv[1] * Tl.Tw[1]) + f2 * Tl.Tv[2] * Tl.Tw[2];
+                    const float hx0 = cx * cx - ((f0 * Tl.Tu[0] * Tl.Tu[0] + f0 * Tl.Tu[1] * Tl.Tu[1]) + f2 * Tl.Tu[2] * Tl.Tu[2]);
+                    const float hy0 = cy * cy - ((f0 * Tl.Tv[0] * Tl.Tv[0] + f0 * Tl.Tv[1] * Tl.Tv[1]) + f2 * Tl.Tv[2] * Tl.Tv[2]);
+                    const float ex = sqrtf(fmaxf(1e-4f, hx0)), ey = sqrtf(fmaxf(1e-4f, hy0));
+                    const float my_radius = ceilf(fmaxf(fmaxf(ex, ey), 3.f * GSR_FILTER_SIZE));
+                    const int r_i = (int)my_radius;
+                    const float rf = (float)r_i;
+                    rect.x = min(gx, max(0, (int)((cx - rf) / (float)GDR_TILE)));
+                    rect.y = min(gy, max(0, (int)((cy - rf) / (float)GDR_TILE)));
+                    rect.z = min(gx, max(0, (int)((cx + rf + (float)(GDR_TILE - 1)) / (float)GDR_TILE)));
+                    rect.w = min(gy, max(0, (int)((cy + rf + (float)(GDR_TILE - 1)) / (float)GDR_TILE)));
+                    tiles = (uint32_t)((rect.z - rect.x) * (rect.w - rect.y));
+                    ok = tiles != 0;
+                    if (ok) {
+                        rad = r_i;
+                        depth = pvz;
+                        T = Tl;
+                        cxy[0] = cx; cxy[1] = cy;
+                        nv[0] = mult * n[0]; nv[1] = mult * n[1]; nv[2] = mult * n[2];
+                        opv = op;
+                        alpha_box(T, cx, cy, op, lo, hi);
+                        if (!sh_loaded) {  // first view in which this surfel is visible
+                            const float* src = shs + (size_t)i * M * 3;
+#pragma unroll
+                            for (int k = 0; k < NB * 3; ++k) sh[k] = src[k];
+                            sh_loaded = true;
+                        }
+                        float dx = p[0] - cam.c[0], dy = p[1] - cam.c[1], dz = p[2] - cam.c[2];
+                        const float inv = 1.f / sqrtf((dx * dx + dy * dy) + dz * dz);
+                        dx *= inv; dy *= inv; dz *= inv;
+                        float bk[NB];
+                        sh_basis<DEG>(dx, dy, dz, bk);
+#pragma unroll
+                        for (int ch = 0; ch < 3; ++ch) rgb[ch] = bk[0] * sh[ch];
+#pragma unroll
+                        for (int k = 1; k < NB; ++k)
+#pragma unroll
+                            for (int ch = 0; ch < 3; ++ch) rgb[ch] = rgb[ch] + bk[k] * sh[3 * k + ch];
+#pragma unroll
+                        for (int ch = 0; ch < 3; ++ch) {
+                            rgb[ch] = rgb[ch] + 0.5f;
+                            if (rgb[ch] < 0.f) clampbits |= (1u << ch);
+                            rgb[ch] = fmaxf(rgb[ch], 0.f);
+                        }
+                    } else {
+                        rect = make_int4(0, 0, 0, 0);
+                    }
+                }
+                if (!ok) tiles = 0;
+            }
+            fv.radii[i] = rad;
+            fv.depths[i] = depth;
+            float4* r = fv.rec + 6 * (size_t)i;
+            r[0] = make_float4(T.Tu[0], T.Tu[1], T.Tu[2], cxy[0]);
+            r[1] = make_float4(T.Tv[0], T.Tv[1], T.Tv[2], cxy[1]);
+            r[2] = make_float4(T.Tw[0], T.Tw[1], T.Tw[2], opv);
+            r[3] = make_float4(nv[0], nv[1], nv[2], rgb[0]);
+            r[4] = make_float4(rgb[1], rgb[2], lo[0], lo[1]);
+            r[5] = make_float4(hi[0], hi[1], 0.f, 0.f);
+            fv.rect[i] = rect;
+            fv.tiles[i] = tiles;
+            fv.clamped[i] = (uint8_t)clampbits;
+        }
+        uint32_t t = tiles;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
+        if ((threadIdx.x & 63) == 0) wsum[v][threadIdx.x >> 6] = t;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < a.V) {
+        const SFwdView& fv = a.v[threadIdx.x];
+        const uint32_t bs = wsum[threadIdx.x][0] + wsum[threadIdx.x][1] + wsum[threadIdx.x][2] + wsum[threadIdx.x][3];
+        fv.block_sums[blockIdx.x] = bs;
+        fv.block_offs[blockIdx.x] = bs ? atomicAdd(fv.num_rendered, bs) : 0u;
+    }
+}
+
+struct SBwdView {
+    const float* view; const float* proj; const float* campos;
+    const int32_t* radii; const uint8_t* clamped; const float4* grad_rec; const float4* rec;
+};
+struct SBwdViewsArgs { int V; SBwdView v[GDR_MAX_VIEWS]; };
+
+template <int DEG>
+__global__ __launch_bounds__(GDR_BLOCK) void surfel_preprocess_bwd_views_kernel(
+    int N, int M, const float* __restrict__ means3D, const float* __restrict__ shs, const float* __restrict__ scales,
+    const float* __restrict__ rotations, const float* __restrict__ opacities, float scale_modifier, int W, int H,
+    uint32_t flags, int accumulate, float4* __restrict__ dL_dmean2D, float* __restrict__ dL_dopacity,
+    float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dsh, float* __restrict__ dL_dscale,
+    float4* __restrict__ dL_drot, const SBwdViewsArgs a) {
+    constexpr int NB = (DEG + 1) * (DEG + 1);
+    constexpr int ROWF = 3 * NB;
+    constexpr bool STAGED = (ROWF % 4) == 0;  // launcher guarantees M == NB when ROWF % 4 == 0 is used (else DEG fallback)
+    using RS = RowStage<STAGED ? ROWF : 4>;
+    __shared__ float lds_rows[STAGED ? RS::LDS_FLOATS : 1];
+    const int row0 = blockIdx.x * GDR_BLOCK, nrows = min(GDR_BLOCK, N - row0);
+    const int i = row0 + threadIdx.x;
+    float* my_row = lds_rows + (STAGED ? (int)threadIdx.x * RS::STRIDE : 0);
+    if (STAGED) {
+        stage_rows_in<STAGED ? ROWF : 4>(shs, row0, nrows, lds_rows);
+        __syncthreads();
+    }
+    auto body = [&]() __attribute__((always_inline)) {
+        float dsh[NB * 3];
+#pragma unroll
+        for (int k = 0; k < NB * 3; ++k) dsh[k] = 0.f;
+        auto put_row = [&]() {
+            if (STAGED) {
+#pragma unroll
+                for (int c = 0; c < ROWF / 4; ++c)
+                    *reinterpret_cast<float4*>(my_row + 4 * c) = make_float4(dsh[4 * c], dsh[4 * c + 1], dsh[4 * c + 2], dsh[4 * c + 3]);
+            }
+        };
+        if (i >= N) return;
+        const float p[3] = {means3D[3 * i], means3D[3 * i + 1], means3D[3 * i + 2]};
+        float4 q = reinterpret_cast<const float4*>(rotations)[i];
+        float sc0 = scales[2 * i], sc1 = scales[2 * i + 1];
+        float inv_n = 1.f;
+        if (flags & GDR_IN_RAW_ROTATIONS) q = act_normalize(q, &inv_n);
+        if (flags & GDR_IN_RAW_SCALES) { sc0 = expf(sc0); sc1 = expf(sc1); }
+        float R[9];
+        quat_to_R(q.x, q.y, q.z, q.w, R);
+        const float s0 = scale_modifier * sc0, s1 = scale_modifier * sc1;
+        const float hw = (float)W / 2.f, hh = (float)H / 2.f, cw = (float)(W - 1) / 2.f, ch_ = (float)(H - 1) / 2.f;
+        float dv[3][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};  // dL/d(s_u t_u), dL/d(s_v t_v), dL/dp (T path)
+        float dn[3] = {0.f, 0.f, 0.f}, dmean[3] = {0.f, 0.f, 0.f}, dop = 0.f;
+        float4 dm2 = make_float4(0.f, 0.f, 0.f, 0.f);
+        bool any_vis = false;
+        const float* sh_g = shs + (size_t)i * M * 3;
+        for (int v = 0; v < a.V; ++v) {
+            const SBwdView& bv = a.v[v];
+            if (bv.radii[i] <= 0) continue;
+            any_vis = true;
+            Cam cam;
+            load_cam(cam, bv.view, bv.proj, bv.campos);
+            const float4* gr = bv.grad_rec + 8 * (size_t)i;
+            const float4 g0 = gr[0], g1 = gr[1], g2 = gr[2], g3 = gr[3], g4 = gr[4];
+            float dT[9] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w, g2.x};
+            const float gcol[3] = {g2.z, g2.w, g3.x};
+            const float gnrm[3] = {g3.y, g3.z, g3.w};
+            const float glx = g4.x, gly = g4.y, gax = g4.z, gay = g4.w;
+            const float4 r0 = bv.rec[6 * (size_t)i], r1 = bv.rec[6 * (size_t)i + 1], r2 = bv.rec[6 * (size_t)i + 2];
+            const float Tu[3] = {r0.x, r0.y, r0.z}, Tv[3] = {r1.x, r1.y, r1.z}, Tw[3] = {r2.x, r2.y, r2.z};
+            const float depth = Tw[2];
+            dm2.x += dT[2] * depth * 0.5f * (float)W; dm2.y += dT[5] * depth * 0.5f * (float)H;
+            dm2.z += gax * depth * 0.5f * (float)W;   dm2.w += gay * depth * 0.5f * (float)H;
+            dop += g2.y;
+            if (glx != 0.f || gly != 0.f) {
+                const float t[3] = {9.f, 9.f, -1.f};
+                const float d = (t[0] * Tw[0] * Tw[0] + t[1] * Tw[1] * Tw[1]) + t[2] * Tw[2] * Tw[2];
+                const float inv_d = 1.f / d;
+                float f[3], dfdot = 0.f;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    f[k] = t[k] * inv_d;
+                    dT[0 + k] += glx * f[k] * Tw[k];
+                    dT[3 + k] += gly * f[k] * Tw[k];
+                    dT[6 + k] += glx * f[k] * Tu[k] + gly * f[k] * Tv[k];
+                    dfdot += (glx * Tu[k] * Tw[k] + gly * Tv[k] * Tw[k]) * f[k];
+                }
+                const float dL_dd = -dfdot * inv_d;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) dT[6 + k] += dL_dd * 2.f * t[k] * Tw[k];
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float dc0 = dT[0 + c] * hw, dc1 = dT[3 + c] * hh, dc3 = dT[0 + c] * cw + dT[3 + c] * ch_ + dT[6 + c];
+#pragma unroll
+                for (int r = 0; r < 3; ++r) dv[c][r] += cam.p[4 * r + 0] * dc0 + cam.p[4 * r + 1] * dc1 + cam.p[4 * r + 3] * dc3;
+            }
+            const float pvx = cam.v[0] * p[0] + cam.v[4] * p[1] + cam.v[8] * p[2] + cam.v[12];
+            const float pvy = cam.v[1] * p[0] + cam.v[5] * p[1] + cam.v[9] * p[2] + cam.v[13];
+            const float pvz = cam.v[2] * p[0] + cam.v[6] * p[1] + cam.v[10] * p[2] + cam.v[14];
+            const float n0 = (cam.v[0] * R[2] + cam.v[4] * R[5]) + cam.v[8] * R[8];
+            const float n1 = (cam.v[1] * R[2] + cam.v[5] * R[5]) + cam.v[9] * R[8];
+            const float n2 = (cam.v[2] * R[2] + cam.v[6] * R[5]) + cam.v[10] * R[8];
+            const float mult = -((pvx * n0 + pvy * n1) + pvz * n2) > 0.f ? 1.f : -1.f;
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+                dn[r] += mult * (cam.v[4 * r + 0] * gnrm[0] + cam.v[4 * r + 1] * gnrm[1] + cam.v[4 * r + 2] * gnrm[2]);
+            {   // SH backward of this view
+                float dx = p[0] - cam.c[0], dy = p[1] - cam.c[1], dz = p[2] - cam.c[2];
+                const float inv = 1.f / sqrtf((dx * dx + dy * dy) + dz * dz);
+                const float ux = dx * inv, uy = dy * inv, uz = dz * inv;
+                float bk[NB], bx[NB], by[NB], bz[NB];
+                sh_basis<DEG>(ux, uy, uz, bk);
+                sh_basis_grad<DEG>(ux, uy, uz, bx, by, bz);
+                const uint32_t cl = bv.clamped[i];
+                const float g[3] = {(cl & 1u) ? 0.f : gcol[0], (cl & 2u) ? 0.f : gcol[1], (cl & 4u) ? 0.f : gcol[2]};
+                float shr[NB * 3];
+                if (STAGED) {
+#pragma unroll
+                    for (int c = 0; c < ROWF / 4; ++c) {
+                        const float4 t = *reinterpret_cast<const float4*>(my_row + 4 * c);
+                        shr[4 * c] = t.x; shr[4 * c + 1] = t.y; shr[4 * c + 2] = t.z; shr[4 * c + 3] = t.w;
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < NB * 3; ++k) shr[k] = sh_g[k];
+                }
+                float ddx = 0.f, ddy = 0.f, ddz = 0.f;
+#pragma unroll
+                for (int k = 0; k < NB; ++k) {
+#pragma unroll
+                    for (int ch = 0; ch < 3; ++ch) {
+                        const float sg = shr[3 * k + ch] * g[ch];
+                        dsh[3 * k + ch] += bk[k] * g[ch];
+                        ddx += bx[k] * sg; ddy += by[k] * sg; ddz += bz[k] * sg;
+                    }
+                }
+                const float dot = ux * ddx + uy * ddy + uz * ddz;
+                dmean[0] += (ddx - ux * dot) * inv;
+                dmean[1] += (ddy - uy * dot) * inv;
+                dmean[2] += (ddz - uz * dot) * inv;
+            }
+        }
+        if (accumulate && !any_vis) { put_row(); return; }
+        // scale / quaternion chain once, from the view-summed world-space gradients
+#pragma unroll
+        for (int r = 0; r < 3; ++r) dmean[r] += dv[2][r];
+        float dR[9], ds0 = 0.f, ds1 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            dR[3 * r + 0] = s0 * dv[0][r];
+            dR[3 * r + 1] = s1 * dv[1][r];
+            dR[3 * r + 2] = dn[r];
+            ds0 += R[3 * r + 0] * dv[0][r];
+            ds1 += R[3 * r + 1] * dv[1][r];
+        }
+        float dscale0 = scale_modifier * ds0, dscale1 = scale_modifier * ds1;
+        const float qr = q.x, qx = q.y, qy = q.z, qz = q.w;
+        float4 drot;
+#define G_(r_, c_) dR[3 * (r_) + (c_)]
+        drot.x = 2.f * (-qz * G_(0, 1) + qy * G_(0, 2) + qz * G_(1, 0) - qx * G_(1, 2) - qy * G_(2, 0) + qx * G_(2, 1));
+        drot.y = 2.f * (qy * G_(0, 1) + qz * G_(0, 2) + qy * G_(1, 0) - 2.f * qx * G_(1, 1) - qr * G_(1, 2) + qz * G_(2, 0) + qr * G_(2, 1) - 2.f * qx * G_(2, 2));
+        drot.z = 2.f * (-2.f * qy * G_(0, 0) + qx * G_(0, 1) + qr * G_(0, 2) + qx * G_(1, 0) + qz * G_(1, 2) - qr * G_(2, 0) + qz * G_(2, 1) - 2.f * qy * G_(2, 2));
+        drot.w = 2.f * (-2.f * qz * G_(0, 0) - qr * G_(0, 1) + qx * G_(0, 2) + qr * G_(1, 0) - 2.f * qz * G_(1, 1) + qy * G_(1, 2) + qx * G_(2, 0) + qy * G_(2, 1));
+#undef G_
+        if (flags & GDR_IN_RAW_SCALES) { dscale0 *= sc0; dscale1 *= sc1; }
+        if (flags & GDR_IN_RAW_ROTATIONS) {
+            const float dot = (q.x * drot.x + q.y * drot.y) + (q.z * drot.z + q.w * drot.w);
+            drot = make_float4((drot.x - q.x * dot) * inv_n, (drot.y - q.y * dot) * inv_n, (drot.z - q.z * dot) * inv_n,
+                               (drot.w - q.w * dot) * inv_n);
+        }
+        if (flags & GDR_IN_RAW_OPACITY) { const float o = act_sigmoid(opacities[i]); dop = dop * (o * (1.f - o)); }
+        if (accumulate) {
+            const float4 om = dL_dmean2D[i];
+            dm2 = make_float4(dm2.x + om.x, dm2.y + om.y, dm2.z + om.z, dm2.w + om.w);
+            dop += dL_dopacity[i];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) dmean[k] += dL_dmeans3D[3 * i + k];
+            dscale0 += dL_dscale[2 * i]; dscale1 += dL_dscale[2 * i + 1];
+            const float4 orot = dL_drot[i];
+            drot = make_float4(drot.x + orot.x, drot.y + orot.y, drot.z + orot.z, drot.w + orot.w);
+        }
+        dL_dmean2D[i] = dm2;
+        dL_dopacity[i] = dop;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) dL_dmeans3D[3 * i + k] = dmean[k];
+        dL_dscale[2 * i] = dscale0; dL_dscale[2 * i + 1] = dscale1;
+        dL_drot[i] = drot;
+        if (STAGED) {
+            put_row();
+        } else {
+            float* o_sh = dL_dsh + (size_t)i * M * 3;
+#pragma unroll
+            for (int k = 0; k < NB * 3; ++k) {
+                if (accumulate) o_sh[k] += dsh[k];
+                else o_sh[k] = dsh[k];
+            }
+            if (!accumulate)
+                for (int k = NB * 3; k < M * 3; ++k) o_sh[k] = 0.f;
+        }
+    };
+    body();
+    if (STAGED) {
+        __syncthreads();
+        stage_rows_out<STAGED ? ROWF : 4>(dL_dsh, row0, nrows, lds_rows, accumulate != 0);
+    }
+}
+
 #define LAUNCH_DEG_S(KID, KERNEL, deg, grid, st, ...)                                          \
     switch (deg) {                                                                            \
         case 0: GDR_LAUNCH(KID, KERNEL<0>, grid, dim3(GDR_BLOCK), st, __VA_ARGS__); break;    \
@@ -503,6 +859,46 @@ hipError_t launch_surfel_preprocess_bwd(const gdr_settings* s, const gsr_inputs*
         default: if (staged) GSR_K9(3, true); else GSR_K9(3, false); break;
     }
 #undef GSR_K9
+    return hipGetLastError();
+}
+
+hipError_t launch_surfel_preprocess_fwd_views(int V, const gdr_settings* s, const gsr_inputs* in, const gdr_geom* geoms,
+                                              int32_t* const* radii, hipStream_t st) {
+    if (in->N == 0) return hipSuccess;
+    SFwdViewsArgs a;
+    a.V = V;
+    for (int v = 0; v < V; ++v) {
+        SFwdView& f = a.v[v];
+        f.view = s[v].viewmatrix; f.proj = s[v].projmatrix; f.campos = s[v].campos;
+        f.radii = radii[v]; f.depths = geoms[v].depths; f.rec = (float4*)geoms[v].rec; f.rect = (int4*)geoms[v].rect;
+        f.tiles = geoms[v].tiles_touched; f.clamped = geoms[v].clamped; f.block_sums = geoms[v].block_sums;
+        f.block_offs = geoms[v].block_offs; f.num_rendered = geoms[v].num_rendered;
+    }
+    const dim3 grid(div_up(in->N, GDR_BLOCK));
+    LAUNCH_DEG_S(GDR_K_PREPROCESS_FWD, surfel_preprocess_fwd_views_kernel, s[0].sh_degree, grid, st, in->N, in->M,
+                 in->means3D, in->scales, s[0].scale_modifier, in->rotations, in->opacities, in->shs, s[0].image_width,
+                 s[0].image_height, in->flags, a);
+    return hipGetLastError();
+}
+
+// requires M == (deg+1)^2 for degrees 1 and 3 (the staged SH rows); the caller falls back to per-view launches otherwise
+hipError_t launch_surfel_preprocess_bwd_views(int V, const gdr_settings* s, const gsr_inputs* in, const gdr_geom* geoms,
+                                              const int32_t* const* radii, float* const* grad_recs,
+                                              const gsr_grad_outputs* go, hipStream_t st) {
+    if (in->N == 0) return hipSuccess;
+    SBwdViewsArgs a;
+    a.V = V;
+    for (int v = 0; v < V; ++v) {
+        SBwdView& b = a.v[v];
+        b.view = s[v].viewmatrix; b.proj = s[v].projmatrix; b.campos = s[v].campos;
+        b.radii = radii[v]; b.clamped = geoms[v].clamped; b.grad_rec = (const float4*)grad_recs[v];
+        b.rec = (const float4*)geoms[v].rec;
+    }
+    const dim3 grid(div_up(in->N, GDR_BLOCK));
+    LAUNCH_DEG_S(GDR_K_PREPROCESS_BWD, surfel_preprocess_bwd_views_kernel, s[0].sh_degree, grid, st, in->N, in->M,
+                 in->means3D, in->shs, in->scales, in->rotations, in->opacities, s[0].scale_modifier, s[0].image_width,
+                 s[0].image_height, in->flags, go->accumulate, (float4*)go->dL_dmeans2D, go->dL_dopacities,
+                 go->dL_dmeans3D, go->dL_dshs, go->dL_dscales, (float4*)go->dL_drotations, a);
     return hipGetLastError();
 }
 

@@ -209,10 +209,21 @@ class _RenderSurfelViews(torch.autograd.Function):
                 st.geom, st.bin, st.img = L.GdrGeom(), L.GdrBinning(), L.GdrImage()
                 L.check(lib.gsr_geom_carve(st.geom_buf.data_ptr(), N, C.byref(st.geom)), "gsr_geom_carve")
                 L.check(lib.gsr_image_carve(st.img_buf.data_ptr(), st.H, st.W, C.byref(st.img)), "gsr_image_carve")
-                L.check(lib.gsr_preprocess_forward(C.byref(s), C.byref(inp), C.byref(st.geom), _ptr(radii[v]), None, stream),
-                        "gsr_preprocess_forward")
                 states.append(st)
                 structs.append(s)
+            same = all(int(rs.image_height) == H and int(rs.image_width) == W for rs in settings_list)
+            if same:   # K1s for all views in groups of <= GDR_MAX_VIEWS launches (inputs read once per group)
+                for lo in range(0, V, L.GDR_MAX_VIEWS):
+                    n = min(L.GDR_MAX_VIEWS, V - lo)
+                    s_arr = (L.GdrSettings * n)(*structs[lo:lo + n])
+                    g_arr = (L.GdrGeom * n)(*[states[lo + k].geom for k in range(n)])
+                    r_arr = (C.c_void_p * n)(*[radii[lo + k].data_ptr() if N else None for k in range(n)])
+                    L.check(lib.gsr_preprocess_forward_views(n, s_arr, C.byref(inp), g_arr, r_arr, stream),
+                            "gsr_preprocess_forward_views")
+            else:
+                for v, st in enumerate(states):
+                    L.check(lib.gsr_preprocess_forward(C.byref(structs[v]), C.byref(inp), C.byref(st.geom), _ptr(radii[v]),
+                                                       None, stream), "gsr_preprocess_forward")
             d_host = torch.cat([st._view(st.geom_buf, st.geom.num_rendered, torch.int32, 1) for st in states]).cpu().tolist()
             for v, st in enumerate(states):
                 st.D = int(d_host[v]) & 0xFFFFFFFF
@@ -260,13 +271,47 @@ class _RenderSurfelViews(torch.autograd.Function):
         f32 = dict(dtype=torch.float32, device=dev)
         out = dict(means3D=torch.empty(N, 3, **f32), means2D=torch.empty(N, 4, **f32), shs=torch.empty(N, M, 3, **f32),
                    opacities=torch.empty(N, 1, **f32), scales=torch.empty(N, 2, **f32), rotations=torch.empty(N, 4, **f32))
-        scratch = torch.empty(max(N, 1) * L.GSR_GRAD_FLOATS, **f32)
         e = torch.empty(0, dtype=torch.float32, device=dev)
         first = True
+        nb = (int(ctx.settings_list[0].sh_degree) + 1) ** 2
+        fused = (all(x is not None for x in g[:V]) and not ((3 * nb) % 4 == 0 and M != nb)
+                 and all(st.H == ctx.states[0].H and st.W == ctx.states[0].W for st in ctx.states))
+        if fused:   # K7s per view into its own record, then ONE K9s launch per <= 8 views
+            with torch.cuda.device(dev):
+                stream = _stream()
+                keep2: list = []
+                inp = _inputs_struct(N, M, means3D, opacities, sh, e, scales, rotations, e, flags)
+                for lo in range(0, V, L.GDR_MAX_VIEWS):
+                    n = min(L.GDR_MAX_VIEWS, V - lo)
+                    recs = torch.empty(n, max(N, 1) * L.GSR_GRAD_FLOATS, **f32)
+                    s_arr = (L.GdrSettings * n)()
+                    g_arr = (L.GdrGeom * n)()
+                    for k in range(n):
+                        v = lo + k
+                        st = ctx.states[v]
+                        s_arr[k] = _settings_struct(ctx.settings_list[v], dev, keep2)
+                        g_arr[k] = st.geom
+                        gc = _f32(g[v], dev)
+                        ga = None if g[V + v] is None else _f32(g[V + v], dev)
+                        keep2 += [gc, ga]
+                        gin = L.GsrGradInputs(gc.data_ptr(), _ptr(ga))
+                        L.check(lib.gsr_render_backward(C.byref(s_arr[k]), N, C.byref(g_arr[k]), C.byref(st.bin),
+                                                        C.byref(st.img), C.byref(gin), recs[k].data_ptr(), stream),
+                                "gsr_render_backward")
+                    r_arr = (C.c_void_p * n)(*[ctx.radii[lo + k].data_ptr() if N else None for k in range(n)])
+                    rec_arr = (C.c_void_p * n)(*[recs[k].data_ptr() for k in range(n)])
+                    gout = L.GsrGradOutputs(_ptr(out["means3D"]), _ptr(out["means2D"]), _ptr(out["shs"]), None,
+                                            _ptr(out["opacities"]), _ptr(out["scales"]), _ptr(out["rotations"]), None, None,
+                                            1 if lo > 0 else 0, 0)
+                    L.check(lib.gsr_preprocess_backward_views(n, s_arr, C.byref(inp), g_arr, r_arr, rec_arr, C.byref(gout),
+                                                              stream), "gsr_preprocess_backward_views")
+                    keep2.append(recs)
+            first = False
+        scratch = torch.empty(max(N, 1) * L.GSR_GRAD_FLOATS, **f32) if not fused else None
         with torch.cuda.device(dev):
             stream = _stream()
             inp = _inputs_struct(N, M, means3D, opacities, sh, e, scales, rotations, e, flags)
-            for v in range(V):
+            for v in range(V if not fused else 0):
                 gc, ga = g[v], g[V + v]
                 if gc is None and ga is None:
                     continue

@@ -100,6 +100,21 @@ int gsr_backward(const gdr_settings* s, const gsr_inputs* in, const gdr_geom* ge
                  const gdr_image* img, uint64_t D, const int32_t* radii, const gsr_grad_inputs* gin,
                  const gsr_grad_outputs* gout, void* stream);
 
+/* ---- multi-view entry points (one surfel set, V <= GDR_MAX_VIEWS views of one image size; as gdr.h's) ----------------
+ * gsr_preprocess_forward_views: K1s for V views in one launch (inputs and activations once); read the V values
+ * geoms[v].num_rendered, then per view gdr_binning_forward + gsr_composite_forward (or gsr_render_forward).
+ * gsr_render_backward: memset + K7s of one view into its own N*GSR_GRAD_FLOATS record.
+ * gsr_preprocess_backward_views: K9s for V views at once (per-view world-space gradients summed in registers, the scale /
+ * quaternion chain once); needs shs + scales + rotations and, at SH degree 1 or 3, M == (sh_degree+1)^2
+ * (GDR_ERR_UNSUPPORTED otherwise: fall back to gsr_backward per view with accumulate). */
+int gsr_preprocess_forward_views(int32_t V, const gdr_settings* s, const gsr_inputs* in, const gdr_geom* geoms,
+                                 int32_t* const* radii, void* stream);
+int gsr_render_backward(const gdr_settings* s, int32_t N, const gdr_geom* geom, const gdr_binning* bin,
+                        const gdr_image* img, const gsr_grad_inputs* gin, float* grad_rec, void* stream);
+int gsr_preprocess_backward_views(int32_t V, const gdr_settings* s, const gsr_inputs* in, const gdr_geom* geoms,
+                                  const int32_t* const* radii, float* const* grad_recs, const gsr_grad_outputs* gout,
+                                  void* stream);
+
 /* ---- the adaptor's per-pixel maps, fused (renderer_2dgs.py:241-278; SURVEY §8f-3 "depth_to_normal fused") ------
  * forward:  allmap (7,H,W), rays (H,W,6) = origin | direction (dataLoader/utils.py:21-34), viewmatrix (16),
  *           depth_ratio r  ->  depth (H,W,1) = (1-r) nan0(allmap[0]/alpha) + r nan0(allmap[5]); acc_map (H,W) = alpha;

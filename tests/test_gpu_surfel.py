@@ -375,3 +375,35 @@ def test_simple_knn_distcuda2_matches_brute_force(oracle_built, kind, N):
     sc = _activation_scale(pts.to("cuda:0"))   # renderer_2dgs.py:92-96
     assert sc.shape == (N, 2)
     np.testing.assert_allclose(sc[:, 0].cpu().numpy(), np.sqrt(np.maximum(ref, 1e-7)), rtol=1e-5)
+
+
+def test_surfel_multiview_kernels_keep_intermediates_bit_exact(oracle_built):
+    """K1s for V views in one launch (gsr_preprocess_forward_views) == V single-view K1s launches == the f32 oracle:
+    radii, rects, T, centre, normal, rgb, sorted lists bit for bit."""
+    from generativedensification_amd import surfel_rasterizer as S
+    from generativedensification_amd.camera import orbit_cameras
+
+    dev = torch.device("cuda:0")
+    V, H, W, n = 3, 96, 128, 4000
+    base = U.make_surfel_case(n, H, W, 41, deg=3, sigma0=(0.0052, 0.03))
+    cams = orbit_cameras(V, W, H)
+    leaves = [base[k].to(dev) for k in ("means3D", "shs", "opacities", "scales", "rotations")]
+    sets = []
+    cases = []
+    for c in cams:
+        case = dict(base)
+        case.update(view=c.world_view_transform.contiguous(), proj=c.full_proj_transform.contiguous(), campos=c.camera_center.contiguous())
+        cases.append(case)
+        sets.append(U.settings_torch(case, dev))
+    m2 = torch.zeros(n, 4, device=dev)
+    res = S._RenderSurfelViews.apply(leaves[0], m2, leaves[1], leaves[2], leaves[3], leaves[4], sets, 0)
+    radii = res[0].cpu().numpy()
+    for v in range(V):
+        o32, _ = U.run_surfel_oracle(cases[v], "f32")
+        np.testing.assert_array_equal(radii[v], o32["radii"])
+        single, _ = U.run_surfel_hip(cases[v])
+        np.testing.assert_array_equal(single["radii"], o32["radii"])
+        for k in ("transMats", "xy", "normal_opacity", "rgb", "rect", "point_list"):
+            np.testing.assert_array_equal(np.asarray(single[k]).astype(np.asarray(o32[k]).dtype).reshape(np.asarray(o32[k]).shape), o32[k], err_msg=k)
+        torch.testing.assert_close(res[1 + v].cpu(), torch.from_numpy(single["color"]), rtol=0, atol=0)
+        torch.testing.assert_close(res[1 + V + v].cpu(), torch.from_numpy(single["allmap"]), rtol=0, atol=0)
