@@ -322,14 +322,28 @@ def _forward_views_impl(means3D, means2D, sh, opacities, scales, rotations, sett
                     sub_g[k].cov3D = g_arr[0].cov3D
             L.check(lib.gdr_preprocess_forward_views(n, sub_s, C.byref(inp), sub_g, r_arr, stream),
                     "gdr_preprocess_forward_views")
+        main = torch.cuda.current_stream()
+        two_stage = bool(BIN_STREAM) and V > 1
+        if two_stage:  # side streams start waiting for K1 before the host blocks on the read-back
+            auxs = _view_streams(dev, min(BIN_STREAM, V))
+            ready = torch.cuda.Event()
+            ready.record(main)
+            for aux in auxs:
+                aux.wait_event(ready)
         # ONE host read-back for all V views
         d_dev = torch.cat([st._view(st.geom_buf, st.geom.num_rendered, torch.int32, 1) for st in states])
         d_host = d_dev.cpu().tolist()
-        for v, st in enumerate(states):
+
+        def alloc_bin(v):
+            st = states[v]
             st.D = int(d_host[v]) & 0xFFFFFFFF
             st.bin_buf = torch.empty(lib.gdr_binning_bytes(st.D), **u8)
             L.check(lib.gdr_binning_carve(st.bin_buf.data_ptr(), st.D, C.byref(st.bin)), "gdr_binning_carve")
             st.bin.global_sort = int(_FORCE_GLOBAL_SORT)
+
+        if not two_stage:
+            for v in range(V):
+                alloc_bin(v)
         def composite(v, sv):  # K6 of view v (with the loss folded into its epilogue when loss_spec is given)
             st = states[v]
             out = L.GdrOutputs(colors[v].data_ptr(), depths[v].data_ptr(), alphas[v].data_ptr(), _ptr(radii[v]))
@@ -343,18 +357,14 @@ def _forward_views_impl(means3D, means2D, sh, opacities, scales, rotations, sett
                                                        float(w_alpha), losses[v:v + 1].data_ptr(), sv),
                         "gdr_composite_forward_loss")
 
-        main = torch.cuda.current_stream()
-        if BIN_STREAM and V > 1:
+        if two_stage:
             # Binning of view v+1 (latency-bound: ~10 short kernels with few workgroups) overlaps K6 of view v
-            # (VALU-bound) on a dedicated stream.  The D read-back above synchronised `main`, so every workspace
-            # allocated since then is free of pending work and may be touched by the side stream at once.
-            auxs = _view_streams(dev, min(BIN_STREAM, V))
-            ready = torch.cuda.Event()
-            ready.record(main)
-            for aux in auxs:
-                aux.wait_event(ready)
+            # (VALU-bound) on dedicated streams.  The D read-back above synchronised `main`, so every workspace
+            # allocated since then is free of pending work and may be touched by a side stream at once; each view's
+            # binning is enqueued as soon as its workspace exists (the GPU idles until the first of these launches).
             binned = []
             for v, st in enumerate(states):
+                alloc_bin(v)
                 aux = auxs[v % len(auxs)]
                 L.check(lib.gdr_binning_forward(C.byref(s_arr[v]), N, C.byref(g_arr[v]), C.byref(st.bin), C.byref(st.img),
                                                 st.D, _ptr(radii[v]), C.c_void_p(aux.cuda_stream)), "gdr_binning_forward")
