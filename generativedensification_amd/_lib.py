@@ -129,6 +129,9 @@ _PROTOS = {
                                       C.POINTER(GdrImage), C.POINTER(GdrGradInputs), C.c_void_p, C.c_void_p]),
     "gdr_render_backward_mean2d": (C.c_int, [C.POINTER(GdrSettings), C.c_int32, C.POINTER(GdrGeom), C.POINTER(GdrBinning),
                                              C.POINTER(GdrImage), C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gdr_render_backward_mean2d_loss": (C.c_int, [C.POINTER(GdrSettings), C.c_int32, C.POINTER(GdrGeom), C.POINTER(GdrBinning),
+                                                  C.POINTER(GdrImage), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                  C.c_void_p]),
     "gdr_preprocess_backward_views": (C.c_int, [C.c_int32, C.POINTER(GdrSettings), C.POINTER(GdrInputs),
                                                 C.POINTER(GdrGeom), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                                 C.POINTER(GdrGradOutputs), C.c_void_p]),

@@ -292,6 +292,20 @@ int gdr_render_backward_loss(const gdr_settings* s, int32_t N, const gdr_geom* g
     return debug_sync(s, "render_bwd_loss", st);
 }
 
+int gdr_render_backward_mean2d_loss(const gdr_settings* s, int32_t N, const gdr_geom* geom, const gdr_binning* bin,
+                                    const gdr_image* img, const float* color, const float* target, const float* g,
+                                    float* dL_dmean2D, void* stream) {
+    if (!s || !geom || !bin || !img || !color || !target || !g || (N > 0 && !dL_dmean2D) || !s->bg) {
+        set_error("render_backward_mean2d_loss: NULL argument", hipSuccess);
+        return GDR_ERR_INVALID_ARG;
+    }
+    if (N <= 0) return GDR_OK;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = launch_render_bwd_mean2d_loss(s, geom, bin, img, color, target, g, dL_dmean2D, st);
+    if (e != hipSuccess) return hip_fail("render_bwd_mean2d_loss", e);
+    return debug_sync(s, "render_bwd_mean2d_loss", st);
+}
+
 int gdr_render_forward(const gdr_settings* s, const gdr_inputs* in, const gdr_geom* geom,
                        gdr_binning* bin, const gdr_image* img, uint64_t D, const gdr_outputs* out,
                        void* stream) {

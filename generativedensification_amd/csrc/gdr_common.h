@@ -97,6 +97,9 @@ hipError_t launch_render_fwd_loss(const gdr_settings* s, const gdr_geom* g, cons
 hipError_t launch_render_bwd_loss(const gdr_settings* s, const gdr_geom* g, const gdr_binning* bin,
                                   const gdr_image* img, const float* color, const float* target, float w_depth,
                                   float w_alpha, const float* go, float* grad_rec, hipStream_t st);
+hipError_t launch_render_bwd_mean2d_loss(const gdr_settings* s, const gdr_geom* g, const gdr_binning* bin,
+                                         const gdr_image* img, const float* color, const float* target, const float* go,
+                                         float* dL_dmean2D, hipStream_t st);
 hipError_t launch_render_bwd_mean2d(const gdr_settings* s, const gdr_geom* g, const gdr_binning* bin,
                                     const gdr_image* img, const float* dL_dcolor, float* dL_dmean2D,
                                     hipStream_t st);

@@ -548,4 +548,19 @@ hipError_t launch_render_bwd_mean2d(const gdr_settings* s, const gdr_geom* g, co
     return hipGetLastError();
 }
 
+// abs-grad-only K7 with the MSE loss folded into its prologue (network.py:865-878 differentiates an image
+// MSE w.r.t. the means2D carrier only)
+hipError_t launch_render_bwd_mean2d_loss(const gdr_settings* s, const gdr_geom* g, const gdr_binning* bin,
+                                         const gdr_image* img, const float* color, const float* target, const float* go,
+                                         float* dL_dmean2D, hipStream_t st) {
+    const int W = s->image_width, H = s->image_height;
+    const int gx = tile_grid_x(W), gy = tile_grid_y(H);
+    const int ntiles = gx * gy;
+    const FusedLoss fl{target, 0.f, 0.f, nullptr, go, color};
+    GDR_LAUNCH(GDR_K_RENDER_BWD, (render_bwd_kernel<true, true>), dim3(ntiles), dim3(GDR_BLOCK), st,
+               (const uint2*)img->ranges, bin->values[bin->sorted], img->tile_order, W, H, gx, ntiles, s->bg,
+               (const float4*)g->rec, img->final_T, img->n_contrib, nullptr, nullptr, nullptr, dL_dmean2D, fl);
+    return hipGetLastError();
+}
+
 }  // namespace gdr

@@ -565,25 +565,27 @@ def render_views_raw(means3D, means2D, sh, opacities, scales, rotations, setting
     return list(out[1:1 + V]), out[0], list(out[1 + V:1 + 2 * V]), list(out[1 + 2 * V:1 + 3 * V])
 
 
-def screenspace_absgrad_raw(means3D, sh, opacities, scales, rotations, settings_list, gt_images, flags=RAW_ALL):
+def screenspace_absgrad_raw(means3D, sh, opacities, scales, rotations, settings_list, gt_images, flags=RAW_ALL, topk=0):
     """SURVEY §8f-2.  What the densification step of the reference computes with
     `vjp(fn, screenspace_point)` (network.py:843-878): loss = mean over all views and pixels of
     (clamp(image, 0, 1) - gt)^2 and its gradient w.r.t. the shared (N,4) means2D carrier
-    (columns 0-1 signed, 2-3 sum of |per-pixel terms|) — nothing else.  Forward as usual; the backward is
-    the mean2D-only K7 variant accumulated over the views into ONE (N,4) buffer (no gradient records, no K8/K9).
-    gt_images: (V,3,H,W).  Returns (loss, grad (N,4))."""
+    (columns 0-1 signed, 2-3 sum of |per-pixel terms|) — nothing else.  The MSE is folded into K6's epilogue and into the
+    prologue of the mean2D-only K7 variant, which accumulates over the views into ONE (N,4) buffer: no dL/dimage
+    tensors, no gradient records, no K8/K9.  gt_images: (V,3,H,W).  Returns (loss, grad (N,4)), and with topk > 0 also
+    the indices of the topk largest ||grad[:, 2:4]||_2 (the selection of network.py:878-893, configs/base.yaml:30)."""
     lib = L.load()
     with torch.no_grad():
         dev = means3D.device
-        N = int(means3D.shape[0])
+        N, V = int(means3D.shape[0]), len(settings_list)
         dummy = torch.empty(0, 4, device=dev)
-        colors, radii, depths, alphas, states, keep, _ = _forward_views_impl(
-            means3D, dummy, sh, opacities, scales, rotations, tuple(settings_list), int(flags))
-        colors = torch.stack(colors)
         gt = _f32(gt_images, dev)
-        diff = colors.clamp(0, 1) - gt
-        loss = (diff * diff).mean()
-        dL = diff * ((colors >= 0) & (colors <= 1)) * (2.0 / diff.numel())  # d loss / d image through the clamp
+        targets = [gt[v] for v in range(V)]
+        losses = torch.zeros(V, dtype=torch.float32, device=dev)
+        colors, radii, depths, alphas, states, keep, _ = _forward_views_impl(
+            means3D, dummy, sh, opacities, scales, rotations, tuple(settings_list), int(flags),
+            loss_spec=(targets, 0.0, 0.0, losses))
+        loss = losses.mean()   # views share one image size: the mean of per-view means is the global mean
+        go = torch.full((1,), 1.0 / V, dtype=torch.float32, device=dev)
         grad = torch.zeros(N, 4, dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             keep2: list = []
@@ -592,9 +594,12 @@ def screenspace_absgrad_raw(means3D, sh, opacities, scales, rotations, settings_
                 s = _settings_struct(settings_list[v], dev, keep2)
                 g = st.geom
                 g.cov3D = states[0].geom.cov3D
-                L.check(lib.gdr_render_backward_mean2d(C.byref(s), N, C.byref(g), C.byref(st.bin), C.byref(st.img),
-                                                       dL[v].data_ptr(), _ptr(grad), stream),
-                        "gdr_render_backward_mean2d")
+                L.check(lib.gdr_render_backward_mean2d_loss(C.byref(s), N, C.byref(g), C.byref(st.bin), C.byref(st.img),
+                                                            colors[v].data_ptr(), targets[v].data_ptr(), go.data_ptr(),
+                                                            _ptr(grad), stream), "gdr_render_backward_mean2d_loss")
+        if topk:
+            idx = torch.topk(grad[:, 2:4].norm(dim=1), min(int(topk), N)).indices
+            return loss, grad, idx
     return loss, grad
 
 

@@ -111,16 +111,18 @@ class Renderer(nn.Module):
                                           [targets_chw[j] for j in range(len(sets))], w_depth, w_alpha)
         return losses
 
-    def screenspace_absgrad(self, cams, bg_colors, gt_images, centers, shs, opacity, scales, rotations, device):
+    def screenspace_absgrad(self, cams, bg_colors, gt_images, centers, shs, opacity, scales, rotations, device, topk=0):
         """Image loss and its (N,4) screen-space gradient over `cams` — the quantity the reference obtains with
         `vjp(fn, screenspace_point)` at network.py:843-878 (fn = MSE of the clamped renders against
-        `gt_images` (V,H,W,3)); only grad[:, 2:4] is consumed there.  Returns (loss, grad)."""
+        `gt_images` (V,H,W,3)); only grad[:, 2:4] is consumed there.  Returns (loss, grad); with topk > 0 also the
+        indices of the topk largest ||grad[:, 2:4]|| (network.py:878-893 selects 12 000, configs/base.yaml:30)."""
         sets = []
         for j, cam in enumerate(cams):
             if bg_colors is not None:
                 self.set_bg_color(bg_colors[j] if isinstance(bg_colors, (list, tuple)) else bg_colors)
             sets.append(self.set_rasterizer(cam, device=device).raster_settings)
-        return screenspace_absgrad_raw(centers, shs, opacity, scales, rotations, sets, gt_images.permute(0, 3, 1, 2))
+        return screenspace_absgrad_raw(centers, shs, opacity, scales, rotations, sets, gt_images.permute(0, 3, 1, 2),
+                                       topk=topk)
 
     def render_img(self, cam, rays, centers, shs, opacity, scales, rotations, device,
                    cov3D_precomp=None, prex="", screenspace_points=None):

@@ -258,6 +258,12 @@ int gdr_render_backward_mean2d(const gdr_settings* s, int32_t N, const gdr_geom*
                                const gdr_binning* bin, const gdr_image* img, const float* dL_dcolor,
                                float* dL_dmean2D, void* stream);
 
+/* the same with the image MSE folded into the prologue (see gdr_render_backward_loss): the per-pixel upstream gradient
+ * is *g * 2/(3 H W) * (clamp(color) - target) inside [0,1], 0 outside; no dL/dimage tensor */
+int gdr_render_backward_mean2d_loss(const gdr_settings* s, int32_t N, const gdr_geom* geom, const gdr_binning* bin,
+                                    const gdr_image* img, const float* color, const float* target, const float* g,
+                                    float* dL_dmean2D, void* stream);
+
 /* ---- fused image loss either side of the path ---------------------------------
  * loss += mean_{c,p}(clamp(color,0,1) - target)^2 + w_depth mean(depth) + w_alpha mean(alpha) for ONE view
  * (renderer.py:261 clamp, loss.py:37-38 MSE; depth/alpha terms: the measurement loss of SURVEY §8d).

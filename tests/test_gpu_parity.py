@@ -365,6 +365,11 @@ def test_screenspace_absgrad_entry_matches_vjp_through_the_reference_sequence():
     sel = torch.topk(grad[:, 2:4].norm(dim=-1), k).indices
     sel_ref = torch.topk(grad_ref[:, 2:4].norm(dim=-1), k).indices
     assert len(set(sel.tolist()) & set(sel_ref.tolist())) >= k - 5
+    # ... which the entry point also returns directly (topk=)
+    loss2, grad2, idx = Renderer(sh_degree=1).screenspace_absgrad(cams, bgs, gt, sc["centers"], sc["shs"], sc["opacity"],
+                                                                  sc["scales"], sc["rotations"], dev, topk=k)
+    assert idx.shape == (k,) and len(set(idx.tolist()) & set(sel_ref.tolist())) >= k - 5
+    assert U.rel_inf(grad2.cpu().numpy(), grad_ref.cpu().numpy()) < 1e-4
 
 
 def test_fused_view_loss_matches_torch_loss_value_and_gradients():
