@@ -124,13 +124,14 @@ def test_product_path_has_no_cpu_fallback():
 
 
 def test_product_packages_never_touch_the_oracle():
-    for pkg in ("generativedensification_amd", "diff_gaussian_rasterization"):
+    for pkg in ("generativedensification_amd", "diff_gaussian_rasterization", "diff_surfel_rasterization", "simple_knn"):
         for dp, _, files in os.walk(os.path.join(ROOT, pkg)):
             for f in files:
                 if f.endswith((".py", ".hip", ".h", ".cpp")) or f == "Makefile":
                     txt = open(os.path.join(dp, f)).read()
                     assert not re.search(r"^\s*(from|import)\s+oracle", txt, flags=re.M), (dp, f)
                     assert "gdr_oracle" not in txt.replace("oracle/gdr_oracle.c", "").replace("oracle_bin()", ""), (dp, f)
+                    assert "gsr_oracle" not in txt.replace("oracle/gsr_oracle.c", ""), (dp, f)
 
 
 def test_settings_record_has_the_reference_fields_in_order():
