@@ -1038,7 +1038,7 @@ hipError_t launch_preprocess_bwd_views(int V, const gdr_settings* s, const gdr_i
                geoms[0].cov3D, W, H, in->flags, go->accumulate, (float4*)go->dL_dmeans2D, go->dL_dopacities,   \
                go->dL_dmeans3D, go->dL_dshs, go->dL_dscales, (float4*)go->dL_drotations, a)
     const int deg = s[0].sh_degree, nb = (deg + 1) * (deg + 1);
-    const bool staged = in->M == nb && (3 * nb) % 4 == 0 && !getenv("GDR_NO_ROW_STAGE");
+    const bool staged = in->M == nb && (3 * nb) % 4 == 0;
     switch (deg) {
         case 0: GDR_K9V(0, false); break;
         case 1: if (staged) GDR_K9V(1, true); else GDR_K9V(1, false); break;
