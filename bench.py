@@ -119,6 +119,9 @@ def main():
     ap.add_argument("--unfused", action="store_true",
                     help="torch activations before the rasterizer, op for op as lightning/renderer.py:225-230")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL on ROCm)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise torch.distributed even at WORLD_SIZE=1 (exercises the RCCL barrier / all-gather / "
+                         "all-reduce calls of the N>1 path on a one-GPU box)")
     ap.add_argument("--single-device", action="store_true",
                     help="developer smoke test of the N>1 code path on a 1-GPU box: every rank uses cuda:0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -127,6 +130,12 @@ def main():
                     help="per-kernel HBM bytes per launch measured with rocprofv3 --pmc (scripts/gpu_pmc.sh); "
                          "{workload: {kernel: bytes}}; missing file/entry -> traffic null")
     args = ap.parse_args()
+
+    # stdout carries exactly ONE line (the JSON result).  Libraries that write to file descriptor 1 from C (RCCL
+    # prints a version banner on rank 0 when the first communicator is created) are sent to stderr instead.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -137,8 +146,14 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if args.force_dist:
+        os.environ["GDR_FORCE_COLLECTIVES"] = "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if args.dist_backend == "nccl":
             try:
                 dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
@@ -246,7 +261,7 @@ def main():
         return all_losses
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -258,7 +273,7 @@ def main():
         last_losses = step()
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -361,6 +376,7 @@ def main():
                        "views_per_gpu": vpg, "image": [h, w], "sh_degree": deg,
                        "num_rendered_per_view": int(d_mean), "parallelism": f"view-sharded x{world}",
                        "grad_allreduce": bool(args.grad_allreduce),
+                       "peak_mem_gb": round(torch.cuda.max_memory_allocated(dev) / 2**30, 2),
                        "entry": ("renderer_2dgs.render_views (all views of the shard, one node)" if surfel and not (args.per_view or args.torch_loss or args.unfused)
                                  else "renderer_2dgs.render_img per view" if surfel else "render_img per view" if args.per_view
                                  else "render_views (all views of the shard, one node)")
@@ -374,8 +390,8 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu_baseline, "kernels": kernels,
             "loss_mean": float(last_losses.mean()),
         }
-        print(json.dumps(out))
-    if world > 1:
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
+    if use_dist:
         dist.destroy_process_group()
 
 

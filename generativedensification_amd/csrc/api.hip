@@ -115,6 +115,7 @@ static int check_common(const gdr_settings* s, const gdr_inputs* in) {
         set_error("negative N or empty image", hipSuccess);
         return GDR_ERR_INVALID_ARG;
     }
+    if (in->N > GDR_MAX_GAUSSIANS) { set_error("N exceeds GDR_MAX_GAUSSIANS", hipSuccess); return GDR_ERR_UNSUPPORTED; }
     if (!s->bg || !s->viewmatrix || !s->projmatrix) {
         set_error("bg/viewmatrix/projmatrix must be device pointers", hipSuccess);
         return GDR_ERR_INVALID_ARG;
@@ -546,6 +547,7 @@ static size_t carve_surfel_image(void* base, int H, int W, gdr_image* im) {
 static int check_surfel(const gdr_settings* s, const gsr_inputs* in) {
     if (!s || !in) { set_error("NULL settings/inputs", hipSuccess); return GDR_ERR_INVALID_ARG; }
     if (in->N < 0 || s->image_height <= 0 || s->image_width <= 0) { set_error("negative N or empty image", hipSuccess); return GDR_ERR_INVALID_ARG; }
+    if (in->N > GDR_MAX_GAUSSIANS) { set_error("N exceeds GDR_MAX_GAUSSIANS", hipSuccess); return GDR_ERR_UNSUPPORTED; }
     if (!s->bg || !s->viewmatrix || !s->projmatrix) { set_error("bg/viewmatrix/projmatrix must be device pointers", hipSuccess); return GDR_ERR_INVALID_ARG; }
     if (in->N > 0) {
         if (!in->means3D || !in->opacities) { set_error("means3D/opacities NULL", hipSuccess); return GDR_ERR_INVALID_ARG; }

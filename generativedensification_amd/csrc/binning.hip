@@ -254,10 +254,13 @@ struct TileSortBufs {
     uint32_t *kA, *vA, *kB, *vB;
 };
 
-// one stable 8-bit pass over [0,L) from (kA,vA) to (kB,vB); cnt: [NW][256] LDS counters (NW waves)
+// one stable 8-bit pass over [0,L) from (kA,vA) to (kB,vB); cnt: [NW][256] LDS counters (NW waves).
+// bstart (optional, 257 entries): receives the exclusive scan of the digit totals (= where each digit's run
+// starts in the output) and L at [256].
 template <int NW>
 __device__ __forceinline__ void tile_sort_pass(const TileSortBufs& b, uint32_t L, uint32_t kmin, int shift,
-                                               uint32_t (*cnt)[GDR_RADIX], uint32_t* scan_lds) {
+                                               uint32_t (*cnt)[GDR_RADIX], uint32_t* scan_lds,
+                                               uint32_t* bstart = nullptr) {
     const uint32_t w = threadIdx.x >> 6, lane = lane_id();
     const uint32_t Lw = ((L + NW * GDR_WAVE - 1) / (NW * GDR_WAVE)) * GDR_WAVE;
     const uint32_t c0 = min(L, w * Lw), c1 = min(L, c0 + Lw);
@@ -278,6 +281,10 @@ __device__ __forceinline__ void tile_sort_pass(const TileSortBufs& b, uint32_t L
         if (owner) {
             uint32_t base = incl - tot;
             for (uint32_t k = 0; k < w; ++k) base += scan_lds[k];
+            if (bstart) {
+                bstart[d] = base;
+                if (d == 0) bstart[GDR_RADIX] = L;
+            }
             for (int k = 0; k < NW; ++k) { const uint32_t c = cnt[k][d]; cnt[k][d] = base; base += c; }
         }
     }
@@ -306,9 +313,56 @@ __device__ __forceinline__ void tile_sort_pass(const TileSortBufs& b, uint32_t L
     __syncthreads();  // (global-memory variant: also the workgroup-scope release/acquire of the stores)
 }
 
+// ties on identical depth bits: ascending Gaussian id — the order the reference's stable sort of
+// (Gaussian-ordered) emission leaves them in; our emission order is arbitrary (block_offs).
+// Runs of up to GDR_TIE_SERIAL equal keys are insertion-sorted by the thread that finds their head; longer runs
+// (thousands of Gaussians at one depth: a grid plane seen head-on) are queued and then sorted by the whole
+// workgroup with four stable 8-bit passes on the ids, vA -> vB -> vA -> vB -> vA.  runs: 2*GDR_TIE_RUNS+1 LDS words.
+#define GDR_TIE_SERIAL 96
+#define GDR_TIE_RUNS 96
+template <int NW>
+__device__ __forceinline__ void tile_sort_ties(const uint32_t* kA, uint32_t* vA, uint32_t* vB, uint32_t L,
+                                               uint32_t (*cnt)[GDR_RADIX], uint32_t* scan_lds, uint32_t* runs) {
+    constexpr uint32_t NT = NW * GDR_WAVE;
+    if (threadIdx.x == 0) runs[2 * GDR_TIE_RUNS] = 0;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i + 1 < L; i += NT) {
+        if (kA[i] == kA[i + 1] && (i == 0 || kA[i - 1] != kA[i])) {
+            uint32_t j = i + 1;
+            while (j < L && kA[j] == kA[i]) ++j;
+            if (j - i > GDR_TIE_SERIAL) {
+                const uint32_t slot = atomicAdd(&runs[2 * GDR_TIE_RUNS], 1u);
+                if (slot < GDR_TIE_RUNS) { runs[2 * slot] = i; runs[2 * slot + 1] = j - i; continue; }
+            }
+            for (uint32_t a = i + 1; a < j; ++a) {  // insertion sort of the run [i, j) by id
+                const uint32_t x = vA[a];
+                uint32_t c = a;
+                while (c > i && vA[c - 1] > x) { vA[c] = vA[c - 1]; --c; }
+                vA[c] = x;
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t nruns = min(runs[2 * GDR_TIE_RUNS], (uint32_t)GDR_TIE_RUNS);
+    for (uint32_t r = 0; r < nruns; ++r) {  // uniform over the workgroup
+        const uint32_t i0 = runs[2 * r], Lr = runs[2 * r + 1];
+        TileSortBufs t;
+        t.kA = t.vA = vA + i0;
+        t.kB = t.vB = vB + i0;
+        for (int shift = 0; shift < 32; shift += GDR_RADIX_BITS) {
+            tile_sort_pass<NW>(t, Lr, 0u, shift, cnt, scan_lds);
+            uint32_t* x = t.kA; t.kA = t.vA = t.kB; t.kB = t.vB = x;
+        }
+    }
+}
+
 // keys_part: tile-partitioned u64 keys (tile << 32 | depth); vals_part: ids; outputs sorted.
-// scratch32: 2*D uint32 of global scratch (depth keys ping-pong for tiles that do not fit in LDS)
-// handles tiles with LMIN < L <= CAP in LDS (TOP: also L > CAP, on the global buffers); NW waves per workgroup
+// scratch32: 2*D uint32 of global scratch (depth keys of the tiles that do not fit in LDS)
+// handles tiles with LMIN < L <= CAP in LDS; NW waves per workgroup.  TOP also takes the lists longer than CAP:
+// one stable pass on the TOP 8 bits of (depth - min depth) through global memory splits the list into 256
+// ordered buckets, then runs of whole buckets that fit are sorted in LDS like short lists (a single bucket
+// larger than CAP — thousands of near-identical depths in one tile — is finished by LSD passes on the global
+// buffers).  3 reads + 2 writes of the list instead of one global round trip per 8 key bits.
 template <int CAP, int LMIN, int NW, bool TOP>
 __global__ __launch_bounds__(NW * GDR_WAVE) void tile_sort_kernel(const uint2* __restrict__ ranges,
                                                                const uint64_t* __restrict__ keys_part,
@@ -322,69 +376,143 @@ __global__ __launch_bounds__(NW * GDR_WAVE) void tile_sort_kernel(const uint2* _
     __shared__ uint32_t cnt[NW][GDR_RADIX];
     __shared__ uint32_t misc[8];
     __shared__ uint32_t mm[2 * NW];
+    __shared__ uint32_t bstart[TOP ? GDR_RADIX + 1 : 1];
+    __shared__ uint32_t bstart2[TOP ? GDR_RADIX + 1 : 1];
+    __shared__ uint32_t tie_runs[2 * GDR_TIE_RUNS + 1];
+    const uint32_t w = threadIdx.x >> 6, lane = lane_id();
+
+    // workgroup reduction of (min, max) over the values each thread collected
+    auto min_max = [&](uint32_t& kmin, uint32_t& kmax) __attribute__((always_inline)) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, off, 64));
+            kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, off, 64));
+        }
+        if (lane == 0) { mm[w] = kmin; mm[NW + w] = kmax; }
+        __syncthreads();
+        for (int k = 0; k < NW; ++k) { kmin = min(kmin, mm[k]); kmax = max(kmax, mm[NW + k]); }
+    };
+    // Lc <= CAP pairs (key_at(i), vsrc[i]) -> sorted at keys_out / vals_out [o, o + Lc)
+    auto sort_in_lds = [&](auto key_at, const uint32_t* vsrc, uint32_t tile, uint32_t o, uint32_t Lc)
+                           __attribute__((always_inline)) {
+        __syncthreads();  // LDS reuse
+        TileSortBufs b;
+        b.kA = lds_elems; b.vA = lds_elems + CAP;
+        b.kB = lds_elems + 2 * CAP; b.vB = lds_elems + 3 * CAP;
+        uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
+        for (uint32_t i = threadIdx.x; i < Lc; i += NT) {
+            const uint32_t k = key_at(i);
+            b.kA[i] = k;
+            b.vA[i] = vsrc[i];
+            kmin = min(kmin, k);
+            kmax = max(kmax, k);
+        }
+        min_max(kmin, kmax);
+        const uint32_t span = kmax - kmin;
+        const int nbits = span ? 32 - __builtin_clz(span) : 0;
+        for (int shift = 0; shift < nbits; shift += GDR_RADIX_BITS) {
+            tile_sort_pass<NW>(b, Lc, kmin, shift, cnt, misc);
+            uint32_t* t = b.kA; b.kA = b.kB; b.kB = t;
+            t = b.vA; b.vA = b.vB; b.vB = t;
+        }
+        tile_sort_ties<NW>(b.kA, b.vA, b.vB, Lc, cnt, misc, tie_runs);
+        for (uint32_t i = threadIdx.x; i < Lc; i += NT) {
+            vals_out[o + i] = b.vA[i];
+            keys_out[o + i] = ((uint64_t)tile << 32) | (uint64_t)b.kA[i];
+        }
+    };
+
     // LMIN > 0 (long-list class): a small grid walks the tiles longest-first (tile_order is sorted by
     // list length / 16, descending) and stops at the first tile that is clearly in the other class
     for (uint32_t slot = blockIdx.x; slot < (uint32_t)ntiles; slot += gridDim.x) {
-    const uint32_t tile = LMIN > 0 ? tile_order[slot] : slot;
-    const uint2 rg = ranges[tile];
-    const uint32_t L = rg.y - rg.x;
-    if (LMIN > 0 && (L >> 4) < ((uint32_t)LMIN >> 4)) return;             // every later tile is shorter
-    if (L <= (uint32_t)LMIN || (!TOP && L > (uint32_t)CAP)) continue;  // other size class
-    __syncthreads();  // LDS reuse across loop iterations
-    const uint32_t w = threadIdx.x >> 6, lane = lane_id();
-    const bool in_lds = L <= (uint32_t)CAP;
-    TileSortBufs b;
-    if (in_lds) {
-        b.kA = lds_elems; b.vA = lds_elems + CAP;
-        b.kB = lds_elems + 2 * CAP; b.vB = lds_elems + 3 * CAP;
-    } else {  // global ping-pong: this tile's own slices of the scratch / value buffers
-        b.kA = scratch32 + rg.x; b.kB = scratch32 + D + rg.x;
-        b.vA = vals_part + rg.x; b.vB = vals_out + rg.x;
-    }
-    uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
-    for (uint32_t i = threadIdx.x; i < L; i += NT) {
-        const uint32_t k = (uint32_t)keys_part[rg.x + i];
-        b.kA[i] = k;
-        if (in_lds) b.vA[i] = vals_part[rg.x + i];
-        kmin = min(kmin, k);
-        kmax = max(kmax, k);
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, off, 64));
-        kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, off, 64));
-    }
-    if (lane == 0) { mm[w] = kmin; mm[NW + w] = kmax; }
-    __syncthreads();
-    for (int k = 0; k < NW; ++k) { kmin = min(kmin, mm[k]); kmax = max(kmax, mm[NW + k]); }
-    const uint32_t span = kmax - kmin;
-    const int nbits = span ? 32 - __builtin_clz(span) : 0;
-    for (int shift = 0; shift < nbits; shift += GDR_RADIX_BITS) {
-        tile_sort_pass<NW>(b, L, kmin, shift, cnt, misc);
-        uint32_t* t = b.kA; b.kA = b.kB; b.kB = t;
-        t = b.vA; b.vA = b.vB; b.vB = t;
-    }
-    // ties on identical depth bits: ascending Gaussian id — the order the reference's stable sort of
-    // (Gaussian-ordered) emission leaves them in; our emission order is arbitrary (block_offs)
-    for (uint32_t i = threadIdx.x; i + 1 < L; i += NT) {
-        if (b.kA[i] == b.kA[i + 1] && (i == 0 || b.kA[i - 1] != b.kA[i])) {
-            uint32_t j = i + 1;
-            while (j < L && b.kA[j] == b.kA[i]) ++j;
-            for (uint32_t a = i + 1; a < j; ++a) {  // insertion sort of the run [i, j) by id
-                const uint32_t x = b.vA[a];
-                uint32_t c = a;
-                while (c > i && b.vA[c - 1] > x) { b.vA[c] = b.vA[c - 1]; --c; }
-                b.vA[c] = x;
+        const uint32_t tile = LMIN > 0 ? tile_order[slot] : slot;
+        const uint2 rg = ranges[tile];
+        const uint32_t L = rg.y - rg.x;
+        if (LMIN > 0 && (L >> 4) < ((uint32_t)LMIN >> 4)) return;          // every later tile is shorter
+        if (L <= (uint32_t)LMIN || (!TOP && L > (uint32_t)CAP)) continue;  // other size class
+        if (L <= (uint32_t)CAP) {
+            const uint64_t* kp = keys_part + rg.x;
+            sort_in_lds([kp](uint32_t i) { return (uint32_t)kp[i]; }, vals_part + rg.x, tile, rg.x, L);
+            continue;
+        }
+        if constexpr (TOP) {
+            // this tile's own slices of the scratch / value buffers
+            uint32_t* const kA = scratch32 + rg.x;
+            uint32_t* const kB = scratch32 + D + rg.x;
+            uint32_t* const vA = vals_part + rg.x;
+            uint32_t* const vB = vals_out + rg.x;
+            __syncthreads();  // mm / bstart reuse
+            uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
+            for (uint32_t i = threadIdx.x; i < L; i += NT) {
+                const uint32_t k = (uint32_t)keys_part[rg.x + i];
+                kA[i] = k;
+                kmin = min(kmin, k);
+                kmax = max(kmax, k);
+            }
+            min_max(kmin, kmax);
+            const uint32_t span = kmax - kmin;
+            const int nbits = span ? 32 - __builtin_clz(span) : 0;
+            // last resort for a bucket that is still longer than CAP: LSD passes on its low `low_bits` bits on the
+            // global buffers (g.kA/g.vA hold it, g.kB/g.vB are its scratch), ties, store at [o, o + Lc)
+            auto finish_global = [&](TileSortBufs g, uint32_t Lc, int low_bits, uint32_t o) __attribute__((always_inline)) {
+                __syncthreads();
+                for (int shift = 0; shift < low_bits; shift += GDR_RADIX_BITS) {
+                    tile_sort_pass<NW>(g, Lc, kmin, shift, cnt, misc);
+                    uint32_t* t = g.kA; g.kA = g.kB; g.kB = t;
+                    t = g.vA; g.vA = g.vB; g.vB = t;
+                }
+                tile_sort_ties<NW>(g.kA, g.vA, g.vB, Lc, cnt, misc, tie_runs);
+                const bool in_place = g.vA == vals_out + o;
+                for (uint32_t i = threadIdx.x; i < Lc; i += NT) {
+                    if (!in_place) vals_out[o + i] = g.vA[i];
+                    keys_out[o + i] = ((uint64_t)tile << 32) | (uint64_t)g.kA[i];
+                }
+            };
+            const int sh1 = nbits > GDR_RADIX_BITS ? nbits - GDR_RADIX_BITS : 0;
+            {
+                TileSortBufs g;
+                g.kA = kA; g.vA = vA; g.kB = kB; g.vB = vB;
+                tile_sort_pass<NW>(g, L, kmin, sh1, cnt, misc, bstart);  // (kB, vB): 256 ordered buckets
+            }
+            uint32_t d0 = 0;
+            while (d0 < GDR_RADIX) {  // uniform over the workgroup: bstart is read-only from here on
+                const uint32_t s0 = bstart[d0];
+                uint32_t d1 = d0 + 1;
+                while (d1 < GDR_RADIX && bstart[d1 + 1] - s0 <= (uint32_t)CAP) ++d1;
+                const uint32_t Lc = bstart[d1] - s0;
+                d0 = d1;
+                if (Lc == 0) continue;
+                if (Lc <= (uint32_t)CAP) {
+                    const uint32_t* kc = kB + s0;
+                    sort_in_lds([kc](uint32_t i) { return kc[i]; }, vB + s0, tile, rg.x + s0, Lc);
+                    continue;
+                }
+                TileSortBufs g;  // one bucket longer than CAP
+                g.kA = kB + s0; g.vA = vB + s0; g.kB = kA + s0; g.vB = vA + s0;
+                if (sh1 == 0) { finish_global(g, Lc, 0, rg.x + s0); continue; }  // one depth value: ties only
+                // second level: the next 8 bits of this bucket, (kB, vB) -> (kA, vA)
+                const int sh2 = sh1 > GDR_RADIX_BITS ? sh1 - GDR_RADIX_BITS : 0;
+                __syncthreads();
+                tile_sort_pass<NW>(g, Lc, kmin, sh2, cnt, misc, bstart2);
+                uint32_t e0 = 0;
+                while (e0 < GDR_RADIX) {
+                    const uint32_t s1 = bstart2[e0];
+                    uint32_t e1 = e0 + 1;
+                    while (e1 < GDR_RADIX && bstart2[e1 + 1] - s1 <= (uint32_t)CAP) ++e1;
+                    const uint32_t Lcc = bstart2[e1] - s1;
+                    e0 = e1;
+                    if (Lcc == 0) continue;
+                    if (Lcc <= (uint32_t)CAP) {
+                        const uint32_t* kc = kA + s0 + s1;
+                        sort_in_lds([kc](uint32_t i) { return kc[i]; }, vA + s0 + s1, tile, rg.x + s0 + s1, Lcc);
+                        continue;
+                    }
+                    TileSortBufs h;
+                    h.kA = kA + s0 + s1; h.vA = vA + s0 + s1; h.kB = kB + s0 + s1; h.vB = vB + s0 + s1;
+                    finish_global(h, Lcc, sh2, rg.x + s0 + s1);
+                }
             }
         }
-    }
-    __syncthreads();
-    for (uint32_t i = threadIdx.x; i < L; i += NT) {
-        const uint32_t v = b.vA[i];
-        const uint32_t k = b.kA[i];
-        if (in_lds || b.vA != vals_out + rg.x) vals_out[rg.x + i] = v;
-        keys_out[rg.x + i] = ((uint64_t)tile << 32) | (uint64_t)k;
-    }
     }  // slot loop
 }
 
@@ -459,9 +587,11 @@ hipError_t launch_sort_tile_bits(gdr_binning* bin, uint64_t D, int nbits, hipStr
 hipError_t launch_tile_sort(gdr_binning* bin, const gdr_image* img, int tiles, uint64_t D, hipStream_t st) {
     if (D == 0) return hipSuccess;
     const int in = bin->sorted, out = in ^ 1;
-    // long lists: 16 waves per workgroup (1 per CU) so that the few heavy tiles finish quickly
+    // long lists: 16 waves per workgroup (1 per CU) so that the few heavy tiles finish quickly; a two-class scheme
+    // (everything beyond the short class bucketed and sorted in short-class chunks, 4 per CU) measured slower at
+    // 2 M - 8 M Gaussians and equal at 32 M
     GDR_LAUNCH(GDR_K_TILE_SORT_LONG, (tile_sort_kernel<GDR_TSORT_LARGE, GDR_TSORT_MEDIUM, 16, true>),
-               dim3(tiles < 128 ? tiles : 128), dim3(16 * GDR_WAVE), st, (const uint2*)img->ranges, bin->keys[in],
+               dim3(tiles < 256 ? tiles : 256), dim3(16 * GDR_WAVE), st, (const uint2*)img->ranges, bin->keys[in],
                bin->values[in], bin->keys[out], bin->values[out], bin->scratch32, D, img->tile_order, tiles);
     GDR_LAUNCH(GDR_K_TILE_SORT_LONG, (tile_sort_kernel<GDR_TSORT_MEDIUM, GDR_TSORT_SMALL, 8, false>),
                dim3(tiles < 512 ? tiles : 512), dim3(8 * GDR_WAVE), st, (const uint2*)img->ranges, bin->keys[in],

@@ -12,6 +12,8 @@ from __future__ import annotations
 
 from typing import Callable, Sequence
 
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -46,10 +48,18 @@ def render_views(renderer, cams: Sequence, bg_colors, gaussians: dict, device, p
     return outs
 
 
+def _no_peers() -> bool:
+    """True when there is nothing to exchange.  GDR_FORCE_COLLECTIVES=1 keeps the collectives in a
+    one-rank group (used to exercise the RCCL calls of the N>1 path on a one-GPU box)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return True
+    return dist.get_world_size() == 1 and os.environ.get("GDR_FORCE_COLLECTIVES", "0") != "1"
+
+
 def gather_view_losses(local_losses: torch.Tensor, n_views: int | None = None) -> torch.Tensor:
     """All-gather of per-view scalar losses in global view order.  Uneven shards are padded
     to the largest shard with NaN and stripped again."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if _no_peers():
         return local_losses
     world = dist.get_world_size()
     n_local = torch.tensor([local_losses.numel()], device=local_losses.device, dtype=torch.int64)
@@ -71,7 +81,7 @@ def allreduce_gaussian_grads(params: Sequence[torch.Tensor]) -> None:
     """Sum the per-Gaussian attribute gradients over ranks: one packed buffer
     (236 B/Gaussian at SH degree 3) moved as reduce-scatter + all-gather so that all
     7 xGMI links of a GPU carry 1/G of it each, instead of a per-tensor ring all-reduce."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if _no_peers():
         return
     world = dist.get_world_size()
     grads = [p.grad for p in params if p.grad is not None]

@@ -47,6 +47,12 @@ extern "C" {
 #define GDR_ERR_UNSUPPORTED (-3)  /* sh_degree > 3, image too large for the key layout */
 #define GDR_ERR_WORKSPACE (-4)    /* caller workspace smaller than required            */
 
+/* Size limits of this build (checked at every entry point, GDR_ERR_UNSUPPORTED beyond them):
+ * per-Gaussian element offsets are computed in 32-bit registers up to 9*N (SH rows use 64-bit
+ * offsets), and num_rendered is a 32-bit counter as in the reference's int num_rendered. */
+#define GDR_MAX_GAUSSIANS (1 << 27) /* 134 M Gaussians: 32 GB of degree-3 inputs               */
+#define GDR_MAX_RENDERED 0xFFFFFFFFull /* D = sum of tiles_touched of one view                  */
+
 #define GDR_TILE 16 /* tile edge in pixels (BLOCK_X = BLOCK_Y = 16) */
 
 /* The 12 fields of GaussianRasterizationSettings (renderer.py:111-124), flattened.

@@ -103,6 +103,14 @@ def test_argument_errors_are_reported_not_thrown():
     s.image_height, s.image_width = 64, 64
     assert lib.gdr_preprocess_forward(C.byref(s), C.byref(i), C.byref(g), None, None, None) == -1  # bg/view/proj NULL
     assert lib.gdr_mark_visible(-1, None, None, None, None, None) == -1
+    # size limit of the build: N > GDR_MAX_GAUSSIANS is refused before any device work (GDR_ERR_UNSUPPORTED)
+    i.N = (1 << 27) + 1
+    s.bg = s.viewmatrix = s.projmatrix = 0x1000
+    assert lib.gdr_preprocess_forward(C.byref(s), C.byref(i), C.byref(g), None, None, None) == -3
+    assert b"GDR_MAX_GAUSSIANS" in lib.gdr_last_error()
+    j = L.GsrInputs()
+    j.N = (1 << 27) + 1
+    assert lib.gsr_preprocess_forward(C.byref(s), C.byref(j), C.byref(g), None, None, None) == -3
 
 
 def test_product_path_has_no_cpu_fallback():

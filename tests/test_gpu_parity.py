@@ -493,6 +493,30 @@ def test_tiny_and_odd_image_sizes_both_paths(oracle_built, H, W):
         assert e_hip <= 2.0 * e_o32 + 2e-4, (k, e_hip, e_o32)
 
 
+@pytest.mark.parametrize("n,band", [(30_000, 0.7), (70_000, 0.0), (50_000, 1.0), (90_000, 1.0)])
+def test_long_tile_lists_bucket_and_band_cases(oracle_built, n, band):
+    """Tile lists of 30k-70k entries (far beyond the 8192-entry LDS capacity of the per-tile depth sort).  `band` = share
+    of the Gaussians squeezed into a depth band ~1e-5 wide: 0.7 puts > 8192 entries into ONE of the 256 top-digit buckets
+    (finished by the global LSD passes) next to ordinary buckets (sorted in LDS chunks); 1.0 is a list whose whole depth
+    span is a few hundred float steps; 0.0 is the plain spread-out case.  Sorted list and ranges bit-exact."""
+    case = U.make_case(n, 48, 48, 41, deg=0, sigma0=(0.01,))
+    m = (case["means3D"] * 0.02).contiguous()
+    nb = int(band * n)
+    if nb:
+        a = case["view"][:3, 2] / case["view"][:3, 2].norm()          # view axis (depth = [p,1] @ view[:,2])
+        m[:nb] = m[:nb] - (1.0 - 1e-4) * (m[:nb] @ a)[:, None] * a    # squeeze the band along it
+        m[5:nb:11] = m[5]                                             # exact ties inside the band
+    case["means3D"] = m
+    case["opacities"] = (case["opacities"] * 0.01).contiguous()
+    hip, _ = U.run_hip(case, U.rand_grads(case))
+    ora, _ = U.run_oracle(case, "f32")
+    lens = ora["ranges"][:, 1].astype(np.int64) - ora["ranges"][:, 0].astype(np.int64)
+    assert lens.max() > 3 * 8192
+    np.testing.assert_array_equal(hip["ranges"], ora["ranges"])
+    np.testing.assert_array_equal(hip["point_list"], ora["point_list"])
+    assert U.outlier_fraction(hip["color"], ora["color"], 1e-3, 1e-4) < 1e-3
+
+
 def test_one_tile_with_a_very_long_list_takes_the_global_sort_path(oracle_built):
     """20k Gaussians stacked on one spot: a single tile list far beyond the 8192-entry LDS classes of the per-tile
     depth sort (tile_sort_long's global ping-pong), equal depths included; sorted list bit-exact, image within tolerance."""
