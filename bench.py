@@ -119,6 +119,9 @@ def main():
     ap.add_argument("--unfused", action="store_true",
                     help="torch activations before the rasterizer, op for op as lightning/renderer.py:225-230")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL on ROCm)")
+    ap.add_argument("--layout", default="cube", choices=["cube", "shell"],
+                    help="scene layout: cube = the BASELINE workloads (uniform in the reference's scene cube); shell = "
+                         "object-like stand-in with skewed tile lists (not a BASELINE number)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed even at WORLD_SIZE=1 (exercises the RCCL barrier / all-gather / "
                          "all-reduce calls of the N>1 path on a one-GPU box)")
@@ -179,11 +182,12 @@ def main():
     n, h, w, deg, vpg = wl["n"], wl["h"], wl["w"], wl["deg"], wl["views_per_gpu"]
     total_views = vpg * world
     if args.workload == "c3" and not args.n:  # two populations of different size (coarse grid + densified points)
-        a = make_scene(262_144, wl["seed"], sh_degree=deg, sigma0=(0.0052,), device=dev)
-        b = make_scene(81_600, wl["seed"] + 1, sh_degree=deg, sigma0=(0.00065,), device=dev)
+        a = make_scene(262_144, wl["seed"], sh_degree=deg, sigma0=(0.0052,), device=dev, layout=args.layout)
+        b = make_scene(81_600, wl["seed"] + 1, sh_degree=deg, sigma0=(0.00065,), device=dev, layout=args.layout)
         scene = {k: torch.cat([a[k], b[k]]).contiguous() for k in a}
     else:
-        scene = make_scene(n, wl["seed"], sh_degree=deg, sigma0=wl["sigma0"] or (0.0052,), device=dev)
+        scene = make_scene(n, wl["seed"], sh_degree=deg, sigma0=wl["sigma0"] or (0.0052,), device=dev,
+                           layout=args.layout)
     surfel = bool(wl.get("surfel"))
     if surfel:
         scene["scales"] = scene["scales"][:, :2].contiguous()
@@ -372,7 +376,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic (seeded random Gaussians with the decoder's statistics, random targets)",
-            "config": {"workload": f"{args.workload}: {wl['desc']}", "n_gaussians": n,
+            "config": {"workload": f"{args.workload}: {wl['desc']}", "n_gaussians": n, "layout": args.layout,
                        "views_per_gpu": vpg, "image": [h, w], "sh_degree": deg,
                        "num_rendered_per_view": int(d_mean), "parallelism": f"view-sharded x{world}",
                        "grad_allreduce": bool(args.grad_allreduce),

@@ -126,9 +126,34 @@ _FORCE_GLOBAL_SORT = False
 import os as _os
 
 VIEW_STREAMS = max(1, int(_os.environ.get("GDR_VIEW_STREAMS", "1")))
-# GDR_BIN_STREAM=n: binning of the views round-robin on n dedicated side streams, compositing on the caller's stream (see
-# _forward_views_impl); measured in BASELINE.md §4.
-BIN_STREAM = max(0, int(_os.environ.get("GDR_BIN_STREAM", "4")))   # number of binning side streams (0 = none; measured 1/2/4)
+# GDR_BIN_STREAM=n: number of side streams that carry the views of a multi-view node (binning, and with GDR_RENDER_SIDE
+# also K6 / K7), round-robin; 0 = everything on the caller's stream; unset = side_count() below.
+# GDR_RENDER_SIDE=1 (default): K6 of a view right behind its binning on the view's side stream, K7 of the views on the
+# side streams too (see _SideViews); 0 = K6 / K7 on the caller's stream, only the binning on the side streams.
+# Measured on MI355X (views/s; cube = uniform scene of the BASELINE workloads, shell = object in front of an empty
+# background, 13 % of the tiles busy):
+#   streams, K6/K7 placement     C4 cube  C4 shell  C2 cube  C3 cube  C3 shell  C5 cube  C5 shell
+#   4, caller's stream (before)    1076      349      2520     2043      632      1021      514
+#   4, side streams                1081      489      2573     2259     1021       992      651
+#   3, side streams                1107      516      2635     2599     1332      1000      684
+#   2, side streams                1120      532      2777     2528     1079      1020      731
+#   1, side stream                 1040      329      2462     1828      586       952      481
+# Two concurrent views fill the CUs that one view's skewed tile lists and kernel tails leave idle; four evict each
+# other's records from L2 (one view's records + gradient records are 2 x 128 MB at 2 M Gaussians).
+RENDER_SIDE = int(_os.environ.get("GDR_RENDER_SIDE", "1"))
+_BIN_STREAM_ENV = _os.environ.get("GDR_BIN_STREAM")
+BIN_STREAM = None if _BIN_STREAM_ENV is None else max(0, int(_BIN_STREAM_ENV))
+
+
+def side_count(H, W):
+    """Side streams for the views of one node: 2 at >= 2000 tiles per view (800x800), 3 for smaller images whose
+    single view cannot fill 256 CUs (512x512 = 1024 tiles)."""
+    if BIN_STREAM is not None:
+        return BIN_STREAM
+    tiles = ((W + 15) // 16) * ((H + 15) // 16)
+    return 2 if tiles >= 2000 else 3
+
+
 _side_streams: dict = {}
 
 
@@ -142,6 +167,36 @@ def _view_streams(dev, n):
 
 def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class _SideViews:
+    """Per-view render launches (K6 / K7 of the views of one node) round-robin on the side streams, joined back
+    into the caller's stream.  The views are independent; one view's kernel leaves CUs idle whenever its tile
+    lists are skewed (an object in front of an empty background: a few hundred busy tiles for 256 CUs) and at
+    its tail, and another view's workgroups fill them.  Off (everything on the caller's stream) when
+    GDR_RENDER_SIDE=0 or for a single view."""
+
+    def __init__(self, dev, n, H, W):
+        self.main = torch.cuda.current_stream()
+        ns = side_count(H, W)
+        self.side = _view_streams(dev, min(ns, n)) if RENDER_SIDE and ns > 0 and n > 1 else None
+        if self.side:
+            ready = torch.cuda.Event()
+            ready.record(self.main)
+            for sd in self.side:
+                sd.wait_event(ready)
+
+    def stream(self, k):
+        if self.side:
+            return C.c_void_p(self.side[k % len(self.side)].cuda_stream)
+        return C.c_void_p(self.main.cuda_stream)
+
+    def join(self):
+        if self.side:
+            for sd in self.side:
+                done = torch.cuda.Event()
+                done.record(sd)
+                self.main.wait_event(done)
 
 
 def forward_raw(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
@@ -323,9 +378,10 @@ def _forward_views_impl(means3D, means2D, sh, opacities, scales, rotations, sett
             L.check(lib.gdr_preprocess_forward_views(n, sub_s, C.byref(inp), sub_g, r_arr, stream),
                     "gdr_preprocess_forward_views")
         main = torch.cuda.current_stream()
-        two_stage = bool(BIN_STREAM) and V > 1
+        n_side = side_count(H, W)
+        two_stage = n_side > 0 and V > 1
         if two_stage:  # side streams start waiting for K1 before the host blocks on the read-back
-            auxs = _view_streams(dev, min(BIN_STREAM, V))
+            auxs = _view_streams(dev, min(n_side, V))
             ready = torch.cuda.Event()
             ready.record(main)
             for aux in auxs:
@@ -371,6 +427,16 @@ def _forward_views_impl(means3D, means2D, sh, opacities, scales, rotations, sett
                 ev = torch.cuda.Event()
                 ev.record(aux)
                 binned.append(ev)
+            if RENDER_SIDE:  # K6 of each view right behind its binning on the view's side stream
+                for v, st in enumerate(states):
+                    aux = auxs[v % len(auxs)]
+                    with torch.cuda.stream(aux):
+                        composite(v, C.c_void_p(aux.cuda_stream))
+                for aux in auxs:
+                    done = torch.cuda.Event()
+                    done.record(aux)
+                    main.wait_event(done)
+                return colors, radii, depths, alphas, states, keep, in_dtypes
             for v, st in enumerate(states):
                 main.wait_event(binned[v])
                 composite(v, stream)
@@ -425,8 +491,6 @@ class _RenderViews(torch.autograd.Function):
                 recs = torch.empty(n, max(N, 1) * 16, **f32)  # one 64-byte gradient record per Gaussian per view
                 s_arr = (L.GdrSettings * n)()
                 g_arr = (L.GdrGeom * n)()
-                main = torch.cuda.current_stream()
-                side = _view_streams(dev, min(VIEW_STREAMS, n)) if VIEW_STREAMS > 1 and n > 1 else None
                 grads_in = []
                 for k in range(n):  # torch-side preparation stays on the caller's stream
                     v = lo + k
@@ -436,28 +500,20 @@ class _RenderViews(torch.autograd.Function):
                     ga = None if g_alphas[v] is None else _f32(g_alphas[v], dev)
                     keep2 += [gc, gd, ga]
                     grads_in.append((gc, gd, ga))
-                if side:
-                    ready = torch.cuda.Event()
-                    ready.record(main)
-                    for sd in side:
-                        sd.wait_event(ready)
+                for k in range(n):
+                    s_arr[k] = _settings_struct(ctx.settings_list[lo + k], dev, keep2)
+                sides = _SideViews(dev, n, states[0].H, states[0].W)  # after every torch-side preparation (the side streams wait for this point)
                 for k in range(n):
                     v = lo + k
                     st = states[v]
-                    s_arr[k] = _settings_struct(ctx.settings_list[v], dev, keep2)
                     g_arr[k] = st.geom
                     g_arr[k].cov3D = states[0].geom.cov3D
                     gc, gd, ga = grads_in[k]
                     gin = L.GdrGradInputs(gc.data_ptr(), _ptr(gd), _ptr(ga))
-                    sv = C.c_void_p(side[k % len(side)].cuda_stream) if side else stream
                     L.check(lib.gdr_render_backward(C.byref(s_arr[k]), N, C.byref(g_arr[k]), C.byref(st.bin),
-                                                    C.byref(st.img), C.byref(gin), recs[k].data_ptr(), sv),
+                                                    C.byref(st.img), C.byref(gin), recs[k].data_ptr(), sides.stream(k)),
                             "gdr_render_backward")
-                if side:
-                    for sd in side:
-                        done = torch.cuda.Event()
-                        done.record(sd)
-                        main.wait_event(done)
+                sides.join()
                 r_arr = (C.c_void_p * n)(*[ctx.radii[lo + k].data_ptr() if N else None for k in range(n)])
                 rec_arr = (C.c_void_p * n)(*[recs[k].data_ptr() for k in range(n)])
                 gout = L.GdrGradOutputs(_ptr(g["means3D"]), _ptr(g["means2D"]), _ptr(g["shs"]), None,
@@ -519,15 +575,19 @@ class _RenderViewsLoss(torch.autograd.Function):
                 s_arr = (L.GdrSettings * n)()
                 g_arr = (L.GdrGeom * n)()
                 for k in range(n):
+                    s_arr[k] = _settings_struct(ctx.settings_list[lo + k], dev, keep2)
+                sides = _SideViews(dev, n, states[0].H, states[0].W)  # after every torch-side preparation (the side streams wait for this point)
+                for k in range(n):
                     v = lo + k
                     st = states[v]
-                    s_arr[k] = _settings_struct(ctx.settings_list[v], dev, keep2)
                     g_arr[k] = st.geom
                     g_arr[k].cov3D = states[0].geom.cov3D
+                    sv = sides.stream(k)
                     L.check(lib.gdr_render_backward_loss(C.byref(s_arr[k]), N, C.byref(g_arr[k]), C.byref(st.bin),
                                                          C.byref(st.img), ctx.colors[v].data_ptr(), ctx.targets[v].data_ptr(),
                                                          ctx.w[0], ctx.w[1], go[v:v + 1].data_ptr(), recs[k].data_ptr(),
-                                                         stream), "gdr_render_backward_loss")
+                                                         sv), "gdr_render_backward_loss")
+                sides.join()
                 r_arr = (C.c_void_p * n)(*[ctx.radii[lo + k].data_ptr() if N else None for k in range(n)])
                 rec_arr = (C.c_void_p * n)(*[recs[k].data_ptr() for k in range(n)])
                 gout = L.GdrGradOutputs(_ptr(g["means3D"]), _ptr(g["means2D"]), _ptr(g["shs"]), None,
@@ -589,14 +649,16 @@ def screenspace_absgrad_raw(means3D, sh, opacities, scales, rotations, settings_
         grad = torch.zeros(N, 4, dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             keep2: list = []
-            stream = _stream()
+            structs = [_settings_struct(settings_list[v], dev, keep2) for v in range(V)]
+            sides = _SideViews(dev, V, states[0].H, states[0].W)  # the views accumulate into `grad` with atomics: any interleaving is valid
             for v, st in enumerate(states):
-                s = _settings_struct(settings_list[v], dev, keep2)
                 g = st.geom
                 g.cov3D = states[0].geom.cov3D
-                L.check(lib.gdr_render_backward_mean2d_loss(C.byref(s), N, C.byref(g), C.byref(st.bin), C.byref(st.img),
-                                                            colors[v].data_ptr(), targets[v].data_ptr(), go.data_ptr(),
-                                                            _ptr(grad), stream), "gdr_render_backward_mean2d_loss")
+                L.check(lib.gdr_render_backward_mean2d_loss(C.byref(structs[v]), N, C.byref(g), C.byref(st.bin),
+                                                            C.byref(st.img), colors[v].data_ptr(), targets[v].data_ptr(),
+                                                            go.data_ptr(), _ptr(grad), sides.stream(v)),
+                        "gdr_render_backward_mean2d_loss")
+            sides.join()
         if topk:
             idx = torch.topk(grad[:, 2:4].norm(dim=1), min(int(topk), N)).indices
             return loss, grad, idx

@@ -230,9 +230,10 @@ class _RenderSurfelViews(torch.autograd.Function):
                 st.bin_buf = torch.empty(lib.gdr_binning_bytes(st.D), **u8)
                 L.check(lib.gdr_binning_carve(st.bin_buf.data_ptr(), st.D, C.byref(st.bin)), "gdr_binning_carve")
                 st.bin.global_sort = int(_R._FORCE_GLOBAL_SORT)
-            if _R.BIN_STREAM and V > 1:   # binning of view v+1 overlaps K6s of view v (rasterizer._forward_views_impl)
+            n_side = _R.side_count(H, W)
+            if n_side and V > 1:   # binning of view v+1 overlaps K6s of view v (rasterizer._forward_views_impl)
                 main = torch.cuda.current_stream()
-                auxs = _R._view_streams(dev, min(_R.BIN_STREAM, V))
+                auxs = _R._view_streams(dev, min(n_side, V))
                 ready = torch.cuda.Event()
                 ready.record(main)
                 for aux in auxs:
@@ -247,10 +248,19 @@ class _RenderSurfelViews(torch.autograd.Function):
                     ev.record(aux)
                     binned.append(ev)
                 for v, st in enumerate(states):
-                    main.wait_event(binned[v])
                     out = L.GsrOutputs(colors[v].data_ptr(), allmaps[v].data_ptr(), _ptr(radii[v]))
+                    if _R.RENDER_SIDE:  # K6s right behind the view's binning on its side stream (rasterizer._SideViews)
+                        sv = C.c_void_p(auxs[v % len(auxs)].cuda_stream)
+                    else:
+                        main.wait_event(binned[v])
+                        sv = stream
                     L.check(lib.gsr_composite_forward(C.byref(structs[v]), C.byref(st.geom), C.byref(st.bin),
-                                                      C.byref(st.img), C.byref(out), stream), "gsr_composite_forward")
+                                                      C.byref(st.img), C.byref(out), sv), "gsr_composite_forward")
+                if _R.RENDER_SIDE:
+                    for aux in auxs:
+                        done = torch.cuda.Event()
+                        done.record(aux)
+                        main.wait_event(done)
             else:
                 for v, st in enumerate(states):
                     out = L.GsrOutputs(colors[v].data_ptr(), allmaps[v].data_ptr(), _ptr(radii[v]))
@@ -286,18 +296,22 @@ class _RenderSurfelViews(torch.autograd.Function):
                     recs = torch.empty(n, max(N, 1) * L.GSR_GRAD_FLOATS, **f32)
                     s_arr = (L.GdrSettings * n)()
                     g_arr = (L.GdrGeom * n)()
-                    for k in range(n):
+                    gins = []
+                    for k in range(n):  # torch-side preparation on the caller's stream first
                         v = lo + k
-                        st = ctx.states[v]
                         s_arr[k] = _settings_struct(ctx.settings_list[v], dev, keep2)
-                        g_arr[k] = st.geom
                         gc = _f32(g[v], dev)
                         ga = None if g[V + v] is None else _f32(g[V + v], dev)
                         keep2 += [gc, ga]
-                        gin = L.GsrGradInputs(gc.data_ptr(), _ptr(ga))
+                        gins.append(L.GsrGradInputs(gc.data_ptr(), _ptr(ga)))
+                    sides = _R._SideViews(dev, n, ctx.states[0].H, ctx.states[0].W)
+                    for k in range(n):
+                        st = ctx.states[lo + k]
+                        g_arr[k] = st.geom
                         L.check(lib.gsr_render_backward(C.byref(s_arr[k]), N, C.byref(g_arr[k]), C.byref(st.bin),
-                                                        C.byref(st.img), C.byref(gin), recs[k].data_ptr(), stream),
-                                "gsr_render_backward")
+                                                        C.byref(st.img), C.byref(gins[k]), recs[k].data_ptr(),
+                                                        sides.stream(k)), "gsr_render_backward")
+                    sides.join()
                     r_arr = (C.c_void_p * n)(*[ctx.radii[lo + k].data_ptr() if N else None for k in range(n)])
                     rec_arr = (C.c_void_p * n)(*[recs[k].data_ptr() for k in range(n)])
                     gout = L.GsrGradOutputs(_ptr(out["means3D"]), _ptr(out["means2D"]), _ptr(out["shs"]), None,

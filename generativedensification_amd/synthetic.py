@@ -7,15 +7,23 @@ import math
 import torch
 
 
-def make_scene(n: int, seed: int, sh_degree: int = 3, sigma0=(0.0052, 0.00065), device="cpu"):
+def make_scene(n: int, seed: int, sh_degree: int = 3, sigma0=(0.0052, 0.00065), device="cpu", layout="cube"):
     """Raw (pre-activation) attributes exactly as `Renderer.render_img` receives them
     (lightning/renderer.py:209-230): centers (N,3), shs (N,M,3), opacity logits (N,1),
     log-scales (N,3), raw quaternions (N,4).  `sigma0` may be one value or a tuple that
-    is mixed in equal parts (C2: 50/50 coarse-like / densified-like)."""
+    is mixed in equal parts (C2: 50/50 coarse-like / densified-like).  `layout`: "cube" = uniform in the
+    reference's scene cube (the BASELINE workloads); "shell" = an object-like stand-in, centres on a bumpy
+    sphere shell of radius ~0.3 (skewed tile lists: long at the silhouette, empty outside the object)."""
     g = torch.Generator().manual_seed(seed)
     if not isinstance(sigma0, (tuple, list)):
         sigma0 = (sigma0,)
     centers = torch.rand(n, 3, generator=g) - 0.5
+    if layout == "shell":
+        d = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1)
+        bump = 0.04 * torch.sin(9.0 * d[:, :1]) * torch.cos(7.0 * d[:, 1:2])
+        centers = d * (0.3 + bump + 0.004 * torch.randn(n, 1, generator=g))
+    elif layout != "cube":
+        raise ValueError(f"unknown layout {layout!r}")
     logs = torch.empty(n, 3)
     per = (n + len(sigma0) - 1) // len(sigma0)
     for k, s0 in enumerate(sigma0):
