@@ -333,6 +333,28 @@ def main():
                             avg_launch_us=kernels[dom]["avg_us"],
                             path_bytes_view=int(alg["_bytes_view"]),
                             path_frac=round(views_per_sec / world * alg["_bytes_view"] / 1e9 / HBM_PEAK_GBS, 4))
+            # The render kernels of different views run on side streams, two launches at a time: each launch then
+            # takes about twice as long as it does alone, and the per-launch figure above halves although the work per
+            # second does not.  A short extra pass with the views serialised gives the launch duration of the kernel
+            # on its own (what `frac` measured before the views overlapped).
+            if R.RENDER_SIDE and vpg > 1 and not (args.per_view or args.torch_loss and surfel):
+                R.RENDER_SIDE = 0
+                try:
+                    L.profile_enable(True)
+                    L.profile_collect(reset=True)
+                    for _ in range(min(args.steps, 3)):
+                        step()
+                    torch.cuda.synchronize()
+                    prof1 = L.profile_collect(reset=True)
+                    L.profile_enable(False)
+                finally:
+                    R.RENDER_SIDE = 1
+                ms1, cnt1 = prof1.get(dom, (0.0, 0))
+                if cnt1:
+                    avg1 = 1e3 * ms1 / cnt1
+                    roofline.update(avg_launch_us_serial=round(avg1, 2),
+                                    frac_serial=round(alg[dom] / (avg1 * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                                    launch_overlap=round(kernels[dom]["avg_us"] / avg1, 2))
 
     # ---- CPU baseline: oracle (C restatement, OpenMP) on a bounded sample ------------------
     cpu_baseline = None

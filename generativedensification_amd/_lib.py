@@ -44,12 +44,14 @@ class GdrGeom(C.Structure):
 
 class GdrBinning(C.Structure):
     _fields_ = [("keys", C.c_void_p * 2), ("values", C.c_void_p * 2), ("hist", C.c_void_p),
-                ("sorted", C.c_int32), ("global_sort", C.c_int32), ("scratch32", C.c_void_p)]
+                ("sorted", C.c_int32), ("global_sort", C.c_int32), ("scratch32", C.c_void_p),
+                ("seg_extra", C.c_void_p), ("seg_count", C.c_void_p), ("seg_state", C.c_void_p),
+                ("seg_len", C.c_int32), ("seg_cap", C.c_int32)]
 
 
 class GdrImage(C.Structure):
     _fields_ = [("ranges", C.c_void_p), ("n_contrib", C.c_void_p), ("final_T", C.c_void_p),
-                ("tile_order", C.c_void_p)]
+                ("tile_order", C.c_void_p), ("seg_base", C.c_void_p)]
 
 
 class GdrOutputs(C.Structure):
@@ -197,7 +199,7 @@ def load():
             fn = getattr(lib, name)  # AttributeError if the symbol is missing
             fn.restype = res
             fn.argtypes = args
-        if lib.gdr_abi_version() != 6:
+        if lib.gdr_abi_version() != 7:
             raise RuntimeError("libgdr_hip.so ABI version mismatch")
         _lib = lib
     return _lib

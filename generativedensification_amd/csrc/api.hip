@@ -92,6 +92,12 @@ static size_t carve_binning(void* base, uint64_t D, gdr_binning* b) {
     t.scratch32 = c.take<uint32_t>(2 * d);
     t.sorted = 0;
     t.global_sort = 0;
+    static const int seg_len_env = getenv("GDR_SEG_LEN") ? atoi(getenv("GDR_SEG_LEN")) : 2048;
+    t.seg_len = seg_len_env > 0 ? ((seg_len_env + GDR_BLOCK - 1) / GDR_BLOCK) * GDR_BLOCK : 0;
+    t.seg_cap = t.seg_len ? (int32_t)(D / (uint64_t)t.seg_len + 1) : 0;
+    t.seg_extra = c.take<uint32_t>(2 * (size_t)(t.seg_cap ? t.seg_cap : 1));
+    t.seg_count = c.take<uint32_t>(2);
+    t.seg_state = c.take<float>(t.seg_cap ? (size_t)2 * t.seg_cap * GDR_SEG_STATE_FLOATS : 1);
     if (b) *b = t;
     return c.off;
 }
@@ -105,6 +111,7 @@ static size_t carve_image(void* base, int H, int W, gdr_image* im) {
     t.n_contrib = c.take<uint32_t>(P ? P : 1);
     t.final_T = c.take<float>(P ? P : 1);
     t.tile_order = c.take<uint32_t>(tiles ? tiles : 1);
+    t.seg_base = c.take<uint32_t>(tiles ? tiles : 1);
     if (im) *im = t;
     return c.off;
 }
@@ -226,7 +233,7 @@ static int binning_stage(const gdr_settings* s, int32_t N, const gdr_geom* geom,
         e = launch_ranges(bin, D, img, tiles, st);
         if (e != hipSuccess) return hip_fail("ranges", e);
         if ((rc = debug_sync(s, "ranges", st))) return rc;
-        e = launch_tile_order(img, tiles, st);
+        e = launch_tile_order(img, bin, tiles, st);
         if (e != hipSuccess) return hip_fail("tile_order", e);
         if ((rc = debug_sync(s, "tile_order", st))) return rc;
     } else {  // default: stable partition by tile, segments, per-tile LDS depth sort
@@ -236,7 +243,7 @@ static int binning_stage(const gdr_settings* s, int32_t N, const gdr_geom* geom,
         e = launch_ranges(bin, D, img, tiles, st);
         if (e != hipSuccess) return hip_fail("ranges", e);
         if ((rc = debug_sync(s, "ranges", st))) return rc;
-        e = launch_tile_order(img, tiles, st);  // longest list first: launch order of tile_sort, K6, K7
+        e = launch_tile_order(img, bin, tiles, st);  // longest list first: launch order of tile_sort, K6, K7
         if (e != hipSuccess) return hip_fail("tile_order", e);
         if ((rc = debug_sync(s, "tile_order", st))) return rc;
         e = launch_tile_sort(bin, img, tiles, D, st);
@@ -541,6 +548,7 @@ static size_t carve_surfel_image(void* base, int H, int W, gdr_image* im) {
     t.n_contrib = c.take<uint32_t>(2 * (P ? P : 1));
     t.final_T = c.take<float>(3 * (P ? P : 1));
     t.tile_order = c.take<uint32_t>(tiles ? tiles : 1);
+    t.seg_base = nullptr;  // the surfel kernels do not cut tile lists
     if (im) *im = t;
     return c.off;
 }

@@ -153,9 +153,12 @@ __global__ __launch_bounds__(GDR_BLOCK) void render_fwd_kernel(
     const uint32_t* __restrict__ tile_order, int W, int H, int gx, int ntiles,
     const float4* __restrict__ rec, const float* __restrict__ bg, float* __restrict__ final_T,
     uint32_t* __restrict__ n_contrib, float* __restrict__ out_color, float* __restrict__ out_depth,
-    float* __restrict__ out_alpha, const FusedLoss fl) {
+    float* __restrict__ out_alpha, const FusedLoss fl, uint32_t* __restrict__ seg_base,
+    float* __restrict__ seg_state, uint2* __restrict__ seg_extra, uint32_t* __restrict__ seg_count, int seg_rounds,
+    int seg_cap) {
     __shared__ SliceLds lds;
     __shared__ int s_done[GDR_BLOCK / GDR_WAVE];
+    __shared__ uint32_t s_slot;
 
     const uint32_t tile = tile_order ? tile_order[blockIdx.x] : xcd_remap(blockIdx.x, (uint32_t)ntiles);
     const int tx = (int)(tile % (uint32_t)gx), ty = (int)(tile / (uint32_t)gx);
@@ -169,6 +172,24 @@ __global__ __launch_bounds__(GDR_BLOCK) void render_fwd_kernel(
     const uint2 range = ranges[tile];
     const int total = (int)(range.y - range.x);
     const int rounds = (total + GDR_BLOCK - 1) / GDR_BLOCK;
+    // A list longer than seg_rounds slices is CUT every seg_rounds slices into nseg segments so that K7 can walk
+    // the segments in parallel workgroups: the compositing state of every pixel is saved at each cut and at the end
+    // of the list (nseg state slots, handed out here), and every segment but the last is entered into seg_extra
+    // (the last one is walked by the tile's own K7 workgroup).
+    uint32_t sb = 0xFFFFFFFFu;
+    if (seg_rounds > 0 && rounds > seg_rounds) {
+        if (threadIdx.x == 0) {
+            const uint32_t nseg = (uint32_t)((rounds + seg_rounds - 1) / seg_rounds);
+            const uint32_t slot = atomicAdd(&seg_count[1], nseg);
+            const uint32_t e0 = atomicAdd(&seg_count[0], nseg - 1u);
+            const bool fits = slot + nseg <= 2u * (uint32_t)seg_cap && e0 + nseg - 1u <= (uint32_t)seg_cap;
+            seg_base[tile] = fits ? slot : 0xFFFFFFFFu;  // (cannot overflow: see carve_binning; checked anyway)
+            for (uint32_t k = 0; fits && k + 1u < nseg; ++k) seg_extra[e0 + k] = make_uint2(tile, k);
+            s_slot = fits ? slot : 0xFFFFFFFFu;
+        }
+        __syncthreads();
+        sb = s_slot;
+    }
 
     if (threadIdx.x == 0) {
         lds.xy[GDR_NULL_ENTRY] = make_float2(0.f, 0.f);
@@ -192,6 +213,11 @@ __global__ __launch_bounds__(GDR_BLOCK) void render_fwd_kernel(
         if (lane == 0) s_done[wave] = live == 0ull ? 1 : 0;
         __syncthreads();
         if (s_done[0] + s_done[1] + s_done[2] + s_done[3] == GDR_BLOCK / GDR_WAVE) break;
+        if (sb != 0xFFFFFFFFu && r > 0 && r % seg_rounds == 0) {  // cut in front of list position r * 256
+            float* st = seg_state + ((size_t)sb + (size_t)(r / seg_rounds - 1)) * GDR_SEG_STATE_FLOATS + threadIdx.x;
+            st[0] = T; st[GDR_BLOCK] = C0; st[2 * GDR_BLOCK] = C1; st[3 * GDR_BLOCK] = C2;
+            st[4 * GDR_BLOCK] = Dp; st[5 * GDR_BLOCK] = Wt;
+        }
         stage_write(lds, r_valid, r_xe, r_co, r_cd);
         __syncthreads();
         {   // prefetch the next slice (lands while this one is composited)
@@ -258,6 +284,12 @@ __global__ __launch_bounds__(GDR_BLOCK) void render_fwd_kernel(
             if (abort) g = GDR_BLOCK / GDR_WAVE;
         }
     }
+    if (sb != 0xFFFFFFFFu) {  // totals of the cut list (K7 forms "everything behind a cut" = totals - prefix)
+        const int nseg = (rounds + seg_rounds - 1) / seg_rounds;
+        float* st = seg_state + ((size_t)sb + (size_t)(nseg - 1)) * GDR_SEG_STATE_FLOATS + threadIdx.x;
+        st[0] = T; st[GDR_BLOCK] = C0; st[2 * GDR_BLOCK] = C1; st[3 * GDR_BLOCK] = C2;
+        st[4 * GDR_BLOCK] = Dp; st[5 * GDR_BLOCK] = Wt;
+    }
     if (inside) {
         const size_t pix = (size_t)py * W + px, P = (size_t)H * W;
         final_T[pix] = T;
@@ -303,11 +335,26 @@ __global__ __launch_bounds__(GDR_BLOCK) void render_bwd_kernel(
     const uint32_t* __restrict__ tile_order, int W, int H, int gx, int ntiles,
     const float* __restrict__ bg, const float4* __restrict__ rec, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
     const float* __restrict__ dL_dpix, const float* __restrict__ dL_ddepthpix,
-    const float* __restrict__ dL_dalphapix, float* __restrict__ grad_rec, const FusedLoss fl) {
+    const float* __restrict__ dL_dalphapix, float* __restrict__ grad_rec, const FusedLoss fl,
+    const uint32_t* __restrict__ seg_base, const float* __restrict__ seg_state, const uint2* __restrict__ seg_extra,
+    const uint32_t* __restrict__ seg_count, int seg_rounds, int n_extra) {
     __shared__ SliceLds lds;
     __shared__ uint32_t s_id[GDR_BLOCK + 1];
 
-    const uint32_t tile = tile_order ? tile_order[blockIdx.x] : xcd_remap(blockIdx.x, (uint32_t)ntiles);
+    // Workgroups [0, n_extra): one segment of a cut list each (the full-length segments, i.e. the longest work
+    // items, are dispatched first); workgroups [n_extra, n_extra + ntiles): one tile each — its whole list, or the
+    // last segment of a cut list.
+    uint32_t tile;
+    int seg = -1;
+    if ((int)blockIdx.x < n_extra) {
+        if (blockIdx.x >= min(seg_count[0], (uint32_t)n_extra)) return;
+        const uint2 e = seg_extra[blockIdx.x];
+        tile = e.x;
+        seg = (int)e.y;
+    } else {
+        const uint32_t b = blockIdx.x - (uint32_t)n_extra;
+        tile = tile_order ? tile_order[b] : xcd_remap(b, (uint32_t)ntiles);
+    }
     const int tx = (int)(tile % (uint32_t)gx), ty = (int)(tile / (uint32_t)gx);
     const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
     const uint32_t row = lane >> 4, li = lane & 15u;
@@ -318,7 +365,18 @@ __global__ __launch_bounds__(GDR_BLOCK) void render_bwd_kernel(
     const float XA = (float)sx0, YA = (float)sy0;
     const size_t pix = (size_t)py * W + px, P = (size_t)H * W;
     const uint2 range = ranges[tile];
-    const int total = (int)(range.y - range.x);
+    // this workgroup walks list positions [seg_lo, seg_hi) of the tile, back to front
+    const int full_total = (int)(range.y - range.x);
+    int seg_lo = 0, seg_hi = full_total, nseg = 1;
+    if (seg_rounds > 0 && full_total > seg_rounds * GDR_BLOCK && seg_base[tile] != 0xFFFFFFFFu) {  // cut by K6
+        const int seg_len = seg_rounds * GDR_BLOCK;
+        nseg = (full_total + seg_len - 1) / seg_len;
+        if (seg < 0) seg = nseg - 1;
+        seg_lo = seg * seg_len;
+        seg_hi = min(full_total, seg_lo + seg_len);
+    }
+    const int total = seg_hi - seg_lo;
+    const uint32_t list_end = range.x + (uint32_t)seg_hi;
     const int rounds = (total + GDR_BLOCK - 1) / GDR_BLOCK;
 
     if (threadIdx.x == 0) {
@@ -329,7 +387,11 @@ __global__ __launch_bounds__(GDR_BLOCK) void render_bwd_kernel(
     }
     const float T_final = inside ? final_T[pix] : 0.f;
     float T = T_final;
-    const int last_contributor = inside ? (int)n_contrib[pix] : 0;
+    const int lc_full = inside ? (int)n_contrib[pix] : 0;
+    // positions are counted from seg_lo below; a pixel whose last contributor lies behind this segment starts
+    // from the state K6 saved at the cut (see the B initialisation further down)
+    const bool from_cut = lc_full > seg_hi;
+    const int last_contributor = from_cut ? total : max(lc_full - seg_lo, 0);
     float gC0 = 0.f, gC1 = 0.f, gC2 = 0.f, gD = 0.f, gA = 0.f;
     if (LOSS) {
         if (inside && last_contributor > 0) {
@@ -350,6 +412,17 @@ __global__ __launch_bounds__(GDR_BLOCK) void render_bwd_kernel(
     // "behind" state B = colour / depth / coverage composited from everything behind the
     // current Gaussian; update B <- B + a (c - B) is the identity for a = 0
     float B0 = 0.f, B1 = 0.f, B2 = 0.f, BD = 0.f, BA = 0.f;
+    if (from_cut) {  // (only in workgroups of seg_extra): T in front of position seg_hi, B = (totals - prefix) / T
+        const float* cu = seg_state + ((size_t)seg_base[tile] + (size_t)seg) * GDR_SEG_STATE_FLOATS + threadIdx.x;
+        const float* to = seg_state + ((size_t)seg_base[tile] + (size_t)(nseg - 1)) * GDR_SEG_STATE_FLOATS + threadIdx.x;
+        T = cu[0];
+        const float rT = 1.f / T;
+        B0 = (to[GDR_BLOCK] - cu[GDR_BLOCK]) * rT;
+        B1 = (to[2 * GDR_BLOCK] - cu[2 * GDR_BLOCK]) * rT;
+        B2 = (to[3 * GDR_BLOCK] - cu[3 * GDR_BLOCK]) * rT;
+        BD = (to[4 * GDR_BLOCK] - cu[4 * GDR_BLOCK]) * rT;
+        BA = (to[5 * GDR_BLOCK] - cu[5 * GDR_BLOCK]) * rT;
+    }
     // the staged conic is log2(e) x the true one: fold 1/log2(e) = ln 2 into the pixel->NDC factors
     const float kx = 0.5f * (float)W * GDR_LN2, ky = 0.5f * (float)H * GDR_LN2;
 
@@ -368,7 +441,7 @@ __global__ __launch_bounds__(GDR_BLOCK) void render_bwd_kernel(
     uint32_t r_id = 0;
     bool r_valid = (int)threadIdx.x < total;
     if (r_valid) {
-        r_id = point_list[range.y - 1 - threadIdx.x];
+        r_id = point_list[list_end - 1u - threadIdx.x];
         { const float4 a0 = rec[4 * (size_t)r_id], a3 = rec[4 * (size_t)r_id + 3];
           r_xe = make_float4(a0.x, a0.y, a3.x, a3.y); r_co = rec[4 * (size_t)r_id + 1]; r_cd = rec[4 * (size_t)r_id + 2]; }
     }
@@ -381,7 +454,7 @@ __global__ __launch_bounds__(GDR_BLOCK) void render_bwd_kernel(
             const int nxt = (r + 1) * GDR_BLOCK + (int)threadIdx.x;
             r_valid = nxt < total;
             if (r_valid) {
-                r_id = point_list[range.y - 1 - nxt];
+                r_id = point_list[list_end - 1u - (uint32_t)nxt];
                 { const float4 a0 = rec[4 * (size_t)r_id], a3 = rec[4 * (size_t)r_id + 3];
           r_xe = make_float4(a0.x, a0.y, a3.x, a3.y); r_co = rec[4 * (size_t)r_id + 1]; r_cd = rec[4 * (size_t)r_id + 2]; }
             }
@@ -479,21 +552,37 @@ __global__ __launch_bounds__(GDR_BLOCK) void render_bwd_kernel(
 
 }  // namespace
 
-hipError_t launch_tile_order(const gdr_image* img, int ntiles, hipStream_t st) {
+hipError_t launch_tile_order(const gdr_image* img, const gdr_binning* bin, int ntiles, hipStream_t st) {
     GDR_LAUNCH(GDR_K_TILE_ORDER, tile_order_kernel, dim3(1), dim3(GDR_BLOCK), st, (const uint2*)img->ranges,
                ntiles, img->tile_order);
+    (void)bin;
     return hipGetLastError();
 }
+
+// segments of cut tile lists (see tile_order_kernel): arguments shared by the K6 / K7 launches
+static inline int seg_rounds_of(const gdr_binning* bin, const gdr_image* img) {
+    return (img->seg_base && bin->seg_len > 0) ? bin->seg_len / GDR_BLOCK : 0;
+}
+#define GDR_SEG_FWD_ARGS(bin, img) \
+    (img)->seg_base, (bin)->seg_state, (uint2*)(bin)->seg_extra, (bin)->seg_count, seg_rounds_of(bin, img), (bin)->seg_cap
+#define GDR_SEG_BWD_ARGS(bin, img)                                                                          \
+    (img)->seg_base, (const float*)(bin)->seg_state, (const uint2*)(bin)->seg_extra, (bin)->seg_count,     \
+        seg_rounds_of(bin, img), (seg_rounds_of(bin, img) ? (bin)->seg_cap : 0)
+#define GDR_BWD_GRID(bin, img, ntiles) dim3((unsigned)((ntiles) + (seg_rounds_of(bin, img) ? (bin)->seg_cap : 0)))
 
 hipError_t launch_render_fwd(const gdr_settings* s, const gdr_geom* g, const gdr_binning* bin,
                              const gdr_image* img, const gdr_outputs* out, hipStream_t st) {
     const int W = s->image_width, H = s->image_height;
     const int gx = tile_grid_x(W), gy = tile_grid_y(H);
     const int ntiles = gx * gy;
+    if (seg_rounds_of(bin, img)) {  // K6 hands out the cut-list rows / state slots from zero
+        const hipError_t e = hipMemsetAsync(bin->seg_count, 0, 2 * sizeof(uint32_t), st);
+        if (e != hipSuccess) return e;
+    }
     GDR_LAUNCH(GDR_K_RENDER_FWD, render_fwd_kernel<false>, dim3(ntiles), dim3(GDR_BLOCK), st,
                (const uint2*)img->ranges, bin->values[bin->sorted], img->tile_order, W, H, gx, ntiles,
                (const float4*)g->rec, s->bg, img->final_T, img->n_contrib, out->color, out->depth, out->alpha,
-               FusedLoss{});
+               FusedLoss{}, GDR_SEG_FWD_ARGS(bin, img));
     return hipGetLastError();
 }
 
@@ -504,9 +593,14 @@ hipError_t launch_render_fwd_loss(const gdr_settings* s, const gdr_geom* g, cons
     const int gx = tile_grid_x(W), gy = tile_grid_y(H);
     const int ntiles = gx * gy;
     const FusedLoss fl{target, w_depth, w_alpha, loss, nullptr, nullptr};
+    if (seg_rounds_of(bin, img)) {
+        const hipError_t e = hipMemsetAsync(bin->seg_count, 0, 2 * sizeof(uint32_t), st);
+        if (e != hipSuccess) return e;
+    }
     GDR_LAUNCH(GDR_K_RENDER_FWD, render_fwd_kernel<true>, dim3(ntiles), dim3(GDR_BLOCK), st,
                (const uint2*)img->ranges, bin->values[bin->sorted], img->tile_order, W, H, gx, ntiles,
-               (const float4*)g->rec, s->bg, img->final_T, img->n_contrib, out->color, out->depth, out->alpha, fl);
+               (const float4*)g->rec, s->bg, img->final_T, img->n_contrib, out->color, out->depth, out->alpha, fl,
+               GDR_SEG_FWD_ARGS(bin, img));
     return hipGetLastError();
 }
 
@@ -517,9 +611,10 @@ hipError_t launch_render_bwd_loss(const gdr_settings* s, const gdr_geom* g, cons
     const int gx = tile_grid_x(W), gy = tile_grid_y(H);
     const int ntiles = gx * gy;
     const FusedLoss fl{target, w_depth, w_alpha, nullptr, go, color};
-    GDR_LAUNCH(GDR_K_RENDER_BWD, (render_bwd_kernel<false, true>), dim3(ntiles), dim3(GDR_BLOCK), st,
+    GDR_LAUNCH(GDR_K_RENDER_BWD, (render_bwd_kernel<false, true>), GDR_BWD_GRID(bin, img, ntiles), dim3(GDR_BLOCK), st,
                (const uint2*)img->ranges, bin->values[bin->sorted], img->tile_order, W, H, gx, ntiles, s->bg,
-               (const float4*)g->rec, img->final_T, img->n_contrib, nullptr, nullptr, nullptr, grad_rec, fl);
+               (const float4*)g->rec, img->final_T, img->n_contrib, nullptr, nullptr, nullptr, grad_rec, fl,
+               GDR_SEG_BWD_ARGS(bin, img));
     return hipGetLastError();
 }
 
@@ -529,10 +624,10 @@ hipError_t launch_render_bwd(const gdr_settings* s, const gdr_geom* g, const gdr
     const int W = s->image_width, H = s->image_height;
     const int gx = tile_grid_x(W), gy = tile_grid_y(H);
     const int ntiles = gx * gy;
-    GDR_LAUNCH(GDR_K_RENDER_BWD, render_bwd_kernel<false>, dim3(ntiles), dim3(GDR_BLOCK), st,
+    GDR_LAUNCH(GDR_K_RENDER_BWD, render_bwd_kernel<false>, GDR_BWD_GRID(bin, img, ntiles), dim3(GDR_BLOCK), st,
                (const uint2*)img->ranges, bin->values[bin->sorted], img->tile_order, W, H, gx, ntiles, s->bg,
                (const float4*)g->rec, img->final_T, img->n_contrib, gi->dL_dcolor, gi->dL_ddepth, gi->dL_dalpha,
-               go->scratch, FusedLoss{});
+               go->scratch, FusedLoss{}, GDR_SEG_BWD_ARGS(bin, img));
     return hipGetLastError();
 }
 
@@ -542,9 +637,10 @@ hipError_t launch_render_bwd_mean2d(const gdr_settings* s, const gdr_geom* g, co
     const int W = s->image_width, H = s->image_height;
     const int gx = tile_grid_x(W), gy = tile_grid_y(H);
     const int ntiles = gx * gy;
-    GDR_LAUNCH(GDR_K_RENDER_BWD, render_bwd_kernel<true>, dim3(ntiles), dim3(GDR_BLOCK), st,
+    GDR_LAUNCH(GDR_K_RENDER_BWD, render_bwd_kernel<true>, GDR_BWD_GRID(bin, img, ntiles), dim3(GDR_BLOCK), st,
                (const uint2*)img->ranges, bin->values[bin->sorted], img->tile_order, W, H, gx, ntiles, s->bg,
-               (const float4*)g->rec, img->final_T, img->n_contrib, dL_dcolor, nullptr, nullptr, dL_dmean2D, FusedLoss{});
+               (const float4*)g->rec, img->final_T, img->n_contrib, dL_dcolor, nullptr, nullptr, dL_dmean2D, FusedLoss{},
+               GDR_SEG_BWD_ARGS(bin, img));
     return hipGetLastError();
 }
 
@@ -557,9 +653,10 @@ hipError_t launch_render_bwd_mean2d_loss(const gdr_settings* s, const gdr_geom* 
     const int gx = tile_grid_x(W), gy = tile_grid_y(H);
     const int ntiles = gx * gy;
     const FusedLoss fl{target, 0.f, 0.f, nullptr, go, color};
-    GDR_LAUNCH(GDR_K_RENDER_BWD, (render_bwd_kernel<true, true>), dim3(ntiles), dim3(GDR_BLOCK), st,
+    GDR_LAUNCH(GDR_K_RENDER_BWD, (render_bwd_kernel<true, true>), GDR_BWD_GRID(bin, img, ntiles), dim3(GDR_BLOCK), st,
                (const uint2*)img->ranges, bin->values[bin->sorted], img->tile_order, W, H, gx, ntiles, s->bg,
-               (const float4*)g->rec, img->final_T, img->n_contrib, nullptr, nullptr, nullptr, dL_dmean2D, fl);
+               (const float4*)g->rec, img->final_T, img->n_contrib, nullptr, nullptr, nullptr, dL_dmean2D, fl,
+               GDR_SEG_BWD_ARGS(bin, img));
     return hipGetLastError();
 }
 

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define GDR_ABI_VERSION 6
+#define GDR_ABI_VERSION 7
 
 #define GDR_OK 0
 #define GDR_ERR_INVALID_ARG (-1)  /* NULL / inconsistent arguments                     */
@@ -128,6 +128,14 @@ typedef struct gdr_binning {
     int32_t global_sort; /* !=0: one global LSD radix sort over all key bits instead of the default
                           * tile partition + per-tile LDS depth sort (same result; A/B and tests) */
     uint32_t* scratch32; /* (2*D) depth-key ping-pong for tile lists that do not fit in LDS */
+    /* Segments of long tile lists (K7 walks the segments of one tile in parallel workgroups):
+     * a tile whose sorted list is longer than seg_len entries is cut every seg_len entries;
+     * K6 saves the per-pixel compositing state at every cut and at the end of the list. */
+    uint32_t* seg_extra; /* (seg_cap,2) (tile, segment) of every segment but the last of its tile */
+    uint32_t* seg_count; /* (2) rows of seg_extra in use, state slots in use (filled by K6)       */
+    float* seg_state;    /* (2*seg_cap, 6, 256) T, colour x3, depth, alpha sums per pixel of the tile */
+    int32_t seg_len;     /* entries per segment (multiple of 256); 0 = lists are never cut          */
+    int32_t seg_cap;     /* D / seg_len + 1                                                         */
 } gdr_binning;
 
 /* Image state (upstream "imgBuffer"). */
@@ -136,6 +144,8 @@ typedef struct gdr_image {
     uint32_t* n_contrib; /* (H*W) 1-based index of the last contributor     */
     float* final_T;      /* (H*W) transmittance after the last contributor  */
     uint32_t* tile_order; /* (tiles) tile ids, longest sorted list first (launch order of K6/K7) */
+    uint32_t* seg_base;   /* (tiles) first seg_state slot of a tile whose list K6 cut (valid for those tiles only);
+                           * NULL (surfel image state): lists are never cut */
 } gdr_image;
 
 typedef struct gdr_outputs {
