@@ -88,6 +88,8 @@ class _State:
             final_T=self._view(ib, im.final_T, torch.float32, H * W).view(H, W),
             num_rendered=D,
         )
+        out["seg_len"] = int(b.seg_len)
+        out["seg_count"] = self._view(bb, b.seg_count, torch.int32, 2)  # rows of seg_extra, state slots (filled by K6)
         out["xy"], out["conic_opacity"], out["rgb"] = out["rec"][:, 0:2], out["rec"][:, 4:8], out["rec"][:, 8:12]
         if D > 0:
             out["keys_sorted"] = self._view(bb, b.keys[s], torch.int64, D)
@@ -143,6 +145,20 @@ VIEW_STREAMS = max(1, int(_os.environ.get("GDR_VIEW_STREAMS", "1")))
 RENDER_SIDE = int(_os.environ.get("GDR_RENDER_SIDE", "1"))
 _BIN_STREAM_ENV = _os.environ.get("GDR_BIN_STREAM")
 BIN_STREAM = None if _BIN_STREAM_ENV is None else max(0, int(_BIN_STREAM_ENV))
+
+
+# Segment length of cut tile lists (include/gdr.h gdr_binning.seg_len): None = the library default (2048, or
+# GDR_SEG_LEN), 0 = lists are never cut, otherwise a multiple of 256.  Tests switch it per call.
+SEG_LEN = None
+
+
+def _apply_seg_len(bin_struct, D):
+    if SEG_LEN is not None:
+        sl = max(0, int(SEG_LEN)) // 256 * 256
+        if sl and sl >= bin_struct.seg_len > 0:   # only lengths >= the carved one fit the carved tables
+            bin_struct.seg_len = sl
+        elif sl == 0:
+            bin_struct.seg_len = 0
 
 
 def side_count(H, W):
@@ -242,6 +258,7 @@ def forward_raw(means3D, sh, colors_precomp, opacities, scales, rotations, cov3D
         st.bin_buf = torch.empty(lib.gdr_binning_bytes(st.D), **u8)
         L.check(lib.gdr_binning_carve(st.bin_buf.data_ptr(), st.D, C.byref(st.bin)), "gdr_binning_carve")
         st.bin.global_sort = int(_FORCE_GLOBAL_SORT)
+        _apply_seg_len(st.bin, st.D)
         out = L.GdrOutputs(color.data_ptr(), depth.data_ptr(), alpha.data_ptr(), _ptr(radii))
         L.check(lib.gdr_render_forward(C.byref(s), C.byref(inp), C.byref(st.geom), C.byref(st.bin),
                                        C.byref(st.img), st.D, C.byref(out), stream), "gdr_render_forward")
@@ -396,6 +413,7 @@ def _forward_views_impl(means3D, means2D, sh, opacities, scales, rotations, sett
             st.bin_buf = torch.empty(lib.gdr_binning_bytes(st.D), **u8)
             L.check(lib.gdr_binning_carve(st.bin_buf.data_ptr(), st.D, C.byref(st.bin)), "gdr_binning_carve")
             st.bin.global_sort = int(_FORCE_GLOBAL_SORT)
+            _apply_seg_len(st.bin, st.D)
 
         if not two_stage:
             for v in range(V):

@@ -517,6 +517,45 @@ def test_long_tile_lists_bucket_and_band_cases(oracle_built, n, band):
     assert U.outlier_fraction(hip["color"], ora["color"], 1e-3, 1e-4) < 1e-3
 
 
+def test_cut_tile_lists_give_the_gradients_of_the_uncut_walk(oracle_built):
+    """Lists longer than seg_len are cut: K6 saves (T, prefix sums) per pixel at every cut, K7 walks the segments in
+    parallel workgroups from those states.  Same case with seg_len = 2048 / 4096 / off: identical forward (bit for bit),
+    gradients equal to the uncut walk's within float-summation noise and to the f64 oracle within tolerance; the
+    tables K6 filled have the expected number of rows."""
+    from generativedensification_amd import rasterizer as R
+
+    case = U.make_case(40_000, 64, 48, 43, deg=1, sigma0=(0.003,))
+    case["means3D"] = (case["means3D"] * 0.3).contiguous()             # two tiles with 25k / 31k entries
+    case["opacities"] = (case["opacities"] * 0.05).contiguous()        # transmittance stays alive: 230 pixels whose
+                                                                        # last contributor lies beyond position 8192
+    grads = U.rand_grads(case)
+    res = {}
+    try:
+        for sl in (0, 2048, 4096):
+            R.SEG_LEN = sl
+            res[sl] = U.run_hip(case, grads)
+    finally:
+        R.SEG_LEN = None
+    (h0, g0) = res[0]
+    lens = (h0["ranges"][:, 1].astype(np.int64) - h0["ranges"][:, 0]).clip(min=0)
+    assert lens.max() > 3 * 2048
+    for sl in (2048, 4096):
+        h, g = res[sl]
+        assert h["seg_len"] == sl
+        nseg = np.where(lens > sl, -(-lens // sl), 0)
+        assert int(h["seg_count"][0]) == int((nseg - (nseg > 0)).sum())   # rows: every segment but the last of its tile
+        assert int(h["seg_count"][1]) == int(nseg.sum())                   # slots: cuts + end of list
+        for k in ("color", "depth", "alpha", "n_contrib", "final_T"):
+            np.testing.assert_array_equal(h[k], h0[k])
+        for k in ("means3D", "means2D", "shs", "opacities", "scales", "rotations"):
+            assert U.rel_inf(g[k], g0[k]) < 2e-5, (sl, k, U.rel_inf(g[k], g0[k]))
+    assert int(h0["seg_count"][0]) == 0 or h0["seg_len"] == 0
+    _, g64 = U.run_oracle(case, "f64", grads, nthreads=8)
+    for sl in (0, 2048, 4096):
+        for k in ("means3D", "opacities", "scales", "rotations", "shs"):
+            assert U.rel_inf(res[sl][1][k].reshape(g64[k].shape), g64[k]) < 5e-4, (sl, k)
+
+
 def test_one_tile_with_a_very_long_list_takes_the_global_sort_path(oracle_built):
     """20k Gaussians stacked on one spot: a single tile list far beyond the 8192-entry LDS classes of the per-tile
     depth sort (tile_sort_long's global ping-pong), equal depths included; sorted list bit-exact, image within tolerance."""
