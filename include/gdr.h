@@ -211,7 +211,10 @@ int gdr_render_forward(const gdr_settings* s, const gdr_inputs* in, const gdr_ge
 /* The two halves of stage 2, for callers that overlap the binning of one view with the compositing of another on
  * separate streams (binning is latency-bound with few workgroups, compositing is VALU-bound):
  * gdr_binning_forward = K3..K5 + tile order + tile sort (also valid for the surfel geometry of gsr.h),
- * gdr_composite_forward = K6.  gdr_render_forward is exactly one after the other on one stream. */
+ * gdr_composite_forward = K6.  gdr_render_forward is exactly one after the other on one stream.
+ * K6 also (re)fills the cut-list tables of `bin` (seg_extra, seg_count, seg_state, img->seg_base) from zero; every
+ * backward entry point below walks the tables of the LATEST compositing call on that (bin, img) pair, so the
+ * compositing and the backward of one view must not run concurrently with another compositing of the same pair. */
 int gdr_binning_forward(const gdr_settings* s, int32_t N, const gdr_geom* geom, gdr_binning* bin, const gdr_image* img,
                         uint64_t D, const int32_t* radii, void* stream);
 int gdr_composite_forward(const gdr_settings* s, const gdr_geom* geom, const gdr_binning* bin, const gdr_image* img,
