@@ -22,6 +22,9 @@ b c4_perview --per-view --unfused --no-cpu-baseline
 b c4_torchloss --torch-loss --no-cpu-baseline
 b c2_perview --workload c2 --per-view --unfused --no-cpu-baseline
 b c5_perview --workload c5 --per-view --unfused --no-cpu-baseline
+b c4_shell --layout shell --no-cpu-baseline
+b c3_shell --workload c3 --layout shell --no-cpu-baseline
+b c5_shell --workload c5 --layout shell --no-cpu-baseline
 for wl in c4 c2 c5; do
   (cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$wl -o $wl -- python $R/bench.py --workload $wl --steps 3 --warmup 1 --no-cpu-baseline --no-roofline > $O/prof_$wl.log 2>&1)
   f=$(find $O/prof_$wl -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/${TAG}_${wl}_kernel_stats.csv && python scripts/stats_print.py $f 3 8
