@@ -97,8 +97,16 @@ __device__ __forceinline__ void block_masks(const SliceLds& s, int g, float XA, 
 // workgroup).  order[k] = tile id of the k-th workgroup.
 // ---------------------------------------------------------------------------------
 #define GDR_ORDER_BUCKETS 1024
+// Cut-list tables (seg_base != nullptr, seg_len > 0): a tile whose list is longer than seg_len entries is cut every
+// seg_len entries into nseg segments.  seg_base[tile] = its first slot in seg_state (nseg slots),
+// 0xFFFFFFFF for uncut tiles; seg_extra = (tile, segment) of every segment but the last of its tile (K7: the last one
+// is walked by the tile's own workgroup); seg_count = {rows of seg_extra, slots}.  Sum nseg <= 2 D / seg_len: the
+// tables (capacity seg_cap rows, 2 * seg_cap slots) cannot overflow; the guards are belt and braces.
 __global__ __launch_bounds__(GDR_BLOCK) void tile_order_kernel(const uint2* __restrict__ ranges, int ntiles,
-                                                                uint32_t* __restrict__ order) {
+                                                                uint32_t* __restrict__ order, int seg_len,
+                                                                uint32_t* __restrict__ seg_base,
+                                                                uint2* __restrict__ seg_extra,
+                                                                uint32_t* __restrict__ seg_count, int seg_cap) {
     __shared__ uint32_t cnt[GDR_ORDER_BUCKETS];
     __shared__ uint32_t wsum[GDR_BLOCK / GDR_WAVE];
     for (int k = threadIdx.x; k < GDR_ORDER_BUCKETS; k += GDR_BLOCK) cnt[k] = 0;
@@ -131,6 +139,49 @@ __global__ __launch_bounds__(GDR_BLOCK) void tile_order_kernel(const uint2* __re
         const uint32_t b = min((r.y - r.x) >> 4, (uint32_t)GDR_ORDER_BUCKETS - 1u);
         order[atomicAdd(&cnt[GDR_ORDER_BUCKETS - 1 - b], 1u)] = (uint32_t)t;
     }
+    if (seg_base == nullptr) return;
+    if (seg_len <= 0) {
+        if (threadIdx.x < 2) seg_count[threadIdx.x] = 0u;
+        return;
+    }
+    uint32_t slot_run = 0u, cut_run = 0u;  // uniform running totals over the chunks of 256 tiles
+    for (int t0 = 0; t0 < ntiles; t0 += GDR_BLOCK) {
+        const int t = t0 + (int)threadIdx.x;
+        uint32_t nseg = 0u;
+        if (t < ntiles) {
+            const uint2 r = ranges[t];
+            const uint32_t len = r.y - r.x;
+            if (len > (uint32_t)seg_len) nseg = (len + (uint32_t)seg_len - 1u) / (uint32_t)seg_len;
+        }
+        const uint32_t cut = nseg ? 1u : 0u;
+        uint32_t inc = nseg, cinc = cut;  // block-wide inclusive scans of (slots, cut tiles)
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t u = __shfl_up(inc, off, 64), v = __shfl_up(cinc, off, 64);
+            if ((int)lane_id() >= off) { inc += u; cinc += v; }
+        }
+        __syncthreads();  // the previous chunk's / the ordering phase's reads of wsum, cnt are done
+        if (lane_id() == 63) { wsum[threadIdx.x >> 6] = inc; cnt[threadIdx.x >> 6] = cinc; }
+        __syncthreads();
+        uint32_t sbase = inc - nseg, cbase = cinc - cut, stot = 0u, ctot = 0u;
+        for (uint32_t w = 0; w < GDR_BLOCK / GDR_WAVE; ++w) {
+            if (w < (threadIdx.x >> 6)) { sbase += wsum[w]; cbase += cnt[w]; }
+            stot += wsum[w]; ctot += cnt[w];
+        }
+        if (t < ntiles) {
+            const uint32_t slot = slot_run + sbase;             // slots before this tile
+            const uint32_t e0 = slot - (cut_run + cbase);       // rows of seg_extra before it: one less per cut tile
+            const bool fits = nseg && slot + nseg <= 2u * (uint32_t)seg_cap && e0 + nseg - 1u <= (uint32_t)seg_cap;
+            seg_base[t] = fits ? slot : 0xFFFFFFFFu;
+            for (uint32_t k = 0; fits && k + 1u < nseg; ++k) seg_extra[e0 + k] = make_uint2((uint32_t)t, k);
+        }
+        slot_run += stot;
+        cut_run += ctot;
+    }
+    if (threadIdx.x == 0) {
+        seg_count[0] = min(slot_run - cut_run, (uint32_t)seg_cap);
+        seg_count[1] = min(slot_run, 2u * (uint32_t)seg_cap);
+    }
 }
 
 // ---------------------------------------------------------------------------------
@@ -147,145 +198,148 @@ struct FusedLoss {
     const float* color;   // K7: the colour K6 wrote, (3,H,W)
 };
 
+// Cut lists (gdr_binning.seg_len, tables built by tile_order_kernel): a tile list longer than seg_rounds slices is
+// cut every seg_rounds slices; in front of every cut and at the end of the list the kernel saves each pixel's
+// compositing state (T and the colour / depth / alpha sums so far) so that K7 can walk the segments of one tile in
+// parallel workgroups.  The forward itself stays one workgroup per tile: compositing every segment speculatively
+// from T = 1 in parallel workgroups (colour is linear in the incoming transmittance) and walking only the segments
+// in which a pixel saturates was built and measured — it doubles the alpha evaluations of cut lists and lost 4-16 %
+// once two views are in flight and the backward is segmented.
 template <bool LOSS>
 __global__ __launch_bounds__(GDR_BLOCK) void render_fwd_kernel(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const uint32_t* __restrict__ tile_order, int W, int H, int gx, int ntiles,
     const float4* __restrict__ rec, const float* __restrict__ bg, float* __restrict__ final_T,
     uint32_t* __restrict__ n_contrib, float* __restrict__ out_color, float* __restrict__ out_depth,
-    float* __restrict__ out_alpha, const FusedLoss fl, uint32_t* __restrict__ seg_base,
-    float* __restrict__ seg_state, uint2* __restrict__ seg_extra, uint32_t* __restrict__ seg_count, int seg_rounds,
-    int seg_cap) {
+    float* __restrict__ out_alpha, const FusedLoss fl, const uint32_t* __restrict__ seg_base,
+    float* __restrict__ seg_state, int seg_rounds) {
     __shared__ SliceLds lds;
     __shared__ int s_done[GDR_BLOCK / GDR_WAVE];
-    __shared__ uint32_t s_slot;
+
+    const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
+    const uint32_t row = lane >> 4, li = lane & 15u;
+    if (threadIdx.x == 0) {
+        lds.xy[GDR_NULL_ENTRY] = make_float2(0.f, 0.f);
+        lds.co[GDR_NULL_ENTRY] = make_float4(0.f, 0.f, 0.f, 0.f);
+        lds.cd[GDR_NULL_ENTRY] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
 
     const uint32_t tile = tile_order ? tile_order[blockIdx.x] : xcd_remap(blockIdx.x, (uint32_t)ntiles);
     const int tx = (int)(tile % (uint32_t)gx), ty = (int)(tile / (uint32_t)gx);
-    const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
-    const uint32_t row = lane >> 4, li = lane & 15u;
     const int sx0 = tx * GDR_TILE + (int)(wave & 1u) * 8, sy0 = ty * GDR_TILE + (int)(wave >> 1) * 8;
     const int px = sx0 + (int)(row & 1u) * 4 + (int)(li & 3u), py = sy0 + (int)(row >> 1) * 4 + (int)(li >> 2);
     const bool inside = px < W && py < H;
     const float pxf = (float)px, pyf = (float)py;
     const float XA = (float)sx0, YA = (float)sy0;  // block k: x in [XA+4(k&1), +3], y in [YA+4(k>>1), +3]
     const uint2 range = ranges[tile];
-    const int total = (int)(range.y - range.x);
-    const int rounds = (total + GDR_BLOCK - 1) / GDR_BLOCK;
-    // A list longer than seg_rounds slices is CUT every seg_rounds slices into nseg segments so that K7 can walk
-    // the segments in parallel workgroups: the compositing state of every pixel is saved at each cut and at the end
-    // of the list (nseg state slots, handed out here), and every segment but the last is entered into seg_extra
-    // (the last one is walked by the tile's own K7 workgroup).
-    uint32_t sb = 0xFFFFFFFFu;
-    if (seg_rounds > 0 && rounds > seg_rounds) {
-        if (threadIdx.x == 0) {
-            const uint32_t nseg = (uint32_t)((rounds + seg_rounds - 1) / seg_rounds);
-            const uint32_t slot = atomicAdd(&seg_count[1], nseg);
-            const uint32_t e0 = atomicAdd(&seg_count[0], nseg - 1u);
-            const bool fits = slot + nseg <= 2u * (uint32_t)seg_cap && e0 + nseg - 1u <= (uint32_t)seg_cap;
-            seg_base[tile] = fits ? slot : 0xFFFFFFFFu;  // (cannot overflow: see carve_binning; checked anyway)
-            for (uint32_t k = 0; fits && k + 1u < nseg; ++k) seg_extra[e0 + k] = make_uint2(tile, k);
-            s_slot = fits ? slot : 0xFFFFFFFFu;
-        }
-        __syncthreads();
-        sb = s_slot;
-    }
+    const int full_total = (int)(range.y - range.x);
+    const int full_rounds = (full_total + GDR_BLOCK - 1) / GDR_BLOCK;
+    const uint32_t sb = (seg_rounds > 0 && full_rounds > seg_rounds) ? seg_base[tile] : 0xFFFFFFFFu;
+    const bool cut = sb != 0xFFFFFFFFu;
+    const int seg_len = seg_rounds * GDR_BLOCK;
+    const int nseg = cut ? (full_rounds + seg_rounds - 1) / seg_rounds : 1;
 
-    if (threadIdx.x == 0) {
-        lds.xy[GDR_NULL_ENTRY] = make_float2(0.f, 0.f);
-        lds.co[GDR_NULL_ENTRY] = make_float4(0.f, 0.f, 0.f, 0.f);
-        lds.cd[GDR_NULL_ENTRY] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
     // a pixel contributes while alpha >= thr; thr = +inf once it is saturated ("done") or outside
     float thr = inside ? GDR_ALPHA_MIN : INFINITY;
     float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f, Wt = 0.f;
     uint32_t last_contributor = 0;
 
-    float4 r_xe = make_float4(0.f, 0.f, 0.f, 0.f), r_co = r_xe, r_cd = r_xe;
-    bool r_valid = (int)threadIdx.x < total;
-    if (r_valid) {
-        const uint32_t id = point_list[range.x + threadIdx.x];
-        { const float4 a0 = rec[4 * (size_t)id], a3 = rec[4 * (size_t)id + 3];
-          r_xe = make_float4(a0.x, a0.y, a3.x, a3.y); r_co = rec[4 * (size_t)id + 1]; r_cd = rec[4 * (size_t)id + 2]; }
-    }
-    for (int r = 0; r < rounds; ++r) {
-        uint64_t live = __ballot(thr < INFINITY);
-        if (lane == 0) s_done[wave] = live == 0ull ? 1 : 0;
-        __syncthreads();
-        if (s_done[0] + s_done[1] + s_done[2] + s_done[3] == GDR_BLOCK / GDR_WAVE) break;
-        if (sb != 0xFFFFFFFFu && r > 0 && r % seg_rounds == 0) {  // cut in front of list position r * 256
-            float* st = seg_state + ((size_t)sb + (size_t)(r / seg_rounds - 1)) * GDR_SEG_STATE_FLOATS + threadIdx.x;
+    // composites list positions [pos0, pos0 + count) of the tile; returns true once every pixel of the tile is done
+    auto walk = [&](int pos0, int count) __attribute__((always_inline)) -> bool {
+        const uint32_t first = range.x + (uint32_t)pos0;
+        const int rounds = (count + GDR_BLOCK - 1) / GDR_BLOCK;
+        float4 r_xe = make_float4(0.f, 0.f, 0.f, 0.f), r_co = r_xe, r_cd = r_xe;
+        bool r_valid = (int)threadIdx.x < count;
+        if (r_valid) {
+            const uint32_t id = point_list[first + threadIdx.x];
+            const float4 a0 = rec[4 * (size_t)id], a3 = rec[4 * (size_t)id + 3];
+            r_xe = make_float4(a0.x, a0.y, a3.x, a3.y); r_co = rec[4 * (size_t)id + 1]; r_cd = rec[4 * (size_t)id + 2];
+        }
+        for (int r = 0; r < rounds; ++r) {
+            uint64_t live = __ballot(thr < INFINITY);
+            if (lane == 0) s_done[wave] = live == 0ull ? 1 : 0;
+            __syncthreads();
+            if (s_done[0] + s_done[1] + s_done[2] + s_done[3] == GDR_BLOCK / GDR_WAVE) return true;
+            stage_write(lds, r_valid, r_xe, r_co, r_cd);
+            __syncthreads();
+            {   // prefetch the next slice (lands while this one is composited)
+                const int nxt = (r + 1) * GDR_BLOCK + (int)threadIdx.x;
+                r_valid = nxt < count;
+                if (r_valid) {
+                    const uint32_t id = point_list[first + (uint32_t)nxt];
+                    const float4 a0 = rec[4 * (size_t)id], a3 = rec[4 * (size_t)id + 3];
+                    r_xe = make_float4(a0.x, a0.y, a3.x, a3.y); r_co = rec[4 * (size_t)id + 1]; r_cd = rec[4 * (size_t)id + 2];
+                }
+            }
+            if (live == 0ull) continue;
+            const uint32_t base = (uint32_t)(pos0 + r * GDR_BLOCK) + 1u;
+#pragma unroll 1
+            for (int g = 0; g < GDR_BLOCK / GDR_WAVE; ++g) {
+                uint64_t m0, m1, m2, m3;
+                block_masks(lds, g, XA, YA, (live & GDR_ROW_MASK(0)) != 0ull, (live & GDR_ROW_MASK(1)) != 0ull,
+                            (live & GDR_ROW_MASK(2)) != 0ull, (live & GDR_ROW_MASK(3)) != 0ull, m0, m1, m2, m3);
+                if ((m0 | m1 | m2 | m3) == 0ull) continue;
+                const uint32_t goff = (uint32_t)(g * GDR_WAVE), nulloff = GDR_NULL_ENTRY - goff;
+                // software pipeline, unrolled by two (ping-pong registers instead of copies): entry A is
+                // composited while B's LDS reads are in flight, and vice versa
+                uint64_t mr = row_select(row, m0, m1, m2, m3);
+                bool abort = false;
+                auto fetch = [&](Entry& en) {
+                    en.e = min(take_bit(mr), nulloff) + goff;  // 0xFFFFFFFF (no entry) -> null entry
+                    en.m = lds.xy[en.e]; en.co = lds.co[en.e]; en.cd = lds.cd[en.e];
+                };
+                auto composite = [&](const Entry& en) {
+                    const float dx = en.m.x - pxf, dy = en.m.y - pyf;
+                    const float p2 = gauss_power(dx, dy, en.co.x, en.co.y, en.co.z);
+                    float alpha = fminf(0.99f, en.co.w * __builtin_amdgcn_exp2f(p2));
+                    alpha = (p2 > 0.f) ? 0.f : alpha;        // reference skips power > 0
+                    const float a_c = (alpha >= thr) ? alpha : 0.f;
+                    const float T_new = fmaf(-a_c, T, T);     // T (1 - alpha); == T when a_c == 0
+                    const bool stop = T_new < 0.0001f;        // only possible when a_c > 0 (T >= 1e-4 while live)
+                    const float w = stop ? 0.f : a_c * T;
+                    T = stop ? T : T_new;
+                    thr = stop ? INFINITY : thr;
+                    C0 = fmaf(en.cd.x, w, C0);
+                    C1 = fmaf(en.cd.y, w, C1);
+                    C2 = fmaf(en.cd.z, w, C2);
+                    Dp = fmaf(en.cd.w, w, Dp);
+                    Wt += w;
+                    last_contributor = (w > 0.f) ? base + en.e : last_contributor;
+                    if (__ballot(stop) != 0ull) {  // rare: some pixel saturated -> retire finished blocks
+                        live = __ballot(thr < INFINITY);
+                        if (((live >> (16 * row)) & 0xFFFFull) == 0ull) mr = 0ull;
+                        if (live == 0ull) abort = true;
+                    }
+                };
+                Entry A, B;
+                fetch(A);
+                for (;;) {
+                    const bool moreA = __ballot(mr != 0ull) != 0ull;
+                    fetch(B);
+                    composite(A);
+                    if (!moreA || abort) break;
+                    const bool moreB = __ballot(mr != 0ull) != 0ull;
+                    fetch(A);
+                    composite(B);
+                    if (!moreB || abort) break;
+                }
+                if (abort) g = GDR_BLOCK / GDR_WAVE;
+            }
+        }
+        return false;
+    };
+
+    for (int sg = 0; sg < nseg; ++sg) {
+        const int pos0 = sg * seg_len;  // (uncut list: one "segment" = the whole list, seg_len unused)
+        const int count = cut ? min(seg_len, full_total - pos0) : full_total;
+        if (cut && sg > 0) {  // cut in front of list position pos0: the state K7 starts the earlier segments from
+            float* st = seg_state + ((size_t)sb + (size_t)(sg - 1)) * GDR_SEG_STATE_FLOATS + threadIdx.x;
             st[0] = T; st[GDR_BLOCK] = C0; st[2 * GDR_BLOCK] = C1; st[3 * GDR_BLOCK] = C2;
             st[4 * GDR_BLOCK] = Dp; st[5 * GDR_BLOCK] = Wt;
         }
-        stage_write(lds, r_valid, r_xe, r_co, r_cd);
-        __syncthreads();
-        {   // prefetch the next slice (lands while this one is composited)
-            const int nxt = (r + 1) * GDR_BLOCK + (int)threadIdx.x;
-            r_valid = nxt < total;
-            if (r_valid) {
-                const uint32_t id = point_list[range.x + nxt];
-                { const float4 a0 = rec[4 * (size_t)id], a3 = rec[4 * (size_t)id + 3];
-          r_xe = make_float4(a0.x, a0.y, a3.x, a3.y); r_co = rec[4 * (size_t)id + 1]; r_cd = rec[4 * (size_t)id + 2]; }
-            }
-        }
-        if (live == 0ull) continue;
-        const uint32_t base = (uint32_t)(r * GDR_BLOCK) + 1u;
-#pragma unroll 1
-        for (int g = 0; g < GDR_BLOCK / GDR_WAVE; ++g) {
-            uint64_t m0, m1, m2, m3;
-            block_masks(lds, g, XA, YA, (live & GDR_ROW_MASK(0)) != 0ull, (live & GDR_ROW_MASK(1)) != 0ull,
-                        (live & GDR_ROW_MASK(2)) != 0ull, (live & GDR_ROW_MASK(3)) != 0ull, m0, m1, m2, m3);
-            if ((m0 | m1 | m2 | m3) == 0ull) continue;
-            const uint32_t goff = (uint32_t)(g * GDR_WAVE), nulloff = GDR_NULL_ENTRY - goff;
-            // software pipeline, unrolled by two (ping-pong registers instead of copies): entry A is
-            // composited while B's LDS reads are in flight, and vice versa
-            uint64_t mr = row_select(row, m0, m1, m2, m3);
-            bool abort = false;
-            auto fetch = [&](Entry& en) {
-                en.e = min(take_bit(mr), nulloff) + goff;  // 0xFFFFFFFF (no entry) -> null entry
-                en.m = lds.xy[en.e]; en.co = lds.co[en.e]; en.cd = lds.cd[en.e];
-            };
-            auto composite = [&](const Entry& en) {
-                const float dx = en.m.x - pxf, dy = en.m.y - pyf;
-                const float p2 = gauss_power(dx, dy, en.co.x, en.co.y, en.co.z);
-                float alpha = fminf(0.99f, en.co.w * __builtin_amdgcn_exp2f(p2));
-                alpha = (p2 > 0.f) ? 0.f : alpha;        // reference skips power > 0
-                const float a_c = (alpha >= thr) ? alpha : 0.f;
-                const float T_new = fmaf(-a_c, T, T);     // T (1 - alpha); == T when a_c == 0
-                const bool stop = T_new < 0.0001f;        // only possible when a_c > 0 (T >= 1e-4 while live)
-                const float w = stop ? 0.f : a_c * T;
-                T = stop ? T : T_new;
-                thr = stop ? INFINITY : thr;
-                C0 = fmaf(en.cd.x, w, C0);
-                C1 = fmaf(en.cd.y, w, C1);
-                C2 = fmaf(en.cd.z, w, C2);
-                Dp = fmaf(en.cd.w, w, Dp);
-                Wt += w;
-                last_contributor = (w > 0.f) ? base + en.e : last_contributor;
-                if (__ballot(stop) != 0ull) {  // rare: some pixel saturated -> retire finished blocks
-                    live = __ballot(thr < INFINITY);
-                    if (((live >> (16 * row)) & 0xFFFFull) == 0ull) mr = 0ull;
-                    if (live == 0ull) abort = true;
-                }
-            };
-            Entry A, B;
-            fetch(A);
-            for (;;) {
-                const bool moreA = __ballot(mr != 0ull) != 0ull;
-                fetch(B);
-                composite(A);
-                if (!moreA || abort) break;
-                const bool moreB = __ballot(mr != 0ull) != 0ull;
-                fetch(A);
-                composite(B);
-                if (!moreB || abort) break;
-            }
-            if (abort) g = GDR_BLOCK / GDR_WAVE;
-        }
+        if (walk(pos0, count)) break;
     }
-    if (sb != 0xFFFFFFFFu) {  // totals of the cut list (K7 forms "everything behind a cut" = totals - prefix)
-        const int nseg = (rounds + seg_rounds - 1) / seg_rounds;
+    if (cut) {  // totals of the cut list (K7 forms "everything behind a cut" = totals - prefix)
         float* st = seg_state + ((size_t)sb + (size_t)(nseg - 1)) * GDR_SEG_STATE_FLOATS + threadIdx.x;
         st[0] = T; st[GDR_BLOCK] = C0; st[2 * GDR_BLOCK] = C1; st[3 * GDR_BLOCK] = C2;
         st[4 * GDR_BLOCK] = Dp; st[5 * GDR_BLOCK] = Wt;
@@ -554,8 +608,8 @@ __global__ __launch_bounds__(GDR_BLOCK) void render_bwd_kernel(
 
 hipError_t launch_tile_order(const gdr_image* img, const gdr_binning* bin, int ntiles, hipStream_t st) {
     GDR_LAUNCH(GDR_K_TILE_ORDER, tile_order_kernel, dim3(1), dim3(GDR_BLOCK), st, (const uint2*)img->ranges,
-               ntiles, img->tile_order);
-    (void)bin;
+               ntiles, img->tile_order, bin->seg_len, img->seg_base, (uint2*)bin->seg_extra, bin->seg_count,
+               bin->seg_cap);
     return hipGetLastError();
 }
 
@@ -563,8 +617,7 @@ hipError_t launch_tile_order(const gdr_image* img, const gdr_binning* bin, int n
 static inline int seg_rounds_of(const gdr_binning* bin, const gdr_image* img) {
     return (img->seg_base && bin->seg_len > 0) ? bin->seg_len / GDR_BLOCK : 0;
 }
-#define GDR_SEG_FWD_ARGS(bin, img) \
-    (img)->seg_base, (bin)->seg_state, (uint2*)(bin)->seg_extra, (bin)->seg_count, seg_rounds_of(bin, img), (bin)->seg_cap
+#define GDR_SEG_FWD_ARGS(bin, img) (img)->seg_base, (bin)->seg_state, seg_rounds_of(bin, img)
 #define GDR_SEG_BWD_ARGS(bin, img)                                                                          \
     (img)->seg_base, (const float*)(bin)->seg_state, (const uint2*)(bin)->seg_extra, (bin)->seg_count,     \
         seg_rounds_of(bin, img), (seg_rounds_of(bin, img) ? (bin)->seg_cap : 0)
@@ -575,10 +628,6 @@ hipError_t launch_render_fwd(const gdr_settings* s, const gdr_geom* g, const gdr
     const int W = s->image_width, H = s->image_height;
     const int gx = tile_grid_x(W), gy = tile_grid_y(H);
     const int ntiles = gx * gy;
-    if (seg_rounds_of(bin, img)) {  // K6 hands out the cut-list rows / state slots from zero
-        const hipError_t e = hipMemsetAsync(bin->seg_count, 0, 2 * sizeof(uint32_t), st);
-        if (e != hipSuccess) return e;
-    }
     GDR_LAUNCH(GDR_K_RENDER_FWD, render_fwd_kernel<false>, dim3(ntiles), dim3(GDR_BLOCK), st,
                (const uint2*)img->ranges, bin->values[bin->sorted], img->tile_order, W, H, gx, ntiles,
                (const float4*)g->rec, s->bg, img->final_T, img->n_contrib, out->color, out->depth, out->alpha,
@@ -593,10 +642,6 @@ hipError_t launch_render_fwd_loss(const gdr_settings* s, const gdr_geom* g, cons
     const int gx = tile_grid_x(W), gy = tile_grid_y(H);
     const int ntiles = gx * gy;
     const FusedLoss fl{target, w_depth, w_alpha, loss, nullptr, nullptr};
-    if (seg_rounds_of(bin, img)) {
-        const hipError_t e = hipMemsetAsync(bin->seg_count, 0, 2 * sizeof(uint32_t), st);
-        if (e != hipSuccess) return e;
-    }
     GDR_LAUNCH(GDR_K_RENDER_FWD, render_fwd_kernel<true>, dim3(ntiles), dim3(GDR_BLOCK), st,
                (const uint2*)img->ranges, bin->values[bin->sorted], img->tile_order, W, H, gx, ntiles,
                (const float4*)g->rec, s->bg, img->final_T, img->n_contrib, out->color, out->depth, out->alpha, fl,

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define GDR_ABI_VERSION 7
+#define GDR_ABI_VERSION 8
 
 #define GDR_OK 0
 #define GDR_ERR_INVALID_ARG (-1)  /* NULL / inconsistent arguments                     */
@@ -132,8 +132,9 @@ typedef struct gdr_binning {
      * a tile whose sorted list is longer than seg_len entries is cut every seg_len entries;
      * K6 saves the per-pixel compositing state at every cut and at the end of the list. */
     uint32_t* seg_extra; /* (seg_cap,2) (tile, segment) of every segment but the last of its tile */
-    uint32_t* seg_count; /* (2) rows of seg_extra in use, state slots in use (filled by K6)       */
-    float* seg_state;    /* (2*seg_cap, 6, 256) T, colour x3, depth, alpha sums per pixel of the tile */
+    uint32_t* seg_count; /* (2) rows of seg_extra, state slots                                    */
+    float* seg_state;    /* (2*seg_cap, 6, 256) K6 -> K7: T, colour x3, depth, alpha sums per pixel of
+                          * the tile in front of each cut, and at the end of the list              */
     int32_t seg_len;     /* entries per segment (multiple of 256); 0 = lists are never cut          */
     int32_t seg_cap;     /* D / seg_len + 1                                                         */
 } gdr_binning;
@@ -144,8 +145,8 @@ typedef struct gdr_image {
     uint32_t* n_contrib; /* (H*W) 1-based index of the last contributor     */
     float* final_T;      /* (H*W) transmittance after the last contributor  */
     uint32_t* tile_order; /* (tiles) tile ids, longest sorted list first (launch order of K6/K7) */
-    uint32_t* seg_base;   /* (tiles) first seg_state slot of a tile whose list K6 cut (valid for those tiles only);
-                           * NULL (surfel image state): lists are never cut */
+    uint32_t* seg_base;   /* (tiles) first seg_state slot of a tile whose list is cut, 0xFFFFFFFF
+                           * otherwise; NULL (surfel image state): lists are never cut */
 } gdr_image;
 
 typedef struct gdr_outputs {
@@ -212,9 +213,8 @@ int gdr_render_forward(const gdr_settings* s, const gdr_inputs* in, const gdr_ge
  * separate streams (binning is latency-bound with few workgroups, compositing is VALU-bound):
  * gdr_binning_forward = K3..K5 + tile order + tile sort (also valid for the surfel geometry of gsr.h),
  * gdr_composite_forward = K6.  gdr_render_forward is exactly one after the other on one stream.
- * K6 also (re)fills the cut-list tables of `bin` (seg_extra, seg_count, seg_state, img->seg_base) from zero; every
- * backward entry point below walks the tables of the LATEST compositing call on that (bin, img) pair, so the
- * compositing and the backward of one view must not run concurrently with another compositing of the same pair. */
+ * The binning stage builds the cut-list tables of `bin` (seg_extra, seg_count, img->seg_base); K6 fills seg_state
+ * and every backward entry point below reads the seg_state of the LATEST compositing call on that (bin, img) pair. */
 int gdr_binning_forward(const gdr_settings* s, int32_t N, const gdr_geom* geom, gdr_binning* bin, const gdr_image* img,
                         uint64_t D, const int32_t* radii, void* stream);
 int gdr_composite_forward(const gdr_settings* s, const gdr_geom* geom, const gdr_binning* bin, const gdr_image* img,

@@ -537,6 +537,8 @@ def test_cut_tile_lists_give_the_gradients_of_the_uncut_walk(oracle_built):
     finally:
         R.SEG_LEN = None
     (h0, g0) = res[0]
+    if res[2048][0]["seg_len"] == 0:
+        pytest.skip("cut lists disabled in this process (GDR_SEG_LEN=0)")
     lens = (h0["ranges"][:, 1].astype(np.int64) - h0["ranges"][:, 0]).clip(min=0)
     assert lens.max() > 3 * 2048
     for sl in (2048, 4096):
@@ -545,7 +547,7 @@ def test_cut_tile_lists_give_the_gradients_of_the_uncut_walk(oracle_built):
         nseg = np.where(lens > sl, -(-lens // sl), 0)
         assert int(h["seg_count"][0]) == int((nseg - (nseg > 0)).sum())   # rows: every segment but the last of its tile
         assert int(h["seg_count"][1]) == int(nseg.sum())                   # slots: cuts + end of list
-        for k in ("color", "depth", "alpha", "n_contrib", "final_T"):
+        for k in ("color", "depth", "alpha", "n_contrib", "final_T"):   # the forward walk itself is unchanged by the cuts
             np.testing.assert_array_equal(h[k], h0[k])
         for k in ("means3D", "means2D", "shs", "opacities", "scales", "rotations"):
             assert U.rel_inf(g[k], g0[k]) < 2e-5, (sl, k, U.rel_inf(g[k], g0[k]))
