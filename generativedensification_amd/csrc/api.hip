@@ -548,7 +548,7 @@ static size_t carve_surfel_image(void* base, int H, int W, gdr_image* im) {
     t.n_contrib = c.take<uint32_t>(2 * (P ? P : 1));
     t.final_T = c.take<float>(3 * (P ? P : 1));
     t.tile_order = c.take<uint32_t>(tiles ? tiles : 1);
-    t.seg_base = nullptr;  // the surfel kernels do not cut tile lists
+    t.seg_base = c.take<uint32_t>(tiles ? tiles : 1);
     if (im) *im = t;
     return c.off;
 }

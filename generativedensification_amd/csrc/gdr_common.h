@@ -88,8 +88,9 @@ hipError_t launch_duplicate(const gdr_geom* g, int N, int W, int H, const int32_
 hipError_t launch_sort(gdr_binning* bin, uint64_t D, int nbits, hipStream_t st);
 hipError_t launch_ranges(const gdr_binning* bin, uint64_t D, const gdr_image* img, int tiles,
                          hipStream_t st);
-// per-pixel compositing state saved at a cut of a long tile list: T, colour x3, depth, alpha sums, 256 pixels each
-#define GDR_SEG_STATE_FLOATS (6 * GDR_BLOCK)
+// per-pixel compositing state saved at a cut of a long tile list, 256 pixels each: 3DGS T, colour x3, depth, alpha
+// sums (6 used); surfels T, colour x3, normal x3, depth, M1, M2 (10)
+#define GDR_SEG_STATE_FLOATS (10 * GDR_BLOCK)
 hipError_t launch_tile_order(const gdr_image* img, const gdr_binning* bin, int tiles, hipStream_t st);
 hipError_t launch_render_fwd(const gdr_settings* s, const gdr_geom* g, const gdr_binning* bin,
                              const gdr_image* img, const gdr_outputs* out, hipStream_t st);

@@ -613,15 +613,6 @@ hipError_t launch_tile_order(const gdr_image* img, const gdr_binning* bin, int n
     return hipGetLastError();
 }
 
-// segments of cut tile lists (see tile_order_kernel): arguments shared by the K6 / K7 launches
-static inline int seg_rounds_of(const gdr_binning* bin, const gdr_image* img) {
-    return (img->seg_base && bin->seg_len > 0) ? bin->seg_len / GDR_BLOCK : 0;
-}
-#define GDR_SEG_FWD_ARGS(bin, img) (img)->seg_base, (bin)->seg_state, seg_rounds_of(bin, img)
-#define GDR_SEG_BWD_ARGS(bin, img)                                                                          \
-    (img)->seg_base, (const float*)(bin)->seg_state, (const uint2*)(bin)->seg_extra, (bin)->seg_count,     \
-        seg_rounds_of(bin, img), (seg_rounds_of(bin, img) ? (bin)->seg_cap : 0)
-#define GDR_BWD_GRID(bin, img, ntiles) dim3((unsigned)((ntiles) + (seg_rounds_of(bin, img) ? (bin)->seg_cap : 0)))
 
 hipError_t launch_render_fwd(const gdr_settings* s, const gdr_geom* g, const gdr_binning* bin,
                              const gdr_image* img, const gdr_outputs* out, hipStream_t st) {

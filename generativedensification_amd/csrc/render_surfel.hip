@@ -105,7 +105,8 @@ __global__ __launch_bounds__(GDR_BLOCK) void surfel_render_fwd_kernel(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, const uint32_t* __restrict__ tile_order,
     int W, int H, int gx, int ntiles, const float4* __restrict__ rec, const float* __restrict__ bg,
     float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float* __restrict__ out_color,
-    float* __restrict__ out_others) {
+    float* __restrict__ out_others, const uint32_t* __restrict__ seg_base, float* __restrict__ seg_state,
+    int seg_rounds) {
     __shared__ SurfelLds lds;
     __shared__ int s_done[GDR_BLOCK / GDR_WAVE];
 
@@ -121,6 +122,10 @@ __global__ __launch_bounds__(GDR_BLOCK) void surfel_render_fwd_kernel(
     const uint2 range = ranges[tile];
     const int total = (int)(range.y - range.x);
     const int rounds = (total + GDR_BLOCK - 1) / GDR_BLOCK;
+
+    // cut list (render.hip, tile_order_kernel): the compositing state of every pixel is saved in front of each cut and
+    // at the end of the list for K7s
+    const uint32_t sb = (seg_rounds > 0 && rounds > seg_rounds) ? seg_base[tile] : 0xFFFFFFFFu;
 
     if (threadIdx.x == 0) null_entry(lds);
     // The distortion sum_i w_i (m_i^2 A_i + M2_i - 2 m_i M1_i) = sum_{j<i} w_i w_j (m_i - m_j)^2 only depends on
@@ -142,6 +147,12 @@ __global__ __launch_bounds__(GDR_BLOCK) void surfel_render_fwd_kernel(
         if (lane == 0) s_done[wave] = live == 0ull ? 1 : 0;
         __syncthreads();
         if (s_done[0] + s_done[1] + s_done[2] + s_done[3] == GDR_BLOCK / GDR_WAVE) break;
+        if (sb != 0xFFFFFFFFu && r > 0 && r % seg_rounds == 0) {  // cut in front of list position r * 256
+            float* st = seg_state + ((size_t)sb + (size_t)(r / seg_rounds - 1)) * GDR_SEG_STATE_FLOATS + threadIdx.x;
+            st[0] = T; st[GDR_BLOCK] = C0; st[2 * GDR_BLOCK] = C1; st[3 * GDR_BLOCK] = C2;
+            st[4 * GDR_BLOCK] = N0; st[5 * GDR_BLOCK] = N1; st[6 * GDR_BLOCK] = N2;
+            st[7 * GDR_BLOCK] = Dp; st[8 * GDR_BLOCK] = M1; st[9 * GDR_BLOCK] = M2;
+        }
         GSR_STAGE(r_valid);
         __syncthreads();
         {
@@ -210,6 +221,13 @@ __global__ __launch_bounds__(GDR_BLOCK) void surfel_render_fwd_kernel(
             if (abort) g = GDR_BLOCK / GDR_WAVE;
         }
     }
+    if (sb != 0xFFFFFFFFu) {  // totals of the cut list
+        const int nseg = (rounds + seg_rounds - 1) / seg_rounds;
+        float* st = seg_state + ((size_t)sb + (size_t)(nseg - 1)) * GDR_SEG_STATE_FLOATS + threadIdx.x;
+        st[0] = T; st[GDR_BLOCK] = C0; st[2 * GDR_BLOCK] = C1; st[3 * GDR_BLOCK] = C2;
+        st[4 * GDR_BLOCK] = N0; st[5 * GDR_BLOCK] = N1; st[6 * GDR_BLOCK] = N2;
+        st[7 * GDR_BLOCK] = Dp; st[8 * GDR_BLOCK] = M1; st[9 * GDR_BLOCK] = M2;
+    }
     if (inside) {
         const size_t pix = (size_t)py * W + px, P = (size_t)H * W;
         final_T[pix] = T; final_T[P + pix] = M1; final_T[2 * P + pix] = M2;
@@ -232,11 +250,25 @@ __global__ __launch_bounds__(GDR_BLOCK) void surfel_render_bwd_kernel(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, const uint32_t* __restrict__ tile_order,
     int W, int H, int gx, int ntiles, const float* __restrict__ bg, const float4* __restrict__ rec,
     const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
-    const float* __restrict__ dL_dothers, float* __restrict__ grad_rec) {
+    const float* __restrict__ dL_dothers, float* __restrict__ grad_rec, const uint32_t* __restrict__ seg_base,
+    const float* __restrict__ seg_state, const uint2* __restrict__ seg_extra, const uint32_t* __restrict__ seg_count,
+    int seg_rounds, int n_extra) {
     __shared__ SurfelLds lds;
     __shared__ uint32_t s_id[GDR_BLOCK + 1];
 
-    const uint32_t tile = tile_order ? tile_order[blockIdx.x] : xcd_remap(blockIdx.x, (uint32_t)ntiles);
+    // workgroups [0, n_extra): one segment of a cut list each; [n_extra, n_extra + ntiles): one tile each — its whole
+    // list, or the last segment of a cut list (same scheme as render_bwd_kernel in render.hip)
+    uint32_t tile;
+    int seg = -1;
+    if ((int)blockIdx.x < n_extra) {
+        if (blockIdx.x >= min(seg_count[0], (uint32_t)n_extra)) return;
+        const uint2 e = seg_extra[blockIdx.x];
+        tile = e.x;
+        seg = (int)e.y;
+    } else {
+        const uint32_t b = blockIdx.x - (uint32_t)n_extra;
+        tile = tile_order ? tile_order[b] : xcd_remap(b, (uint32_t)ntiles);
+    }
     const int tx = (int)(tile % (uint32_t)gx), ty = (int)(tile / (uint32_t)gx);
     const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
     const uint32_t row = lane >> 4, li = lane & 15u;
@@ -247,18 +279,33 @@ __global__ __launch_bounds__(GDR_BLOCK) void surfel_render_bwd_kernel(
     const float XA = (float)sx0, YA = (float)sy0;
     const size_t pix = (size_t)py * W + px, P = (size_t)H * W;
     const uint2 range = ranges[tile];
-    const int total = (int)(range.y - range.x);
+    // this workgroup walks list positions [seg_lo, seg_hi) of the tile, back to front
+    const int full_total = (int)(range.y - range.x);
+    int seg_lo = 0, seg_hi = full_total, nseg = 1;
+    if (seg_rounds > 0 && full_total > seg_rounds * GDR_BLOCK && seg_base[tile] != 0xFFFFFFFFu) {
+        const int seg_len = seg_rounds * GDR_BLOCK;
+        nseg = (full_total + seg_len - 1) / seg_len;
+        if (seg < 0) seg = nseg - 1;
+        seg_lo = seg * seg_len;
+        seg_hi = min(full_total, seg_lo + seg_len);
+    }
+    const int total = seg_hi - seg_lo;
+    const uint32_t list_end = range.x + (uint32_t)seg_hi;
     const int rounds = (total + GDR_BLOCK - 1) / GDR_BLOCK;
 
     if (threadIdx.x == 0) { null_entry(lds); s_id[GDR_NULL_ENTRY] = 0; }
     // reference depth of the shifted normalised depth m' (see K6s): the tile's FIRST list entry
-    const float r_ref = total > 0 ? __builtin_amdgcn_rcpf(fmaxf(rec[6 * (size_t)point_list[range.x] + 2].z, GSR_NEAR)) : 1.f;
+    const float r_ref = full_total > 0 ? __builtin_amdgcn_rcpf(fmaxf(rec[6 * (size_t)point_list[range.x] + 2].z, GSR_NEAR)) : 1.f;
     const float T_final = inside ? final_T[pix] : 0.f;
     const float final_D = inside ? final_T[P + pix] : 0.f, final_D2 = inside ? final_T[2 * P + pix] : 0.f;
     const float final_A = 1.f - T_final;
     float T = T_final;
-    const int last_contributor = inside ? (int)n_contrib[pix] : 0;
-    const int med_contributor = inside ? (int)n_contrib[P + pix] : 0;
+    const int lc_full = inside ? (int)n_contrib[pix] : 0;
+    // positions are counted from seg_lo below; a pixel whose last contributor lies behind this segment starts from
+    // the state K6s saved at the cut
+    const bool from_cut = lc_full > seg_hi;
+    const int last_contributor = from_cut ? total : max(lc_full - seg_lo, 0);
+    const int med_contributor = (inside ? (int)n_contrib[P + pix] : 0) - seg_lo;
     float gC0 = 0.f, gC1 = 0.f, gC2 = 0.f, gDepth = 0.f, gAlpha = 0.f, gN0 = 0.f, gN1 = 0.f, gN2 = 0.f, gMed = 0.f, gReg = 0.f;
     // a pixel without contributors reads no upstream gradient: the adaptor's torch ops hand NaN (0/0) to the depth
     // and alpha channels of empty pixels (renderer_2dgs.py:253-254 backward), which must not leak into a row reduction
@@ -272,6 +319,24 @@ __global__ __launch_bounds__(GDR_BLOCK) void surfel_render_bwd_kernel(
     }
     const float bgT = -T_final * ((bg[0] * gC0 + bg[1] * gC1) + bg[2] * gC2);
     float B0 = 0.f, B1 = 0.f, B2 = 0.f, BD = 0.f, BA = 0.f, BN0 = 0.f, BN1 = 0.f, BN2 = 0.f, BW = 0.f;
+    if (from_cut) {  // T in front of position seg_hi; every "behind" state = (total - prefix at the cut) / T
+        const float* cu = seg_state + ((size_t)seg_base[tile] + (size_t)seg) * GDR_SEG_STATE_FLOATS + threadIdx.x;
+        const float* to = seg_state + ((size_t)seg_base[tile] + (size_t)(nseg - 1)) * GDR_SEG_STATE_FLOATS + threadIdx.x;
+        T = cu[0];
+        const float rT = 1.f / T;
+        B0 = (to[GDR_BLOCK] - cu[GDR_BLOCK]) * rT;
+        B1 = (to[2 * GDR_BLOCK] - cu[2 * GDR_BLOCK]) * rT;
+        B2 = (to[3 * GDR_BLOCK] - cu[3 * GDR_BLOCK]) * rT;
+        BN0 = (to[4 * GDR_BLOCK] - cu[4 * GDR_BLOCK]) * rT;
+        BN1 = (to[5 * GDR_BLOCK] - cu[5 * GDR_BLOCK]) * rT;
+        BN2 = (to[6 * GDR_BLOCK] - cu[6 * GDR_BLOCK]) * rT;
+        BD = (to[7 * GDR_BLOCK] - cu[7 * GDR_BLOCK]) * rT;
+        const float dWs = T - T_final;                                  // alpha weight behind the cut
+        BA = dWs * rT;
+        // distortion weights dLw_j = (m_j^2 A + D2 - 2 m_j D) gReg summed with w_j over the entries behind the cut
+        const float dM1 = to[8 * GDR_BLOCK] - cu[8 * GDR_BLOCK], dM2 = to[9 * GDR_BLOCK] - cu[9 * GDR_BLOCK];
+        BW = (fmaf(final_A, dM2, final_D2 * dWs) - 2.f * final_D * dM1) * gReg * rT;
+    }
 
     int row_last = last_contributor;
     row_last = max(row_last, __shfl_xor(row_last, 1, 64));
@@ -285,7 +350,7 @@ __global__ __launch_bounds__(GDR_BLOCK) void surfel_render_bwd_kernel(
     float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0, q2 = q0, q3 = q0, q4 = q0, q5 = q0;
     uint32_t r_id = 0;
     bool r_valid = (int)threadIdx.x < total;
-    if (r_valid) { r_id = point_list[range.y - 1 - threadIdx.x]; GSR_LOAD_REC(r_id); }
+    if (r_valid) { r_id = point_list[list_end - 1u - threadIdx.x]; GSR_LOAD_REC(r_id); }
     for (int r = 0; r < rounds; ++r) {
         __syncthreads();
         GSR_STAGE(r_valid);
@@ -294,7 +359,7 @@ __global__ __launch_bounds__(GDR_BLOCK) void surfel_render_bwd_kernel(
         {
             const int nxt = (r + 1) * GDR_BLOCK + (int)threadIdx.x;
             r_valid = nxt < total;
-            if (r_valid) { r_id = point_list[range.y - 1 - nxt]; GSR_LOAD_REC(r_id); }
+            if (r_valid) { r_id = point_list[list_end - 1u - (uint32_t)nxt]; GSR_LOAD_REC(r_id); }
         }
         const int top = total - 1 - r * GDR_BLOCK;  // list position of LDS entry e: top - e
         if (top - (GDR_BLOCK - 1) >= wave_last) continue;
@@ -397,7 +462,7 @@ hipError_t launch_surfel_render_fwd(const gdr_settings* s, const gdr_geom* g, co
     const int ntiles = gx * gy;
     GDR_LAUNCH(GDR_K_RENDER_FWD, surfel_render_fwd_kernel, dim3(ntiles), dim3(GDR_BLOCK), st, (const uint2*)img->ranges,
                bin->values[bin->sorted], img->tile_order, W, H, gx, ntiles, (const float4*)g->rec, s->bg, img->final_T,
-               img->n_contrib, out->color, out->allmap);
+               img->n_contrib, out->color, out->allmap, GDR_SEG_FWD_ARGS(bin, img));
     return hipGetLastError();
 }
 
@@ -407,9 +472,9 @@ hipError_t launch_surfel_render_bwd(const gdr_settings* s, const gdr_geom* g, co
     const int W = s->image_width, H = s->image_height;
     const int gx = tile_grid_x(W), gy = tile_grid_y(H);
     const int ntiles = gx * gy;
-    GDR_LAUNCH(GDR_K_RENDER_BWD, surfel_render_bwd_kernel, dim3(ntiles), dim3(GDR_BLOCK), st, (const uint2*)img->ranges,
+    GDR_LAUNCH(GDR_K_RENDER_BWD, surfel_render_bwd_kernel, GDR_BWD_GRID(bin, img, ntiles), dim3(GDR_BLOCK), st, (const uint2*)img->ranges,
                bin->values[bin->sorted], img->tile_order, W, H, gx, ntiles, s->bg, (const float4*)g->rec, img->final_T,
-               img->n_contrib, gi->dL_dcolor, gi->dL_dallmap, grad_rec);
+               img->n_contrib, gi->dL_dcolor, gi->dL_dallmap, grad_rec, GDR_SEG_BWD_ARGS(bin, img));
     return hipGetLastError();
 }
 

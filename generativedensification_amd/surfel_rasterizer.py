@@ -46,7 +46,8 @@ class _SurfelState(_State):
             transMats=torch.cat([rec[:, 0:3], rec[:, 4:7], rec[:, 8:11]], 1),
             xy=torch.stack([rec[:, 3], rec[:, 7]], 1),
             normal_opacity=torch.cat([rec[:, 12:15], rec[:, 11:12]], 1),
-            rgb=rec[:, 15:18], box=rec[:, 18:22])
+            rgb=rec[:, 15:18], box=rec[:, 18:22], seg_len=int(b.seg_len),
+            seg_count=self._view(bb, b.seg_count, torch.int32, 2))
         s = b.sorted
         if D > 0:
             out["keys_sorted"] = self._view(bb, b.keys[s], torch.int64, D)
@@ -103,6 +104,7 @@ def forward_raw(means3D, sh, colors_precomp, opacities, scales, rotations, trans
         st.bin_buf = torch.empty(lib.gdr_binning_bytes(st.D), **u8)
         L.check(lib.gdr_binning_carve(st.bin_buf.data_ptr(), st.D, C.byref(st.bin)), "gdr_binning_carve")
         st.bin.global_sort = int(_R._FORCE_GLOBAL_SORT)
+        _R._apply_seg_len(st.bin, st.D)
         out = L.GsrOutputs(color.data_ptr(), allmap.data_ptr(), _ptr(radii))
         L.check(lib.gsr_render_forward(C.byref(s), C.byref(inp), C.byref(st.geom), C.byref(st.bin), C.byref(st.img),
                                        st.D, C.byref(out), stream), "gsr_render_forward")
@@ -230,6 +232,7 @@ class _RenderSurfelViews(torch.autograd.Function):
                 st.bin_buf = torch.empty(lib.gdr_binning_bytes(st.D), **u8)
                 L.check(lib.gdr_binning_carve(st.bin_buf.data_ptr(), st.D, C.byref(st.bin)), "gdr_binning_carve")
                 st.bin.global_sort = int(_R._FORCE_GLOBAL_SORT)
+                _R._apply_seg_len(st.bin, st.D)
             n_side = _R.side_count(H, W)
             if n_side and V > 1:   # binning of view v+1 overlaps K6s of view v (rasterizer._forward_views_impl)
                 main = torch.cuda.current_stream()

@@ -133,8 +133,9 @@ typedef struct gdr_binning {
      * K6 saves the per-pixel compositing state at every cut and at the end of the list. */
     uint32_t* seg_extra; /* (seg_cap,2) (tile, segment) of every segment but the last of its tile */
     uint32_t* seg_count; /* (2) rows of seg_extra, state slots                                    */
-    float* seg_state;    /* (2*seg_cap, 6, 256) K6 -> K7: T, colour x3, depth, alpha sums per pixel of
-                          * the tile in front of each cut, and at the end of the list              */
+    float* seg_state;    /* (2*seg_cap, 10, 256) K6 -> K7: per pixel of the tile, in front of each cut and at
+                          * the end of the list: T, colour x3, depth, alpha sums (gdr); T, colour x3,
+                          * normal x3, depth, M1, M2 (gsr)                                          */
     int32_t seg_len;     /* entries per segment (multiple of 256); 0 = lists are never cut          */
     int32_t seg_cap;     /* D / seg_len + 1                                                         */
 } gdr_binning;
@@ -145,8 +146,7 @@ typedef struct gdr_image {
     uint32_t* n_contrib; /* (H*W) 1-based index of the last contributor     */
     float* final_T;      /* (H*W) transmittance after the last contributor  */
     uint32_t* tile_order; /* (tiles) tile ids, longest sorted list first (launch order of K6/K7) */
-    uint32_t* seg_base;   /* (tiles) first seg_state slot of a tile whose list is cut, 0xFFFFFFFF
-                           * otherwise; NULL (surfel image state): lists are never cut */
+    uint32_t* seg_base;   /* (tiles) first seg_state slot of a tile whose list is cut, 0xFFFFFFFF otherwise */
 } gdr_image;
 
 typedef struct gdr_outputs {

@@ -63,6 +63,43 @@ def test_surfel_forward_and_backward_vs_oracle(oracle_built, N, H, W, seed, deg,
     assert e_hip < max(5e-5, e_o32), (e_hip, e_o32)
 
 
+def test_cut_surfel_lists_give_the_gradients_of_the_uncut_walk(oracle_built):
+    """2DGS counterpart of test_gpu_parity.py::test_cut_tile_lists_...: K6s saves (T, colour, normal, depth, M1, M2 sums)
+    per pixel at every cut, K7s walks the segments in parallel workgroups — the distortion weights behind a cut come
+    from the saved moments.  seg_len 2048 / 4096 / off: identical forward, gradients equal within float-summation noise
+    and within the usual tolerance of the f64 oracle."""
+    from generativedensification_amd import rasterizer as R
+
+    case = U.make_surfel_case(40_000, 64, 48, 47, deg=1, sigma0=(0.003,), bg=(1.0, 0.5, 0.2))
+    case["means3D"] = (case["means3D"] * 0.3).contiguous()
+    case["opacities"] = (case["opacities"] * 0.05).contiguous()
+    grads = U.rand_surfel_grads(case)
+    res = {}
+    try:
+        for sl in (0, 2048, 4096):
+            R.SEG_LEN = sl
+            res[sl] = U.run_surfel_hip(case, grads)
+    finally:
+        R.SEG_LEN = None
+    h0, g0 = res[0]
+    if res[2048][0]["seg_len"] == 0:
+        pytest.skip("cut lists disabled in this process (GDR_SEG_LEN=0)")
+    lens = (h0["ranges"][:, 1].astype(np.int64) - h0["ranges"][:, 0]).clip(min=0)
+    assert lens.max() > 3 * 2048 and int((h0["n_contrib"][0] > 8192).sum()) > 50
+    for sl in (2048, 4096):
+        h, g = res[sl]
+        nseg = np.where(lens > sl, -(-lens // sl), 0)
+        assert h["seg_len"] == sl and int(h["seg_count"][0]) == int((nseg - (nseg > 0)).sum())
+        for k in ("color", "allmap", "n_contrib", "final_T"):
+            np.testing.assert_array_equal(h[k], h0[k])
+        for k in ("means3D", "means2D", "shs", "opacities", "scales", "rotations"):
+            assert U.rel_inf(g[k], g0[k]) < 5e-5, (sl, k, U.rel_inf(g[k], g0[k]))
+    o32, g32 = U.run_surfel_oracle(case, "f32", grads)
+    o64, g64 = U.run_surfel_oracle(case, "f64", grads, nthreads=8)
+    for sl in (0, 2048):
+        _check_grads(res[sl][1], g32, g64, ("means3D", "shs", "opacities", "scales", "rotations"))
+
+
 def test_subpixel_surfels_are_no_worse_than_the_fp32_formulation(oracle_built):
     """Densified-like surfels (sigma 0.65 mm = sub-pixel) mostly render through the low-pass branch; the object-space
     branch is ill-conditioned in fp32 for them.  HIP must track the f32 oracle (same formulation) to 1e-4 and be no
