@@ -391,7 +391,11 @@ int gdr_preprocess_forward_views(int32_t V, const gdr_settings* s, const gdr_inp
     }
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = hipSuccess;
-    for (int v = 0; v < V && e == hipSuccess; ++v) e = hipMemsetAsync(geoms[v].num_rendered, 0, sizeof(uint32_t), st);
+    bool packed = true;  // the V counters in one array (geoms[v].num_rendered = base + v): one fill instead of V
+    for (int v = 1; v < V; ++v) packed = packed && geoms[v].num_rendered == geoms[0].num_rendered + v;
+    if (packed) e = hipMemsetAsync(geoms[0].num_rendered, 0, (size_t)V * sizeof(uint32_t), st);
+    else
+        for (int v = 0; v < V && e == hipSuccess; ++v) e = hipMemsetAsync(geoms[v].num_rendered, 0, sizeof(uint32_t), st);
     if (e != hipSuccess) return hip_fail("memset num_rendered", e);
     e = launch_preprocess_fwd_views(V, s, in, geoms, radii, st);
     if (e != hipSuccess) return hip_fail("preprocess_fwd_views", e);
@@ -702,7 +706,11 @@ int gsr_preprocess_forward_views(int32_t V, const gdr_settings* s, const gsr_inp
     if (!radii) { set_error("surfel views: radii NULL", hipSuccess); return GDR_ERR_INVALID_ARG; }
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = hipSuccess;
-    for (int v = 0; v < V && e == hipSuccess; ++v) e = hipMemsetAsync(geoms[v].num_rendered, 0, sizeof(uint32_t), st);
+    bool packed = true;  // the V counters in one array (geoms[v].num_rendered = base + v): one fill instead of V
+    for (int v = 1; v < V; ++v) packed = packed && geoms[v].num_rendered == geoms[0].num_rendered + v;
+    if (packed) e = hipMemsetAsync(geoms[0].num_rendered, 0, (size_t)V * sizeof(uint32_t), st);
+    else
+        for (int v = 0; v < V && e == hipSuccess; ++v) e = hipMemsetAsync(geoms[v].num_rendered, 0, sizeof(uint32_t), st);
     if (e != hipSuccess) return hip_fail("memset num_rendered", e);
     e = launch_surfel_preprocess_fwd_views(V, s, in, geoms, radii, st);
     if (e != hipSuccess) return hip_fail("surfel_preprocess_fwd_views", e);

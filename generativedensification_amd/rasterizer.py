@@ -63,7 +63,7 @@ class _State:
     """Typed views of the three workspaces of one forward call (kept for backward and
     exposed to the parity tests)."""
 
-    __slots__ = ("N", "M", "H", "W", "D", "geom_buf", "bin_buf", "img_buf", "geom", "bin", "img")
+    __slots__ = ("N", "M", "H", "W", "D", "geom_buf", "bin_buf", "img_buf", "geom", "bin", "img", "counters")
 
     def _view(self, buf, ptr, dtype, count):
         off = ptr - buf.data_ptr()
@@ -341,6 +341,8 @@ class _RasterizeGaussians(torch.autograd.Function):
 # separate autograd accumulation passes.  Same arithmetic as V calls of rasterize_gaussians.
 # --------------------------------------------------------------------------------------------
 RAW_ALL = L.GDR_IN_RAW_OPACITY | L.GDR_IN_RAW_SCALES | L.GDR_IN_RAW_ROTATIONS
+_PREALLOC = _os.environ.get("GDR_PREALLOC", "1") != "0"   # A/B switch of the two host-latency measures below
+_D_HINT: dict = {}   # (N, H, W, V) -> duplicate counts per view of the previous call (sizes the next call's workspaces)
 
 
 def _forward_views_impl(means3D, means2D, sh, opacities, scales, rotations, settings_list, flags, loss_spec=None):
@@ -365,6 +367,9 @@ def _forward_views_impl(means3D, means2D, sh, opacities, scales, rotations, sett
     depths = [torch.empty(1, H, W, **f32) for _ in range(V)]
     alphas = [torch.empty(1, H, W, **f32) for _ in range(V)]
     radii = torch.empty(V, N, dtype=torch.int32, device=dev)
+    # the V duplicate counters in one array: one fill before K1, one copy to the host (no gather kernel)
+    counters = torch.empty(V, dtype=torch.int32, device=dev)
+    hint = _D_HINT.get((N, H, W, V)) if _PREALLOC else None
     states = []
     with torch.cuda.device(dev):
         stream = _stream()
@@ -381,6 +386,13 @@ def _forward_views_impl(means3D, means2D, sh, opacities, scales, rotations, sett
             L.check(lib.gdr_geom_carve(st.geom_buf.data_ptr(), N, C.byref(st.geom)), "gdr_geom_carve")
             L.check(lib.gdr_image_carve(st.img_buf.data_ptr(), H, W, C.byref(st.img)), "gdr_image_carve")
             st.geom.cov3D = states[0].geom.cov3D if states else st.geom.cov3D  # view-independent: shared
+            if _PREALLOC:
+                st.geom.num_rendered = counters.data_ptr() + 4 * v
+            st.counters = counters
+            # binning workspace sized from the previous call of this shape, allocated BEFORE the read-back so that the
+            # host has nothing to allocate between the read-back and the first binning launch (re-allocated below if
+            # the view turns out to need more)
+            st.bin_buf = torch.empty(lib.gdr_binning_bytes(hint[v] + hint[v] // 4 + 4096), **u8) if hint else None
             g_arr[v] = st.geom
             states.append(st)
         # K1 for all views in groups of <= GDR_MAX_VIEWS launches (inputs read once per group)
@@ -404,13 +416,19 @@ def _forward_views_impl(means3D, means2D, sh, opacities, scales, rotations, sett
             for aux in auxs:
                 aux.wait_event(ready)
         # ONE host read-back for all V views
-        d_dev = torch.cat([st._view(st.geom_buf, st.geom.num_rendered, torch.int32, 1) for st in states])
-        d_host = d_dev.cpu().tolist()
+        if not _PREALLOC:
+            counters = torch.cat([st._view(st.geom_buf, st.geom.num_rendered, torch.int32, 1) for st in states])
+        d_host = [int(d) & 0xFFFFFFFF for d in counters.cpu().tolist()]
+        _D_HINT[(N, H, W, V)] = d_host
+        if len(_D_HINT) > 64:
+            _D_HINT.pop(next(iter(_D_HINT)))
 
         def alloc_bin(v):
             st = states[v]
-            st.D = int(d_host[v]) & 0xFFFFFFFF
-            st.bin_buf = torch.empty(lib.gdr_binning_bytes(st.D), **u8)
+            st.D = d_host[v]
+            need = lib.gdr_binning_bytes(st.D)
+            if st.bin_buf is None or st.bin_buf.numel() < need:
+                st.bin_buf = torch.empty(need, **u8)
             L.check(lib.gdr_binning_carve(st.bin_buf.data_ptr(), st.D, C.byref(st.bin)), "gdr_binning_carve")
             st.bin.global_sort = int(_FORCE_GLOBAL_SORT)
             _apply_seg_len(st.bin, st.D)

@@ -199,6 +199,10 @@ class _RenderSurfelViews(torch.autograd.Function):
         allmaps = [torch.empty(7, H, W, **f32) for _ in range(V)]
         radii = torch.empty(V, N, dtype=torch.int32, device=dev)
         states, structs = [], []
+        # duplicate counters of the V views in one array, binning workspaces sized from the previous call of this shape
+        # and allocated before the read-back (rasterizer._forward_views_impl)
+        counters = torch.empty(V, dtype=torch.int32, device=dev)
+        hint = _R._D_HINT.get(("surfel", N, H, W, V)) if _R._PREALLOC else None
         with torch.cuda.device(dev):
             stream = _stream()
             inp = _inputs_struct(N, M, means3D, opacities, sh, e, scales, rotations, e, flags)
@@ -211,6 +215,9 @@ class _RenderSurfelViews(torch.autograd.Function):
                 st.geom, st.bin, st.img = L.GdrGeom(), L.GdrBinning(), L.GdrImage()
                 L.check(lib.gsr_geom_carve(st.geom_buf.data_ptr(), N, C.byref(st.geom)), "gsr_geom_carve")
                 L.check(lib.gsr_image_carve(st.img_buf.data_ptr(), st.H, st.W, C.byref(st.img)), "gsr_image_carve")
+                st.geom.num_rendered = counters.data_ptr() + 4 * v
+                st.counters = counters
+                st.bin_buf = torch.empty(lib.gdr_binning_bytes(hint[v] + hint[v] // 4 + 4096), **u8) if hint else None
                 states.append(st)
                 structs.append(s)
             same = all(int(rs.image_height) == H and int(rs.image_width) == W for rs in settings_list)
@@ -226,10 +233,13 @@ class _RenderSurfelViews(torch.autograd.Function):
                 for v, st in enumerate(states):
                     L.check(lib.gsr_preprocess_forward(C.byref(structs[v]), C.byref(inp), C.byref(st.geom), _ptr(radii[v]),
                                                        None, stream), "gsr_preprocess_forward")
-            d_host = torch.cat([st._view(st.geom_buf, st.geom.num_rendered, torch.int32, 1) for st in states]).cpu().tolist()
+            d_host = [int(d) & 0xFFFFFFFF for d in counters.cpu().tolist()]
+            _R._D_HINT[("surfel", N, H, W, V)] = d_host
             for v, st in enumerate(states):
-                st.D = int(d_host[v]) & 0xFFFFFFFF
-                st.bin_buf = torch.empty(lib.gdr_binning_bytes(st.D), **u8)
+                st.D = d_host[v]
+                need = lib.gdr_binning_bytes(st.D)
+                if st.bin_buf is None or st.bin_buf.numel() < need:
+                    st.bin_buf = torch.empty(need, **u8)
                 L.check(lib.gdr_binning_carve(st.bin_buf.data_ptr(), st.D, C.byref(st.bin)), "gdr_binning_carve")
                 st.bin.global_sort = int(_R._FORCE_GLOBAL_SORT)
                 _R._apply_seg_len(st.bin, st.D)
