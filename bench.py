@@ -122,6 +122,8 @@ def main():
     ap.add_argument("--layout", default="cube", choices=["cube", "shell"],
                     help="scene layout: cube = the BASELINE workloads (uniform in the reference's scene cube); shell = "
                          "object-like stand-in with skewed tile lists (not a BASELINE number)")
+    ap.add_argument("--host-profile", action="store_true",
+                    help="cProfile of the host side of the timed steps (top entries to stderr; slows the run)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed even at WORLD_SIZE=1 (exercises the RCCL barrier / all-gather / "
                          "all-reduce calls of the N>1 path on a one-GPU box)")
@@ -272,11 +274,23 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
+    prof_host = None
+    if args.host_profile:
+        import cProfile
+        prof_host = cProfile.Profile()
+        prof_host.enable()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         last_losses = step()
     barrier()
     elapsed = time.perf_counter() - t0
+    if prof_host is not None:
+        import io
+        import pstats
+        prof_host.disable()
+        buf = io.StringIO()
+        pstats.Stats(prof_host, stream=buf).sort_stats("tottime").print_stats(40)
+        print(buf.getvalue(), file=sys.stderr)
     if use_dist:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -218,7 +218,8 @@ def test_vjp_and_no_grad_and_autocast_contracts():
     assert all(torch.isfinite(v.grad).all() for v in leaves.values())
 
 
-def test_fused_multiview_entry_matches_per_view_reference_sequence():
+@pytest.mark.parametrize("V", [3, 10])   # 10 > GDR_MAX_VIEWS = 8: two kernel groups, the second accumulating
+def test_fused_multiview_entry_matches_per_view_reference_sequence(V):
     """render_views (activations inside K1/K9, grads summed over views inside K9, one D read-back)
     == the reference's sequence (torch activations + one rasterizer call per view + autograd sum)."""
     from generativedensification_amd.camera import orbit_cameras
@@ -226,11 +227,12 @@ def test_fused_multiview_entry_matches_per_view_reference_sequence():
     from generativedensification_amd.synthetic import make_scene, make_targets, view_loss
 
     dev = torch.device("cuda:0")
-    n, h, w, V = 30_000, 160, 208, 3
+    n, h, w = 30_000, 160, 208
     sc = make_scene(n, 77, sh_degree=3, sigma0=(0.0052, 0.00065, 0.02))
     cams = orbit_cameras(V, w, h, device=dev)
     tg = make_targets(V, h, w, 77).to(dev)
-    bgs = [torch.tensor(c, device=dev) for c in ([1.0, 1.0, 1.0], [0.5, 0.5, 0.5], [0.0, 0.0, 0.0])]  # gobjverse.py:112-117
+    three = ([1.0, 1.0, 1.0], [0.5, 0.5, 0.5], [0.0, 0.0, 0.0])   # gobjverse.py:112-117
+    bgs = [torch.tensor(three[j % 3], device=dev) for j in range(V)]
 
     def run(fused):
         r = Renderer(sh_degree=3, fused=fused)
@@ -255,8 +257,14 @@ def test_fused_multiview_entry_matches_per_view_reference_sequence():
         for k in ("image", "depth", "acc_map"):
             assert a[k].shape == b[k].shape
             assert U.outlier_fraction(a[k].detach().cpu().numpy(), b[k].detach().cpu().numpy(), 1e-4, 1e-5) < 1e-4, k
+    # The two sequences agree to ~3e-7 per view.  The in-kernel activations differ from torch's by an ulp, which can
+    # flip ONE marginal alpha >= 1/255 decision in a view (10 views: one pixel each in two of them, |d image| 7e-4,
+    # scripts/mv_diag.py); the Gaussians under such a pixel then differ by that pixel's gradient.  Counted, not hidden:
+    flips = sum(int(((a["image"] - b["image"]).abs() > 1e-4).any(-1).sum()) for a, b in zip(o_fus, o_ref))
+    assert flips <= V // 3
     for k in g_ref:
-        assert U.rel_inf(g_fus[k], g_ref[k]) < 1e-4, k
+        assert U.rel_inf(g_fus[k], g_ref[k]) < (1e-4 if flips == 0 else 1e-3), (k, flips)
+        assert U.outlier_fraction(g_fus[k], g_ref[k], 1e-3, 1e-5 * np.abs(g_ref[k]).max()) < 1e-3, k
     assert g_fus["ssp"].shape == (n, 4) and (g_fus["ssp"][:, 2:] >= 0).all()
 
 
@@ -427,7 +435,8 @@ def test_fused_view_loss_matches_torch_loss_value_and_gradients():
         torch.testing.assert_close(x, y, rtol=1e-6, atol=1e-12)
 
 
-def test_loss_folded_into_k6_k7_matches_the_torch_loss_on_render_views():
+@pytest.mark.parametrize("V", [3, 9])
+def test_loss_folded_into_k6_k7_matches_the_torch_loss_on_render_views(V):
     """Renderer.render_views_loss (K6 epilogue accumulates the loss, K7 prologue forms dL/dpixel) == synthetic.view_loss
     on render_views' dicts + autograd: values to 2e-6, Gaussian gradients to 1e-4, per-view bg colours, non-unit
     upstream gradients, a good share of pixels outside [0,1] (clamp mask)."""
@@ -436,14 +445,15 @@ def test_loss_folded_into_k6_k7_matches_the_torch_loss_on_render_views():
     from generativedensification_amd.synthetic import make_scene, make_targets, view_loss
 
     dev = torch.device("cuda:0")
-    n, h, w, V = 25_000, 150, 200, 3
+    n, h, w = 25_000, 150, 200
     sc = make_scene(n, 93, sh_degree=3, sigma0=(0.0052, 0.02))
     sc["shs"][:, 0] *= 3.0
     cams = orbit_cameras(V, w, h, device=dev)
     tg = make_targets(V, h, w, 93).to(dev)
     tg_chw = tg.permute(0, 3, 1, 2).contiguous()
-    bgs = [torch.tensor(c, device=dev) for c in ([1.0, 1.0, 1.0], [0.5, 0.5, 0.5], [0.0, 0.0, 0.0])]
-    wts = torch.tensor([0.7, 1.9, 1.0], device=dev)
+    three = ([1.0, 1.0, 1.0], [0.5, 0.5, 0.5], [0.0, 0.0, 0.0])
+    bgs = [torch.tensor(three[j % 3], device=dev) for j in range(V)]
+    wts = torch.tensor([0.7, 1.9, 1.0, 0.4, 1.3, 2.2, 0.9, 1.6, 0.5, 1.1][:V], device=dev)
     r = Renderer(sh_degree=3, fused=True)
 
     def run(folded):

@@ -329,7 +329,8 @@ def test_nan_upstream_gradients_at_empty_pixels_do_not_leak():
             torch.testing.assert_close(dirty[k], v, rtol=1e-5, atol=1e-6 * float(v.abs().max()), msg=k)
 
 
-def test_surfel_multiview_node_and_fused_loss_match_the_per_view_sequence():
+@pytest.mark.parametrize("V", [3, 9])   # 9 > GDR_MAX_VIEWS: a second, accumulating group of K1s / K9s launches
+def test_surfel_multiview_node_and_fused_loss_match_the_per_view_sequence(V):
     """Renderer2D.render_views (one node, K9s accumulating over views) + losses.surfel_view_loss_fused == the
     reference's sequence: render_img per view (torch activations) + synthetic.surfel_loss (torch ops) + autograd sum."""
     from generativedensification_amd.camera import build_rays, orbit_cameras
@@ -338,7 +339,7 @@ def test_surfel_multiview_node_and_fused_loss_match_the_per_view_sequence():
     from generativedensification_amd.synthetic import make_scene, make_targets, surfel_loss
 
     dev = torch.device("cuda:0")
-    n, h, w, V = 20_000, 144, 176, 3
+    n, h, w = 20_000, 144, 176
     sc = make_scene(n, 77, sh_degree=3, sigma0=(0.0052, 0.02))
     sc["scales"] = sc["scales"][:, :2].contiguous()
     sc["shs"][:, 0] *= 2.0
@@ -346,8 +347,9 @@ def test_surfel_multiview_node_and_fused_loss_match_the_per_view_sequence():
     rays = [build_rays(torch.inverse(c.world_view_transform.T.cpu()), 0.75, 0.75, h, w).to(dev) for c in cams]
     tg = make_targets(V, h, w, 77).to(dev)
     tg_chw = tg.permute(0, 3, 1, 2).contiguous()
-    bgs = [torch.tensor(c, device=dev) for c in ([1.0, 1.0, 1.0], [0.5, 0.5, 0.5], [0.0, 0.0, 0.0])]
-    wts = torch.tensor([0.7, 1.9, 1.0], device=dev)
+    three = ([1.0, 1.0, 1.0], [0.5, 0.5, 0.5], [0.0, 0.0, 0.0])
+    bgs = [torch.tensor(three[j % 3], device=dev) for j in range(V)]
+    wts = torch.tensor([0.7, 1.9, 1.0, 0.4, 1.3, 2.2, 0.9, 1.6, 0.5][:V], device=dev)
 
     def run(mode):
         r = Renderer(sh_degree=3, fused=(mode != "reference"))
@@ -375,7 +377,7 @@ def test_surfel_multiview_node_and_fused_loss_match_the_per_view_sequence():
         l, g = run(mode)
         np.testing.assert_allclose(l, l_ref, rtol=2e-5, err_msg=mode)
         for k in g_ref:
-            assert U.rel_inf(g[k], g_ref[k]) < 2e-4, (mode, k)
+            assert U.rel_inf(g[k], g_ref[k]) < (2e-4 if V <= 3 else 4e-4), (mode, k)   # fp32 noise of 9 summed views
             assert U.outlier_fraction(g[k], g_ref[k], 1e-3, 1e-5 * np.abs(g_ref[k]).max()) < 1e-3, (mode, k)
         assert g["ssp"].shape == (n, 4) and (g["ssp"][:, 2:] >= 0).all()
 
