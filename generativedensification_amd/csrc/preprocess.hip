@@ -691,7 +691,7 @@ struct BwdViewsArgs { int V; BwdView v[GDR_MAX_VIEWS]; };
 
 // STAGED (M == NB and 3 NB a multiple of 4: degrees 1 and 3): SH rows in, SH gradient rows out through LDS with
 // coalesced accesses (device_math.h RowStage)
-template <int DEG, bool STAGED>
+template <int DEG, bool STAGED, bool PREFETCH = false>
 __global__ __launch_bounds__(GDR_BLOCK) void preprocess_bwd_views_kernel(
     int N, int M, const float* __restrict__ means3D, const float* __restrict__ shs,
     const float* __restrict__ scales, const float* __restrict__ rotations,
@@ -729,15 +729,39 @@ __global__ __launch_bounds__(GDR_BLOCK) void preprocess_bwd_views_kernel(
     const float* sh_g = shs + (size_t)i * M * 3;
     auto sh = [&](int idx) -> float { return STAGED ? my_row[idx] : sh_g[idx]; };
 
+    // The gradient record of view v+1 is fetched while view v is processed: with 2 waves per SIMD (219 VGPRs) a
+    // dependent radii -> record load per view left ~3 TB/s worth of bytes in flight.
+    int n_rad = 0;
+    float4 n_g2 = make_float4(0.f, 0.f, 0.f, 0.f), n_gconic = n_g2, n_gcolor = n_g2;
+    uint32_t n_cl = 0u;
+    auto fetch_view = [&](int v) __attribute__((always_inline)) {
+        const BwdView& b = a.v[v];
+        n_rad = b.radii[i];
+        if (n_rad > 0) {
+            n_g2 = b.grad_rec[4 * i]; n_gconic = b.grad_rec[4 * i + 1]; n_gcolor = b.grad_rec[4 * i + 2];
+            n_cl = b.clamped[i];
+        }
+    };
+    if (PREFETCH) fetch_view(0);
     for (int v = 0; v < a.V; ++v) {
         const BwdView& bv = a.v[v];
-        if (bv.radii[i] <= 0) continue;
+        int rad;
+        float4 g2, gconic, gcolor;
+        uint32_t cl_v = 0u;
+        if (PREFETCH) {
+            rad = n_rad; g2 = n_g2; gconic = n_gconic; gcolor = n_gcolor; cl_v = n_cl;
+            if (v + 1 < a.V) fetch_view(v + 1);
+        } else {
+            rad = bv.radii[i];
+        }
+        if (rad <= 0) continue;
         any_vis = true;
         Cam cam;
         load_cam(cam, bv.view, bv.proj, bv.campos);
-        const float4 g2 = bv.grad_rec[4 * i];
-        const float4 gconic = bv.grad_rec[4 * i + 1];
-        const float4 gcolor = bv.grad_rec[4 * i + 2];
+        if (!PREFETCH) {
+            g2 = bv.grad_rec[4 * i]; gconic = bv.grad_rec[4 * i + 1]; gcolor = bv.grad_rec[4 * i + 2];
+            cl_v = bv.clamped[i];
+        }
         dm2 = make_float4(dm2.x + g2.x, dm2.y + g2.y, dm2.z + g2.z, dm2.w + g2.w);
         dop += gcolor.w;
         const float pvx = cam.v[0] * px_ + cam.v[4] * py_ + cam.v[8] * pz_ + cam.v[12];
@@ -796,7 +820,7 @@ __global__ __launch_bounds__(GDR_BLOCK) void preprocess_bwd_views_kernel(
             float bk[NB], bx[NB], by[NB], bz[NB];
             sh_basis<DEG>(ux, uy, uz, bk);
             sh_basis_grad<DEG>(ux, uy, uz, bx, by, bz);
-            const uint32_t cl = bv.clamped[i];
+            const uint32_t cl = cl_v;
             const float g[3] = {(cl & 1u) ? 0.f : gcolor.x, (cl & 2u) ? 0.f : gcolor.y,
                                 (cl & 4u) ? 0.f : gcolor.z};
             float ddx = 0.f, ddy = 0.f, ddz = 0.f;
@@ -1032,7 +1056,16 @@ hipError_t launch_preprocess_bwd_views(int V, const gdr_settings* s, const gdr_i
         b.radii = radii[v]; b.clamped = geoms[v].clamped; b.grad_rec = (const float4*)grad_recs[v];
     }
     const int grid = div_up(N, GDR_BLOCK);
+    // record prefetch (see the kernel): degree 3 only — 404 -> 381 us per 4 views at 2 M Gaussians with the same 2 waves
+    // per SIMD; at degree 1 the extra registers cost a wave per SIMD (C3: 82 -> 90 us)
+    static const bool prefetch = getenv("GDR_K9_PREFETCH") ? atoi(getenv("GDR_K9_PREFETCH")) != 0 : true;
 #define GDR_K9V(DEG_, ST_)                                                                                  \
+    if (prefetch && V > 1 && DEG_ == 3)                                                                     \
+        GDR_LAUNCH(GDR_K_PREPROCESS_BWD, (preprocess_bwd_views_kernel<DEG_, ST_, true>), dim3(grid), dim3(GDR_BLOCK), st, N,  \
+               in->M, in->means3D, in->shs, in->scales, in->rotations, in->opacities, s[0].scale_modifier,     \
+               geoms[0].cov3D, W, H, in->flags, go->accumulate, (float4*)go->dL_dmeans2D, go->dL_dopacities,   \
+               go->dL_dmeans3D, go->dL_dshs, go->dL_dscales, (float4*)go->dL_drotations, a);                  \
+    else                                                                                                    \
     GDR_LAUNCH(GDR_K_PREPROCESS_BWD, (preprocess_bwd_views_kernel<DEG_, ST_>), dim3(grid), dim3(GDR_BLOCK), st, N,  \
                in->M, in->means3D, in->shs, in->scales, in->rotations, in->opacities, s[0].scale_modifier,     \
                geoms[0].cov3D, W, H, in->flags, go->accumulate, (float4*)go->dL_dmeans2D, go->dL_dopacities,   \
