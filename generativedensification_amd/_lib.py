@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GDR_LIB_PATH") or os.path.join(_HERE, "lib", "libgdr_hip.so")
 
 GDR_OK = 0
-GDR_IN_RAW_OPACITY, GDR_IN_RAW_SCALES, GDR_IN_RAW_ROTATIONS = 1, 2, 4
+GDR_IN_RAW_OPACITY, GDR_IN_RAW_SCALES, GDR_IN_RAW_ROTATIONS, GDR_IN_NO_DEPTH_TO_MEAN = 1, 2, 4, 8
 GDR_MAX_VIEWS = 8
 GDR_ERR_WORKSPACE = -4
 

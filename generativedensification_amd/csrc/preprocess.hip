@@ -349,7 +349,7 @@ __global__ __launch_bounds__(GDR_BLOCK) void preprocess_bwd_kernel(
             dmean[k] = cam.v[4 * k + 0] * dtx + cam.v[4 * k + 1] * dty + cam.v[4 * k + 2] * dtz;
             dmean[k] += (cam.p[4 * k + 0] * m_w - cam.p[4 * k + 3] * mul1) * g2.x +
                         (cam.p[4 * k + 1] * m_w - cam.p[4 * k + 3] * mul2) * g2.y;
-            dmean[k] += cam.v[4 * k + 2] * gconic.w;
+            if (!(flags & GDR_IN_NO_DEPTH_TO_MEAN)) dmean[k] += cam.v[4 * k + 2] * gconic.w;  // risk R1 switch
         }
         // SH backward (A.5-iv)
         if (!colors_precomp) {
@@ -811,7 +811,7 @@ __global__ __launch_bounds__(GDR_BLOCK) void preprocess_bwd_views_kernel(
             dmean[k] += cam.v[4 * k + 0] * dtx + cam.v[4 * k + 1] * dty + cam.v[4 * k + 2] * dtz;
             dmean[k] += (cam.p[4 * k + 0] * m_w - cam.p[4 * k + 3] * mul1) * g2.x +
                         (cam.p[4 * k + 1] * m_w - cam.p[4 * k + 3] * mul2) * g2.y;
-            dmean[k] += cam.v[4 * k + 2] * gconic.w;
+            if (!(flags & GDR_IN_NO_DEPTH_TO_MEAN)) dmean[k] += cam.v[4 * k + 2] * gconic.w;  // risk R1 switch
         }
         {   // SH backward
             float dx = px_ - cam.c[0], dy = py_ - cam.c[1], dz = pz_ - cam.c[2];

@@ -112,9 +112,16 @@ def _settings_struct(rs: GaussianRasterizationSettings, dev, keep: list) -> L.Gd
                          campos.data_ptr())
 
 
+# Parity-risk switch R1 (include/gdr.h GDR_IN_NO_DEPTH_TO_MEAN): True (default) = dL/d(depth image) also
+# moves the Gaussian centres (depth_i = view-space z of the centre); False = it does not.  GDR_DEPTH_TO_MEAN=0 or
+# rasterizer.DEPTH_TO_MEAN = False.
+DEPTH_TO_MEAN = __import__("os").environ.get("GDR_DEPTH_TO_MEAN", "1") != "0"
+
+
 def _inputs_struct(N, M, means3D, opacities, sh, colors_precomp, scales, rotations, cov3Ds, flags=0) -> L.GdrInputs:
+    flags = int(flags) | (0 if DEPTH_TO_MEAN else L.GDR_IN_NO_DEPTH_TO_MEAN)
     return L.GdrInputs(N, M, _ptr(means3D), _ptr(opacities), _ptr(sh), _ptr(colors_precomp), _ptr(scales),
-                       _ptr(rotations), _ptr(cov3Ds), int(flags), 0)
+                       _ptr(rotations), _ptr(cov3Ds), flags, 0)
 
 
 # test / A-B hook: one global radix sort instead of tile partition + per-tile LDS sort

@@ -24,8 +24,16 @@ from .rasterizer import (GaussianRasterizationSettings, GaussianRasterizer, rend
 
 
 class Renderer(nn.Module):
-    def __init__(self, sh_degree: int = 3, white_background: bool = True, radius: float = 1, fused: bool = True):
+    def __init__(self, sh_degree: int = 3, white_background: bool = True, radius: float = 1, fused: bool = True,
+                 depth_mode: str = "sum"):
         super().__init__()
+        # depth_mode: parity-risk switch R4.  "sum" (default, what the call sites of the reference imply:
+        # depth compared with metric z, network.py:743-752): depth = sum_i w_i z_i.  "normalized": the other convention
+        # a fork may use, depth = sum_i w_i z_i / sum_i w_i, formed here from the rasterizer's depth and alpha (autograd
+        # carries the quotient rule); not available for the loss-folding entry points.
+        if depth_mode not in ("sum", "normalized"):
+            raise ValueError("depth_mode must be 'sum' or 'normalized'")
+        self.depth_mode = depth_mode
         # fused=True: render_img/render_views hand the RAW tensors to the rasterizer, which applies
         # sigmoid/exp/normalize inside its per-Gaussian kernels (same maths, fewer HBM passes);
         # fused=False: op-for-op the reference sequence (torch activations, then the rasterizer).
@@ -82,6 +90,8 @@ class Renderer(nn.Module):
             pass
         images, radii, depths, alphas = render_views_raw(centers, screenspace_points, shs, opacity, scales,
                                                          rotations, sets)
+        if self.depth_mode == "normalized":
+            depths = [d / a.clamp_min(1e-10) for d, a in zip(depths, alphas)]
         if raw:
             return [{f"color{prex}": images[v], f"depth{prex}": depths[v], f"alpha{prex}": alphas[v]}
                     for v in range(len(sets))]
@@ -96,6 +106,8 @@ class Renderer(nn.Module):
         """Per-view image losses (V,) of all `cams` with the loss folded into the rasterizer's K6 epilogue / K7 prologue
         (SURVEY §8f-4): loss_v = mean((clamp(image_v) - target_v)^2) + w_depth mean(depth_v) + w_alpha mean(alpha_v) —
         `synthetic.view_loss` on render_views' dicts, without materialising dL/dimage.  targets_chw: (V,3,H,W)."""
+        if self.depth_mode != "sum":
+            raise NotImplementedError("render_views_loss folds the loss of the un-normalised depth; use render_views")
         sets = []
         for j, cam in enumerate(cams):
             if bg_colors is not None:
@@ -147,6 +159,8 @@ class Renderer(nn.Module):
             means3D=centers, means2D=screenspace_points, shs=shs, opacities=opacity, scales=scales,
             rotations=rotations, cov3D_precomp=cov3D_precomp)
         image = image.clamp(0, 1)
+        if self.depth_mode == "normalized":
+            depth = depth / alpha.clamp_min(1e-10)
         return {
             f"image{prex}": image.permute(1, 2, 0),
             f"depth{prex}": depth.permute(1, 2, 0),

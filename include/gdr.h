@@ -97,6 +97,11 @@ typedef struct gdr_inputs {
 #define GDR_IN_RAW_OPACITY 1u
 #define GDR_IN_RAW_SCALES 2u
 #define GDR_IN_RAW_ROTATIONS 4u
+/* parity-risk switch R1: the CUDA fork's source is unavailable, so whether its backward sends
+ * dL/d(depth image) into the Gaussian centres (depth_i = z of the centre in view space) is unknown; default = it
+ * does (ashawkey lineage).  With this flag the depth gradient still reaches the opacities / conics / 2D means
+ * through the blend weights, but no longer moves the centres along the view axis. */
+#define GDR_IN_NO_DEPTH_TO_MEAN 8u
 
 /* Geometry state written by the forward and re-read by the backward
  * (upstream "geomBuffer").  Carved from one caller allocation by gdr_geom_carve. */

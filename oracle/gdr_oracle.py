@@ -164,7 +164,8 @@ class Oracle:
                      view=view, proj=proj, campos=campos, bg=bg, s=s, vals=vals),
         )
 
-    def backward(self, ctx: dict, grad_color, grad_depth=None, grad_alpha=None) -> dict:
+    def backward(self, ctx: dict, grad_color, grad_depth=None, grad_alpha=None, depth_to_mean: bool = True) -> dict:
+        """depth_to_mean=False: parity-risk variant R1 — the per-Gaussian depth gradient is not sent into means3D."""
         rt, lib = self.rt, self.lib
         i = ctx["_in"]
         s = i["s"]
@@ -196,7 +197,8 @@ class Oracle:
             self.creal(float(s.scale_modifier)), _p(cov3D), C.c_int(int(i["c3"] is not None)),
             C.c_int(int(i["cp"] is not None)), _p(i["view"]), _p(i["proj"]), _p(i["campos"]),
             C.c_int(W), C.c_int(H), self.creal(float(s.tanfovx)), self.creal(float(s.tanfovy)),
-            _p(d_mean2D), _p(d_conic), _p(d_color), _p(d_depth), _p(d_means3D), _p(d_cov3D),
+            _p(d_mean2D), _p(d_conic), _p(d_color), _p(d_depth if depth_to_mean else np.zeros_like(d_depth)),
+            _p(d_means3D), _p(d_cov3D),
             _p(d_sh), _p(d_scale), _p(d_rot), C.c_int(self.nthreads))
         return dict(
             means3D=d_means3D, means2D=d_mean2D, shs=d_sh if M else None,

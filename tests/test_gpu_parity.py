@@ -527,6 +527,52 @@ def test_long_tile_lists_bucket_and_band_cases(oracle_built, n, band):
     assert U.outlier_fraction(hip["color"], ora["color"], 1e-3, 1e-4) < 1e-3
 
 
+def test_parity_risk_switches_r1_and_r4(oracle_built):
+    """the fork's source is unavailable, so two of its possible conventions are switchable.
+    R1 (rasterizer.DEPTH_TO_MEAN / GDR_IN_NO_DEPTH_TO_MEAN): dL/d(depth image) does / does not move the centres —
+    HIP == oracle in both settings, and the settings differ.  R4 (Renderer(depth_mode=...)): depth = sum w z (default)
+    or sum w z / sum w."""
+    from generativedensification_amd import rasterizer as R
+    from generativedensification_amd.camera import orbit_cameras
+    from generativedensification_amd.renderer import Renderer
+    from generativedensification_amd.synthetic import make_scene
+
+    case = U.make_case(4000, 96, 112, 51, deg=2, sigma0=(0.02, 0.05))
+    grads = U.rand_grads(case)
+    from oracle.gdr_oracle import Oracle
+    o = Oracle("f64", nthreads=8)
+    ctx = o.forward(U._np(case["means3D"]), U._np(case["opacities"]), U.settings_np(case), shs=U._np(case["shs"]),
+                    scales=U._np(case["scales"]), rotations=U._np(case["rotations"]))
+    res = {}
+    try:
+        for on in (True, False):
+            R.DEPTH_TO_MEAN = on
+            _, hg = U.run_hip(case, grads)
+            g64 = o.backward(ctx, U._np(grads[0]), U._np(grads[1]), U._np(grads[2]), depth_to_mean=on)
+            res[on] = hg["means3D"]
+            assert U.rel_inf(hg["means3D"].reshape(g64["means3D"].shape), g64["means3D"]) < 1e-4, on
+            for k in ("opacities", "scales", "rotations"):
+                assert U.rel_inf(hg[k].reshape(g64[k].shape), g64[k]) < 1e-4, (on, k)
+    finally:
+        R.DEPTH_TO_MEAN = True
+    assert U.rel_inf(res[False], res[True]) > 1e-2      # the depth path is a real part of the default gradient
+
+    dev = torch.device("cuda:0")
+    sc = {k: v.to(dev) for k, v in make_scene(5000, 9, sh_degree=1, sigma0=(0.02,)).items()}
+    cam = orbit_cameras(1, 96, 80, device=dev)[0]
+    args = (cam, None, sc["centers"], sc["shs"], sc["opacity"], sc["scales"], sc["rotations"], dev)
+    a = Renderer(sh_degree=1).render_img(*args)
+    leaf = sc["centers"].clone().requires_grad_(True)
+    b = Renderer(sh_degree=1, depth_mode="normalized").render_img(cam, None, leaf, *args[3:])
+    acc = a["acc_map"].unsqueeze(-1)
+    torch.testing.assert_close(b["depth"], a["depth"] / acc.clamp_min(1e-10))
+    hit = acc > 0.5
+    dn = b["depth"].detach()[hit]
+    assert float(dn.min()) > 0.5 and float(dn.max()) < 3.5   # metric z of the orbit cameras
+    b["depth"].sum().backward()
+    assert torch.isfinite(leaf.grad).all() and float(leaf.grad.abs().max()) > 0
+
+
 def test_cut_tile_lists_give_the_gradients_of_the_uncut_walk(oracle_built):
     """Lists longer than seg_len are cut: K6 saves (T, prefix sums) per pixel at every cut, K7 walks the segments in
     parallel workgroups from those states.  Same case with seg_len = 2048 / 4096 / off: identical forward (bit for bit),
