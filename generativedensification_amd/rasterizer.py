@@ -127,13 +127,10 @@ def _inputs_struct(N, M, means3D, opacities, sh, colors_precomp, scales, rotatio
 # test / A-B hook: one global radix sort instead of tile partition + per-tile LDS sort
 _FORCE_GLOBAL_SORT = False
 
-# The per-view stages (binning + render) of a multi-view node are independent and CAN be spread over a pool of
-# HIP streams (GDR_VIEW_STREAMS=n) so that one view's latency-bound binning kernels overlap another view's
-# render kernels.  Measured on MI355X: 2M Gaussians 841 -> 808 (2 streams) -> 738 views/s (4 streams): concurrent
-# render kernels evict each other's records from L2/MALL and break the longest-tile-first order; 200k: +1.4 %.
-# Default: everything on the caller's stream.
 import os as _os
 
+# GDR_VIEW_STREAMS=n (legacy switch, only used with GDR_BIN_STREAM=0): the whole per-view pipeline (binning + K6) of a
+# multi-view node round-robin on n streams.  Superseded by the scheme below, which is the default.
 VIEW_STREAMS = max(1, int(_os.environ.get("GDR_VIEW_STREAMS", "1")))
 # GDR_BIN_STREAM=n: number of side streams that carry the views of a multi-view node (binning, and with GDR_RENDER_SIDE
 # also K6 / K7), round-robin; 0 = everything on the caller's stream; unset = side_count() below.
