@@ -219,11 +219,16 @@ def main():
         for p in plist:
             p.grad = None
         if surfel and not (args.per_view or args.torch_loss or args.unfused):
-            # all views of the shard in one surfel node + fused loss kernels (maps never materialised)
-            outs = renderer.render_views(cams, rays, None, params["centers"], params["shs"], params["opacity"],
-                                         params["scales"], params["rotations"], dev, raw=True)
-            lv = torch.stack([surfel_view_loss_fused(o["color"], o["allmap"], rays[j], cams[j].world_view_transform,
-                                                     targets_chw[j]) for j, o in enumerate(outs)])
+            if not args.loss_kernels:
+                # all views of the shard AND their fused loss kernels in one surfel node (the loss kernels of a view run
+                # on its side stream, next to the other views' render kernels; maps never materialised)
+                lv = renderer.render_views_loss(cams, rays, None, targets_chw, params["centers"], params["shs"],
+                                                params["opacity"], params["scales"], params["rotations"], dev)
+            else:   # previous default: one surfel node + one fused-loss autograd node per view
+                outs = renderer.render_views(cams, rays, None, params["centers"], params["shs"], params["opacity"],
+                                             params["scales"], params["rotations"], dev, raw=True)
+                lv = torch.stack([surfel_view_loss_fused(o["color"], o["allmap"], rays[j], cams[j].world_view_transform,
+                                                         targets_chw[j]) for j, o in enumerate(outs)])
             lv.sum().backward()
             losses = lv.detach()
         elif surfel:        # 2DGS adaptor: one render_img (image + depth/normal/distortion maps) + backward per view
@@ -421,7 +426,11 @@ def main():
                                  else "renderer_2dgs.render_img per view" if surfel else "render_img per view" if args.per_view
                                  else "render_views (all views of the shard, one node)")
                        + (", torch activations" if args.unfused else ", activations fused into K1/K9"),
-                       "loss": ("fused HIP kernels (MSE + 1000 distortion + 0.2 normal consistency + 0.1 depth + 0.1 alpha)"
+                       "loss": ("fused HIP kernels inside the render node, on the views' side streams "
+                                "(MSE + 1000 distortion + 0.2 normal consistency + 0.1 depth + 0.1 alpha)"
+                                if surfel and not (args.per_view or args.torch_loss or args.unfused or args.loss_kernels)
+                                else "fused HIP kernels, one autograd node per view "
+                                "(MSE + 1000 distortion + 0.2 normal consistency + 0.1 depth + 0.1 alpha)"
                                 if surfel and not (args.per_view or args.torch_loss or args.unfused)
                                 else "torch ops (MSE + 1000 distortion + 0.2 normal consistency + 0.1 depth + 0.1 alpha)" if surfel
                                 else "torch ops" if (args.per_view or args.stacked_loss or args.torch_loss or args.unfused)

@@ -24,7 +24,8 @@ from torch import nn
 
 from . import _lib as L
 from .rasterizer import GaussianRasterizationSettings
-from .surfel_rasterizer import GaussianRasterizer, _RasterizeSurfels, render_surfel_views_raw
+from .surfel_rasterizer import (GaussianRasterizer, _RasterizeSurfels, render_surfel_views_loss_raw,
+                                render_surfel_views_raw)
 
 RAW_ALL = L.GDR_IN_RAW_OPACITY | L.GDR_IN_RAW_SCALES | L.GDR_IN_RAW_ROTATIONS
 
@@ -170,6 +171,36 @@ class Renderer(nn.Module):
                          f"acc_map{prex}": acc, f"rend_normal{prex}": rend_normal, f"depth_normal{prex}": depth_normal,
                          f"rend_dist{prex}": rend_dist})
         return outs
+
+    def render_views_loss(self, cams, rays_list, bg_colors, targets_chw, centers, shs, opacity, scales, rotations, device,
+                          depth_ratio=0.0, w_dist=1000.0, w_normal=0.2, w_depth=0.1, w_alpha=0.1, screenspace_points=None):
+        """Per-view losses (V,) = synthetic.surfel_loss of what render_views would return for each view, with the fused
+        loss kernels of a view inside the rasterizer node, on the view's side stream (no dL/dimage
+        tensors, no per-view autograd nodes).  targets_chw: (V,3,H,W)."""
+        sets = []
+        for j, cam in enumerate(cams):
+            if bg_colors is not None:
+                self.set_bg_color(bg_colors[j] if isinstance(bg_colors, (list, tuple)) else bg_colors)
+            sets.append(self.set_rasterizer(cam, device=device).raster_settings)
+        if screenspace_points is None:
+            screenspace_points = torch.zeros((centers.shape[0], 4), dtype=centers.dtype, requires_grad=True,
+                                             device=device) + 0
+        try:
+            screenspace_points.retain_grad()
+        except Exception:
+            pass
+        views = [cam.world_view_transform for cam in cams]
+        tg = [targets_chw[j] for j in range(len(sets))]
+        if self.fused:
+            args = (centers, screenspace_points, shs, opacity, scales, rotations)
+            flags = RAW_ALL
+        else:
+            args = (centers, screenspace_points, shs, self.get_opacity(opacity), self.get_scaling(scales),
+                    self.get_rotation(rotations))
+            flags = 0
+        losses, _ = render_surfel_views_loss_raw(*args, sets, rays_list, views, tg, depth_ratio, w_dist, w_normal, w_depth,
+                                                 w_alpha, flags)
+        return losses
 
     def render_img(self, cam, rays, centers, shs, opacity, scales, rotations, device, cov3D_precomp=None, prex="",
                    depth_ratio=0.0, screenspace_points=None):

@@ -179,9 +179,9 @@ class _RasterizeSurfels(torch.autograd.Function):
 # view without a host sync, ONE read-back of the V duplicate counts, binning + K6s per view; backward runs K7s + K9s
 # per view with K9s ACCUMULATING into one set of gradient buffers (no autograd accumulation passes).
 # --------------------------------------------------------------------------------------------
-class _RenderSurfelViews(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, means3D, means2D, sh, opacities, scales, rotations, settings_list, flags):
+def _surfel_forward_views_impl(ctx, means3D, means2D, sh, opacities, scales, rotations, settings_list, flags, loss_spec=None):
+        """Forward of the multi-view surfel nodes.  loss_spec = (rays, views, targets, weights, losses): the per-view
+        image loss (gsr_view_loss_forward) is enqueued right behind the view's K6s on the same stream."""
         lib = L.load()
         _require_hip(means3D, "means3D")
         dev = means3D.device
@@ -198,6 +198,15 @@ class _RenderSurfelViews(torch.autograd.Function):
         colors = [torch.empty(3, H, W, **f32) for _ in range(V)]
         allmaps = [torch.empty(7, H, W, **f32) for _ in range(V)]
         radii = torch.empty(V, N, dtype=torch.int32, device=dev)
+
+        def view_loss(v, sv):  # loss of view v from (color, allmap), on the stream its K6s runs on
+            if loss_spec is None:
+                return
+            rays, views, targets, wts, losses = loss_spec
+            L.check(lib.gsr_view_loss_forward(colors[v].data_ptr(), allmaps[v].data_ptr(), rays[v].data_ptr(),
+                                              views[v].data_ptr(), targets[v].data_ptr(), H, W, *wts,
+                                              losses[v:v + 1].data_ptr(), sv), "gsr_view_loss_forward")
+
         states, structs = [], []
         # duplicate counters of the V views in one array, binning workspaces sized from the previous call of this shape
         # and allocated before the read-back (rasterizer._forward_views_impl)
@@ -269,6 +278,7 @@ class _RenderSurfelViews(torch.autograd.Function):
                         sv = stream
                     L.check(lib.gsr_composite_forward(C.byref(structs[v]), C.byref(st.geom), C.byref(st.bin),
                                                       C.byref(st.img), C.byref(out), sv), "gsr_composite_forward")
+                    view_loss(v, sv)
                 if _R.RENDER_SIDE:
                     for aux in auxs:
                         done = torch.cuda.Event()
@@ -279,9 +289,18 @@ class _RenderSurfelViews(torch.autograd.Function):
                     out = L.GsrOutputs(colors[v].data_ptr(), allmaps[v].data_ptr(), _ptr(radii[v]))
                     L.check(lib.gsr_render_forward(C.byref(structs[v]), C.byref(inp), C.byref(st.geom), C.byref(st.bin),
                                                    C.byref(st.img), st.D, C.byref(out), stream), "gsr_render_forward")
+                    view_loss(v, stream)
         ctx.states, ctx.keep, ctx.settings_list, ctx.radii, ctx.flags = states, keep, settings_list, radii, int(flags)
         ctx.means2D_shape, ctx.in_dtypes, ctx.V = tuple(means2D.shape), in_dtypes, V
         ctx.mark_non_differentiable(radii)
+        return radii, colors, allmaps
+
+
+class _RenderSurfelViews(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, opacities, scales, rotations, settings_list, flags):
+        radii, colors, allmaps = _surfel_forward_views_impl(ctx, means3D, means2D, sh, opacities, scales, rotations,
+                                                            settings_list, flags)
         return (radii, *colors, *allmaps)
 
     @staticmethod
@@ -366,6 +385,105 @@ class _RenderSurfelViews(torch.autograd.Function):
         grads = [out["means3D"], gm2, out["shs"], out["opacities"], out["scales"], out["rotations"]]
         grads = [t if t.dtype == dt else t.to(dt) for t, dt in zip(grads, ctx.in_dtypes)]
         return (*grads, None, None)
+
+
+class _RenderSurfelViewsLoss(torch.autograd.Function):
+    """V views of one surfel set AND their image losses in one node (SURVEY §8f-4 for the 2DGS path): the fused loss
+    kernels of a view (gsr_view_loss_forward / _backward: the adaptor's maps + clamp + MSE + distortion + normal
+    consistency + depth / alpha means) run on the view's side stream right behind its K6s / in front of its K7s, so
+    they overlap the other views' render kernels instead of running alone between the forward and the backward; no
+    dL/dimage tensors cross autograd.  Returns (losses (V,), radii (V,N))."""
+
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, opacities, scales, rotations, settings_list, flags, rays, views, targets, wts):
+        dev = means3D.device
+        V = len(settings_list)
+        H, W = int(settings_list[0].image_height), int(settings_list[0].image_width)
+        if any(int(rs.image_height) != H or int(rs.image_width) != W for rs in settings_list):
+            raise RuntimeError("render_views_loss: all views must share one image size")
+        rays = [r.to(device=dev, dtype=torch.float32).contiguous() for r in rays]
+        views = [m.to(device=dev, dtype=torch.float32).contiguous() for m in views]
+        targets = [t.to(device=dev, dtype=torch.float32).contiguous() for t in targets]
+        losses = torch.zeros(V, dtype=torch.float32, device=dev)
+        wts = tuple(float(x) for x in wts)
+        radii, colors, allmaps = _surfel_forward_views_impl(ctx, means3D, means2D, sh, opacities, scales, rotations,
+                                                            settings_list, flags, loss_spec=(rays, views, targets, wts, losses))
+        ctx.loss_in = (colors, allmaps, rays, views, targets, wts)
+        return losses, radii
+
+    @staticmethod
+    def backward(ctx, g_losses, g_radii):
+        lib = L.load()
+        V = ctx.V
+        colors, allmaps, rays, views, targets, wts = ctx.loss_in
+        means3D, opacities, sh, _, scales, rotations, _, flags = ctx.keep[:8]
+        dev = means3D.device
+        N, M = int(means3D.shape[0]), int(sh.shape[1])
+        H, W = ctx.states[0].H, ctx.states[0].W
+        f32 = dict(dtype=torch.float32, device=dev)
+        out = dict(means3D=torch.empty(N, 3, **f32), means2D=torch.empty(N, 4, **f32), shs=torch.empty(N, M, 3, **f32),
+                   opacities=torch.empty(N, 1, **f32), scales=torch.empty(N, 2, **f32), rotations=torch.empty(N, 4, **f32))
+        e = torch.empty(0, dtype=torch.float32, device=dev)
+        go = g_losses.to(torch.float32).contiguous()
+        with torch.cuda.device(dev):
+            stream = _stream()
+            keep2: list = []
+            inp = _inputs_struct(N, M, means3D, opacities, sh, e, scales, rotations, e, flags)
+            for lo in range(0, V, L.GDR_MAX_VIEWS):
+                n = min(L.GDR_MAX_VIEWS, V - lo)
+                recs = torch.empty(n, max(N, 1) * L.GSR_GRAD_FLOATS, **f32)
+                dcs = [torch.empty(3, H, W, **f32) for _ in range(n)]
+                das = [torch.empty(7, H, W, **f32) for _ in range(n)]
+                scr = [torch.empty(9, H, W, **f32) for _ in range(n)]
+                s_arr = (L.GdrSettings * n)()
+                g_arr = (L.GdrGeom * n)()
+                for k in range(n):
+                    s_arr[k] = _settings_struct(ctx.settings_list[lo + k], dev, keep2)
+                sides = _R._SideViews(dev, n, H, W)  # after every torch-side preparation
+                for k in range(n):
+                    v = lo + k
+                    st = ctx.states[v]
+                    g_arr[k] = st.geom
+                    sv = sides.stream(k)
+                    L.check(lib.gsr_view_loss_backward(colors[v].data_ptr(), allmaps[v].data_ptr(), rays[v].data_ptr(),
+                                                       views[v].data_ptr(), targets[v].data_ptr(), H, W, *wts,
+                                                       go[v:v + 1].data_ptr(), scr[k].data_ptr(), dcs[k].data_ptr(),
+                                                       das[k].data_ptr(), sv), "gsr_view_loss_backward")
+                    gin = L.GsrGradInputs(dcs[k].data_ptr(), das[k].data_ptr())
+                    L.check(lib.gsr_render_backward(C.byref(s_arr[k]), N, C.byref(g_arr[k]), C.byref(st.bin),
+                                                    C.byref(st.img), C.byref(gin), recs[k].data_ptr(), sv),
+                            "gsr_render_backward")
+                sides.join()
+                r_arr = (C.c_void_p * n)(*[ctx.radii[lo + k].data_ptr() if N else None for k in range(n)])
+                rec_arr = (C.c_void_p * n)(*[recs[k].data_ptr() for k in range(n)])
+                gout = L.GsrGradOutputs(_ptr(out["means3D"]), _ptr(out["means2D"]), _ptr(out["shs"]), None,
+                                        _ptr(out["opacities"]), _ptr(out["scales"]), _ptr(out["rotations"]), None, None,
+                                        1 if lo > 0 else 0, 0)
+                L.check(lib.gsr_preprocess_backward_views(n, s_arr, C.byref(inp), g_arr, r_arr, rec_arr, C.byref(gout),
+                                                          stream), "gsr_preprocess_backward_views")
+                keep2 += [recs, dcs, das, scr]
+        gm2 = out["means2D"]
+        cols = ctx.means2D_shape[1] if len(ctx.means2D_shape) == 2 else 4
+        if cols == 3:
+            gm2 = torch.cat([gm2[:, :2], torch.zeros_like(gm2[:, :1])], dim=1)
+        elif cols != 4:
+            gm2 = gm2[:, :cols].contiguous()
+        grads = [out["means3D"], gm2, out["shs"], out["opacities"], out["scales"], out["rotations"]]
+        grads = [t if t.dtype == dt else t.to(dt) for t, dt in zip(grads, ctx.in_dtypes)]
+        return (*grads, None, None, None, None, None, None)
+
+
+def render_surfel_views_loss_raw(means3D, means2D, sh, opacities, scales, rotations, settings_list, rays, viewmatrices,
+                                 targets_chw, depth_ratio=0.0, w_dist=1000.0, w_normal=0.2, w_depth=0.1, w_alpha=0.1,
+                                 flags=0):
+    """Per-view losses (V,) of V views of one surfel set, the loss kernels folded into the node (see the class).
+    rays: V tensors (H,W,6); viewmatrices: V world_view_transform; targets_chw: V tensors (3,H,W).  (losses, radii)."""
+    nb = (int(settings_list[0].sh_degree) + 1) ** 2
+    if (3 * nb) % 4 == 0 and int(sh.shape[1]) != nb:
+        raise RuntimeError("render_views_loss: shs must hold exactly (sh_degree+1)^2 coefficients")
+    return _RenderSurfelViewsLoss.apply(means3D, means2D, sh, opacities, scales, rotations, list(settings_list), int(flags),
+                                        list(rays), list(viewmatrices), list(targets_chw),
+                                        (depth_ratio, w_dist, w_normal, w_depth, w_alpha))
 
 
 def render_surfel_views_raw(means3D, means2D, sh, opacities, scales, rotations, settings_list, flags=0):

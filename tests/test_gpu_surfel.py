@@ -365,15 +365,17 @@ def test_surfel_multiview_node_and_fused_loss_match_the_per_view_sequence(V):
         elif mode == "views":
             outs = r.render_views(cams, rays, bgs, *args, depth_ratio=0.3, screenspace_points=ssp)
             lv = torch.stack([surfel_loss(o, tg[j]) for j, o in enumerate(outs)])
-        else:
+        elif mode == "fused_loss":
             outs = r.render_views(cams, rays, bgs, *args, screenspace_points=ssp, raw=True)
             lv = torch.stack([surfel_view_loss_fused(o["color"], o["allmap"], rays[j], cams[j].world_view_transform,
                                                      tg_chw[j], depth_ratio=0.3) for j, o in enumerate(outs)])
+        else:  # the loss kernels inside the node, on the views' side streams
+            lv = r.render_views_loss(cams, rays, bgs, tg_chw, *args, depth_ratio=0.3, screenspace_points=ssp)
         grads = torch.autograd.grad((lv * wts).sum(), list(leaves.values()) + [ssp])
         return lv.detach().cpu().numpy(), {k: g_.cpu().numpy() for k, g_ in zip(list(leaves) + ["ssp"], grads)}
 
     l_ref, g_ref = run("reference")
-    for mode in ("views", "fused_loss"):
+    for mode in ("views", "fused_loss", "folded_loss"):
         l, g = run(mode)
         np.testing.assert_allclose(l, l_ref, rtol=2e-5, err_msg=mode)
         for k in g_ref:
