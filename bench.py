@@ -343,7 +343,8 @@ def main():
             achieved = alg[dom] / avg_s / 1e9
             traffic = None
             try:
-                traffic = json.load(open(args.traffic_json)).get(args.workload, {}).get(dom + "_kernel")
+                tj = json.load(open(args.traffic_json)).get(args.workload, {})
+                traffic = tj.get(("surfel_" if surfel else "") + dom + "_kernel", tj.get(dom + "_kernel"))
             except Exception:
                 pass
             roofline = dict(bound="hbm", kernel=dom, achieved=round(achieved, 1), peak=HBM_PEAK_GBS,
