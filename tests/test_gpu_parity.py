@@ -476,6 +476,20 @@ def test_loss_folded_into_k6_k7_matches_the_torch_loss_on_render_views(V):
     assert g_fold["ssp"].shape == (n, 4) and (g_fold["ssp"][:, 2:] >= 0).all()
 
 
+@pytest.mark.parametrize("H,W", [(1080, 1920), (4112, 4100)])
+def test_large_images_tile_ids_beyond_12_bits(oracle_built, H, W):
+    """8 160 tiles (13 tile bits) and 66 306 tiles (17 bits: a third partition pass, 260 chunks in the tile-order /
+    cut-list scan): sorted list, ranges and image against the oracle."""
+    case = U.make_case(1500, H, W, 61, deg=1, sigma0=(0.01, 0.08))
+    hip, _ = U.run_hip(case, U.rand_grads(case))
+    ora, _ = U.run_oracle(case, "f32", nthreads=8)
+    for k in ("radii", "rect", "tiles_touched", "ranges", "point_list"):
+        np.testing.assert_array_equal(np.asarray(hip[k]).astype(np.asarray(ora[k]).dtype).reshape(np.asarray(ora[k]).shape), ora[k], err_msg=k)
+    assert hip["num_rendered"] == ora["num_rendered"] and hip["num_rendered"] > 50_000
+    assert U.outlier_fraction(hip["color"], ora["color"], 1e-4, 1e-4) < 1e-4
+    assert float((hip["n_contrib"].astype(np.int64) != ora["n_contrib"]).mean()) < 1e-4
+
+
 @pytest.mark.parametrize("H,W", [(1, 1), (5, 37), (16, 16), (17, 300)])
 def test_tiny_and_odd_image_sizes_both_paths(oracle_built, H, W):
     """Degenerate image shapes (single pixel, one partial tile, a 19-tile strip) through both rasterizers."""
