@@ -195,8 +195,9 @@ def _surfel_forward_views_impl(ctx, means3D, means2D, sh, opacities, scales, rot
         e = torch.empty(0, dtype=torch.float32, device=dev)
         keep = [means3D, opacities, sh, e, scales, rotations, e, int(flags)]
         f32, u8 = dict(dtype=torch.float32, device=dev), dict(dtype=torch.uint8, device=dev)
-        colors = [torch.empty(3, H, W, **f32) for _ in range(V)]
-        allmaps = [torch.empty(7, H, W, **f32) for _ in range(V)]
+        sizes = [(int(rs.image_height), int(rs.image_width)) for rs in settings_list]   # views may differ in size
+        colors = [torch.empty(3, h, w, **f32) for h, w in sizes]
+        allmaps = [torch.empty(7, h, w, **f32) for h, w in sizes]
         radii = torch.empty(V, N, dtype=torch.int32, device=dev)
 
         def view_loss(v, sv):  # loss of view v from (color, allmap), on the stream its K6s runs on

@@ -147,3 +147,40 @@ def test_settings_record_has_the_reference_fields_in_order():
 
     assert S._fields == ("image_height", "image_width", "tanfovx", "tanfovy", "bg", "scale_modifier", "viewmatrix",
                          "projmatrix", "sh_degree", "campos", "prefiltered", "debug")  # lightning/renderer.py:111-124
+
+
+def test_host_policy_helpers_without_gpu():
+    """Host-side policy of the multi-view nodes: side-stream count by tile count, the GDR_BIN_STREAM override, and the
+    per-call segment-length override of the cut lists (only lengths the carved tables can hold)."""
+    from generativedensification_amd import _lib as L
+    from generativedensification_amd import rasterizer as R
+
+    saved = R.BIN_STREAM, R.SEG_LEN
+    try:
+        R.BIN_STREAM = None
+        assert R.side_count(800, 800) == 2 and R.side_count(512, 512) == 3 and R.side_count(1080, 1920) == 2
+        R.BIN_STREAM = 0
+        assert R.side_count(800, 800) == 0
+        R.BIN_STREAM = 4
+        assert R.side_count(64, 64) == 4
+        b = L.GdrBinning()
+        b.seg_len = 2048
+        R.SEG_LEN = None
+        R._apply_seg_len(b, 10_000)
+        assert b.seg_len == 2048
+        R.SEG_LEN = 4096
+        R._apply_seg_len(b, 10_000)
+        assert b.seg_len == 4096
+        b.seg_len = 2048
+        R.SEG_LEN = 512          # shorter than carved: the tables would overflow -> ignored
+        R._apply_seg_len(b, 10_000)
+        assert b.seg_len == 2048
+        R.SEG_LEN = 0
+        R._apply_seg_len(b, 10_000)
+        assert b.seg_len == 0
+    finally:
+        R.BIN_STREAM, R.SEG_LEN = saved
+    lib = L.load()
+    small, big = lib.gdr_binning_bytes(1000), lib.gdr_binning_bytes(4_000_000)
+    assert big > small and big >= 4_000_000 * (8 + 8 + 4 + 4 + 8) + 2 * (4_000_000 // 2048) * 10 * 256 * 4
+

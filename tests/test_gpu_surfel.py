@@ -63,6 +63,45 @@ def test_surfel_forward_and_backward_vs_oracle(oracle_built, N, H, W, seed, deg,
     assert e_hip < max(5e-5, e_o32), (e_hip, e_o32)
 
 
+def test_surfel_views_of_different_sizes_fall_back_to_per_view_kernels():
+    """render_surfel_views_raw with views of different image sizes (no shared K1s/K9s launch): same result as one
+    rasterizer call per view."""
+    from generativedensification_amd import surfel_rasterizer as S
+    import diff_surfel_rasterization as D
+
+    dev = torch.device("cuda:0")
+    cases = [U.make_surfel_case(4000, h, w, 71, deg=1, sigma0=(0.02, 0.05)) for h, w in ((96, 128), (64, 80))]
+    base = cases[0]
+    sets = [U.settings_torch(dict(base, H=c["H"], W=c["W"], view=c["view"], proj=c["proj"], campos=c["campos"],
+                                  tanfovx=c["tanfovx"], tanfovy=c["tanfovy"]), dev) for c in cases]
+    t = lambda k: base[k].to(dev)
+
+    def run(fused):
+        leaves = {k: t(k).clone().requires_grad_(True) for k in ("means3D", "shs", "opacities", "scales", "rotations")}
+        m2 = torch.zeros(base["N"], 4, device=dev, requires_grad=True)
+        if fused:
+            colors, radii, allmaps = S.render_surfel_views_raw(leaves["means3D"], m2, leaves["shs"], leaves["opacities"],
+                                                               leaves["scales"], leaves["rotations"], sets, 0)
+        else:
+            colors, allmaps = [], []
+            for rs in sets:
+                c, _, a = D.GaussianRasterizer(rs)(means3D=leaves["means3D"], means2D=m2, shs=leaves["shs"],
+                                                   opacities=leaves["opacities"], scales=leaves["scales"],
+                                                   rotations=leaves["rotations"])
+                colors.append(c); allmaps.append(a)
+        loss = sum((c * c).mean() + a[:6].mean() for c, a in zip(colors, allmaps))
+        g = torch.autograd.grad(loss, list(leaves.values()))
+        return [c.detach().cpu().numpy() for c in colors], {k: x.cpu().numpy() for k, x in zip(leaves, g)}
+
+    c_ref, g_ref = run(False)
+    c_fus, g_fus = run(True)
+    for a, b in zip(c_fus, c_ref):
+        assert a.shape == b.shape
+        np.testing.assert_array_equal(a, b)
+    for k in g_ref:
+        assert U.rel_inf(g_fus[k], g_ref[k]) < 1e-5, k
+
+
 def test_cut_surfel_lists_give_the_gradients_of_the_uncut_walk(oracle_built):
     """2DGS counterpart of test_gpu_parity.py::test_cut_tile_lists_...: K6s saves (T, colour, normal, depth, M1, M2 sums)
     per pixel at every cut, K7s walks the segments in parallel workgroups — the distortion weights behind a cut come
