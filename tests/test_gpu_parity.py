@@ -268,6 +268,47 @@ def test_fused_multiview_entry_matches_per_view_reference_sequence(V):
     assert g_fus["ssp"].shape == (n, 4) and (g_fus["ssp"][:, 2:] >= 0).all()
 
 
+@pytest.mark.parametrize("surfel", [False, True])
+def test_multiview_node_with_a_view_that_sees_nothing(surfel):
+    """One of three cameras looks away from the scene (num_rendered = 0 for that view: empty binning workspace, empty
+    tile lists): its image is the background, and the node's gradients equal those of the two seeing views alone."""
+    from generativedensification_amd.camera import MiniCam, look_at_c2w, orbit_cameras
+    from generativedensification_amd.synthetic import make_scene
+
+    dev = torch.device("cuda:0")
+    n, h, w = 8000, 96, 112
+    sc = make_scene(n, 5, sh_degree=1, sigma0=(0.01, 0.03))
+    if surfel:
+        from generativedensification_amd.renderer_2dgs import Renderer
+        sc["scales"] = sc["scales"][:, :2].contiguous()
+    else:
+        from generativedensification_amd.renderer import Renderer
+    cams = orbit_cameras(2, w, h, device=dev)
+    eye = torch.tensor([0.0, 0.0, 1.9])
+    away = MiniCam(look_at_c2w(eye, 2.0 * eye), w, h, 0.75, 0.75, 1.1, 2.7, dev)   # the scene is behind this camera
+    bg = torch.tensor([0.2, 0.6, 1.0], device=dev)
+    r = Renderer(sh_degree=1, white_background=False)
+
+    def run(cs):
+        leaves = {k: v.to(dev).clone().requires_grad_(True) for k, v in sc.items()}
+        args = (leaves["centers"], leaves["shs"], leaves["opacity"], leaves["scales"], leaves["rotations"], dev)
+        outs = r.render_views(cs, [None] * len(cs), bg, *args, raw=True) if surfel else r.render_views(cs, bg, *args, raw=True)
+        loss = sum((o["color"] ** 2).mean() + (o["allmap"][:2] if surfel else o["depth"]).mean() for o in outs)
+        g = torch.autograd.grad(loss, list(leaves.values()))
+        return outs, {k: x.cpu().numpy() for k, x in zip(leaves, g)}
+
+    o3, g3 = run([cams[0], away, cams[1]])
+    o2, g2 = run(cams)
+    blank = o3[1]["color"]
+    torch.testing.assert_close(blank, bg.view(3, 1, 1).expand_as(blank))
+    assert float((o3[1]["allmap"] if surfel else o3[1]["alpha"]).detach().abs().max()) == 0.0
+    for a, b in ((o3[0], o2[0]), (o3[2], o2[1])):
+        np.testing.assert_array_equal(a["color"].detach().cpu().numpy(), b["color"].detach().cpu().numpy())
+    for k in g2:
+        assert np.isfinite(g3[k]).all()
+        assert U.rel_inf(g3[k], g2[k]) < 1e-5, k
+
+
 def test_multiview_kernels_keep_integer_intermediates_bit_exact(oracle_built):
     """The multi-view K1 (inputs read once for V views) must give the oracle's radii / sorted list per view
     when fed the same ACTIVATED inputs (flags = 0)."""
