@@ -268,6 +268,58 @@ def test_fused_multiview_entry_matches_per_view_reference_sequence(V):
     assert g_fus["ssp"].shape == (n, 4) and (g_fus["ssp"][:, 2:] >= 0).all()
 
 
+def test_float64_noncontiguous_inputs_and_debug_mode():
+    """The boundary accepts what a caller may hand it: float64 tensors, non-contiguous views (a transposed SH block, a
+    strided slice of a bigger tensor) — same result as float32 contiguous inputs, gradients come back in the callers'
+    dtypes — and `debug=True` (synchronise + check after every kernel) runs the same kernels."""
+    import diff_gaussian_rasterization as D
+
+    dev = torch.device("cuda:0")
+    case = U.make_case(3000, 80, 96, 87, deg=1, sigma0=(0.02, 0.05))
+    rs = U.settings_torch(case, dev)
+    t = {k: case[k].to(dev) for k in ("means3D", "shs", "opacities", "scales", "rotations")}
+
+    def run(inputs, settings):
+        leaves = {k: v.clone().requires_grad_(True) for k, v in inputs.items()}
+        m2 = torch.zeros(case["N"], 4, device=dev, dtype=leaves["opacities"].dtype, requires_grad=True)
+        views = dict(leaves)
+        if "shs_T" in leaves:      # (N,3,M) storage seen as (N,M,3): non-contiguous
+            views["shs"] = leaves["shs_T"].transpose(1, 2)
+        if "means_wide" in leaves:  # every second row of a (2N,3) tensor
+            views["means3D"] = leaves["means_wide"][::2]
+        img, radii, depth, alpha = D.GaussianRasterizer(settings)(
+            means3D=views["means3D"], means2D=m2, shs=views["shs"], opacities=views["opacities"], scales=views["scales"],
+            rotations=views["rotations"])
+        loss = (img.float() ** 2).mean() + depth.float().mean() + alpha.float().mean()
+        g = torch.autograd.grad(loss, list(leaves.values()))
+        return img.detach().float().cpu().numpy(), dict(zip(leaves, g))
+
+    img0, g0 = run(t, rs)
+    # float64 everywhere
+    img1, g1 = run({k: v.double() for k, v in t.items()}, rs)
+    np.testing.assert_array_equal(img1, img0)
+    for k in g0:
+        assert g1[k].dtype == torch.float64
+        assert U.rel_inf(g1[k].float().cpu().numpy(), g0[k].cpu().numpy()) < 1e-5, k
+    # non-contiguous views
+    wide = torch.zeros(2 * case["N"], 3, device=dev)
+    wide[::2] = t["means3D"]
+    nc = dict(t)
+    nc.pop("shs"); nc.pop("means3D")
+    nc["shs_T"] = t["shs"].transpose(1, 2).contiguous()
+    nc["means_wide"] = wide
+    img2, g2 = run(nc, rs)
+    np.testing.assert_array_equal(img2, img0)
+    assert U.rel_inf(g2["shs_T"].transpose(1, 2).cpu().numpy(), g0["shs"].cpu().numpy()) < 1e-5
+    assert U.rel_inf(g2["means_wide"][::2].cpu().numpy(), g0["means3D"].cpu().numpy()) < 1e-5
+    assert not g2["means_wide"][1::2].any()
+    # debug mode
+    img3, g3 = run(t, rs._replace(debug=True))
+    np.testing.assert_array_equal(img3, img0)
+    for k in g0:
+        assert U.rel_inf(g3[k].cpu().numpy(), g0[k].cpu().numpy()) < 1e-5, k
+
+
 @pytest.mark.parametrize("deg", [0, 1, 2])
 def test_active_sh_degree_below_the_stored_coefficients(oracle_built, deg):
     """shs hold 16 coefficients (M = 16) but only (deg+1)^2 are active — the progressive-SH situation of 3DGS training
