@@ -439,6 +439,7 @@ int gdr_preprocess_backward_views(int32_t V, const gdr_settings* s, const gdr_in
                                   const gdr_geom* geoms, const int32_t* const* radii,
                                   float* const* grad_recs, const gdr_grad_outputs* gout, void* stream) {
     if (V < 1 || V > GDR_MAX_VIEWS) { set_error("views: V out of range", hipSuccess); return GDR_ERR_UNSUPPORTED; }
+    if (s && in && in->N == 0) return GDR_OK;  // no Gaussians: the (empty) gradient buffers may be NULL
     if (!s || !in || !geoms || !radii || !grad_recs || !gout || !gout->dL_dmeans3D || !gout->dL_dmeans2D ||
         !gout->dL_dshs || !gout->dL_dopacities || !gout->dL_dscales || !gout->dL_drotations) {
         set_error("backward_views: NULL argument", hipSuccess);
@@ -735,6 +736,7 @@ int gsr_render_backward(const gdr_settings* s, int32_t N, const gdr_geom* geom, 
 int gsr_preprocess_backward_views(int32_t V, const gdr_settings* s, const gsr_inputs* in, const gdr_geom* geoms,
                                   const int32_t* const* radii, float* const* grad_recs, const gsr_grad_outputs* gout,
                                   void* stream) {
+    if (V >= 1 && V <= GDR_MAX_VIEWS && s && in && in->N == 0) return GDR_OK;  // nothing to differentiate
     int rc = check_surfel_views(V, s, in, geoms);
     if (rc) return rc;
     if (!radii || !grad_recs || !gout || !gout->dL_dmeans3D || !gout->dL_dmeans2D || !gout->dL_dshs ||

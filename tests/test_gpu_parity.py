@@ -361,6 +361,38 @@ def test_active_sh_degree_below_the_stored_coefficients(oracle_built, deg):
 
 
 @pytest.mark.parametrize("surfel", [False, True])
+def test_multiview_nodes_with_no_gaussians_at_all(surfel):
+    """N = 0 through the multi-view nodes (forward, folded loss, backward): background images, zero-size gradients."""
+    from generativedensification_amd.camera import build_rays, orbit_cameras
+
+    dev = torch.device("cuda:0")
+    h, w, V = 48, 64, 3
+    cams = orbit_cameras(V, w, h, device=dev)
+    bg = torch.tensor([0.3, 0.5, 0.7], device=dev)
+    z = lambda *shape: torch.zeros(*shape, device=dev, requires_grad=True)
+    tg = torch.rand(V, 3, h, w, device=dev)
+    if surfel:
+        from generativedensification_amd.renderer_2dgs import Renderer
+        r = Renderer(sh_degree=1, white_background=False)
+        rays = [build_rays(torch.inverse(c.world_view_transform.T.cpu()), 0.75, 0.75, h, w).to(dev) for c in cams]
+        args = (z(0, 3), z(0, 4, 3), z(0, 1), z(0, 2), z(0, 4), dev)
+        outs = r.render_views(cams, rays, bg, *args, raw=True)
+        lv = r.render_views_loss(cams, rays, bg, tg, *args)
+    else:
+        from generativedensification_amd.renderer import Renderer
+        r = Renderer(sh_degree=1, white_background=False)
+        args = (z(0, 3), z(0, 4, 3), z(0, 1), z(0, 3), z(0, 4), dev)
+        outs = r.render_views(cams, bg, *args, raw=True)
+        lv = r.render_views_loss(cams, bg, tg, *args)
+    for o in outs:
+        torch.testing.assert_close(o["color"], bg.view(3, 1, 1).expand(3, h, w))
+    assert lv.shape == (V,) and torch.isfinite(lv).all()
+    g = torch.autograd.grad(lv.sum() + sum(o["color"].sum() for o in outs), list(args[:5]), allow_unused=True)
+    for x, a in zip(g, args[:5]):
+        assert x is None or x.shape == a.shape
+
+
+@pytest.mark.parametrize("surfel", [False, True])
 def test_multiview_node_with_a_view_that_sees_nothing(surfel):
     """One of three cameras looks away from the scene (num_rendered = 0 for that view: empty binning workspace, empty
     tile lists): its image is the background, and the node's gradients equal those of the two seeing views alone."""
