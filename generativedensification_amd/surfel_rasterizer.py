@@ -245,6 +245,8 @@ def _surfel_forward_views_impl(ctx, means3D, means2D, sh, opacities, scales, rot
                                                        None, stream), "gsr_preprocess_forward")
             d_host = [int(d) & 0xFFFFFFFF for d in counters.cpu().tolist()]
             _R._D_HINT[("surfel", N, H, W, V)] = d_host
+            if len(_R._D_HINT) > 64:
+                _R._D_HINT.pop(next(iter(_R._D_HINT)))
             for v, st in enumerate(states):
                 st.D = d_host[v]
                 need = lib.gdr_binning_bytes(st.D)
