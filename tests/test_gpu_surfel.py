@@ -391,7 +391,7 @@ def test_surfel_multiview_node_and_fused_loss_match_the_per_view_sequence(V):
     wts = torch.tensor([0.7, 1.9, 1.0, 0.4, 1.3, 2.2, 0.9, 1.6, 0.5][:V], device=dev)
 
     def run(mode):
-        r = Renderer(sh_degree=3, fused=(mode != "reference"))
+        r = Renderer(sh_degree=3, fused=(mode not in ("reference", "folded_loss_torch_activations")))
         leaves = {k: v.to(dev).clone().requires_grad_(True) for k, v in sc.items()}
         ssp = torch.zeros(n, 4, device=dev, requires_grad=True)
         args = (leaves["centers"], leaves["shs"], leaves["opacity"], leaves["scales"], leaves["rotations"], dev)
@@ -414,7 +414,7 @@ def test_surfel_multiview_node_and_fused_loss_match_the_per_view_sequence(V):
         return lv.detach().cpu().numpy(), {k: g_.cpu().numpy() for k, g_ in zip(list(leaves) + ["ssp"], grads)}
 
     l_ref, g_ref = run("reference")
-    for mode in ("views", "fused_loss", "folded_loss"):
+    for mode in ("views", "fused_loss", "folded_loss", "folded_loss_torch_activations"):
         l, g = run(mode)
         np.testing.assert_allclose(l, l_ref, rtol=2e-5, err_msg=mode)
         for k in g_ref:
