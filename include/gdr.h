@@ -200,6 +200,9 @@ int gdr_binning_carve(void* base, uint64_t D, gdr_binning* out);
 int gdr_image_carve(void* base, int32_t H, int32_t W, gdr_image* out);
 
 /* ---- forward ---------------------------------------------------------------------
+ * gdr_preprocess_forward + gdr_render_forward (or gdr_forward = both) replace the forward half of the extension,
+ * `_C.rasterize_gaussians`, reached from `rasterizer(means3D=…, …)` at /root/reference/lightning/renderer.py:250-259 and
+ * /root/reference/lightning/point_decoder/layers/gaussian_renderer.py:88-108.
  * Stage 1 (K1 + K2): per-Gaussian projection, EWA covariance, SH colour, tile rect,
  * and the scan total.  radii is written here.  If num_rendered_host != NULL the
  * stream is synchronised and D is returned through it (the one host read the
@@ -246,7 +249,10 @@ int gdr_forward(const gdr_settings* s, const gdr_inputs* in, const gdr_geom* geo
                 gdr_binning* bin, const gdr_image* img, uint64_t D_cap, const gdr_outputs* out,
                 uint32_t* num_rendered_host, void* stream);
 
-/* ---- backward (K7 + K8/K9) -------------------------------------------------------- */
+/* ---- backward (K7 + K8/K9) --------------------------------------------------------
+ * Replaces `_C.rasterize_gaussians_backward`, reached through autograd from the losses on the render outputs
+ * (/root/reference/lightning/network.py:746-752, 836, 854, 971) and through `vjp` w.r.t. the (N,4) means2D carrier
+ * (/root/reference/lightning/network.py:865-878). */
 int gdr_backward(const gdr_settings* s, const gdr_inputs* in, const gdr_geom* geom,
                  const gdr_binning* bin, const gdr_image* img, uint64_t D,
                  const int32_t* radii, const gdr_grad_inputs* gin, const gdr_grad_outputs* gout,
