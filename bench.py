@@ -2,7 +2,12 @@
 """bench.py — views/sec forward+backward @ 800x800 of the Gaussian-splatting render path
 (BASELINE.json `metric`), on N GPUs of one node, one rank per GPU.
 
-    python bench.py [--gpus N --steps K --warmup W]          (N>1: launched by torch.distributed.run)
+    python bench.py [--gpus N --steps K --warmup W]
+
+N>1: one rank per GPU over RCCL.  Either launched by `python -m torch.distributed.run --nproc-per-node N ...
+bench.py --gpus N` (RANK / LOCAL_RANK / WORLD_SIZE in the environment), or — when WORLD_SIZE is unset — bench.py
+re-executes ITSELF under torch.distributed.run with N ranks.  WORLD_SIZE != --gpus is an error, never a silent
+one-GPU run.
 
 A "step" = one pass of the hot path over one batch: every view of this rank's shard is
 rendered through the reference boundary (`Renderer.render_img` -> `GaussianRasterizer`,
@@ -118,10 +123,14 @@ def main():
                     help="call render_img + backward once per view (the reference's loop) instead of render_views")
     ap.add_argument("--unfused", action="store_true",
                     help="torch activations before the rasterizer, op for op as lightning/renderer.py:225-230")
-    ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL on ROCm)")
+    ap.add_argument("--dist-backend", default=None,
+                    help="torch.distributed backend (default nccl = RCCL on ROCm; gloo with --single-device, because RCCL "
+                         "refuses two ranks on one device)")
     ap.add_argument("--layout", default="cube", choices=["cube", "shell"],
                     help="scene layout: cube = the BASELINE workloads (uniform in the reference's scene cube); shell = "
                          "object-like stand-in with skewed tile lists (not a BASELINE number)")
+    ap.add_argument("--order", default="random", choices=["random", "morton"],
+                    help="memory order of the Gaussians: random (default, the worst case) or 3D Morton order")
     ap.add_argument("--host-profile", action="store_true",
                     help="cProfile of the host side of the timed steps (top entries to stderr; slows the run)")
     ap.add_argument("--force-dist", action="store_true",
@@ -135,6 +144,22 @@ def main():
                     help="per-kernel HBM bytes per launch measured with rocprofv3 --pmc (scripts/gpu_pmc.sh); "
                          "{workload: {kernel: bytes}}; missing file/entry -> traffic null")
     args = ap.parse_args()
+    if args.dist_backend is None:
+        args.dist_backend = "gloo" if args.single_device else "nccl"
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # not under a launcher: become N ranks (one per GPU; --single-device: N ranks on cuda:0 over gloo)
+        import socket
+        import subprocess
+        sk = socket.socket()
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+        sk.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), "--", os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        raise SystemExit(subprocess.call(cmd, env=env))
 
     # stdout carries exactly ONE line (the JSON result).  Libraries that write to file descriptor 1 from C (RCCL
     # prints a version banner on rank 0 when the first communicator is created) are sent to stderr instead.
@@ -145,6 +170,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a {world}-rank run "
+                         f"as a {args.gpus}-GPU number")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (no CPU fallback for the product path)")
     if args.single_device:
@@ -166,7 +194,11 @@ def main():
                 dist.init_process_group("nccl")
         else:
             dist.init_process_group(args.dist_backend)
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if use_dist and dist.get_world_size() != args.gpus:
+        raise SystemExit(f"bench.py: process group has {dist.get_world_size()} ranks, --gpus {args.gpus}")
+    if world > 1 and not args.single_device and torch.cuda.device_count() < world:
+        raise SystemExit(f"bench.py: {world} ranks but only {torch.cuda.device_count()} visible GPUs "
+                         "(--single-device runs every rank on cuda:0 for a smoke test)")
 
     from generativedensification_amd import _lib as L
     from generativedensification_amd.camera import orbit_cameras
@@ -184,12 +216,14 @@ def main():
     n, h, w, deg, vpg = wl["n"], wl["h"], wl["w"], wl["deg"], wl["views_per_gpu"]
     total_views = vpg * world
     if args.workload == "c3" and not args.n:  # two populations of different size (coarse grid + densified points)
-        a = make_scene(262_144, wl["seed"], sh_degree=deg, sigma0=(0.0052,), device=dev, layout=args.layout)
-        b = make_scene(81_600, wl["seed"] + 1, sh_degree=deg, sigma0=(0.00065,), device=dev, layout=args.layout)
+        a = make_scene(262_144, wl["seed"], sh_degree=deg, sigma0=(0.0052,), device=dev, layout=args.layout,
+                       order=args.order)
+        b = make_scene(81_600, wl["seed"] + 1, sh_degree=deg, sigma0=(0.00065,), device=dev, layout=args.layout,
+                       order=args.order)
         scene = {k: torch.cat([a[k], b[k]]).contiguous() for k in a}
     else:
         scene = make_scene(n, wl["seed"], sh_degree=deg, sigma0=wl["sigma0"] or (0.0052,), device=dev,
-                           layout=args.layout)
+                           layout=args.layout, order=args.order)
     surfel = bool(wl.get("surfel"))
     if surfel:
         scene["scales"] = scene["scales"][:, :2].contiguous()
@@ -415,10 +449,11 @@ def main():
     if rank == 0:
         out = {
             "metric": "views/sec fwd+bwd @ 800x800", "value": round(views_per_sec, 2), "unit": "views/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+            "n_gpus": world, "world_size": dist.get_world_size() if use_dist else 1,
+            "dist_backend": (dist.get_backend() if use_dist else None), "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic (seeded random Gaussians with the decoder's statistics, random targets)",
-            "config": {"workload": f"{args.workload}: {wl['desc']}", "n_gaussians": n, "layout": args.layout,
+            "config": {"workload": f"{args.workload}: {wl['desc']}", "n_gaussians": n, "layout": args.layout, "order": args.order,
                        "views_per_gpu": vpg, "image": [h, w], "sh_degree": deg,
                        "num_rendered_per_view": int(d_mean), "parallelism": f"view-sharded x{world}",
                        "grad_allreduce": bool(args.grad_allreduce),

@@ -24,7 +24,10 @@ static std::vector<ProfRec> g_prof_pending;
 static std::vector<hipEvent_t> g_prof_pool;
 static double g_prof_ms[GDR_K_COUNT];
 static uint64_t g_prof_cnt[GDR_K_COUNT];
-static hipEvent_t g_prof_open = nullptr;
+// the event opened by prof_begin and closed by the prof_end that follows it on the SAME host thread (GDR_LAUNCH
+// brackets one launch): per thread, so that two host threads driving distinct workspaces with profiling on do not
+// pair each other's events (the shared tables below are guarded by the mutex)
+static thread_local hipEvent_t g_prof_open = nullptr;
 static std::mutex g_prof_mu;
 
 static hipEvent_t prof_event() {
@@ -92,8 +95,7 @@ static size_t carve_binning(void* base, uint64_t D, gdr_binning* b) {
     t.scratch32 = c.take<uint32_t>(2 * d);
     t.sorted = 0;
     t.global_sort = 0;
-    static const int seg_len_env = getenv("GDR_SEG_LEN") ? atoi(getenv("GDR_SEG_LEN")) : 2048;
-    t.seg_len = seg_len_env > 0 ? ((seg_len_env + GDR_BLOCK - 1) / GDR_BLOCK) * GDR_BLOCK : 0;
+    t.seg_len = GDR_DEFAULT_SEG_LEN;  // callers may raise it (a multiple of 256) or set 0 after carving (include/gdr.h)
     t.seg_cap = t.seg_len ? (int32_t)(D / (uint64_t)t.seg_len + 1) : 0;
     t.seg_extra = c.take<uint32_t>(2 * (size_t)(t.seg_cap ? t.seg_cap : 1));
     t.seg_count = c.take<uint32_t>(2);
@@ -346,6 +348,7 @@ int gdr_backward(const gdr_settings* s, const gdr_inputs* in, const gdr_geom* ge
     (void)D;
     int rc = check_common(s, in);
     if (rc) return rc;
+    if (in->N == 0) return GDR_OK;  // no Gaussians: the (empty) gradient buffers may be NULL
     if (!geom || !bin || !img || !gin || !gout || !gin->dL_dcolor || !gout->dL_dmeans3D ||
         !gout->dL_dmeans2D || !gout->dL_dopacities || !gout->scratch || (in->N > 0 && !radii)) {
         set_error("backward: NULL argument", hipSuccess);
@@ -657,6 +660,7 @@ int gsr_backward(const gdr_settings* s, const gsr_inputs* in, const gdr_geom* ge
     (void)D;
     int rc = check_surfel(s, in);
     if (rc) return rc;
+    if (in->N == 0) return GDR_OK;  // no surfels: the (empty) gradient buffers may be NULL
     if (!geom || !bin || !img || !gin || !gout || !gin->dL_dcolor || !gout->dL_dmeans3D || !gout->dL_dmeans2D ||
         !gout->dL_dopacities || !gout->scratch || (in->N > 0 && !radii)) {
         set_error("surfel backward: NULL argument", hipSuccess);

@@ -14,7 +14,10 @@
 namespace gdr {
 namespace {
 
-__device__ __forceinline__ float nan0(float v) { return (v != v || v == INFINITY) ? 0.f : v; }  // nan_to_num(x, 0, 0)
+// torch.nan_to_num(x, 0, 0) of renderer_2dgs.py:249,254: nan -> 0, +inf -> 0, and -inf -> the most negative finite
+// float (neginf is left at its default there); none of the three passes a gradient
+#define GSR_NEG_MAX (-3.402823466e+38f)
+__device__ __forceinline__ float nan0(float v) { return (v != v || v == INFINITY) ? 0.f : (v == -INFINITY ? GSR_NEG_MAX : v); }
 
 struct Maps {
     const float* allmap; const float* rays; int H, W; float r;
@@ -24,10 +27,11 @@ struct Maps {
 __device__ __forceinline__ float surf_depth(const Maps& m, int q, size_t P, bool* exp_ok, bool* med_ok) {
     const float D = m.allmap[q], a = m.allmap[P + q], med = m.allmap[5 * P + q];
     const float e = D / a;
-    const bool eo = !(e != e) && e != INFINITY, mo = !(med != med) && med != INFINITY;
+    // differentiable only where the value is finite (nan_to_num's backward masks nan and both infinities)
+    const bool eo = !(e != e) && e != INFINITY && e != -INFINITY, mo = !(med != med) && med != INFINITY && med != -INFINITY;
     if (exp_ok) *exp_ok = eo;
     if (med_ok) *med_ok = mo;
-    return (1.f - m.r) * (eo ? e : 0.f) + m.r * (mo ? med : 0.f);
+    return (1.f - m.r) * nan0(e) + m.r * nan0(med);
 }
 
 __device__ __forceinline__ void point_at(const Maps& m, int q, size_t P, float* p) {

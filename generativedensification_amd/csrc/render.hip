@@ -36,6 +36,14 @@
 #include "gdr_common.h"
 #include "render_common.h"
 
+// GDR_ABLATE (measurement builds only, scripts/ablate_build.sh -> build/libgdr_abl<k>.so; results are WRONG):
+//   1 K7 without the atomics            2 K7 without row reduction + atomics     3 K6/K7 gather records by list
+//   4 K6/K7 stage the slices but skip the inner loops                              position instead of by sorted id
+//   5 K7 without exp/rcp (constants)    6 K6/K7 inner loop without the LDS entry reads (registers reused)
+#ifndef GDR_ABLATE
+#define GDR_ABLATE 0
+#endif
+
 namespace gdr {
 
 namespace {
@@ -251,7 +259,8 @@ __global__ __launch_bounds__(GDR_BLOCK) void render_fwd_kernel(
         float4 r_xe = make_float4(0.f, 0.f, 0.f, 0.f), r_co = r_xe, r_cd = r_xe;
         bool r_valid = (int)threadIdx.x < count;
         if (r_valid) {
-            const uint32_t id = point_list[first + threadIdx.x];
+            uint32_t id = point_list[first + threadIdx.x];
+            if (GDR_ABLATE == 3) id = (first + threadIdx.x) & 0xFFFFFu;  // (needs N >= 2^20)
             const float4 a0 = rec[4 * (size_t)id], a3 = rec[4 * (size_t)id + 3];
             r_xe = make_float4(a0.x, a0.y, a3.x, a3.y); r_co = rec[4 * (size_t)id + 1]; r_cd = rec[4 * (size_t)id + 2];
         }
@@ -266,12 +275,13 @@ __global__ __launch_bounds__(GDR_BLOCK) void render_fwd_kernel(
                 const int nxt = (r + 1) * GDR_BLOCK + (int)threadIdx.x;
                 r_valid = nxt < count;
                 if (r_valid) {
-                    const uint32_t id = point_list[first + (uint32_t)nxt];
+                    uint32_t id = point_list[first + (uint32_t)nxt];
+                    if (GDR_ABLATE == 3) id = (first + (uint32_t)nxt) & 0xFFFFFu;
                     const float4 a0 = rec[4 * (size_t)id], a3 = rec[4 * (size_t)id + 3];
                     r_xe = make_float4(a0.x, a0.y, a3.x, a3.y); r_co = rec[4 * (size_t)id + 1]; r_cd = rec[4 * (size_t)id + 2];
                 }
             }
-            if (live == 0ull) continue;
+            if (live == 0ull || GDR_ABLATE == 4) continue;
             const uint32_t base = (uint32_t)(pos0 + r * GDR_BLOCK) + 1u;
 #pragma unroll 1
             for (int g = 0; g < GDR_BLOCK / GDR_WAVE; ++g) {
@@ -286,6 +296,12 @@ __global__ __launch_bounds__(GDR_BLOCK) void render_fwd_kernel(
                 bool abort = false;
                 auto fetch = [&](Entry& en) {
                     en.e = min(take_bit(mr), nulloff) + goff;  // 0xFFFFFFFF (no entry) -> null entry
+                    if (GDR_ABLATE == 6) {
+                        const float f_ = (float)en.e;
+                        en.m = make_float2(pxf + 0.3f, pyf + f_ * 1e-3f); en.co = make_float4(0.5f, 0.1f, 0.5f, en.e < GDR_NULL_ENTRY ? 0.5f : 0.f);
+                        en.cd = make_float4(f_, 0.5f, 0.25f, 2.f);
+                        return;
+                    }
                     en.m = lds.xy[en.e]; en.co = lds.co[en.e]; en.cd = lds.cd[en.e];
                 };
                 auto composite = [&](const Entry& en) {
@@ -479,6 +495,7 @@ __global__ __launch_bounds__(GDR_BLOCK) void render_bwd_kernel(
     }
     // the staged conic is log2(e) x the true one: fold 1/log2(e) = ln 2 into the pixel->NDC factors
     const float kx = 0.5f * (float)W * GDR_LN2, ky = 0.5f * (float)H * GDR_LN2;
+    float abl_sink = 0.f;  // (ablation builds: keeps the arithmetic alive)
 
     // deepest contributor per 4x4 block (row of 16 lanes) and per wave
     int row_last = last_contributor;
@@ -496,6 +513,7 @@ __global__ __launch_bounds__(GDR_BLOCK) void render_bwd_kernel(
     bool r_valid = (int)threadIdx.x < total;
     if (r_valid) {
         r_id = point_list[list_end - 1u - threadIdx.x];
+        if (GDR_ABLATE == 3) r_id = (list_end - 1u - threadIdx.x) & 0xFFFFFu;
         { const float4 a0 = rec[4 * (size_t)r_id], a3 = rec[4 * (size_t)r_id + 3];
           r_xe = make_float4(a0.x, a0.y, a3.x, a3.y); r_co = rec[4 * (size_t)r_id + 1]; r_cd = rec[4 * (size_t)r_id + 2]; }
     }
@@ -509,12 +527,13 @@ __global__ __launch_bounds__(GDR_BLOCK) void render_bwd_kernel(
             r_valid = nxt < total;
             if (r_valid) {
                 r_id = point_list[list_end - 1u - (uint32_t)nxt];
+                if (GDR_ABLATE == 3) r_id = (list_end - 1u - (uint32_t)nxt) & 0xFFFFFu;
                 { const float4 a0 = rec[4 * (size_t)r_id], a3 = rec[4 * (size_t)r_id + 3];
           r_xe = make_float4(a0.x, a0.y, a3.x, a3.y); r_co = rec[4 * (size_t)r_id + 1]; r_cd = rec[4 * (size_t)r_id + 2]; }
             }
         }
         const int top = total - 1 - r * GDR_BLOCK;  // list position of LDS entry e: top - e
-        if (top - (GDR_BLOCK - 1) >= wave_last) continue;  // whole slice behind every last contributor
+        if (top - (GDR_BLOCK - 1) >= wave_last || GDR_ABLATE == 4) continue;  // whole slice behind every last contributor
         // Row sub-lists of the slice's four 64-entry groups, one 64-bit mask per group and lane (all 16 lanes of a row
         // hold the same four masks).  A row walks them back to back at its own pace — rows only re-synchronise at slice
         // boundaries, so a row whose block has few entries in one group does not wait for the others there.
@@ -535,13 +554,19 @@ __global__ __launch_bounds__(GDR_BLOCK) void render_bwd_kernel(
             auto fetch = [&](Entry& en) __attribute__((always_inline)) {
                 const uint32_t goff = gi << 6;
                 en.e = min(take_bit(mr), GDR_NULL_ENTRY - goff) + goff;  // 0xFFFFFFFF (no entry) -> null entry
+                if (GDR_ABLATE == 6) {
+                    const float f_ = (float)en.e;
+                    en.m = make_float2(pxf + 0.3f, pyf + f_ * 1e-3f); en.co = make_float4(0.5f, 0.1f, 0.5f, en.e < GDR_NULL_ENTRY ? 0.5f : 0.f);
+                    en.cd = make_float4(f_, 0.5f, 0.25f, 2.f);
+                } else {
                 en.m = lds.xy[en.e]; en.co = lds.co[en.e]; en.cd = lds.cd[en.e];
+                }
                 if (__ballot(mr == 0ull && gi < 3u) != 0ull) GDR_REFILL(mr, gi, q1, q2, q3);
             };
             auto accumulate = [&](const Entry& en) {
                 const float dx = en.m.x - pxf, dy = en.m.y - pyf;
                 const float p2 = gauss_power(dx, dy, en.co.x, en.co.y, en.co.z);
-                const float G = __builtin_amdgcn_exp2f(p2);
+                const float G = GDR_ABLATE == 5 ? p2 * 0.001f + 0.5f : __builtin_amdgcn_exp2f(p2);
                 float alpha = fminf(0.99f, en.co.w * G);
                 alpha = (p2 > 0.f) ? 0.f : alpha;
                 // contributes iff it did in the forward: alpha >= 1/255 and position < last_contributor
@@ -552,7 +577,7 @@ __global__ __launch_bounds__(GDR_BLOCK) void render_bwd_kernel(
                 if (hb == 0ull) return;
                 const float a = hit ? alpha : 0.f;
                 const float hm = hit ? 1.f : 0.f;
-                const float r_oma = __builtin_amdgcn_rcpf(1.f - a);  // == 1 when a == 0
+                const float r_oma = GDR_ABLATE == 5 ? 1.f + a : __builtin_amdgcn_rcpf(1.f - a);  // == 1 when a == 0
                 T = T * r_oma;                                        // transmittance in FRONT of this Gaussian
                 const float w = a * T;
                 const float d0 = en.cd.x - B0, d1 = en.cd.y - B1, d2 = en.cd.z - B2;
@@ -580,7 +605,16 @@ __global__ __launch_bounds__(GDR_BLOCK) void render_bwd_kernel(
                 const float vals[12] = {v_mx, v_my, fabsf(v_mx), fabsf(v_my),
                                         -0.5f * gdx * dx * dL_dG, -gdx * dy * dL_dG, -0.5f * gdy * dy * dL_dG,
                                         w * gD, w * gC0, w * gC1, w * gC2, G * dL_dalpha};
-                const float tot = row_reduce_scatter12(vals, li);
+                float tot;
+                if (GDR_ABLATE == 2) {
+                    tot = 0.f;
+#pragma unroll
+                    for (int k_ = 0; k_ < 12; ++k_) tot += vals[k_];
+                    abl_sink += tot;
+                    return;
+                }
+                tot = row_reduce_scatter12(vals, li);
+                if (GDR_ABLATE == 1) { abl_sink += tot; return; }
                 const bool publish = ((hb >> (16 * row)) & 0xFFFFull) != 0ull;
                 // lanes 0..11 of every row that had a hit add the row totals to the Gaussian's
                 // 64-byte gradient record: one global_atomic_add_f32 instruction, one cache line
@@ -602,6 +636,7 @@ __global__ __launch_bounds__(GDR_BLOCK) void render_bwd_kernel(
             }
         }
     }
+    if (GDR_ABLATE && abl_sink == 12345.678f) grad_rec[0] = abl_sink;
 }
 
 }  // namespace

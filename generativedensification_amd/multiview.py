@@ -80,14 +80,20 @@ def gather_view_losses(local_losses: torch.Tensor, n_views: int | None = None) -
 def allreduce_gaussian_grads(params: Sequence[torch.Tensor]) -> None:
     """Sum the per-Gaussian attribute gradients over ranks: one packed buffer
     (236 B/Gaussian at SH degree 3) moved as reduce-scatter + all-gather so that all
-    7 xGMI links of a GPU carry 1/G of it each, instead of a per-tensor ring all-reduce."""
+    7 xGMI links of a GPU carry 1/G of it each, instead of a per-tensor ring all-reduce.
+
+    Participation is unconditional and the buffer layout is rank-invariant: EVERY tensor of `params` takes part
+    with its full size (a missing .grad counts as zeros and is created), so a rank whose shard is empty
+    (n_views < world) or that produced gradients for only some tensors issues the same two collectives with the
+    same sizes as every other rank.  After the call every rank holds the summed gradient in every p.grad."""
     if _no_peers():
         return
     world = dist.get_world_size()
-    grads = [p.grad for p in params if p.grad is not None]
-    if not grads:
+    params = list(params)
+    if not params:
         return
-    flat = torch.cat([g.reshape(-1) for g in grads])
+    flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).to(params[0].dtype)
+                      for p in params])
     n = flat.numel()
     padded = (n + world - 1) // world * world
     if padded != n:
@@ -96,6 +102,10 @@ def allreduce_gaussian_grads(params: Sequence[torch.Tensor]) -> None:
     dist.reduce_scatter_tensor(shard, flat, op=dist.ReduceOp.SUM)
     dist.all_gather_into_tensor(flat, shard)
     off = 0
-    for g in grads:
-        g.copy_(flat[off: off + g.numel()].view_as(g))
-        off += g.numel()
+    for p in params:
+        g = flat[off: off + p.numel()].view_as(p).to(p.dtype)
+        if p.grad is None:
+            p.grad = g.clone()
+        else:
+            p.grad.copy_(g)
+        off += p.numel()

@@ -151,9 +151,11 @@ _BIN_STREAM_ENV = _os.environ.get("GDR_BIN_STREAM")
 BIN_STREAM = None if _BIN_STREAM_ENV is None else max(0, int(_BIN_STREAM_ENV))
 
 
-# Segment length of cut tile lists (include/gdr.h gdr_binning.seg_len): None = the library default (2048, or
-# GDR_SEG_LEN), 0 = lists are never cut, otherwise a multiple of 256.  Tests switch it per call.
-SEG_LEN = None
+# Segment length of cut tile lists (include/gdr.h gdr_binning.seg_len): None = the library default
+# (GDR_DEFAULT_SEG_LEN = 2048), 0 = lists are never cut, otherwise a multiple of 256 >= 2048 (the tables are carved for
+# 2048).  Tests switch it per call; GDR_SEG_LEN in the environment presets it (host-side policy: the library itself
+# reads no environment variable).
+SEG_LEN = int(_os.environ["GDR_SEG_LEN"]) if _os.environ.get("GDR_SEG_LEN") else None
 
 
 def _apply_seg_len(bin_struct, D):
@@ -303,6 +305,20 @@ def backward_raw(st: _State, keep, raster_settings, radii, grad_color, grad_dept
     return g
 
 
+def _save_inputs(ctx, keep, n=7):
+    """The n f32 input tensors of a node go through ctx.save_for_backward, as in the upstream extension: autograd's
+    version counters then turn an in-place update between forward and backward (an optimizer step, a densification
+    write) into an error instead of K9 silently differentiating the modified values, and the buffers are released with
+    the graph.  The rest of `keep` (device copies of the settings that side-stream kernels may still read, ints) only
+    has to stay alive."""
+    ctx.save_for_backward(*keep[:n])
+    ctx.keep_rest = list(keep[n:])
+
+
+def _saved_inputs(ctx):
+    return list(ctx.saved_tensors) + ctx.keep_rest
+
+
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
@@ -311,7 +327,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings)
         ctx.raster_settings = raster_settings
         ctx.state = st
-        ctx.keep = keep
+        _save_inputs(ctx, keep)
         ctx.radii = radii
         ctx.means2D_shape = tuple(means2D.shape)
         ctx.in_dtypes = tuple(t.dtype for t in (means3D, means2D, sh, colors_precomp, opacities, scales,
@@ -321,7 +337,7 @@ class _RasterizeGaussians(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_color, grad_radii, grad_depth, grad_alpha):
-        g = backward_raw(ctx.state, ctx.keep, ctx.raster_settings, ctx.radii, grad_color, grad_depth,
+        g = backward_raw(ctx.state, _saved_inputs(ctx), ctx.raster_settings, ctx.radii, grad_color, grad_depth,
                          grad_alpha)
         gm2 = g["means2D"]
         cols = ctx.means2D_shape[1] if len(ctx.means2D_shape) == 2 else 4
@@ -505,7 +521,8 @@ class _RenderViews(torch.autograd.Function):
     def forward(ctx, means3D, means2D, sh, opacities, scales, rotations, settings_list, flags):
         colors, radii, depths, alphas, states, keep, in_dtypes = _forward_views_impl(
             means3D, means2D, sh, opacities, scales, rotations, settings_list, flags)
-        ctx.states, ctx.keep, ctx.settings_list, ctx.flags = states, keep, settings_list, flags
+        ctx.states, ctx.settings_list, ctx.flags = states, settings_list, flags
+        _save_inputs(ctx, keep)
         ctx.radii, ctx.in_dtypes, ctx.means2D_shape = radii, in_dtypes, tuple(means2D.shape)
         ctx.mark_non_differentiable(radii)
         return (radii, *colors, *depths, *alphas)
@@ -513,7 +530,7 @@ class _RenderViews(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_radii, *g_views):
         lib = L.load()
-        means3D, opacities, sh, e, scales, rotations, _ = ctx.keep[:7]
+        means3D, opacities, sh, e, scales, rotations, _ = _saved_inputs(ctx)[:7]
         dev = means3D.device
         states = ctx.states
         N, M, V = states[0].N, states[0].M, len(states)
@@ -588,7 +605,8 @@ class _RenderViewsLoss(torch.autograd.Function):
         colors, radii, depths, alphas, states, keep, in_dtypes = _forward_views_impl(
             means3D, means2D, sh, opacities, scales, rotations, settings_list, flags,
             loss_spec=(targets, w_depth, w_alpha, losses))
-        ctx.states, ctx.keep, ctx.settings_list, ctx.flags = states, keep, settings_list, flags
+        ctx.states, ctx.settings_list, ctx.flags = states, settings_list, flags
+        _save_inputs(ctx, keep)
         ctx.radii, ctx.in_dtypes, ctx.means2D_shape = radii, in_dtypes, tuple(means2D.shape)
         ctx.colors, ctx.targets, ctx.w = colors, targets, (float(w_depth), float(w_alpha))
         ctx.mark_non_differentiable(radii)
@@ -597,7 +615,7 @@ class _RenderViewsLoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_losses, g_radii):
         lib = L.load()
-        means3D, opacities, sh, e, scales, rotations, _ = ctx.keep[:7]
+        means3D, opacities, sh, e, scales, rotations, _ = _saved_inputs(ctx)[:7]
         dev = means3D.device
         states = ctx.states
         N, M, V = states[0].N, states[0].M, len(states)
@@ -647,22 +665,50 @@ class _RenderViewsLoss(torch.autograd.Function):
         return (*grads, None, None, None, None, None)
 
 
+def _size_groups(settings_list):
+    """Views grouped by image size, in first-appearance order: [(indices, settings)], one multi-view node each."""
+    groups: dict = {}
+    for v, rs in enumerate(settings_list):
+        groups.setdefault((int(rs.image_height), int(rs.image_width)), []).append(v)
+    return [(idx, [settings_list[v] for v in idx]) for idx in groups.values()]
+
+
 def render_views_loss_raw(means3D, means2D, sh, opacities, scales, rotations, settings_list, targets_chw, w_depth=0.1,
                           w_alpha=0.1, flags=RAW_ALL):
     """Per-view losses (V,) of V views of one Gaussian set with the loss folded into K6/K7; targets_chw: V tensors
-    (3,H,W).  Returns (losses, radii)."""
-    return _RenderViewsLoss.apply(means3D, means2D, sh, opacities, scales, rotations, list(settings_list), int(flags),
-                                  list(targets_chw), float(w_depth), float(w_alpha))
+    (3,H,W).  Returns (losses, radii).  Views of different image sizes are rendered by one node per size."""
+    groups = _size_groups(settings_list)
+    if len(groups) <= 1:
+        return _RenderViewsLoss.apply(means3D, means2D, sh, opacities, scales, rotations, list(settings_list), int(flags),
+                                      list(targets_chw), float(w_depth), float(w_alpha))
+    V = len(settings_list)
+    losses, radii = [None] * V, [None] * V
+    for idx, sets in groups:
+        l, r = _RenderViewsLoss.apply(means3D, means2D, sh, opacities, scales, rotations, sets, int(flags),
+                                      [targets_chw[v] for v in idx], float(w_depth), float(w_alpha))
+        for k, v in enumerate(idx):
+            losses[v], radii[v] = l[k], r[k]
+    return torch.stack(losses), torch.stack(radii)
 
 
 def render_views_raw(means3D, means2D, sh, opacities, scales, rotations, settings_list, flags=RAW_ALL):
     """V views of one Gaussian set in one autograd node.  With flags=RAW_ALL the opacity /
     scale / rotation tensors are the adaptor's RAW (pre-activation) tensors.
     Returns (colors, radii (V,N) int32, depths, alphas) with colors / depths / alphas LISTS of V per-view
-    tensors (3,H,W) / (1,H,W) / (1,H,W)."""
+    tensors (3,H,W) / (1,H,W) / (1,H,W).  Views of different image sizes (the multi-view kernels need one size per
+    launch) are rendered by one node per size, like the surfel twin does."""
     V = len(settings_list)
-    out = _RenderViews.apply(means3D, means2D, sh, opacities, scales, rotations, tuple(settings_list), int(flags))
-    return list(out[1:1 + V]), out[0], list(out[1 + V:1 + 2 * V]), list(out[1 + 2 * V:1 + 3 * V])
+    groups = _size_groups(settings_list)
+    if len(groups) <= 1:
+        out = _RenderViews.apply(means3D, means2D, sh, opacities, scales, rotations, tuple(settings_list), int(flags))
+        return list(out[1:1 + V]), out[0], list(out[1 + V:1 + 2 * V]), list(out[1 + 2 * V:1 + 3 * V])
+    colors, radii, depths, alphas = [None] * V, [None] * V, [None] * V, [None] * V
+    for idx, sets in groups:
+        n = len(idx)
+        out = _RenderViews.apply(means3D, means2D, sh, opacities, scales, rotations, tuple(sets), int(flags))
+        for k, v in enumerate(idx):
+            colors[v], radii[v], depths[v], alphas[v] = out[1 + k], out[0][k], out[1 + n + k], out[1 + 2 * n + k]
+    return colors, torch.stack(radii), depths, alphas
 
 
 def screenspace_absgrad_raw(means3D, sh, opacities, scales, rotations, settings_list, gt_images, flags=RAW_ALL, topk=0):

@@ -149,7 +149,8 @@ class _RasterizeSurfels(torch.autograd.Function):
                 raster_settings, flags=0):
         color, radii, allmap, st, keep = forward_raw(means3D, sh, colors_precomp, opacities, scales, rotations,
                                                      transMat_precomp, raster_settings, flags)
-        ctx.raster_settings, ctx.state, ctx.keep, ctx.radii = raster_settings, st, keep, radii
+        ctx.raster_settings, ctx.state, ctx.radii = raster_settings, st, radii
+        _R._save_inputs(ctx, keep)
         ctx.means2D_shape = tuple(means2D.shape)
         ctx.tm_shape = tuple(transMat_precomp.shape)
         ctx.in_dtypes = tuple(t.dtype for t in (means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
@@ -159,7 +160,7 @@ class _RasterizeSurfels(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_color, grad_radii, grad_allmap):
-        g = backward_raw(ctx.state, ctx.keep, ctx.raster_settings, ctx.radii, grad_color, grad_allmap)
+        g = backward_raw(ctx.state, _R._saved_inputs(ctx), ctx.raster_settings, ctx.radii, grad_color, grad_allmap)
         gm2 = g["means2D"]
         cols = ctx.means2D_shape[1] if len(ctx.means2D_shape) == 2 else 4
         if cols == 3:  # upstream's (N,3) carrier: xy signal, z = 0
@@ -293,7 +294,8 @@ def _surfel_forward_views_impl(ctx, means3D, means2D, sh, opacities, scales, rot
                     L.check(lib.gsr_render_forward(C.byref(structs[v]), C.byref(inp), C.byref(st.geom), C.byref(st.bin),
                                                    C.byref(st.img), st.D, C.byref(out), stream), "gsr_render_forward")
                     view_loss(v, stream)
-        ctx.states, ctx.keep, ctx.settings_list, ctx.radii, ctx.flags = states, keep, settings_list, radii, int(flags)
+        ctx.states, ctx.settings_list, ctx.radii, ctx.flags = states, settings_list, radii, int(flags)
+        _R._save_inputs(ctx, keep)
         ctx.means2D_shape, ctx.in_dtypes, ctx.V = tuple(means2D.shape), in_dtypes, V
         ctx.mark_non_differentiable(radii)
         return radii, colors, allmaps
@@ -310,7 +312,7 @@ class _RenderSurfelViews(torch.autograd.Function):
     def backward(ctx, g_radii, *g):
         lib = L.load()
         V = ctx.V
-        means3D, opacities, sh, _, scales, rotations, _, flags = ctx.keep[:8]
+        means3D, opacities, sh, _, scales, rotations, _, flags = _R._saved_inputs(ctx)[:8]
         dev = means3D.device
         N, M = int(means3D.shape[0]), int(sh.shape[1])
         f32 = dict(dtype=torch.float32, device=dev)
@@ -419,7 +421,7 @@ class _RenderSurfelViewsLoss(torch.autograd.Function):
         lib = L.load()
         V = ctx.V
         colors, allmaps, rays, views, targets, wts = ctx.loss_in
-        means3D, opacities, sh, _, scales, rotations, _, flags = ctx.keep[:8]
+        means3D, opacities, sh, _, scales, rotations, _, flags = _R._saved_inputs(ctx)[:8]
         dev = means3D.device
         N, M = int(means3D.shape[0]), int(sh.shape[1])
         H, W = ctx.states[0].H, ctx.states[0].W

@@ -7,7 +7,20 @@ import math
 import torch
 
 
-def make_scene(n: int, seed: int, sh_degree: int = 3, sigma0=(0.0052, 0.00065), device="cpu", layout="cube"):
+def morton_order(centers: torch.Tensor, bits: int = 10) -> torch.Tensor:
+    """Permutation that sorts points by the 3D Morton code of their position in their bounding box."""
+    c = centers.detach().float().cpu()
+    lo, hi = c.min(0).values, c.max(0).values
+    q = ((c - lo) / (hi - lo).clamp_min(1e-12) * (2 ** bits - 1)).long().clamp_(0, 2 ** bits - 1)
+    code = torch.zeros(c.shape[0], dtype=torch.long)
+    for b in range(bits):
+        for a in range(3):
+            code |= ((q[:, a] >> b) & 1) << (3 * b + a)
+    return torch.argsort(code)
+
+
+def make_scene(n: int, seed: int, sh_degree: int = 3, sigma0=(0.0052, 0.00065), device="cpu", layout="cube",
+               order="random"):
     """Raw (pre-activation) attributes exactly as `Renderer.render_img` receives them
     (lightning/renderer.py:209-230): centers (N,3), shs (N,M,3), opacity logits (N,1),
     log-scales (N,3), raw quaternions (N,4).  `sigma0` may be one value or a tuple that
@@ -38,6 +51,10 @@ def make_scene(n: int, seed: int, sh_degree: int = 3, sigma0=(0.0052, 0.00065), 
     if m > 1:
         shs[:, 1:] = 0.1 * torch.randn(n, m - 1, 3, generator=g)
     perm = torch.randperm(n, generator=g)  # interleave the sigma0 populations
+    if order == "morton":   # memory order = spatial order (what a voxel-grid decoder emits), same set of Gaussians
+        perm = perm[morton_order(centers[perm])]
+    elif order != "random":
+        raise ValueError(f"unknown order {order!r}")
     out = dict(centers=centers[perm], shs=shs[perm], opacity=opac[perm], scales=logs[perm],
                rotations=rots[perm])
     return {k: v.contiguous().to(device) for k, v in out.items()}

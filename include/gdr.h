@@ -53,6 +53,7 @@ extern "C" {
 #define GDR_MAX_GAUSSIANS (1 << 27) /* 134 M Gaussians: 32 GB of degree-3 inputs               */
 #define GDR_MAX_RENDERED 0xFFFFFFFFull /* D = sum of tiles_touched of one view                  */
 
+#define GDR_DEFAULT_SEG_LEN 2048 /* gdr_binning.seg_len as carved (the library reads no environment variable) */
 #define GDR_TILE 16 /* tile edge in pixels (BLOCK_X = BLOCK_Y = 16) */
 
 /* The 12 fields of GaussianRasterizationSettings (renderer.py:111-124), flattened.
@@ -141,7 +142,8 @@ typedef struct gdr_binning {
     float* seg_state;    /* (2*seg_cap, 10, 256) K6 -> K7: per pixel of the tile, in front of each cut and at
                           * the end of the list: T, colour x3, depth, alpha sums (gdr); T, colour x3,
                           * normal x3, depth, M1, M2 (gsr)                                          */
-    int32_t seg_len;     /* entries per segment (multiple of 256); 0 = lists are never cut          */
+    int32_t seg_len;     /* entries per segment (multiple of 256); 0 = lists are never cut.  gdr_binning_carve sets
+                          * GDR_DEFAULT_SEG_LEN and sizes the tables for it; a caller may RAISE it or set 0 afterwards */
     int32_t seg_cap;     /* D / seg_len + 1                                                         */
 } gdr_binning;
 

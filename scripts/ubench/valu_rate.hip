@@ -1,0 +1,99 @@
+// Issue-rate microbenchmark for gfx950: cycles per wave64 instruction per SIMD for the instruction kinds K6/K7 are
+// made of (fma, packed fma, exp, DPP add, cndmask, 64-bit and, ds_read_b128 broadcast).  Build + run:
+//   hipcc --offload-arch=gfx950 -O3 scripts/ubench/valu_rate.hip -o build/valu_rate && build/valu_rate
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdint.h>
+
+#define REP 256
+#define ITERS 200
+
+template <int KIND>
+__global__ __launch_bounds__(256) void k(float* out, int iters) {
+    __shared__ float4 lds[1024];
+    float a0 = threadIdx.x * 1e-3f, a1 = a0 + 1.f, a2 = a0 + 2.f, a3 = a0 + 3.f, a4 = a0 + 4.f, a5 = a0 + 5.f, a6 = a0 + 6.f, a7 = a0 + 7.f;
+    const float b = 1.0001f, c = 1e-7f;
+    lds[threadIdx.x] = make_float4(a0, a1, a2, a3);
+    __syncthreads();
+    uint32_t addr = (threadIdx.x & 48u) * 16u;  // one address per 16-lane row (broadcast inside the row)
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int r = 0; r < REP / 8; ++r) {
+            if (KIND == 0) {
+                asm volatile("v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %1, %1, %8, %9\n v_fma_f32 %2, %2, %8, %9\n v_fma_f32 %3, %3, %8, %9\n"
+                             "v_fma_f32 %4, %4, %8, %9\n v_fma_f32 %5, %5, %8, %9\n v_fma_f32 %6, %6, %8, %9\n v_fma_f32 %7, %7, %8, %9\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));
+            } else if (KIND == 1) {
+                asm volatile("v_pk_fma_f32 %0, %0, %4, %5\n v_pk_fma_f32 %1, %1, %4, %5\n v_pk_fma_f32 %2, %2, %4, %5\n v_pk_fma_f32 %3, %3, %4, %5\n"
+                             "v_pk_fma_f32 %0, %0, %4, %5\n v_pk_fma_f32 %1, %1, %4, %5\n v_pk_fma_f32 %2, %2, %4, %5\n v_pk_fma_f32 %3, %3, %4, %5\n"
+                             : "+v"(*(double*)&a0), "+v"(*(double*)&a2), "+v"(*(double*)&a4), "+v"(*(double*)&a6)
+                             : "v"(*(const double*)&lds[0]), "v"(*(const double*)&lds[1]));
+            } else if (KIND == 2) {
+                asm volatile("v_exp_f32 %0, %0\n v_exp_f32 %1, %1\n v_exp_f32 %2, %2\n v_exp_f32 %3, %3\n"
+                             "v_exp_f32 %4, %4\n v_exp_f32 %5, %5\n v_exp_f32 %6, %6\n v_exp_f32 %7, %7\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+            } else if (KIND == 3) {
+                asm volatile("v_add_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %1, %1, %1 row_mirror row_mask:0xf bank_mask:0xf\n"
+                             "v_add_f32_dpp %2, %2, %2 row_mirror row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %3, %3, %3 row_mirror row_mask:0xf bank_mask:0xf\n"
+                             "v_add_f32_dpp %4, %4, %4 row_mirror row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %5, %5, %5 row_mirror row_mask:0xf bank_mask:0xf\n"
+                             "v_add_f32_dpp %6, %6, %6 row_mirror row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %7, %7, %7 row_mirror row_mask:0xf bank_mask:0xf\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+            } else if (KIND == 4) {
+                asm volatile("v_cndmask_b32 %0, %0, %1, vcc\n v_cndmask_b32 %1, %1, %2, vcc\n v_cndmask_b32 %2, %2, %3, vcc\n v_cndmask_b32 %3, %3, %4, vcc\n"
+                             "v_cndmask_b32 %4, %4, %5, vcc\n v_cndmask_b32 %5, %5, %6, vcc\n v_cndmask_b32 %6, %6, %7, vcc\n v_cndmask_b32 %7, %7, %0, vcc\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : : "vcc");
+            } else if (KIND == 5) {
+                asm volatile("v_mul_f32 %0, %0, %8\n v_mul_f32 %1, %1, %8\n v_mul_f32 %2, %2, %8\n v_mul_f32 %3, %3, %8\n"
+                             "v_mul_f32 %4, %4, %8\n v_mul_f32 %5, %5, %8\n v_mul_f32 %6, %6, %8\n v_mul_f32 %7, %7, %8\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b));
+            } else if (KIND == 6) {  // ds_read_b128, one address per 16-lane row + 7 fma per read
+                float4 t;
+                asm volatile("ds_read_b128 %0, %1\n s_waitcnt lgkmcnt(0)\n" : "=v"(t) : "v"(addr));
+                a0 += t.x; a1 += t.y; a2 += t.z; a3 += t.w;
+            } else if (KIND == 7) {  // v_rcp_f32
+                asm volatile("v_rcp_f32 %0, %0\n v_rcp_f32 %1, %1\n v_rcp_f32 %2, %2\n v_rcp_f32 %3, %3\n"
+                             "v_rcp_f32 %4, %4\n v_rcp_f32 %5, %5\n v_rcp_f32 %6, %6\n v_rcp_f32 %7, %7\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+            } else if (KIND == 8) {  // 8 independent ds_read_b128 in flight, row-broadcast addresses
+                float4 t0, t1, t2, t3;
+                asm volatile("ds_read_b128 %0, %4\n ds_read_b128 %1, %4 offset:16\n ds_read_b128 %2, %4 offset:32\n ds_read_b128 %3, %4 offset:48\n s_waitcnt lgkmcnt(0)\n"
+                             : "=v"(t0), "=v"(t1), "=v"(t2), "=v"(t3) : "v"(addr));
+                a0 += t0.x + t1.x; a1 += t2.y + t3.y;
+            }
+        }
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
+}
+
+template <int KIND>
+static void run(const char* name, int insts_per_rep8, int waves_per_simd) {
+    float* out;
+    const int blocks = 256 * waves_per_simd;  // 256 CUs x waves_per_simd workgroups of 4 waves (one per SIMD)
+    hipMalloc(&out, (size_t)blocks * 256 * 4);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(k<KIND>, dim3(blocks), dim3(256), 0, 0, out, 4);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(k<KIND>, dim3(blocks), dim3(256), 0, 0, out, ITERS);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    const double insts_per_simd = (double)ITERS * (REP / 8) * insts_per_rep8 * waves_per_simd;
+    printf("%-28s waves/SIMD %d: %.3f ms  -> %.2f ns per wave-instruction per SIMD (%.2f cycles @2.4 GHz)\n", name,
+           waves_per_simd, ms, ms * 1e6 / insts_per_simd, ms * 1e6 / insts_per_simd * 2.4);
+    hipFree(out);
+}
+
+int main() {
+    for (int w : {1, 2, 4, 8}) {
+        run<0>("v_fma_f32", 8, w);
+        run<5>("v_mul_f32", 8, w);
+        run<1>("v_pk_fma_f32", 8, w);
+        run<2>("v_exp_f32", 8, w);
+        run<7>("v_rcp_f32", 8, w);
+        run<3>("v_add_f32_dpp row_mirror", 8, w);
+        run<4>("v_cndmask_b32", 8, w);
+        run<6>("ds_read_b128 (dependent)", 1, w);
+        run<8>("ds_read_b128 x4 in flight", 4, w);
+    }
+    return 0;
+}

@@ -1,0 +1,119 @@
+"""-m gpu: boundary behaviour of the two rasterizer packages that the reference's callers rely on implicitly
+(/root/reference/lightning/renderer.py:250-259, renderer_2dgs.py:224-234): an empty Gaussian set differentiates to empty
+gradients, views of different sizes render through the multi-view node, and the autograd node notices an in-place update
+of its inputs between forward and backward (upstream saves them with save_for_backward)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def _settings(H, W, dev, deg=1):
+    from generativedensification_amd.camera import orbit_cameras
+    from generativedensification_amd.rasterizer import GaussianRasterizationSettings
+    cam = orbit_cameras(4, W, H, device=dev)[1]
+    return GaussianRasterizationSettings(
+        image_height=H, image_width=W, tanfovx=math.tan(0.375), tanfovy=math.tan(0.375), bg=torch.ones(3, device=dev),
+        scale_modifier=1.0, viewmatrix=cam.world_view_transform, projmatrix=cam.full_proj_transform, sh_degree=deg,
+        campos=cam.camera_center, prefiltered=False, debug=False)
+
+
+@pytest.mark.parametrize("surfel", [False, True])
+def test_backward_through_an_empty_gaussian_set(surfel):
+    """N = 0 through GaussianRasterizer(...) and .backward(): the single-view gdr_backward / gsr_backward used to
+    reject the (NULL) empty gradient buffers before looking at N (round-1 advisor finding)."""
+    dev = torch.device(DEV)
+    rs = _settings(48, 64, dev)
+    if surfel:
+        from diff_surfel_rasterization import GaussianRasterizer
+    else:
+        from diff_gaussian_rasterization import GaussianRasterizer
+    z = lambda *s: torch.zeros(*s, device=dev, requires_grad=True)
+    means, m2d, shs, op = z(0, 3), z(0, 4), z(0, 4, 3), z(0, 1)
+    scales, rots = z(0, 2 if surfel else 3), z(0, 4)
+    out = GaussianRasterizer(rs)(means3D=means, means2D=m2d, opacities=op, shs=shs, scales=scales, rotations=rots)
+    color = out[0]
+    assert torch.allclose(color, torch.ones_like(color))       # background only
+    sum(o.float().sum() for o in out if o.dtype.is_floating_point).backward()
+    torch.cuda.synchronize()
+    for t in (means, shs, op, scales, rots):   # autograd may leave the gradient of an empty leaf unset; if set, it is empty
+        assert t.grad is None or t.grad.shape == t.shape
+
+
+def test_render_views_with_mixed_image_sizes_matches_per_view_calls():
+    """3DGS render_views / render_views_loss with views of different sizes: one node per size (the surfel twin already
+    did this); same images, losses and gradients as the per-view reference call pattern."""
+    from generativedensification_amd.camera import orbit_cameras
+    from generativedensification_amd.renderer import Renderer
+    from generativedensification_amd.synthetic import make_scene, make_targets, view_loss
+    dev = torch.device(DEV)
+    scene = make_scene(20_000, 5, sh_degree=1, sigma0=(0.01,), device=dev)
+    sizes = [(96, 128), (64, 80), (96, 128)]
+    cams = [orbit_cameras(3, w, h, device=dev)[j] for j, (h, w) in enumerate(sizes)]
+    targets = [make_targets(1, h, w, 7 + j)[0].to(dev) for j, (h, w) in enumerate(sizes)]
+    r = Renderer(sh_degree=1)
+    r.set_bg_color(torch.ones(3, device=dev))
+
+    def grads_of(fn):
+        p = {k: v.clone().requires_grad_(True) for k, v in scene.items()}
+        losses = fn(p)
+        losses.sum().backward()
+        return losses.detach().cpu().numpy(), {k: v.grad.cpu().numpy() for k, v in p.items()}
+
+    def per_view(p):
+        return torch.stack([view_loss(r.render_img(c, None, p["centers"], p["shs"], p["opacity"], p["scales"],
+                                                   p["rotations"], dev), t) for c, t in zip(cams, targets)])
+
+    def one_call(p):
+        outs = r.render_views(cams, None, p["centers"], p["shs"], p["opacity"], p["scales"], p["rotations"], dev)
+        assert [tuple(o["image"].shape) for o in outs] == [(h, w, 3) for h, w in sizes]
+        return torch.stack([view_loss(o, t) for o, t in zip(outs, targets)])
+
+    def folded(p):
+        return r.render_views_loss(cams, None, [t.permute(2, 0, 1).contiguous() for t in targets], p["centers"], p["shs"],
+                                   p["opacity"], p["scales"], p["rotations"], dev)
+
+    l0, g0 = grads_of(per_view)
+    for fn in (one_call, folded):
+        l1, g1 = grads_of(fn)
+        np.testing.assert_allclose(l1, l0, rtol=1e-5)
+        for k in g0:
+            tol = 1e-4 * np.abs(g0[k]) + 1e-6 * np.abs(g0[k]).max()
+            assert (np.abs(g1[k] - g0[k]) > tol).mean() < 1e-4, (fn.__name__, k)
+
+
+@pytest.mark.parametrize("entry", ["rasterizer", "render_views", "surfel"])
+def test_inplace_update_between_forward_and_backward_is_an_error(entry):
+    """The input tensors are saved with ctx.save_for_backward: K9 recomputes covariance / projection / SH terms from
+    them, so a write in between must raise (autograd's version check) rather than return gradients of other values."""
+    from generativedensification_amd.synthetic import make_scene
+    dev = torch.device(DEV)
+    scene = make_scene(2000, 3, sh_degree=1, sigma0=(0.02,), device=dev)
+    p = {k: v.requires_grad_(True) for k, v in scene.items()}
+    rs = _settings(64, 64, dev)
+    if entry == "rasterizer":
+        from diff_gaussian_rasterization import GaussianRasterizer
+        act = dict(means3D=p["centers"] * 1.0, opacities=torch.sigmoid(p["opacity"]), shs=p["shs"] * 1.0,
+                   scales=torch.exp(p["scales"]), rotations=torch.nn.functional.normalize(p["rotations"]))
+        out = GaussianRasterizer(rs)(means2D=torch.zeros(2000, 4, device=dev, requires_grad=True), **act)[0]
+        victim = act["means3D"]
+    elif entry == "surfel":
+        from diff_surfel_rasterization import GaussianRasterizer
+        act = dict(means3D=p["centers"] * 1.0, opacities=torch.sigmoid(p["opacity"]), shs=p["shs"] * 1.0,
+                   scales=torch.exp(p["scales"][:, :2]), rotations=torch.nn.functional.normalize(p["rotations"]))
+        out = GaussianRasterizer(rs)(means2D=torch.zeros(2000, 4, device=dev, requires_grad=True), **act)[0]
+        victim = act["means3D"]
+    else:
+        from generativedensification_amd.rasterizer import render_views_raw
+        victim = p["centers"] * 1.0
+        out = render_views_raw(victim, torch.zeros(2000, 4, device=dev, requires_grad=True), p["shs"], p["opacity"],
+                               p["scales"], p["rotations"], [rs, rs])[0][1]
+    with torch.no_grad():
+        victim.add_(0.01)
+    with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+        out.sum().backward()

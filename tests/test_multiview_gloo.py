@@ -44,16 +44,19 @@ def _worker(rank, world, port, n_views, q):
 
         g = {k: torch.ones(5, 3, requires_grad=True) for k in ("centers", "shs", "opacity", "scales", "rotations")}
         outs = render_views(FakeRenderer(), [float(i) for i in mine], [torch.full((3,), float(i)) for i in mine], g, "cpu")
-        losses = torch.stack([o["image"].reshape(()) for o in outs])
-        losses.sum().backward()
+        if outs:   # a rank whose shard is empty (n_views < world) renders nothing and has no .grad at all
+            losses = torch.stack([o["image"].reshape(()) for o in outs])
+            losses.sum().backward()
+        else:
+            losses = torch.empty(0)
         allv = gather_view_losses(losses.detach(), n_views)
         allreduce_gaussian_grads(list(g.values()))
-        q.put((rank, allv.tolist(), g["centers"].grad[0, 0].item(), g["rotations"].grad is None))
+        q.put((rank, allv.tolist(), g["centers"].grad[0, 0].item(), float(g["rotations"].grad.abs().sum())))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_views", [4, 5])
+@pytest.mark.parametrize("n_views", [4, 5, 1])
 def test_gather_losses_and_grad_sum_world2(n_views):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -66,10 +69,23 @@ def test_gather_losses_and_grad_sum_world2(n_views):
         p.join(60)
         assert p.exitcode == 0
     expect = [15.0 * i + 3.0 * i for i in range(n_views)]  # centers.sum()=15 times cam i, plus bg sum 3*i
-    for rank, allv, gsum, rot_none in res:
+    for rank, allv, gsum, rot_abs in res:
         assert allv == expect, (rank, allv)          # global view order, both ranks hold all V losses
         assert gsum == float(sum(range(n_views)))    # d/dcenters summed over ALL views after the reduce
-        assert rot_none                              # tensors without grad are skipped
+        # every tensor takes part on every rank (rank-invariant buffer; n_views = 1 leaves rank 1 without any
+        # .grad before the call): a tensor no rank had a gradient for comes back as zeros, not as a hang
+        assert rot_abs == 0.0
+
+
+def test_bench_refuses_a_world_size_that_is_not_gpus():
+    """`bench.py --gpus N` must never report a 1-rank run as an N-GPU number (round-1 verdict, weak point)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr and r.stdout.strip() == ""
 
 
 def test_single_process_is_a_no_op():
