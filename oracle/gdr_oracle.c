@@ -33,6 +33,14 @@
 
 int oracle_real_bytes(void) { return (int)sizeof(real); }
 
+const int32_t* g_oracle_tile_sel = NULL;
+int g_oracle_tile_sel_n = 0;
+/* tiles = NULL: every tile (default).  The array must stay alive until the selection is reset. */
+void oracle_select_tiles(const int32_t* tiles, int n) {
+    g_oracle_tile_sel = n > 0 ? tiles : NULL;
+    g_oracle_tile_sel_n = n > 0 ? n : 0;
+}
+
 /* ------------------------------------------------------------------------- */
 /* A.1 preprocess forward.  One Gaussian at a time (K1).                      */
 /* rect = (minx, miny, maxx, maxy) in tile units.                            */
@@ -250,7 +258,9 @@ void oracle_render_fwd(int W, int H, const uint32_t* ranges, const uint32_t* poi
 #ifdef _OPENMP
 #pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads > 0 ? nthreads : 1)
 #endif
-    for (int t = 0; t < gx * gy; ++t) {
+    for (int it = 0; it < ORACLE_TILE_COUNT(gx * gy); ++it) {
+        const int t = ORACLE_TILE_AT(it);
+        if (t < 0 || t >= gx * gy) continue;
         int tx0 = (t % gx) * BLOCK_X, ty0 = (t / gx) * BLOCK_Y;
         uint32_t r0 = ranges[2 * t], r1 = ranges[2 * t + 1];
         for (int ly = 0; ly < BLOCK_Y; ++ly)
@@ -306,7 +316,9 @@ void oracle_render_bwd(int W, int H, const uint32_t* ranges, const uint32_t* poi
 #ifdef _OPENMP
 #pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads > 0 ? nthreads : 1)
 #endif
-    for (int t = 0; t < gx * gy; ++t) {
+    for (int it = 0; it < ORACLE_TILE_COUNT(gx * gy); ++it) {
+        const int t = ORACLE_TILE_AT(it);
+        if (t < 0 || t >= gx * gy) continue;
         int tx0 = (t % gx) * BLOCK_X, ty0 = (t / gx) * BLOCK_Y;
         uint32_t r0 = ranges[2 * t];
         for (int ly = 0; ly < BLOCK_Y; ++ly)

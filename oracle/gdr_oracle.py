@@ -84,6 +84,23 @@ class Oracle:
         assert self.lib.oracle_real_bytes() == np.dtype(self.rt).itemsize
         self.nthreads = int(nthreads)
 
+    def _select(self, tiles):
+        """Context manager: restrict the render loops to the tile ids in `tiles` (None = all).  See oracle_common.h."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def cm():
+            if tiles is None:
+                yield
+                return
+            t = np.ascontiguousarray(np.asarray(tiles, dtype=np.int32))
+            self.lib.oracle_select_tiles(_p(t), C.c_int(int(t.size)))
+            try:
+                yield
+            finally:
+                self.lib.oracle_select_tiles(None, C.c_int(0))
+        return cm()
+
     def _a(self, x, shape=None):
         if x is None:
             return None
@@ -93,8 +110,11 @@ class Oracle:
         return a
 
     def forward(self, means3D, opacities, s: Settings, shs=None, colors_precomp=None, scales=None,
-                rotations=None, cov3D_precomp=None) -> dict:
+                rotations=None, cov3D_precomp=None, tiles=None) -> dict:
+        """tiles: optional tile ids (y * grid_x + x); only those tiles are composited (the rest of the images stays
+        zero) — preprocess and binning always cover everything.  backward() of the returned ctx uses the same tiles."""
         rt, lib = self.rt, self.lib
+        tile_sel = tiles   # (`tiles` is reused below for tiles_touched)
         means3D = self._a(means3D)
         N = means3D.shape[0]
         H, W = int(s.image_height), int(s.image_width)
@@ -151,10 +171,12 @@ class Oracle:
         alpha = np.zeros((1, H, W), rt)
         n_contrib = np.zeros((H, W), np.uint32)
         final_T = np.zeros((H, W), rt)
-        lib.oracle_render_fwd(C.c_int(W), C.c_int(H), _p(ranges), _p(vals), _p(xy), _p(rgb),
-                              _p(conic_opacity), _p(depths), _p(bg), _p(color), _p(depth),
-                              _p(alpha), _p(n_contrib), _p(final_T), C.c_int(self.nthreads))
+        with self._select(tile_sel):
+            lib.oracle_render_fwd(C.c_int(W), C.c_int(H), _p(ranges), _p(vals), _p(xy), _p(rgb),
+                                  _p(conic_opacity), _p(depths), _p(bg), _p(color), _p(depth),
+                                  _p(alpha), _p(n_contrib), _p(final_T), C.c_int(self.nthreads))
         return dict(
+            _tiles=tile_sel,
             color=color, depth=depth, alpha=alpha, radii=radii, num_rendered=D,
             xy=xy, depths=depths, cov3D=cov3D, rgb=rgb, conic_opacity=conic_opacity,
             tiles_touched=tiles, rect=rect, clamped=clamped, offsets=offsets,
@@ -180,11 +202,12 @@ class Oracle:
         d_opac = np.zeros((N, 1), rt)
         d_color = np.zeros((N, 3), rt)
         d_depth = np.zeros(N, rt)
-        lib.oracle_render_bwd(C.c_int(W), C.c_int(H), _p(ctx["ranges"]), _p(i["vals"]), _p(i["bg"]),
-                              _p(ctx["xy"]), _p(ctx["conic_opacity"]), _p(ctx["rgb"]),
-                              _p(ctx["depths"]), _p(ctx["final_T"]), _p(ctx["n_contrib"]), _p(gC),
-                              _p(gD), _p(gA), _p(d_mean2D), _p(d_conic), _p(d_opac), _p(d_color),
-                              _p(d_depth), C.c_int(self.nthreads))
+        with self._select(ctx.get("_tiles")):
+            lib.oracle_render_bwd(C.c_int(W), C.c_int(H), _p(ctx["ranges"]), _p(i["vals"]), _p(i["bg"]),
+                                  _p(ctx["xy"]), _p(ctx["conic_opacity"]), _p(ctx["rgb"]),
+                                  _p(ctx["depths"]), _p(ctx["final_T"]), _p(ctx["n_contrib"]), _p(gC),
+                                  _p(gD), _p(gA), _p(d_mean2D), _p(d_conic), _p(d_opac), _p(d_color),
+                                  _p(d_depth), C.c_int(self.nthreads))
         d_means3D = np.zeros((N, 3), rt)
         d_cov3D = np.zeros((N, 6), rt)
         d_sh = np.zeros((N, max(M, 1), 3), rt)
@@ -219,10 +242,10 @@ class Oracle:
 # --------------------------------------------------------------------------------------
 # Oracle-backed stand-in for the boundary package (tests / golden generation only).
 # --------------------------------------------------------------------------------------
-def make_standin_module(precision: str = "f32") -> types.ModuleType:
+def make_standin_module(precision: str = "f32", nthreads: int = 1) -> types.ModuleType:
     import torch
 
-    oracle = Oracle(precision)
+    oracle = Oracle(precision, nthreads=nthreads)
     tdt = torch.float32 if precision == "f32" else torch.float64
 
     class GaussianRasterizationSettings(NamedTuple):

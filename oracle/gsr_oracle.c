@@ -213,7 +213,9 @@ void oracle_surfel_render_fwd(int W, int H, const uint32_t* ranges, const uint32
 #ifdef _OPENMP
 #pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads > 0 ? nthreads : 1)
 #endif
-    for (int t = 0; t < gx * gy; ++t) {
+    for (int it = 0; it < ORACLE_TILE_COUNT(gx * gy); ++it) {
+        const int t = ORACLE_TILE_AT(it);
+        if (t < 0 || t >= gx * gy) continue;
         int tx0 = (t % gx) * BLOCK_X, ty0 = (t / gx) * BLOCK_Y;
         uint32_t r0 = ranges[2 * t], r1 = ranges[2 * t + 1];
         for (int ly = 0; ly < BLOCK_Y; ++ly)
@@ -272,7 +274,9 @@ void oracle_surfel_render_bwd(int W, int H, const uint32_t* ranges, const uint32
 #ifdef _OPENMP
 #pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads > 0 ? nthreads : 1)
 #endif
-    for (int t = 0; t < gx * gy; ++t) {
+    for (int it = 0; it < ORACLE_TILE_COUNT(gx * gy); ++it) {
+        const int t = ORACLE_TILE_AT(it);
+        if (t < 0 || t >= gx * gy) continue;
         int tx0 = (t % gx) * BLOCK_X, ty0 = (t / gx) * BLOCK_Y;
         uint32_t r0 = ranges[2 * t];
         for (int ly = 0; ly < BLOCK_Y; ++ly)

@@ -20,8 +20,10 @@ class SurfelOracle(Oracle):
     """forward()/backward() of the surfel path over numpy arrays; every intermediate is returned."""
 
     def forward(self, means3D, opacities, s: Settings, shs=None, colors_precomp=None, scales=None,
-                rotations=None, transMat_precomp=None) -> dict:
+                rotations=None, transMat_precomp=None, tiles=None) -> dict:
+        """tiles: see Oracle.forward (only those tiles are composited / differentiated)."""
         rt, lib = self.rt, self.lib
+        tile_sel = tiles   # (`tiles` is reused below for tiles_touched)
         means3D = self._a(means3D)
         N = means3D.shape[0]
         H, W = int(s.image_height), int(s.image_width)
@@ -66,10 +68,12 @@ class SurfelOracle(Oracle):
         allmap = np.zeros((7, H, W), rt)
         n_contrib = np.zeros((2, H, W), np.uint32)
         final_T = np.zeros((3, H, W), rt)
-        lib.oracle_surfel_render_fwd(C.c_int(W), C.c_int(H), _p(ranges), _p(vals), _p(xy), _p(rgb), _p(transMats),
-                                     _p(normal_opacity), _p(bg), _p(color), _p(allmap), _p(n_contrib), _p(final_T),
-                                     C.c_int(self.nthreads))
+        with self._select(tile_sel):
+            lib.oracle_surfel_render_fwd(C.c_int(W), C.c_int(H), _p(ranges), _p(vals), _p(xy), _p(rgb), _p(transMats),
+                                         _p(normal_opacity), _p(bg), _p(color), _p(allmap), _p(n_contrib), _p(final_T),
+                                         C.c_int(self.nthreads))
         return dict(
+            _tiles=tile_sel,
             color=color, allmap=allmap, radii=radii, num_rendered=D, xy=xy, depths=depths, transMats=transMats,
             rgb=rgb, normal_opacity=normal_opacity, tiles_touched=tiles, rect=rect, clamped=clamped, offsets=offsets,
             keys_unsorted=keys_u[:D], vals_unsorted=vals_u[:D], keys_sorted=keys[:D], point_list=vals[:D],
@@ -91,10 +95,11 @@ class SurfelOracle(Oracle):
         d_nrm = np.zeros((N, 3), rt)
         d_opac = np.zeros((N, 1), rt)
         d_color = np.zeros((N, 3), rt)
-        lib.oracle_surfel_render_bwd(
-            C.c_int(W), C.c_int(H), _p(ctx["ranges"]), _p(i["vals"]), _p(i["bg"]), _p(ctx["xy"]),
-            _p(ctx["normal_opacity"]), _p(ctx["transMats"]), _p(ctx["rgb"]), _p(ctx["final_T"]), _p(ctx["n_contrib"]),
-            _p(gC), _p(gO), _p(d_T), _p(d_m2), _p(d_nrm), _p(d_opac), _p(d_color), C.c_int(self.nthreads))
+        with self._select(ctx.get("_tiles")):
+            lib.oracle_surfel_render_bwd(
+                C.c_int(W), C.c_int(H), _p(ctx["ranges"]), _p(i["vals"]), _p(i["bg"]), _p(ctx["xy"]),
+                _p(ctx["normal_opacity"]), _p(ctx["transMats"]), _p(ctx["rgb"]), _p(ctx["final_T"]), _p(ctx["n_contrib"]),
+                _p(gC), _p(gO), _p(d_T), _p(d_m2), _p(d_nrm), _p(d_opac), _p(d_color), C.c_int(self.nthreads))
         d_means3D = np.zeros((N, 3), rt)
         d_Tout = np.zeros((N, 9), rt)
         d_sh = np.zeros((N, max(M, 1), 3), rt)
@@ -116,11 +121,11 @@ class SurfelOracle(Oracle):
             _partial=dict(transMat=d_T, mean2D=d_m2, normal=d_nrm, color=d_color))
 
 
-def make_surfel_standin_module(precision: str = "f32") -> types.ModuleType:
+def make_surfel_standin_module(precision: str = "f32", nthreads: int = 1) -> types.ModuleType:
     """Oracle-backed `diff_surfel_rasterization` (GaussianRasterizationSettings, GaussianRasterizer)."""
     import torch
 
-    oracle = SurfelOracle(precision)
+    oracle = SurfelOracle(precision, nthreads=nthreads)
     tdt = torch.float32 if precision == "f32" else torch.float64
 
     class GaussianRasterizationSettings(NamedTuple):

@@ -135,6 +135,16 @@ static inline void sh_basis_grad(int deg, real x, real y, real z, real* bx, real
 }
 
 /* += with an OpenMP atomic when several tiles run concurrently */
+/* Tile selection of the four render loops (oracle_select_tiles): NULL = every tile; otherwise only the listed tiles are
+ * composited / differentiated, so that a comparison at BASELINE sizes (2 M Gaussians, 800x800) costs a fraction of a
+ * full render on a host with few cores.  Pixels outside the selection keep whatever the output arrays held (the
+ * Python front-end zero-fills); a backward over a selection equals the full backward with the upstream pixel
+ * gradients zeroed outside the selected tiles. */
+extern const int32_t* g_oracle_tile_sel;
+extern int g_oracle_tile_sel_n;
+#define ORACLE_TILE_COUNT(all) (g_oracle_tile_sel ? g_oracle_tile_sel_n : (all))
+#define ORACLE_TILE_AT(it) (g_oracle_tile_sel ? (int)g_oracle_tile_sel[it] : (it))
+
 static inline void accum(real* p, real v, int atomic) {
     if (atomic) {
 #ifdef _OPENMP

@@ -172,3 +172,74 @@ def run_surfel_hip(case, grads=None, dev="cuda:0"):
 def rand_surfel_grads(case, seed=123):
     g = torch.Generator().manual_seed(seed)
     return torch.randn(3, case["H"], case["W"], generator=g), torch.randn(7, case["H"], case["W"], generator=g)
+
+
+# ---- per-element gradient comparison (round-2: replaces max-norm-relative checks) ----------------------------------
+def elem_stats(a, ref, rtol=1e-4, atol_rel=1e-6):
+    """Per-ELEMENT comparison |a - ref| <= rtol |ref| + atol, atol = atol_rel * max|ref| (an absolute floor two orders
+    below the old max-norm bar: elements that are sums of cancelling fp32 terms cannot be relative-exact to
+    themselves).  Returns (fraction of elements outside, worst |a-ref| / (rtol |ref| + atol), max-norm relative error)."""
+    a = np.asarray(a, np.float64).reshape(-1)
+    ref = np.asarray(ref, np.float64).reshape(-1)
+    if ref.size == 0:
+        return 0.0, 0.0, 0.0
+    scale = max(float(np.abs(ref).max()), 1e-300)
+    tol = rtol * np.abs(ref) + atol_rel * scale
+    err = np.abs(a - ref)
+    return float((err > tol).mean()), float((err / tol).max()), float(err.max() / scale)
+
+
+def tile_mask(tiles, H, W):
+    """Boolean (H,W) mask of the pixels of the given tile ids (y * grid_x + x, 16x16 tiles)."""
+    gx = (W + 15) // 16
+    m = np.zeros((H, W), bool)
+    for t in np.asarray(tiles).reshape(-1):
+        ty, tx = divmod(int(t), gx)
+        m[ty * 16:ty * 16 + 16, tx * 16:tx * 16 + 16] = True
+    return m
+
+
+def pick_tiles(ranges, n_long=16, n_rand=32, seed=0):
+    """Sample of tile ids for a sampled-tile oracle comparison: the n_long longest lists + n_rand random non-empty."""
+    r = np.asarray(ranges).astype(np.int64).reshape(-1, 2)
+    length = r[:, 1] - r[:, 0]
+    order = np.argsort(-length, kind="stable")
+    long_ = order[:n_long]
+    rest = order[n_long:][length[order[n_long:]] > 0]
+    g = np.random.default_rng(seed)
+    rnd = g.choice(rest, size=min(n_rand, rest.size), replace=False) if rest.size else np.empty(0, np.int64)
+    return np.unique(np.concatenate([long_[length[long_] > 0], rnd])).astype(np.int32)
+
+
+# Fraction of gradient elements allowed outside 1e-4 |ref| + 1e-6 max|ref| of the float32 oracle.  Measured on MI355X
+# at every BASELINE size (tests/test_gpu_oracle_fullsize.py, BASELINE.md §4): 0 to 9e-6, max-norm relative 2e-7..2e-6 —
+# K7's atomics and K9's fused multiply-adds only reorder / contract fp32 sums.
+MAX_OUTSIDE = 1e-4
+
+
+def assert_grads(hg, g64, g32, keys, what, max_outside=MAX_OUTSIDE, rtol=1e-4, atol_rel=1e-6, maxnorm=1e-4, bar32=True):
+    """hg: HIP; g32: float32 oracle (the bar); g64: float64 oracle (the arbiter).  bar32=False (2DGS path only): the
+    fp32 formulation is ill-conditioned enough that two fp32 evaluations differ from each other by more than either
+    does from float64 in places — only the arbiter comparison is asserted there."""
+    for k in keys:
+        r32 = np.asarray(g32[k]).reshape(hg[k].shape)
+        r64 = np.asarray(g64[k]).reshape(hg[k].shape)
+        out, worst, maxn = elem_stats(hg[k], r32, rtol, atol_rel)
+        o_h64, _, m_h64 = elem_stats(hg[k], r64, rtol, atol_rel)
+        o_3264, _, m_3264 = elem_stats(r32, r64, rtol, atol_rel)
+        print(f"[{what}] {k:10s} vs f32 oracle: outside {out:.2e} worst/tol {worst:.1f} max-norm rel {maxn:.2e} | "
+              f"vs f64: hip {o_h64:.2e} / {m_h64:.2e}, f32 oracle {o_3264:.2e} / {m_3264:.2e}")
+        assert np.isfinite(hg[k]).all(), (what, k)
+        if bar32:
+            # where HIP and the f32 oracle disagree beyond the bar, float64 arbitrates: HIP passes only if it is at
+            # least as close to float64 as the f32 oracle is (long sequential fp32 sums of the one-thread oracle lose
+            # more than the GPU's partial sums: 3000 screen-filling Gaussians, 65 k terms per sum)
+            closer = o_h64 <= o_3264 and m_h64 <= m_3264
+            assert out < max_outside or closer, (what, k, out, o_h64, o_3264)
+            assert maxn < maxnorm, (what, k, maxn)
+        else:
+            assert o_h64 < max_outside, (what, k, o_h64)
+        # as accurate as the fp32 algorithm allows: no further from float64 than the f32 oracle
+        assert m_h64 <= 1.25 * m_3264 + 1e-6 and o_h64 <= 1.25 * o_3264 + 1e-4, (what, k, m_h64, m_3264, o_h64, o_3264)
+
+
