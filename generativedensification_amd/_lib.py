@@ -134,6 +134,11 @@ _PROTOS = {
     "gdr_render_backward_mean2d_loss": (C.c_int, [C.POINTER(GdrSettings), C.c_int32, C.POINTER(GdrGeom), C.POINTER(GdrBinning),
                                                   C.POINTER(GdrImage), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                                   C.c_void_p]),
+    "gdr_composite_forward_lossgrad": (C.c_int, [C.POINTER(GdrSettings), C.POINTER(GdrGeom), C.POINTER(GdrBinning),
+                                                 C.POINTER(GdrImage), C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gdr_topk_workspace_bytes": (C.c_size_t, []),
+    "gdr_topk_absgrad": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_void_p]),
     "gdr_preprocess_backward_views": (C.c_int, [C.c_int32, C.POINTER(GdrSettings), C.POINTER(GdrInputs),
                                                 C.POINTER(GdrGeom), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                                 C.POINTER(GdrGradOutputs), C.c_void_p]),
@@ -199,7 +204,7 @@ def load():
             fn = getattr(lib, name)  # AttributeError if the symbol is missing
             fn.restype = res
             fn.argtypes = args
-        if lib.gdr_abi_version() != 8:
+        if lib.gdr_abi_version() != 9:
             raise RuntimeError("libgdr_hip.so ABI version mismatch")
         _lib = lib
     return _lib

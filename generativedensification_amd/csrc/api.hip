@@ -286,6 +286,29 @@ int gdr_composite_forward_loss(const gdr_settings* s, const gdr_geom* geom, cons
     return debug_sync(s, "render_fwd_loss", st);
 }
 
+int gdr_composite_forward_lossgrad(const gdr_settings* s, const gdr_geom* geom, const gdr_binning* bin, const gdr_image* img,
+                                   const float* target, float go_scale, float* loss, float* dL_dcolor, void* stream) {
+    if (!s || !geom || !bin || !img || !target || !loss || !dL_dcolor) {
+        set_error("composite_forward_lossgrad: NULL argument", hipSuccess);
+        return GDR_ERR_INVALID_ARG;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = launch_render_fwd_lossgrad(s, geom, bin, img, target, go_scale, loss, dL_dcolor, st);
+    if (e != hipSuccess) return hip_fail("render_fwd_lossgrad", e);
+    return debug_sync(s, "render_fwd_lossgrad", st);
+}
+
+size_t gdr_topk_workspace_bytes(void) { return select_workspace_bytes(); }
+
+int gdr_topk_absgrad(int32_t N, const float* grad, const uint8_t* candidates, int32_t k, void* workspace, uint8_t* mask,
+                     int32_t* indices, void* stream) {
+    if (N < 0 || k < 0 || (N > 0 && (!grad || !workspace || !mask))) { set_error("topk_absgrad: bad argument", hipSuccess); return GDR_ERR_INVALID_ARG; }
+    if (N == 0) return GDR_OK;
+    hipError_t e = launch_topk_absgrad(N, grad, candidates, k, k >= N, workspace, mask, indices, (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail("topk_absgrad", e);
+    return GDR_OK;
+}
+
 int gdr_render_backward_loss(const gdr_settings* s, int32_t N, const gdr_geom* geom, const gdr_binning* bin,
                              const gdr_image* img, const float* color, const float* target, float w_depth, float w_alpha,
                              const float* g, float* grad_rec, void* stream) {
@@ -511,7 +534,8 @@ int gdr_profile_collect(double* ms_total, uint64_t* launches, int32_t n, int32_t
 const char* gdr_kernel_name(int32_t id) {
     static const char* names[GDR_K_COUNT] = {"preprocess_fwd", "scan_block_sums", "duplicate_with_keys",
         "sort_hist", "sort_rowscan", "sort_scatter", "tile_ranges", "render_fwd", "render_bwd",
-        "preprocess_bwd", "mark_visible", "tile_order", "tile_sort", "tile_sort_long", "view_loss", "surfel_maps", "knn"};
+        "preprocess_bwd", "mark_visible", "tile_order", "tile_sort", "tile_sort_long", "view_loss", "surfel_maps", "knn",
+        "topk_select"};
     return (id >= 0 && id < GDR_K_COUNT) ? names[id] : "";
 }
 int gdr_kernel_count(void) { return GDR_K_COUNT; }

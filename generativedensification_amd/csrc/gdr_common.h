@@ -36,6 +36,7 @@ enum {
     GDR_K_VIEW_LOSS,
     GDR_K_SURFEL_MAPS,
     GDR_K_KNN,
+    GDR_K_SELECT,
     GDR_K_COUNT
 };
 
@@ -97,6 +98,12 @@ hipError_t launch_render_fwd(const gdr_settings* s, const gdr_geom* g, const gdr
 hipError_t launch_render_fwd_loss(const gdr_settings* s, const gdr_geom* g, const gdr_binning* bin,
                                   const gdr_image* img, const gdr_outputs* out, const float* target, float w_depth,
                                   float w_alpha, float* loss, hipStream_t st);
+hipError_t launch_render_fwd_lossgrad(const gdr_settings* s, const gdr_geom* g, const gdr_binning* bin,
+                                      const gdr_image* img, const float* target, float go_scale, float* loss,
+                                      float* dL_dcolor, hipStream_t st);
+hipError_t launch_topk_absgrad(int N, const float* grad, const uint8_t* cand, int k, bool all, void* workspace,
+                               uint8_t* mask, int32_t* idx, hipStream_t st);
+size_t select_workspace_bytes();
 hipError_t launch_render_bwd_loss(const gdr_settings* s, const gdr_geom* g, const gdr_binning* bin,
                                   const gdr_image* img, const float* color, const float* target, float w_depth,
                                   float w_alpha, const float* go, float* grad_rec, hipStream_t st);

@@ -204,6 +204,7 @@ struct FusedLoss {
     float* loss;          // K6: accumulated (caller zeroes)
     const float* go;      // K7: upstream scalar gradient (device)
     const float* color;   // K7: the colour K6 wrote, (3,H,W)
+    float go_scale;       // K6 LOSS = 2: host-known upstream scalar (1 / views for the mean over views)
 };
 
 // Cut lists (gdr_binning.seg_len, tables built by tile_order_kernel): a tile list longer than seg_rounds slices is
@@ -213,7 +214,10 @@ struct FusedLoss {
 // from T = 1 in parallel workgroups (colour is linear in the incoming transmittance) and walking only the segments
 // in which a pixel saturates was built and measured — it doubles the alpha evaluations of cut lists and lost 4-16 %
 // once two views are in flight and the backward is segmented.
-template <bool LOSS>
+// LOSS = 2 (the abs-grad-only path of network.py:865-878): the MSE is folded in as for LOSS = 1 but NO image
+// leaves the kernel — instead of colour / depth / alpha it writes d loss / d colour of the pixel (times go_scale) into
+// out_color, which the mean2D-only K7 reads as its upstream gradient; per pixel 12 + 8 bytes instead of 20 + 8.
+template <int LOSS>
 __global__ __launch_bounds__(GDR_BLOCK) void render_fwd_kernel(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const uint32_t* __restrict__ tile_order, int W, int H, int gx, int ntiles,
@@ -364,11 +368,19 @@ __global__ __launch_bounds__(GDR_BLOCK) void render_fwd_kernel(
         const size_t pix = (size_t)py * W + px, P = (size_t)H * W;
         final_T[pix] = T;
         n_contrib[pix] = last_contributor;
-        out_color[pix] = fmaf(T, bg[0], C0);
-        out_color[P + pix] = fmaf(T, bg[1], C1);
-        out_color[2 * P + pix] = fmaf(T, bg[2], C2);
-        out_depth[pix] = Dp;
-        out_alpha[pix] = Wt;
+        if (LOSS == 2) {   // d (mean_{c,p} (clamp(c) - target)^2) / d colour: the clamp passes the gradient inside [0,1]
+            const float k = fl.go_scale * 2.f / (3.f * (float)P);
+            const float c0 = fmaf(T, bg[0], C0), c1 = fmaf(T, bg[1], C1), c2 = fmaf(T, bg[2], C2);
+            out_color[pix] = (c0 >= 0.f && c0 <= 1.f) ? k * (c0 - fl.target[pix]) : 0.f;
+            out_color[P + pix] = (c1 >= 0.f && c1 <= 1.f) ? k * (c1 - fl.target[P + pix]) : 0.f;
+            out_color[2 * P + pix] = (c2 >= 0.f && c2 <= 1.f) ? k * (c2 - fl.target[2 * P + pix]) : 0.f;
+        } else {
+            out_color[pix] = fmaf(T, bg[0], C0);
+            out_color[P + pix] = fmaf(T, bg[1], C1);
+            out_color[2 * P + pix] = fmaf(T, bg[2], C2);
+            out_depth[pix] = Dp;
+            out_alpha[pix] = Wt;
+        }
     }
     if (LOSS) {
         float lp = 0.f;
@@ -654,7 +666,7 @@ hipError_t launch_render_fwd(const gdr_settings* s, const gdr_geom* g, const gdr
     const int W = s->image_width, H = s->image_height;
     const int gx = tile_grid_x(W), gy = tile_grid_y(H);
     const int ntiles = gx * gy;
-    GDR_LAUNCH(GDR_K_RENDER_FWD, render_fwd_kernel<false>, dim3(ntiles), dim3(GDR_BLOCK), st,
+    GDR_LAUNCH(GDR_K_RENDER_FWD, render_fwd_kernel<0>, dim3(ntiles), dim3(GDR_BLOCK), st,
                (const uint2*)img->ranges, bin->values[bin->sorted], img->tile_order, W, H, gx, ntiles,
                (const float4*)g->rec, s->bg, img->final_T, img->n_contrib, out->color, out->depth, out->alpha,
                FusedLoss{}, GDR_SEG_FWD_ARGS(bin, img));
@@ -667,10 +679,25 @@ hipError_t launch_render_fwd_loss(const gdr_settings* s, const gdr_geom* g, cons
     const int W = s->image_width, H = s->image_height;
     const int gx = tile_grid_x(W), gy = tile_grid_y(H);
     const int ntiles = gx * gy;
-    const FusedLoss fl{target, w_depth, w_alpha, loss, nullptr, nullptr};
-    GDR_LAUNCH(GDR_K_RENDER_FWD, render_fwd_kernel<true>, dim3(ntiles), dim3(GDR_BLOCK), st,
+    const FusedLoss fl{target, w_depth, w_alpha, loss, nullptr, nullptr, 1.f};
+    GDR_LAUNCH(GDR_K_RENDER_FWD, render_fwd_kernel<1>, dim3(ntiles), dim3(GDR_BLOCK), st,
                (const uint2*)img->ranges, bin->values[bin->sorted], img->tile_order, W, H, gx, ntiles,
                (const float4*)g->rec, s->bg, img->final_T, img->n_contrib, out->color, out->depth, out->alpha, fl,
+               GDR_SEG_FWD_ARGS(bin, img));
+    return hipGetLastError();
+}
+
+// K6 of the abs-grad-only path: loss accumulated, d loss / d colour written instead of any image (LOSS = 2)
+hipError_t launch_render_fwd_lossgrad(const gdr_settings* s, const gdr_geom* g, const gdr_binning* bin,
+                                      const gdr_image* img, const float* target, float go_scale, float* loss,
+                                      float* dL_dcolor, hipStream_t st) {
+    const int W = s->image_width, H = s->image_height;
+    const int gx = tile_grid_x(W), gy = tile_grid_y(H);
+    const int ntiles = gx * gy;
+    const FusedLoss fl{target, 0.f, 0.f, loss, nullptr, nullptr, go_scale};
+    GDR_LAUNCH(GDR_K_RENDER_FWD, render_fwd_kernel<2>, dim3(ntiles), dim3(GDR_BLOCK), st,
+               (const uint2*)img->ranges, bin->values[bin->sorted], img->tile_order, W, H, gx, ntiles,
+               (const float4*)g->rec, s->bg, img->final_T, img->n_contrib, dL_dcolor, nullptr, nullptr, fl,
                GDR_SEG_FWD_ARGS(bin, img));
     return hipGetLastError();
 }
@@ -681,7 +708,7 @@ hipError_t launch_render_bwd_loss(const gdr_settings* s, const gdr_geom* g, cons
     const int W = s->image_width, H = s->image_height;
     const int gx = tile_grid_x(W), gy = tile_grid_y(H);
     const int ntiles = gx * gy;
-    const FusedLoss fl{target, w_depth, w_alpha, nullptr, go, color};
+    const FusedLoss fl{target, w_depth, w_alpha, nullptr, go, color, 1.f};
     GDR_LAUNCH(GDR_K_RENDER_BWD, (render_bwd_kernel<false, true>), GDR_BWD_GRID(bin, img, ntiles), dim3(GDR_BLOCK), st,
                (const uint2*)img->ranges, bin->values[bin->sorted], img->tile_order, W, H, gx, ntiles, s->bg,
                (const float4*)g->rec, img->final_T, img->n_contrib, nullptr, nullptr, nullptr, grad_rec, fl,
@@ -723,7 +750,7 @@ hipError_t launch_render_bwd_mean2d_loss(const gdr_settings* s, const gdr_geom* 
     const int W = s->image_width, H = s->image_height;
     const int gx = tile_grid_x(W), gy = tile_grid_y(H);
     const int ntiles = gx * gy;
-    const FusedLoss fl{target, 0.f, 0.f, nullptr, go, color};
+    const FusedLoss fl{target, 0.f, 0.f, nullptr, go, color, 1.f};
     GDR_LAUNCH(GDR_K_RENDER_BWD, (render_bwd_kernel<true, true>), GDR_BWD_GRID(bin, img, ntiles), dim3(GDR_BLOCK), st,
                (const uint2*)img->ranges, bin->values[bin->sorted], img->tile_order, W, H, gx, ntiles, s->bg,
                (const float4*)g->rec, img->final_T, img->n_contrib, nullptr, nullptr, nullptr, dL_dmean2D, fl,

@@ -383,9 +383,10 @@ def _forward_views_impl(means3D, means2D, sh, opacities, scales, rotations, sett
     f32, u8 = dict(dtype=torch.float32, device=dev), dict(dtype=torch.uint8, device=dev)
     # one tensor per view (not slices of a stacked buffer): a per-view loss then back-propagates straight into
     # that view's gradient, without autograd's select-backward zero-fill + add of the whole stack per view
-    colors = [torch.empty(3, H, W, **f32) for _ in range(V)]
-    depths = [torch.empty(1, H, W, **f32) for _ in range(V)]
-    alphas = [torch.empty(1, H, W, **f32) for _ in range(V)]
+    lossgrad = loss_spec is not None and loss_spec[0] == "lossgrad"   # abs-grad-only path: no image leaves K6
+    colors = [torch.empty(3, H, W, **f32) for _ in range(V)]    # (lossgrad: d loss / d colour per pixel instead)
+    depths = [None if lossgrad else torch.empty(1, H, W, **f32) for _ in range(V)]
+    alphas = [None if lossgrad else torch.empty(1, H, W, **f32) for _ in range(V)]
     radii = torch.empty(V, N, dtype=torch.int32, device=dev)
     # the V duplicate counters in one array: one fill before K1, one copy to the host (no gather kernel)
     counters = torch.empty(V, dtype=torch.int32, device=dev)
@@ -458,6 +459,13 @@ def _forward_views_impl(means3D, means2D, sh, opacities, scales, rotations, sett
                 alloc_bin(v)
         def composite(v, sv):  # K6 of view v (with the loss folded into its epilogue when loss_spec is given)
             st = states[v]
+            if lossgrad:
+                _, targets, go_scale, losses = loss_spec
+                L.check(lib.gdr_composite_forward_lossgrad(C.byref(s_arr[v]), C.byref(g_arr[v]), C.byref(st.bin),
+                                                           C.byref(st.img), targets[v].data_ptr(), float(go_scale),
+                                                           losses[v:v + 1].data_ptr(), colors[v].data_ptr(), sv),
+                        "gdr_composite_forward_lossgrad")
+                return
             out = L.GdrOutputs(colors[v].data_ptr(), depths[v].data_ptr(), alphas[v].data_ptr(), _ptr(radii[v]))
             if loss_spec is None:
                 L.check(lib.gdr_composite_forward(C.byref(s_arr[v]), C.byref(g_arr[v]), C.byref(st.bin), C.byref(st.img),
@@ -711,14 +719,44 @@ def render_views_raw(means3D, means2D, sh, opacities, scales, rotations, setting
     return colors, torch.stack(radii), depths, alphas
 
 
+def topk_absgrad(grad, k, candidates=None, return_indices=False):
+    """Device top-k of the densification score ||grad[:, 2:4]||_2 (network.py:876-893; k_num = 12 000,
+    configs/base.yaml:30) as the boolean mask the reference builds from torch.topk's indices — radix select in
+    libgdr_hip.so (gdr_topk_absgrad), no sort, no score tensor.  candidates: optional bool (N,) restricting the
+    selection (the reference's `grad[mask]`); k >= number of candidates selects every candidate.  Returns mask (N,)
+    bool, and with return_indices also the selected ids (min(k, candidates),) int64 in no particular order."""
+    lib = L.load()
+    _require_hip(grad, "grad")
+    dev = grad.device
+    g = _f32(grad, dev)
+    N = int(g.shape[0])
+    if g.dim() != 2 or g.shape[1] != 4:
+        raise RuntimeError("topk_absgrad: grad must be (N,4)")
+    cand = None if candidates is None else candidates.to(device=dev, dtype=torch.uint8).contiguous()
+    mask = torch.empty(N, dtype=torch.uint8, device=dev)
+    k = max(0, int(k))
+    idx = torch.full((min(k, N),), -1, dtype=torch.int32, device=dev) if return_indices else None
+    ws = torch.empty(int(lib.gdr_topk_workspace_bytes()), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        L.check(lib.gdr_topk_absgrad(N, _ptr(g), _ptr(cand), k, _ptr(ws), _ptr(mask), _ptr(idx), _stream()),
+                "gdr_topk_absgrad")
+    mask = mask.bool()
+    if return_indices:
+        idx = idx[idx >= 0].long()     # fewer than k candidates: the tail stays unwritten
+        return mask, idx
+    return mask
+
+
 def screenspace_absgrad_raw(means3D, sh, opacities, scales, rotations, settings_list, gt_images, flags=RAW_ALL, topk=0):
     """SURVEY §8f-2.  What the densification step of the reference computes with
     `vjp(fn, screenspace_point)` (network.py:843-878): loss = mean over all views and pixels of
     (clamp(image, 0, 1) - gt)^2 and its gradient w.r.t. the shared (N,4) means2D carrier
-    (columns 0-1 signed, 2-3 sum of |per-pixel terms|) — nothing else.  The MSE is folded into K6's epilogue and into the
-    prologue of the mean2D-only K7 variant, which accumulates over the views into ONE (N,4) buffer: no dL/dimage
-    tensors, no gradient records, no K8/K9.  gt_images: (V,3,H,W).  Returns (loss, grad (N,4)), and with topk > 0 also
-    the indices of the topk largest ||grad[:, 2:4]||_2 (the selection of network.py:878-893, configs/base.yaml:30)."""
+    (columns 0-1 signed, 2-3 sum of |per-pixel terms|) — nothing else.  K6 runs in its loss-only form
+    (gdr_composite_forward_lossgrad): it accumulates the MSE and writes d loss / d colour per pixel, never an image;
+    the mean2D-only K7 accumulates over the views into ONE (N,4) buffer: no colour / depth / alpha tensors, no
+    gradient records, no K8/K9.  gt_images: (V,3,H,W).  Returns (loss, grad (N,4)), and with topk > 0 also
+    the indices of the topk largest ||grad[:, 2:4]||_2 (the selection of network.py:878-893, configs/base.yaml:30) from
+    the device radix select (topk_absgrad)."""
     lib = L.load()
     with torch.no_grad():
         dev = means3D.device
@@ -727,11 +765,10 @@ def screenspace_absgrad_raw(means3D, sh, opacities, scales, rotations, settings_
         gt = _f32(gt_images, dev)
         targets = [gt[v] for v in range(V)]
         losses = torch.zeros(V, dtype=torch.float32, device=dev)
-        colors, radii, depths, alphas, states, keep, _ = _forward_views_impl(
+        dcolors, radii, _, _, states, keep, _ = _forward_views_impl(
             means3D, dummy, sh, opacities, scales, rotations, tuple(settings_list), int(flags),
-            loss_spec=(targets, 0.0, 0.0, losses))
+            loss_spec=("lossgrad", targets, 1.0 / V, losses))
         loss = losses.mean()   # views share one image size: the mean of per-view means is the global mean
-        go = torch.full((1,), 1.0 / V, dtype=torch.float32, device=dev)
         grad = torch.zeros(N, 4, dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             keep2: list = []
@@ -740,13 +777,12 @@ def screenspace_absgrad_raw(means3D, sh, opacities, scales, rotations, settings_
             for v, st in enumerate(states):
                 g = st.geom
                 g.cov3D = states[0].geom.cov3D
-                L.check(lib.gdr_render_backward_mean2d_loss(C.byref(structs[v]), N, C.byref(g), C.byref(st.bin),
-                                                            C.byref(st.img), colors[v].data_ptr(), targets[v].data_ptr(),
-                                                            go.data_ptr(), _ptr(grad), sides.stream(v)),
-                        "gdr_render_backward_mean2d_loss")
+                L.check(lib.gdr_render_backward_mean2d(C.byref(structs[v]), N, C.byref(g), C.byref(st.bin), C.byref(st.img),
+                                                       dcolors[v].data_ptr(), _ptr(grad), sides.stream(v)),
+                        "gdr_render_backward_mean2d")
             sides.join()
         if topk:
-            idx = torch.topk(grad[:, 2:4].norm(dim=1), min(int(topk), N)).indices
+            _, idx = topk_absgrad(grad, int(topk), return_indices=True)
             return loss, grad, idx
     return loss, grad
 

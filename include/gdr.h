@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define GDR_ABI_VERSION 8
+#define GDR_ABI_VERSION 9
 
 #define GDR_OK 0
 #define GDR_ERR_INVALID_ARG (-1)  /* NULL / inconsistent arguments                     */
@@ -295,6 +295,26 @@ int gdr_render_backward_mean2d(const gdr_settings* s, int32_t N, const gdr_geom*
 int gdr_render_backward_mean2d_loss(const gdr_settings* s, int32_t N, const gdr_geom* geom, const gdr_binning* bin,
                                     const gdr_image* img, const float* color, const float* target, const float* g,
                                     float* dL_dmean2D, void* stream);
+
+/* The abs-grad-only path end to end (replaces the vjp of /root/reference/lightning/network.py:843-878 and the
+ * torch.topk of :876-893):
+ *   gdr_composite_forward_lossgrad   K6 with the MSE of one view folded in and NO image output: loss += mean_{c,p}
+ *                                    (clamp(color) - target)^2 (device float, caller zeroes), and dL_dcolor (3,H,W) :=
+ *                                    go_scale * d loss / d color per pixel — the only per-pixel array it writes besides the
+ *                                    backward state (final T, contributor count).  go_scale = the upstream scalar known on
+ *                                    the host (1 / views for a mean over the views).
+ *   gdr_render_backward_mean2d       consumes that dL_dcolor (above).
+ *   gdr_topk_absgrad                 selection on score_i = ||dL_dmean2D[i, 2:4]||_2: mask[i] = 1 for the k largest
+ *                                    scores among the candidates (candidates == NULL: all N; k >= number of candidates:
+ *                                    every candidate — the reference's `gradient_point >= 0` branch); indices (k, may be
+ *                                    NULL) receives the selected ids in no particular order (the reference only builds
+ *                                    a mask from them).  Radix select, no sort; ties at the threshold are cut arbitrarily,
+ *                                    as torch.topk leaves them.  workspace: gdr_topk_workspace_bytes() bytes. */
+int gdr_composite_forward_lossgrad(const gdr_settings* s, const gdr_geom* geom, const gdr_binning* bin, const gdr_image* img,
+                                   const float* target, float go_scale, float* loss, float* dL_dcolor, void* stream);
+size_t gdr_topk_workspace_bytes(void);
+int gdr_topk_absgrad(int32_t N, const float* dL_dmean2D, const uint8_t* candidates, int32_t k, void* workspace,
+                     uint8_t* mask, int32_t* indices, void* stream);
 
 /* ---- fused image loss either side of the path ---------------------------------
  * loss += mean_{c,p}(clamp(color,0,1) - target)^2 + w_depth mean(depth) + w_alpha mean(alpha) for ONE view

@@ -24,4 +24,13 @@ for n, sig in ((262144, (0.0052,)), (2000000, (0.00065,))):
     a = t(lambda: vjp(fn, torch.zeros(n, 4, device=dev)))
     b = t(lambda: vjp(fn2, torch.zeros(n, 4, device=dev)))
     c = t(lambda: r.screenspace_absgrad(cams, None, gt, sc['centers'], sc['shs'], sc['opacity'], sc['scales'], sc['rotations'], dev))
-    print(f'N={n} {h}x{w} 4 views SH1: vjp(render_img per view) {a:.2f} ms | vjp(render_views) {b:.2f} ms | screenspace_absgrad {c:.2f} ms')
+    from generativedensification_amd.rasterizer import topk_absgrad
+    _, grad = r.screenspace_absgrad(cams, None, gt, sc['centers'], sc['shs'], sc['opacity'], sc['scales'], sc['rotations'], dev)
+    def ref_topk():   # network.py:876-893: norm, topk, mask
+        s_ = torch.norm(grad[:, 2:4], dim=-1, keepdim=True).squeeze()
+        idx = torch.topk(s_, 12000, dim=0).indices
+        m = torch.zeros_like(s_, dtype=torch.bool); m[idx] = True
+        return m
+    d = t(ref_topk, 50); e = t(lambda: topk_absgrad(grad, 12000), 50)
+    print(f'N={n} {h}x{w} 4 views SH1: vjp(render_img per view) {a:.2f} ms | vjp(render_views) {b:.2f} ms | screenspace_absgrad {c:.2f} ms'
+          f' | top-12000 mask: torch norm+topk+scatter {d * 1e3:.0f} us, device radix select {e * 1e3:.0f} us')

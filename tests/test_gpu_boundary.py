@@ -117,3 +117,43 @@ def test_inplace_update_between_forward_and_backward_is_an_error(entry):
         victim.add_(0.01)
     with pytest.raises(RuntimeError, match="modified by an inplace operation"):
         out.sum().backward()
+
+
+def test_device_topk_of_the_densification_score_matches_torch_topk():
+    """gdr_topk_absgrad (radix select) == the mask the reference builds from torch.topk(||grad[:, 2:4]||, k)
+    (network.py:876-893): identical sets wherever the k-th score is not tied, correct counts with ties / zeros /
+    a candidate mask / k >= N."""
+    from generativedensification_amd.rasterizer import topk_absgrad
+    dev = torch.device(DEV)
+    g = torch.Generator().manual_seed(3)
+    for N, k in ((200_000, 12_000), (5_000, 12_000), (70_001, 1), (1000, 999)):
+        grad = torch.randn(N, 4, generator=g).to(dev) * torch.rand(N, 1, generator=g).to(dev) ** 4
+        score = grad[:, 2:4].norm(dim=-1)
+        mask, idx = topk_absgrad(grad, k, return_indices=True)
+        kk = min(k, N)
+        assert mask.dtype == torch.bool and int(mask.sum()) == kk and idx.shape == (kk,)
+        assert set(idx.tolist()) == set(torch.nonzero(mask).flatten().tolist())
+        if k < N:
+            ref = torch.topk(score, k).indices
+            kth = float(score[ref].min())
+            sure = score > kth * (1 + 1e-6)                 # (our sqrt(fma) vs torch.norm: an ulp at the threshold)
+            assert bool(mask[sure].all()) and not bool(mask[score < kth * (1 - 1e-6)].any())
+        else:
+            assert bool(mask.all())
+    # many exact ties at the threshold (zeros): exactly k selected, every non-zero score among them
+    grad = torch.zeros(50_000, 4, device=dev)
+    grad[:300, 2] = torch.arange(1, 301, device=dev).float()
+    mask = topk_absgrad(grad, 1000)
+    assert int(mask.sum()) == 1000 and bool(mask[:300].all())
+    # candidates (the reference's grad[mask]): only candidates are selected; k beyond their number selects all of them
+    cand = torch.zeros(50_000, dtype=torch.bool, device=dev)
+    cand[100:400] = True
+    mask = topk_absgrad(grad, 50, candidates=cand)
+    assert int(mask.sum()) == 50 and bool(mask[250:300].all()) and not bool(mask[~cand].any())
+    mask = topk_absgrad(grad, 12_000, candidates=cand)
+    assert bool((mask == cand).all())
+    # NaN scores never win
+    grad = torch.rand(1000, 4, device=dev)
+    grad[::7, 2] = float("nan")
+    mask = topk_absgrad(grad, 100)
+    assert int(mask.sum()) == 100 and not bool(mask[::7].any())
