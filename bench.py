@@ -58,7 +58,7 @@ WORKLOADS = {
 }
 
 
-def algorithmic_bytes(n, d, p, m, tiles):
+def algorithmic_bytes(n, d, p, m, tiles, v=1):
     """Per-kernel ALGORITHMIC HBM bytes per launch (stated in DESIGN.md).
     A = input attribute bytes / Gaussian, S = saved state, G = partial grads, K = key+value."""
     A = 12 + 12 + 16 + 4 + 12 * m
@@ -79,13 +79,16 @@ def algorithmic_bytes(n, d, p, m, tiles):
         render_fwd=d * 44 + p * 28,
         render_bwd=d * (44 + G) + p * 28,
         preprocess_bwd=n * (A + S + G) + n * (A + 16),
+        # multi-view kernels (v views per launch): inputs read once, per-view state v times, outputs written once
+        preprocess_fwd_views=n * (A + v * S),
+        preprocess_bwd_views=n * (A + v * (S + G)) + n * (A + 16),
         _passes=passes,
         _bytes_view=n * (A + S) + n * 28 + d * K + d * (8 + passes * 2 * K) + d * 8 + d * 44 + p * 28
         + d * (44 + G) + p * 28 + n * (A + S + G) + n * (A + 16),
     )
 
 
-def surfel_algorithmic_bytes(n, d, p, m, tiles):
+def surfel_algorithmic_bytes(n, d, p, m, tiles, v=1):
     """2DGS path: A = 12 + 8 + 16 + 4 + 12 M input bytes / surfel, S = 96-byte render record + depth, rect, tiles,
     clamp (25), G = 20 partial gradients (80), K = key + value; per pixel 15 floats out (image 3, allmap 7, final
     T/M1/M2 3, n_contrib 2) and 15 in (10 gradients + 5 state)."""
@@ -93,9 +96,10 @@ def surfel_algorithmic_bytes(n, d, p, m, tiles):
     S, G, K = 96 + 25, 80, 12
     bits = 32 + max(1, math.ceil(math.log2(max(tiles, 2))))
     passes = (bits + 7) // 8
-    out = algorithmic_bytes(n, d, p, m, tiles)
+    out = algorithmic_bytes(n, d, p, m, tiles, v)
     out.update(preprocess_fwd=n * (A + S), render_fwd=d * (4 + 96) + p * 60, render_bwd=d * (4 + 96 + G) + p * 60,
-               preprocess_bwd=n * (A + S + 128) + n * (A + 16), _passes=passes)
+               preprocess_bwd=n * (A + S + 128) + n * (A + 16), preprocess_fwd_views=n * (A + v * S),
+               preprocess_bwd_views=n * (A + v * (S + 128)) + n * (A + 16), _passes=passes)
     out["_bytes_view"] = (out["preprocess_fwd"] + n * 28 + d * K + d * (8 + passes * 2 * K) + d * 8 + out["render_fwd"]
                           + out["render_bwd"] + out["preprocess_bwd"])
     return out
@@ -337,10 +341,15 @@ def main():
     views_per_sec = total_views * args.steps / elapsed
     ms_per_step = 1e3 * elapsed / args.steps
 
+    def note(msg):
+        if rank == 0:
+            print(f"[bench] {msg} (t+{time.perf_counter() - t0:.1f}s)", file=sys.stderr, flush=True)
+
+    note(f"timed region done: {views_per_sec:.1f} views/s")
     # ---- D (num_rendered) per view, measured ----------------------------------------
     from generativedensification_amd import rasterizer as R
     from generativedensification_amd import surfel_rasterizer as SR
-    d_views = []
+    d_views, pair_views = [], []
     with torch.no_grad():
         for cam in cams:
             rs = renderer.set_rasterizer(cam, device=dev).raster_settings
@@ -351,11 +360,18 @@ def main():
                                                    torch.nn.functional.normalize(params["rotations"].detach()), e, rs)
             st = fr[-2]
             d_views.append(st.D)
+            # pixel-Gaussian evaluations of the reference algorithm for this view: every pixel walks its tile's list up to
+            # its last contributor -> sum of n_contrib; the backward walks the same entries again
+            try:
+                nc = st.tensors()["n_contrib"]
+                pair_views.append(int((nc if nc.dim() == 2 else nc.reshape(-1, h, w)[0]).long().sum()))
+            except Exception:
+                pass
             del st, fr
     d_mean = sum(d_views) / len(d_views)
     tiles = ((w + 15) // 16) * ((h + 15) // 16)
     m = (deg + 1) ** 2
-    alg = (surfel_algorithmic_bytes if surfel else algorithmic_bytes)(n, d_mean, h * w, m, tiles)
+    alg = (surfel_algorithmic_bytes if surfel else algorithmic_bytes)(n, d_mean, h * w, m, tiles, min(vpg, 8))
 
     # ---- roofline: per-kernel HIP-event timing, second pass of the same K steps -----------
     roofline = None
@@ -368,25 +384,67 @@ def main():
         torch.cuda.synchronize()
         prof = L.profile_collect(reset=True)
         L.profile_enable(False)
+        try:
+            pmc = json.load(open(args.traffic_json))
+        except Exception:
+            pmc = {}
+        tj, vj = pmc.get(args.workload, {}), pmc.get(args.workload + "_valu", {})
+
+        def pmc_name(name):   # bench kernel id -> kernel symbol in the rocprofv3 summaries
+            alias = {"duplicate_with_keys": "duplicate", "tile_ranges": "ranges", "tile_sort_long": "tile_sort"}
+            base = ("surfel_" if surfel and name in ("preprocess_fwd", "preprocess_bwd", "render_fwd", "render_bwd") else "") \
+                + alias.get(name, name)
+            for cand in (base + "_views_kernel", base + "_kernel"):
+                if cand in tj or cand in vj:
+                    return cand
+            return base + "_kernel"
+
         for name, (ms, cnt) in prof.items():
             if cnt:
-                kernels[name] = dict(avg_us=round(1e3 * ms / cnt, 2), launches=cnt, total_ms=round(ms, 3))
+                k = dict(avg_us=round(1e3 * ms / cnt, 2), launches=cnt, total_ms=round(ms, 3))
+                if alg.get(name):      # algorithmic bytes per launch against the 8 TB/s HBM peak, per kernel
+                    multi = name in ("preprocess_fwd", "preprocess_bwd") and cnt < args.steps * vpg   # views kernels
+                    per_launch = alg[name + "_views"] if multi else alg[name]
+                    k["alg_bytes"] = int(per_launch)
+                    k["alg_GBs"] = round(per_launch / (k["avg_us"] * 1e-6) / 1e9, 1)
+                    k["frac"] = round(k["alg_GBs"] / HBM_PEAK_GBS, 4)
+                if pmc_name(name) in tj:
+                    k["traffic"] = tj[pmc_name(name)]
+                kernels[name] = k
         if kernels:
             dom = max(kernels, key=lambda k: kernels[k]["total_ms"])
             avg_s = kernels[dom]["avg_us"] * 1e-6
-            achieved = alg[dom] / avg_s / 1e9
-            traffic = None
-            try:
-                tj = json.load(open(args.traffic_json)).get(args.workload, {})
-                traffic = tj.get(("surfel_" if surfel else "") + dom + "_kernel", tj.get(dom + "_kernel"))
-            except Exception:
-                pass
+            achieved = kernels[dom].get("alg_bytes", alg[dom]) / avg_s / 1e9
+            traffic = kernels[dom].get("traffic")
             roofline = dict(bound="hbm", kernel=dom, achieved=round(achieved, 1), peak=HBM_PEAK_GBS,
                             unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4),
                             traffic=traffic, alg_bytes_per_launch=int(alg[dom]),
                             avg_launch_us=kernels[dom]["avg_us"],
                             path_bytes_view=int(alg["_bytes_view"]),
                             path_frac=round(views_per_sec / world * alg["_bytes_view"] / 1e9 / HBM_PEAK_GBS, 4))
+            # what the counters say the whole path moves per step (sum over kernels of launches x PMC bytes per launch;
+            # kernels without a PMC figure count with their algorithmic bytes), against the same peak: the algorithmic
+            # path_frac charges the per-Gaussian bytes of K1 / K9 once per view although the multi-view kernels read the
+            # inputs once per node — this one does not
+            moved = sum(k["launches"] * (k.get("traffic") or k.get("alg_bytes") or 0) for nm, k in kernels.items()) / args.steps
+            if not surfel:    # gradient-record memsets: 64 B per Gaussian and view (hipMemsetAsync, not a library kernel)
+                moved += vpg * n * 64
+            roofline.update(path_bytes_step_measured=int(moved),
+                            path_frac_measured=round(moved / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
+            # K6 / K7 are VALU-issue bound, not HBM bound: pixel-Gaussian evaluations and VALU issue rate
+            if pair_views:
+                pairs = sum(pair_views) / len(pair_views)
+                roofline.update(pairs_per_view=int(pairs), pairs_per_s=round(2 * pairs * views_per_sec / world, 1),
+                                pairs_note="sum over pixels of n_contrib = list entries the reference's per-pixel loops "
+                                           "evaluate in the forward; x2 for the backward; per GPU")
+            iv = vj.get(pmc_name(dom))
+            if iv:      # SQ_INSTS_VALU per launch (rocprofv3 --pmc): one wave64 VALU instruction issues in >= 2 cycles
+                simds, clk = 1024, 2.4e9            # on a SIMD32 (v_mul_f32 class, scripts/ubench/valu_rate.hip)
+                roofline.update(valu_insts_per_launch=int(iv),
+                                valu_issue_frac=round(iv * 2 / (kernels[dom]["avg_us"] * 1e-6 * simds * clk), 4),
+                                valu_note="SQ_INSTS_VALU x 2 cycles / (launch time x 1024 SIMDs x 2.4 GHz): fraction of the "
+                                          "peak VALU issue rate; the kernel's own mix (DPP, compares, 3-source fma, exp: "
+                                          "3.5-8 cycles each) averages ~3.6 cycles per instruction")
             # The render kernels of different views run on side streams, two launches at a time: each launch then
             # takes about twice as long as it does alone, and the per-launch figure above halves although the work per
             # second does not.  A short extra pass with the views serialised gives the launch duration of the kernel
@@ -410,6 +468,7 @@ def main():
                                     frac_serial=round(alg[dom] / (avg1 * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
                                     launch_overlap=round(kernels[dom]["avg_us"] / avg1, 2))
 
+    note("roofline pass done")
     # ---- CPU baseline: oracle (C restatement, OpenMP) on a bounded sample ------------------
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -446,6 +505,28 @@ def main():
                             sample=f"oracle C restatement (OpenMP, {cores} threads), {reps} x fwd+bwd of 1 view {h}x{w}, "
                                    f"all {n} Gaussians ({tc:.2f} s each)")
 
+    # ---- the literal "PyTorch-CPU" baseline of north_star: the vectorised torch restatement with autograd
+    # (oracle/torch_ref.py), all host cores, on a bounded sample (a prefix of the Gaussian set at the full image size;
+    # the cost per view is linear in the number of Gaussians at fixed tile occupancy, so the rate is scaled by n_s / n)
+    note("C-oracle baseline done")
+    cpu_baseline_torch = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not surfel and args.workload != "c3":
+        import subprocess
+        thr = min(os.cpu_count() or 1, 16)   # torch's intra-op pool degrades on small per-tile tensors beyond this
+        cmd = [sys.executable, os.path.join(ROOT, "scripts", "torch_cpu_baseline.py"), "--n", str(n), "--seed", str(wl["seed"]),
+               "--sigma0", ",".join(str(x) for x in (wl["sigma0"] or (0.0052,))), "--h", str(h), "--w", str(w), "--deg", str(deg),
+               "--layout", args.layout, "--threads", str(thr)]
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=150)
+            res = json.loads(r.stdout.strip().splitlines()[-1])
+            cpu_baseline_torch = dict(
+                value=round(1.0 / res["seconds"] * (res["n_sample"] / n), 6), unit="views/s", cores=res["threads"], kind="port",
+                sample=f"oracle/torch_ref.py (vectorised PyTorch forward + autograd backward, {res['threads']} threads), 1 x "
+                       f"fwd+bwd of 1 view {h}x{w} on the first {res['n_sample']} of {n} Gaussians ({res['seconds']:.1f} s); "
+                       f"rate scaled by {res['n_sample']}/{n} (cost is linear in N at fixed image size)")
+        except Exception as ex:   # a baseline leg must never stall or fail the bench
+            cpu_baseline_torch = dict(value=None, unit="views/s", kind="port", sample=f"not measured: {type(ex).__name__}")
+
     if rank == 0:
         out = {
             "metric": "views/sec fwd+bwd @ 800x800", "value": round(views_per_sec, 2), "unit": "views/s",
@@ -472,7 +553,7 @@ def main():
                                 else "torch ops" if (args.per_view or args.stacked_loss or args.torch_loss or args.unfused)
                                 else "fused HIP loss kernels (clamp+MSE+0.1 mean depth+0.1 mean alpha)" if args.loss_kernels
                                 else "folded into K6 epilogue / K7 prologue (clamp+MSE+0.1 mean depth+0.1 mean alpha)")},
-            "roofline": roofline, "cpu_baseline": cpu_baseline, "kernels": kernels,
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "cpu_baseline_torch": cpu_baseline_torch, "kernels": kernels,
             "loss_mean": float(last_losses.mean()),
         }
         os.write(result_fd, (json.dumps(out) + "\n").encode())
