@@ -46,7 +46,7 @@ class GdrBinning(C.Structure):
     _fields_ = [("keys", C.c_void_p * 2), ("values", C.c_void_p * 2), ("hist", C.c_void_p),
                 ("sorted", C.c_int32), ("global_sort", C.c_int32), ("scratch32", C.c_void_p),
                 ("seg_extra", C.c_void_p), ("seg_count", C.c_void_p), ("seg_state", C.c_void_p),
-                ("seg_len", C.c_int32), ("seg_cap", C.c_int32)]
+                ("seg_len", C.c_int32), ("seg_cap", C.c_int32), ("deep_max_busy", C.c_int32), ("reserved0", C.c_int32)]
 
 
 class GdrImage(C.Structure):

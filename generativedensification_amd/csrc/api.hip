@@ -95,10 +95,12 @@ static size_t carve_binning(void* base, uint64_t D, gdr_binning* b) {
     t.scratch32 = c.take<uint32_t>(2 * d);
     t.sorted = 0;
     t.global_sort = 0;
+    t.deep_max_busy = GDR_DEFAULT_DEEP_MAX_BUSY;
+    t.reserved0 = 0;
     t.seg_len = GDR_DEFAULT_SEG_LEN;  // callers may raise it (a multiple of 256) or set 0 after carving (include/gdr.h)
     t.seg_cap = t.seg_len ? (int32_t)(D / (uint64_t)t.seg_len + 1) : 0;
     t.seg_extra = c.take<uint32_t>(2 * (size_t)(t.seg_cap ? t.seg_cap : 1));
-    t.seg_count = c.take<uint32_t>(2);
+    t.seg_count = c.take<uint32_t>(4);
     t.seg_state = c.take<float>(t.seg_cap ? (size_t)2 * t.seg_cap * GDR_SEG_STATE_FLOATS : 1);
     if (b) *b = t;
     return c.off;
@@ -535,7 +537,7 @@ const char* gdr_kernel_name(int32_t id) {
     static const char* names[GDR_K_COUNT] = {"preprocess_fwd", "scan_block_sums", "duplicate_with_keys",
         "sort_hist", "sort_rowscan", "sort_scatter", "tile_ranges", "render_fwd", "render_bwd",
         "preprocess_bwd", "mark_visible", "tile_order", "tile_sort", "tile_sort_long", "view_loss", "surfel_maps", "knn",
-        "topk_select"};
+        "topk_select", "render_fwd_deep"};
     return (id >= 0 && id < GDR_K_COUNT) ? names[id] : "";
 }
 int gdr_kernel_count(void) { return GDR_K_COUNT; }

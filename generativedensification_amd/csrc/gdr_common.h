@@ -37,6 +37,7 @@ enum {
     GDR_K_SURFEL_MAPS,
     GDR_K_KNN,
     GDR_K_SELECT,
+    GDR_K_RENDER_FWD_DEEP,
     GDR_K_COUNT
 };
 

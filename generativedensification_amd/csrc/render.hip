@@ -114,7 +114,8 @@ __global__ __launch_bounds__(GDR_BLOCK) void tile_order_kernel(const uint2* __re
                                                                 uint32_t* __restrict__ order, int seg_len,
                                                                 uint32_t* __restrict__ seg_base,
                                                                 uint2* __restrict__ seg_extra,
-                                                                uint32_t* __restrict__ seg_count, int seg_cap) {
+                                                                uint32_t* __restrict__ seg_count, int seg_cap,
+                                                                uint32_t deep_max_busy) {
     __shared__ uint32_t cnt[GDR_ORDER_BUCKETS];
     __shared__ uint32_t wsum[GDR_BLOCK / GDR_WAVE];
     for (int k = threadIdx.x; k < GDR_ORDER_BUCKETS; k += GDR_BLOCK) cnt[k] = 0;
@@ -149,8 +150,25 @@ __global__ __launch_bounds__(GDR_BLOCK) void tile_order_kernel(const uint2* __re
     }
     if (seg_base == nullptr) return;
     if (seg_len <= 0) {
-        if (threadIdx.x < 2) seg_count[threadIdx.x] = 0u;
+        if (threadIdx.x < 3) seg_count[threadIdx.x] = 0u;
         return;
+    }
+    {   // seg_count[2] = "deep" flag: few busy tiles (an object in front of an empty background) -> the forward of the
+        // cut tiles runs with 16 instead of 64 pixels per wave (render_fwd_deep_kernel).  Busy = list of >= 64 entries;
+        // the chip holds 1024 forward workgroups at once (256 CUs x 4), so below ~768 busy tiles CUs sit on one
+        // workgroup (one wave per SIMD) and the walk of a long list is latency-bound.
+        uint32_t mine = 0u;
+        for (int t = threadIdx.x; t < ntiles; t += GDR_BLOCK) {
+            const uint2 r = ranges[t];
+            mine += (r.y - r.x) >= 64u ? 1u : 0u;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off, 64);
+        __syncthreads();
+        if (lane_id() == 0) wsum[threadIdx.x >> 6] = mine;
+        __syncthreads();
+        if (threadIdx.x == 0) seg_count[2] = (wsum[0] + wsum[1] + wsum[2] + wsum[3]) <= deep_max_busy ? 1u : 0u;
+        __syncthreads();
     }
     uint32_t slot_run = 0u, cut_run = 0u;  // uniform running totals over the chunks of 256 tiles
     for (int t0 = 0; t0 < ntiles; t0 += GDR_BLOCK) {
@@ -224,7 +242,7 @@ __global__ __launch_bounds__(GDR_BLOCK) void render_fwd_kernel(
     const float4* __restrict__ rec, const float* __restrict__ bg, float* __restrict__ final_T,
     uint32_t* __restrict__ n_contrib, float* __restrict__ out_color, float* __restrict__ out_depth,
     float* __restrict__ out_alpha, const FusedLoss fl, const uint32_t* __restrict__ seg_base,
-    float* __restrict__ seg_state, int seg_rounds) {
+    float* __restrict__ seg_state, int seg_rounds, const uint32_t* __restrict__ deep_flag) {
     __shared__ SliceLds lds;
     __shared__ int s_done[GDR_BLOCK / GDR_WAVE];
 
@@ -248,6 +266,7 @@ __global__ __launch_bounds__(GDR_BLOCK) void render_fwd_kernel(
     const int full_rounds = (full_total + GDR_BLOCK - 1) / GDR_BLOCK;
     const uint32_t sb = (seg_rounds > 0 && full_rounds > seg_rounds) ? seg_base[tile] : 0xFFFFFFFFu;
     const bool cut = sb != 0xFFFFFFFFu;
+    if (cut && deep_flag && *deep_flag) return;  // rendered by render_fwd_deep_kernel (launched in front of this one)
     const int seg_len = seg_rounds * GDR_BLOCK;
     const int nseg = cut ? (full_rounds + seg_rounds - 1) / seg_rounds : 1;
 
@@ -399,6 +418,226 @@ __global__ __launch_bounds__(GDR_BLOCK) void render_fwd_kernel(
         if (lane == 0) wl[wave] = lp;
         __syncthreads();
         if (threadIdx.x == 0) atomicAdd(fl.loss, (wl[0] + wl[1]) + (wl[2] + wl[3]));
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// K6 "deep": the forward of CUT tile lists when few tiles are busy (seg_count[2], set by tile_order_kernel).
+// An object in front of an empty background (the reference's scenes: /root/reference/dataLoader/gobjverse.py:46-104)
+// puts all duplicates into a few hundred tiles with 10^4 entries each: the standard kernel then has ONE workgroup per
+// CU (one wave per SIMD) walking a long list, and LDS / transcendental / DPP latencies are fully exposed (C4 `shell`:
+// 897 us against 207 us for the same number of duplicates spread over 2500 tiles).  Compositing is sequential per
+// pixel, so more parallelism has to come from fewer pixels per wave: here a workgroup takes an 8x8 QUARTER of the tile
+// (4 workgroups per tile, each staging the tile's slices itself), a wave a 4x4 block, and the FOUR lanes of a pixel
+// take four consecutive entries of the block's culled sub-list: alpha is evaluated for the four in parallel, the
+// transmittance chain T_{j+1} = T_j - alpha_j T_j runs through the quad with three DPP moves (same operation order as
+// the standard kernel: identical T, identical skip / stop decisions), every lane accumulates its own partial colour /
+// depth / coverage sums, reduced once per cut and at the end.  A pixel that saturates inside an iteration (rare: once
+// per pixel) sends its wave through a sequential replay of that iteration.  4x the waves for the same work.
+// Pixel state saved at the cuts uses the standard kernel's thread order, so K7 is unchanged.
+// ---------------------------------------------------------------------------------
+template <int LOSS>
+__global__ __launch_bounds__(GDR_BLOCK) void render_fwd_deep_kernel(
+    const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, const uint32_t* __restrict__ tile_order,
+    int W, int H, int gx, int ntiles, const float4* __restrict__ rec, const float* __restrict__ bg,
+    float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float* __restrict__ out_color,
+    float* __restrict__ out_depth, float* __restrict__ out_alpha, const FusedLoss fl,
+    const uint32_t* __restrict__ seg_base, float* __restrict__ seg_state, int seg_rounds,
+    const uint32_t* __restrict__ deep_flag) {
+    __shared__ SliceLds lds;
+    __shared__ uint16_t clist[GDR_BLOCK / GDR_WAVE][GDR_BLOCK];
+    __shared__ int s_done[GDR_BLOCK / GDR_WAVE];
+    if (*deep_flag == 0u || (int)(blockIdx.x >> 2) >= ntiles) return;
+    const uint32_t tile = tile_order[blockIdx.x >> 2], quarter = blockIdx.x & 3u;
+    const uint2 range = ranges[tile];
+    const int full_total = (int)(range.y - range.x);
+    const int full_rounds = (full_total + GDR_BLOCK - 1) / GDR_BLOCK;
+    const uint32_t sb = (seg_rounds > 0 && full_rounds > seg_rounds) ? seg_base[tile] : 0xFFFFFFFFu;
+    if (sb == 0xFFFFFFFFu) return;   // not a cut tile: the standard kernel renders it
+    const int seg_len = seg_rounds * GDR_BLOCK;
+    const int nseg = (full_rounds + seg_rounds - 1) / seg_rounds;
+
+    const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
+    const uint32_t pq = lane >> 2, j = lane & 3u;   // pixel of the wave's 4x4 block, sub-lane (entry slot) of the pixel
+    if (threadIdx.x == 0) {
+        lds.xy[GDR_NULL_ENTRY] = make_float2(0.f, 0.f);
+        lds.co[GDR_NULL_ENTRY] = make_float4(0.f, 0.f, 0.f, 0.f);
+        lds.cd[GDR_NULL_ENTRY] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const int tx = (int)(tile % (uint32_t)gx), ty = (int)(tile / (uint32_t)gx);
+    const int bx0 = tx * GDR_TILE + (int)(quarter & 1u) * 8 + (int)(wave & 1u) * 4;
+    const int by0 = ty * GDR_TILE + (int)(quarter >> 1) * 8 + (int)(wave >> 1) * 4;
+    const int px = bx0 + (int)(pq & 3u), py = by0 + (int)(pq >> 2);
+    const bool inside = px < W && py < H;
+    const float pxf = (float)px, pyf = (float)py;
+    const float BX = (float)bx0, BY = (float)by0;
+    const uint32_t tid_std = quarter * 64u + wave * 16u + pq;  // this pixel's thread in the standard kernel / in K7
+
+    float thr = inside ? GDR_ALPHA_MIN : INFINITY;
+    float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f, Wt = 0.f;   // T: the pixel's (same on its 4 lanes); sums: per lane
+    uint32_t last_contributor = 0;
+
+    auto quad_sum = [&](float v) __attribute__((always_inline)) -> float {
+        v += dpp_get<0xB1, 0xf>(v);   // quad_perm [1,0,3,2]
+        v += dpp_get<0x4E, 0xf>(v);   // quad_perm [2,3,0,1]
+        return v;
+    };
+    auto save_state = [&](int slot) __attribute__((always_inline)) {
+        const float c0 = quad_sum(C0), c1 = quad_sum(C1), c2 = quad_sum(C2), dp = quad_sum(Dp), wt = quad_sum(Wt);
+        if (j == 0u) {
+            float* st = seg_state + ((size_t)sb + (size_t)slot) * GDR_SEG_STATE_FLOATS + tid_std;
+            st[0] = T; st[GDR_BLOCK] = c0; st[2 * GDR_BLOCK] = c1; st[3 * GDR_BLOCK] = c2;
+            st[4 * GDR_BLOCK] = dp; st[5 * GDR_BLOCK] = wt;
+        }
+    };
+
+    auto walk = [&](int pos0, int count) __attribute__((always_inline)) -> bool {
+        const uint32_t first = range.x + (uint32_t)pos0;
+        const int rounds = (count + GDR_BLOCK - 1) / GDR_BLOCK;
+        float4 r_xe = make_float4(0.f, 0.f, 0.f, 0.f), r_co = r_xe, r_cd = r_xe;
+        bool r_valid = (int)threadIdx.x < count;
+        if (r_valid) {
+            const uint32_t id = point_list[first + threadIdx.x];
+            const float4 a0 = rec[4 * (size_t)id], a3 = rec[4 * (size_t)id + 3];
+            r_xe = make_float4(a0.x, a0.y, a3.x, a3.y); r_co = rec[4 * (size_t)id + 1]; r_cd = rec[4 * (size_t)id + 2];
+        }
+        for (int r = 0; r < rounds; ++r) {
+            uint64_t live = __ballot(thr < INFINITY);
+            if (lane == 0) s_done[wave] = live == 0ull ? 1 : 0;
+            __syncthreads();
+            if (s_done[0] + s_done[1] + s_done[2] + s_done[3] == GDR_BLOCK / GDR_WAVE) return true;
+            stage_write(lds, r_valid, r_xe, r_co, r_cd);
+            __syncthreads();
+            {   // prefetch the next slice
+                const int nxt = (r + 1) * GDR_BLOCK + (int)threadIdx.x;
+                r_valid = nxt < count;
+                if (r_valid) {
+                    const uint32_t id = point_list[first + (uint32_t)nxt];
+                    const float4 a0 = rec[4 * (size_t)id], a3 = rec[4 * (size_t)id + 3];
+                    r_xe = make_float4(a0.x, a0.y, a3.x, a3.y); r_co = rec[4 * (size_t)id + 1]; r_cd = rec[4 * (size_t)id + 2];
+                }
+            }
+            if (live == 0ull) continue;
+            // the block's sub-list of this slice, compacted in list order into clist[wave]
+            int n = 0;
+#pragma unroll
+            for (int g = 0; g < GDR_BLOCK / GDR_WAVE; ++g) {
+                const float2 m = lds.xy[g * GDR_WAVE + (int)lane];
+                const float2 hh = lds.ext[g * GDR_WAVE + (int)lane];
+                const bool ov = hh.x >= 0.f && m.x + hh.x >= BX && m.x - hh.x <= BX + 3.f && m.y + hh.y >= BY &&
+                                m.y - hh.y <= BY + 3.f;
+                const uint64_t mk = __ballot(ov);
+                const int below = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
+                if (ov) clist[wave][n + below] = (uint16_t)(g * GDR_WAVE + (int)lane);
+                n += __popcll(mk);
+            }
+            if (n == 0) continue;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // clist is wave-private: LDS order within the wave
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            const uint32_t base = (uint32_t)(pos0 + r * GDR_BLOCK) + 1u;
+            auto fetch = [&](int i, Entry& en) __attribute__((always_inline)) {
+                const int idx = i + (int)j;
+                en.e = idx < n ? (uint32_t)clist[wave][idx] : (uint32_t)GDR_NULL_ENTRY;
+                en.m = lds.xy[en.e]; en.co = lds.co[en.e]; en.cd = lds.cd[en.e];
+            };
+            Entry cur, nxt;
+            fetch(0, cur);
+            bool all_done = false;
+            for (int i = 0; i < n && !all_done; i += 4) {
+                if (i + 4 < n) fetch(i + 4, nxt);
+                const float dx = cur.m.x - pxf, dy = cur.m.y - pyf;
+                const float p2 = gauss_power(dx, dy, cur.co.x, cur.co.y, cur.co.z);
+                float alpha = fminf(0.99f, cur.co.w * __builtin_amdgcn_exp2f(p2));
+                alpha = (p2 > 0.f) ? 0.f : alpha;         // (null entry: opacity 0 -> alpha 0)
+                float a_c = (alpha >= thr) ? alpha : 0.f;
+                // transmittance in front of this lane's entry: chain through the quad, T_{j+1} = fma(-a_j, T_j, T_j)
+                float Tj = T;
+                float u = fmaf(-a_c, Tj, Tj);
+                float x = dpp_get<0x90, 0xf>(u);          // quad_perm [0,0,1,2]: lane j reads lane j - 1
+                Tj = j >= 1u ? x : Tj;
+                u = fmaf(-a_c, Tj, Tj); x = dpp_get<0x90, 0xf>(u); Tj = j >= 2u ? x : Tj;
+                u = fmaf(-a_c, Tj, Tj); x = dpp_get<0x90, 0xf>(u); Tj = j >= 3u ? x : Tj;
+                u = fmaf(-a_c, Tj, Tj);                   // transmittance behind this lane's entry
+                float w;
+                if (__ballot(u < 0.0001f) == 0ull) {      // nobody saturates in this iteration (the common case)
+                    w = a_c * Tj;
+                    T = dpp_get<0xFF, 0xf>(u);            // quad_perm [3,3,3,3]: behind the fourth entry
+                } else {
+                    // sequential replay of the four entries, exactly the standard kernel's per-entry step
+                    float Tq = T, thr_q = thr;
+                    w = 0.f;
+#pragma unroll
+                    for (uint32_t k = 0; k < 4u; ++k) {
+                        const float ak = (alpha >= thr_q) ? alpha : 0.f;
+                        const float Tn = fmaf(-ak, Tq, Tq);
+                        const bool stop = Tn < 0.0001f;
+                        const float wk = stop ? 0.f : ak * Tq;
+                        const float Ta = stop ? Tq : Tn, tha = stop ? INFINITY : thr_q;
+                        w = j == k ? wk : w;
+                        Tq = k == 0u ? dpp_get<0x00, 0xf>(Ta) : (k == 1u ? dpp_get<0x55, 0xf>(Ta) : (k == 2u ? dpp_get<0xAA, 0xf>(Ta) : dpp_get<0xFF, 0xf>(Ta)));
+                        thr_q = k == 0u ? dpp_get<0x00, 0xf>(tha) : (k == 1u ? dpp_get<0x55, 0xf>(tha) : (k == 2u ? dpp_get<0xAA, 0xf>(tha) : dpp_get<0xFF, 0xf>(tha)));
+                    }
+                    T = Tq; thr = thr_q;
+                    all_done = __ballot(thr < INFINITY) == 0ull;
+                }
+                C0 = fmaf(cur.cd.x, w, C0);
+                C1 = fmaf(cur.cd.y, w, C1);
+                C2 = fmaf(cur.cd.z, w, C2);
+                Dp = fmaf(cur.cd.w, w, Dp);
+                Wt += w;
+                last_contributor = (w > 0.f) ? base + cur.e : last_contributor;
+                cur = nxt;
+            }
+        }
+        return false;
+    };
+
+    for (int sg = 0; sg < nseg; ++sg) {
+        const int pos0 = sg * seg_len;
+        const int count = min(seg_len, full_total - pos0);
+        if (sg > 0) save_state(sg - 1);
+        if (walk(pos0, count)) break;
+    }
+    save_state(nseg - 1);
+    {
+        const float c0 = quad_sum(C0), c1 = quad_sum(C1), c2 = quad_sum(C2), dp = quad_sum(Dp), wt = quad_sum(Wt);
+        uint32_t lc = last_contributor;
+        lc = max(lc, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lc, 0xB1, 0xf, 0xf, false));
+        lc = max(lc, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lc, 0x4E, 0xf, 0xf, false));
+        float lp = 0.f;
+        if (inside && j == 0u) {
+            const size_t pix = (size_t)py * W + px, P = (size_t)H * W;
+            final_T[pix] = T;
+            n_contrib[pix] = lc;
+            const float f0 = fmaf(T, bg[0], c0), f1 = fmaf(T, bg[1], c1), f2 = fmaf(T, bg[2], c2);
+            if (LOSS == 2) {
+                const float k = fl.go_scale * 2.f / (3.f * (float)P);
+                out_color[pix] = (f0 >= 0.f && f0 <= 1.f) ? k * (f0 - fl.target[pix]) : 0.f;
+                out_color[P + pix] = (f1 >= 0.f && f1 <= 1.f) ? k * (f1 - fl.target[P + pix]) : 0.f;
+                out_color[2 * P + pix] = (f2 >= 0.f && f2 <= 1.f) ? k * (f2 - fl.target[2 * P + pix]) : 0.f;
+            } else {
+                out_color[pix] = f0; out_color[P + pix] = f1; out_color[2 * P + pix] = f2;
+                out_depth[pix] = dp;
+                out_alpha[pix] = wt;
+            }
+            if (LOSS) {
+                const float invp = 1.f / (float)P;
+                const float e0 = fminf(fmaxf(f0, 0.f), 1.f) - fl.target[pix];
+                const float e1 = fminf(fmaxf(f1, 0.f), 1.f) - fl.target[P + pix];
+                const float e2 = fminf(fmaxf(f2, 0.f), 1.f) - fl.target[2 * P + pix];
+                lp = (fmaf(e0, e0, fmaf(e1, e1, e2 * e2)) * (1.f / 3.f) + fl.w_depth * dp + fl.w_alpha * wt) * invp;
+            }
+        }
+        if (LOSS) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) lp += __shfl_xor(lp, off, 64);
+            __syncthreads();
+            float* wl = reinterpret_cast<float*>(s_done);
+            if (lane == 0) wl[wave] = lp;
+            __syncthreads();
+            if (threadIdx.x == 0) atomicAdd(fl.loss, (wl[0] + wl[1]) + (wl[2] + wl[3]));
+        }
     }
 }
 
@@ -656,20 +895,35 @@ __global__ __launch_bounds__(GDR_BLOCK) void render_bwd_kernel(
 hipError_t launch_tile_order(const gdr_image* img, const gdr_binning* bin, int ntiles, hipStream_t st) {
     GDR_LAUNCH(GDR_K_TILE_ORDER, tile_order_kernel, dim3(1), dim3(GDR_BLOCK), st, (const uint2*)img->ranges,
                ntiles, img->tile_order, bin->seg_len, img->seg_base, (uint2*)bin->seg_extra, bin->seg_count,
-               bin->seg_cap);
+               bin->seg_cap, (uint32_t)(bin->deep_max_busy > 0 ? bin->deep_max_busy : 0));
     return hipGetLastError();
 }
 
+
+// cut tiles in "deep" mode (seg_count[2]): 4 workgroups per cut tile, in front of the standard launch
+#define GDR_DEEP_FLAG(bin, img) (seg_rounds_of(bin, img) ? (const uint32_t*)(bin)->seg_count + 2 : nullptr)
+#define GDR_DEEP_LAUNCH(LOSSV, COLOR, DEPTH, ALPHA, FL)                                                                  \
+    do {                                                                                                                  \
+        if (seg_rounds_of(bin, img) && img->tile_order && bin->deep_max_busy > 0) {                                       \
+            int ndeep = bin->seg_cap < ntiles ? bin->seg_cap : ntiles;     /* cut tiles <= busy tiles <= deep_max_busy */ \
+            ndeep = 4 * (ndeep < bin->deep_max_busy ? ndeep : bin->deep_max_busy);                                        \
+            GDR_LAUNCH(GDR_K_RENDER_FWD_DEEP, render_fwd_deep_kernel<LOSSV>, dim3(ndeep), dim3(GDR_BLOCK), st,             \
+                       (const uint2*)img->ranges, bin->values[bin->sorted], img->tile_order, W, H, gx, ntiles,            \
+                       (const float4*)g->rec, s->bg, img->final_T, img->n_contrib, COLOR, DEPTH, ALPHA, FL,               \
+                       GDR_SEG_FWD_ARGS(bin, img), GDR_DEEP_FLAG(bin, img));                                              \
+        }                                                                                                                 \
+    } while (0)
 
 hipError_t launch_render_fwd(const gdr_settings* s, const gdr_geom* g, const gdr_binning* bin,
                              const gdr_image* img, const gdr_outputs* out, hipStream_t st) {
     const int W = s->image_width, H = s->image_height;
     const int gx = tile_grid_x(W), gy = tile_grid_y(H);
     const int ntiles = gx * gy;
+    GDR_DEEP_LAUNCH(0, out->color, out->depth, out->alpha, FusedLoss{});
     GDR_LAUNCH(GDR_K_RENDER_FWD, render_fwd_kernel<0>, dim3(ntiles), dim3(GDR_BLOCK), st,
                (const uint2*)img->ranges, bin->values[bin->sorted], img->tile_order, W, H, gx, ntiles,
                (const float4*)g->rec, s->bg, img->final_T, img->n_contrib, out->color, out->depth, out->alpha,
-               FusedLoss{}, GDR_SEG_FWD_ARGS(bin, img));
+               FusedLoss{}, GDR_SEG_FWD_ARGS(bin, img), img->tile_order ? GDR_DEEP_FLAG(bin, img) : nullptr);
     return hipGetLastError();
 }
 
@@ -680,10 +934,11 @@ hipError_t launch_render_fwd_loss(const gdr_settings* s, const gdr_geom* g, cons
     const int gx = tile_grid_x(W), gy = tile_grid_y(H);
     const int ntiles = gx * gy;
     const FusedLoss fl{target, w_depth, w_alpha, loss, nullptr, nullptr, 1.f};
+    GDR_DEEP_LAUNCH(1, out->color, out->depth, out->alpha, fl);
     GDR_LAUNCH(GDR_K_RENDER_FWD, render_fwd_kernel<1>, dim3(ntiles), dim3(GDR_BLOCK), st,
                (const uint2*)img->ranges, bin->values[bin->sorted], img->tile_order, W, H, gx, ntiles,
                (const float4*)g->rec, s->bg, img->final_T, img->n_contrib, out->color, out->depth, out->alpha, fl,
-               GDR_SEG_FWD_ARGS(bin, img));
+               GDR_SEG_FWD_ARGS(bin, img), img->tile_order ? GDR_DEEP_FLAG(bin, img) : nullptr);
     return hipGetLastError();
 }
 
@@ -695,10 +950,12 @@ hipError_t launch_render_fwd_lossgrad(const gdr_settings* s, const gdr_geom* g, 
     const int gx = tile_grid_x(W), gy = tile_grid_y(H);
     const int ntiles = gx * gy;
     const FusedLoss fl{target, 0.f, 0.f, loss, nullptr, nullptr, go_scale};
+    float* const none = nullptr;
+    GDR_DEEP_LAUNCH(2, dL_dcolor, none, none, fl);
     GDR_LAUNCH(GDR_K_RENDER_FWD, render_fwd_kernel<2>, dim3(ntiles), dim3(GDR_BLOCK), st,
                (const uint2*)img->ranges, bin->values[bin->sorted], img->tile_order, W, H, gx, ntiles,
-               (const float4*)g->rec, s->bg, img->final_T, img->n_contrib, dL_dcolor, nullptr, nullptr, fl,
-               GDR_SEG_FWD_ARGS(bin, img));
+               (const float4*)g->rec, s->bg, img->final_T, img->n_contrib, dL_dcolor, none, none, fl,
+               GDR_SEG_FWD_ARGS(bin, img), img->tile_order ? GDR_DEEP_FLAG(bin, img) : nullptr);
     return hipGetLastError();
 }
 

@@ -89,7 +89,7 @@ class _State:
             num_rendered=D,
         )
         out["seg_len"] = int(b.seg_len)
-        out["seg_count"] = self._view(bb, b.seg_count, torch.int32, 2)  # rows of seg_extra, state slots (filled by K6)
+        out["seg_count"] = self._view(bb, b.seg_count, torch.int32, 3)  # rows of seg_extra, state slots (filled by K6)
         out["xy"], out["conic_opacity"], out["rgb"] = out["rec"][:, 0:2], out["rec"][:, 4:8], out["rec"][:, 8:12]
         if D > 0:
             out["keys_sorted"] = self._view(bb, b.keys[s], torch.int64, D)
@@ -158,7 +158,13 @@ BIN_STREAM = None if _BIN_STREAM_ENV is None else max(0, int(_BIN_STREAM_ENV))
 SEG_LEN = int(_os.environ["GDR_SEG_LEN"]) if _os.environ.get("GDR_SEG_LEN") else None
 
 
+# K6 "deep" forward (include/gdr.h gdr_binning.deep_max_busy): None = library default (768 busy tiles), 0 = never.
+DEEP_MAX_BUSY = int(_os.environ["GDR_DEEP_MAX_BUSY"]) if _os.environ.get("GDR_DEEP_MAX_BUSY") else None
+
+
 def _apply_seg_len(bin_struct, D):
+    if DEEP_MAX_BUSY is not None:
+        bin_struct.deep_max_busy = max(0, int(DEEP_MAX_BUSY))
     if SEG_LEN is not None:
         sl = max(0, int(SEG_LEN)) // 256 * 256
         if sl and sl >= bin_struct.seg_len > 0:   # only lengths >= the carved one fit the carved tables

@@ -53,6 +53,7 @@ extern "C" {
 #define GDR_MAX_GAUSSIANS (1 << 27) /* 134 M Gaussians: 32 GB of degree-3 inputs               */
 #define GDR_MAX_RENDERED 0xFFFFFFFFull /* D = sum of tiles_touched of one view                  */
 
+#define GDR_DEFAULT_DEEP_MAX_BUSY 768 /* gdr_binning.deep_max_busy as carved: 3/4 of the 1024 resident K6 workgroups */
 #define GDR_DEFAULT_SEG_LEN 2048 /* gdr_binning.seg_len as carved (the library reads no environment variable) */
 #define GDR_TILE 16 /* tile edge in pixels (BLOCK_X = BLOCK_Y = 16) */
 
@@ -138,13 +139,18 @@ typedef struct gdr_binning {
      * a tile whose sorted list is longer than seg_len entries is cut every seg_len entries;
      * K6 saves the per-pixel compositing state at every cut and at the end of the list. */
     uint32_t* seg_extra; /* (seg_cap,2) (tile, segment) of every segment but the last of its tile */
-    uint32_t* seg_count; /* (2) rows of seg_extra, state slots                                    */
+    uint32_t* seg_count; /* (4) rows of seg_extra, state slots, "deep forward" flag (few busy tiles), - */
     float* seg_state;    /* (2*seg_cap, 10, 256) K6 -> K7: per pixel of the tile, in front of each cut and at
                           * the end of the list: T, colour x3, depth, alpha sums (gdr); T, colour x3,
                           * normal x3, depth, M1, M2 (gsr)                                          */
     int32_t seg_len;     /* entries per segment (multiple of 256); 0 = lists are never cut.  gdr_binning_carve sets
                           * GDR_DEFAULT_SEG_LEN and sizes the tables for it; a caller may RAISE it or set 0 afterwards */
     int32_t seg_cap;     /* D / seg_len + 1                                                         */
+    int32_t deep_max_busy; /* K6 renders the CUT tiles with 16 instead of 64 pixels per wave ("deep" forward, 4 workgroups
+                          * per tile) when at most this many tiles hold >= 64 entries — an object in front of an empty
+                          * background leaves most CUs with one workgroup walking a long list.  gdr_binning_carve sets
+                          * GDR_DEFAULT_DEEP_MAX_BUSY; 0 = never. */
+    int32_t reserved0;
 } gdr_binning;
 
 /* Image state (upstream "imgBuffer"). */

@@ -759,11 +759,14 @@ def test_cut_tile_lists_give_the_gradients_of_the_uncut_walk(oracle_built):
     grads = U.rand_grads(case)
     res = {}
     try:
+        R.DEEP_MAX_BUSY = 0     # (the deep forward of cut tiles is compared with this one below)
         for sl in (0, 2048, 4096):
             R.SEG_LEN = sl
             res[sl] = U.run_hip(case, grads)
+        R.DEEP_MAX_BUSY, R.SEG_LEN = None, 2048
+        deep = U.run_hip(case, grads)
     finally:
-        R.SEG_LEN = None
+        R.SEG_LEN, R.DEEP_MAX_BUSY = None, None
     (h0, g0) = res[0]
     if res[2048][0]["seg_len"] == 0:
         pytest.skip("cut lists disabled in this process (GDR_SEG_LEN=0)")
@@ -780,6 +783,17 @@ def test_cut_tile_lists_give_the_gradients_of_the_uncut_walk(oracle_built):
         for k in ("means3D", "means2D", "shs", "opacities", "scales", "rotations"):
             assert U.rel_inf(g[k], g0[k]) < 2e-5, (sl, k, U.rel_inf(g[k], g0[k]))
     assert int(h0["seg_count"][0]) == 0 or h0["seg_len"] == 0
+    # "deep" forward of the cut tiles (two busy tiles here: 16 pixels per wave, four list entries per pixel and iteration):
+    # the transmittance chain is the standard kernel's operation for operation -> identical T, contributor counts and stop
+    # decisions; the colour / depth / coverage sums are four partial sums per pixel -> equal up to summation order
+    hd, gd = deep
+    assert int(hd["seg_count"][2]) == 1 and int(res[2048][0]["seg_count"][2]) == 0
+    for k in ("n_contrib", "final_T"):
+        np.testing.assert_array_equal(hd[k], h0[k])
+    for k in ("color", "depth", "alpha"):
+        assert U.rel_inf(hd[k], h0[k]) < 2e-6, k
+    for k in ("means3D", "means2D", "shs", "opacities", "scales", "rotations"):
+        assert U.rel_inf(gd[k], g0[k]) < 2e-5, (k, U.rel_inf(gd[k], g0[k]))
     _, g64 = U.run_oracle(case, "f64", grads, nthreads=8)
     for sl in (0, 2048, 4096):
         for k in ("means3D", "opacities", "scales", "rotations", "shs"):
