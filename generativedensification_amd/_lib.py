@@ -111,6 +111,9 @@ _PROTOS = {
                                      C.POINTER(GdrOutputs), C.c_void_p]),
     "gdr_binning_forward": (C.c_int, [C.POINTER(GdrSettings), C.c_int32, C.POINTER(GdrGeom), C.POINTER(GdrBinning),
                                       C.POINTER(GdrImage), C.c_uint64, C.c_void_p, C.c_void_p]),
+    "gdr_binning_forward_views": (C.c_int, [C.c_int32, C.POINTER(GdrSettings), C.c_int32, C.POINTER(GdrGeom),
+                                            C.POINTER(GdrBinning), C.POINTER(GdrImage), C.POINTER(C.c_uint64),
+                                            C.POINTER(C.c_void_p), C.c_void_p]),
     "gdr_composite_forward": (C.c_int, [C.POINTER(GdrSettings), C.POINTER(GdrGeom), C.POINTER(GdrBinning),
                                         C.POINTER(GdrImage), C.POINTER(GdrOutputs), C.c_void_p]),
     "gdr_composite_forward_loss": (C.c_int, [C.POINTER(GdrSettings), C.POINTER(GdrGeom), C.POINTER(GdrBinning),

@@ -214,53 +214,72 @@ int gdr_preprocess_forward(const gdr_settings* s, const gdr_inputs* in, const gd
     return GDR_OK;
 }
 
-// K3..K5 + tile sort: everything between K1 and K6; shared by the 3DGS and the surfel path (only the geometry's
-// depths / rects / tiles_touched / block offsets and the radii are read)
-static int binning_stage(const gdr_settings* s, int32_t N, const gdr_geom* geom, gdr_binning* bin, const gdr_image* img,
-                         uint64_t D, const int32_t* radii, hipStream_t st) {
+// K3..K5 + tile sort: everything between K1 and K6, for V views at once (every launch covers all views: BinViews);
+// shared by the 3DGS and the surfel path (only the geometry's depths / rects / tiles_touched / block offsets and the
+// radii are read).  All views share one image size.
+static int binning_stage_views(int V, const gdr_settings* s, int32_t N, const gdr_geom* geoms, gdr_binning* bins,
+                               const gdr_image* imgs, const uint64_t* D, const int32_t* const* radii, hipStream_t st) {
     int rc;
-    const int W = s->image_width, H = s->image_height;
+    const int W = s[0].image_width, H = s[0].image_height;
     const int tiles = tile_grid_x(W) * tile_grid_y(H);
     hipError_t e;
-    if (bin->global_sort) {  // stable global sort: duplicates must be emitted in Gaussian order
-        e = launch_scan_block_sums(geom, N, st);
-        if (e != hipSuccess) return hip_fail("scan_block_sums", e);
+    const bool global_sort = bins[0].global_sort != 0;
+    if (global_sort) {  // stable global sort: duplicates must be emitted in Gaussian order
+        for (int v = 0; v < V; ++v) {
+            e = launch_scan_block_sums(&geoms[v], N, st);
+            if (e != hipSuccess) return hip_fail("scan_block_sums", e);
+        }
     }
-    e = launch_duplicate(geom, N, W, H, radii, bin->global_sort ? geom->block_sums : geom->block_offs, bin->keys[0],
-                         bin->values[0], D, st);
+    BinViews vs;
+    fill_bin_views(&vs, V, geoms, bins, imgs, D, radii);
+    e = launch_duplicate_views(vs, V, N, W, st);
     if (e != hipSuccess) return hip_fail("duplicate", e);
-    if ((rc = debug_sync(s, "duplicate", st))) return rc;
-    if (bin->global_sort) {  // one global stable LSD radix sort over all key bits
-        e = launch_sort(bin, D, key_bits(tiles), st);
-        if (e != hipSuccess) return hip_fail("sort", e);
-        if ((rc = debug_sync(s, "sort", st))) return rc;
-        e = launch_ranges(bin, D, img, tiles, st);
-        if (e != hipSuccess) return hip_fail("ranges", e);
-        if ((rc = debug_sync(s, "ranges", st))) return rc;
-        e = launch_tile_order(img, bin, tiles, st);
-        if (e != hipSuccess) return hip_fail("tile_order", e);
-        if ((rc = debug_sync(s, "tile_order", st))) return rc;
-    } else {  // default: stable partition by tile, segments, per-tile LDS depth sort
-        e = launch_sort_tile_bits(bin, D, key_bits(tiles), st);
-        if (e != hipSuccess) return hip_fail("sort_tile_bits", e);
-        if ((rc = debug_sync(s, "sort_tile_bits", st))) return rc;
-        e = launch_ranges(bin, D, img, tiles, st);
-        if (e != hipSuccess) return hip_fail("ranges", e);
-        if ((rc = debug_sync(s, "ranges", st))) return rc;
-        e = launch_tile_order(img, bin, tiles, st);  // longest list first: launch order of tile_sort, K6, K7
-        if (e != hipSuccess) return hip_fail("tile_order", e);
-        if ((rc = debug_sync(s, "tile_order", st))) return rc;
-        e = launch_tile_sort(bin, img, tiles, D, st);
+    if ((rc = debug_sync(&s[0], "duplicate", st))) return rc;
+    int sorted = 0;
+    // global_sort: one stable LSD radix sort over all key bits; default: stable partition by tile (the tile bits only)
+    e = launch_sort_views(vs, V, global_sort ? 0 : 32, key_bits(tiles), &sorted, st);
+    if (e != hipSuccess) return hip_fail("sort", e);
+    if ((rc = debug_sync(&s[0], "sort", st))) return rc;
+    e = launch_ranges_views(vs, V, sorted, tiles, st);
+    if (e != hipSuccess) return hip_fail("ranges", e);
+    if ((rc = debug_sync(&s[0], "ranges", st))) return rc;
+    e = launch_tile_order_views(vs, V, tiles, st);  // longest list first: launch order of tile_sort, K6, K7
+    if (e != hipSuccess) return hip_fail("tile_order", e);
+    if ((rc = debug_sync(&s[0], "tile_order", st))) return rc;
+    if (!global_sort) {  // per-tile LDS depth sort of the partitioned lists
+        e = launch_tile_sort_views(vs, V, sorted, tiles, st);
         if (e != hipSuccess) return hip_fail("tile_sort", e);
-        if ((rc = debug_sync(s, "tile_sort", st))) return rc;
+        if ((rc = debug_sync(&s[0], "tile_sort", st))) return rc;
+        sorted ^= 1;
     }
+    for (int v = 0; v < V; ++v) bins[v].sorted = sorted;
     return GDR_OK;
+}
+
+static int binning_stage(const gdr_settings* s, int32_t N, const gdr_geom* geom, gdr_binning* bin, const gdr_image* img,
+                         uint64_t D, const int32_t* radii, hipStream_t st) {
+    return binning_stage_views(1, s, N, geom, bin, img, &D, &radii, st);
 }
 
 int gdr_binning_forward(const gdr_settings* s, int32_t N, const gdr_geom* geom, gdr_binning* bin, const gdr_image* img,
                         uint64_t D, const int32_t* radii, void* stream) {
     if (!s || !geom || !bin || !img || N < 0 || (N > 0 && !radii)) { set_error("binning_forward: bad argument", hipSuccess); return GDR_ERR_INVALID_ARG; }
     return binning_stage(s, N, geom, bin, img, D, radii, (hipStream_t)stream);
+}
+
+int gdr_binning_forward_views(int32_t V, const gdr_settings* s, int32_t N, const gdr_geom* geoms, gdr_binning* bins,
+                              const gdr_image* imgs, const uint64_t* D, const int32_t* const* radii, void* stream) {
+    if (V < 1 || V > GDR_MAX_VIEWS) { set_error("binning_forward_views: V out of range", hipSuccess); return GDR_ERR_UNSUPPORTED; }
+    if (!s || !geoms || !bins || !imgs || !D || !radii || N < 0) { set_error("binning_forward_views: bad argument", hipSuccess); return GDR_ERR_INVALID_ARG; }
+    for (int v = 0; v < V; ++v) {
+        if (s[v].image_width != s[0].image_width || s[v].image_height != s[0].image_height ||
+            bins[v].global_sort != bins[0].global_sort) {
+            set_error("binning_forward_views: image size / sort mode must match", hipSuccess);
+            return GDR_ERR_INVALID_ARG;
+        }
+        if (N > 0 && !radii[v]) { set_error("binning_forward_views: radii NULL", hipSuccess); return GDR_ERR_INVALID_ARG; }
+    }
+    return binning_stage_views(V, s, N, geoms, bins, imgs, D, radii, (hipStream_t)stream);
 }
 
 int gdr_composite_forward(const gdr_settings* s, const gdr_geom* geom, const gdr_binning* bin, const gdr_image* img,

@@ -12,6 +12,8 @@
 //
 // CDNA4 notes: wave = 64, so the in-wave stable ranking uses 64-bit ballots (one per
 // digit bit) instead of 32-wide match_any; LDS holds one 256-bin counter row per wave.
+#include <string.h>
+
 #include "gdr_common.h"
 
 namespace gdr {
@@ -73,11 +75,19 @@ __global__ __launch_bounds__(GDR_BLOCK) void scan_block_sums_kernel(uint32_t* __
 // ---------------------------------------------------------------------------------
 // K3
 // ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(GDR_BLOCK) void duplicate_kernel(
-    int N, int gx, const int32_t* __restrict__ radii, const float* __restrict__ depths,
-    const int4* __restrict__ rect, const uint32_t* __restrict__ tiles_touched,
-    const uint32_t* __restrict__ block_offsets, uint64_t* __restrict__ keys,
-    uint32_t* __restrict__ vals, uint64_t D) {
+// (every binning kernel takes the BinViews table by value and works on view blockIdx.y: the ~13 launches of the
+// binning chain are issued ONCE for all views of a multi-view node — the chain is launch-rate and latency bound,
+// gdr_common.h)
+__global__ __launch_bounds__(GDR_BLOCK) void duplicate_kernel(const BinViews vs, int N, int gx) {
+    const BinView& bv = vs.v[blockIdx.y];
+    const int32_t* __restrict__ radii = bv.radii;
+    const float* __restrict__ depths = bv.depths;
+    const int4* __restrict__ rect = bv.rect;
+    const uint32_t* __restrict__ tiles_touched = bv.tiles_touched;
+    const uint32_t* __restrict__ block_offsets = bv.block_offs;
+    uint64_t* __restrict__ keys = bv.keys[0];
+    uint32_t* __restrict__ vals = bv.vals[0];
+    const uint64_t D = bv.D;
     __shared__ uint32_t lds[8];
     const int i = blockIdx.x * GDR_BLOCK + threadIdx.x;
     const uint32_t t = i < N ? tiles_touched[i] : 0u;
@@ -105,9 +115,13 @@ __device__ __forceinline__ uint64_t tile_index(uint32_t blk, uint32_t wave, int 
            (uint64_t)round * GDR_WAVE + lane_id();
 }
 
-__global__ __launch_bounds__(GDR_BLOCK) void sort_hist_kernel(const uint64_t* __restrict__ keys,
-                                                               uint64_t D, int shift, uint32_t nblk,
-                                                               uint32_t* __restrict__ hist) {
+__global__ __launch_bounds__(GDR_BLOCK) void sort_hist_kernel(const BinViews vs, int cur, int shift) {
+    const BinView& bv = vs.v[blockIdx.y];
+    const uint32_t nblk = bv.nblk;
+    if (blockIdx.x >= nblk) return;   // (the grid is sized for the view with the most duplicates)
+    const uint64_t* __restrict__ keys = bv.keys[cur];
+    const uint64_t D = bv.D;
+    uint32_t* __restrict__ hist = bv.hist;
     __shared__ uint32_t cnt[GDR_BLOCK / GDR_WAVE][GDR_RADIX];
     for (int k = threadIdx.x; k < (GDR_BLOCK / GDR_WAVE) * GDR_RADIX; k += GDR_BLOCK)
         (&cnt[0][0])[k] = 0;
@@ -127,9 +141,12 @@ __global__ __launch_bounds__(GDR_BLOCK) void sort_hist_kernel(const uint64_t* __
 }
 
 // one workgroup per digit: exclusive scan of its row of nblk per-block counts.
-__global__ __launch_bounds__(GDR_BLOCK) void sort_rowscan_kernel(uint32_t* __restrict__ hist,
-                                                                  uint32_t nblk,
-                                                                  uint32_t* __restrict__ totals) {
+__global__ __launch_bounds__(GDR_BLOCK) void sort_rowscan_kernel(const BinViews vs) {
+    const BinView& bv = vs.v[blockIdx.y];
+    const uint32_t nblk = bv.nblk;
+    uint32_t* __restrict__ hist = bv.hist;
+    uint32_t* __restrict__ totals = bv.hist + (uint64_t)nblk * GDR_RADIX;
+    if (nblk == 0) return;
     __shared__ uint32_t lds[8];
     uint32_t* row = hist + (uint64_t)blockIdx.x * nblk;
     uint32_t carry = 0;
@@ -144,10 +161,17 @@ __global__ __launch_bounds__(GDR_BLOCK) void sort_rowscan_kernel(uint32_t* __res
     if (threadIdx.x == 0) totals[blockIdx.x] = carry;
 }
 
-__global__ __launch_bounds__(GDR_BLOCK) void sort_scatter_kernel(
-    const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
-    uint64_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, uint64_t D, int shift,
-    uint32_t nblk, const uint32_t* __restrict__ hist, const uint32_t* __restrict__ totals) {
+__global__ __launch_bounds__(GDR_BLOCK) void sort_scatter_kernel(const BinViews vs, int cur, int shift) {
+    const BinView& bv = vs.v[blockIdx.y];
+    const uint32_t nblk = bv.nblk;
+    if (blockIdx.x >= nblk) return;
+    const uint64_t* __restrict__ keys_in = bv.keys[cur];
+    const uint32_t* __restrict__ vals_in = bv.vals[cur];
+    uint64_t* __restrict__ keys_out = bv.keys[cur ^ 1];
+    uint32_t* __restrict__ vals_out = bv.vals[cur ^ 1];
+    const uint64_t D = bv.D;
+    const uint32_t* __restrict__ hist = bv.hist;
+    const uint32_t* __restrict__ totals = bv.hist + (uint64_t)nblk * GDR_RADIX;
     __shared__ uint32_t cnt[GDR_BLOCK / GDR_WAVE][GDR_RADIX];
     __shared__ uint32_t lds[8];
     for (int k = threadIdx.x; k < (GDR_BLOCK / GDR_WAVE) * GDR_RADIX; k += GDR_BLOCK)
@@ -213,8 +237,17 @@ __global__ __launch_bounds__(GDR_BLOCK) void sort_scatter_kernel(
 // ---------------------------------------------------------------------------------
 // K5
 // ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(GDR_BLOCK) void ranges_kernel(const uint64_t* __restrict__ keys, uint64_t D,
-                                                            uint2* __restrict__ ranges) {
+// (ranges of empty tiles must read (0,0): cleared by ranges_clear_kernel in front of this one)
+__global__ __launch_bounds__(GDR_BLOCK) void ranges_clear_kernel(const BinViews vs, int tiles) {
+    const int t = blockIdx.x * GDR_BLOCK + threadIdx.x;
+    if (t < tiles) vs.v[blockIdx.y].ranges[t] = make_uint2(0u, 0u);
+}
+
+__global__ __launch_bounds__(GDR_BLOCK) void ranges_kernel(const BinViews vs, int cur) {
+    const BinView& bv = vs.v[blockIdx.y];
+    const uint64_t* __restrict__ keys = bv.keys[cur];
+    const uint64_t D = bv.D;
+    uint2* __restrict__ ranges = bv.ranges;
     const uint64_t e = (uint64_t)blockIdx.x * GDR_BLOCK + threadIdx.x;
     if (e >= D) return;
     const uint32_t t = (uint32_t)(keys[e] >> 32);
@@ -364,13 +397,17 @@ __device__ __forceinline__ void tile_sort_ties(const uint32_t* kA, uint32_t* vA,
 // larger than CAP — thousands of near-identical depths in one tile — is finished by LSD passes on the global
 // buffers).  3 reads + 2 writes of the list instead of one global round trip per 8 key bits.
 template <int CAP, int LMIN, int NW, bool TOP>
-__global__ __launch_bounds__(NW * GDR_WAVE) void tile_sort_kernel(const uint2* __restrict__ ranges,
-                                                               const uint64_t* __restrict__ keys_part,
-                                                               uint32_t* __restrict__ vals_part,
-                                                               uint64_t* __restrict__ keys_out,
-                                                               uint32_t* __restrict__ vals_out,
-                                                               uint32_t* __restrict__ scratch32, uint64_t D,
-                                                               const uint32_t* __restrict__ tile_order, int ntiles) {
+__global__ __launch_bounds__(NW * GDR_WAVE) void tile_sort_kernel(const BinViews vs, int in, int ntiles) {
+    const BinView& bv = vs.v[blockIdx.y];
+    const uint2* __restrict__ ranges = bv.ranges;
+    const uint64_t* __restrict__ keys_part = bv.keys[in];
+    uint32_t* __restrict__ vals_part = bv.vals[in];
+    uint64_t* __restrict__ keys_out = bv.keys[in ^ 1];
+    uint32_t* __restrict__ vals_out = bv.vals[in ^ 1];
+    uint32_t* __restrict__ scratch32 = bv.scratch32;
+    const uint64_t D = bv.D;
+    const uint32_t* __restrict__ tile_order = bv.tile_order;
+    if (D == 0) return;
     constexpr uint32_t NT = NW * GDR_WAVE;
     __shared__ uint32_t lds_elems[4 * CAP];
     __shared__ uint32_t cnt[NW][GDR_RADIX];
@@ -530,86 +567,76 @@ hipError_t launch_scan_block_sums(const gdr_geom* g, int N, hipStream_t st) {
     return hipGetLastError();
 }
 
-hipError_t launch_duplicate(const gdr_geom* g, int N, int W, int H, const int32_t* radii,
-                            const uint32_t* block_offsets, uint64_t* keys, uint32_t* vals, uint64_t D,
-                            hipStream_t st) {
-    (void)H;
-    if (N == 0) return hipSuccess;
-    GDR_LAUNCH(GDR_K_DUPLICATE, duplicate_kernel, dim3(div_up(N, GDR_BLOCK)), dim3(GDR_BLOCK), st, N,
-                       tile_grid_x(W), radii, g->depths, (const int4*)g->rect, g->tiles_touched,
-                       block_offsets, keys, vals, D);
+// ---- BinViews table of V views ------------------------------------------------------------------------------
+void fill_bin_views(BinViews* vs, int V, const gdr_geom* geoms, const gdr_binning* bins, const gdr_image* imgs,
+                    const uint64_t* D, const int32_t* const* radii) {
+    memset(vs, 0, sizeof(*vs));
+    for (int v = 0; v < V; ++v) {
+        BinView& b = vs->v[v];
+        const gdr_geom& g = geoms[v];
+        const gdr_binning& bn = bins[v];
+        b.radii = radii ? radii[v] : nullptr;
+        b.depths = g.depths; b.rect = (const int4*)g.rect; b.tiles_touched = g.tiles_touched;
+        b.block_offs = bn.global_sort ? g.block_sums : g.block_offs;
+        b.keys[0] = bn.keys[0]; b.keys[1] = bn.keys[1]; b.vals[0] = bn.values[0]; b.vals[1] = bn.values[1];
+        b.hist = bn.hist; b.scratch32 = bn.scratch32;
+        b.ranges = (uint2*)imgs[v].ranges; b.tile_order = imgs[v].tile_order; b.seg_base = imgs[v].seg_base;
+        b.seg_extra = (uint2*)bn.seg_extra; b.seg_count = bn.seg_count;
+        b.D = D[v]; b.nblk = (uint32_t)((D[v] + GDR_SORT_TILE - 1) / GDR_SORT_TILE);
+        b.seg_len = bn.seg_len; b.seg_cap = bn.seg_cap;
+        b.deep_max_busy = (uint32_t)(bn.deep_max_busy > 0 ? bn.deep_max_busy : 0);
+    }
+}
+
+static uint64_t max_D(const BinViews& vs, int V) {
+    uint64_t m = 0;
+    for (int v = 0; v < V; ++v) m = vs.v[v].D > m ? vs.v[v].D : m;
+    return m;
+}
+
+hipError_t launch_duplicate_views(const BinViews& vs, int V, int N, int W, hipStream_t st) {
+    if (N == 0 || max_D(vs, V) == 0) return hipSuccess;
+    GDR_LAUNCH(GDR_K_DUPLICATE, duplicate_kernel, dim3(div_up(N, GDR_BLOCK), V), dim3(GDR_BLOCK), st, vs, N, tile_grid_x(W));
     return hipGetLastError();
 }
 
-hipError_t launch_sort(gdr_binning* bin, uint64_t D, int nbits, hipStream_t st) {
-    bin->sorted = 0;
-    if (D == 0) return hipSuccess;
-    const uint32_t nblk = (uint32_t)((D + GDR_SORT_TILE - 1) / GDR_SORT_TILE);
-    uint32_t* hist = bin->hist;
-    uint32_t* totals = bin->hist + (uint64_t)nblk * GDR_RADIX;
+// stable LSD passes over key bits [lo, hi) of every view; *sorted = buffer index that holds the result
+hipError_t launch_sort_views(const BinViews& vs, int V, int lo, int hi, int* sorted, hipStream_t st) {
+    *sorted = 0;
+    const uint64_t md = max_D(vs, V);
+    if (md == 0) return hipSuccess;
+    const uint32_t nblk = (uint32_t)((md + GDR_SORT_TILE - 1) / GDR_SORT_TILE);
     int cur = 0;
-    for (int shift = 0; shift < nbits; shift += GDR_RADIX_BITS) {
-        GDR_LAUNCH(GDR_K_SORT_HIST, sort_hist_kernel, dim3(nblk), dim3(GDR_BLOCK), st, bin->keys[cur], D,
-                           shift, nblk, hist);
-        GDR_LAUNCH(GDR_K_SORT_ROWSCAN, sort_rowscan_kernel, dim3(GDR_RADIX), dim3(GDR_BLOCK), st, hist, nblk,
-                           totals);
-        GDR_LAUNCH(GDR_K_SORT_SCATTER, sort_scatter_kernel, dim3(nblk), dim3(GDR_BLOCK), st, bin->keys[cur],
-                           bin->values[cur], bin->keys[cur ^ 1], bin->values[cur ^ 1], D, shift,
-                           nblk, hist, totals);
+    for (int shift = lo; shift < hi; shift += GDR_RADIX_BITS) {
+        GDR_LAUNCH(GDR_K_SORT_HIST, sort_hist_kernel, dim3(nblk, V), dim3(GDR_BLOCK), st, vs, cur, shift);
+        GDR_LAUNCH(GDR_K_SORT_ROWSCAN, sort_rowscan_kernel, dim3(GDR_RADIX, V), dim3(GDR_BLOCK), st, vs);
+        GDR_LAUNCH(GDR_K_SORT_SCATTER, sort_scatter_kernel, dim3(nblk, V), dim3(GDR_BLOCK), st, vs, cur, shift);
         cur ^= 1;
     }
-    bin->sorted = cur;
+    *sorted = cur;
     return hipGetLastError();
 }
 
-// stable partition of the pairs by tile: the LSD passes restricted to key bits [32, nbits)
-hipError_t launch_sort_tile_bits(gdr_binning* bin, uint64_t D, int nbits, hipStream_t st) {
-    bin->sorted = 0;
-    if (D == 0) return hipSuccess;
-    const uint32_t nblk = (uint32_t)((D + GDR_SORT_TILE - 1) / GDR_SORT_TILE);
-    uint32_t* hist = bin->hist;
-    uint32_t* totals = bin->hist + (uint64_t)nblk * GDR_RADIX;
-    int cur = 0;
-    for (int shift = 32; shift < nbits; shift += GDR_RADIX_BITS) {
-        GDR_LAUNCH(GDR_K_SORT_HIST, sort_hist_kernel, dim3(nblk), dim3(GDR_BLOCK), st, bin->keys[cur], D,
-                   shift, nblk, hist);
-        GDR_LAUNCH(GDR_K_SORT_ROWSCAN, sort_rowscan_kernel, dim3(GDR_RADIX), dim3(GDR_BLOCK), st, hist, nblk,
-                   totals);
-        GDR_LAUNCH(GDR_K_SORT_SCATTER, sort_scatter_kernel, dim3(nblk), dim3(GDR_BLOCK), st, bin->keys[cur],
-                   bin->values[cur], bin->keys[cur ^ 1], bin->values[cur ^ 1], D, shift, nblk, hist, totals);
-        cur ^= 1;
-    }
-    bin->sorted = cur;
+hipError_t launch_ranges_views(const BinViews& vs, int V, int cur, int tiles, hipStream_t st) {
+    GDR_LAUNCH(GDR_K_RANGES, ranges_clear_kernel, dim3(div_up(tiles, GDR_BLOCK), V), dim3(GDR_BLOCK), st, vs, tiles);
+    const uint64_t md = max_D(vs, V);
+    if (md == 0) return hipGetLastError();
+    GDR_LAUNCH(GDR_K_RANGES, ranges_kernel, dim3(div_up((int64_t)md, GDR_BLOCK), V), dim3(GDR_BLOCK), st, vs, cur);
     return hipGetLastError();
 }
 
-// per-tile depth sort; input = buffers [bin->sorted] (tile-partitioned), output = the other pair
-hipError_t launch_tile_sort(gdr_binning* bin, const gdr_image* img, int tiles, uint64_t D, hipStream_t st) {
-    if (D == 0) return hipSuccess;
-    const int in = bin->sorted, out = in ^ 1;
+// per-tile depth sort; input = buffers [in] (tile-partitioned), output = the other pair
+hipError_t launch_tile_sort_views(const BinViews& vs, int V, int in, int tiles, hipStream_t st) {
+    if (max_D(vs, V) == 0) return hipSuccess;
     // long lists: 16 waves per workgroup (1 per CU) so that the few heavy tiles finish quickly; a two-class scheme
     // (everything beyond the short class bucketed and sorted in short-class chunks, 4 per CU) measured slower at
     // 2 M - 8 M Gaussians and equal at 32 M
     GDR_LAUNCH(GDR_K_TILE_SORT_LONG, (tile_sort_kernel<GDR_TSORT_LARGE, GDR_TSORT_MEDIUM, 16, true>),
-               dim3(tiles < 256 ? tiles : 256), dim3(16 * GDR_WAVE), st, (const uint2*)img->ranges, bin->keys[in],
-               bin->values[in], bin->keys[out], bin->values[out], bin->scratch32, D, img->tile_order, tiles);
+               dim3(tiles < 256 ? tiles : 256, V), dim3(16 * GDR_WAVE), st, vs, in, tiles);
     GDR_LAUNCH(GDR_K_TILE_SORT_LONG, (tile_sort_kernel<GDR_TSORT_MEDIUM, GDR_TSORT_SMALL, 8, false>),
-               dim3(tiles < 512 ? tiles : 512), dim3(8 * GDR_WAVE), st, (const uint2*)img->ranges, bin->keys[in],
-               bin->values[in], bin->keys[out], bin->values[out], bin->scratch32, D, img->tile_order, tiles);
-    GDR_LAUNCH(GDR_K_TILE_SORT, (tile_sort_kernel<GDR_TSORT_SMALL, 0, 4, false>), dim3(tiles), dim3(GDR_BLOCK), st,
-               (const uint2*)img->ranges, bin->keys[in], bin->values[in], bin->keys[out], bin->values[out],
-               bin->scratch32, D, img->tile_order, tiles);
-    bin->sorted = out;
-    return hipGetLastError();
-}
-
-hipError_t launch_ranges(const gdr_binning* bin, uint64_t D, const gdr_image* img, int tiles,
-                         hipStream_t st) {
-    hipError_t e = hipMemsetAsync(img->ranges, 0, (size_t)tiles * 2 * sizeof(uint32_t), st);
-    if (e != hipSuccess) return e;
-    if (D == 0) return hipSuccess;
-    GDR_LAUNCH(GDR_K_RANGES, ranges_kernel, dim3(div_up((int64_t)D, GDR_BLOCK)), dim3(GDR_BLOCK), st,
-                       bin->keys[bin->sorted], D, (uint2*)img->ranges);
+               dim3(tiles < 512 ? tiles : 512, V), dim3(8 * GDR_WAVE), st, vs, in, tiles);
+    GDR_LAUNCH(GDR_K_TILE_SORT, (tile_sort_kernel<GDR_TSORT_SMALL, 0, 4, false>), dim3(tiles, V), dim3(GDR_BLOCK), st, vs, in,
+               tiles);
     return hipGetLastError();
 }
 

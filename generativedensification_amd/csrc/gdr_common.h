@@ -81,19 +81,28 @@ hipError_t launch_preprocess_bwd_views(int V, const gdr_settings* s, const gdr_i
 hipError_t launch_mark_visible(int N, const float* means3D, const float* view, uint8_t* present,
                                hipStream_t st);
 hipError_t launch_scan_block_sums(const gdr_geom* g, int N, hipStream_t st);
-// tile-binned sort (binning.hip)
-hipError_t launch_sort_tile_bits(gdr_binning* bin, uint64_t D, int nbits, hipStream_t st);
-hipError_t launch_tile_sort(gdr_binning* bin, const gdr_image* img, int tiles, uint64_t D, hipStream_t st);
-hipError_t launch_duplicate(const gdr_geom* g, int N, int W, int H, const int32_t* radii,
-                            const uint32_t* block_offsets, uint64_t* keys, uint32_t* vals, uint64_t D,
-                            hipStream_t st);
-hipError_t launch_sort(gdr_binning* bin, uint64_t D, int nbits, hipStream_t st);
-hipError_t launch_ranges(const gdr_binning* bin, uint64_t D, const gdr_image* img, int tiles,
-                         hipStream_t st);
+// ---- binning (binning.hip): every kernel works on a table of V <= GDR_MAX_VIEWS views, view = blockIdx.y ------------
+// The binning chain of one view is ~13 short dependent launches (duplicate, 2 x (hist, row scan, scatter), ranges,
+// tile order, 3 x tile sort) that leave most of the chip idle and cost the host ~5-10 us each: a multi-view node issues
+// the chain ONCE for all its views (kernel timeline of a C4 step, scripts/gpu_timeline.sh: 52 launches spread over
+// 700 us before, host-launch bound).
+struct BinView {
+    const int32_t* radii; const float* depths; const int4* rect; const uint32_t* tiles_touched; const uint32_t* block_offs;
+    uint64_t* keys[2]; uint32_t* vals[2]; uint32_t* hist; uint32_t* scratch32;
+    uint2* ranges; uint32_t* tile_order; uint32_t* seg_base; uint2* seg_extra; uint32_t* seg_count;
+    uint64_t D; uint32_t nblk; int32_t seg_len, seg_cap; uint32_t deep_max_busy;
+};
+struct BinViews { BinView v[GDR_MAX_VIEWS]; };
+void fill_bin_views(BinViews* vs, int V, const gdr_geom* geoms, const gdr_binning* bins, const gdr_image* imgs,
+                    const uint64_t* D, const int32_t* const* radii);
+hipError_t launch_duplicate_views(const BinViews& vs, int V, int N, int W, hipStream_t st);
+hipError_t launch_sort_views(const BinViews& vs, int V, int lo, int hi, int* sorted, hipStream_t st);
+hipError_t launch_ranges_views(const BinViews& vs, int V, int cur, int tiles, hipStream_t st);
+hipError_t launch_tile_sort_views(const BinViews& vs, int V, int in, int tiles, hipStream_t st);
+hipError_t launch_tile_order_views(const BinViews& vs, int V, int tiles, hipStream_t st);
 // per-pixel compositing state saved at a cut of a long tile list, 256 pixels each: 3DGS T, colour x3, depth, alpha
 // sums (6 used); surfels T, colour x3, normal x3, depth, M1, M2 (10)
 #define GDR_SEG_STATE_FLOATS (10 * GDR_BLOCK)
-hipError_t launch_tile_order(const gdr_image* img, const gdr_binning* bin, int tiles, hipStream_t st);
 hipError_t launch_render_fwd(const gdr_settings* s, const gdr_geom* g, const gdr_binning* bin,
                              const gdr_image* img, const gdr_outputs* out, hipStream_t st);
 hipError_t launch_render_fwd_loss(const gdr_settings* s, const gdr_geom* g, const gdr_binning* bin,

@@ -110,12 +110,15 @@ __device__ __forceinline__ void block_masks(const SliceLds& s, int g, float XA, 
 // 0xFFFFFFFF for uncut tiles; seg_extra = (tile, segment) of every segment but the last of its tile (K7: the last one
 // is walked by the tile's own workgroup); seg_count = {rows of seg_extra, slots}.  Sum nseg <= 2 D / seg_len: the
 // tables (capacity seg_cap rows, 2 * seg_cap slots) cannot overflow; the guards are belt and braces.
-__global__ __launch_bounds__(GDR_BLOCK) void tile_order_kernel(const uint2* __restrict__ ranges, int ntiles,
-                                                                uint32_t* __restrict__ order, int seg_len,
-                                                                uint32_t* __restrict__ seg_base,
-                                                                uint2* __restrict__ seg_extra,
-                                                                uint32_t* __restrict__ seg_count, int seg_cap,
-                                                                uint32_t deep_max_busy) {
+__global__ __launch_bounds__(GDR_BLOCK) void tile_order_kernel(const BinViews vs, int ntiles) {
+    const BinView& bv = vs.v[blockIdx.y];   // one workgroup per view
+    const uint2* __restrict__ ranges = bv.ranges;
+    uint32_t* __restrict__ order = bv.tile_order;
+    const int seg_len = bv.seg_len, seg_cap = bv.seg_cap;
+    uint32_t* __restrict__ seg_base = bv.seg_base;
+    uint2* __restrict__ seg_extra = bv.seg_extra;
+    uint32_t* __restrict__ seg_count = bv.seg_count;
+    const uint32_t deep_max_busy = bv.deep_max_busy;
     __shared__ uint32_t cnt[GDR_ORDER_BUCKETS];
     __shared__ uint32_t wsum[GDR_BLOCK / GDR_WAVE];
     for (int k = threadIdx.x; k < GDR_ORDER_BUCKETS; k += GDR_BLOCK) cnt[k] = 0;
@@ -892,10 +895,8 @@ __global__ __launch_bounds__(GDR_BLOCK) void render_bwd_kernel(
 
 }  // namespace
 
-hipError_t launch_tile_order(const gdr_image* img, const gdr_binning* bin, int ntiles, hipStream_t st) {
-    GDR_LAUNCH(GDR_K_TILE_ORDER, tile_order_kernel, dim3(1), dim3(GDR_BLOCK), st, (const uint2*)img->ranges,
-               ntiles, img->tile_order, bin->seg_len, img->seg_base, (uint2*)bin->seg_extra, bin->seg_count,
-               bin->seg_cap, (uint32_t)(bin->deep_max_busy > 0 ? bin->deep_max_busy : 0));
+hipError_t launch_tile_order_views(const BinViews& vs, int V, int ntiles, hipStream_t st) {
+    GDR_LAUNCH(GDR_K_TILE_ORDER, tile_order_kernel, dim3(1, V), dim3(GDR_BLOCK), st, vs, ntiles);
     return hipGetLastError();
 }
 

@@ -79,7 +79,6 @@ class _State:
         out = dict(
             depths=self._view(gb, g.depths, torch.float32, N),
             rec=self._view(gb, g.rec, torch.float32, 16 * N).view(N, 16),
-            cov3D=self._view(gb, g.cov3D, torch.float32, 6 * N).view(N, 6),
             rect=self._view(gb, g.rect, torch.int32, 4 * N).view(N, 4),
             tiles_touched=self._view(gb, g.tiles_touched, torch.int32, N),
             clamped=self._view(gb, g.clamped, torch.uint8, N),
@@ -88,6 +87,8 @@ class _State:
             final_T=self._view(ib, im.final_T, torch.float32, H * W).view(H, W),
             num_rendered=D,
         )
+        if gb.data_ptr() <= g.cov3D < gb.data_ptr() + gb.numel():   # (views > 0 of a multi-view node share view 0's)
+            out["cov3D"] = self._view(gb, g.cov3D, torch.float32, 6 * N).view(N, 6)
         out["seg_len"] = int(b.seg_len)
         out["seg_count"] = self._view(bb, b.seg_count, torch.int32, 3)  # rows of seg_extra, state slots (filled by K6)
         out["xy"], out["conic_opacity"], out["rgb"] = out["rec"][:, 0:2], out["rec"][:, 4:8], out["rec"][:, 8:12]
@@ -147,6 +148,10 @@ VIEW_STREAMS = max(1, int(_os.environ.get("GDR_VIEW_STREAMS", "1")))
 # Two concurrent views fill the CUs that one view's skewed tile lists and kernel tails leave idle; four evict each
 # other's records from L2 (one view's records + gradient records are 2 x 128 MB at 2 M Gaussians).
 RENDER_SIDE = int(_os.environ.get("GDR_RENDER_SIDE", "1"))
+# streams that carry the views' forward chains (binning + K6) of a multi-view node, the caller's stream included
+FWD_STREAMS = int(_os.environ.get("GDR_FWD_STREAMS", "4"))
+# views per binning chain of a multi-view node (gdr_binning_forward_views covers a group of views with every launch)
+BIN_GROUP = int(_os.environ.get("GDR_BIN_GROUP", "1"))
 _BIN_STREAM_ENV = _os.environ.get("GDR_BIN_STREAM")
 BIN_STREAM = None if _BIN_STREAM_ENV is None else max(0, int(_BIN_STREAM_ENV))
 
@@ -371,6 +376,21 @@ _PREALLOC = _os.environ.get("GDR_PREALLOC", "1") != "0"   # A/B switch of the tw
 _D_HINT: dict = {}   # (N, H, W, V) -> duplicate counts per view of the previous call (sizes the next call's workspaces)
 
 
+def binning_views(lib, s_arr, N, g_arr, states, radii, lo, hi, stream, fn="gdr_binning_forward_views"):
+    """K3..K5 + tile sort of views [lo, hi) in shared launches (<= GDR_MAX_VIEWS views per chain)."""
+    for a in range(lo, hi, L.GDR_MAX_VIEWS):
+        n = min(L.GDR_MAX_VIEWS, hi - a)
+        sub_s = (L.GdrSettings * n)(*[s_arr[a + k] for k in range(n)])
+        sub_g = (L.GdrGeom * n)(*[g_arr[a + k] for k in range(n)])
+        b_arr = (L.GdrBinning * n)(*[states[a + k].bin for k in range(n)])
+        i_arr = (L.GdrImage * n)(*[states[a + k].img for k in range(n)])
+        d_arr = (C.c_uint64 * n)(*[states[a + k].D for k in range(n)])
+        r_arr = (C.c_void_p * n)(*[(radii[a + k].data_ptr() if N else None) for k in range(n)])
+        L.check(getattr(lib, fn)(n, sub_s, N, sub_g, b_arr, i_arr, d_arr, r_arr, stream), fn)
+        for k in range(n):
+            states[a + k].bin.sorted = b_arr[k].sorted
+
+
 def _forward_views_impl(means3D, means2D, sh, opacities, scales, rotations, settings_list, flags, loss_spec=None):
     """K1 for all views (one launch per <= 8 views), ONE host read of the V duplicate counts, then binning +
     K6 per view.  Returns (colors, radii, depths, alphas, states, keep, in_dtypes)."""
@@ -488,7 +508,46 @@ def _forward_views_impl(means3D, means2D, sh, opacities, scales, rotations, sett
             # (VALU-bound) on dedicated streams.  The D read-back above synchronised `main`, so every workspace
             # allocated since then is free of pending work and may be touched by a side stream at once; each view's
             # binning is enqueued as soon as its workspace exists (the GPU idles until the first of these launches).
-            binned = []
+            # The host issues ~12 launches per view for the binning and the GPU retires these short kernels about as fast
+            # as they arrive (kernel timeline of a C4 step, scripts/gpu_timeline.sh: 690 us from the first binning launch
+            # to the last, launch-rate bound), so the ORDER of enqueueing decides when the first render kernel can start:
+            # views are enqueued in groups of len(bins) — binning of the group on the binning streams, then K6 of the
+            # group on the render streams behind the views' binning events — and the next group's binning launches go out
+            # while the GPU composites.  Render streams = the caller's stream + one more: with the two binning streams
+            # that is four HIP streams, the number of hardware queues a process gets by default (more alias onto the
+            # same queues and serialise).
+            binned = [None] * V
+            if RENDER_SIDE:
+                # ONE binning chain for all views (gdr_binning_forward_views: every launch covers all the views, ~13 launches
+                # per <= 8 views instead of 13 per view) on the caller's stream, then K6 of the views round-robin over
+                # FWD_STREAMS streams (the caller's + side streams).  Kernel timeline of a C4 step before this
+                # (scripts/gpu_timeline.sh): 52 binning launches spread over 700 us, bound by the host's launch rate, the
+                # first K6 200 us behind its own view's binning.
+                for v in range(V):
+                    alloc_bin(v)
+                nfs = max(1, min(FWD_STREAMS, V))
+                fstreams = [main] + _view_streams(dev, max(nfs - 1, len(auxs)))[:nfs - 1]
+                for fs in fstreams[1:]:
+                    fs.wait_event(ready)
+                grp = max(1, min(BIN_GROUP, L.GDR_MAX_VIEWS))
+                for c, lo in enumerate(range(0, V, grp)):   # one chain per group of views, the groups round-robin over the streams
+                    fs = fstreams[c % nfs]
+                    sp = C.c_void_p(fs.cuda_stream)
+                    hi = min(V, lo + grp)
+                    if hi - lo > 1:
+                        binning_views(lib, s_arr, N, g_arr, states, radii, lo, hi, sp)
+                    else:
+                        st = states[lo]
+                        L.check(lib.gdr_binning_forward(C.byref(s_arr[lo]), N, C.byref(g_arr[lo]), C.byref(st.bin),
+                                                        C.byref(st.img), st.D, _ptr(radii[lo]), sp), "gdr_binning_forward")
+                    with torch.cuda.stream(fs):
+                        for v in range(lo, hi):
+                            composite(v, sp)
+                for fs in fstreams[1:]:
+                    done = torch.cuda.Event()
+                    done.record(fs)
+                    main.wait_event(done)
+                return colors, radii, depths, alphas, states, keep, in_dtypes
             for v, st in enumerate(states):
                 alloc_bin(v)
                 aux = auxs[v % len(auxs)]
@@ -496,17 +555,7 @@ def _forward_views_impl(means3D, means2D, sh, opacities, scales, rotations, sett
                                                 st.D, _ptr(radii[v]), C.c_void_p(aux.cuda_stream)), "gdr_binning_forward")
                 ev = torch.cuda.Event()
                 ev.record(aux)
-                binned.append(ev)
-            if RENDER_SIDE:  # K6 of each view right behind its binning on the view's side stream
-                for v, st in enumerate(states):
-                    aux = auxs[v % len(auxs)]
-                    with torch.cuda.stream(aux):
-                        composite(v, C.c_void_p(aux.cuda_stream))
-                for aux in auxs:
-                    done = torch.cuda.Event()
-                    done.record(aux)
-                    main.wait_event(done)
-                return colors, radii, depths, alphas, states, keep, in_dtypes
+                binned[v] = ev
             for v, st in enumerate(states):
                 main.wait_event(binned[v])
                 composite(v, stream)

@@ -264,30 +264,37 @@ def _surfel_forward_views_impl(ctx, means3D, means2D, sh, opacities, scales, rot
                 ready.record(main)
                 for aux in auxs:
                     aux.wait_event(ready)
-                binned = []
-                for v, st in enumerate(states):
-                    aux = auxs[v % len(auxs)]
-                    L.check(lib.gdr_binning_forward(C.byref(structs[v]), N, C.byref(st.geom), C.byref(st.bin),
-                                                    C.byref(st.img), st.D, _ptr(radii[v]), C.c_void_p(aux.cuda_stream)),
-                            "gdr_binning_forward")
+                same = all(st.H == states[0].H and st.W == states[0].W for st in states)
+                fstreams = [main] + list(auxs)
+                if same and _R.RENDER_SIDE:
+                    # one binning chain for all views on the caller's stream (rasterizer._forward_views_impl), then K6s +
+                    # the fused loss kernels of the views round-robin over the streams
+                    _R.binning_views(lib, structs, N, [st.geom for st in states], states, radii, 0, V, stream)
                     ev = torch.cuda.Event()
-                    ev.record(aux)
-                    binned.append(ev)
-                for v, st in enumerate(states):
-                    out = L.GsrOutputs(colors[v].data_ptr(), allmaps[v].data_ptr(), _ptr(radii[v]))
-                    if _R.RENDER_SIDE:  # K6s right behind the view's binning on its side stream (rasterizer._SideViews)
-                        sv = C.c_void_p(auxs[v % len(auxs)].cuda_stream)
-                    else:
-                        main.wait_event(binned[v])
-                        sv = stream
-                    L.check(lib.gsr_composite_forward(C.byref(structs[v]), C.byref(st.geom), C.byref(st.bin),
-                                                      C.byref(st.img), C.byref(out), sv), "gsr_composite_forward")
-                    view_loss(v, sv)
-                if _R.RENDER_SIDE:
+                    ev.record(main)
                     for aux in auxs:
-                        done = torch.cuda.Event()
-                        done.record(aux)
-                        main.wait_event(done)
+                        aux.wait_event(ev)
+                    for v, st in enumerate(states):
+                        out = L.GsrOutputs(colors[v].data_ptr(), allmaps[v].data_ptr(), _ptr(radii[v]))
+                        sv = C.c_void_p(fstreams[v % len(fstreams)].cuda_stream)
+                        L.check(lib.gsr_composite_forward(C.byref(structs[v]), C.byref(st.geom), C.byref(st.bin),
+                                                          C.byref(st.img), C.byref(out), sv), "gsr_composite_forward")
+                        view_loss(v, sv)
+                else:
+                    for v, st in enumerate(states):   # views of different sizes: one chain per view on the side streams
+                        aux = auxs[v % len(auxs)]
+                        L.check(lib.gdr_binning_forward(C.byref(structs[v]), N, C.byref(st.geom), C.byref(st.bin),
+                                                        C.byref(st.img), st.D, _ptr(radii[v]), C.c_void_p(aux.cuda_stream)),
+                                "gdr_binning_forward")
+                        out = L.GsrOutputs(colors[v].data_ptr(), allmaps[v].data_ptr(), _ptr(radii[v]))
+                        L.check(lib.gsr_composite_forward(C.byref(structs[v]), C.byref(st.geom), C.byref(st.bin),
+                                                          C.byref(st.img), C.byref(out), C.c_void_p(aux.cuda_stream)),
+                                "gsr_composite_forward")
+                        view_loss(v, C.c_void_p(aux.cuda_stream))
+                for aux in auxs:
+                    done = torch.cuda.Event()
+                    done.record(aux)
+                    main.wait_event(done)
             else:
                 for v, st in enumerate(states):
                     out = L.GsrOutputs(colors[v].data_ptr(), allmaps[v].data_ptr(), _ptr(radii[v]))

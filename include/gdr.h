@@ -233,6 +233,11 @@ int gdr_render_forward(const gdr_settings* s, const gdr_inputs* in, const gdr_ge
  * and every backward entry point below reads the seg_state of the LATEST compositing call on that (bin, img) pair. */
 int gdr_binning_forward(const gdr_settings* s, int32_t N, const gdr_geom* geom, gdr_binning* bin, const gdr_image* img,
                         uint64_t D, const int32_t* radii, void* stream);
+/* the same for V <= GDR_MAX_VIEWS views of ONE image size in the same launches (every binning kernel covers all the views,
+ * view = blockIdx.y): the chain is ~13 short dependent launches whatever the number of views.  geoms / bins / imgs / D /
+ * radii: arrays of V. */
+int gdr_binning_forward_views(int32_t V, const gdr_settings* s, int32_t N, const gdr_geom* geoms, gdr_binning* bins,
+                              const gdr_image* imgs, const uint64_t* D, const int32_t* const* radii, void* stream);
 int gdr_composite_forward(const gdr_settings* s, const gdr_geom* geom, const gdr_binning* bin, const gdr_image* img,
                           const gdr_outputs* out, void* stream);
 

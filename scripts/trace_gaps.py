@@ -32,3 +32,9 @@ for si in range(1, len(starts) - 1):
     print(f"step {si}: wall {(t1 - t0) / 1e3:.0f} us, GPU busy {busy / 1e3:.0f} us ({100 * busy / (t1 - t0):.1f} %), idle {(t1 - t0 - busy) / 1e3:.0f} us")
     for g, a, b in sorted(gaps, reverse=True)[:6]:
         print(f"     gap {g / 1e3:7.1f} us after {a} before {b}")
+if "--timeline" in sys.argv and len(starts) > 2:   # one step, kernel by kernel: start (us from the step's K1), duration, queue
+    qcol = next((c for c in ("Queue_Id", "Stream_Id", "Correlation_Id") if c in rows[0]), None)
+    full = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"]), r.get(qcol, "")) for r in rows))
+    a, b = full[starts[1]][0], full[starts[2]][0]
+    for s, e, n, q in full[starts[1]:starts[2]]:
+        print(f"{(s - a) / 1e3:8.1f} +{(e - s) / 1e3:7.1f}  q{q}  {n}")
