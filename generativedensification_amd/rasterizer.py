@@ -157,8 +157,8 @@ BIN_STREAM = None if _BIN_STREAM_ENV is None else max(0, int(_BIN_STREAM_ENV))
 
 
 # Segment length of cut tile lists (include/gdr.h gdr_binning.seg_len): None = the library default
-# (GDR_DEFAULT_SEG_LEN = 2048), 0 = lists are never cut, otherwise a multiple of 256 >= 2048 (the tables are carved for
-# 2048).  Tests switch it per call; GDR_SEG_LEN in the environment presets it (host-side policy: the library itself
+# (GDR_DEFAULT_SEG_LEN = 512), 0 = lists are never cut, otherwise a multiple of 256 >= 512 (the tables are carved for
+# 512).  Tests switch it per call; GDR_SEG_LEN in the environment presets it (host-side policy: the library itself
 # reads no environment variable).
 SEG_LEN = int(_os.environ["GDR_SEG_LEN"]) if _os.environ.get("GDR_SEG_LEN") else None
 
