@@ -450,8 +450,13 @@ __global__ __launch_bounds__(GDR_BLOCK) void render_fwd_deep_kernel(
     __shared__ SliceLds lds;
     __shared__ uint16_t clist[GDR_BLOCK / GDR_WAVE][GDR_BLOCK];
     __shared__ int s_done[GDR_BLOCK / GDR_WAVE];
-    if (*deep_flag == 0u || (int)(blockIdx.x >> 2) >= ntiles) return;
-    const uint32_t tile = tile_order[blockIdx.x >> 2], quarter = blockIdx.x & 3u;
+    // The four quarter workgroups of a tile gather the same records: workgroups are dealt round-robin to the 8 XCDs
+    // (blockIdx % 8), each with its own L2, so the quarters of one tile are blocks b, b + 8, b + 16, b + 24 — same
+    // XCD, dispatched back to back — and three of the four gathers hit in L2 (HBM fetch of the kernel at C4 `shell`:
+    // 1.7 GB with quarter = blockIdx & 3, which spread a tile over four XCDs).
+    const uint32_t slot = (blockIdx.x >> 5) * 8u + (blockIdx.x & 7u), quarter = (blockIdx.x >> 3) & 3u;
+    if (*deep_flag == 0u || (int)slot >= ntiles) return;
+    const uint32_t tile = tile_order[slot];
     const uint2 range = ranges[tile];
     const int full_total = (int)(range.y - range.x);
     const int full_rounds = (full_total + GDR_BLOCK - 1) / GDR_BLOCK;
@@ -907,7 +912,7 @@ hipError_t launch_tile_order_views(const BinViews& vs, int V, int ntiles, hipStr
     do {                                                                                                                  \
         if (seg_rounds_of(bin, img) && img->tile_order && bin->deep_max_busy > 0) {                                       \
             int ndeep = bin->seg_cap < ntiles ? bin->seg_cap : ntiles;     /* cut tiles <= busy tiles <= deep_max_busy */ \
-            ndeep = 4 * (ndeep < bin->deep_max_busy ? ndeep : bin->deep_max_busy);                                        \
+            ndeep = 4 * (((ndeep < bin->deep_max_busy ? ndeep : bin->deep_max_busy) + 7) / 8 * 8);                        \
             GDR_LAUNCH(GDR_K_RENDER_FWD_DEEP, render_fwd_deep_kernel<LOSSV>, dim3(ndeep), dim3(GDR_BLOCK), st,             \
                        (const uint2*)img->ranges, bin->values[bin->sorted], img->tile_order, W, H, gx, ntiles,            \
                        (const float4*)g->rec, s->bg, img->final_T, img->n_contrib, COLOR, DEPTH, ALPHA, FL,               \
