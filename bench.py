@@ -464,6 +464,8 @@ def main():
                 ms1, cnt1 = prof1.get(dom, (0.0, 0))
                 if cnt1:
                     avg1 = 1e3 * ms1 / cnt1
+                    if roofline.get("valu_insts_per_launch"):
+                        roofline["valu_issue_frac_serial"] = round(roofline["valu_insts_per_launch"] * 2 / (avg1 * 1e-6 * 1024 * 2.4e9), 4)
                     roofline.update(avg_launch_us_serial=round(avg1, 2),
                                     frac_serial=round(alg[dom] / (avg1 * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
                                     launch_overlap=round(kernels[dom]["avg_us"] / avg1, 2))
