@@ -157,8 +157,8 @@ BIN_STREAM = None if _BIN_STREAM_ENV is None else max(0, int(_BIN_STREAM_ENV))
 
 
 # Segment length of cut tile lists (include/gdr.h gdr_binning.seg_len): None = the library default
-# (GDR_DEFAULT_SEG_LEN = 512), 0 = lists are never cut, otherwise a multiple of 256 >= 512 (the tables are carved for
-# 512).  Tests switch it per call; GDR_SEG_LEN in the environment presets it (host-side policy: the library itself
+# (GDR_DEFAULT_SEG_LEN = 256, raised to 512 for images of >= 2000 tiles), 0 = lists are never cut, otherwise a multiple
+# of 256.  Tests switch it per call; GDR_SEG_LEN in the environment presets it (host-side policy: the library itself
 # reads no environment variable).
 SEG_LEN = int(_os.environ["GDR_SEG_LEN"]) if _os.environ.get("GDR_SEG_LEN") else None
 
@@ -167,9 +167,11 @@ SEG_LEN = int(_os.environ["GDR_SEG_LEN"]) if _os.environ.get("GDR_SEG_LEN") else
 DEEP_MAX_BUSY = int(_os.environ["GDR_DEEP_MAX_BUSY"]) if _os.environ.get("GDR_DEEP_MAX_BUSY") else None
 
 
-def _apply_seg_len(bin_struct, D):
+def _apply_seg_len(bin_struct, D, tiles=None):
     if DEEP_MAX_BUSY is not None:
         bin_struct.deep_max_busy = max(0, int(DEEP_MAX_BUSY))
+    if SEG_LEN is None and tiles is not None and tiles >= 2000 and 0 < bin_struct.seg_len < 512:
+        bin_struct.seg_len = 512     # large images: 512-entry segments (include/gdr.h GDR_DEFAULT_SEG_LEN)
     if SEG_LEN is not None:
         sl = max(0, int(SEG_LEN)) // 256 * 256
         if sl and sl >= bin_struct.seg_len > 0:   # only lengths >= the carved one fit the carved tables
@@ -275,7 +277,7 @@ def forward_raw(means3D, sh, colors_precomp, opacities, scales, rotations, cov3D
         st.bin_buf = torch.empty(lib.gdr_binning_bytes(st.D), **u8)
         L.check(lib.gdr_binning_carve(st.bin_buf.data_ptr(), st.D, C.byref(st.bin)), "gdr_binning_carve")
         st.bin.global_sort = int(_FORCE_GLOBAL_SORT)
-        _apply_seg_len(st.bin, st.D)
+        _apply_seg_len(st.bin, st.D, ((W + 15) // 16) * ((H + 15) // 16))
         out = L.GdrOutputs(color.data_ptr(), depth.data_ptr(), alpha.data_ptr(), _ptr(radii))
         L.check(lib.gdr_render_forward(C.byref(s), C.byref(inp), C.byref(st.geom), C.byref(st.bin),
                                        C.byref(st.img), st.D, C.byref(out), stream), "gdr_render_forward")
@@ -478,7 +480,7 @@ def _forward_views_impl(means3D, means2D, sh, opacities, scales, rotations, sett
                 st.bin_buf = torch.empty(need, **u8)
             L.check(lib.gdr_binning_carve(st.bin_buf.data_ptr(), st.D, C.byref(st.bin)), "gdr_binning_carve")
             st.bin.global_sort = int(_FORCE_GLOBAL_SORT)
-            _apply_seg_len(st.bin, st.D)
+            _apply_seg_len(st.bin, st.D, ((W + 15) // 16) * ((H + 15) // 16))
 
         if not two_stage:
             for v in range(V):

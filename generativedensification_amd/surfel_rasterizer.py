@@ -104,7 +104,7 @@ def forward_raw(means3D, sh, colors_precomp, opacities, scales, rotations, trans
         st.bin_buf = torch.empty(lib.gdr_binning_bytes(st.D), **u8)
         L.check(lib.gdr_binning_carve(st.bin_buf.data_ptr(), st.D, C.byref(st.bin)), "gdr_binning_carve")
         st.bin.global_sort = int(_R._FORCE_GLOBAL_SORT)
-        _R._apply_seg_len(st.bin, st.D)
+        _R._apply_seg_len(st.bin, st.D, ((st.W + 15) // 16) * ((st.H + 15) // 16))
         out = L.GsrOutputs(color.data_ptr(), allmap.data_ptr(), _ptr(radii))
         L.check(lib.gsr_render_forward(C.byref(s), C.byref(inp), C.byref(st.geom), C.byref(st.bin), C.byref(st.img),
                                        st.D, C.byref(out), stream), "gsr_render_forward")
@@ -255,7 +255,7 @@ def _surfel_forward_views_impl(ctx, means3D, means2D, sh, opacities, scales, rot
                     st.bin_buf = torch.empty(need, **u8)
                 L.check(lib.gdr_binning_carve(st.bin_buf.data_ptr(), st.D, C.byref(st.bin)), "gdr_binning_carve")
                 st.bin.global_sort = int(_R._FORCE_GLOBAL_SORT)
-                _R._apply_seg_len(st.bin, st.D)
+                _R._apply_seg_len(st.bin, st.D, ((st.W + 15) // 16) * ((st.H + 15) // 16))
             n_side = _R.side_count(H, W)
             if n_side and V > 1:   # binning of view v+1 overlaps K6s of view v (rasterizer._forward_views_impl)
                 main = torch.cuda.current_stream()

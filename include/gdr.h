@@ -54,9 +54,11 @@ extern "C" {
 #define GDR_MAX_RENDERED 0xFFFFFFFFull /* D = sum of tiles_touched of one view                  */
 
 #define GDR_DEFAULT_DEEP_MAX_BUSY 768 /* gdr_binning.deep_max_busy as carved: 3/4 of the 1024 resident K6 workgroups */
-#define GDR_DEFAULT_SEG_LEN 512 /* gdr_binning.seg_len as carved (the library reads no environment variable).  2048 in
-                                 * round 1; 512 balances K7's (tile, segment) workgroups on object-like scenes (C3 shell
-                                 * 2130 -> 2640, C2 shell 1970 -> 2460 views/s) at the same speed on uniform ones */
+#define GDR_DEFAULT_SEG_LEN 256 /* gdr_binning.seg_len as carved (the library reads no environment variable); callers may
+                                 * raise it after carving.  2048 in round 1; short segments balance K7's (tile, segment)
+                                 * workgroups: 512 vs 2048 C3 shell 2130 -> 2640, C2 shell 1970 -> 2460 views/s at the same
+                                 * speed on uniform scenes; 256 gains another 4-6 % on 512x512 images and loses 2 % at
+                                 * 2 M Gaussians 800x800, so the Python host raises it to 512 for >= 2000 tiles. */
 #define GDR_TILE 16 /* tile edge in pixels (BLOCK_X = BLOCK_Y = 16) */
 
 /* The 12 fields of GaussianRasterizationSettings (renderer.py:111-124), flattened.
