@@ -288,3 +288,62 @@ def test_screenspace_absgrad_and_topk_vs_oracle(oracle_built):
     sure_out = set(np.nonzero(score < kth * (1 - 1e-3))[0].tolist())
     got = set(idx.cpu().tolist())
     assert len(got) == k and sure_in <= got and not (got & sure_out)
+
+
+def test_surfel_render_views_backward_vs_oracle(oracle_built):
+    """The 2DGS multi-view node (K1s / K9s for all views, activations folded in) against torch autograd through the
+    SURFEL ORACLE stand-in, one call per view (renderer_2dgs.py:92-96, 224-234 semantics) — round 1 only compared it
+    with the per-view HIP sequence.  Upstream: random gradients on the colour and on allmap channels 0..5 (the
+    distortion channel is ill-conditioned in fp32, DESIGN §9, and checked at single-view size in test_gpu_surfel.py)."""
+    from generativedensification_amd.camera import build_rays, orbit_cameras
+    from generativedensification_amd.renderer_2dgs import Renderer
+    from generativedensification_amd.synthetic import make_scene
+    from oracle.gsr_oracle import make_surfel_standin_module
+    dev = torch.device("cuda:0")
+    V, n, h, w, deg = 3, 20_000, 144, 176, 2
+    sc = make_scene(n, 81, sh_degree=deg, sigma0=(0.0052, 0.02))
+    sc["scales"] = sc["scales"][:, :2].contiguous()
+    cams = orbit_cameras(V, w, h)
+    g = torch.Generator().manual_seed(5)
+    gc = [torch.randn(3, h, w, generator=g) for _ in range(V)]
+    ga = [torch.randn(7, h, w, generator=g) for _ in range(V)]
+    for a in ga:
+        a[6] = 0
+
+    def oracle_ref(precision):
+        mod = make_surfel_standin_module(precision, nthreads=1 if precision == "f32" else THREADS)
+        dt = torch.float32 if precision == "f32" else torch.float64
+        leaves = {k: v.to(dt).clone().requires_grad_(True) for k, v in sc.items()}
+        ssp = torch.zeros(n, 4, dtype=dt, requires_grad=True)
+        total, outs = 0, []
+        for v, cam in enumerate(cams):
+            rs = mod.GaussianRasterizationSettings(
+                image_height=h, image_width=w, tanfovx=math.tan(0.375), tanfovy=math.tan(0.375), bg=torch.ones(3, dtype=dt),
+                scale_modifier=1.0, viewmatrix=cam.world_view_transform.to(dt), projmatrix=cam.full_proj_transform.to(dt),
+                sh_degree=deg, campos=cam.camera_center.to(dt), prefiltered=False, debug=False)
+            color, radii, allmap = mod.GaussianRasterizer(rs)(
+                means3D=leaves["centers"], means2D=ssp, shs=leaves["shs"], opacities=torch.sigmoid(leaves["opacity"]),
+                scales=torch.exp(leaves["scales"]), rotations=torch.nn.functional.normalize(leaves["rotations"]))
+            total = total + (color * gc[v].to(dt)).sum() + (allmap * ga[v].to(dt)).sum()
+            outs.append((color.detach().numpy(), allmap.detach().numpy()))
+        grads = torch.autograd.grad(total, list(leaves.values()) + [ssp])
+        return outs, {k: x.numpy() for k, x in zip(list(leaves) + ["ssp"], grads)}
+
+    o32, g32 = oracle_ref("f32")
+    _, g64 = oracle_ref("f64")
+    r = Renderer(sh_degree=deg, white_background=True)
+    leaves = {k: v.to(dev).clone().requires_grad_(True) for k, v in sc.items()}
+    ssp = torch.zeros(n, 4, device=dev, requires_grad=True)
+    cams_d = _cams_to(cams, dev)
+    rays = [build_rays(torch.inverse(c.world_view_transform.T.cpu()), 0.75, 0.75, h, w).to(dev) for c in cams]
+    outs = r.render_views(cams_d, rays, None, leaves["centers"], leaves["shs"], leaves["opacity"], leaves["scales"],
+                          leaves["rotations"], dev, screenspace_points=ssp, raw=True)
+    total = 0
+    for v, o in enumerate(outs):
+        assert U.outlier_fraction(o["color"].detach().cpu().numpy(), o32[v][0], 1e-4, 1e-5) < 1e-4
+        for c in range(6):
+            assert U.outlier_fraction(o["allmap"][c].detach().cpu().numpy(), o32[v][1][c], 1e-4, 1e-4) < 2e-4, c
+        total = total + (o["color"] * gc[v].to(dev)).sum() + (o["allmap"] * ga[v].to(dev)).sum()
+    grads = torch.autograd.grad(total, list(leaves.values()) + [ssp])
+    g_hip = {k: x.cpu().numpy() for k, x in zip(list(leaves) + ["ssp"], grads)}
+    _assert_grads(g_hip, g64, g32, list(g32), "surfel render_views", bar32=False, max_outside=2e-3)
