@@ -119,3 +119,30 @@ def test_bench_gpus2_spawns_two_ranks_by_itself():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["world_size"] == 2 and out["dist_backend"] == "gloo"
     assert out["config"]["views_per_gpu"] == 4 and out["value"] > 0
+
+
+def test_bench_line_contract_on_one_gpu():
+    """The JSON line the driver parses: contract fields, the `roofline` object (dominant kernel timed with HIP events on
+    its launch stream, per-kernel fractions, measured path fraction, pairs/s) and both CPU baselines — on a reduced C2 so
+    that the oracle legs take seconds."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "c2", "--n", "20000", "--steps", "3",
+                        "--warmup", "1"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout           # exactly ONE line on stdout
+    out = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in out, k
+    assert out["n_gpus"] == 1 and out["steps"] == 3 and out["dtype"] == "f32" and out["vs_baseline"] is None
+    assert "workload" in out["config"] and "model" not in out["config"]
+    rf = out["roofline"]
+    assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and rf["unit"] == "GB/s"
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and rf["avg_launch_us"] > 0
+    assert rf["kernel"] in out["kernels"] and 0 < rf["path_frac_measured"] < 1 and rf["pairs_per_s"] > 0
+    assert all("avg_us" in k for k in out["kernels"].values())
+    cb = out["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and "oracle" in cb["sample"]
+    ct = out["cpu_baseline_torch"]
+    assert ct["kind"] == "port" and (ct["value"] is None or ct["value"] > 0)
