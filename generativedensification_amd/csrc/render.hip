@@ -100,6 +100,46 @@ __device__ __forceinline__ void block_masks(const SliceLds& s, int g, float XA, 
     m3 = __ballot(x1 && y1 && a3);
 }
 
+// Compacted row lists (round 2).  Instead of carrying 64-bit sub-list masks in VGPRs and peeling one bit per iteration
+// (v_ffbl x2, min3, 64-bit and / add, selects, a ballot + branch for "any lane has more": ~22 VALU + SALU per iteration,
+// half of K6's inner loop), every lane appends its staged entry's index to the lists of the rows (4x4 blocks) it
+// overlaps: position = entries of that row so far + v_mbcnt of the row's ballot.  The lists (uint16 slice indices,
+// pre-filled with the null entry so that a row that runs out keeps reading harmless entries) live in LDS, wave-private;
+// the inner loop is a COUNTED loop to the longest row list of the wave: one ds_read_b64 of four indices per four
+// iterations, one v_bfe per iteration.  Rows of a wave re-synchronise only per slice, with no refill logic.
+struct RowLists {
+    uint16_t idx[GDR_BLOCK / GDR_WAVE][4][GDR_BLOCK];   // [wave][row][position]
+    uint16_t pad[8];                                     // the read-ahead of the last row's last positions (null entries)
+};
+
+// pre-fill this wave's four lists with the null entry (2 x 16 bytes per lane = 2 KiB)
+__device__ __forceinline__ void row_lists_clear(RowLists& rl, uint32_t wave) {
+    uint4* p = reinterpret_cast<uint4*>(&rl.idx[wave][0][0]);
+    const uint32_t nn = (uint32_t)GDR_NULL_ENTRY | ((uint32_t)GDR_NULL_ENTRY << 16);
+    p[lane_id()] = make_uint4(nn, nn, nn, nn);
+    p[GDR_WAVE + lane_id()] = make_uint4(nn, nn, nn, nn);
+}
+
+// append group g's entries (one per lane) to the row lists; n[r] = list lengths so far (wave-uniform)
+__device__ __forceinline__ void row_lists_append(RowLists& rl, uint32_t wave, int g, uint64_t m0, uint64_t m1, uint64_t m2,
+                                                 uint64_t m3, int (&n)[4]) {
+    const uint32_t lane = lane_id();
+    const uint16_t e = (uint16_t)(g * GDR_WAVE + (int)lane);
+    const uint64_t m[4] = {m0, m1, m2, m3};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(m[r] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m[r], (uint32_t)n[r]));
+        if ((m[r] >> lane) & 1ull) rl.idx[wave][r][pos] = e;
+        n[r] += __popcll(m[r]);
+    }
+}
+
+__device__ __forceinline__ void wave_lds_fence() {   // wave-private LDS data written by some lanes, read by others
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
 // ---------------------------------------------------------------------------------
 // tile order: tiles sorted by descending list length (counting sort on length/16, one
 // workgroup).  order[k] = tile id of the k-th workgroup.
@@ -247,6 +287,7 @@ __global__ __launch_bounds__(GDR_BLOCK) void render_fwd_kernel(
     float* __restrict__ out_alpha, const FusedLoss fl, const uint32_t* __restrict__ seg_base,
     float* __restrict__ seg_state, int seg_rounds, const uint32_t* __restrict__ deep_flag) {
     __shared__ SliceLds lds;
+    __shared__ RowLists rlists;
     __shared__ int s_done[GDR_BLOCK / GDR_WAVE];
 
     const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
@@ -256,6 +297,7 @@ __global__ __launch_bounds__(GDR_BLOCK) void render_fwd_kernel(
         lds.co[GDR_NULL_ENTRY] = make_float4(0.f, 0.f, 0.f, 0.f);
         lds.cd[GDR_NULL_ENTRY] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    if (threadIdx.x < 8) rlists.pad[threadIdx.x] = (uint16_t)GDR_NULL_ENTRY;
 
     const uint32_t tile = tile_order ? tile_order[blockIdx.x] : xcd_remap(blockIdx.x, (uint32_t)ntiles);
     const int tx = (int)(tile % (uint32_t)gx), ty = (int)(tile / (uint32_t)gx);
@@ -309,64 +351,65 @@ __global__ __launch_bounds__(GDR_BLOCK) void render_fwd_kernel(
             }
             if (live == 0ull || GDR_ABLATE == 4) continue;
             const uint32_t base = (uint32_t)(pos0 + r * GDR_BLOCK) + 1u;
-#pragma unroll 1
+            // this wave's row lists of the slice (compacted, see RowLists)
+            int n[4] = {0, 0, 0, 0};
+            row_lists_clear(rlists, wave);
+            wave_lds_fence();
+#pragma unroll
             for (int g = 0; g < GDR_BLOCK / GDR_WAVE; ++g) {
                 uint64_t m0, m1, m2, m3;
                 block_masks(lds, g, XA, YA, (live & GDR_ROW_MASK(0)) != 0ull, (live & GDR_ROW_MASK(1)) != 0ull,
                             (live & GDR_ROW_MASK(2)) != 0ull, (live & GDR_ROW_MASK(3)) != 0ull, m0, m1, m2, m3);
-                if ((m0 | m1 | m2 | m3) == 0ull) continue;
-                const uint32_t goff = (uint32_t)(g * GDR_WAVE), nulloff = GDR_NULL_ENTRY - goff;
-                // software pipeline, unrolled by two (ping-pong registers instead of copies): entry A is
-                // composited while B's LDS reads are in flight, and vice versa
-                uint64_t mr = row_select(row, m0, m1, m2, m3);
-                bool abort = false;
-                auto fetch = [&](Entry& en) {
-                    en.e = min(take_bit(mr), nulloff) + goff;  // 0xFFFFFFFF (no entry) -> null entry
-                    if (GDR_ABLATE == 6) {
-                        const float f_ = (float)en.e;
-                        en.m = make_float2(pxf + 0.3f, pyf + f_ * 1e-3f); en.co = make_float4(0.5f, 0.1f, 0.5f, en.e < GDR_NULL_ENTRY ? 0.5f : 0.f);
-                        en.cd = make_float4(f_, 0.5f, 0.25f, 2.f);
-                        return;
-                    }
-                    en.m = lds.xy[en.e]; en.co = lds.co[en.e]; en.cd = lds.cd[en.e];
-                };
-                auto composite = [&](const Entry& en) {
-                    const float dx = en.m.x - pxf, dy = en.m.y - pyf;
-                    const float p2 = gauss_power(dx, dy, en.co.x, en.co.y, en.co.z);
-                    float alpha = fminf(0.99f, en.co.w * __builtin_amdgcn_exp2f(p2));
-                    alpha = (p2 > 0.f) ? 0.f : alpha;        // reference skips power > 0
-                    const float a_c = (alpha >= thr) ? alpha : 0.f;
-                    const float T_new = fmaf(-a_c, T, T);     // T (1 - alpha); == T when a_c == 0
-                    const bool stop = T_new < 0.0001f;        // only possible when a_c > 0 (T >= 1e-4 while live)
-                    const float w = stop ? 0.f : a_c * T;
-                    T = stop ? T : T_new;
-                    thr = stop ? INFINITY : thr;
-                    C0 = fmaf(en.cd.x, w, C0);
-                    C1 = fmaf(en.cd.y, w, C1);
-                    C2 = fmaf(en.cd.z, w, C2);
-                    Dp = fmaf(en.cd.w, w, Dp);
-                    Wt += w;
-                    last_contributor = (w > 0.f) ? base + en.e : last_contributor;
-                    if (__ballot(stop) != 0ull) {  // rare: some pixel saturated -> retire finished blocks
-                        live = __ballot(thr < INFINITY);
-                        if (((live >> (16 * row)) & 0xFFFFull) == 0ull) mr = 0ull;
-                        if (live == 0ull) abort = true;
-                    }
-                };
-                Entry A, B;
-                fetch(A);
-                for (;;) {
-                    const bool moreA = __ballot(mr != 0ull) != 0ull;
-                    fetch(B);
-                    composite(A);
-                    if (!moreA || abort) break;
-                    const bool moreB = __ballot(mr != 0ull) != 0ull;
-                    fetch(A);
-                    composite(B);
-                    if (!moreB || abort) break;
-                }
-                if (abort) g = GDR_BLOCK / GDR_WAVE;
+                row_lists_append(rlists, wave, g, m0, m1, m2, m3, n);
             }
+            const int nmax = max(max(n[0], n[1]), max(n[2], n[3]));
+            if (nmax == 0) continue;
+            wave_lds_fence();
+            const uint16_t* my_list = &rlists.idx[wave][row][0];
+            bool abort = false;
+            auto fetch = [&](Entry& en, uint32_t e) __attribute__((always_inline)) {
+                en.e = e;
+                en.m = lds.xy[e]; en.co = lds.co[e]; en.cd = lds.cd[e];
+            };
+            auto composite = [&](const Entry& en) __attribute__((always_inline)) {
+                const float dx = en.m.x - pxf, dy = en.m.y - pyf;
+                const float p2 = gauss_power(dx, dy, en.co.x, en.co.y, en.co.z);
+                float alpha = fminf(0.99f, en.co.w * __builtin_amdgcn_exp2f(p2));
+                alpha = (p2 > 0.f) ? 0.f : alpha;        // reference skips power > 0
+                const float a_c = (alpha >= thr) ? alpha : 0.f;
+                const float T_new = fmaf(-a_c, T, T);     // T (1 - alpha); == T when a_c == 0
+                const bool stop = T_new < 0.0001f;        // only possible when a_c > 0 (T >= 1e-4 while live)
+                const float w = stop ? 0.f : a_c * T;
+                T = stop ? T : T_new;
+                thr = stop ? INFINITY : thr;
+                C0 = fmaf(en.cd.x, w, C0);
+                C1 = fmaf(en.cd.y, w, C1);
+                C2 = fmaf(en.cd.z, w, C2);
+                Dp = fmaf(en.cd.w, w, Dp);
+                Wt += w;
+                last_contributor = (w > 0.f) ? base + en.e : last_contributor;
+                if (__ballot(stop) != 0ull) {  // rare: some pixel saturated
+                    live = __ballot(thr < INFINITY);
+                    if (live == 0ull) abort = true;
+                }
+            };
+            // four list positions per 8-byte LDS read; entry k+1 is fetched while entry k is composited
+            Entry A, B;
+            uint2 q = *reinterpret_cast<const uint2*>(my_list);
+            fetch(A, q.x & 0xFFFFu);
+            for (int i = 0; i < nmax && !abort; i += 4) {
+                const uint2 qn = *reinterpret_cast<const uint2*>(my_list + i + 4);   // (the lists are 256 long, the slice
+                fetch(B, q.x >> 16);                                                 //  at most 256: i + 4 <= 256 reads
+                composite(A);                                                        //  the next row's list or the pad)
+                fetch(A, q.y & 0xFFFFu);
+                composite(B);
+                fetch(B, q.y >> 16);
+                composite(A);
+                fetch(A, qn.x & 0xFFFFu);
+                composite(B);
+                q = qn;
+            }
+            if (abort) continue;
         }
         return false;
     };
@@ -668,6 +711,7 @@ __global__ __launch_bounds__(GDR_BLOCK) void render_bwd_kernel(
     const uint32_t* __restrict__ seg_base, const float* __restrict__ seg_state, const uint2* __restrict__ seg_extra,
     const uint32_t* __restrict__ seg_count, int seg_rounds, int n_extra) {
     __shared__ SliceLds lds;
+    __shared__ RowLists rlists;
     __shared__ uint32_t s_id[GDR_BLOCK + 1];
 
     // Workgroups [0, n_extra): one segment of a cut list each (the full-length segments, i.e. the longest work
@@ -714,6 +758,7 @@ __global__ __launch_bounds__(GDR_BLOCK) void render_bwd_kernel(
         lds.cd[GDR_NULL_ENTRY] = make_float4(0.f, 0.f, 0.f, 0.f);
         s_id[GDR_NULL_ENTRY] = 0;
     }
+    if (threadIdx.x < 8) rlists.pad[threadIdx.x] = (uint16_t)GDR_NULL_ENTRY;
     const float T_final = inside ? final_T[pix] : 0.f;
     float T = T_final;
     const int lc_full = inside ? (int)n_contrib[pix] : 0;
@@ -796,31 +841,27 @@ __global__ __launch_bounds__(GDR_BLOCK) void render_bwd_kernel(
         // Row sub-lists of the slice's four 64-entry groups, one 64-bit mask per group and lane (all 16 lanes of a row
         // hold the same four masks).  A row walks them back to back at its own pace — rows only re-synchronise at slice
         // boundaries, so a row whose block has few entries in one group does not wait for the others there.
-        auto group_mask = [&](int g) -> uint64_t {
+        // this wave's compacted row lists of the slice (RowLists): entries in front of each block's deepest contributor
+        int n[4] = {0, 0, 0, 0};
+        row_lists_clear(rlists, wave);
+        wave_lds_fence();
+#pragma unroll
+        for (int g = 0; g < GDR_BLOCK / GDR_WAVE; ++g) {
             const int gtop = top - g * GDR_WAVE;  // position of this group's entry 0
-            if (gtop - (GDR_WAVE - 1) >= wave_last) return 0ull;
+            if (gtop - (GDR_WAVE - 1) >= wave_last) continue;
             uint64_t m0, m1, m2, m3;
             const int mypos = gtop - (int)lane;
             block_masks(lds, g, XA, YA, mypos < rl0, mypos < rl1, mypos < rl2, mypos < rl3, m0, m1, m2, m3);
-            return row_select(row, m0, m1, m2, m3);
-        };
-        const uint64_t q0 = group_mask(0), q1 = group_mask(1), q2 = group_mask(2), q3 = group_mask(3);
-        if (__ballot((q0 | q1 | q2 | q3) != 0ull) == 0ull) continue;
+            row_lists_append(rlists, wave, g, m0, m1, m2, m3, n);
+        }
+        const int nmax = max(max(n[0], n[1]), max(n[2], n[3]));
+        if (nmax == 0) continue;
+        wave_lds_fence();
         {
-            uint32_t gi = 0u;
-            uint64_t mr = q0;
-            GDR_REFILL(mr, gi, q1, q2, q3);
-            auto fetch = [&](Entry& en) __attribute__((always_inline)) {
-                const uint32_t goff = gi << 6;
-                en.e = min(take_bit(mr), GDR_NULL_ENTRY - goff) + goff;  // 0xFFFFFFFF (no entry) -> null entry
-                if (GDR_ABLATE == 6) {
-                    const float f_ = (float)en.e;
-                    en.m = make_float2(pxf + 0.3f, pyf + f_ * 1e-3f); en.co = make_float4(0.5f, 0.1f, 0.5f, en.e < GDR_NULL_ENTRY ? 0.5f : 0.f);
-                    en.cd = make_float4(f_, 0.5f, 0.25f, 2.f);
-                } else {
-                en.m = lds.xy[en.e]; en.co = lds.co[en.e]; en.cd = lds.cd[en.e];
-                }
-                if (__ballot(mr == 0ull && gi < 3u) != 0ull) GDR_REFILL(mr, gi, q1, q2, q3);
+            const uint16_t* my_list = &rlists.idx[wave][row][0];
+            auto fetch = [&](Entry& en, uint32_t e) __attribute__((always_inline)) {
+                en.e = e;
+                en.m = lds.xy[e]; en.co = lds.co[e]; en.cd = lds.cd[e];
             };
             auto accumulate = [&](const Entry& en) {
                 const float dx = en.m.x - pxf, dy = en.m.y - pyf;
@@ -881,17 +922,21 @@ __global__ __launch_bounds__(GDR_BLOCK) void render_bwd_kernel(
                 if (li < 12u && publish)
                     atomicAdd(grad_rec + 16 * (size_t)s_id[en.e] + li, tot);
             };
-            Entry A, B;  // unrolled by two: ping-pong registers instead of copies
-            fetch(A);
-            for (;;) {
-                const bool moreA = __ballot(mr != 0ull) != 0ull;
-                fetch(B);
+            // four list positions per 8-byte LDS read; entry k+1 is fetched while entry k is accumulated
+            Entry A, B;
+            uint2 q = *reinterpret_cast<const uint2*>(my_list);
+            fetch(A, q.x & 0xFFFFu);
+            for (int i = 0; i < nmax; i += 4) {
+                const uint2 qn = *reinterpret_cast<const uint2*>(my_list + i + 4);
+                fetch(B, q.x >> 16);
                 accumulate(A);
-                if (!moreA) break;
-                const bool moreB = __ballot(mr != 0ull) != 0ull;
-                fetch(A);
+                fetch(A, q.y & 0xFFFFu);
                 accumulate(B);
-                if (!moreB) break;
+                fetch(B, q.y >> 16);
+                accumulate(A);
+                fetch(A, qn.x & 0xFFFFu);
+                accumulate(B);
+                q = qn;
             }
         }
     }
