@@ -355,7 +355,7 @@ __global__ __launch_bounds__(GDR_BLOCK) void render_fwd_kernel(
             int n[4] = {0, 0, 0, 0};
             row_lists_clear(rlists, wave);
             wave_lds_fence();
-#pragma unroll
+#pragma unroll 1
             for (int g = 0; g < GDR_BLOCK / GDR_WAVE; ++g) {
                 uint64_t m0, m1, m2, m3;
                 block_masks(lds, g, XA, YA, (live & GDR_ROW_MASK(0)) != 0ull, (live & GDR_ROW_MASK(1)) != 0ull,
@@ -845,7 +845,7 @@ __global__ __launch_bounds__(GDR_BLOCK) void render_bwd_kernel(
         int n[4] = {0, 0, 0, 0};
         row_lists_clear(rlists, wave);
         wave_lds_fence();
-#pragma unroll
+#pragma unroll 1
         for (int g = 0; g < GDR_BLOCK / GDR_WAVE; ++g) {
             const int gtop = top - g * GDR_WAVE;  // position of this group's entry 0
             if (gtop - (GDR_WAVE - 1) >= wave_last) continue;
