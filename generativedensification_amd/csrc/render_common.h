@@ -161,6 +161,46 @@ __device__ __forceinline__ uint64_t row_select(uint32_t row, uint64_t m0, uint64
     return row == 0 ? m0 : (row == 1 ? m1 : (row == 2 ? m2 : m3));
 }
 
+// Compacted row lists (round 2).  Instead of carrying 64-bit sub-list masks in VGPRs and peeling one bit per iteration
+// (v_ffbl x2, min3, 64-bit and / add, selects, a ballot + branch for "any lane has more": ~22 VALU + SALU per iteration,
+// half of K6's inner loop), every lane appends its staged entry's index to the lists of the rows (4x4 blocks) it
+// overlaps: position = entries of that row so far + v_mbcnt of the row's ballot.  The lists (uint16 slice indices,
+// pre-filled with the null entry so that a row that runs out keeps reading harmless entries) live in LDS, wave-private;
+// the inner loop is a COUNTED loop to the longest row list of the wave: one ds_read_b64 of four indices per four
+// iterations, one v_bfe per iteration.  Rows of a wave re-synchronise only per slice, with no refill logic.
+struct RowLists {
+    uint16_t idx[GDR_BLOCK / GDR_WAVE][4][GDR_BLOCK];   // [wave][row][position]
+    uint16_t pad[8];                                     // the read-ahead of the last row's last positions (null entries)
+};
+
+// pre-fill this wave's four lists with the null entry (2 x 16 bytes per lane = 2 KiB)
+__device__ __forceinline__ void row_lists_clear(RowLists& rl, uint32_t wave) {
+    uint4* p = reinterpret_cast<uint4*>(&rl.idx[wave][0][0]);
+    const uint32_t nn = (uint32_t)GDR_NULL_ENTRY | ((uint32_t)GDR_NULL_ENTRY << 16);
+    p[lane_id()] = make_uint4(nn, nn, nn, nn);
+    p[GDR_WAVE + lane_id()] = make_uint4(nn, nn, nn, nn);
+}
+
+// append group g's entries (one per lane) to the row lists; n[r] = list lengths so far (wave-uniform)
+__device__ __forceinline__ void row_lists_append(RowLists& rl, uint32_t wave, int g, uint64_t m0, uint64_t m1, uint64_t m2,
+                                                 uint64_t m3, int (&n)[4]) {
+    const uint32_t lane = lane_id();
+    const uint16_t e = (uint16_t)(g * GDR_WAVE + (int)lane);
+    const uint64_t m[4] = {m0, m1, m2, m3};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(m[r] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m[r], (uint32_t)n[r]));
+        if ((m[r] >> lane) & 1ull) rl.idx[wave][r][pos] = e;
+        n[r] += __popcll(m[r]);
+    }
+}
+
+__device__ __forceinline__ void wave_lds_fence() {   // wave-private LDS data written by some lanes, read by others
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
 }  // namespace
 
 // segments of cut tile lists (see tile_order_kernel): arguments shared by the K6 / K7 launches

@@ -108,6 +108,7 @@ __global__ __launch_bounds__(GDR_BLOCK) void surfel_render_fwd_kernel(
     float* __restrict__ out_others, const uint32_t* __restrict__ seg_base, float* __restrict__ seg_state,
     int seg_rounds) {
     __shared__ SurfelLds lds;
+    __shared__ RowLists rlists;
     __shared__ int s_done[GDR_BLOCK / GDR_WAVE];
 
     const uint32_t tile = tile_order ? tile_order[blockIdx.x] : xcd_remap(blockIdx.x, (uint32_t)ntiles);
@@ -128,6 +129,7 @@ __global__ __launch_bounds__(GDR_BLOCK) void surfel_render_fwd_kernel(
     const uint32_t sb = (seg_rounds > 0 && rounds > seg_rounds) ? seg_base[tile] : 0xFFFFFFFFu;
 
     if (threadIdx.x == 0) null_entry(lds);
+    if (threadIdx.x < 8) rlists.pad[threadIdx.x] = (uint16_t)GDR_NULL_ENTRY;
     // The distortion sum_i w_i (m_i^2 A_i + M2_i - 2 m_i M1_i) = sum_{j<i} w_i w_j (m_i - m_j)^2 only depends on
     // DIFFERENCES of the normalised depth m = far/(far-near) (1 - near/z).  Evaluated with m ~ 0.9 in fp32 it cancels
     // to ~1e-4 of its terms (the reference's loss weights it by 1000, loss.py:52); here m is taken relative to the
@@ -162,18 +164,26 @@ __global__ __launch_bounds__(GDR_BLOCK) void surfel_render_fwd_kernel(
         }
         if (live == 0ull) continue;
         const uint32_t base = (uint32_t)(r * GDR_BLOCK) + 1u;
+        // this wave's compacted row lists of the slice (render_common.h RowLists)
+        int n[4] = {0, 0, 0, 0};
+        row_lists_clear(rlists, wave);
+        wave_lds_fence();
 #pragma unroll 1
         for (int g = 0; g < GDR_BLOCK / GDR_WAVE; ++g) {
             uint64_t m0, m1, m2, m3;
             block_masks(lds, g, XA, YA, (live & GDR_ROW_MASK(0)) != 0ull, (live & GDR_ROW_MASK(1)) != 0ull,
                         (live & GDR_ROW_MASK(2)) != 0ull, (live & GDR_ROW_MASK(3)) != 0ull, m0, m1, m2, m3);
-            if ((m0 | m1 | m2 | m3) == 0ull) continue;
-            const uint32_t goff = (uint32_t)(g * GDR_WAVE), nulloff = GDR_NULL_ENTRY - goff;
-            uint64_t mr = row_select(row, m0, m1, m2, m3);
+            row_lists_append(rlists, wave, g, m0, m1, m2, m3, n);
+        }
+        const int nmax = max(max(n[0], n[1]), max(n[2], n[3]));
+        if (nmax == 0) continue;
+        wave_lds_fence();
+        {
+            const uint16_t* my_list = &rlists.idx[wave][row][0];
             bool abort = false;
-            auto fetch = [&](SEntry& en) {
-                en.e = min(take_bit(mr), nulloff) + goff;
-                en.tu = lds.tu[en.e]; en.tv = lds.tv[en.e]; en.tw = lds.tw[en.e]; en.nr = lds.nr[en.e]; en.gb = lds.gb[en.e];
+            auto fetch = [&](SEntry& en, uint32_t e) __attribute__((always_inline)) {
+                en.e = e;
+                en.tu = lds.tu[e]; en.tv = lds.tv[e]; en.tw = lds.tw[e]; en.nr = lds.nr[e]; en.gb = lds.gb[e];
             };
             auto composite = [&](const SEntry& en) {
                 Hit h;
@@ -202,23 +212,24 @@ __global__ __launch_bounds__(GDR_BLOCK) void surfel_render_fwd_kernel(
                 last_contributor = contributes ? base + en.e : last_contributor;
                 if (__ballot(stop) != 0ull) {
                     live = __ballot(thr < INFINITY);
-                    if (((live >> (16 * row)) & 0xFFFFull) == 0ull) mr = 0ull;
                     if (live == 0ull) abort = true;
                 }
             };
-            SEntry A, B;
-            fetch(A);
-            for (;;) {
-                const bool moreA = __ballot(mr != 0ull) != 0ull;
-                fetch(B);
+            SEntry A, B;   // four list positions per 8-byte LDS read; entry k+1 is fetched while entry k is composited
+            uint2 q = *reinterpret_cast<const uint2*>(my_list);
+            fetch(A, q.x & 0xFFFFu);
+            for (int i = 0; i < nmax && !abort; i += 4) {
+                const uint2 qn = *reinterpret_cast<const uint2*>(my_list + i + 4);
+                fetch(B, q.x >> 16);
                 composite(A);
-                if (!moreA || abort) break;
-                const bool moreB = __ballot(mr != 0ull) != 0ull;
-                fetch(A);
+                fetch(A, q.y & 0xFFFFu);
                 composite(B);
-                if (!moreB || abort) break;
+                fetch(B, q.y >> 16);
+                composite(A);
+                fetch(A, qn.x & 0xFFFFu);
+                composite(B);
+                q = qn;
             }
-            if (abort) g = GDR_BLOCK / GDR_WAVE;
         }
     }
     if (sb != 0xFFFFFFFFu) {  // totals of the cut list
@@ -254,6 +265,7 @@ __global__ __launch_bounds__(GDR_BLOCK) void surfel_render_bwd_kernel(
     const float* __restrict__ seg_state, const uint2* __restrict__ seg_extra, const uint32_t* __restrict__ seg_count,
     int seg_rounds, int n_extra) {
     __shared__ SurfelLds lds;
+    __shared__ RowLists rlists;
     __shared__ uint32_t s_id[GDR_BLOCK + 1];
 
     // workgroups [0, n_extra): one segment of a cut list each; [n_extra, n_extra + ntiles): one tile each — its whole
@@ -294,6 +306,7 @@ __global__ __launch_bounds__(GDR_BLOCK) void surfel_render_bwd_kernel(
     const int rounds = (total + GDR_BLOCK - 1) / GDR_BLOCK;
 
     if (threadIdx.x == 0) { null_entry(lds); s_id[GDR_NULL_ENTRY] = 0; }
+    if (threadIdx.x < 8) rlists.pad[threadIdx.x] = (uint16_t)GDR_NULL_ENTRY;
     // reference depth of the shifted normalised depth m' (see K6s): the tile's FIRST list entry
     const float r_ref = full_total > 0 ? __builtin_amdgcn_rcpf(fmaxf(rec[6 * (size_t)point_list[range.x] + 2].z, GSR_NEAR)) : 1.f;
     const float T_final = inside ? final_T[pix] : 0.f;
@@ -363,25 +376,26 @@ __global__ __launch_bounds__(GDR_BLOCK) void surfel_render_bwd_kernel(
         }
         const int top = total - 1 - r * GDR_BLOCK;  // list position of LDS entry e: top - e
         if (top - (GDR_BLOCK - 1) >= wave_last) continue;
-        auto group_mask = [&](int g) -> uint64_t {
+        int n[4] = {0, 0, 0, 0};   // this wave's compacted row lists of the slice (render_common.h RowLists)
+        row_lists_clear(rlists, wave);
+        wave_lds_fence();
+#pragma unroll 1
+        for (int g = 0; g < GDR_BLOCK / GDR_WAVE; ++g) {
             const int gtop = top - g * GDR_WAVE;  // position of this group's entry 0
-            if (gtop - (GDR_WAVE - 1) >= wave_last) return 0ull;
+            if (gtop - (GDR_WAVE - 1) >= wave_last) continue;
             uint64_t m0, m1, m2, m3;
             const int mypos = gtop - (int)lane;
             block_masks(lds, g, XA, YA, mypos < rl0, mypos < rl1, mypos < rl2, mypos < rl3, m0, m1, m2, m3);
-            return row_select(row, m0, m1, m2, m3);
-        };
-        const uint64_t q0 = group_mask(0), q1 = group_mask(1), q2 = group_mask(2), q3 = group_mask(3);
-        if (__ballot((q0 | q1 | q2 | q3) != 0ull) == 0ull) continue;
+            row_lists_append(rlists, wave, g, m0, m1, m2, m3, n);
+        }
+        const int nmax = max(max(n[0], n[1]), max(n[2], n[3]));
+        if (nmax == 0) continue;
+        wave_lds_fence();
         {
-            uint32_t gi = 0u;
-            uint64_t mr = q0;
-            GDR_REFILL(mr, gi, q1, q2, q3);
-            auto fetch = [&](SEntry& en) __attribute__((always_inline)) {
-                const uint32_t goff = gi << 6;
-                en.e = min(take_bit(mr), GDR_NULL_ENTRY - goff) + goff;
-                en.tu = lds.tu[en.e]; en.tv = lds.tv[en.e]; en.tw = lds.tw[en.e]; en.nr = lds.nr[en.e]; en.gb = lds.gb[en.e];
-                if (__ballot(mr == 0ull && gi < 3u) != 0ull) GDR_REFILL(mr, gi, q1, q2, q3);
+            const uint16_t* my_list = &rlists.idx[wave][row][0];
+            auto fetch = [&](SEntry& en, uint32_t e) __attribute__((always_inline)) {
+                en.e = e;
+                en.tu = lds.tu[e]; en.tv = lds.tv[e]; en.tw = lds.tw[e]; en.nr = lds.nr[e]; en.gb = lds.gb[e];
             };
             auto accumulate = [&](const SEntry& en) {
                 Hit h;
@@ -438,16 +452,19 @@ __global__ __launch_bounds__(GDR_BLOCK) void surfel_render_bwd_kernel(
                 }
             };
             SEntry A, B;
-            fetch(A);
-            for (;;) {
-                const bool moreA = __ballot(mr != 0ull) != 0ull;
-                fetch(B);
+            uint2 q = *reinterpret_cast<const uint2*>(my_list);
+            fetch(A, q.x & 0xFFFFu);
+            for (int i = 0; i < nmax; i += 4) {
+                const uint2 qn = *reinterpret_cast<const uint2*>(my_list + i + 4);
+                fetch(B, q.x >> 16);
                 accumulate(A);
-                if (!moreA) break;
-                const bool moreB = __ballot(mr != 0ull) != 0ull;
-                fetch(A);
+                fetch(A, q.y & 0xFFFFu);
                 accumulate(B);
-                if (!moreB) break;
+                fetch(B, q.y >> 16);
+                accumulate(A);
+                fetch(A, qn.x & 0xFFFFu);
+                accumulate(B);
+                q = qn;
             }
         }
     }
