@@ -46,7 +46,8 @@ class GdrBinning(C.Structure):
     _fields_ = [("keys", C.c_void_p * 2), ("values", C.c_void_p * 2), ("hist", C.c_void_p),
                 ("sorted", C.c_int32), ("global_sort", C.c_int32), ("scratch32", C.c_void_p),
                 ("seg_extra", C.c_void_p), ("seg_count", C.c_void_p), ("seg_state", C.c_void_p),
-                ("seg_len", C.c_int32), ("seg_cap", C.c_int32), ("deep_max_busy", C.c_int32), ("reserved0", C.c_int32)]
+                ("seg_len", C.c_int32), ("seg_cap", C.c_int32), ("deep_max_busy", C.c_int32), ("reserved0", C.c_int32),
+                ("d_dev", C.c_void_p)]
 
 
 class GdrImage(C.Structure):
@@ -207,7 +208,7 @@ def load():
             fn = getattr(lib, name)  # AttributeError if the symbol is missing
             fn.restype = res
             fn.argtypes = args
-        if lib.gdr_abi_version() != 9:
+        if lib.gdr_abi_version() != 10:
             raise RuntimeError("libgdr_hip.so ABI version mismatch")
         _lib = lib
     return _lib

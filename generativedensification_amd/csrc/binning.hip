@@ -49,6 +49,18 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* lds, u
     return base + incl - v;
 }
 
+// Duplicate count of a view.  Host-sized call: bv.D.  Device-sized call (gdr_binning.d_dev, include/gdr.h): the count
+// K1 left on the device, clamped to the capacity the buffers were carved for (the caller compares the two afterwards
+// and repeats the view if it did not fit), and the sort's block count derived from it.
+__device__ __forceinline__ uint64_t view_D(const BinView& bv) {
+    if (!bv.d_dev) return bv.D;
+    const uint64_t d = *bv.d_dev;
+    return d < bv.D ? d : bv.D;
+}
+__device__ __forceinline__ uint32_t view_nblk(const BinView& bv, uint64_t D) {
+    return bv.d_dev ? (uint32_t)((D + GDR_SORT_TILE - 1) / GDR_SORT_TILE) : bv.nblk;
+}
+
 // ---------------------------------------------------------------------------------
 // K2: single workgroup, exclusive scan of block_sums[0..nb) in place;
 //     block_sums[nb] = num_rendered[0] = total.
@@ -87,7 +99,7 @@ __global__ __launch_bounds__(GDR_BLOCK) void duplicate_kernel(const BinViews vs,
     const uint32_t* __restrict__ block_offsets = bv.block_offs;
     uint64_t* __restrict__ keys = bv.keys[0];
     uint32_t* __restrict__ vals = bv.vals[0];
-    const uint64_t D = bv.D;
+    const uint64_t D = bv.D;   // (the capacity of the buffers in a device-sized call)
     __shared__ uint32_t lds[8];
     const int i = blockIdx.x * GDR_BLOCK + threadIdx.x;
     const uint32_t t = i < N ? tiles_touched[i] : 0u;
@@ -117,10 +129,10 @@ __device__ __forceinline__ uint64_t tile_index(uint32_t blk, uint32_t wave, int 
 
 __global__ __launch_bounds__(GDR_BLOCK) void sort_hist_kernel(const BinViews vs, int cur, int shift) {
     const BinView& bv = vs.v[blockIdx.y];
-    const uint32_t nblk = bv.nblk;
-    if (blockIdx.x >= nblk) return;   // (the grid is sized for the view with the most duplicates)
+    const uint64_t D = view_D(bv);
+    const uint32_t nblk = view_nblk(bv, D);
+    if (blockIdx.x >= nblk) return;   // (the grid is sized for the view with the most duplicates / for the capacity)
     const uint64_t* __restrict__ keys = bv.keys[cur];
-    const uint64_t D = bv.D;
     uint32_t* __restrict__ hist = bv.hist;
     __shared__ uint32_t cnt[GDR_BLOCK / GDR_WAVE][GDR_RADIX];
     for (int k = threadIdx.x; k < (GDR_BLOCK / GDR_WAVE) * GDR_RADIX; k += GDR_BLOCK)
@@ -143,7 +155,7 @@ __global__ __launch_bounds__(GDR_BLOCK) void sort_hist_kernel(const BinViews vs,
 // one workgroup per digit: exclusive scan of its row of nblk per-block counts.
 __global__ __launch_bounds__(GDR_BLOCK) void sort_rowscan_kernel(const BinViews vs) {
     const BinView& bv = vs.v[blockIdx.y];
-    const uint32_t nblk = bv.nblk;
+    const uint32_t nblk = view_nblk(bv, view_D(bv));
     uint32_t* __restrict__ hist = bv.hist;
     uint32_t* __restrict__ totals = bv.hist + (uint64_t)nblk * GDR_RADIX;
     if (nblk == 0) return;
@@ -163,13 +175,13 @@ __global__ __launch_bounds__(GDR_BLOCK) void sort_rowscan_kernel(const BinViews 
 
 __global__ __launch_bounds__(GDR_BLOCK) void sort_scatter_kernel(const BinViews vs, int cur, int shift) {
     const BinView& bv = vs.v[blockIdx.y];
-    const uint32_t nblk = bv.nblk;
+    const uint64_t D = view_D(bv);
+    const uint32_t nblk = view_nblk(bv, D);
     if (blockIdx.x >= nblk) return;
     const uint64_t* __restrict__ keys_in = bv.keys[cur];
     const uint32_t* __restrict__ vals_in = bv.vals[cur];
     uint64_t* __restrict__ keys_out = bv.keys[cur ^ 1];
     uint32_t* __restrict__ vals_out = bv.vals[cur ^ 1];
-    const uint64_t D = bv.D;
     const uint32_t* __restrict__ hist = bv.hist;
     const uint32_t* __restrict__ totals = bv.hist + (uint64_t)nblk * GDR_RADIX;
     __shared__ uint32_t cnt[GDR_BLOCK / GDR_WAVE][GDR_RADIX];
@@ -246,7 +258,7 @@ __global__ __launch_bounds__(GDR_BLOCK) void ranges_clear_kernel(const BinViews 
 __global__ __launch_bounds__(GDR_BLOCK) void ranges_kernel(const BinViews vs, int cur) {
     const BinView& bv = vs.v[blockIdx.y];
     const uint64_t* __restrict__ keys = bv.keys[cur];
-    const uint64_t D = bv.D;
+    const uint64_t D = view_D(bv);
     uint2* __restrict__ ranges = bv.ranges;
     const uint64_t e = (uint64_t)blockIdx.x * GDR_BLOCK + threadIdx.x;
     if (e >= D) return;
@@ -405,9 +417,9 @@ __global__ __launch_bounds__(NW * GDR_WAVE) void tile_sort_kernel(const BinViews
     uint64_t* __restrict__ keys_out = bv.keys[in ^ 1];
     uint32_t* __restrict__ vals_out = bv.vals[in ^ 1];
     uint32_t* __restrict__ scratch32 = bv.scratch32;
-    const uint64_t D = bv.D;
+    const uint64_t D = bv.D;   // offset of the second scratch half: the carved size, not the live count
     const uint32_t* __restrict__ tile_order = bv.tile_order;
-    if (D == 0) return;
+    if (view_D(bv) == 0) return;
     constexpr uint32_t NT = NW * GDR_WAVE;
     __shared__ uint32_t lds_elems[4 * CAP];
     __shared__ uint32_t cnt[NW][GDR_RADIX];
@@ -583,6 +595,7 @@ void fill_bin_views(BinViews* vs, int V, const gdr_geom* geoms, const gdr_binnin
         b.ranges = (uint2*)imgs[v].ranges; b.tile_order = imgs[v].tile_order; b.seg_base = imgs[v].seg_base;
         b.seg_extra = (uint2*)bn.seg_extra; b.seg_count = bn.seg_count;
         b.D = D[v]; b.nblk = (uint32_t)((D[v] + GDR_SORT_TILE - 1) / GDR_SORT_TILE);
+        b.d_dev = bn.d_dev;
         b.seg_len = bn.seg_len; b.seg_cap = bn.seg_cap;
         b.deep_max_busy = (uint32_t)(bn.deep_max_busy > 0 ? bn.deep_max_busy : 0);
     }

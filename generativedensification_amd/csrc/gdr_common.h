@@ -91,6 +91,7 @@ struct BinView {
     uint64_t* keys[2]; uint32_t* vals[2]; uint32_t* hist; uint32_t* scratch32;
     uint2* ranges; uint32_t* tile_order; uint32_t* seg_base; uint2* seg_extra; uint32_t* seg_count;
     uint64_t D; uint32_t nblk; int32_t seg_len, seg_cap; uint32_t deep_max_busy;
+    const uint32_t* d_dev;   // gdr_binning.d_dev: the duplicate count stays on the device, D/nblk above are CAPACITIES
 };
 struct BinViews { BinView v[GDR_MAX_VIEWS]; };
 void fill_bin_views(BinViews* vs, int V, const gdr_geom* geoms, const gdr_binning* bins, const gdr_image* imgs,

@@ -130,9 +130,6 @@ _FORCE_GLOBAL_SORT = False
 
 import os as _os
 
-# GDR_VIEW_STREAMS=n (legacy switch, only used with GDR_BIN_STREAM=0): the whole per-view pipeline (binning + K6) of a
-# multi-view node round-robin on n streams.  Superseded by the scheme below, which is the default.
-VIEW_STREAMS = max(1, int(_os.environ.get("GDR_VIEW_STREAMS", "1")))
 # GDR_BIN_STREAM=n: number of side streams that carry the views of a multi-view node (binning, and with GDR_RENDER_SIDE
 # also K6 / K7), round-robin; 0 = everything on the caller's stream; unset = side_count() below.
 # GDR_RENDER_SIDE=1 (default): K6 of a view right behind its binning on the view's side stream, K7 of the views on the
@@ -270,17 +267,36 @@ def forward_raw(means3D, sh, colors_precomp, opacities, scales, rotations, cov3D
         alpha = torch.empty(1, H, W, **f32)
         radii = torch.empty(N, dtype=torch.int32, device=dev)
         stream = _stream()
-        d_host = C.c_uint32(0)
-        L.check(lib.gdr_preprocess_forward(C.byref(s), C.byref(inp), C.byref(st.geom), _ptr(radii),
-                                           C.byref(d_host), stream), "gdr_preprocess_forward")
-        st.D = int(d_host.value)
-        st.bin_buf = torch.empty(lib.gdr_binning_bytes(st.D), **u8)
-        L.check(lib.gdr_binning_carve(st.bin_buf.data_ptr(), st.D, C.byref(st.bin)), "gdr_binning_carve")
-        st.bin.global_sort = int(_FORCE_GLOBAL_SORT)
-        _apply_seg_len(st.bin, st.D, ((W + 15) // 16) * ((H + 15) // 16))
+        tiles = ((W + 15) // 16) * ((H + 15) // 16)
+        st.bin_buf = None
         out = L.GdrOutputs(color.data_ptr(), depth.data_ptr(), alpha.data_ptr(), _ptr(radii))
-        L.check(lib.gdr_render_forward(C.byref(s), C.byref(inp), C.byref(st.geom), C.byref(st.bin),
-                                       C.byref(st.img), st.D, C.byref(out), stream), "gdr_render_forward")
+        key = (N, H, W)
+        cap = _d_capacity(key) if N > 0 else None
+
+        def render():    # K3..K6 behind K1 on the caller's stream
+            L.check(lib.gdr_render_forward(C.byref(s), C.byref(inp), C.byref(st.geom), C.byref(st.bin),
+                                           C.byref(st.img), st.D, C.byref(out), stream), "gdr_render_forward")
+
+        if cap is None:   # first call of this shape: the read-back upstream performs in every call
+            d_host = C.c_uint32(0)
+            L.check(lib.gdr_preprocess_forward(C.byref(s), C.byref(inp), C.byref(st.geom), _ptr(radii),
+                                               C.byref(d_host), stream), "gdr_preprocess_forward")
+            d = int(d_host.value)
+            _carve_binning(lib, st, d, tiles)
+            render()
+        else:             # device-sized call (DEFER_D above): nothing waits for K1 until everything is enqueued
+            L.check(lib.gdr_preprocess_forward(C.byref(s), C.byref(inp), C.byref(st.geom), _ptr(radii), None, stream),
+                    "gdr_preprocess_forward")
+            st.counters = st._view(st.geom_buf, st.geom.num_rendered, torch.int32, 1)
+            readback = _CountReadback(st.counters)
+            _carve_binning(lib, st, cap, tiles, d_dev=st.geom.num_rendered)
+            render()
+            d = readback.wait()[0]
+            if d > cap:
+                _carve_binning(lib, st, d, tiles)
+                render()
+            st.D = d
+        _d_record(key, [d])
     return color, radii, depth, alpha, st, keep
 
 
@@ -374,8 +390,58 @@ class _RasterizeGaussians(torch.autograd.Function):
 # separate autograd accumulation passes.  Same arithmetic as V calls of rasterize_gaussians.
 # --------------------------------------------------------------------------------------------
 RAW_ALL = L.GDR_IN_RAW_OPACITY | L.GDR_IN_RAW_SCALES | L.GDR_IN_RAW_ROTATIONS
-_PREALLOC = _os.environ.get("GDR_PREALLOC", "1") != "0"   # A/B switch of the two host-latency measures below
-_D_HINT: dict = {}   # (N, H, W, V) -> duplicate counts per view of the previous call (sizes the next call's workspaces)
+
+# ---- the duplicate count D without a host stall --------------------------------------------------------------
+# K1 leaves D (the reference's num_rendered) on the device; the sort buffers are sized by it, and upstream reads it back
+# in the middle of every forward call — the host waits for K1, the GPU then waits for the host to allocate and launch.
+# Here the FIRST call of a shape (N, H, W, V) does the same.  Later calls carve the binning workspaces for a CAPACITY
+# derived from the counts this shape has produced so far, point the binning kernels at the device word
+# (gdr_binning.d_dev: a device-sized call, include/gdr.h) and enqueue binning + K6 of every view right behind K1; the
+# counts travel to pinned host memory meanwhile and are compared with the capacity once everything is enqueued.  A view
+# that did not fit (nothing was written out of bounds, but its lists are truncated) is repeated with an exactly sized
+# workspace before the call returns, so the results never depend on the guess.
+DEFER_D = _os.environ.get("GDR_DEFER_D", "1") != "0"
+D_SLACK = float(_os.environ.get("GDR_D_SLACK", "1.25"))   # capacity = slack x the largest recent count of the shape
+_D_HINT: dict = {}   # shape key -> decaying maximum of the duplicate counts of one view of that shape
+
+
+def _d_capacity(key):
+    """Entries to carve each view's binning workspace for, or None: no history yet (or GDR_DEFER_D=0) -> read D back."""
+    h = _D_HINT.get(key) if DEFER_D else None
+    return None if h is None else int(h * D_SLACK) + 4096
+
+
+def _d_record(key, d_host):
+    prev = _D_HINT.pop(key, 0)     # (re-inserted at the end: the dict doubles as an LRU of 64 shapes)
+    _D_HINT[key] = max(max(d_host, default=0), int(prev * 0.97))
+    if len(_D_HINT) > 64:
+        _D_HINT.pop(next(iter(_D_HINT)))
+
+
+class _CountReadback:
+    """The V duplicate counters on their way to pinned host memory, behind K1 on the caller's stream."""
+
+    def __init__(self, counters):
+        self.host = torch.empty(counters.shape, dtype=counters.dtype, pin_memory=True)
+        self.host.copy_(counters, non_blocking=True)
+        self.event = torch.cuda.Event()
+        self.event.record()
+
+    def wait(self):
+        self.event.synchronize()
+        return [int(d) & 0xFFFFFFFF for d in self.host.tolist()]
+
+
+def _carve_binning(lib, st, entries, tiles, d_dev=None):
+    """Workspace of one view for `entries` duplicates (exact count, or a capacity with d_dev = the device counter)."""
+    need = lib.gdr_binning_bytes(entries)
+    if st.bin_buf is None or st.bin_buf.numel() < need:
+        st.bin_buf = torch.empty(need, dtype=torch.uint8, device=st.geom_buf.device)
+    L.check(lib.gdr_binning_carve(st.bin_buf.data_ptr(), entries, C.byref(st.bin)), "gdr_binning_carve")
+    st.bin.global_sort = int(_FORCE_GLOBAL_SORT)
+    st.bin.d_dev = d_dev
+    st.D = entries
+    _apply_seg_len(st.bin, entries, tiles)
 
 
 def binning_views(lib, s_arr, N, g_arr, states, radii, lo, hi, stream, fn="gdr_binning_forward_views"):
@@ -394,8 +460,9 @@ def binning_views(lib, s_arr, N, g_arr, states, radii, lo, hi, stream, fn="gdr_b
 
 
 def _forward_views_impl(means3D, means2D, sh, opacities, scales, rotations, settings_list, flags, loss_spec=None):
-    """K1 for all views (one launch per <= 8 views), ONE host read of the V duplicate counts, then binning +
-    K6 per view.  Returns (colors, radii, depths, alphas, states, keep, in_dtypes)."""
+    """K1 for all views (one launch per <= 8 views), then every view's chain binning -> K6 on one of FWD_STREAMS
+    streams; the duplicate counts are read back without stalling either side (see DEFER_D above).
+    Returns (colors, radii, depths, alphas, states, keep, in_dtypes)."""
     lib = L.load()
     _require_hip(means3D, "means3D")
     dev = means3D.device
@@ -406,6 +473,7 @@ def _forward_views_impl(means3D, means2D, sh, opacities, scales, rotations, sett
     H, W = int(settings_list[0].image_height), int(settings_list[0].image_width)
     if any(int(rs.image_height) != H or int(rs.image_width) != W for rs in settings_list):
         raise RuntimeError("render_views: all views must share one image size")
+    tiles = ((W + 15) // 16) * ((H + 15) // 16)
     e = torch.empty(0, dtype=torch.float32, device=dev)
     keep = [means3D, opacities, sh, e, scales, rotations, e]
     f32, u8 = dict(dtype=torch.float32, device=dev), dict(dtype=torch.uint8, device=dev)
@@ -418,10 +486,11 @@ def _forward_views_impl(means3D, means2D, sh, opacities, scales, rotations, sett
     radii = torch.empty(V, N, dtype=torch.int32, device=dev)
     # the V duplicate counters in one array: one fill before K1, one copy to the host (no gather kernel)
     counters = torch.empty(V, dtype=torch.int32, device=dev)
-    hint = _D_HINT.get((N, H, W, V)) if _PREALLOC else None
+    key = (N, H, W, V)
     states = []
     with torch.cuda.device(dev):
         stream = _stream()
+        main = torch.cuda.current_stream()
         inp = _inputs_struct(N, M, means3D, opacities, sh, e, scales, rotations, e, flags)
         s_arr = (L.GdrSettings * V)()
         g_arr = (L.GdrGeom * V)()
@@ -431,17 +500,13 @@ def _forward_views_impl(means3D, means2D, sh, opacities, scales, rotations, sett
             st.N, st.M, st.H, st.W = N, M, H, W
             st.geom_buf = torch.empty(lib.gdr_geom_bytes(N), **u8)
             st.img_buf = torch.empty(lib.gdr_image_bytes(H, W), **u8)
+            st.bin_buf = None
             st.geom, st.bin, st.img = L.GdrGeom(), L.GdrBinning(), L.GdrImage()
             L.check(lib.gdr_geom_carve(st.geom_buf.data_ptr(), N, C.byref(st.geom)), "gdr_geom_carve")
             L.check(lib.gdr_image_carve(st.img_buf.data_ptr(), H, W, C.byref(st.img)), "gdr_image_carve")
             st.geom.cov3D = states[0].geom.cov3D if states else st.geom.cov3D  # view-independent: shared
-            if _PREALLOC:
-                st.geom.num_rendered = counters.data_ptr() + 4 * v
+            st.geom.num_rendered = counters.data_ptr() + 4 * v
             st.counters = counters
-            # binning workspace sized from the previous call of this shape, allocated BEFORE the read-back so that the
-            # host has nothing to allocate between the read-back and the first binning launch (re-allocated below if
-            # the view turns out to need more)
-            st.bin_buf = torch.empty(lib.gdr_binning_bytes(hint[v] + hint[v] // 4 + 4096), **u8) if hint else None
             g_arr[v] = st.geom
             states.append(st)
         # K1 for all views in groups of <= GDR_MAX_VIEWS launches (inputs read once per group)
@@ -455,36 +520,27 @@ def _forward_views_impl(means3D, means2D, sh, opacities, scales, rotations, sett
                     sub_g[k].cov3D = g_arr[0].cov3D
             L.check(lib.gdr_preprocess_forward_views(n, sub_s, C.byref(inp), sub_g, r_arr, stream),
                     "gdr_preprocess_forward_views")
-        main = torch.cuda.current_stream()
-        n_side = side_count(H, W)
-        two_stage = n_side > 0 and V > 1
-        if two_stage:  # side streams start waiting for K1 before the host blocks on the read-back
-            auxs = _view_streams(dev, min(n_side, V))
+        # The views' chains (binning -> K6) round-robin over FWD_STREAMS streams, the caller's included: the binning is
+        # ~12 short, latency-bound kernels per view that overlap the VALU-bound K6 of other views, and two concurrent K6
+        # fill the CUs that one view's skewed tile lists and kernel tails leave idle.  Four streams = the number of
+        # hardware queues a process gets by default (more alias onto the same queues and serialise).
+        nfs = max(1, min(FWD_STREAMS, V)) if RENDER_SIDE and V > 1 and side_count(H, W) > 0 else 1
+        fstreams = [main] + _view_streams(dev, nfs - 1)
+        if nfs > 1:   # the side streams start waiting for K1 now, before the host does anything else
             ready = torch.cuda.Event()
             ready.record(main)
-            for aux in auxs:
-                aux.wait_event(ready)
-        # ONE host read-back for all V views
-        if not _PREALLOC:
-            counters = torch.cat([st._view(st.geom_buf, st.geom.num_rendered, torch.int32, 1) for st in states])
-        d_host = [int(d) & 0xFFFFFFFF for d in counters.cpu().tolist()]
-        _D_HINT[(N, H, W, V)] = d_host
-        if len(_D_HINT) > 64:
-            _D_HINT.pop(next(iter(_D_HINT)))
+            for fs in fstreams[1:]:
+                fs.wait_event(ready)
+        readback = _CountReadback(counters)
+        cap = _d_capacity(key) if N > 0 else None
+        if cap is None:         # first call of this shape: D decides the workspace sizes, as upstream
+            d_host = readback.wait()
+            for v, st in enumerate(states):
+                _carve_binning(lib, st, d_host[v], tiles)
+        else:
+            for v, st in enumerate(states):
+                _carve_binning(lib, st, cap, tiles, d_dev=st.geom.num_rendered)
 
-        def alloc_bin(v):
-            st = states[v]
-            st.D = d_host[v]
-            need = lib.gdr_binning_bytes(st.D)
-            if st.bin_buf is None or st.bin_buf.numel() < need:
-                st.bin_buf = torch.empty(need, **u8)
-            L.check(lib.gdr_binning_carve(st.bin_buf.data_ptr(), st.D, C.byref(st.bin)), "gdr_binning_carve")
-            st.bin.global_sort = int(_FORCE_GLOBAL_SORT)
-            _apply_seg_len(st.bin, st.D, ((W + 15) // 16) * ((H + 15) // 16))
-
-        if not two_stage:
-            for v in range(V):
-                alloc_bin(v)
         def composite(v, sv):  # K6 of view v (with the loss folded into its epilogue when loss_spec is given)
             st = states[v]
             if lossgrad:
@@ -505,79 +561,35 @@ def _forward_views_impl(means3D, means2D, sh, opacities, scales, rotations, sett
                                                        float(w_alpha), losses[v:v + 1].data_ptr(), sv),
                         "gdr_composite_forward_loss")
 
-        if two_stage:
-            # Binning of view v+1 (latency-bound: ~10 short kernels with few workgroups) overlaps K6 of view v
-            # (VALU-bound) on dedicated streams.  The D read-back above synchronised `main`, so every workspace
-            # allocated since then is free of pending work and may be touched by a side stream at once; each view's
-            # binning is enqueued as soon as its workspace exists (the GPU idles until the first of these launches).
-            # The host issues ~12 launches per view for the binning and the GPU retires these short kernels about as fast
-            # as they arrive (kernel timeline of a C4 step, scripts/gpu_timeline.sh: 690 us from the first binning launch
-            # to the last, launch-rate bound), so the ORDER of enqueueing decides when the first render kernel can start:
-            # views are enqueued in groups of len(bins) — binning of the group on the binning streams, then K6 of the
-            # group on the render streams behind the views' binning events — and the next group's binning launches go out
-            # while the GPU composites.  Render streams = the caller's stream + one more: with the two binning streams
-            # that is four HIP streams, the number of hardware queues a process gets by default (more alias onto the
-            # same queues and serialise).
-            binned = [None] * V
-            if RENDER_SIDE:
-                # ONE binning chain for all views (gdr_binning_forward_views: every launch covers all the views, ~13 launches
-                # per <= 8 views instead of 13 per view) on the caller's stream, then K6 of the views round-robin over
-                # FWD_STREAMS streams (the caller's + side streams).  Kernel timeline of a C4 step before this
-                # (scripts/gpu_timeline.sh): 52 binning launches spread over 700 us, bound by the host's launch rate, the
-                # first K6 200 us behind its own view's binning.
-                for v in range(V):
-                    alloc_bin(v)
-                nfs = max(1, min(FWD_STREAMS, V))
-                fstreams = [main] + _view_streams(dev, max(nfs - 1, len(auxs)))[:nfs - 1]
-                for fs in fstreams[1:]:
-                    fs.wait_event(ready)
-                grp = max(1, min(BIN_GROUP, L.GDR_MAX_VIEWS))
-                for c, lo in enumerate(range(0, V, grp)):   # one chain per group of views, the groups round-robin over the streams
-                    fs = fstreams[c % nfs]
-                    sp = C.c_void_p(fs.cuda_stream)
-                    hi = min(V, lo + grp)
-                    if hi - lo > 1:
-                        binning_views(lib, s_arr, N, g_arr, states, radii, lo, hi, sp)
-                    else:
-                        st = states[lo]
-                        L.check(lib.gdr_binning_forward(C.byref(s_arr[lo]), N, C.byref(g_arr[lo]), C.byref(st.bin),
-                                                        C.byref(st.img), st.D, _ptr(radii[lo]), sp), "gdr_binning_forward")
-                    with torch.cuda.stream(fs):
-                        for v in range(lo, hi):
-                            composite(v, sp)
-                for fs in fstreams[1:]:
-                    done = torch.cuda.Event()
-                    done.record(fs)
-                    main.wait_event(done)
-                return colors, radii, depths, alphas, states, keep, in_dtypes
+        def chain(lo, hi, fs):   # binning of views [lo, hi) in shared launches, then their K6, all on stream fs
+            sp = C.c_void_p(fs.cuda_stream)
+            if hi - lo > 1:
+                binning_views(lib, s_arr, N, g_arr, states, radii, lo, hi, sp)
+            else:
+                st = states[lo]
+                L.check(lib.gdr_binning_forward(C.byref(s_arr[lo]), N, C.byref(g_arr[lo]), C.byref(st.bin),
+                                                C.byref(st.img), st.D, _ptr(radii[lo]), sp), "gdr_binning_forward")
+            for v in range(lo, hi):
+                composite(v, sp)
+
+        grp = max(1, min(BIN_GROUP, L.GDR_MAX_VIEWS))
+        for c, lo in enumerate(range(0, V, grp)):
+            chain(lo, min(V, lo + grp), fstreams[c % nfs])
+        for fs in fstreams[1:]:   # the caller's stream continues only after every view is rendered
+            done = torch.cuda.Event()
+            done.record(fs)
+            main.wait_event(done)
+        if cap is not None:
+            d_host = readback.wait()     # (K1 finished long ago: the host has enqueued ~15 launches per view since)
+            for v in [v for v in range(V) if d_host[v] > cap]:
+                # the guess was too small for this view: again, exactly sized, behind everything else
+                _carve_binning(lib, states[v], d_host[v], tiles)
+                if loss_spec is not None:
+                    loss_spec[-1][v:v + 1].zero_()
+                chain(v, v + 1, main)
             for v, st in enumerate(states):
-                alloc_bin(v)
-                aux = auxs[v % len(auxs)]
-                L.check(lib.gdr_binning_forward(C.byref(s_arr[v]), N, C.byref(g_arr[v]), C.byref(st.bin), C.byref(st.img),
-                                                st.D, _ptr(radii[v]), C.c_void_p(aux.cuda_stream)), "gdr_binning_forward")
-                ev = torch.cuda.Event()
-                ev.record(aux)
-                binned[v] = ev
-            for v, st in enumerate(states):
-                main.wait_event(binned[v])
-                composite(v, stream)
-            return colors, radii, depths, alphas, states, keep, in_dtypes
-        side = _view_streams(dev, min(VIEW_STREAMS, V)) if VIEW_STREAMS > 1 and V > 1 else None
-        if side:
-            ready = torch.cuda.Event()
-            ready.record(main)
-            for sd in side:
-                sd.wait_event(ready)
-        for v, st in enumerate(states):
-            sv = C.c_void_p(side[v % len(side)].cuda_stream) if side else stream
-            L.check(lib.gdr_binning_forward(C.byref(s_arr[v]), N, C.byref(g_arr[v]), C.byref(st.bin), C.byref(st.img), st.D,
-                                            _ptr(radii[v]), sv), "gdr_binning_forward")
-            composite(v, sv)
-        if side:
-            for sd in side:  # the caller's stream continues only after every view is rendered
-                done = torch.cuda.Event()
-                done.record(sd)
-                main.wait_event(done)
+                st.D = d_host[v]
+        _d_record(key, d_host)
     return colors, radii, depths, alphas, states, keep, in_dtypes
 
 

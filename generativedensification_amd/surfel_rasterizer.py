@@ -97,17 +97,36 @@ def forward_raw(means3D, sh, colors_precomp, opacities, scales, rotations, trans
         allmap = torch.empty(7, H, W, **f32)
         radii = torch.empty(N, dtype=torch.int32, device=dev)
         stream = _stream()
-        d_host = C.c_uint32(0)
-        L.check(lib.gsr_preprocess_forward(C.byref(s), C.byref(inp), C.byref(st.geom), _ptr(radii), C.byref(d_host),
-                                           stream), "gsr_preprocess_forward")
-        st.D = int(d_host.value)
-        st.bin_buf = torch.empty(lib.gdr_binning_bytes(st.D), **u8)
-        L.check(lib.gdr_binning_carve(st.bin_buf.data_ptr(), st.D, C.byref(st.bin)), "gdr_binning_carve")
-        st.bin.global_sort = int(_R._FORCE_GLOBAL_SORT)
-        _R._apply_seg_len(st.bin, st.D, ((st.W + 15) // 16) * ((st.H + 15) // 16))
+        tiles = ((W + 15) // 16) * ((H + 15) // 16)
+        st.bin_buf = None
         out = L.GsrOutputs(color.data_ptr(), allmap.data_ptr(), _ptr(radii))
-        L.check(lib.gsr_render_forward(C.byref(s), C.byref(inp), C.byref(st.geom), C.byref(st.bin), C.byref(st.img),
-                                       st.D, C.byref(out), stream), "gsr_render_forward")
+        key = ("surfel", N, H, W)
+        cap = _R._d_capacity(key) if N > 0 else None
+
+        def render():    # K3..K6s behind K1s on the caller's stream
+            L.check(lib.gsr_render_forward(C.byref(s), C.byref(inp), C.byref(st.geom), C.byref(st.bin), C.byref(st.img),
+                                           st.D, C.byref(out), stream), "gsr_render_forward")
+
+        if cap is None:   # first call of this shape: read D back, as upstream does in every call
+            d_host = C.c_uint32(0)
+            L.check(lib.gsr_preprocess_forward(C.byref(s), C.byref(inp), C.byref(st.geom), _ptr(radii), C.byref(d_host),
+                                               stream), "gsr_preprocess_forward")
+            d = int(d_host.value)
+            _R._carve_binning(lib, st, d, tiles)
+            render()
+        else:             # device-sized call (rasterizer.DEFER_D): capacity check after everything is enqueued
+            L.check(lib.gsr_preprocess_forward(C.byref(s), C.byref(inp), C.byref(st.geom), _ptr(radii), None, stream),
+                    "gsr_preprocess_forward")
+            st.counters = st._view(st.geom_buf, st.geom.num_rendered, torch.int32, 1)
+            readback = _R._CountReadback(st.counters)
+            _R._carve_binning(lib, st, cap, tiles, d_dev=st.geom.num_rendered)
+            render()
+            d = readback.wait()[0]
+            if d > cap:
+                _R._carve_binning(lib, st, d, tiles)
+                render()
+            st.D = d
+        _R._d_record(key, [d])
     return color, radii, allmap, st, keep
 
 
@@ -210,12 +229,13 @@ def _surfel_forward_views_impl(ctx, means3D, means2D, sh, opacities, scales, rot
                                               losses[v:v + 1].data_ptr(), sv), "gsr_view_loss_forward")
 
         states, structs = [], []
-        # duplicate counters of the V views in one array, binning workspaces sized from the previous call of this shape
-        # and allocated before the read-back (rasterizer._forward_views_impl)
+        # duplicate counters of the V views in one array; their read-back does not stall the call once the shape has a
+        # history (rasterizer.DEFER_D: device-sized binning calls, capacity check after everything is enqueued)
         counters = torch.empty(V, dtype=torch.int32, device=dev)
-        hint = _R._D_HINT.get(("surfel", N, H, W, V)) if _R._PREALLOC else None
+        key = ("surfel", N, H, W, V)
         with torch.cuda.device(dev):
             stream = _stream()
+            main = torch.cuda.current_stream()
             inp = _inputs_struct(N, M, means3D, opacities, sh, e, scales, rotations, e, flags)
             for v, rs in enumerate(settings_list):
                 s = _settings_struct(rs, dev, keep)
@@ -223,12 +243,12 @@ def _surfel_forward_views_impl(ctx, means3D, means2D, sh, opacities, scales, rot
                 st.N, st.M, st.H, st.W = N, M, int(rs.image_height), int(rs.image_width)
                 st.geom_buf = torch.empty(lib.gsr_geom_bytes(N), **u8)
                 st.img_buf = torch.empty(lib.gsr_image_bytes(st.H, st.W), **u8)
+                st.bin_buf = None
                 st.geom, st.bin, st.img = L.GdrGeom(), L.GdrBinning(), L.GdrImage()
                 L.check(lib.gsr_geom_carve(st.geom_buf.data_ptr(), N, C.byref(st.geom)), "gsr_geom_carve")
                 L.check(lib.gsr_image_carve(st.img_buf.data_ptr(), st.H, st.W, C.byref(st.img)), "gsr_image_carve")
                 st.geom.num_rendered = counters.data_ptr() + 4 * v
                 st.counters = counters
-                st.bin_buf = torch.empty(lib.gdr_binning_bytes(hint[v] + hint[v] // 4 + 4096), **u8) if hint else None
                 states.append(st)
                 structs.append(s)
             same = all(int(rs.image_height) == H and int(rs.image_width) == W for rs in settings_list)
@@ -244,63 +264,51 @@ def _surfel_forward_views_impl(ctx, means3D, means2D, sh, opacities, scales, rot
                 for v, st in enumerate(states):
                     L.check(lib.gsr_preprocess_forward(C.byref(structs[v]), C.byref(inp), C.byref(st.geom), _ptr(radii[v]),
                                                        None, stream), "gsr_preprocess_forward")
-            d_host = [int(d) & 0xFFFFFFFF for d in counters.cpu().tolist()]
-            _R._D_HINT[("surfel", N, H, W, V)] = d_host
-            if len(_R._D_HINT) > 64:
-                _R._D_HINT.pop(next(iter(_R._D_HINT)))
-            for v, st in enumerate(states):
-                st.D = d_host[v]
-                need = lib.gdr_binning_bytes(st.D)
-                if st.bin_buf is None or st.bin_buf.numel() < need:
-                    st.bin_buf = torch.empty(need, **u8)
-                L.check(lib.gdr_binning_carve(st.bin_buf.data_ptr(), st.D, C.byref(st.bin)), "gdr_binning_carve")
-                st.bin.global_sort = int(_R._FORCE_GLOBAL_SORT)
-                _R._apply_seg_len(st.bin, st.D, ((st.W + 15) // 16) * ((st.H + 15) // 16))
-            n_side = _R.side_count(H, W)
-            if n_side and V > 1:   # binning of view v+1 overlaps K6s of view v (rasterizer._forward_views_impl)
-                main = torch.cuda.current_stream()
-                auxs = _R._view_streams(dev, min(n_side, V))
+            # every view's chain (binning -> K6s -> fused loss kernel) on one of the forward streams, the caller's
+            # included (rasterizer._forward_views_impl)
+            nfs = max(1, min(_R.FWD_STREAMS, V)) if _R.RENDER_SIDE and V > 1 and _R.side_count(H, W) > 0 else 1
+            fstreams = [main] + _R._view_streams(dev, nfs - 1)
+            if nfs > 1:
                 ready = torch.cuda.Event()
                 ready.record(main)
-                for aux in auxs:
-                    aux.wait_event(ready)
-                same = all(st.H == states[0].H and st.W == states[0].W for st in states)
-                fstreams = [main] + list(auxs)
-                if same and _R.RENDER_SIDE:
-                    # one binning chain for all views on the caller's stream (rasterizer._forward_views_impl), then K6s +
-                    # the fused loss kernels of the views round-robin over the streams
-                    _R.binning_views(lib, structs, N, [st.geom for st in states], states, radii, 0, V, stream)
-                    ev = torch.cuda.Event()
-                    ev.record(main)
-                    for aux in auxs:
-                        aux.wait_event(ev)
-                    for v, st in enumerate(states):
-                        out = L.GsrOutputs(colors[v].data_ptr(), allmaps[v].data_ptr(), _ptr(radii[v]))
-                        sv = C.c_void_p(fstreams[v % len(fstreams)].cuda_stream)
-                        L.check(lib.gsr_composite_forward(C.byref(structs[v]), C.byref(st.geom), C.byref(st.bin),
-                                                          C.byref(st.img), C.byref(out), sv), "gsr_composite_forward")
-                        view_loss(v, sv)
-                else:
-                    for v, st in enumerate(states):   # views of different sizes: one chain per view on the side streams
-                        aux = auxs[v % len(auxs)]
-                        L.check(lib.gdr_binning_forward(C.byref(structs[v]), N, C.byref(st.geom), C.byref(st.bin),
-                                                        C.byref(st.img), st.D, _ptr(radii[v]), C.c_void_p(aux.cuda_stream)),
-                                "gdr_binning_forward")
-                        out = L.GsrOutputs(colors[v].data_ptr(), allmaps[v].data_ptr(), _ptr(radii[v]))
-                        L.check(lib.gsr_composite_forward(C.byref(structs[v]), C.byref(st.geom), C.byref(st.bin),
-                                                          C.byref(st.img), C.byref(out), C.c_void_p(aux.cuda_stream)),
-                                "gsr_composite_forward")
-                        view_loss(v, C.c_void_p(aux.cuda_stream))
-                for aux in auxs:
-                    done = torch.cuda.Event()
-                    done.record(aux)
-                    main.wait_event(done)
-            else:
+                for fs in fstreams[1:]:
+                    fs.wait_event(ready)
+            readback = _R._CountReadback(counters)
+            cap = _R._d_capacity(key) if N > 0 else None
+            tiles_of = lambda st: ((st.W + 15) // 16) * ((st.H + 15) // 16)
+            if cap is None:
+                d_host = readback.wait()
                 for v, st in enumerate(states):
-                    out = L.GsrOutputs(colors[v].data_ptr(), allmaps[v].data_ptr(), _ptr(radii[v]))
-                    L.check(lib.gsr_render_forward(C.byref(structs[v]), C.byref(inp), C.byref(st.geom), C.byref(st.bin),
-                                                   C.byref(st.img), st.D, C.byref(out), stream), "gsr_render_forward")
-                    view_loss(v, stream)
+                    _R._carve_binning(lib, st, d_host[v], tiles_of(st))
+            else:
+                for st in states:
+                    _R._carve_binning(lib, st, cap, tiles_of(st), d_dev=st.geom.num_rendered)
+
+            def chain(v, fs):
+                st, sv = states[v], C.c_void_p(fs.cuda_stream)
+                L.check(lib.gdr_binning_forward(C.byref(structs[v]), N, C.byref(st.geom), C.byref(st.bin), C.byref(st.img),
+                                                st.D, _ptr(radii[v]), sv), "gdr_binning_forward")
+                out = L.GsrOutputs(colors[v].data_ptr(), allmaps[v].data_ptr(), _ptr(radii[v]))
+                L.check(lib.gsr_composite_forward(C.byref(structs[v]), C.byref(st.geom), C.byref(st.bin), C.byref(st.img),
+                                                  C.byref(out), sv), "gsr_composite_forward")
+                view_loss(v, sv)
+
+            for v in range(V):
+                chain(v, fstreams[v % nfs])
+            for fs in fstreams[1:]:
+                done = torch.cuda.Event()
+                done.record(fs)
+                main.wait_event(done)
+            if cap is not None:
+                d_host = readback.wait()
+                for v in [v for v in range(V) if d_host[v] > cap]:   # the capacity guess was too small: repeat the view
+                    _R._carve_binning(lib, states[v], d_host[v], tiles_of(states[v]))
+                    if loss_spec is not None:
+                        loss_spec[-1][v:v + 1].zero_()
+                    chain(v, main)
+                for v, st in enumerate(states):
+                    st.D = d_host[v]
+            _R._d_record(key, d_host)
         ctx.states, ctx.settings_list, ctx.radii, ctx.flags = states, settings_list, radii, int(flags)
         _R._save_inputs(ctx, keep)
         ctx.means2D_shape, ctx.in_dtypes, ctx.V = tuple(means2D.shape), in_dtypes, V

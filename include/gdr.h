@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define GDR_ABI_VERSION 9
+#define GDR_ABI_VERSION 10
 
 #define GDR_OK 0
 #define GDR_ERR_INVALID_ARG (-1)  /* NULL / inconsistent arguments                     */
@@ -155,6 +155,13 @@ typedef struct gdr_binning {
                           * background leaves most CUs with one workgroup walking a long list.  gdr_binning_carve sets
                           * GDR_DEFAULT_DEEP_MAX_BUSY; 0 = never. */
     int32_t reserved0;
+    const uint32_t* d_dev; /* NULL (gdr_binning_carve): the D passed to the binning entry points is the duplicate count,
+                          * read back from geom->num_rendered by the caller.  Non-NULL = a DEVICE-SIZED call: the binning
+                          * kernels read the count from this device word (geom->num_rendered) themselves and the D passed
+                          * to gdr_binning_carve / gdr_binning_forward* is only the CAPACITY the buffers were carved for —
+                          * the caller can enqueue binning + K6 behind K1 without waiting for K1, and compares the count
+                          * with the capacity afterwards.  A count above the capacity is clamped (nothing is written out
+                          * of bounds; the images are then incomplete and the view must be repeated with enough room). */
 } gdr_binning;
 
 /* Image state (upstream "imgBuffer"). */

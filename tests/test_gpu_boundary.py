@@ -193,3 +193,95 @@ def test_batched_binning_chain_gives_the_same_lists_and_images(group):
         for k in ("keys_sorted", "point_list", "ranges", "n_contrib"):
             assert torch.equal(t1[v][k], tg[v][k]), (v, k)
         assert torch.equal(c1[v], cg[v])
+
+
+@pytest.mark.parametrize("surfel", [False, True])
+def test_device_sized_binning_equals_the_read_back_and_an_overflow_repeats_the_view(surfel):
+    """rasterizer.DEFER_D: the first call of a shape reads the duplicate count back before binning (upstream's flow);
+    later calls bin with the count left on the device and buffers carved for a capacity; a capacity that turns out too
+    small repeats the view.  All three must give bit-identical lists, images and fused losses, and leave the exact
+    count in the state."""
+    from generativedensification_amd import rasterizer as R
+    from generativedensification_amd.camera import orbit_cameras
+    from generativedensification_amd.synthetic import make_scene, make_targets
+    dev = torch.device(DEV)
+    V, H, W, N = 3, 160, 208, 40_000
+    scene = make_scene(N, 23, sh_degree=1, sigma0=(0.01, 0.002), device=dev)
+    cams = orbit_cameras(V, W, H, device=dev)
+    targets = make_targets(V, H, W, 5).to(dev).permute(0, 3, 1, 2).contiguous()
+    if surfel:
+        from generativedensification_amd.renderer_2dgs import Renderer
+        key, key1 = ("surfel", N, H, W, V), ("surfel", N, H, W)      # (render_img = the single-view rasterizer)
+    else:
+        from generativedensification_amd.renderer import Renderer
+        key, key1 = (N, H, W, V), (N, H, W, 1)                        # (render_img = a one-view node)
+    sc = scene["scales"][:, :2].contiguous() if surfel else scene["scales"]
+    args = (scene["centers"], scene["shs"], scene["opacity"], sc, scene["rotations"], dev)
+    if surfel:
+        from generativedensification_amd.camera import build_rays
+        r = Renderer(sh_degree=1)
+        rays = [build_rays(torch.inverse(c.world_view_transform.T.cpu()), 0.75, 0.75, H, W).to(dev) for c in cams]
+        views = lambda: r.render_views(cams, rays, None, *args)
+        fused = lambda: r.render_views_loss(cams, rays, None, targets, *args)
+        single = lambda: r.render_img(cams[1], rays[1], *args)
+    else:
+        r = Renderer(sh_degree=1, white_background=True)
+        r.set_bg_color(torch.ones(3, device=dev))
+        views = lambda: r.render_views(cams, None, *args)
+        fused = lambda: r.render_views_loss(cams, None, targets, *args)
+        single = lambda: r.render_img(cams[1], None, *args)
+
+    def run(hint):
+        def prep():
+            if hint == "none":
+                R._D_HINT.clear()
+            elif hint == "small":       # capacity 4108 entries: every view overflows and is repeated
+                R._D_HINT[key], R._D_HINT[key1] = 10, 10
+        res = []
+        with torch.no_grad():
+            for fn in (views, fused, single):
+                prep()
+                res.append(fn())
+        torch.cuda.synchronize()
+        return [o["image"].clone() for o in res[0]], res[1].clone(), res[2]["image"].clone()
+
+    saved = dict(R._D_HINT)
+    try:
+        img0, loss0, one0 = run("none")                 # no history: read-back flow
+        views()
+        assert key in R._D_HINT and key1 in R._D_HINT and R._d_capacity(key) > R._D_HINT[key] > 0
+        img1, loss1, one1 = run("history")              # device-sized calls
+        img2, loss2, one2 = run("small")
+        assert R._D_HINT[key1] > 10      # (the last call of the run was the one-view node: its history is real again)
+        for imgs, losses, one in ((img1, loss1, one1), (img2, loss2, one2)):
+            assert all(torch.equal(a, b) for a, b in zip(imgs, img0)) and torch.equal(one, one0)
+            np.testing.assert_allclose(losses.cpu().numpy(), loss0.cpu().numpy(), rtol=2e-6)   # (atomic order)
+        # the state of a device-sized call holds the exact count and the same sorted lists
+        if not surfel:
+            sets = [Renderer(sh_degree=1).set_rasterizer(c, device=dev).raster_settings for c in cams]
+            res = []
+            for hint in (None, 10):
+                if hint is None:
+                    R._D_HINT.pop(key, None)
+                else:
+                    R._D_HINT[key] = hint
+                with torch.no_grad():
+                    states = R._forward_views_impl(scene["centers"], torch.empty(0, 4, device=dev), scene["shs"],
+                                                   scene["opacity"], scene["scales"], scene["rotations"], tuple(sets),
+                                                   R.RAW_ALL)[4]
+                torch.cuda.synchronize()
+                res.append([st.tensors() for st in states])
+            with torch.no_grad():   # and once more with a capacity that fits
+                states = R._forward_views_impl(scene["centers"], torch.empty(0, 4, device=dev), scene["shs"],
+                                               scene["opacity"], scene["scales"], scene["rotations"], tuple(sets),
+                                               R.RAW_ALL)[4]
+            assert all(st.bin.d_dev for st in states)
+            res.append([st.tensors() for st in states])
+            for other in res[1:]:
+                for a, b in zip(res[0], other):
+                    assert a["num_rendered"] == b["num_rendered"] > 0
+                    for k in ("keys_sorted", "point_list", "ranges", "n_contrib"):
+                        assert torch.equal(a[k], b[k]), k
+    finally:
+        R._D_HINT.clear()
+        R._D_HINT.update(saved)
