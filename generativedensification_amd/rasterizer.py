@@ -130,18 +130,15 @@ _FORCE_GLOBAL_SORT = False
 
 import os as _os
 
-# GDR_BIN_STREAM=n: number of side streams that carry the views of a multi-view node (binning, and with GDR_RENDER_SIDE
-# also K6 / K7), round-robin; 0 = everything on the caller's stream; unset = side_count() below.
-# GDR_RENDER_SIDE=1 (default): K6 of a view right behind its binning on the view's side stream, K7 of the views on the
-# side streams too (see _SideViews); 0 = K6 / K7 on the caller's stream, only the binning on the side streams.
-# Measured on MI355X (views/s; cube = uniform scene of the BASELINE workloads, shell = object in front of an empty
-# background, 13 % of the tiles busy):
-#   streams, K6/K7 placement     C4 cube  C4 shell  C2 cube  C3 cube  C3 shell  C5 cube  C5 shell
-#   4, caller's stream (before)    1076      349      2520     2043      632      1021      514
-#   4, side streams                1081      489      2573     2259     1021       992      651
-#   3, side streams                1107      516      2635     2599     1332      1000      684
-#   2, side streams                1120      532      2777     2528     1079      1020      731
-#   1, side stream                 1040      329      2462     1828      586       952      481
+# Streams of a multi-view node.  Forward: every view's chain binning -> K6 on one of FWD_STREAMS streams, the caller's
+# included (_forward_views_impl).  Backward: K7 of the views round-robin on side_count() side streams (_SideViews; 2 at
+# 800x800, 3 for smaller images; GDR_BIN_STREAM=n / GDR_BWD_STREAMS=n override, 0 = the caller's stream only).
+# GDR_RENDER_SIDE=0: everything on the caller's stream (bench.py's serial pass for per-kernel durations).
+# Measured on MI355X (views/s; K7 of the views on n side streams, one box, round 2):
+#   n   C4 cube  C4 shell  C3 cube  C3 shell  C2 cube  C2 shell  C5 cube  C5 shell
+#   0    1220      877      2724     2578      2877     2521      1009      948
+#   2    1237      929      2770     3113      2977     2641      1073     1029
+#   3    1220      925      2889     3062      2898     2717      1055     1023
 # Two concurrent views fill the CUs that one view's skewed tile lists and kernel tails leave idle; four evict each
 # other's records from L2 (one view's records + gradient records are 2 x 128 MB at 2 M Gaussians).
 RENDER_SIDE = int(_os.environ.get("GDR_RENDER_SIDE", "1"))
@@ -149,6 +146,8 @@ RENDER_SIDE = int(_os.environ.get("GDR_RENDER_SIDE", "1"))
 FWD_STREAMS = int(_os.environ.get("GDR_FWD_STREAMS", "4"))
 # views per binning chain of a multi-view node (gdr_binning_forward_views covers a group of views with every launch)
 BIN_GROUP = int(_os.environ.get("GDR_BIN_GROUP", "1"))
+# side streams of the backward (K7 of the views); unset = side_count()
+BWD_STREAMS = int(_os.environ["GDR_BWD_STREAMS"]) if _os.environ.get("GDR_BWD_STREAMS") else None
 _BIN_STREAM_ENV = _os.environ.get("GDR_BIN_STREAM")
 BIN_STREAM = None if _BIN_STREAM_ENV is None else max(0, int(_BIN_STREAM_ENV))
 
@@ -210,7 +209,7 @@ class _SideViews:
 
     def __init__(self, dev, n, H, W):
         self.main = torch.cuda.current_stream()
-        ns = side_count(H, W)
+        ns = side_count(H, W) if BWD_STREAMS is None else BWD_STREAMS
         self.side = _view_streams(dev, min(ns, n)) if RENDER_SIDE and ns > 0 and n > 1 else None
         if self.side:
             ready = torch.cuda.Event()
@@ -561,16 +560,22 @@ def _forward_views_impl(means3D, means2D, sh, opacities, scales, rotations, sett
                                                        float(w_alpha), losses[v:v + 1].data_ptr(), sv),
                         "gdr_composite_forward_loss")
 
-        def chain(lo, hi, fs):   # binning of views [lo, hi) in shared launches, then their K6, all on stream fs
+        def chain(lo, hi, fs):   # binning of views [lo, hi) in shared launches on stream fs, then their K6
             sp = C.c_void_p(fs.cuda_stream)
-            if hi - lo > 1:
-                binning_views(lib, s_arr, N, g_arr, states, radii, lo, hi, sp)
-            else:
+            if hi - lo == 1:
                 st = states[lo]
                 L.check(lib.gdr_binning_forward(C.byref(s_arr[lo]), N, C.byref(g_arr[lo]), C.byref(st.bin),
                                                 C.byref(st.img), st.D, _ptr(radii[lo]), sp), "gdr_binning_forward")
-            for v in range(lo, hi):
-                composite(v, sp)
+                composite(lo, sp)
+                return
+            binning_views(lib, s_arr, N, g_arr, states, radii, lo, hi, sp)
+            binned = torch.cuda.Event()
+            binned.record(fs)
+            for v in range(lo, hi):      # the group's K6 spread over the streams again
+                ks = fstreams[v % nfs] if fs in fstreams else fs
+                if ks is not fs:
+                    ks.wait_event(binned)
+                composite(v, C.c_void_p(ks.cuda_stream))
 
         grp = max(1, min(BIN_GROUP, L.GDR_MAX_VIEWS))
         for c, lo in enumerate(range(0, V, grp)):

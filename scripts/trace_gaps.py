@@ -11,6 +11,8 @@ if "--names" in sys.argv: print(sorted(set(e[2] for e in ev)))
 starts = [i for i, e in enumerate(ev) if "preprocess_fwd_views" in e[2] or "surfel_preprocess_fwd" in e[2]]
 if len(starts) > 4 and "surfel" in ev[starts[0]][2]:
     starts = starts[::4]
+if "--every" in sys.argv:   # per-view call pattern: a step = every K-th single-view K1
+    starts = [i for i, e in enumerate(ev) if "preprocess_fwd" in e[2]][::int(sys.argv[sys.argv.index("--every") + 1])]
 print("kernels", len(ev), "steps", len(starts))
 for si in range(1, len(starts) - 1):
     seg = ev[starts[si]:starts[si + 1]]
