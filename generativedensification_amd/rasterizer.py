@@ -146,6 +146,11 @@ RENDER_SIDE = int(_os.environ.get("GDR_RENDER_SIDE", "1"))
 FWD_STREAMS = int(_os.environ.get("GDR_FWD_STREAMS", "4"))
 # views per binning chain of a multi-view node (gdr_binning_forward_views covers a group of views with every launch)
 BIN_GROUP = int(_os.environ.get("GDR_BIN_GROUP", "1"))
+# views per K9 launch of a multi-view node's backward.  Smaller groups let the K9 of a group (HBM-bound) run under the
+# next group's K7 (VALU-bound) on a stream of its own (_SideViews) — measured on MI355X and NOT the default: every K9
+# launch re-reads the inputs and read-modify-writes the gradients, and K7's gathers lose bandwidth to it
+# (views/s, groups of 8 / 2 / 1: C4 1234 / 1112 / 916, C3 2918 / 2865 / 2825, C2 2957 / 2879 / 2764, C5 1067 / 1056 / 1010).
+BWD_GROUP = int(_os.environ.get("GDR_BWD_GROUP", str(L.GDR_MAX_VIEWS)))
 # side streams of the backward (K7 of the views); unset = side_count()
 BWD_STREAMS = int(_os.environ["GDR_BWD_STREAMS"]) if _os.environ.get("GDR_BWD_STREAMS") else None
 _BIN_STREAM_ENV = _os.environ.get("GDR_BIN_STREAM")
@@ -201,30 +206,66 @@ def _stream():
 
 
 class _SideViews:
-    """Per-view render launches (K6 / K7 of the views of one node) round-robin on the side streams, joined back
-    into the caller's stream.  The views are independent; one view's kernel leaves CUs idle whenever its tile
-    lists are skewed (an object in front of an empty background: a few hundred busy tiles for 256 CUs) and at
-    its tail, and another view's workgroups fill them.  Off (everything on the caller's stream) when
-    GDR_RENDER_SIDE=0 or for a single view."""
+    """Streams of the backward of a multi-view node.  K7 of the views runs round-robin on side streams: the views are
+    independent, one view's kernel leaves CUs idle whenever its tile lists are skewed (an object in front of an empty
+    background: a few hundred busy tiles for 256 CUs) and at its tail, and another view's workgroups fill them.  K9 (one
+    launch per group of BWD_GROUP views, summing their records into the per-Gaussian gradients; every launch after the
+    first accumulates) follows its group's K7; with more than one group it goes onto a stream of its own, so that a
+    group's K9 can run under the next group's K7 (see BWD_GROUP for what that measured).
+    Everything on the caller's stream when GDR_RENDER_SIDE=0 or for a single view.
+
+        sides = _SideViews(dev, V, H, W)      # after all torch-side preparation: the side streams wait for this point
+        for lo, n in sides.groups():
+            ... K7 of views lo .. lo+n-1 on sides.stream(v) ...
+            ... K9 of the group on sides.k9_stream(lo, n), accumulate = lo > 0 ...
+        sides.join()
+    """
 
     def __init__(self, dev, n, H, W):
         self.main = torch.cuda.current_stream()
+        self.n = n
         ns = side_count(H, W) if BWD_STREAMS is None else BWD_STREAMS
-        self.side = _view_streams(dev, min(ns, n)) if RENDER_SIDE and ns > 0 and n > 1 else None
+        self.group = max(1, min(BWD_GROUP, L.GDR_MAX_VIEWS))
+        on = bool(RENDER_SIDE and ns > 0 and n > 1)
+        self.pipelined = on and n > self.group
+        if self.pipelined:      # caller's + 2 x K7 + K9 = the four hardware queues of a process
+            pool = _view_streams(dev, 3)
+            self.side, self.k9 = pool[:min(ns, 2)], pool[2]
+        else:
+            self.side, self.k9 = (_view_streams(dev, min(ns, n)) if on else None), None
         if self.side:
             ready = torch.cuda.Event()
             ready.record(self.main)
-            for sd in self.side:
+            for sd in self.side + ([self.k9] if self.k9 is not None else []):
                 sd.wait_event(ready)
+
+    def groups(self):
+        """(first view, views) of every K9 launch."""
+        step = self.group if self.pipelined else L.GDR_MAX_VIEWS
+        return [(lo, min(step, self.n - lo)) for lo in range(0, self.n, step)]
+
+    def _side_of(self, k):
+        return self.side[k % len(self.side)]
 
     def stream(self, k):
         if self.side:
-            return C.c_void_p(self.side[k % len(self.side)].cuda_stream)
+            return C.c_void_p(self._side_of(k).cuda_stream)
         return C.c_void_p(self.main.cuda_stream)
+
+    def k9_stream(self, lo, n):
+        """The stream for K9 of views [lo, lo+n), made to wait for their K7."""
+        if not self.side:
+            return C.c_void_p(self.main.cuda_stream)
+        target = self.k9 if self.pipelined else self.main
+        for sd in {self._side_of(k) for k in range(lo, lo + n)}:
+            done = torch.cuda.Event()
+            done.record(sd)
+            target.wait_event(done)
+        return C.c_void_p(target.cuda_stream)
 
     def join(self):
         if self.side:
-            for sd in self.side:
+            for sd in self.side + ([self.k9] if self.k9 is not None else []):
                 done = torch.cuda.Event()
                 done.record(sd)
                 self.main.wait_event(done)
@@ -625,42 +666,40 @@ class _RenderViews(torch.autograd.Function):
             keep2: list = []
             stream = _stream()
             inp = _inputs_struct(N, M, means3D, opacities, sh, e, scales, rotations, e, ctx.flags)
-            for lo in range(0, V, L.GDR_MAX_VIEWS):
-                n = min(L.GDR_MAX_VIEWS, V - lo)
+            grads_in = []
+            for v in range(V):  # torch-side preparation stays on the caller's stream
+                gc = (_f32(g_colors[v], dev) if g_colors[v] is not None
+                      else torch.zeros(3, H, W, dtype=torch.float32, device=dev))
+                gd = None if g_depths[v] is None else _f32(g_depths[v], dev)
+                ga = None if g_alphas[v] is None else _f32(g_alphas[v], dev)
+                keep2 += [gc, gd, ga]
+                grads_in.append((gc, gd, ga))
+            sets = [_settings_struct(rs, dev, keep2) for rs in ctx.settings_list]
+            sides = _SideViews(dev, V, H, W)  # after every torch-side preparation (the side streams wait for this point)
+            for lo, n in sides.groups():
                 recs = torch.empty(n, max(N, 1) * 16, **f32)  # one 64-byte gradient record per Gaussian per view
-                s_arr = (L.GdrSettings * n)()
+                s_arr = (L.GdrSettings * n)(*sets[lo:lo + n])
                 g_arr = (L.GdrGeom * n)()
-                grads_in = []
-                for k in range(n):  # torch-side preparation stays on the caller's stream
-                    v = lo + k
-                    gc = (_f32(g_colors[v], dev) if g_colors[v] is not None
-                          else torch.zeros(3, H, W, dtype=torch.float32, device=dev))
-                    gd = None if g_depths[v] is None else _f32(g_depths[v], dev)
-                    ga = None if g_alphas[v] is None else _f32(g_alphas[v], dev)
-                    keep2 += [gc, gd, ga]
-                    grads_in.append((gc, gd, ga))
-                for k in range(n):
-                    s_arr[k] = _settings_struct(ctx.settings_list[lo + k], dev, keep2)
-                sides = _SideViews(dev, n, states[0].H, states[0].W)  # after every torch-side preparation (the side streams wait for this point)
                 for k in range(n):
                     v = lo + k
                     st = states[v]
                     g_arr[k] = st.geom
                     g_arr[k].cov3D = states[0].geom.cov3D
-                    gc, gd, ga = grads_in[k]
+                    gc, gd, ga = grads_in[v]
                     gin = L.GdrGradInputs(gc.data_ptr(), _ptr(gd), _ptr(ga))
                     L.check(lib.gdr_render_backward(C.byref(s_arr[k]), N, C.byref(g_arr[k]), C.byref(st.bin),
-                                                    C.byref(st.img), C.byref(gin), recs[k].data_ptr(), sides.stream(k)),
+                                                    C.byref(st.img), C.byref(gin), recs[k].data_ptr(), sides.stream(v)),
                             "gdr_render_backward")
-                sides.join()
                 r_arr = (C.c_void_p * n)(*[ctx.radii[lo + k].data_ptr() if N else None for k in range(n)])
                 rec_arr = (C.c_void_p * n)(*[recs[k].data_ptr() for k in range(n)])
                 gout = L.GdrGradOutputs(_ptr(g["means3D"]), _ptr(g["means2D"]), _ptr(g["shs"]), None,
                                         _ptr(g["opacities"]), _ptr(g["scales"]), _ptr(g["rotations"]), None, None,
                                         1 if lo > 0 else 0, 0)
                 L.check(lib.gdr_preprocess_backward_views(n, s_arr, C.byref(inp), g_arr, r_arr, rec_arr,
-                                                          C.byref(gout), stream), "gdr_preprocess_backward_views")
+                                                          C.byref(gout), sides.k9_stream(lo, n)),
+                        "gdr_preprocess_backward_views")
                 keep2.append(recs)
+            sides.join()
         gm2 = g["means2D"]
         cols = ctx.means2D_shape[1] if len(ctx.means2D_shape) == 2 else 4
         if cols == 3:
@@ -709,33 +748,31 @@ class _RenderViewsLoss(torch.autograd.Function):
             keep2: list = []
             stream = _stream()
             inp = _inputs_struct(N, M, means3D, opacities, sh, e, scales, rotations, e, ctx.flags)
-            for lo in range(0, V, L.GDR_MAX_VIEWS):
-                n = min(L.GDR_MAX_VIEWS, V - lo)
+            sets = [_settings_struct(rs, dev, keep2) for rs in ctx.settings_list]
+            sides = _SideViews(dev, V, states[0].H, states[0].W)  # after every torch-side preparation (the side streams wait for this point)
+            for lo, n in sides.groups():
                 recs = torch.empty(n, max(N, 1) * 16, **f32)
-                s_arr = (L.GdrSettings * n)()
+                s_arr = (L.GdrSettings * n)(*sets[lo:lo + n])
                 g_arr = (L.GdrGeom * n)()
-                for k in range(n):
-                    s_arr[k] = _settings_struct(ctx.settings_list[lo + k], dev, keep2)
-                sides = _SideViews(dev, n, states[0].H, states[0].W)  # after every torch-side preparation (the side streams wait for this point)
                 for k in range(n):
                     v = lo + k
                     st = states[v]
                     g_arr[k] = st.geom
                     g_arr[k].cov3D = states[0].geom.cov3D
-                    sv = sides.stream(k)
                     L.check(lib.gdr_render_backward_loss(C.byref(s_arr[k]), N, C.byref(g_arr[k]), C.byref(st.bin),
                                                          C.byref(st.img), ctx.colors[v].data_ptr(), ctx.targets[v].data_ptr(),
                                                          ctx.w[0], ctx.w[1], go[v:v + 1].data_ptr(), recs[k].data_ptr(),
-                                                         sv), "gdr_render_backward_loss")
-                sides.join()
+                                                         sides.stream(v)), "gdr_render_backward_loss")
                 r_arr = (C.c_void_p * n)(*[ctx.radii[lo + k].data_ptr() if N else None for k in range(n)])
                 rec_arr = (C.c_void_p * n)(*[recs[k].data_ptr() for k in range(n)])
                 gout = L.GdrGradOutputs(_ptr(g["means3D"]), _ptr(g["means2D"]), _ptr(g["shs"]), None,
                                         _ptr(g["opacities"]), _ptr(g["scales"]), _ptr(g["rotations"]), None, None,
                                         1 if lo > 0 else 0, 0)
                 L.check(lib.gdr_preprocess_backward_views(n, s_arr, C.byref(inp), g_arr, r_arr, rec_arr,
-                                                          C.byref(gout), stream), "gdr_preprocess_backward_views")
+                                                          C.byref(gout), sides.k9_stream(lo, n)),
+                        "gdr_preprocess_backward_views")
                 keep2.append(recs)
+            sides.join()
         gm2 = g["means2D"]
         cols = ctx.means2D_shape[1] if len(ctx.means2D_shape) == 2 else 4
         if cols == 3:

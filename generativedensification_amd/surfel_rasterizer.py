@@ -343,35 +343,33 @@ class _RenderSurfelViews(torch.autograd.Function):
                 stream = _stream()
                 keep2: list = []
                 inp = _inputs_struct(N, M, means3D, opacities, sh, e, scales, rotations, e, flags)
-                for lo in range(0, V, L.GDR_MAX_VIEWS):
-                    n = min(L.GDR_MAX_VIEWS, V - lo)
+                sets, gins = [], []
+                for v in range(V):  # torch-side preparation on the caller's stream first
+                    sets.append(_settings_struct(ctx.settings_list[v], dev, keep2))
+                    gc = _f32(g[v], dev)
+                    ga = None if g[V + v] is None else _f32(g[V + v], dev)
+                    keep2 += [gc, ga]
+                    gins.append(L.GsrGradInputs(gc.data_ptr(), _ptr(ga)))
+                sides = _R._SideViews(dev, V, ctx.states[0].H, ctx.states[0].W)
+                for lo, n in sides.groups():   # K7s per view, K9s per group behind its views' K7s (rasterizer._SideViews)
                     recs = torch.empty(n, max(N, 1) * L.GSR_GRAD_FLOATS, **f32)
-                    s_arr = (L.GdrSettings * n)()
+                    s_arr = (L.GdrSettings * n)(*sets[lo:lo + n])
                     g_arr = (L.GdrGeom * n)()
-                    gins = []
-                    for k in range(n):  # torch-side preparation on the caller's stream first
-                        v = lo + k
-                        s_arr[k] = _settings_struct(ctx.settings_list[v], dev, keep2)
-                        gc = _f32(g[v], dev)
-                        ga = None if g[V + v] is None else _f32(g[V + v], dev)
-                        keep2 += [gc, ga]
-                        gins.append(L.GsrGradInputs(gc.data_ptr(), _ptr(ga)))
-                    sides = _R._SideViews(dev, n, ctx.states[0].H, ctx.states[0].W)
                     for k in range(n):
                         st = ctx.states[lo + k]
                         g_arr[k] = st.geom
                         L.check(lib.gsr_render_backward(C.byref(s_arr[k]), N, C.byref(g_arr[k]), C.byref(st.bin),
-                                                        C.byref(st.img), C.byref(gins[k]), recs[k].data_ptr(),
-                                                        sides.stream(k)), "gsr_render_backward")
-                    sides.join()
+                                                        C.byref(st.img), C.byref(gins[lo + k]), recs[k].data_ptr(),
+                                                        sides.stream(lo + k)), "gsr_render_backward")
                     r_arr = (C.c_void_p * n)(*[ctx.radii[lo + k].data_ptr() if N else None for k in range(n)])
                     rec_arr = (C.c_void_p * n)(*[recs[k].data_ptr() for k in range(n)])
                     gout = L.GsrGradOutputs(_ptr(out["means3D"]), _ptr(out["means2D"]), _ptr(out["shs"]), None,
                                             _ptr(out["opacities"]), _ptr(out["scales"]), _ptr(out["rotations"]), None, None,
                                             1 if lo > 0 else 0, 0)
                     L.check(lib.gsr_preprocess_backward_views(n, s_arr, C.byref(inp), g_arr, r_arr, rec_arr, C.byref(gout),
-                                                              stream), "gsr_preprocess_backward_views")
+                                                              sides.k9_stream(lo, n)), "gsr_preprocess_backward_views")
                     keep2.append(recs)
+                sides.join()
             first = False
         scratch = torch.empty(max(N, 1) * L.GSR_GRAD_FLOATS, **f32) if not fused else None
         with torch.cuda.device(dev):
@@ -449,22 +447,20 @@ class _RenderSurfelViewsLoss(torch.autograd.Function):
             stream = _stream()
             keep2: list = []
             inp = _inputs_struct(N, M, means3D, opacities, sh, e, scales, rotations, e, flags)
-            for lo in range(0, V, L.GDR_MAX_VIEWS):
-                n = min(L.GDR_MAX_VIEWS, V - lo)
+            sets = [_settings_struct(rs, dev, keep2) for rs in ctx.settings_list]
+            sides = _R._SideViews(dev, V, H, W)  # after every torch-side preparation
+            for lo, n in sides.groups():
                 recs = torch.empty(n, max(N, 1) * L.GSR_GRAD_FLOATS, **f32)
                 dcs = [torch.empty(3, H, W, **f32) for _ in range(n)]
                 das = [torch.empty(7, H, W, **f32) for _ in range(n)]
                 scr = [torch.empty(9, H, W, **f32) for _ in range(n)]
-                s_arr = (L.GdrSettings * n)()
+                s_arr = (L.GdrSettings * n)(*sets[lo:lo + n])
                 g_arr = (L.GdrGeom * n)()
-                for k in range(n):
-                    s_arr[k] = _settings_struct(ctx.settings_list[lo + k], dev, keep2)
-                sides = _R._SideViews(dev, n, H, W)  # after every torch-side preparation
                 for k in range(n):
                     v = lo + k
                     st = ctx.states[v]
                     g_arr[k] = st.geom
-                    sv = sides.stream(k)
+                    sv = sides.stream(v)
                     L.check(lib.gsr_view_loss_backward(colors[v].data_ptr(), allmaps[v].data_ptr(), rays[v].data_ptr(),
                                                        views[v].data_ptr(), targets[v].data_ptr(), H, W, *wts,
                                                        go[v:v + 1].data_ptr(), scr[k].data_ptr(), dcs[k].data_ptr(),
@@ -473,15 +469,15 @@ class _RenderSurfelViewsLoss(torch.autograd.Function):
                     L.check(lib.gsr_render_backward(C.byref(s_arr[k]), N, C.byref(g_arr[k]), C.byref(st.bin),
                                                     C.byref(st.img), C.byref(gin), recs[k].data_ptr(), sv),
                             "gsr_render_backward")
-                sides.join()
                 r_arr = (C.c_void_p * n)(*[ctx.radii[lo + k].data_ptr() if N else None for k in range(n)])
                 rec_arr = (C.c_void_p * n)(*[recs[k].data_ptr() for k in range(n)])
                 gout = L.GsrGradOutputs(_ptr(out["means3D"]), _ptr(out["means2D"]), _ptr(out["shs"]), None,
                                         _ptr(out["opacities"]), _ptr(out["scales"]), _ptr(out["rotations"]), None, None,
                                         1 if lo > 0 else 0, 0)
                 L.check(lib.gsr_preprocess_backward_views(n, s_arr, C.byref(inp), g_arr, r_arr, rec_arr, C.byref(gout),
-                                                          stream), "gsr_preprocess_backward_views")
+                                                          sides.k9_stream(lo, n)), "gsr_preprocess_backward_views")
                 keep2 += [recs, dcs, das, scr]
+            sides.join()
         gm2 = out["means2D"]
         cols = ctx.means2D_shape[1] if len(ctx.means2D_shape) == 2 else 4
         if cols == 3:

@@ -1,6 +1,8 @@
 #!/bin/bash
-O=gpurun_out/q; mkdir -p $O; R=$(pwd)
-wl=c4
-(cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv -d $R/$O/trace_pv -o t -- python $R/bench.py --workload $wl --per-view --unfused --steps 4 --warmup 2 --no-cpu-baseline --no-roofline > $R/$O/trace_pv.log 2>&1)
-f=$(find $O/trace_pv -name "*kernel_trace.csv" | head -1); python scripts/trace_gaps.py $f --every 4 --timeline > $O/timeline_pv.txt; rm -rf $O/trace_pv
-timeout 300 python bench.py --workload c4 --per-view --unfused --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --host-profile 2> $O/host_pv.txt >/dev/null
+run() { timeout 300 python bench.py "$@" --steps 40 --warmup 5 --no-cpu-baseline --no-roofline 2>/dev/null | python -c "import sys,json; o=json.loads(sys.stdin.read()); print(o['value'], o['ms_per_step'])"; }
+timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_boundary.py tests/test_gpu_surfel.py tests/test_gpu_multirank.py -x -q 2>&1 | tail -3
+for wl in c4 c3 c2 c5; do
+  for b in 8 2 1; do
+    echo "== $wl BWD_GROUP=$b"; GDR_BWD_GROUP=$b run --workload $wl; GDR_BWD_GROUP=$b run --workload $wl --layout shell
+  done
+done
