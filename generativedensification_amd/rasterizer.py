@@ -227,7 +227,7 @@ class _SideViews:
         ns = side_count(H, W) if BWD_STREAMS is None else BWD_STREAMS
         self.group = max(1, min(BWD_GROUP, L.GDR_MAX_VIEWS))
         on = bool(RENDER_SIDE and ns > 0 and n > 1)
-        self.pipelined = on and n > self.group
+        self.pipelined = on and n > self.group and self.group < L.GDR_MAX_VIEWS   # (off by default: see BWD_GROUP)
         if self.pipelined:      # caller's + 2 x K7 + K9 = the four hardware queues of a process
             pool = _view_streams(dev, 3)
             self.side, self.k9 = pool[:min(ns, 2)], pool[2]
