@@ -17,6 +17,7 @@ path: non-HIP tensors raise.
 from __future__ import annotations
 
 import ctypes as C
+import os as _os
 from typing import NamedTuple, Optional
 
 import torch
@@ -116,7 +117,7 @@ def _settings_struct(rs: GaussianRasterizationSettings, dev, keep: list) -> L.Gd
 # Parity-risk switch R1 (include/gdr.h GDR_IN_NO_DEPTH_TO_MEAN): True (default) = dL/d(depth image) also
 # moves the Gaussian centres (depth_i = view-space z of the centre); False = it does not.  GDR_DEPTH_TO_MEAN=0 or
 # rasterizer.DEPTH_TO_MEAN = False.
-DEPTH_TO_MEAN = __import__("os").environ.get("GDR_DEPTH_TO_MEAN", "1") != "0"
+DEPTH_TO_MEAN = _os.environ.get("GDR_DEPTH_TO_MEAN", "1") != "0"
 
 
 def _inputs_struct(N, M, means3D, opacities, sh, colors_precomp, scales, rotations, cov3Ds, flags=0) -> L.GdrInputs:
@@ -127,8 +128,6 @@ def _inputs_struct(N, M, means3D, opacities, sh, colors_precomp, scales, rotatio
 
 # test / A-B hook: one global radix sort instead of tile partition + per-tile LDS sort
 _FORCE_GLOBAL_SORT = False
-
-import os as _os
 
 # Streams of a multi-view node.  Forward: every view's chain binning -> K6 on one of FWD_STREAMS streams, the caller's
 # included (_forward_views_impl).  Backward: K7 of the views round-robin on side_count() side streams (_SideViews; 2 at
@@ -198,7 +197,6 @@ def _view_streams(dev, n):
     while len(pool) < n:
         pool.append(torch.cuda.Stream(device=dev))
     return pool[:n]
-
 
 
 def _stream():
