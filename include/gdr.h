@@ -290,8 +290,10 @@ int gdr_backward(const gdr_settings* s, const gdr_inputs* in, const gdr_geom* ge
  * V per-view partial gradients in registers before writing each output once.
  * s, geoms: arrays of V structs; radii, grad_recs: arrays of V device pointers (host arrays).
  * Requires in->shs, in->scales, in->rotations (no colors_precomp / cov3D_precomp).
- * Sequence: gdr_preprocess_forward_views; read the V values geoms[v].num_rendered;
- *           per view gdr_render_forward; ...; per view gdr_render_backward (K7 into its own
+ * Sequence: gdr_preprocess_forward_views; read the V values geoms[v].num_rendered (or, for
+ *           device-sized calls — gdr_binning.d_dev — only start copying them to the host);
+ *           per view gdr_render_forward; (device-sized: compare counts and capacities, repeat
+ *           the views that did not fit); ...; per view gdr_render_backward (K7 into its own
  *           N*16-float record); gdr_preprocess_backward_views. */
 #define GDR_MAX_VIEWS 8
 int gdr_preprocess_forward_views(int32_t V, const gdr_settings* s, const gdr_inputs* in,
