@@ -245,7 +245,8 @@ def test_device_sized_binning_equals_the_read_back_and_an_overflow_repeats_the_v
         torch.cuda.synchronize()
         return [o["image"].clone() for o in res[0]], res[1].clone(), res[2]["image"].clone()
 
-    saved = dict(R._D_HINT)
+    saved, saved_defer = dict(R._D_HINT), R.DEFER_D
+    R.DEFER_D = True
     try:
         img0, loss0, one0 = run("none")                 # no history: read-back flow
         views()
@@ -283,6 +284,7 @@ def test_device_sized_binning_equals_the_read_back_and_an_overflow_repeats_the_v
                     for k in ("keys_sorted", "point_list", "ranges", "n_contrib"):
                         assert torch.equal(a[k], b[k]), k
     finally:
+        R.DEFER_D = saved_defer
         R._D_HINT.clear()
         R._D_HINT.update(saved)
 
