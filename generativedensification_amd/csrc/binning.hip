@@ -288,9 +288,10 @@ __global__ __launch_bounds__(GDR_BLOCK) void ranges_kernel(const BinViews vs, in
 // by its workgroup with the same code on the global ping-pong buffers.
 // =================================================================================
 // three size classes so that LDS footprint (= workgroups per CU) follows the list length:
-//   short  (L <= 2048): 36 KiB, 4 waves, 4 workgroups per CU, one workgroup per tile;
-//   medium (L <= 4096): 68 KiB, 8 waves, 2 per CU   } small grids that walk the tiles longest-first
-//   long   (L <= 8192 in LDS, beyond that on the global ping-pong buffers): 132 KiB, 16 waves, 1 per CU }
+//   short  (L <= 2048): 20 KiB, 4 waves, one workgroup per tile;
+//   medium (L <= 4096): 40 KiB, 8 waves   } small grids that walk the tiles longest-first
+//   long   (L <= 8192 in LDS, beyond that on the global ping-pong buffers): 80 KiB, 16 waves }
+// (lists are sorted IN PLACE in LDS, tile_sort_pass_lds: 8 bytes per entry)
 #define GDR_TSORT_SMALL 2048
 #define GDR_TSORT_MEDIUM 4096
 #define GDR_TSORT_LARGE 8192
@@ -358,6 +359,70 @@ __device__ __forceinline__ void tile_sort_pass(const TileSortBufs& b, uint32_t L
     __syncthreads();  // (global-memory variant: also the workgroup-scope release/acquire of the stores)
 }
 
+// The same stable 8-bit pass IN PLACE on an LDS-resident list (kA, vA; kA == vA allowed: ids sorted by themselves):
+// every lane first takes the <= EPT elements of its wave's chunk it is responsible for into registers, so that after
+// the counting barrier nobody reads the list any more and the ranked elements can be written straight back — no second
+// buffer: 8 bytes of LDS per entry instead of 16, twice the workgroups per CU (the binning chains of a multi-view node run
+// next to other views' K6, which leaves ~50 KB of LDS per CU).  L <= NW * 64 * EPT.
+template <int NW, int EPT>
+__device__ __forceinline__ void tile_sort_pass_lds(uint32_t* kA, uint32_t* vA, uint32_t L, uint32_t kmin, int shift,
+                                                   uint32_t (*cnt)[GDR_RADIX], uint32_t* scan_lds) {
+    const uint32_t w = threadIdx.x >> 6, lane = lane_id();
+    const uint32_t Lw = ((L + NW * GDR_WAVE - 1) / (NW * GDR_WAVE)) * GDR_WAVE;
+    const uint32_t c0 = min(L, w * Lw), c1 = min(L, c0 + Lw);
+    for (int k = threadIdx.x; k < NW * GDR_RADIX; k += NW * GDR_WAVE) (&cnt[0][0])[k] = 0;
+    __syncthreads();
+    uint32_t key[EPT], val[EPT];
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) {
+        const uint32_t i = c0 + (uint32_t)j * GDR_WAVE + lane;
+        const bool valid = i < c1;
+        key[j] = valid ? kA[i] : 0u;
+        val[j] = valid ? vA[i] : 0u;
+        if (valid) atomicAdd(&cnt[w][((key[j] - kmin) >> shift) & (GDR_RADIX - 1)], 1u);
+    }
+    __syncthreads();
+    {   // the first 256 threads own one digit each: per-wave offsets + exclusive scan of the digit totals
+        const uint32_t d = threadIdx.x & (GDR_RADIX - 1);
+        const bool owner = threadIdx.x < GDR_RADIX;
+        uint32_t tot = 0;
+        if (owner)
+            for (int k = 0; k < NW; ++k) tot += cnt[k][d];
+        const uint32_t incl = wave_incl_scan(owner ? tot : 0u);
+        if (owner && lane == 63) scan_lds[w] = incl;
+        __syncthreads();
+        if (owner) {
+            uint32_t base = incl - tot;
+            for (uint32_t k = 0; k < w; ++k) base += scan_lds[k];
+            for (int k = 0; k < NW; ++k) { const uint32_t c = cnt[k][d]; cnt[k][d] = base; base += c; }
+        }
+    }
+    __syncthreads();   // (every element of the list is in a register by now: the writes below overwrite nothing unread)
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) {
+        const uint32_t i0 = c0 + (uint32_t)j * GDR_WAVE;
+        if (i0 >= c1) break;   // uniform over the wave
+        const bool valid = i0 + lane < c1;
+        const uint32_t d = ((key[j] - kmin) >> shift) & (GDR_RADIX - 1);
+        uint64_t m = __ballot(valid);
+#pragma unroll
+        for (int bit = 0; bit < GDR_RADIX_BITS; ++bit) {
+            const uint64_t bal = __ballot((d >> bit) & 1u);
+            m &= ((d >> bit) & 1u) ? bal : ~bal;
+        }
+        uint32_t prior = 0;
+        if (valid) prior = cnt[w][d];
+        const uint32_t below = (uint32_t)__popcll(m & lanemask_lt());
+        if (valid) {
+            kA[prior + below] = key[j];
+            vA[prior + below] = val[j];
+            if ((m >> lane) == 1ull) cnt[w][d] = prior + below + 1u;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+}
+
 // ties on identical depth bits: ascending Gaussian id — the order the reference's stable sort of
 // (Gaussian-ordered) emission leaves them in; our emission order is arbitrary (block_offs).
 // Runs of up to GDR_TIE_SERIAL equal keys are insertion-sorted by the thread that finds their head; longer runs
@@ -365,7 +430,8 @@ __device__ __forceinline__ void tile_sort_pass(const TileSortBufs& b, uint32_t L
 // workgroup with four stable 8-bit passes on the ids, vA -> vB -> vA -> vB -> vA.  runs: 2*GDR_TIE_RUNS+1 LDS words.
 #define GDR_TIE_SERIAL 96
 #define GDR_TIE_RUNS 96
-template <int NW>
+// EPT > 0: the list is LDS-resident, long runs are sorted in place (tile_sort_pass_lds), vB is not used.
+template <int NW, int EPT = 0>
 __device__ __forceinline__ void tile_sort_ties(const uint32_t* kA, uint32_t* vA, uint32_t* vB, uint32_t L,
                                                uint32_t (*cnt)[GDR_RADIX], uint32_t* scan_lds, uint32_t* runs) {
     constexpr uint32_t NT = NW * GDR_WAVE;
@@ -391,6 +457,11 @@ __device__ __forceinline__ void tile_sort_ties(const uint32_t* kA, uint32_t* vA,
     const uint32_t nruns = min(runs[2 * GDR_TIE_RUNS], (uint32_t)GDR_TIE_RUNS);
     for (uint32_t r = 0; r < nruns; ++r) {  // uniform over the workgroup
         const uint32_t i0 = runs[2 * r], Lr = runs[2 * r + 1];
+        if constexpr (EPT > 0) {
+            for (int shift = 0; shift < 32; shift += GDR_RADIX_BITS)
+                tile_sort_pass_lds<NW, EPT>(vA + i0, vA + i0, Lr, 0u, shift, cnt, scan_lds);
+            continue;
+        }
         TileSortBufs t;
         t.kA = t.vA = vA + i0;
         t.kB = t.vB = vB + i0;
@@ -421,7 +492,7 @@ __global__ __launch_bounds__(NW * GDR_WAVE) void tile_sort_kernel(const BinViews
     const uint32_t* __restrict__ tile_order = bv.tile_order;
     if (view_D(bv) == 0) return;
     constexpr uint32_t NT = NW * GDR_WAVE;
-    __shared__ uint32_t lds_elems[4 * CAP];
+    __shared__ uint32_t lds_elems[2 * CAP];   // (depth key, id) of a list of <= CAP entries, sorted in place
     __shared__ uint32_t cnt[NW][GDR_RADIX];
     __shared__ uint32_t misc[8];
     __shared__ uint32_t mm[2 * NW];
@@ -445,29 +516,26 @@ __global__ __launch_bounds__(NW * GDR_WAVE) void tile_sort_kernel(const BinViews
     auto sort_in_lds = [&](auto key_at, const uint32_t* vsrc, uint32_t tile, uint32_t o, uint32_t Lc)
                            __attribute__((always_inline)) {
         __syncthreads();  // LDS reuse
-        TileSortBufs b;
-        b.kA = lds_elems; b.vA = lds_elems + CAP;
-        b.kB = lds_elems + 2 * CAP; b.vB = lds_elems + 3 * CAP;
+        constexpr int EPT = CAP / (int)NT;
+        uint32_t* const kA = lds_elems;
+        uint32_t* const vA = lds_elems + CAP;
         uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
         for (uint32_t i = threadIdx.x; i < Lc; i += NT) {
             const uint32_t k = key_at(i);
-            b.kA[i] = k;
-            b.vA[i] = vsrc[i];
+            kA[i] = k;
+            vA[i] = vsrc[i];
             kmin = min(kmin, k);
             kmax = max(kmax, k);
         }
         min_max(kmin, kmax);
         const uint32_t span = kmax - kmin;
         const int nbits = span ? 32 - __builtin_clz(span) : 0;
-        for (int shift = 0; shift < nbits; shift += GDR_RADIX_BITS) {
-            tile_sort_pass<NW>(b, Lc, kmin, shift, cnt, misc);
-            uint32_t* t = b.kA; b.kA = b.kB; b.kB = t;
-            t = b.vA; b.vA = b.vB; b.vB = t;
-        }
-        tile_sort_ties<NW>(b.kA, b.vA, b.vB, Lc, cnt, misc, tie_runs);
+        for (int shift = 0; shift < nbits; shift += GDR_RADIX_BITS)
+            tile_sort_pass_lds<NW, EPT>(kA, vA, Lc, kmin, shift, cnt, misc);
+        tile_sort_ties<NW, EPT>(kA, vA, nullptr, Lc, cnt, misc, tie_runs);
         for (uint32_t i = threadIdx.x; i < Lc; i += NT) {
-            vals_out[o + i] = b.vA[i];
-            keys_out[o + i] = ((uint64_t)tile << 32) | (uint64_t)b.kA[i];
+            vals_out[o + i] = vA[i];
+            keys_out[o + i] = ((uint64_t)tile << 32) | (uint64_t)kA[i];
         }
     };
 
@@ -641,9 +709,9 @@ hipError_t launch_ranges_views(const BinViews& vs, int V, int cur, int tiles, hi
 // per-tile depth sort; input = buffers [in] (tile-partitioned), output = the other pair
 hipError_t launch_tile_sort_views(const BinViews& vs, int V, int in, int tiles, hipStream_t st) {
     if (max_D(vs, V) == 0) return hipSuccess;
-    // long lists: 16 waves per workgroup (1 per CU) so that the few heavy tiles finish quickly; a two-class scheme
-    // (everything beyond the short class bucketed and sorted in short-class chunks, 4 per CU) measured slower at
-    // 2 M - 8 M Gaussians and equal at 32 M
+    // long lists: 16 waves per workgroup so that the few heavy tiles finish quickly; a two-class scheme (everything
+    // beyond the short class bucketed and sorted in short-class chunks) measured slower at 2 M - 8 M Gaussians and equal
+    // at 32 M; medium and long merged into one 16-wave class: C4 1251 -> 1231, C3 2924 -> 2897, shells +1 %
     GDR_LAUNCH(GDR_K_TILE_SORT_LONG, (tile_sort_kernel<GDR_TSORT_LARGE, GDR_TSORT_MEDIUM, 16, true>),
                dim3(tiles < 256 ? tiles : 256, V), dim3(16 * GDR_WAVE), st, vs, in, tiles);
     GDR_LAUNCH(GDR_K_TILE_SORT_LONG, (tile_sort_kernel<GDR_TSORT_MEDIUM, GDR_TSORT_SMALL, 8, false>),
