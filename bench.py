@@ -473,6 +473,7 @@ def main():
     note("roofline pass done")
     # ---- CPU baseline: oracle (C restatement, OpenMP) on a bounded sample ------------------
     cpu_baseline = None
+    psnr_vs_oracle = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         import numpy as np
         from oracle.gdr_oracle import Oracle, Settings
@@ -506,6 +507,17 @@ def main():
         cpu_baseline = dict(value=round(1.0 / tc * (n_s / n), 4), unit="views/s", cores=cores, kind="port",
                             sample=f"oracle C restatement (OpenMP, {cores} threads), {reps} x fwd+bwd of 1 view {h}x{w}, "
                                    f"all {n} Gaussians ({tc:.2f} s each)")
+        # BASELINE.json's metric ends in "PSNR vs ref": the image the oracle just rendered against the HIP render of
+        # the same view at the benchmark's own size (the oracle as the checker, outside every timed region)
+        with torch.no_grad():
+            a = (params["centers"], params["shs"], params["opacity"], params["scales"], params["rotations"], dev)
+            hip_img = (renderer.render_img(cam, rays[0], *a) if surfel else renderer.render_img(cam, None, *a))["image"]
+        hip_img = hip_img.permute(2, 0, 1).cpu().numpy()
+        ref_img = np.clip(ctx["color"], 0.0, 1.0)
+        mse = float(((hip_img - ref_img) ** 2).mean())
+        psnr_vs_oracle = dict(psnr_db=round(10 * math.log10(1.0 / max(mse, 1e-20)), 1),
+                              max_abs_rgb=float(np.abs(hip_img - ref_img).max()),
+                              view="view 0 of the rank, full size, all Gaussians; oracle = f32 C restatement (parity unpinned: DESIGN 0)")
 
     # ---- the literal "PyTorch-CPU" baseline of north_star: the vectorised torch restatement with autograd
     # (oracle/torch_ref.py), all host cores, on a bounded sample (a prefix of the Gaussian set at the full image size;
@@ -555,7 +567,8 @@ def main():
                                 else "torch ops" if (args.per_view or args.stacked_loss or args.torch_loss or args.unfused)
                                 else "fused HIP loss kernels (clamp+MSE+0.1 mean depth+0.1 mean alpha)" if args.loss_kernels
                                 else "folded into K6 epilogue / K7 prologue (clamp+MSE+0.1 mean depth+0.1 mean alpha)")},
-            "roofline": roofline, "cpu_baseline": cpu_baseline, "cpu_baseline_torch": cpu_baseline_torch, "kernels": kernels,
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "cpu_baseline_torch": cpu_baseline_torch,
+            "psnr_vs_oracle": psnr_vs_oracle, "kernels": kernels,
             "loss_mean": float(last_losses.mean()),
         }
         os.write(result_fd, (json.dumps(out) + "\n").encode())

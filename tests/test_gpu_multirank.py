@@ -144,5 +144,6 @@ def test_bench_line_contract_on_one_gpu():
     assert all("avg_us" in k for k in out["kernels"].values())
     cb = out["cpu_baseline"]
     assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and "oracle" in cb["sample"]
+    assert out["psnr_vs_oracle"]["psnr_db"] > 60 and out["psnr_vs_oracle"]["max_abs_rgb"] < 5e-3   # "PSNR vs ref" of the metric
     ct = out["cpu_baseline_torch"]
     assert ct["kind"] == "port" and (ct["value"] is None or ct["value"] > 0)
