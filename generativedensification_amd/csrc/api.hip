@@ -233,7 +233,7 @@ static int binning_stage_views(int V, const gdr_settings* s, int32_t N, const gd
     }
     BinViews vs;
     fill_bin_views(&vs, V, geoms, bins, imgs, D, radii);
-    e = launch_duplicate_views(vs, V, N, W, st);
+    e = launch_duplicate_views(vs, V, N, W, H, st);
     if (e != hipSuccess) return hip_fail("duplicate", e);
     if ((rc = debug_sync(&s[0], "duplicate", st))) return rc;
     int sorted = 0;

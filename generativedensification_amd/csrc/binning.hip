@@ -90,8 +90,11 @@ __global__ __launch_bounds__(GDR_BLOCK) void scan_block_sums_kernel(uint32_t* __
 // (every binning kernel takes the BinViews table by value and works on view blockIdx.y: the ~13 launches of the
 // binning chain are issued ONCE for all views of a multi-view node — the chain is launch-rate and latency bound,
 // gdr_common.h)
-__global__ __launch_bounds__(GDR_BLOCK) void duplicate_kernel(const BinViews vs, int N, int gx) {
+__global__ __launch_bounds__(GDR_BLOCK) void duplicate_kernel(const BinViews vs, int N, int gx, int tiles) {
     const BinView& bv = vs.v[blockIdx.y];
+    // (ranges of empty tiles must read (0,0) after K5: cleared here, long before ranges_kernel runs — one launch less in
+    // a chain whose short kernels each wait for a free slot between other views' kernels)
+    for (int t = blockIdx.x * GDR_BLOCK + threadIdx.x; t < tiles; t += gridDim.x * GDR_BLOCK) bv.ranges[t] = make_uint2(0u, 0u);
     const int32_t* __restrict__ radii = bv.radii;
     const float* __restrict__ depths = bv.depths;
     const int4* __restrict__ rect = bv.rect;
@@ -249,7 +252,7 @@ __global__ __launch_bounds__(GDR_BLOCK) void sort_scatter_kernel(const BinViews 
 // ---------------------------------------------------------------------------------
 // K5
 // ---------------------------------------------------------------------------------
-// (ranges of empty tiles must read (0,0): cleared by ranges_clear_kernel in front of this one)
+// (ranges of empty tiles must read (0,0): cleared by duplicate_kernel; by this kernel when there is nothing to duplicate)
 __global__ __launch_bounds__(GDR_BLOCK) void ranges_clear_kernel(const BinViews vs, int tiles) {
     const int t = blockIdx.x * GDR_BLOCK + threadIdx.x;
     if (t < tiles) vs.v[blockIdx.y].ranges[t] = make_uint2(0u, 0u);
@@ -675,9 +678,14 @@ static uint64_t max_D(const BinViews& vs, int V) {
     return m;
 }
 
-hipError_t launch_duplicate_views(const BinViews& vs, int V, int N, int W, hipStream_t st) {
-    if (N == 0 || max_D(vs, V) == 0) return hipSuccess;
-    GDR_LAUNCH(GDR_K_DUPLICATE, duplicate_kernel, dim3(div_up(N, GDR_BLOCK), V), dim3(GDR_BLOCK), st, vs, N, tile_grid_x(W));
+hipError_t launch_duplicate_views(const BinViews& vs, int V, int N, int W, int H, hipStream_t st) {
+    const int tiles = tile_grid_x(W) * tile_grid_y(H);
+    if (N == 0 || max_D(vs, V) == 0) {   // nothing to duplicate: only the ranges are cleared
+        GDR_LAUNCH(GDR_K_RANGES, ranges_clear_kernel, dim3(div_up(tiles, GDR_BLOCK), V), dim3(GDR_BLOCK), st, vs, tiles);
+        return hipGetLastError();
+    }
+    GDR_LAUNCH(GDR_K_DUPLICATE, duplicate_kernel, dim3(div_up(N, GDR_BLOCK), V), dim3(GDR_BLOCK), st, vs, N, tile_grid_x(W),
+               tiles);
     return hipGetLastError();
 }
 
@@ -699,9 +707,8 @@ hipError_t launch_sort_views(const BinViews& vs, int V, int lo, int hi, int* sor
 }
 
 hipError_t launch_ranges_views(const BinViews& vs, int V, int cur, int tiles, hipStream_t st) {
-    GDR_LAUNCH(GDR_K_RANGES, ranges_clear_kernel, dim3(div_up(tiles, GDR_BLOCK), V), dim3(GDR_BLOCK), st, vs, tiles);
-    const uint64_t md = max_D(vs, V);
-    if (md == 0) return hipGetLastError();
+    const uint64_t md = max_D(vs, V);   // (the ranges were cleared by launch_duplicate_views)
+    if (md == 0) return hipSuccess;
     GDR_LAUNCH(GDR_K_RANGES, ranges_kernel, dim3(div_up((int64_t)md, GDR_BLOCK), V), dim3(GDR_BLOCK), st, vs, cur);
     return hipGetLastError();
 }

@@ -96,7 +96,7 @@ struct BinView {
 struct BinViews { BinView v[GDR_MAX_VIEWS]; };
 void fill_bin_views(BinViews* vs, int V, const gdr_geom* geoms, const gdr_binning* bins, const gdr_image* imgs,
                     const uint64_t* D, const int32_t* const* radii);
-hipError_t launch_duplicate_views(const BinViews& vs, int V, int N, int W, hipStream_t st);
+hipError_t launch_duplicate_views(const BinViews& vs, int V, int N, int W, int H, hipStream_t st);
 hipError_t launch_sort_views(const BinViews& vs, int V, int lo, int hi, int* sorted, hipStream_t st);
 hipError_t launch_ranges_views(const BinViews& vs, int V, int cur, int tiles, hipStream_t st);
 hipError_t launch_tile_sort_views(const BinViews& vs, int V, int in, int tiles, hipStream_t st);
