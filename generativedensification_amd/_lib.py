@@ -47,7 +47,8 @@ class GdrBinning(C.Structure):
                 ("sorted", C.c_int32), ("global_sort", C.c_int32), ("scratch32", C.c_void_p),
                 ("seg_extra", C.c_void_p), ("seg_count", C.c_void_p), ("seg_state", C.c_void_p),
                 ("seg_len", C.c_int32), ("seg_cap", C.c_int32), ("deep_max_busy", C.c_int32), ("reserved0", C.c_int32),
-                ("d_dev", C.c_void_p)]
+                ("d_dev", C.c_void_p), ("stats_out", C.c_void_p), ("hint_long", C.c_int32), ("hint_medium", C.c_int32),
+                ("hint_no_deep", C.c_int32), ("reserved1", C.c_int32)]
 
 
 class GdrImage(C.Structure):
@@ -208,7 +209,7 @@ def load():
             fn = getattr(lib, name)  # AttributeError if the symbol is missing
             fn.restype = res
             fn.argtypes = args
-        if lib.gdr_abi_version() != 10:
+        if lib.gdr_abi_version() != 11:
             raise RuntimeError("libgdr_hip.so ABI version mismatch")
         _lib = lib
     return _lib

@@ -98,6 +98,8 @@ static size_t carve_binning(void* base, uint64_t D, gdr_binning* b) {
     t.deep_max_busy = GDR_DEFAULT_DEEP_MAX_BUSY;
     t.reserved0 = 0;
     t.d_dev = nullptr;
+    t.stats_out = nullptr;
+    t.hint_long = t.hint_medium = t.hint_no_deep = t.reserved1 = 0;
     t.seg_len = GDR_DEFAULT_SEG_LEN;  // callers may raise it (a multiple of 256) or set 0 after carving (include/gdr.h)
     t.seg_cap = t.seg_len ? (int32_t)(D / (uint64_t)t.seg_len + 1) : 0;
     t.seg_extra = c.take<uint32_t>(2 * (size_t)(t.seg_cap ? t.seg_cap : 1));

@@ -295,9 +295,7 @@ __global__ __launch_bounds__(GDR_BLOCK) void ranges_kernel(const BinViews vs, in
 //   medium (L <= 4096): 40 KiB, 8 waves   } small grids that walk the tiles longest-first
 //   long   (L <= 8192 in LDS, beyond that on the global ping-pong buffers): 80 KiB, 16 waves }
 // (lists are sorted IN PLACE in LDS, tile_sort_pass_lds: 8 bytes per entry)
-#define GDR_TSORT_SMALL 2048
-#define GDR_TSORT_MEDIUM 4096
-#define GDR_TSORT_LARGE 8192
+// (GDR_TSORT_SMALL / MEDIUM / LARGE = 2048 / 4096 / 8192: gdr_common.h)
 
 struct TileSortBufs {
     uint32_t *kA, *vA, *kB, *vB;
@@ -667,6 +665,7 @@ void fill_bin_views(BinViews* vs, int V, const gdr_geom* geoms, const gdr_binnin
         b.seg_extra = (uint2*)bn.seg_extra; b.seg_count = bn.seg_count;
         b.D = D[v]; b.nblk = (uint32_t)((D[v] + GDR_SORT_TILE - 1) / GDR_SORT_TILE);
         b.d_dev = bn.d_dev;
+        b.stats_out = bn.stats_out; b.hint_long = bn.hint_long; b.hint_medium = bn.hint_medium;
         b.seg_len = bn.seg_len; b.seg_cap = bn.seg_cap;
         b.deep_max_busy = (uint32_t)(bn.deep_max_busy > 0 ? bn.deep_max_busy : 0);
     }
@@ -713,16 +712,33 @@ hipError_t launch_ranges_views(const BinViews& vs, int V, int cur, int tiles, hi
     return hipGetLastError();
 }
 
+// one launch covers all views: the largest hint of the views, 0 (= worst-case grid) if a view has none
+static int merged_hint(const BinViews& vs, int V, bool long_class) {
+    int h = 0;
+    for (int v = 0; v < V; ++v) {
+        const int x = long_class ? vs.v[v].hint_long : vs.v[v].hint_medium;
+        if (x <= 0) return 0;
+        h = x > h ? x : h;
+    }
+    return h;
+}
+
 // per-tile depth sort; input = buffers [in] (tile-partitioned), output = the other pair
 hipError_t launch_tile_sort_views(const BinViews& vs, int V, int in, int tiles, hipStream_t st) {
     if (max_D(vs, V) == 0) return hipSuccess;
     // long lists: 16 waves per workgroup so that the few heavy tiles finish quickly; a two-class scheme (everything
     // beyond the short class bucketed and sorted in short-class chunks) measured slower at 2 M - 8 M Gaussians and equal
     // at 32 M; medium and long merged into one 16-wave class: C4 1251 -> 1231, C3 2924 -> 2897, shells +1 %
+    // the long / medium classes are usually sparse or empty, and every one of their workgroups needs 80 / 40 KB of LDS on
+    // a CU: with a hint from the previous call of this scene shape (gdr_binning.hint_*) only as many as there were tiles
+    int g_long = tiles < 256 ? tiles : 256, g_medium = tiles < 512 ? tiles : 512;
+    const int h_long = merged_hint(vs, V, true), h_medium = merged_hint(vs, V, false);
+    if (h_long > 0 && h_long < g_long) g_long = h_long;
+    if (h_medium > 0 && h_medium < g_medium) g_medium = h_medium;
     GDR_LAUNCH(GDR_K_TILE_SORT_LONG, (tile_sort_kernel<GDR_TSORT_LARGE, GDR_TSORT_MEDIUM, 16, true>),
-               dim3(tiles < 256 ? tiles : 256, V), dim3(16 * GDR_WAVE), st, vs, in, tiles);
+               dim3(g_long, V), dim3(16 * GDR_WAVE), st, vs, in, tiles);
     GDR_LAUNCH(GDR_K_TILE_SORT_LONG, (tile_sort_kernel<GDR_TSORT_MEDIUM, GDR_TSORT_SMALL, 8, false>),
-               dim3(tiles < 512 ? tiles : 512, V), dim3(8 * GDR_WAVE), st, vs, in, tiles);
+               dim3(g_medium, V), dim3(8 * GDR_WAVE), st, vs, in, tiles);
     GDR_LAUNCH(GDR_K_TILE_SORT, (tile_sort_kernel<GDR_TSORT_SMALL, 0, 4, false>), dim3(tiles, V), dim3(GDR_BLOCK), st, vs, in,
                tiles);
     return hipGetLastError();

@@ -92,7 +92,13 @@ struct BinView {
     uint2* ranges; uint32_t* tile_order; uint32_t* seg_base; uint2* seg_extra; uint32_t* seg_count;
     uint64_t D; uint32_t nblk; int32_t seg_len, seg_cap; uint32_t deep_max_busy;
     const uint32_t* d_dev;   // gdr_binning.d_dev: the duplicate count stays on the device, D/nblk above are CAPACITIES
+    uint32_t* stats_out;     // gdr_binning.stats_out (tile_order_kernel writes it)
+    int32_t hint_long, hint_medium;   // host side only: grid sizes of the tile sort's long / medium class
 };
+// tile sort size classes (list entries): one workgroup per tile up to SMALL, small grids walking the longer tiles
+#define GDR_TSORT_SMALL 2048
+#define GDR_TSORT_MEDIUM 4096
+#define GDR_TSORT_LARGE 8192
 struct BinViews { BinView v[GDR_MAX_VIEWS]; };
 void fill_bin_views(BinViews* vs, int V, const gdr_geom* geoms, const gdr_binning* bins, const gdr_image* imgs,
                     const uint64_t* D, const int32_t* const* radii);

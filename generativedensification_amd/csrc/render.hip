@@ -151,6 +151,29 @@ __global__ __launch_bounds__(GDR_BLOCK) void tile_order_kernel(const BinViews vs
         const uint32_t b = min((r.y - r.x) >> 4, (uint32_t)GDR_ORDER_BUCKETS - 1u);
         order[atomicAdd(&cnt[GDR_ORDER_BUCKETS - 1 - b], 1u)] = (uint32_t)t;
     }
+    // what the caller may feed back into the next call of this scene shape (gdr_binning.stats_out): tiles in the tile
+    // sort's long / medium class, busy tiles (lists of >= 64 entries)
+    uint32_t n_long = 0u, n_medium = 0u, n_busy = 0u;
+    for (int t = threadIdx.x; t < ntiles; t += GDR_BLOCK) {
+        const uint2 r = ranges[t];
+        const uint32_t len = r.y - r.x;
+        n_long += len > (uint32_t)GDR_TSORT_MEDIUM ? 1u : 0u;
+        n_medium += (len > (uint32_t)GDR_TSORT_SMALL && len <= (uint32_t)GDR_TSORT_MEDIUM) ? 1u : 0u;
+        n_busy += len >= 64u ? 1u : 0u;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        n_long += __shfl_xor(n_long, off, 64); n_medium += __shfl_xor(n_medium, off, 64); n_busy += __shfl_xor(n_busy, off, 64);
+    }
+    __syncthreads();   // (cnt is free again: the ordering phase is over)
+    if (lane_id() == 0) { cnt[threadIdx.x >> 6] = n_long; cnt[4 + (threadIdx.x >> 6)] = n_medium; cnt[8 + (threadIdx.x >> 6)] = n_busy; }
+    __syncthreads();
+    n_long = cnt[0] + cnt[1] + cnt[2] + cnt[3]; n_medium = cnt[4] + cnt[5] + cnt[6] + cnt[7]; n_busy = cnt[8] + cnt[9] + cnt[10] + cnt[11];
+    const uint32_t deep = (seg_base != nullptr && seg_len > 0 && n_busy <= deep_max_busy) ? 1u : 0u;
+    if (threadIdx.x == 0 && bv.stats_out) {
+        bv.stats_out[0] = n_long; bv.stats_out[1] = n_medium; bv.stats_out[2] = deep; bv.stats_out[3] = n_busy;
+    }
+    __syncthreads();
     if (seg_base == nullptr) return;
     if (seg_len <= 0) {
         if (threadIdx.x < 3) seg_count[threadIdx.x] = 0u;
@@ -160,18 +183,7 @@ __global__ __launch_bounds__(GDR_BLOCK) void tile_order_kernel(const BinViews vs
         // cut tiles runs with 16 instead of 64 pixels per wave (render_fwd_deep_kernel).  Busy = list of >= 64 entries;
         // the chip holds 1024 forward workgroups at once (256 CUs x 4), so below ~768 busy tiles CUs sit on one
         // workgroup (one wave per SIMD) and the walk of a long list is latency-bound.
-        uint32_t mine = 0u;
-        for (int t = threadIdx.x; t < ntiles; t += GDR_BLOCK) {
-            const uint2 r = ranges[t];
-            mine += (r.y - r.x) >= 64u ? 1u : 0u;
-        }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off, 64);
-        __syncthreads();
-        if (lane_id() == 0) wsum[threadIdx.x >> 6] = mine;
-        __syncthreads();
-        if (threadIdx.x == 0) seg_count[2] = (wsum[0] + wsum[1] + wsum[2] + wsum[3]) <= deep_max_busy ? 1u : 0u;
-        __syncthreads();
+        if (threadIdx.x == 0) seg_count[2] = deep;
     }
     uint32_t slot_run = 0u, cut_run = 0u;  // uniform running totals over the chunks of 256 tiles
     for (int t0 = 0; t0 < ntiles; t0 += GDR_BLOCK) {
@@ -912,10 +924,10 @@ hipError_t launch_tile_order_views(const BinViews& vs, int V, int ntiles, hipStr
 
 
 // cut tiles in "deep" mode (seg_count[2]): 4 workgroups per cut tile, in front of the standard launch
-#define GDR_DEEP_FLAG(bin, img) (seg_rounds_of(bin, img) ? (const uint32_t*)(bin)->seg_count + 2 : nullptr)
+#define GDR_DEEP_FLAG(bin, img) (seg_rounds_of(bin, img) && !(bin)->hint_no_deep ? (const uint32_t*)(bin)->seg_count + 2 : nullptr)
 #define GDR_DEEP_LAUNCH(LOSSV, COLOR, DEPTH, ALPHA, FL)                                                                  \
     do {                                                                                                                  \
-        if (seg_rounds_of(bin, img) && img->tile_order && bin->deep_max_busy > 0) {                                       \
+        if (seg_rounds_of(bin, img) && img->tile_order && bin->deep_max_busy > 0 && !bin->hint_no_deep) {                                    \
             int ndeep = bin->seg_cap < ntiles ? bin->seg_cap : ntiles;     /* cut tiles <= busy tiles <= deep_max_busy */ \
             ndeep = 4 * (((ndeep < bin->deep_max_busy ? ndeep : bin->deep_max_busy) + 7) / 8 * 8);                        \
             GDR_LAUNCH(GDR_K_RENDER_FWD_DEEP, render_fwd_deep_kernel<LOSSV>, dim3(ndeep), dim3(GDR_BLOCK), st,             \

@@ -310,6 +310,8 @@ def forward_raw(means3D, sh, colors_precomp, opacities, scales, rotations, cov3D
         out = L.GdrOutputs(color.data_ptr(), depth.data_ptr(), alpha.data_ptr(), _ptr(radii))
         key = (N, H, W)
         cap = _d_capacity(key) if N > 0 else None
+        stats = _launch_stats(key, 1)
+        srow = None if stats is None else stats[0]
 
         def render():    # K3..K6 behind K1 on the caller's stream
             L.check(lib.gdr_render_forward(C.byref(s), C.byref(inp), C.byref(st.geom), C.byref(st.bin),
@@ -320,18 +322,18 @@ def forward_raw(means3D, sh, colors_precomp, opacities, scales, rotations, cov3D
             L.check(lib.gdr_preprocess_forward(C.byref(s), C.byref(inp), C.byref(st.geom), _ptr(radii),
                                                C.byref(d_host), stream), "gdr_preprocess_forward")
             d = int(d_host.value)
-            _carve_binning(lib, st, d, tiles)
+            _carve_binning(lib, st, d, tiles, stats=srow)
             render()
         else:             # device-sized call (DEFER_D above): nothing waits for K1 until everything is enqueued
             L.check(lib.gdr_preprocess_forward(C.byref(s), C.byref(inp), C.byref(st.geom), _ptr(radii), None, stream),
                     "gdr_preprocess_forward")
             st.counters = st._view(st.geom_buf, st.geom.num_rendered, torch.int32, 1)
             readback = _CountReadback(st.counters)
-            _carve_binning(lib, st, cap, tiles, d_dev=st.geom.num_rendered)
+            _carve_binning(lib, st, cap, tiles, d_dev=st.geom.num_rendered, stats=srow)
             render()
             d = readback.wait()[0]
             if d > cap:
-                _carve_binning(lib, st, d, tiles)
+                _carve_binning(lib, st, d, tiles, stats=srow)
                 render()
             st.D = d
         _d_record(key, [d])
@@ -470,8 +472,31 @@ class _CountReadback:
         return [int(d) & 0xFFFFFFFF for d in self.host.tolist()]
 
 
-def _carve_binning(lib, st, entries, tiles, d_dev=None):
-    """Workspace of one view for `entries` duplicates (exact count, or a capacity with d_dev = the device counter)."""
+# ---- launch-size feedback (gdr_binning.stats_out / hint_*) ----------------------------------------------------
+# The binning stage of a view reports how many tiles fell into the tile sort's long / medium class and whether the deep
+# forward applied; the next call of the same shape sizes those launches from it (empty classes: 1 workgroup instead of
+# 256 / 512 with 80 / 40 KB of LDS each; no deep launch of 3072 workgroups that leave at once).  Results never depend
+# on it: the classes walk their tiles with a grid stride, and K6 renders every tile the standard way without the deep
+# launch.  The words live in pinned host memory the kernels write directly (4 words per view and shape, kept for the
+# life of the process: the GPU may still be writing when a shape is last used).
+LAUNCH_HINTS = _os.environ.get("GDR_LAUNCH_HINTS", "1") != "0"
+_LAUNCH_STATS: dict = {}
+
+
+def _launch_stats(key, V):
+    """Pinned int32 (V, 4) of the shape `key` ({long tiles, medium tiles, deep flag, busy tiles} per view; -1 = no call
+    yet), or None (switched off / too many shapes)."""
+    if not LAUNCH_HINTS:
+        return None
+    t = _LAUNCH_STATS.get(key)
+    if t is None and len(_LAUNCH_STATS) < 1024:
+        t = _LAUNCH_STATS[key] = torch.full((V, 4), -1, dtype=torch.int32).pin_memory()
+    return t
+
+
+def _carve_binning(lib, st, entries, tiles, d_dev=None, stats=None):
+    """Workspace of one view for `entries` duplicates (exact count, or a capacity with d_dev = the device counter);
+    stats: this view's row of _launch_stats (read for the hints of this call, then handed to the kernels to refresh)."""
     need = lib.gdr_binning_bytes(entries)
     if st.bin_buf is None or st.bin_buf.numel() < need:
         st.bin_buf = torch.empty(need, dtype=torch.uint8, device=st.geom_buf.device)
@@ -480,6 +505,12 @@ def _carve_binning(lib, st, entries, tiles, d_dev=None):
     st.bin.d_dev = d_dev
     st.D = entries
     _apply_seg_len(st.bin, entries, tiles)
+    if stats is not None:
+        n_long, n_medium, deep, _ = stats.tolist()
+        if n_long >= 0:     # a previous call of this shape has reported (25 % + 1 of slack: scenes drift)
+            st.bin.hint_long, st.bin.hint_medium = n_long + n_long // 4 + 1, n_medium + n_medium // 4 + 1
+            st.bin.hint_no_deep = int(deep == 0)
+        st.bin.stats_out = stats.data_ptr()
 
 
 def binning_views(lib, s_arr, N, g_arr, states, radii, lo, hi, stream, fn="gdr_binning_forward_views"):
@@ -571,13 +602,15 @@ def _forward_views_impl(means3D, means2D, sh, opacities, scales, rotations, sett
                 fs.wait_event(ready)
         readback = _CountReadback(counters)
         cap = _d_capacity(key) if N > 0 else None
+        stats = _launch_stats(key, V)
+        srow = (lambda v: None) if stats is None else (lambda v: stats[v])
         if cap is None:         # first call of this shape: D decides the workspace sizes, as upstream
             d_host = readback.wait()
             for v, st in enumerate(states):
-                _carve_binning(lib, st, d_host[v], tiles)
+                _carve_binning(lib, st, d_host[v], tiles, stats=srow(v))
         else:
             for v, st in enumerate(states):
-                _carve_binning(lib, st, cap, tiles, d_dev=st.geom.num_rendered)
+                _carve_binning(lib, st, cap, tiles, d_dev=st.geom.num_rendered, stats=srow(v))
 
         def composite(v, sv):  # K6 of view v (with the loss folded into its epilogue when loss_spec is given)
             st = states[v]
@@ -627,7 +660,7 @@ def _forward_views_impl(means3D, means2D, sh, opacities, scales, rotations, sett
             d_host = readback.wait()     # (K1 finished long ago: the host has enqueued ~15 launches per view since)
             for v in [v for v in range(V) if d_host[v] > cap]:
                 # the guess was too small for this view: again, exactly sized, behind everything else
-                _carve_binning(lib, states[v], d_host[v], tiles)
+                _carve_binning(lib, states[v], d_host[v], tiles, stats=srow(v))
                 if loss_spec is not None:
                     loss_spec[-1][v:v + 1].zero_()
                 chain(v, v + 1, main)

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define GDR_ABI_VERSION 10
+#define GDR_ABI_VERSION 11
 
 #define GDR_OK 0
 #define GDR_ERR_INVALID_ARG (-1)  /* NULL / inconsistent arguments                     */
@@ -162,6 +162,14 @@ typedef struct gdr_binning {
                           * the caller can enqueue binning + K6 behind K1 without waiting for K1, and compares the count
                           * with the capacity afterwards.  A count above the capacity is clamped (nothing is written out
                           * of bounds; the images are then incomplete and the view must be repeated with enough room). */
+    /* Launch-size feedback between calls that render the same kind of scene (all optional, results never depend on it):
+     * the binning stage reports what it found, the caller passes it back into the next call of that shape. */
+    uint32_t* stats_out; /* NULL, or 4 device-writable words (pinned host memory works): {tiles in the tile sort's long
+                          * class (> 4096 entries), tiles in its medium class (2049..4096), "deep forward" flag, busy tiles} */
+    int32_t hint_long;   /* > 0: workgroups for the tile sort's long class; 0 = sized for the worst case.  Every value >= 1 */
+    int32_t hint_medium; /*      is correct (the classes walk their tiles with a grid stride), a wrong one only costs time   */
+    int32_t hint_no_deep;/* != 0: the deep forward is not launched; K6 renders every tile the standard way (same images)     */
+    int32_t reserved1;
 } gdr_binning;
 
 /* Image state (upstream "imgBuffer"). */

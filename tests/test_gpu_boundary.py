@@ -337,3 +337,48 @@ def test_backward_in_k9_groups_on_their_own_stream_gives_the_same_gradients(surf
                 assert (np.abs(g1[k] - g0[k]) > tol).mean() < 1e-4, (fused_loss, k)
     finally:
         R.BWD_GROUP = saved
+
+
+def test_launch_hints_only_size_launches():
+    """gdr_binning.stats_out / hint_* (rasterizer._launch_stats): the binning stage reports its tile classes and the
+    next call of the shape sizes the long / medium tile-sort grids and skips the deep-forward launch from that.  Wrong
+    hints (an object-like scene after hints that say "no long lists, no deep forward") must give the same sorted lists and
+    contributor counts, and the same image up to the deep forward's summation order."""
+    from generativedensification_amd import rasterizer as R
+    from generativedensification_amd.camera import orbit_cameras
+    from generativedensification_amd.renderer import Renderer
+    from generativedensification_amd.synthetic import make_scene
+    dev = torch.device(DEV)
+    V, H, W, N = 2, 256, 256, 400_000
+    scene = make_scene(N, 29, sh_degree=1, sigma0=(0.004,), device=dev, layout="shell")   # long lists at the silhouette
+    cams = orbit_cameras(V, W, H, device=dev)
+    sets = [Renderer(sh_degree=1).set_rasterizer(c, device=dev).raster_settings for c in cams]
+    key = (N, H, W, V)
+
+    def run():
+        with torch.no_grad():
+            colors, _, _, _, states, _, _ = R._forward_views_impl(scene["centers"], torch.empty(0, 4, device=dev), scene["shs"],
+                                                                  scene["opacity"], scene["scales"], scene["rotations"],
+                                                                  tuple(sets), R.RAW_ALL)
+        torch.cuda.synchronize()
+        return colors, [st.tensors() for st in states], [(st.bin.hint_long, st.bin.hint_medium, st.bin.hint_no_deep) for st in states]
+
+    saved = R._LAUNCH_STATS.pop(key, None)
+    try:
+        c0, t0, h0 = run()                                   # no history: worst-case grids
+        assert all(h == (0, 0, 0) for h in h0)
+        stats = R._LAUNCH_STATS[key]
+        assert (stats >= 0).all() and int(stats[:, 0].max()) > 0, stats   # the scene does have lists > 4096 entries
+        c1, t1, h1 = run()                                   # sized from the report
+        assert all(h[0] > 0 and h[1] > 0 for h in h1)
+        stats.zero_()                                        # "no long / medium lists, no deep forward": all wrong
+        c2, t2, h2 = run()
+        assert all(h == (1, 1, 1) for h in h2) and int(stats[:, 0].max()) > 0   # (and the report is right again)
+        for cs, ts in ((c1, t1), (c2, t2)):
+            for v in range(V):
+                for k in ("keys_sorted", "point_list", "ranges", "n_contrib"):
+                    assert torch.equal(ts[v][k], t0[v][k]), k
+                assert float((cs[v] - c0[v]).abs().max()) < 2e-5
+    finally:
+        if saved is not None:
+            R._LAUNCH_STATS[key] = saved
