@@ -176,6 +176,10 @@ __global__ __launch_bounds__(GDR_BLOCK) void sort_rowscan_kernel(const BinViews 
     if (threadIdx.x == 0) totals[blockIdx.x] = carry;
 }
 
+// STAGED (the first pass of the tile partition, whose digits — the low 8 bits of the tile id — are spread evenly: ~16 keys
+// per digit and workgroup): the workgroup's keys are first put in digit order in LDS and then written out by consecutive
+// threads, so that a wave writes a few runs of consecutive pairs instead of 64 scattered 8- and 4-byte words.
+template <bool STAGED>
 __global__ __launch_bounds__(GDR_BLOCK) void sort_scatter_kernel(const BinViews vs, int cur, int shift) {
     const BinView& bv = vs.v[blockIdx.y];
     const uint64_t D = view_D(bv);
@@ -226,6 +230,46 @@ __global__ __launch_bounds__(GDR_BLOCK) void sort_scatter_kernel(const BinViews 
         if (valid && (m >> lane_id()) == 1ull) cnt[w][d] = prior + below + 1u;
     }
     __syncthreads();
+    if constexpr (STAGED) {
+        __shared__ uint64_t s_key[GDR_SORT_TILE];
+        __shared__ uint32_t s_val[GDR_SORT_TILE];
+        __shared__ uint32_t s_delta[GDR_RADIX];   // global position - position in the workgroup's digit-ordered list
+        {
+            const uint32_t d = threadIdx.x;
+            uint32_t tot = 0;
+#pragma unroll
+            for (int k = 0; k < GDR_BLOCK / GDR_WAVE; ++k) tot += cnt[k][d];
+            uint32_t lbase = block_excl_scan(tot, lds, nullptr);   // where digit d starts in the local list
+            s_delta[d] = digit_base + hist[(uint64_t)d * nblk + blockIdx.x] - lbase;
+#pragma unroll
+            for (int k = 0; k < GDR_BLOCK / GDR_WAVE; ++k) {
+                const uint32_t c = cnt[k][d];
+                cnt[k][d] = lbase;
+                lbase += c;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < GDR_SORT_ITEMS; ++j) {
+            const uint64_t idx = tile_index(blockIdx.x, w, j);
+            if (idx < D) {
+                const uint32_t d = (uint32_t)(key[j] >> shift) & (GDR_RADIX - 1);
+                const uint32_t lpos = cnt[w][d] + rank[j];
+                s_key[lpos] = key[j];
+                s_val[lpos] = val[j];
+            }
+        }
+        __syncthreads();
+        const uint64_t first = (uint64_t)blockIdx.x * GDR_SORT_TILE;
+        const uint32_t n = (uint32_t)(D - first < (uint64_t)GDR_SORT_TILE ? D - first : (uint64_t)GDR_SORT_TILE);
+        for (uint32_t i = threadIdx.x; i < n; i += GDR_BLOCK) {
+            const uint64_t k = s_key[i];
+            const uint32_t pos = i + s_delta[(uint32_t)(k >> shift) & (GDR_RADIX - 1)];
+            keys_out[pos] = k;
+            vals_out[pos] = s_val[i];
+        }
+        return;
+    }
     {   // per-digit: turn per-wave counts into global start positions
         const uint32_t d = threadIdx.x;
         uint32_t base = digit_base + hist[(uint64_t)d * nblk + blockIdx.x];
@@ -698,7 +742,10 @@ hipError_t launch_sort_views(const BinViews& vs, int V, int lo, int hi, int* sor
     for (int shift = lo; shift < hi; shift += GDR_RADIX_BITS) {
         GDR_LAUNCH(GDR_K_SORT_HIST, sort_hist_kernel, dim3(nblk, V), dim3(GDR_BLOCK), st, vs, cur, shift);
         GDR_LAUNCH(GDR_K_SORT_ROWSCAN, sort_rowscan_kernel, dim3(GDR_RADIX, V), dim3(GDR_BLOCK), st, vs);
-        GDR_LAUNCH(GDR_K_SORT_SCATTER, sort_scatter_kernel, dim3(nblk, V), dim3(GDR_BLOCK), st, vs, cur, shift);
+        if (shift == lo && hi - lo <= 2 * GDR_RADIX_BITS)   // first pass of the tile partition: evenly spread digits
+            GDR_LAUNCH(GDR_K_SORT_SCATTER, sort_scatter_kernel<true>, dim3(nblk, V), dim3(GDR_BLOCK), st, vs, cur, shift);
+        else
+            GDR_LAUNCH(GDR_K_SORT_SCATTER, sort_scatter_kernel<false>, dim3(nblk, V), dim3(GDR_BLOCK), st, vs, cur, shift);
         cur ^= 1;
     }
     *sorted = cur;
