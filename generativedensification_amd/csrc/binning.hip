@@ -775,7 +775,9 @@ hipError_t launch_tile_sort_views(const BinViews& vs, int V, int in, int tiles, 
     if (max_D(vs, V) == 0) return hipSuccess;
     // long lists: 16 waves per workgroup so that the few heavy tiles finish quickly; a two-class scheme (everything
     // beyond the short class bucketed and sorted in short-class chunks) measured slower at 2 M - 8 M Gaussians and equal
-    // at 32 M; medium and long merged into one 16-wave class: C4 1251 -> 1231, C3 2924 -> 2897, shells +1 %
+    // at 32 M; medium and long merged into one 16-wave class: C4 1251 -> 1231, C3 2924 -> 2897, shells +1 %; short and
+    // medium merged into one class per tile (4 waves x 16 elements per lane, 36 KB): C3 shell +4.7 %, C2 -4.5 %; (8 waves,
+    // 40 KB): C2 -2.3 %, others +-0
     // the long / medium classes are usually sparse or empty, and every one of their workgroups needs 80 / 40 KB of LDS on
     // a CU: with a hint from the previous call of this scene shape (gdr_binning.hint_*) only as many as there were tiles
     int g_long = tiles < 256 ? tiles : 256, g_medium = tiles < 512 ? tiles : 512;
