@@ -310,7 +310,7 @@ def forward_raw(means3D, sh, colors_precomp, opacities, scales, rotations, cov3D
         out = L.GdrOutputs(color.data_ptr(), depth.data_ptr(), alpha.data_ptr(), _ptr(radii))
         key = (N, H, W)
         cap = _d_capacity(key) if N > 0 else None
-        stats = _launch_stats(key, 1)
+        stats, hints = _launch_stats(key, 1)
         srow = None if stats is None else stats[0]
 
         def render():    # K3..K6 behind K1 on the caller's stream
@@ -322,18 +322,18 @@ def forward_raw(means3D, sh, colors_precomp, opacities, scales, rotations, cov3D
             L.check(lib.gdr_preprocess_forward(C.byref(s), C.byref(inp), C.byref(st.geom), _ptr(radii),
                                                C.byref(d_host), stream), "gdr_preprocess_forward")
             d = int(d_host.value)
-            _carve_binning(lib, st, d, tiles, stats=srow)
+            _carve_binning(lib, st, d, tiles, stats=srow, hints=hints)
             render()
         else:             # device-sized call (DEFER_D above): nothing waits for K1 until everything is enqueued
             L.check(lib.gdr_preprocess_forward(C.byref(s), C.byref(inp), C.byref(st.geom), _ptr(radii), None, stream),
                     "gdr_preprocess_forward")
             st.counters = st._view(st.geom_buf, st.geom.num_rendered, torch.int32, 1)
             readback = _CountReadback(st.counters)
-            _carve_binning(lib, st, cap, tiles, d_dev=st.geom.num_rendered, stats=srow)
+            _carve_binning(lib, st, cap, tiles, d_dev=st.geom.num_rendered, stats=srow, hints=hints)
             render()
             d = readback.wait()[0]
             if d > cap:
-                _carve_binning(lib, st, d, tiles, stats=srow)
+                _carve_binning(lib, st, d, tiles, stats=srow, hints=hints)
                 render()
             st.D = d
         _d_record(key, [d])
@@ -484,20 +484,35 @@ LAUNCH_HINTS = _os.environ.get("GDR_LAUNCH_HINTS", "1") != "0"
 _LAUNCH_STATS: dict = {}
 
 
+_HINT_STATE: dict = {}   # shape key -> [long tiles, medium tiles, calls until the deep launch may be dropped]: decaying maxima
+
+
 def _launch_stats(key, V):
-    """Pinned int32 (V, 4) of the shape `key` ({long tiles, medium tiles, deep flag, busy tiles} per view; -1 = no call
-    yet), or None (switched off / too many shapes)."""
+    """(pinned int32 (V, 4) the kernels of this call report into — {long tiles, medium tiles, deep flag, busy tiles} per
+    view, -1 = no call yet —, hints for this call = (workgroups of the long class, of the medium class, no deep launch)
+    or None).  The hints are the decaying maximum over the views and the recent calls of the shape (cameras change from
+    step to step) plus 25 %, and never below 16 / 32 workgroups: a scene that suddenly has a hundred long lists costs a
+    few rounds on a small grid, not one workgroup sorting them all."""
     if not LAUNCH_HINTS:
-        return None
+        return None, None
     t = _LAUNCH_STATS.get(key)
-    if t is None and len(_LAUNCH_STATS) < 1024:
+    if t is None:
+        if len(_LAUNCH_STATS) >= 1024:
+            return None, None
         t = _LAUNCH_STATS[key] = torch.full((V, 4), -1, dtype=torch.int32).pin_memory()
-    return t
+    seen = [r for r in t.tolist() if r[0] >= 0]
+    if not seen:
+        return t, None
+    n_long, n_medium, deep = max(r[0] for r in seen), max(r[1] for r in seen), any(r[2] for r in seen)
+    st = _HINT_STATE.setdefault(key, [0, 0, 0])
+    st[0], st[1] = max(n_long, st[0] * 9 // 10), max(n_medium, st[1] * 9 // 10)
+    st[2] = 8 if deep else max(0, st[2] - 1)
+    return t, (max(16, st[0] + st[0] // 4 + 1), max(32, st[1] + st[1] // 4 + 1), int(st[2] == 0))
 
 
-def _carve_binning(lib, st, entries, tiles, d_dev=None, stats=None):
+def _carve_binning(lib, st, entries, tiles, d_dev=None, stats=None, hints=None):
     """Workspace of one view for `entries` duplicates (exact count, or a capacity with d_dev = the device counter);
-    stats: this view's row of _launch_stats (read for the hints of this call, then handed to the kernels to refresh)."""
+    stats / hints: this view's row of the report tensor and the call's launch hints (_launch_stats)."""
     need = lib.gdr_binning_bytes(entries)
     if st.bin_buf is None or st.bin_buf.numel() < need:
         st.bin_buf = torch.empty(need, dtype=torch.uint8, device=st.geom_buf.device)
@@ -506,11 +521,9 @@ def _carve_binning(lib, st, entries, tiles, d_dev=None, stats=None):
     st.bin.d_dev = d_dev
     st.D = entries
     _apply_seg_len(st.bin, entries, tiles)
+    if hints is not None:
+        st.bin.hint_long, st.bin.hint_medium, st.bin.hint_no_deep = hints
     if stats is not None:
-        n_long, n_medium, deep, _ = stats.tolist()
-        if n_long >= 0:     # a previous call of this shape has reported (25 % + 1 of slack: scenes drift)
-            st.bin.hint_long, st.bin.hint_medium = n_long + n_long // 4 + 1, n_medium + n_medium // 4 + 1
-            st.bin.hint_no_deep = int(deep == 0)
         st.bin.stats_out = stats.data_ptr()
 
 
@@ -603,15 +616,15 @@ def _forward_views_impl(means3D, means2D, sh, opacities, scales, rotations, sett
                 fs.wait_event(ready)
         readback = _CountReadback(counters)
         cap = _d_capacity(key) if N > 0 else None
-        stats = _launch_stats(key, V)
+        stats, hints = _launch_stats(key, V)
         srow = (lambda v: None) if stats is None else (lambda v: stats[v])
         if cap is None:         # first call of this shape: D decides the workspace sizes, as upstream
             d_host = readback.wait()
             for v, st in enumerate(states):
-                _carve_binning(lib, st, d_host[v], tiles, stats=srow(v))
+                _carve_binning(lib, st, d_host[v], tiles, stats=srow(v), hints=hints)
         else:
             for v, st in enumerate(states):
-                _carve_binning(lib, st, cap, tiles, d_dev=st.geom.num_rendered, stats=srow(v))
+                _carve_binning(lib, st, cap, tiles, d_dev=st.geom.num_rendered, stats=srow(v), hints=hints)
 
         def composite(v, sv):  # K6 of view v (with the loss folded into its epilogue when loss_spec is given)
             st = states[v]
@@ -661,7 +674,7 @@ def _forward_views_impl(means3D, means2D, sh, opacities, scales, rotations, sett
             d_host = readback.wait()     # (K1 finished long ago: the host has enqueued ~15 launches per view since)
             for v in [v for v in range(V) if d_host[v] > cap]:
                 # the guess was too small for this view: again, exactly sized, behind everything else
-                _carve_binning(lib, states[v], d_host[v], tiles, stats=srow(v))
+                _carve_binning(lib, states[v], d_host[v], tiles, stats=srow(v), hints=hints)
                 if loss_spec is not None:
                     loss_spec[-1][v:v + 1].zero_()
                 chain(v, v + 1, main)

@@ -102,7 +102,7 @@ def forward_raw(means3D, sh, colors_precomp, opacities, scales, rotations, trans
         out = L.GsrOutputs(color.data_ptr(), allmap.data_ptr(), _ptr(radii))
         key = ("surfel", N, H, W)
         cap = _R._d_capacity(key) if N > 0 else None
-        stats = _R._launch_stats(key, 1)
+        stats, hints = _R._launch_stats(key, 1)
         srow = None if stats is None else stats[0]
 
         def render():    # K3..K6s behind K1s on the caller's stream
@@ -114,18 +114,18 @@ def forward_raw(means3D, sh, colors_precomp, opacities, scales, rotations, trans
             L.check(lib.gsr_preprocess_forward(C.byref(s), C.byref(inp), C.byref(st.geom), _ptr(radii), C.byref(d_host),
                                                stream), "gsr_preprocess_forward")
             d = int(d_host.value)
-            _R._carve_binning(lib, st, d, tiles, stats=srow)
+            _R._carve_binning(lib, st, d, tiles, stats=srow, hints=hints)
             render()
         else:             # device-sized call (rasterizer.DEFER_D): capacity check after everything is enqueued
             L.check(lib.gsr_preprocess_forward(C.byref(s), C.byref(inp), C.byref(st.geom), _ptr(radii), None, stream),
                     "gsr_preprocess_forward")
             st.counters = st._view(st.geom_buf, st.geom.num_rendered, torch.int32, 1)
             readback = _R._CountReadback(st.counters)
-            _R._carve_binning(lib, st, cap, tiles, d_dev=st.geom.num_rendered, stats=srow)
+            _R._carve_binning(lib, st, cap, tiles, d_dev=st.geom.num_rendered, stats=srow, hints=hints)
             render()
             d = readback.wait()[0]
             if d > cap:
-                _R._carve_binning(lib, st, d, tiles, stats=srow)
+                _R._carve_binning(lib, st, d, tiles, stats=srow, hints=hints)
                 render()
             st.D = d
         _R._d_record(key, [d])
@@ -278,15 +278,15 @@ def _surfel_forward_views_impl(ctx, means3D, means2D, sh, opacities, scales, rot
             readback = _R._CountReadback(counters)
             cap = _R._d_capacity(key) if N > 0 else None
             tiles_of = lambda st: ((st.W + 15) // 16) * ((st.H + 15) // 16)
-            stats = _R._launch_stats(key, V)
+            stats, hints = _R._launch_stats(key, V)
             srow = (lambda v: None) if stats is None else (lambda v: stats[v])
             if cap is None:
                 d_host = readback.wait()
                 for v, st in enumerate(states):
-                    _R._carve_binning(lib, st, d_host[v], tiles_of(st), stats=srow(v))
+                    _R._carve_binning(lib, st, d_host[v], tiles_of(st), stats=srow(v), hints=hints)
             else:
                 for v, st in enumerate(states):
-                    _R._carve_binning(lib, st, cap, tiles_of(st), d_dev=st.geom.num_rendered, stats=srow(v))
+                    _R._carve_binning(lib, st, cap, tiles_of(st), d_dev=st.geom.num_rendered, stats=srow(v), hints=hints)
 
             def chain(v, fs):
                 st, sv = states[v], C.c_void_p(fs.cuda_stream)
@@ -306,7 +306,7 @@ def _surfel_forward_views_impl(ctx, means3D, means2D, sh, opacities, scales, rot
             if cap is not None:
                 d_host = readback.wait()
                 for v in [v for v in range(V) if d_host[v] > cap]:   # the capacity guess was too small: repeat the view
-                    _R._carve_binning(lib, states[v], d_host[v], tiles_of(states[v]), stats=srow(v))
+                    _R._carve_binning(lib, states[v], d_host[v], tiles_of(states[v]), stats=srow(v), hints=hints)
                     if loss_spec is not None:
                         loss_spec[-1][v:v + 1].zero_()
                     chain(v, main)

@@ -363,22 +363,26 @@ def test_launch_hints_only_size_launches():
         torch.cuda.synchronize()
         return colors, [st.tensors() for st in states], [(st.bin.hint_long, st.bin.hint_medium, st.bin.hint_no_deep) for st in states]
 
-    saved = R._LAUNCH_STATS.pop(key, None)
+    saved = R._LAUNCH_STATS.pop(key, None), R._HINT_STATE.pop(key, None)
     try:
         c0, t0, h0 = run()                                   # no history: worst-case grids
         assert all(h == (0, 0, 0) for h in h0)
         stats = R._LAUNCH_STATS[key]
         assert (stats >= 0).all() and int(stats[:, 0].max()) > 0, stats   # the scene does have lists > 4096 entries
-        c1, t1, h1 = run()                                   # sized from the report
-        assert all(h[0] > 0 and h[1] > 0 for h in h1)
+        c1, t1, h1 = run()                                   # sized from the report: max over the views + 25 %, floors 16 / 32
+        n_long = int(stats[:, 0].max())
+        assert all(h[0] == max(16, n_long + n_long // 4 + 1) and h[1] >= 32 for h in h1)
         stats.zero_()                                        # "no long / medium lists, no deep forward": all wrong
+        R._HINT_STATE[key] = [0, 0, 0]
         c2, t2, h2 = run()
-        assert all(h == (1, 1, 1) for h in h2) and int(stats[:, 0].max()) > 0   # (and the report is right again)
+        assert all(h == (16, 32, 1) for h in h2) and int(stats[:, 0].max()) > 0   # (and the report is right again)
         for cs, ts in ((c1, t1), (c2, t2)):
             for v in range(V):
                 for k in ("keys_sorted", "point_list", "ranges", "n_contrib"):
                     assert torch.equal(ts[v][k], t0[v][k]), k
                 assert float((cs[v] - c0[v]).abs().max()) < 2e-5
     finally:
-        if saved is not None:
-            R._LAUNCH_STATS[key] = saved
+        if saved[0] is not None:
+            R._LAUNCH_STATS[key] = saved[0]
+        if saved[1] is not None:
+            R._HINT_STATE[key] = saved[1]
