@@ -495,6 +495,7 @@ def _launch_stats(key, V):
     few rounds on a small grid, not one workgroup sorting them all."""
     if not LAUNCH_HINTS:
         return None, None
+    key = (torch.cuda.current_device(),) + tuple(key)   # one report tensor per device and shape
     t = _LAUNCH_STATS.get(key)
     if t is None:
         if len(_LAUNCH_STATS) >= 1024:

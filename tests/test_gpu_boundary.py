@@ -353,7 +353,7 @@ def test_launch_hints_only_size_launches():
     scene = make_scene(N, 29, sh_degree=1, sigma0=(0.004,), device=dev, layout="shell")   # long lists at the silhouette
     cams = orbit_cameras(V, W, H, device=dev)
     sets = [Renderer(sh_degree=1).set_rasterizer(c, device=dev).raster_settings for c in cams]
-    key = (N, H, W, V)
+    key = (torch.cuda.current_device(), N, H, W, V)
 
     def run():
         with torch.no_grad():
