@@ -168,6 +168,13 @@ def test_host_policy_helpers_without_gpu():
         R.SEG_LEN = None
         R._apply_seg_len(b, 10_000)
         assert b.seg_len == 2048
+        # the automatic choice: 512 on large images whose tiles are all busy with long lists, the carved 256 otherwise
+        for D, tiles, busy, want in ((3_400_000, 2500, None, 512), (3_400_000, 2500, 2000, 512), (3_400_000, 2500, 330, 256),
+                                     (730_000, 2500, 2500, 256), (1_070_000, 1024, 1024, 256)):
+            b.seg_len = 256
+            R._apply_seg_len(b, D, tiles, busy)
+            assert b.seg_len == want, (D, tiles, busy)
+        b.seg_len = 2048
         R.SEG_LEN = 4096
         R._apply_seg_len(b, 10_000)
         assert b.seg_len == 4096
