@@ -505,7 +505,11 @@ def _launch_stats(key, V):
     if t is None:
         if len(_LAUNCH_STATS) >= 1024:
             return None, None
-        t = _LAUNCH_STATS[key] = torch.full((V, 4), -1, dtype=torch.int32).pin_memory()
+        try:
+            t = torch.full((V, 4), -1, dtype=torch.int32).pin_memory()
+        except RuntimeError:    # no page-locked memory to be had: the feedback is an optimisation, not a requirement
+            return None, None
+        _LAUNCH_STATS[key] = t
     seen = [r for r in t.tolist() if r[0] >= 0]
     if not seen:
         return t, None
