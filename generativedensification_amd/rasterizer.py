@@ -468,12 +468,19 @@ class _CountReadback:
     """The V duplicate counters on their way to pinned host memory, behind K1 on the caller's stream."""
 
     def __init__(self, counters):
-        self.host = torch.empty(counters.shape, dtype=counters.dtype, pin_memory=True)
+        self.counters = counters
+        try:
+            self.host = torch.empty(counters.shape, dtype=counters.dtype, pin_memory=True)
+        except RuntimeError:    # no page-locked memory: a blocking copy when the counts are needed
+            self.host = None
+            return
         self.host.copy_(counters, non_blocking=True)
         self.event = torch.cuda.Event()
         self.event.record()
 
     def wait(self):
+        if self.host is None:
+            return [int(d) & 0xFFFFFFFF for d in self.counters.cpu().tolist()]
         self.event.synchronize()
         return [int(d) & 0xFFFFFFFF for d in self.host.tolist()]
 
