@@ -313,8 +313,8 @@ def forward_raw(means3D, sh, colors_precomp, opacities, scales, rotations, cov3D
         tiles = ((W + 15) // 16) * ((H + 15) // 16)
         st.bin_buf = None
         out = L.GdrOutputs(color.data_ptr(), depth.data_ptr(), alpha.data_ptr(), _ptr(radii))
-        key = (N, H, W)
-        cap = _d_capacity(key) if N > 0 else None
+        key = shape_key(N, H, W)
+        cap = _d_capacity(key, N) if N > 0 else None
         stats, hints = _launch_stats(key, 1)
         srow = None if stats is None else stats[0]
 
@@ -341,7 +341,7 @@ def forward_raw(means3D, sh, colors_precomp, opacities, scales, rotations, cov3D
                 _carve_binning(lib, st, d, tiles, stats=srow, hints=hints)
                 render()
             st.D = d
-        _d_record(key, [d])
+        _d_record(key, [d], N)
     return color, radii, depth, alpha, st, keep
 
 
@@ -448,18 +448,25 @@ RAW_ALL = L.GDR_IN_RAW_OPACITY | L.GDR_IN_RAW_SCALES | L.GDR_IN_RAW_ROTATIONS
 DEFER_D = _os.environ.get("GDR_DEFER_D", "1") != "0"
 D_SLACK = float(_os.environ.get("GDR_D_SLACK", "1.5"))   # capacity = slack x the largest recent count of the shape (measured:
 # 1.02 / 1.25 / 2.0 run at the same speed — surplus workgroups leave at once —, so the slack only costs memory)
-_D_HINT: dict = {}   # shape key -> decaying maximum of the duplicate counts of one view of that shape
+_D_HINT: dict = {}   # shape key -> decaying maximum of duplicates PER GAUSSIAN of one view of that shape
 
 
-def _d_capacity(key):
+def shape_key(N, *rest):
+    """Key of the per-shape histories (duplicate counts, launch reports): the Gaussian count enters as its power-of-two
+    bucket — a densifying model renders a different N every step, and what carries over between neighbouring N is the
+    number of duplicates per Gaussian, not the number of duplicates."""
+    return (int(N).bit_length(),) + tuple(rest)
+
+
+def _d_capacity(key, N):
     """Entries to carve each view's binning workspace for, or None: no history yet (or GDR_DEFER_D=0) -> read D back."""
     h = _D_HINT.get(key) if DEFER_D else None
-    return None if h is None else int(h * D_SLACK) + 4096
+    return None if h is None else int(h * N * D_SLACK) + 4096
 
 
-def _d_record(key, d_host):
-    prev = _D_HINT.pop(key, 0)     # (re-inserted at the end: the dict doubles as an LRU of 64 shapes)
-    _D_HINT[key] = max(max(d_host, default=0), int(prev * 0.97))
+def _d_record(key, d_host, N):
+    prev = _D_HINT.pop(key, 0.0)     # (re-inserted at the end: the dict doubles as an LRU of 64 shapes)
+    _D_HINT[key] = max(max(d_host, default=0) / max(N, 1), prev * 0.97)
     if len(_D_HINT) > 64:
         _D_HINT.pop(next(iter(_D_HINT)))
 
@@ -586,7 +593,7 @@ def _forward_views_impl(means3D, means2D, sh, opacities, scales, rotations, sett
     radii = torch.empty(V, N, dtype=torch.int32, device=dev)
     # the V duplicate counters in one array: one fill before K1, one copy to the host (no gather kernel)
     counters = torch.empty(V, dtype=torch.int32, device=dev)
-    key = (N, H, W, V)
+    key = shape_key(N, H, W, V)
     states = []
     with torch.cuda.device(dev):
         stream = _stream()
@@ -632,7 +639,7 @@ def _forward_views_impl(means3D, means2D, sh, opacities, scales, rotations, sett
             for fs in fstreams[1:]:
                 fs.wait_event(ready)
         readback = _CountReadback(counters)
-        cap = _d_capacity(key) if N > 0 else None
+        cap = _d_capacity(key, N) if N > 0 else None
         stats, hints = _launch_stats(key, V)
         srow = (lambda v: None) if stats is None else (lambda v: stats[v])
         if cap is None:         # first call of this shape: D decides the workspace sizes, as upstream
@@ -697,7 +704,7 @@ def _forward_views_impl(means3D, means2D, sh, opacities, scales, rotations, sett
                 chain(v, v + 1, main)
             for v, st in enumerate(states):
                 st.D = d_host[v]
-        _d_record(key, d_host)
+        _d_record(key, d_host, N)
     return colors, radii, depths, alphas, states, keep, in_dtypes
 
 

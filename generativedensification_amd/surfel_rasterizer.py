@@ -100,8 +100,8 @@ def forward_raw(means3D, sh, colors_precomp, opacities, scales, rotations, trans
         tiles = ((W + 15) // 16) * ((H + 15) // 16)
         st.bin_buf = None
         out = L.GsrOutputs(color.data_ptr(), allmap.data_ptr(), _ptr(radii))
-        key = ("surfel", N, H, W)
-        cap = _R._d_capacity(key) if N > 0 else None
+        key = ("surfel",) + _R.shape_key(N, H, W)
+        cap = _R._d_capacity(key, N) if N > 0 else None
         stats, hints = _R._launch_stats(key, 1)
         srow = None if stats is None else stats[0]
 
@@ -128,7 +128,7 @@ def forward_raw(means3D, sh, colors_precomp, opacities, scales, rotations, trans
                 _R._carve_binning(lib, st, d, tiles, stats=srow, hints=hints)
                 render()
             st.D = d
-        _R._d_record(key, [d])
+        _R._d_record(key, [d], N)
     return color, radii, allmap, st, keep
 
 
@@ -234,7 +234,7 @@ def _surfel_forward_views_impl(ctx, means3D, means2D, sh, opacities, scales, rot
         # duplicate counters of the V views in one array; their read-back does not stall the call once the shape has a
         # history (rasterizer.DEFER_D: device-sized binning calls, capacity check after everything is enqueued)
         counters = torch.empty(V, dtype=torch.int32, device=dev)
-        key = ("surfel", N, H, W, V)
+        key = ("surfel",) + _R.shape_key(N, H, W, V)
         with torch.cuda.device(dev):
             stream = _stream()
             main = torch.cuda.current_stream()
@@ -276,7 +276,7 @@ def _surfel_forward_views_impl(ctx, means3D, means2D, sh, opacities, scales, rot
                 for fs in fstreams[1:]:
                     fs.wait_event(ready)
             readback = _R._CountReadback(counters)
-            cap = _R._d_capacity(key) if N > 0 else None
+            cap = _R._d_capacity(key, N) if N > 0 else None
             tiles_of = lambda st: ((st.W + 15) // 16) * ((st.H + 15) // 16)
             stats, hints = _R._launch_stats(key, V)
             srow = (lambda v: None) if stats is None else (lambda v: stats[v])
@@ -312,7 +312,7 @@ def _surfel_forward_views_impl(ctx, means3D, means2D, sh, opacities, scales, rot
                     chain(v, main)
                 for v, st in enumerate(states):
                     st.D = d_host[v]
-            _R._d_record(key, d_host)
+            _R._d_record(key, d_host, N)
         ctx.states, ctx.settings_list, ctx.radii, ctx.flags = states, settings_list, radii, int(flags)
         _R._save_inputs(ctx, keep)
         ctx.means2D_shape, ctx.in_dtypes, ctx.V = tuple(means2D.shape), in_dtypes, V

@@ -9,6 +9,6 @@ for k in ${KS:-1 2 3 4 5 6}; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -fhip-fp32-correctly-rounded-divide-sqrt \
       -DGDR_ABLATE=$k -c $S/render.hip -o build/render_abl$k.o
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/libgdr_abl$k.so $L/preprocess.o $L/preprocess_surfel.o \
-      $L/binning.o build/render_abl$k.o $L/render_surfel.o $L/loss.o $L/maps_surfel.o $L/knn.o $L/api.o
+      $L/binning.o build/render_abl$k.o $L/render_surfel.o $L/loss.o $L/maps_surfel.o $L/knn.o $L/select.o $L/api.o
 done
 ls -la build/*.so

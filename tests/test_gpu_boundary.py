@@ -211,10 +211,10 @@ def test_device_sized_binning_equals_the_read_back_and_an_overflow_repeats_the_v
     targets = make_targets(V, H, W, 5).to(dev).permute(0, 3, 1, 2).contiguous()
     if surfel:
         from generativedensification_amd.renderer_2dgs import Renderer
-        key, key1 = ("surfel", N, H, W, V), ("surfel", N, H, W)      # (render_img = the single-view rasterizer)
+        key, key1 = ("surfel",) + R.shape_key(N, H, W, V), ("surfel",) + R.shape_key(N, H, W)   # (render_img = the single-view rasterizer)
     else:
         from generativedensification_amd.renderer import Renderer
-        key, key1 = (N, H, W, V), (N, H, W, 1)                        # (render_img = a one-view node)
+        key, key1 = R.shape_key(N, H, W, V), R.shape_key(N, H, W, 1)        # (render_img = a one-view node)
     sc = scene["scales"][:, :2].contiguous() if surfel else scene["scales"]
     args = (scene["centers"], scene["shs"], scene["opacity"], sc, scene["rotations"], dev)
     if surfel:
@@ -235,8 +235,8 @@ def test_device_sized_binning_equals_the_read_back_and_an_overflow_repeats_the_v
         def prep():
             if hint == "none":
                 R._D_HINT.clear()
-            elif hint == "small":       # capacity 4108 entries: every view overflows and is repeated
-                R._D_HINT[key], R._D_HINT[key1] = 10, 10
+            elif hint == "small":       # capacity ~4100 entries: every view overflows and is repeated
+                R._D_HINT[key], R._D_HINT[key1] = 1e-4, 1e-4
         res = []
         with torch.no_grad():
             for fn in (views, fused, single):
@@ -250,10 +250,10 @@ def test_device_sized_binning_equals_the_read_back_and_an_overflow_repeats_the_v
     try:
         img0, loss0, one0 = run("none")                 # no history: read-back flow
         views()
-        assert key in R._D_HINT and key1 in R._D_HINT and R._d_capacity(key) > R._D_HINT[key] > 0
+        assert key in R._D_HINT and key1 in R._D_HINT and R._d_capacity(key, N) > R._D_HINT[key] * N > 0
         img1, loss1, one1 = run("history")              # device-sized calls
         img2, loss2, one2 = run("small")
-        assert R._D_HINT[key1] > 10      # (the last call of the run was the one-view node: its history is real again)
+        assert R._D_HINT[key1] > 1e-2    # (the last call of the run was the one-view node: its history is real again)
         for imgs, losses, one in ((img1, loss1, one1), (img2, loss2, one2)):
             assert all(torch.equal(a, b) for a, b in zip(imgs, img0)) and torch.equal(one, one0)
             np.testing.assert_allclose(losses.cpu().numpy(), loss0.cpu().numpy(), rtol=2e-6)   # (atomic order)
@@ -261,7 +261,7 @@ def test_device_sized_binning_equals_the_read_back_and_an_overflow_repeats_the_v
         if not surfel:
             sets = [Renderer(sh_degree=1).set_rasterizer(c, device=dev).raster_settings for c in cams]
             res = []
-            for hint in (None, 10):
+            for hint in (None, 1e-4):
                 if hint is None:
                     R._D_HINT.pop(key, None)
                 else:
@@ -353,7 +353,7 @@ def test_launch_hints_only_size_launches():
     scene = make_scene(N, 29, sh_degree=1, sigma0=(0.004,), device=dev, layout="shell")   # long lists at the silhouette
     cams = orbit_cameras(V, W, H, device=dev)
     sets = [Renderer(sh_degree=1).set_rasterizer(c, device=dev).raster_settings for c in cams]
-    key = (torch.cuda.current_device(), N, H, W, V)
+    key = (torch.cuda.current_device(),) + R.shape_key(N, H, W, V)
 
     def run():
         with torch.no_grad():
@@ -386,3 +386,48 @@ def test_launch_hints_only_size_launches():
             R._LAUNCH_STATS[key] = saved[0]
         if saved[1] is not None:
             R._HINT_STATE[key] = saved[1]
+
+
+def test_history_of_a_shape_carries_over_to_a_neighbouring_gaussian_count():
+    """A densifying model renders a different N every step: the histories are keyed by the power-of-two bucket of N and
+    hold duplicates PER GAUSSIAN, so a call with 25 % more Gaussians than the last one is already device-sized — and
+    gives the lists of the read-back flow."""
+    from generativedensification_amd import rasterizer as R
+    from generativedensification_amd.camera import orbit_cameras
+    from generativedensification_amd.renderer import Renderer
+    from generativedensification_amd.synthetic import make_scene
+    dev = torch.device(DEV)
+    V, H, W, N = 2, 160, 208, 50_000
+    scene = make_scene(N, 37, sh_degree=1, sigma0=(0.01, 0.002), device=dev)
+    cams = orbit_cameras(V, W, H, device=dev)
+    sets = [Renderer(sh_degree=1).set_rasterizer(c, device=dev).raster_settings for c in cams]
+
+    def run(n):
+        with torch.no_grad():
+            colors, _, _, _, states, _, _ = R._forward_views_impl(
+                scene["centers"][:n], torch.empty(0, 4, device=dev), scene["shs"][:n], scene["opacity"][:n],
+                scene["scales"][:n], scene["rotations"][:n], tuple(sets), R.RAW_ALL)
+        torch.cuda.synchronize()
+        return colors, states
+
+    assert R.shape_key(40_000, H, W, V) == R.shape_key(N, H, W, V)
+    saved, saved_defer = dict(R._D_HINT), R.DEFER_D
+    try:
+        R.DEFER_D = False
+        c_ref, s_ref = run(N)
+        R.DEFER_D = True
+        R._D_HINT.clear()
+        _, s0 = run(40_000)
+        assert not any(st.bin.d_dev for st in s0)            # first call of the shape: read-back
+        c1, s1 = run(N)
+        assert all(st.bin.d_dev for st in s1)                # 25 % more Gaussians: device-sized from the ratio
+        for v in range(V):
+            a, b = s_ref[v].tensors(), s1[v].tensors()
+            assert a["num_rendered"] == b["num_rendered"]
+            for k in ("keys_sorted", "point_list", "ranges", "n_contrib"):
+                assert torch.equal(a[k], b[k]), k
+            assert torch.equal(c_ref[v], c1[v])
+    finally:
+        R.DEFER_D = saved_defer
+        R._D_HINT.clear()
+        R._D_HINT.update(saved)
