@@ -337,7 +337,9 @@ __global__ __launch_bounds__(GDR_BLOCK) void ranges_kernel(const BinViews vs, in
 // three size classes so that LDS footprint (= workgroups per CU) follows the list length:
 //   short  (L <= 2048): 20 KiB, 4 waves, one workgroup per tile;
 //   medium (L <= 4096): 40 KiB, 8 waves   } small grids that walk the tiles longest-first
-//   long   (L <= 8192 in LDS, beyond that on the global ping-pong buffers): 80 KiB, 16 waves }
+//   long   (L <= 16384 in LDS, beyond that on the global ping-pong buffers): 144 KiB, 16 waves, 16 elements per lane }
+//          (8192 / 80 KiB until object-like scenes were measured: their 10-19 k-entry lists took the global route; C4 shell
+//          963 -> 991, C3 shell 3120 -> 3210, uniform scenes unchanged)
 // (lists are sorted IN PLACE in LDS, tile_sort_pass_lds: 8 bytes per entry)
 // (GDR_TSORT_SMALL / MEDIUM / LARGE = 2048 / 4096 / 8192: gdr_common.h)
 

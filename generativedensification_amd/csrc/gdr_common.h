@@ -98,7 +98,7 @@ struct BinView {
 // tile sort size classes (list entries): one workgroup per tile up to SMALL, small grids walking the longer tiles
 #define GDR_TSORT_SMALL 2048
 #define GDR_TSORT_MEDIUM 4096
-#define GDR_TSORT_LARGE 8192
+#define GDR_TSORT_LARGE 16384
 struct BinViews { BinView v[GDR_MAX_VIEWS]; };
 void fill_bin_views(BinViews* vs, int V, const gdr_geom* geoms, const gdr_binning* bins, const gdr_image* imgs,
                     const uint64_t* D, const int32_t* const* radii);

@@ -677,8 +677,8 @@ def test_tiny_and_odd_image_sizes_both_paths(oracle_built, H, W):
 
 @pytest.mark.parametrize("n,band", [(30_000, 0.7), (70_000, 0.0), (50_000, 1.0), (90_000, 1.0)])
 def test_long_tile_lists_bucket_and_band_cases(oracle_built, n, band):
-    """Tile lists of 30k-70k entries (far beyond the 8192-entry LDS capacity of the per-tile depth sort).  `band` = share
-    of the Gaussians squeezed into a depth band ~1e-5 wide: 0.7 puts > 8192 entries into ONE of the 256 top-digit buckets
+    """Tile lists of 30k-70k entries (far beyond the 16384-entry LDS capacity of the per-tile depth sort).  `band` = share
+    of the Gaussians squeezed into a depth band ~1e-5 wide: 0.7 puts > 16384 entries into ONE of the 256 top-digit buckets
     (finished by the global LSD passes) next to ordinary buckets (sorted in LDS chunks); 1.0 is a list whose whole depth
     span is a few hundred float steps; 0.0 is the plain spread-out case.  Sorted list and ranges bit-exact."""
     case = U.make_case(n, 48, 48, 41, deg=0, sigma0=(0.01,))
@@ -801,7 +801,7 @@ def test_cut_tile_lists_give_the_gradients_of_the_uncut_walk(oracle_built):
 
 
 def test_one_tile_with_a_very_long_list_takes_the_global_sort_path(oracle_built):
-    """20k Gaussians stacked on one spot: a single tile list far beyond the 8192-entry LDS classes of the per-tile
+    """20k Gaussians stacked on one spot: a single tile list beyond the 16384-entry LDS classes of the per-tile
     depth sort (tile_sort_long's global ping-pong), equal depths included; sorted list bit-exact, image within tolerance."""
     case = U.make_case(20_000, 48, 48, 37, deg=0, sigma0=(0.01,))
     case["means3D"] = (case["means3D"] * 0.02).contiguous()          # all inside one or two tiles at the image centre
