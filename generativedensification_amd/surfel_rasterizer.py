@@ -275,7 +275,7 @@ def _surfel_forward_views_impl(ctx, means3D, means2D, sh, opacities, scales, rot
                 ready.record(main)
                 for fs in fstreams[1:]:
                     fs.wait_event(ready)
-            readback = _R._CountReadback(counters)
+            readback = _R._CountReadback(counters, fstreams[-1])
             cap = _R._d_capacity(key, N) if N > 0 else None
             tiles_of = lambda st: ((st.W + 15) // 16) * ((st.H + 15) // 16)
             stats, hints = _R._launch_stats(key, V)
