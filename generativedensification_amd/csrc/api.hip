@@ -99,7 +99,7 @@ static size_t carve_binning(void* base, uint64_t D, gdr_binning* b) {
     t.reserved0 = 0;
     t.d_dev = nullptr;
     t.stats_out = nullptr;
-    t.hint_long = t.hint_medium = t.hint_no_deep = t.reserved1 = 0;
+    t.hint_long = t.hint_medium = t.hint_no_deep = t.grad_rec_cleared = 0;
     t.seg_len = GDR_DEFAULT_SEG_LEN;  // callers may raise it (a multiple of 256) or set 0 after carving (include/gdr.h)
     t.seg_cap = t.seg_len ? (int32_t)(D / (uint64_t)t.seg_len + 1) : 0;
     t.seg_extra = c.take<uint32_t>(2 * (size_t)(t.seg_cap ? t.seg_cap : 1));
@@ -342,7 +342,7 @@ int gdr_render_backward_loss(const gdr_settings* s, int32_t N, const gdr_geom* g
     }
     if (N <= 0) return GDR_OK;
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(grad_rec, 0, (size_t)N * 16 * sizeof(float), st);
+    hipError_t e = bin->grad_rec_cleared ? hipSuccess : hipMemsetAsync(grad_rec, 0, (size_t)N * 16 * sizeof(float), st);
     if (e != hipSuccess) return hip_fail("memset gradient records", e);
     e = launch_render_bwd_loss(s, geom, bin, img, color, target, w_depth, w_alpha, g, grad_rec, st);
     if (e != hipSuccess) return hip_fail("render_bwd_loss", e);
@@ -461,7 +461,7 @@ int gdr_render_backward(const gdr_settings* s, int32_t N, const gdr_geom* geom, 
     }
     if (N <= 0) return GDR_OK;
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(grad_rec, 0, (size_t)N * 16 * sizeof(float), st);
+    hipError_t e = bin->grad_rec_cleared ? hipSuccess : hipMemsetAsync(grad_rec, 0, (size_t)N * 16 * sizeof(float), st);
     if (e != hipSuccess) return hip_fail("memset gradient records", e);
     gdr_grad_outputs go;
     memset(&go, 0, sizeof(go));
@@ -778,7 +778,7 @@ int gsr_render_backward(const gdr_settings* s, int32_t N, const gdr_geom* geom, 
     }
     if (N <= 0) return GDR_OK;
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(grad_rec, 0, (size_t)N * GSR_GRAD_FLOATS * sizeof(float), st);
+    hipError_t e = bin->grad_rec_cleared ? hipSuccess : hipMemsetAsync(grad_rec, 0, (size_t)N * GSR_GRAD_FLOATS * sizeof(float), st);
     if (e != hipSuccess) return hip_fail("memset gradient records", e);
     e = launch_surfel_render_bwd(s, geom, bin, img, gin, grad_rec, st);
     if (e != hipSuccess) return hip_fail("surfel_render_bwd", e);

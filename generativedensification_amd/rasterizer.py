@@ -242,6 +242,17 @@ class _SideViews:
             for sd in self.side + ([self.k9] if self.k9 is not None else []):
                 sd.wait_event(ready)
 
+    @staticmethod
+    def k7_streams(dev, n, H, W):
+        """The torch stream K7 of each of n views will run on (what __init__ sets up), or None: caller's stream only."""
+        ns = side_count(H, W) if BWD_STREAMS is None else BWD_STREAMS
+        if not (RENDER_SIDE and ns > 0 and n > 1):
+            return None
+        group = max(1, min(BWD_GROUP, L.GDR_MAX_VIEWS))
+        pipelined = n > group and group < L.GDR_MAX_VIEWS
+        side = _view_streams(dev, 3)[:min(ns, 2)] if pipelined else _view_streams(dev, min(ns, n))
+        return [side[k % len(side)] for k in range(n)]
+
     def groups(self):
         """(first view, views) of every K9 launch."""
         step = self.group if self.pipelined else L.GDR_MAX_VIEWS
@@ -377,6 +388,38 @@ def backward_raw(st: _State, keep, raster_settings, radii, grad_color, grad_dept
                                  C.byref(st.img), st.D, _ptr(radii), C.byref(gin), C.byref(gout),
                                  _stream()), "gdr_backward")
     return g
+
+
+EARLY_CLEAR = _os.environ.get("GDR_EARLY_CLEAR", "1") != "0"
+
+
+def _early_records(ctx, dev, V, N, H, W, floats):
+    """Gradient records of the V views (V, N * floats), zero-filled NOW — at the end of the forward — on the streams their
+    K7 will run on, behind whatever those streams still have to do: the clear (64 B per Gaussian and view, 130 us of HBM
+    time per C4 step) then runs under the tail of the forward, the loss and autograd's hand-over instead of in front of
+    every K7.  Only with side streams (otherwise the clear would sit between the forward and the loss) and only if a
+    gradient was asked for; ctx.recs is consumed by the first backward (a second one clears its own)."""
+    ctx.recs = None
+    if not (EARLY_CLEAR and N > 0 and any(ctx.needs_input_grad[:6])):
+        return
+    streams = _SideViews.k7_streams(dev, V, H, W)
+    if streams is None:
+        return
+    recs = torch.empty(V, N * floats, dtype=torch.float32, device=dev)
+    for v in range(V):
+        with torch.cuda.stream(streams[v]):
+            recs[v].zero_()
+    ctx.recs = recs
+
+
+def _take_records(ctx, lo, n, N, floats, dev):
+    """(records of views [lo, lo + n), already cleared?) for one K9 group of a backward."""
+    if getattr(ctx, "recs", None) is not None and lo + n <= ctx.recs.shape[0]:
+        recs = ctx.recs[lo:lo + n]
+        if lo + n == ctx.recs.shape[0]:
+            ctx.recs = None
+        return recs, 1
+    return torch.empty(n, max(N, 1) * floats, dtype=torch.float32, device=dev), 0
 
 
 def _save_inputs(ctx, keep, n=7):
@@ -720,6 +763,7 @@ class _RenderViews(torch.autograd.Function):
         _save_inputs(ctx, keep)
         ctx.radii, ctx.in_dtypes, ctx.means2D_shape = radii, in_dtypes, tuple(means2D.shape)
         ctx.mark_non_differentiable(radii)
+        _early_records(ctx, means3D.device, len(states), states[0].N, states[0].H, states[0].W, 16)
         return (radii, *colors, *depths, *alphas)
 
     @staticmethod
@@ -749,12 +793,13 @@ class _RenderViews(torch.autograd.Function):
             sets = [_settings_struct(rs, dev, keep2) for rs in ctx.settings_list]
             sides = _SideViews(dev, V, H, W)  # after every torch-side preparation (the side streams wait for this point)
             for lo, n in sides.groups():
-                recs = torch.empty(n, max(N, 1) * 16, **f32)  # one 64-byte gradient record per Gaussian per view
+                recs, cleared = _take_records(ctx, lo, n, N, 16, dev)  # one 64-byte gradient record per Gaussian per view
                 s_arr = (L.GdrSettings * n)(*sets[lo:lo + n])
                 g_arr = (L.GdrGeom * n)()
                 for k in range(n):
                     v = lo + k
                     st = states[v]
+                    st.bin.grad_rec_cleared = cleared
                     g_arr[k] = st.geom
                     g_arr[k].cov3D = states[0].geom.cov3D
                     gc, gd, ga = grads_in[v]
@@ -803,6 +848,7 @@ class _RenderViewsLoss(torch.autograd.Function):
         ctx.radii, ctx.in_dtypes, ctx.means2D_shape = radii, in_dtypes, tuple(means2D.shape)
         ctx.colors, ctx.targets, ctx.w = colors, targets, (float(w_depth), float(w_alpha))
         ctx.mark_non_differentiable(radii)
+        _early_records(ctx, dev, V, states[0].N, states[0].H, states[0].W, 16)
         return losses, radii
 
     @staticmethod
@@ -823,12 +869,13 @@ class _RenderViewsLoss(torch.autograd.Function):
             sets = [_settings_struct(rs, dev, keep2) for rs in ctx.settings_list]
             sides = _SideViews(dev, V, states[0].H, states[0].W)  # after every torch-side preparation (the side streams wait for this point)
             for lo, n in sides.groups():
-                recs = torch.empty(n, max(N, 1) * 16, **f32)
+                recs, cleared = _take_records(ctx, lo, n, N, 16, dev)
                 s_arr = (L.GdrSettings * n)(*sets[lo:lo + n])
                 g_arr = (L.GdrGeom * n)()
                 for k in range(n):
                     v = lo + k
                     st = states[v]
+                    st.bin.grad_rec_cleared = cleared
                     g_arr[k] = st.geom
                     g_arr[k].cov3D = states[0].geom.cov3D
                     L.check(lib.gdr_render_backward_loss(C.byref(s_arr[k]), N, C.byref(g_arr[k]), C.byref(st.bin),

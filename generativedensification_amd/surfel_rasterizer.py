@@ -317,6 +317,10 @@ def _surfel_forward_views_impl(ctx, means3D, means2D, sh, opacities, scales, rot
         _R._save_inputs(ctx, keep)
         ctx.means2D_shape, ctx.in_dtypes, ctx.V = tuple(means2D.shape), in_dtypes, V
         ctx.mark_non_differentiable(radii)
+        if same:   # (the records of the fused backward: cleared now, under the tail of the forward — rasterizer._early_records)
+            _R._early_records(ctx, dev, V, N, H, W, L.GSR_GRAD_FLOATS)
+        else:
+            ctx.recs = None
         return radii, colors, allmaps
 
 
@@ -356,11 +360,12 @@ class _RenderSurfelViews(torch.autograd.Function):
                     gins.append(L.GsrGradInputs(gc.data_ptr(), _ptr(ga)))
                 sides = _R._SideViews(dev, V, ctx.states[0].H, ctx.states[0].W)
                 for lo, n in sides.groups():   # K7s per view, K9s per group behind its views' K7s (rasterizer._SideViews)
-                    recs = torch.empty(n, max(N, 1) * L.GSR_GRAD_FLOATS, **f32)
+                    recs, cleared = _R._take_records(ctx, lo, n, N, L.GSR_GRAD_FLOATS, dev)
                     s_arr = (L.GdrSettings * n)(*sets[lo:lo + n])
                     g_arr = (L.GdrGeom * n)()
                     for k in range(n):
                         st = ctx.states[lo + k]
+                        st.bin.grad_rec_cleared = cleared
                         g_arr[k] = st.geom
                         L.check(lib.gsr_render_backward(C.byref(s_arr[k]), N, C.byref(g_arr[k]), C.byref(st.bin),
                                                         C.byref(st.img), C.byref(gins[lo + k]), recs[k].data_ptr(),
@@ -454,7 +459,7 @@ class _RenderSurfelViewsLoss(torch.autograd.Function):
             sets = [_settings_struct(rs, dev, keep2) for rs in ctx.settings_list]
             sides = _R._SideViews(dev, V, H, W)  # after every torch-side preparation
             for lo, n in sides.groups():
-                recs = torch.empty(n, max(N, 1) * L.GSR_GRAD_FLOATS, **f32)
+                recs, cleared = _R._take_records(ctx, lo, n, N, L.GSR_GRAD_FLOATS, dev)
                 dcs = [torch.empty(3, H, W, **f32) for _ in range(n)]
                 das = [torch.empty(7, H, W, **f32) for _ in range(n)]
                 scr = [torch.empty(9, H, W, **f32) for _ in range(n)]
@@ -463,6 +468,7 @@ class _RenderSurfelViewsLoss(torch.autograd.Function):
                 for k in range(n):
                     v = lo + k
                     st = ctx.states[v]
+                    st.bin.grad_rec_cleared = cleared
                     g_arr[k] = st.geom
                     sv = sides.stream(v)
                     L.check(lib.gsr_view_loss_backward(colors[v].data_ptr(), allmaps[v].data_ptr(), rays[v].data_ptr(),

@@ -169,7 +169,9 @@ typedef struct gdr_binning {
     int32_t hint_long;   /* > 0: workgroups for the tile sort's long class; 0 = sized for the worst case.  Every value >= 1 */
     int32_t hint_medium; /*      is correct (the classes walk their tiles with a grid stride), a wrong one only costs time   */
     int32_t hint_no_deep;/* != 0: the deep forward is not launched; K6 renders every tile the standard way (same images)     */
-    int32_t reserved1;
+    int32_t grad_rec_cleared; /* != 0: the caller has already zero-filled the gradient record it passes to the K7 entry points
+                          * for this view (e.g. early, on a side stream, while the forward still runs): they skip their own
+                          * clear of N*64 bytes */
 } gdr_binning;
 
 /* Image state (upstream "imgBuffer"). */

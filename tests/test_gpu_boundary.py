@@ -431,3 +431,46 @@ def test_history_of_a_shape_carries_over_to_a_neighbouring_gaussian_count():
         R.DEFER_D = saved_defer
         R._D_HINT.clear()
         R._D_HINT.update(saved)
+
+
+@pytest.mark.parametrize("surfel", [False, True])
+def test_second_backward_through_a_node_clears_its_own_records(surfel):
+    """rasterizer._early_records: the gradient records are zero-filled at the end of the forward, on the streams K7 will
+    use, and consumed by the first backward; a second backward through the same node (retain_graph) must not find the
+    first one's sums in them: .grad after two backwards == 2 x .grad after one."""
+    from generativedensification_amd.camera import build_rays, orbit_cameras
+    from generativedensification_amd.synthetic import make_scene, make_targets
+    dev = torch.device(DEV)
+    V, H, W, N = 3, 128, 160, 20_000
+    scene = make_scene(N, 43, sh_degree=1, sigma0=(0.01, 0.003), device=dev)
+    if surfel:
+        scene["scales"] = scene["scales"][:, :2].contiguous()
+    cams = orbit_cameras(V, W, H, device=dev)
+    targets = make_targets(V, H, W, 3).to(dev).permute(0, 3, 1, 2).contiguous()
+    if surfel:
+        from generativedensification_amd.renderer_2dgs import Renderer
+        r = Renderer(sh_degree=1)
+        rays = [build_rays(torch.inverse(c.world_view_transform.T.cpu()), 0.75, 0.75, H, W).to(dev) for c in cams]
+    else:
+        from generativedensification_amd.renderer import Renderer
+        r = Renderer(sh_degree=1, white_background=True)
+        r.set_bg_color(torch.ones(3, device=dev))
+    for fused_loss in (True, False):
+        grads = []
+        for times in (1, 2):
+            p = {k: v.clone().requires_grad_(True) for k, v in scene.items()}
+            a = (p["centers"], p["shs"], p["opacity"], p["scales"], p["rotations"], dev)
+            if fused_loss:
+                lv = r.render_views_loss(cams, rays, None, targets, *a) if surfel else r.render_views_loss(cams, None, targets, *a)
+            else:
+                outs = r.render_views(cams, rays, None, *a) if surfel else r.render_views(cams, None, *a)
+                lv = torch.stack([((o["image"].permute(2, 0, 1) - targets[j]) ** 2).mean() for j, o in enumerate(outs)])
+            loss = lv.sum()
+            for t in range(times):
+                loss.backward(retain_graph=t + 1 < times)
+            torch.cuda.synchronize()
+            grads.append({k: v.grad.cpu().numpy() for k, v in p.items()})
+        for k in grads[0]:
+            ref = 2.0 * grads[0][k]
+            tol = 1e-4 * np.abs(ref) + 1e-6 * np.abs(ref).max()
+            assert (np.abs(grads[1][k] - ref) > tol).mean() < 1e-4, (fused_loss, k)
