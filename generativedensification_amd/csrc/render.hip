@@ -110,7 +110,9 @@ __device__ __forceinline__ void block_masks(const SliceLds& s, int g, float XA, 
 // 0xFFFFFFFF for uncut tiles; seg_extra = (tile, segment) of every segment but the last of its tile (K7: the last one
 // is walked by the tile's own workgroup); seg_count = {rows of seg_extra, slots}.  Sum nseg <= 2 D / seg_len: the
 // tables (capacity seg_cap rows, 2 * seg_cap slots) cannot overflow; the guards are belt and braces.
-__global__ __launch_bounds__(GDR_BLOCK) void tile_order_kernel(const BinViews vs, int ntiles) {
+#define GDR_ORDER_THREADS 1024   // one workgroup per view, sixteen waves: every phase below is a few trips over the tiles
+__global__ __launch_bounds__(GDR_ORDER_THREADS) void tile_order_kernel(const BinViews vs, int ntiles) {
+    constexpr int TB = GDR_ORDER_THREADS, NWV = TB / GDR_WAVE;
     const BinView& bv = vs.v[blockIdx.y];   // one workgroup per view
     const uint2* __restrict__ ranges = bv.ranges;
     uint32_t* __restrict__ order = bv.tile_order;
@@ -120,33 +122,33 @@ __global__ __launch_bounds__(GDR_BLOCK) void tile_order_kernel(const BinViews vs
     uint32_t* __restrict__ seg_count = bv.seg_count;
     const uint32_t deep_max_busy = bv.deep_max_busy;
     __shared__ uint32_t cnt[GDR_ORDER_BUCKETS];
-    __shared__ uint32_t wsum[GDR_BLOCK / GDR_WAVE];
-    for (int k = threadIdx.x; k < GDR_ORDER_BUCKETS; k += GDR_BLOCK) cnt[k] = 0;
+    __shared__ uint32_t wsum[NWV];
+    for (int k = threadIdx.x; k < GDR_ORDER_BUCKETS; k += TB) cnt[k] = 0;
     __syncthreads();
-    for (int t = threadIdx.x; t < ntiles; t += GDR_BLOCK) {
+    for (int t = threadIdx.x; t < ntiles; t += TB) {
         const uint2 r = ranges[t];
         const uint32_t b = min((r.y - r.x) >> 4, (uint32_t)GDR_ORDER_BUCKETS - 1u);
         atomicAdd(&cnt[GDR_ORDER_BUCKETS - 1 - b], 1u);  // bucket 0 = longest lists
     }
     __syncthreads();
-    // exclusive scan of the 1024 buckets: 4 per thread
-    uint32_t v[4], s = 0;
+    // exclusive scan of the 1024 buckets: one per thread
+    static_assert(GDR_ORDER_BUCKETS == TB, "one bucket per thread");
+    {
+        const uint32_t s = cnt[threadIdx.x];
+        uint32_t incl = s;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { v[k] = cnt[threadIdx.x * 4 + k]; s += v[k]; }
-    uint32_t incl = s;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t t = __shfl_up(incl, off, 64);
-        if ((int)lane_id() >= off) incl += t;
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t t = __shfl_up(incl, off, 64);
+            if ((int)lane_id() >= off) incl += t;
+        }
+        if (lane_id() == 63) wsum[threadIdx.x >> 6] = incl;
+        __syncthreads();
+        uint32_t base = incl - s;
+        for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) base += wsum[w];
+        cnt[threadIdx.x] = base;
     }
-    if (lane_id() == 63) wsum[threadIdx.x >> 6] = incl;
     __syncthreads();
-    uint32_t base = incl - s;
-    for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) base += wsum[w];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { cnt[threadIdx.x * 4 + k] = base; base += v[k]; }
-    __syncthreads();
-    for (int t = threadIdx.x; t < ntiles; t += GDR_BLOCK) {
+    for (int t = threadIdx.x; t < ntiles; t += TB) {
         const uint2 r = ranges[t];
         const uint32_t b = min((r.y - r.x) >> 4, (uint32_t)GDR_ORDER_BUCKETS - 1u);
         order[atomicAdd(&cnt[GDR_ORDER_BUCKETS - 1 - b], 1u)] = (uint32_t)t;
@@ -154,7 +156,7 @@ __global__ __launch_bounds__(GDR_BLOCK) void tile_order_kernel(const BinViews vs
     // what the caller may feed back into the next call of this scene shape (gdr_binning.stats_out): tiles in the tile
     // sort's long / medium class, busy tiles (lists of >= 64 entries)
     uint32_t n_long = 0u, n_medium = 0u, n_busy = 0u;
-    for (int t = threadIdx.x; t < ntiles; t += GDR_BLOCK) {
+    for (int t = threadIdx.x; t < ntiles; t += TB) {
         const uint2 r = ranges[t];
         const uint32_t len = r.y - r.x;
         n_long += len > (uint32_t)GDR_TSORT_MEDIUM ? 1u : 0u;
@@ -166,9 +168,10 @@ __global__ __launch_bounds__(GDR_BLOCK) void tile_order_kernel(const BinViews vs
         n_long += __shfl_xor(n_long, off, 64); n_medium += __shfl_xor(n_medium, off, 64); n_busy += __shfl_xor(n_busy, off, 64);
     }
     __syncthreads();   // (cnt is free again: the ordering phase is over)
-    if (lane_id() == 0) { cnt[threadIdx.x >> 6] = n_long; cnt[4 + (threadIdx.x >> 6)] = n_medium; cnt[8 + (threadIdx.x >> 6)] = n_busy; }
+    if (lane_id() == 0) { cnt[threadIdx.x >> 6] = n_long; cnt[NWV + (threadIdx.x >> 6)] = n_medium; cnt[2 * NWV + (threadIdx.x >> 6)] = n_busy; }
     __syncthreads();
-    n_long = cnt[0] + cnt[1] + cnt[2] + cnt[3]; n_medium = cnt[4] + cnt[5] + cnt[6] + cnt[7]; n_busy = cnt[8] + cnt[9] + cnt[10] + cnt[11];
+    n_long = n_medium = n_busy = 0u;
+    for (int w = 0; w < NWV; ++w) { n_long += cnt[w]; n_medium += cnt[NWV + w]; n_busy += cnt[2 * NWV + w]; }
     const uint32_t deep = (seg_base != nullptr && seg_len > 0 && n_busy <= deep_max_busy) ? 1u : 0u;
     if (threadIdx.x == 0 && bv.stats_out) {
         bv.stats_out[0] = n_long; bv.stats_out[1] = n_medium; bv.stats_out[2] = deep; bv.stats_out[3] = n_busy;
@@ -185,8 +188,8 @@ __global__ __launch_bounds__(GDR_BLOCK) void tile_order_kernel(const BinViews vs
         // workgroup (one wave per SIMD) and the walk of a long list is latency-bound.
         if (threadIdx.x == 0) seg_count[2] = deep;
     }
-    uint32_t slot_run = 0u, cut_run = 0u;  // uniform running totals over the chunks of 256 tiles
-    for (int t0 = 0; t0 < ntiles; t0 += GDR_BLOCK) {
+    uint32_t slot_run = 0u, cut_run = 0u;  // uniform running totals over the chunks of TB tiles
+    for (int t0 = 0; t0 < ntiles; t0 += TB) {
         const int t = t0 + (int)threadIdx.x;
         uint32_t nseg = 0u;
         if (t < ntiles) {
@@ -205,7 +208,7 @@ __global__ __launch_bounds__(GDR_BLOCK) void tile_order_kernel(const BinViews vs
         if (lane_id() == 63) { wsum[threadIdx.x >> 6] = inc; cnt[threadIdx.x >> 6] = cinc; }
         __syncthreads();
         uint32_t sbase = inc - nseg, cbase = cinc - cut, stot = 0u, ctot = 0u;
-        for (uint32_t w = 0; w < GDR_BLOCK / GDR_WAVE; ++w) {
+        for (uint32_t w = 0; w < (uint32_t)NWV; ++w) {
             if (w < (threadIdx.x >> 6)) { sbase += wsum[w]; cbase += cnt[w]; }
             stot += wsum[w]; ctot += cnt[w];
         }
@@ -918,7 +921,7 @@ __global__ __launch_bounds__(GDR_BLOCK) void render_bwd_kernel(
 }  // namespace
 
 hipError_t launch_tile_order_views(const BinViews& vs, int V, int ntiles, hipStream_t st) {
-    GDR_LAUNCH(GDR_K_TILE_ORDER, tile_order_kernel, dim3(1, V), dim3(GDR_BLOCK), st, vs, ntiles);
+    GDR_LAUNCH(GDR_K_TILE_ORDER, tile_order_kernel, dim3(1, V), dim3(GDR_ORDER_THREADS), st, vs, ntiles);
     return hipGetLastError();
 }
 
