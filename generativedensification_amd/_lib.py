@@ -12,12 +12,14 @@ import os
 import torch  # noqa: F401  (loads the HIP runtime first — see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# GDR_LIB_PATH: developer override (ablation builds); the product default is the in-tree library
+# GDR_LIB_PATH: developer override (A/B of two builds of the library); the product default is the in-tree library.  A
+# library whose gdr_build_tag() is not "release" (a measurement build) is refused unless GDR_ALLOW_EXPERIMENTAL_LIB=1.
 LIB_PATH = os.environ.get("GDR_LIB_PATH") or os.path.join(_HERE, "lib", "libgdr_hip.so")
 
 GDR_OK = 0
 GDR_IN_RAW_OPACITY, GDR_IN_RAW_SCALES, GDR_IN_RAW_ROTATIONS, GDR_IN_NO_DEPTH_TO_MEAN = 1, 2, 4, 8
 GDR_MAX_VIEWS = 8
+GDR_DEFAULT_SEG_LEN = 256
 GDR_ERR_WORKSPACE = -4
 
 
@@ -105,6 +107,9 @@ _PROTOS = {
     "gdr_image_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
     "gdr_geom_carve": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(GdrGeom)]),
     "gdr_binning_carve": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(GdrBinning)]),
+    "gdr_binning_bytes_seg": (C.c_size_t, [C.c_uint64, C.c_int32]),
+    "gdr_binning_carve_seg": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int32, C.POINTER(GdrBinning)]),
+    "gdr_build_tag": (C.c_char_p, []),
     "gdr_image_carve": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(GdrImage)]),
     "gdr_preprocess_forward": (C.c_int, [C.POINTER(GdrSettings), C.POINTER(GdrInputs), C.POINTER(GdrGeom),
                                          C.c_void_p, C.POINTER(C.c_uint32), C.c_void_p]),
@@ -209,8 +214,12 @@ def load():
             fn = getattr(lib, name)  # AttributeError if the symbol is missing
             fn.restype = res
             fn.argtypes = args
-        if lib.gdr_abi_version() != 11:
+        if lib.gdr_abi_version() != 12:
             raise RuntimeError("libgdr_hip.so ABI version mismatch")
+        tag = (lib.gdr_build_tag() or b"").decode()
+        if tag != "release" and os.environ.get("GDR_ALLOW_EXPERIMENTAL_LIB") != "1":
+            raise RuntimeError(f"{LIB_PATH} is a '{tag}' build of the library (measurement-only, results may be wrong); "
+                               "set GDR_ALLOW_EXPERIMENTAL_LIB=1 to load it anyway")
         _lib = lib
     return _lib
 

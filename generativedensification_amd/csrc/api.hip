@@ -83,7 +83,7 @@ static size_t carve_geom(void* base, int64_t N, gdr_geom* g) {
     return c.off;
 }
 
-static size_t carve_binning(void* base, uint64_t D, gdr_binning* b) {
+static size_t carve_binning(void* base, uint64_t D, gdr_binning* b, int32_t seg_len = GDR_DEFAULT_SEG_LEN) {
     Carver c(base);
     gdr_binning t;
     const size_t d = (size_t)(D > 0 ? D : 1);
@@ -100,7 +100,7 @@ static size_t carve_binning(void* base, uint64_t D, gdr_binning* b) {
     t.d_dev = nullptr;
     t.stats_out = nullptr;
     t.hint_long = t.hint_medium = t.hint_no_deep = t.grad_rec_cleared = 0;
-    t.seg_len = GDR_DEFAULT_SEG_LEN;  // callers may raise it (a multiple of 256) or set 0 after carving (include/gdr.h)
+    t.seg_len = seg_len > 0 ? (seg_len + GDR_BLOCK - 1) / GDR_BLOCK * GDR_BLOCK : 0;  // callers may raise it (a multiple of 256) or set 0 after carving (include/gdr.h)
     t.seg_cap = t.seg_len ? (int32_t)(D / (uint64_t)t.seg_len + 1) : 0;
     t.seg_extra = c.take<uint32_t>(2 * (size_t)(t.seg_cap ? t.seg_cap : 1));
     t.seg_count = c.take<uint32_t>(4);
@@ -173,6 +173,10 @@ using namespace gdr;
 extern "C" {
 
 int gdr_abi_version(void) { return GDR_ABI_VERSION; }
+#ifndef GDR_BUILD_TAG
+#define GDR_BUILD_TAG "release"
+#endif
+const char* gdr_build_tag(void) { return GDR_BUILD_TAG; }
 const char* gdr_last_error(void) { return g_err; }
 
 size_t gdr_geom_bytes(int32_t N) { return carve_geom(nullptr, N, nullptr); }
@@ -187,6 +191,12 @@ int gdr_geom_carve(void* base, int32_t N, gdr_geom* out) {
 int gdr_binning_carve(void* base, uint64_t D, gdr_binning* out) {
     if (!base || !out || ((uintptr_t)base & 255u)) { set_error("binning base NULL/unaligned", hipSuccess); return GDR_ERR_INVALID_ARG; }
     carve_binning(base, D, out);
+    return GDR_OK;
+}
+size_t gdr_binning_bytes_seg(uint64_t D, int32_t seg_len) { return carve_binning(nullptr, D, nullptr, seg_len); }
+int gdr_binning_carve_seg(void* base, uint64_t D, int32_t seg_len, gdr_binning* out) {
+    if (!base || !out || ((uintptr_t)base & 255u) || seg_len < 0) { set_error("binning base NULL/unaligned or seg_len < 0", hipSuccess); return GDR_ERR_INVALID_ARG; }
+    carve_binning(base, D, out, seg_len);
     return GDR_OK;
 }
 int gdr_image_carve(void* base, int32_t H, int32_t W, gdr_image* out) {
@@ -328,7 +338,7 @@ int gdr_topk_absgrad(int32_t N, const float* grad, const uint8_t* candidates, in
                      int32_t* indices, void* stream) {
     if (N < 0 || k < 0 || (N > 0 && (!grad || !workspace || !mask))) { set_error("topk_absgrad: bad argument", hipSuccess); return GDR_ERR_INVALID_ARG; }
     if (N == 0) return GDR_OK;
-    hipError_t e = launch_topk_absgrad(N, grad, candidates, k, k >= N, workspace, mask, indices, (hipStream_t)stream);
+    hipError_t e = launch_topk_absgrad(N, grad, candidates, k, workspace, mask, indices, (hipStream_t)stream);
     if (e != hipSuccess) return hip_fail("topk_absgrad", e);
     return GDR_OK;
 }

@@ -341,7 +341,7 @@ __global__ __launch_bounds__(GDR_BLOCK) void ranges_kernel(const BinViews vs, in
 //          (8192 / 80 KiB until object-like scenes were measured: their 10-19 k-entry lists took the global route; C4 shell
 //          963 -> 991, C3 shell 3120 -> 3210, uniform scenes unchanged)
 // (lists are sorted IN PLACE in LDS, tile_sort_pass_lds: 8 bytes per entry)
-// (GDR_TSORT_SMALL / MEDIUM / LARGE = 2048 / 4096 / 8192: gdr_common.h)
+// (GDR_TSORT_SMALL / MEDIUM / LARGE = 2048 / 4096 / 16384: gdr_common.h)
 
 struct TileSortBufs {
     uint32_t *kA, *vA, *kB, *vB;
@@ -780,7 +780,7 @@ hipError_t launch_tile_sort_views(const BinViews& vs, int V, int in, int tiles, 
     // at 32 M; medium and long merged into one 16-wave class: C4 1251 -> 1231, C3 2924 -> 2897, shells +1 %; short and
     // medium merged into one class per tile (4 waves x 16 elements per lane, 36 KB): C3 shell +4.7 %, C2 -4.5 %; (8 waves,
     // 40 KB): C2 -2.3 %, others +-0
-    // the long / medium classes are usually sparse or empty, and every one of their workgroups needs 80 / 40 KB of LDS on
+    // the long / medium classes are usually sparse or empty, and every one of their workgroups needs 144 / 40 KB of LDS on
     // a CU: with a hint from the previous call of this scene shape (gdr_binning.hint_*) only as many as there were tiles
     int g_long = tiles < 256 ? tiles : 256, g_medium = tiles < 512 ? tiles : 512;
     const int h_long = merged_hint(vs, V, true), h_medium = merged_hint(vs, V, false);

@@ -118,7 +118,7 @@ hipError_t launch_render_fwd_loss(const gdr_settings* s, const gdr_geom* g, cons
 hipError_t launch_render_fwd_lossgrad(const gdr_settings* s, const gdr_geom* g, const gdr_binning* bin,
                                       const gdr_image* img, const float* target, float go_scale, float* loss,
                                       float* dL_dcolor, hipStream_t st);
-hipError_t launch_topk_absgrad(int N, const float* grad, const uint8_t* cand, int k, bool all, void* workspace,
+hipError_t launch_topk_absgrad(int N, const float* grad, const uint8_t* cand, int k, void* workspace,
                                uint8_t* mask, int32_t* idx, hipStream_t st);
 size_t select_workspace_bytes();
 hipError_t launch_render_bwd_loss(const gdr_settings* s, const gdr_geom* g, const gdr_binning* bin,

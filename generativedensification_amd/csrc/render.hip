@@ -36,14 +36,6 @@
 #include "gdr_common.h"
 #include "render_common.h"
 
-// GDR_ABLATE (measurement builds only, scripts/ablate_build.sh -> build/libgdr_abl<k>.so; results are WRONG):
-//   1 K7 without the atomics            2 K7 without row reduction + atomics     3 K6/K7 gather records by list
-//   4 K6/K7 stage the slices but skip the inner loops                              position instead of by sorted id
-//   5 K7 without exp/rcp (constants)    6 K6/K7 inner loop without the LDS entry reads (registers reused)
-#ifndef GDR_ABLATE
-#define GDR_ABLATE 0
-#endif
-
 namespace gdr {
 
 namespace {
@@ -302,8 +294,7 @@ __global__ __launch_bounds__(GDR_BLOCK) void render_fwd_kernel(
         float4 r_xe = make_float4(0.f, 0.f, 0.f, 0.f), r_co = r_xe, r_cd = r_xe;
         bool r_valid = (int)threadIdx.x < count;
         if (r_valid) {
-            uint32_t id = point_list[first + threadIdx.x];
-            if (GDR_ABLATE == 3) id = (first + threadIdx.x) & 0xFFFFFu;  // (needs N >= 2^20)
+            const uint32_t id = point_list[first + threadIdx.x];
             const float4 a0 = rec[4 * (size_t)id], a3 = rec[4 * (size_t)id + 3];
             r_xe = make_float4(a0.x, a0.y, a3.x, a3.y); r_co = rec[4 * (size_t)id + 1]; r_cd = rec[4 * (size_t)id + 2];
         }
@@ -318,13 +309,12 @@ __global__ __launch_bounds__(GDR_BLOCK) void render_fwd_kernel(
                 const int nxt = (r + 1) * GDR_BLOCK + (int)threadIdx.x;
                 r_valid = nxt < count;
                 if (r_valid) {
-                    uint32_t id = point_list[first + (uint32_t)nxt];
-                    if (GDR_ABLATE == 3) id = (first + (uint32_t)nxt) & 0xFFFFFu;
+                    const uint32_t id = point_list[first + (uint32_t)nxt];
                     const float4 a0 = rec[4 * (size_t)id], a3 = rec[4 * (size_t)id + 3];
                     r_xe = make_float4(a0.x, a0.y, a3.x, a3.y); r_co = rec[4 * (size_t)id + 1]; r_cd = rec[4 * (size_t)id + 2];
                 }
             }
-            if (live == 0ull || GDR_ABLATE == 4) continue;
+            if (live == 0ull) continue;
             const uint32_t base = (uint32_t)(pos0 + r * GDR_BLOCK) + 1u;
             // this wave's row lists of the slice (compacted, see RowLists)
             int n[4] = {0, 0, 0, 0};
@@ -373,9 +363,9 @@ __global__ __launch_bounds__(GDR_BLOCK) void render_fwd_kernel(
             uint2 q = *reinterpret_cast<const uint2*>(my_list);
             fetch(A, q.x & 0xFFFFu);
             for (int i = 0; i < nmax && !abort; i += 4) {
-                const uint2 qn = *reinterpret_cast<const uint2*>(my_list + i + 4);   // (the lists are 256 long, the slice
-                fetch(B, q.x >> 16);                                                 //  at most 256: i + 4 <= 256 reads
-                composite(A);                                                        //  the next row's list or the pad)
+                const uint2 qn = *reinterpret_cast<const uint2*>(my_list + min(i + 4, GDR_BLOCK - 4));
+                fetch(B, q.x >> 16);    // (read-ahead clamped to this row's own list: the last read repeats entries 252..255,
+                composite(A);           //  which are never composited)
                 fetch(A, q.y & 0xFFFFu);
                 composite(B);
                 fetch(B, q.y >> 16);
@@ -774,7 +764,6 @@ __global__ __launch_bounds__(GDR_BLOCK) void render_bwd_kernel(
     }
     // the staged conic is log2(e) x the true one: fold 1/log2(e) = ln 2 into the pixel->NDC factors
     const float kx = 0.5f * (float)W * GDR_LN2, ky = 0.5f * (float)H * GDR_LN2;
-    float abl_sink = 0.f;  // (ablation builds: keeps the arithmetic alive)
 
     // deepest contributor per 4x4 block (row of 16 lanes) and per wave
     int row_last = last_contributor;
@@ -792,7 +781,6 @@ __global__ __launch_bounds__(GDR_BLOCK) void render_bwd_kernel(
     bool r_valid = (int)threadIdx.x < total;
     if (r_valid) {
         r_id = point_list[list_end - 1u - threadIdx.x];
-        if (GDR_ABLATE == 3) r_id = (list_end - 1u - threadIdx.x) & 0xFFFFFu;
         { const float4 a0 = rec[4 * (size_t)r_id], a3 = rec[4 * (size_t)r_id + 3];
           r_xe = make_float4(a0.x, a0.y, a3.x, a3.y); r_co = rec[4 * (size_t)r_id + 1]; r_cd = rec[4 * (size_t)r_id + 2]; }
     }
@@ -806,13 +794,12 @@ __global__ __launch_bounds__(GDR_BLOCK) void render_bwd_kernel(
             r_valid = nxt < total;
             if (r_valid) {
                 r_id = point_list[list_end - 1u - (uint32_t)nxt];
-                if (GDR_ABLATE == 3) r_id = (list_end - 1u - (uint32_t)nxt) & 0xFFFFFu;
                 { const float4 a0 = rec[4 * (size_t)r_id], a3 = rec[4 * (size_t)r_id + 3];
           r_xe = make_float4(a0.x, a0.y, a3.x, a3.y); r_co = rec[4 * (size_t)r_id + 1]; r_cd = rec[4 * (size_t)r_id + 2]; }
             }
         }
         const int top = total - 1 - r * GDR_BLOCK;  // list position of LDS entry e: top - e
-        if (top - (GDR_BLOCK - 1) >= wave_last || GDR_ABLATE == 4) continue;  // whole slice behind every last contributor
+        if (top - (GDR_BLOCK - 1) >= wave_last) continue;  // whole slice behind every last contributor
         // Row sub-lists of the slice's four 64-entry groups, one 64-bit mask per group and lane (all 16 lanes of a row
         // hold the same four masks).  A row walks them back to back at its own pace — rows only re-synchronise at slice
         // boundaries, so a row whose block has few entries in one group does not wait for the others there.
@@ -841,7 +828,7 @@ __global__ __launch_bounds__(GDR_BLOCK) void render_bwd_kernel(
             auto accumulate = [&](const Entry& en) {
                 const float dx = en.m.x - pxf, dy = en.m.y - pyf;
                 const float p2 = gauss_power(dx, dy, en.co.x, en.co.y, en.co.z);
-                const float G = GDR_ABLATE == 5 ? p2 * 0.001f + 0.5f : __builtin_amdgcn_exp2f(p2);
+                const float G = __builtin_amdgcn_exp2f(p2);
                 float alpha = fminf(0.99f, en.co.w * G);
                 alpha = (p2 > 0.f) ? 0.f : alpha;
                 // contributes iff it did in the forward: alpha >= 1/255 and position < last_contributor
@@ -852,7 +839,7 @@ __global__ __launch_bounds__(GDR_BLOCK) void render_bwd_kernel(
                 if (hb == 0ull) return;
                 const float a = hit ? alpha : 0.f;
                 const float hm = hit ? 1.f : 0.f;
-                const float r_oma = GDR_ABLATE == 5 ? 1.f + a : __builtin_amdgcn_rcpf(1.f - a);  // == 1 when a == 0
+                const float r_oma = __builtin_amdgcn_rcpf(1.f - a);  // == 1 when a == 0
                 T = T * r_oma;                                        // transmittance in FRONT of this Gaussian
                 const float w = a * T;
                 const float d0 = en.cd.x - B0, d1 = en.cd.y - B1, d2 = en.cd.z - B2;
@@ -880,16 +867,7 @@ __global__ __launch_bounds__(GDR_BLOCK) void render_bwd_kernel(
                 const float vals[12] = {v_mx, v_my, fabsf(v_mx), fabsf(v_my),
                                         -0.5f * gdx * dx * dL_dG, -gdx * dy * dL_dG, -0.5f * gdy * dy * dL_dG,
                                         w * gD, w * gC0, w * gC1, w * gC2, G * dL_dalpha};
-                float tot;
-                if (GDR_ABLATE == 2) {
-                    tot = 0.f;
-#pragma unroll
-                    for (int k_ = 0; k_ < 12; ++k_) tot += vals[k_];
-                    abl_sink += tot;
-                    return;
-                }
-                tot = row_reduce_scatter12(vals, li);
-                if (GDR_ABLATE == 1) { abl_sink += tot; return; }
+                const float tot = row_reduce_scatter12(vals, li);
                 const bool publish = ((hb >> (16 * row)) & 0xFFFFull) != 0ull;
                 // lanes 0..11 of every row that had a hit add the row totals to the Gaussian's
                 // 64-byte gradient record: one global_atomic_add_f32 instruction, one cache line
@@ -902,7 +880,7 @@ __global__ __launch_bounds__(GDR_BLOCK) void render_bwd_kernel(
             uint2 q = *reinterpret_cast<const uint2*>(my_list);
             fetch(A, q.x & 0xFFFFu);
             for (int i = 0; i < nmax; i += 4) {
-                const uint2 qn = *reinterpret_cast<const uint2*>(my_list + i + 4);
+                const uint2 qn = *reinterpret_cast<const uint2*>(my_list + min(i + 4, GDR_BLOCK - 4));
                 fetch(B, q.x >> 16);
                 accumulate(A);
                 fetch(A, q.y & 0xFFFFu);
@@ -915,7 +893,6 @@ __global__ __launch_bounds__(GDR_BLOCK) void render_bwd_kernel(
             }
         }
     }
-    if (GDR_ABLATE && abl_sink == 12345.678f) grad_rec[0] = abl_sink;
 }
 
 }  // namespace

@@ -168,9 +168,9 @@ __device__ __forceinline__ uint64_t row_select(uint32_t row, uint64_t m0, uint64
 // pre-filled with the null entry so that a row that runs out keeps reading harmless entries) live in LDS, wave-private;
 // the inner loop is a COUNTED loop to the longest row list of the wave: one ds_read_b64 of four indices per four
 // iterations, one v_bfe per iteration.  Rows of a wave re-synchronise only per slice, with no refill logic.
-struct RowLists {
+struct alignas(16) RowLists {
     uint16_t idx[GDR_BLOCK / GDR_WAVE][4][GDR_BLOCK];   // [wave][row][position]
-    uint16_t pad[8];                                     // the read-ahead of the last row's last positions (null entries)
+    uint16_t pad[8];   // (null entries; the read-ahead is clamped to the row's own list: no wave reads another wave's lists)
 };
 
 // pre-fill this wave's four lists with the null entry (2 x 16 bytes per lane = 2 KiB)

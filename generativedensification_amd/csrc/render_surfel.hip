@@ -219,7 +219,7 @@ __global__ __launch_bounds__(GDR_BLOCK) void surfel_render_fwd_kernel(
             uint2 q = *reinterpret_cast<const uint2*>(my_list);
             fetch(A, q.x & 0xFFFFu);
             for (int i = 0; i < nmax && !abort; i += 4) {
-                const uint2 qn = *reinterpret_cast<const uint2*>(my_list + i + 4);
+                const uint2 qn = *reinterpret_cast<const uint2*>(my_list + min(i + 4, GDR_BLOCK - 4));
                 fetch(B, q.x >> 16);
                 composite(A);
                 fetch(A, q.y & 0xFFFFu);
@@ -455,7 +455,7 @@ __global__ __launch_bounds__(GDR_BLOCK) void surfel_render_bwd_kernel(
             uint2 q = *reinterpret_cast<const uint2*>(my_list);
             fetch(A, q.x & 0xFFFFu);
             for (int i = 0; i < nmax; i += 4) {
-                const uint2 qn = *reinterpret_cast<const uint2*>(my_list + i + 4);
+                const uint2 qn = *reinterpret_cast<const uint2*>(my_list + min(i + 4, GDR_BLOCK - 4));
                 fetch(B, q.x >> 16);
                 accumulate(A);
                 fetch(A, q.y & 0xFFFFu);

@@ -167,22 +167,18 @@ SEG_LEN = int(_os.environ["GDR_SEG_LEN"]) if _os.environ.get("GDR_SEG_LEN") else
 DEEP_MAX_BUSY = int(_os.environ["GDR_DEEP_MAX_BUSY"]) if _os.environ.get("GDR_DEEP_MAX_BUSY") else None
 
 
-def _apply_seg_len(bin_struct, D, tiles=None, busy=None):
-    """Host-side policy of the cut lists.  D: duplicates expected in the view; busy: tiles with >= 64 entries in the
-    previous call of the shape (None: unknown).  512-entry segments pay on large images whose tiles are all busy with
-    long lists (C4 +2.5 %, C5 +1.3 % over 256); scenes with few busy tiles (an object in front of a background) or short
-    lists keep the carved 256 (C2 shell +5 %, C5 shell +4 %, C4 shell +1.2 %, C2 +0.5 % over 512)."""
-    if DEEP_MAX_BUSY is not None:
-        bin_struct.deep_max_busy = max(0, int(DEEP_MAX_BUSY))
-    if (SEG_LEN is None and tiles is not None and tiles >= 2000 and 0 < bin_struct.seg_len < 512
-            and D >= 500 * tiles and (busy is None or 2 * busy >= tiles)):
-        bin_struct.seg_len = 512     # (include/gdr.h GDR_DEFAULT_SEG_LEN)
+def _seg_len_for(D, tiles=None, busy=None):
+    """Host-side policy of the cut lists: the segment length a view's binning workspace is carved for
+    (gdr_binning_carve_seg sizes the cut-list tables for it: 80 bytes per duplicate at 256, 40 at 512).  D: duplicates
+    expected in the view; busy: tiles with >= 64 entries in the previous call of the shape (None: unknown).  512-entry
+    segments pay on large images whose tiles are all busy with long lists (C4 +2.5 %, C5 +1.3 % over 256); scenes with
+    few busy tiles (an object in front of a background) or short lists keep 256 (C2 shell +5 %, C5 shell +4 %, C4 shell
+    +1.2 %, C2 +0.5 % over 512)."""
     if SEG_LEN is not None:
-        sl = max(0, int(SEG_LEN)) // 256 * 256
-        if sl and sl >= bin_struct.seg_len > 0:   # only lengths >= the carved one fit the carved tables
-            bin_struct.seg_len = sl
-        elif sl == 0:
-            bin_struct.seg_len = 0
+        return max(0, int(SEG_LEN)) // 256 * 256
+    if tiles is not None and tiles >= 2000 and D >= 500 * tiles and (busy is None or 2 * busy >= tiles):
+        return 512
+    return L.GDR_DEFAULT_SEG_LEN
 
 
 def side_count(H, W):
@@ -406,6 +402,14 @@ def _early_records(ctx, dev, V, N, H, W, floats):
     if streams is None:
         return
     recs = torch.empty(V, N * floats, dtype=torch.float32, device=dev)
+    # `recs` comes from the caller's stream's allocator pool: the block may still be in use by kernels queued on that
+    # stream, and not every K7 stream is one of the forward's streams — each K7 stream waits for this point of the
+    # caller's stream before it touches the block, and the allocator is told about every stream that uses it
+    allocated = torch.cuda.Event()
+    allocated.record(torch.cuda.current_stream())
+    for sd in set(streams):
+        sd.wait_event(allocated)
+        recs.record_stream(sd)
     for v in range(V):
         with torch.cuda.stream(streams[v]):
             recs[v].zero_()
@@ -541,7 +545,7 @@ class _CountReadback:
 # ---- launch-size feedback (gdr_binning.stats_out / hint_*) ----------------------------------------------------
 # The binning stage of a view reports how many tiles fell into the tile sort's long / medium class and whether the deep
 # forward applied; the next call of the same shape sizes those launches from it (empty classes: 1 workgroup instead of
-# 256 / 512 with 80 / 40 KB of LDS each; no deep launch of 3072 workgroups that leave at once).  Results never depend
+# 256 / 512 with 144 / 40 KB of LDS each; no deep launch of 3072 workgroups that leave at once).  Results never depend
 # on it: the classes walk their tiles with a grid stride, and K6 renders every tile the standard way without the deep
 # launch.  The words live in pinned host memory the kernels write directly (4 words per view and shape, kept for the
 # life of the process: the GPU may still be writing when a shape is last used).
@@ -583,14 +587,16 @@ def _launch_stats(key, V):
 def _carve_binning(lib, st, entries, tiles, d_dev=None, stats=None, hints=None):
     """Workspace of one view for `entries` duplicates (exact count, or a capacity with d_dev = the device counter);
     stats / hints: this view's row of the report tensor and the call's launch hints (_launch_stats)."""
-    need = lib.gdr_binning_bytes(entries)
+    seg_len = _seg_len_for(entries if d_dev is None else int(entries / D_SLACK), tiles, None if hints is None else hints[3])
+    need = lib.gdr_binning_bytes_seg(entries, seg_len)
     if st.bin_buf is None or st.bin_buf.numel() < need:
         st.bin_buf = torch.empty(need, dtype=torch.uint8, device=st.geom_buf.device)
-    L.check(lib.gdr_binning_carve(st.bin_buf.data_ptr(), entries, C.byref(st.bin)), "gdr_binning_carve")
+    L.check(lib.gdr_binning_carve_seg(st.bin_buf.data_ptr(), entries, seg_len, C.byref(st.bin)), "gdr_binning_carve_seg")
     st.bin.global_sort = int(_FORCE_GLOBAL_SORT)
     st.bin.d_dev = d_dev
     st.D = entries
-    _apply_seg_len(st.bin, entries if d_dev is None else int(entries / D_SLACK), tiles, None if hints is None else hints[3])
+    if DEEP_MAX_BUSY is not None:
+        st.bin.deep_max_busy = max(0, int(DEEP_MAX_BUSY))
     if hints is not None:
         st.bin.hint_long, st.bin.hint_medium, st.bin.hint_no_deep = hints[:3]
     if stats is not None:

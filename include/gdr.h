@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define GDR_ABI_VERSION 11
+#define GDR_ABI_VERSION 12
 
 #define GDR_OK 0
 #define GDR_ERR_INVALID_ARG (-1)  /* NULL / inconsistent arguments                     */
@@ -219,6 +219,9 @@ typedef struct gdr_grad_outputs {
 /* ---- sizes and carving ---------------------------------------------------------- */
 int gdr_abi_version(void);
 const char* gdr_last_error(void); /* thread-local, host string */
+/* "release" for the product build.  Anything else marks a measurement / experimental build of the library (compiled with
+ * -DGDR_BUILD_TAG=...): the Python loader refuses to load such a library unless GDR_ALLOW_EXPERIMENTAL_LIB=1 is set. */
+const char* gdr_build_tag(void);
 
 size_t gdr_geom_bytes(int32_t N);
 size_t gdr_binning_bytes(uint64_t D);
@@ -226,6 +229,11 @@ size_t gdr_image_bytes(int32_t H, int32_t W);
 /* base must be 256-byte aligned and at least gdr_*_bytes(...) long. */
 int gdr_geom_carve(void* base, int32_t N, gdr_geom* out);
 int gdr_binning_carve(void* base, uint64_t D, gdr_binning* out);
+/* The same with the cut-list tables (seg_extra, seg_state: 2 * (D / seg_len + 1) slots of 10 KB — 80 bytes per
+ * duplicate at seg_len = 256, 40 at 512) sized for the segment length the caller is going to use: seg_len = a multiple
+ * of 256, or 0 (lists are never cut: no tables).  out->seg_len = seg_len. */
+size_t gdr_binning_bytes_seg(uint64_t D, int32_t seg_len);
+int gdr_binning_carve_seg(void* base, uint64_t D, int32_t seg_len, gdr_binning* out);
 int gdr_image_carve(void* base, int32_t H, int32_t W, gdr_image* out);
 
 /* ---- forward ---------------------------------------------------------------------
@@ -339,8 +347,10 @@ int gdr_render_backward_mean2d_loss(const gdr_settings* s, int32_t N, const gdr_
  *                                    the host (1 / views for a mean over the views).
  *   gdr_render_backward_mean2d       consumes that dL_dcolor (above).
  *   gdr_topk_absgrad                 selection on score_i = ||dL_dmean2D[i, 2:4]||_2: mask[i] = 1 for the k largest
- *                                    scores among the candidates (candidates == NULL: all N; k >= number of candidates:
- *                                    every candidate — the reference's `gradient_point >= 0` branch); indices (k, may be
+ *                                    scores among the candidates (candidates == NULL: all N; fewer than k candidates —
+ *                                    counted on the device — : every candidate with score >= 0, the reference's
+ *                                    `gradient_point >= 0` branch, which drops NaN; otherwise NaN ranks above every
+ *                                    number, as in torch.topk); indices (k, may be
  *                                    NULL) receives the selected ids in no particular order (the reference only builds
  *                                    a mask from them).  Radix select, no sort; ties at the threshold are cut arbitrarily,
  *                                    as torch.topk leaves them.  workspace: gdr_topk_workspace_bytes() bytes. */

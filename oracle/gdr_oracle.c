@@ -321,8 +321,19 @@ void oracle_render_bwd(int W, int H, const uint32_t* ranges, const uint32_t* poi
         if (t < 0 || t >= gx * gy) continue;
         int tx0 = (t % gx) * BLOCK_X, ty0 = (t / gx) * BLOCK_Y;
         uint32_t r0 = ranges[2 * t];
-        for (int ly = 0; ly < BLOCK_Y; ++ly)
-            for (int lx = 0; lx < BLOCK_X; ++lx) {
+        /* Summation structure (round 3): the per-Gaussian sums are formed as the GPU forms them — the 16 pixel terms of a
+         * 4x4 pixel block are summed first (K7: one DPP row), the block totals are then added to the Gaussian's
+         * accumulators (K7: one atomic per row) — instead of one long sequential fp32 sum over all pixels of all tiles.
+         * The reference's CUDA adds every pixel term with atomicAdd in no particular order, so any order restates it;
+         * this one keeps the float32 restatement's rounding error at the level of the GPU's (a screen-filling Gaussian
+         * is a 65 k-term sum).  blk: NS partial sums per list position of this tile. */
+        enum { NS = 12 };
+        const uint32_t Ltile = ranges[2 * t + 1] - r0;
+        real* blk = (real*)calloc((size_t)(Ltile ? Ltile : 1) * NS, sizeof(real));
+        for (int b4 = 0; b4 < (BLOCK_X / 4) * (BLOCK_Y / 4); ++b4) {
+            uint32_t kmax = 0;
+            for (int q4 = 0; q4 < 16; ++q4) {
+                const int lx = (b4 % (BLOCK_X / 4)) * 4 + (q4 & 3), ly = (b4 / (BLOCK_X / 4)) * 4 + (q4 >> 2);
                 int px = tx0 + lx, py = ty0 + ly;
                 if (px >= W || py >= H) continue;
                 size_t pix = (size_t)py * W + px;
@@ -330,6 +341,7 @@ void oracle_render_bwd(int W, int H, const uint32_t* ranges, const uint32_t* poi
                 const real T_final = final_T[pix];
                 real T = T_final;
                 uint32_t last = n_contrib[pix];
+                if (last > kmax) kmax = last;
                 real gC[3] = {dL_dpix[pix], dL_dpix[(size_t)H * W + pix], dL_dpix[(size_t)2 * H * W + pix]};
                 real gD = dL_ddepthpix[pix], gA = dL_dalphapix[pix];
                 real accum_rec[3] = {0, 0, 0}, last_color[3] = {0, 0, 0};
@@ -352,13 +364,13 @@ void oracle_render_bwd(int W, int H, const uint32_t* ranges, const uint32_t* poi
                         accum_rec[ch] = last_alpha * last_color[ch] + (RC(1) - last_alpha) * accum_rec[ch];
                         last_color[ch] = c;
                         dL_dalpha += (c - accum_rec[ch]) * gC[ch];
-                        accum(dL_dcolor + 3 * j + ch, w * gC[ch], atomic);
+                        blk[NS * k + 8 + ch] += w * gC[ch];
                     }
                     real dep = depths[j];
                     accum_depth = last_alpha * last_depth + (RC(1) - last_alpha) * accum_depth;
                     last_depth = dep;
                     dL_dalpha += (dep - accum_depth) * gD;
-                    accum(dL_ddepth + j, w * gD, atomic);
+                    blk[NS * k + 7] += w * gD;
                     accum_alpha = last_alpha + (RC(1) - last_alpha) * accum_alpha;
                     dL_dalpha += (RC(1) - accum_alpha) * gA;
                     dL_dalpha *= T;
@@ -370,16 +382,27 @@ void oracle_render_bwd(int W, int H, const uint32_t* ranges, const uint32_t* poi
                     real dG_ddelx = -gdx * co[0] - gdy * co[1];
                     real dG_ddely = -gdy * co[2] - gdx * co[1];
                     real mx = dL_dG * dG_ddelx * ddelx_dx, my = dL_dG * dG_ddely * ddely_dy;
-                    accum(dL_dmean2D + 4 * j + 0, mx, atomic);
-                    accum(dL_dmean2D + 4 * j + 1, my, atomic);
-                    accum(dL_dmean2D + 4 * j + 2, R_FABS(mx), atomic);
-                    accum(dL_dmean2D + 4 * j + 3, R_FABS(my), atomic);
-                    accum(dL_dconic + 4 * j + 0, RC(-0.5) * gdx * dx * dL_dG, atomic);
-                    accum(dL_dconic + 4 * j + 1, -gdx * dy * dL_dG, atomic);
-                    accum(dL_dconic + 4 * j + 2, RC(-0.5) * gdy * dy * dL_dG, atomic);
-                    accum(dL_dopacity + j, G * dL_dalpha, atomic);
+                    blk[NS * k + 0] += mx;
+                    blk[NS * k + 1] += my;
+                    blk[NS * k + 2] += R_FABS(mx);
+                    blk[NS * k + 3] += R_FABS(my);
+                    blk[NS * k + 4] += RC(-0.5) * gdx * dx * dL_dG;
+                    blk[NS * k + 5] += -gdx * dy * dL_dG;
+                    blk[NS * k + 6] += RC(-0.5) * gdy * dy * dL_dG;
+                    blk[NS * k + 11] += G * dL_dalpha;
                 }
             }
+            for (uint32_t k = 0; k < kmax; ++k) {   /* block totals -> the Gaussian's accumulators */
+                real* a = blk + (size_t)NS * k;
+                const uint32_t j = point_list[r0 + k];
+                real* const dst[NS] = {dL_dmean2D + 4 * j, dL_dmean2D + 4 * j + 1, dL_dmean2D + 4 * j + 2, dL_dmean2D + 4 * j + 3,
+                                       dL_dconic + 4 * j, dL_dconic + 4 * j + 1, dL_dconic + 4 * j + 2, dL_ddepth + j,
+                                       dL_dcolor + 3 * j, dL_dcolor + 3 * j + 1, dL_dcolor + 3 * j + 2, dL_dopacity + j};
+                for (int s_ = 0; s_ < NS; ++s_)
+                    if (a[s_] != RC(0)) { accum(dst[s_], a[s_], atomic); a[s_] = RC(0); }
+            }
+        }
+        free(blk);
     }
 }
 

@@ -279,8 +279,16 @@ void oracle_surfel_render_bwd(int W, int H, const uint32_t* ranges, const uint32
         if (t < 0 || t >= gx * gy) continue;
         int tx0 = (t % gx) * BLOCK_X, ty0 = (t / gx) * BLOCK_Y;
         uint32_t r0 = ranges[2 * t];
-        for (int ly = 0; ly < BLOCK_Y; ++ly)
-            for (int lx = 0; lx < BLOCK_X; ++lx) {
+        /* Summation structure (round 3, as oracle_render_bwd in gdr_oracle.c): the 16 pixel terms of a 4x4 pixel block
+         * are summed first (K7s: one DPP row), the block totals are then added to the surfel's accumulators (K7s: one
+         * atomic per row) — any order restates the reference's per-pixel atomicAdd. */
+        enum { NS = 20 };   /* transMat 0..8, mean2D 9..12, normal 13..15, colour 16..18, opacity 19 */
+        const uint32_t Ltile = ranges[2 * t + 1] - r0;
+        real* blk = (real*)calloc((size_t)(Ltile ? Ltile : 1) * NS, sizeof(real));
+        for (int b4 = 0; b4 < (BLOCK_X / 4) * (BLOCK_Y / 4); ++b4) {
+            uint32_t kmax = 0;
+            for (int q4 = 0; q4 < 16; ++q4) {
+                const int lx = (b4 % (BLOCK_X / 4)) * 4 + (q4 & 3), ly = (b4 / (BLOCK_X / 4)) * 4 + (q4 >> 2);
                 int px = tx0 + lx, py = ty0 + ly;
                 if (px >= W || py >= H) continue;
                 size_t pix = (size_t)py * W + px;
@@ -289,6 +297,7 @@ void oracle_surfel_render_bwd(int W, int H, const uint32_t* ranges, const uint32
                 const real final_A = RC(1) - T_final;
                 real T = T_final;
                 uint32_t last = n_contrib[pix], med_c = n_contrib[HW + pix];
+                if (last > kmax) kmax = last;
                 real gC[3] = {dL_dpix[pix], dL_dpix[HW + pix], dL_dpix[2 * HW + pix]};
                 const real gDepth = dL_dothers[0 * HW + pix], gAlpha = dL_dothers[1 * HW + pix];
                 const real gN[3] = {dL_dothers[2 * HW + pix], dL_dothers[3 * HW + pix], dL_dothers[4 * HW + pix]};
@@ -313,7 +322,7 @@ void oracle_surfel_render_bwd(int W, int H, const uint32_t* ranges, const uint32
                         accum_rec[ch] = last_alpha * last_color[ch] + (RC(1) - last_alpha) * accum_rec[ch];
                         last_color[ch] = c;
                         dL_dalpha += (c - accum_rec[ch]) * gC[ch];
-                        accum(dL_dcolor + 3 * j + ch, w * gC[ch], atomic);
+                        blk[NS * k + 16 + ch] += w * gC[ch];
                     }
                     real dL_dz = 0;
                     const real c_d = h.depth;
@@ -334,7 +343,7 @@ void oracle_surfel_render_bwd(int W, int H, const uint32_t* ranges, const uint32
                         accum_nrm[ch] = last_alpha * last_nrm[ch] + (RC(1) - last_alpha) * accum_nrm[ch];
                         last_nrm[ch] = no[ch];
                         dL_dalpha += (no[ch] - accum_nrm[ch]) * gN[ch];
-                        accum(dL_dnormal + 3 * j + ch, w * gN[ch], atomic);
+                        blk[NS * k + 13 + ch] += w * gN[ch];
                     }
                     dL_dalpha *= T;
                     last_alpha = alpha;
@@ -353,21 +362,34 @@ void oracle_surfel_render_bwd(int W, int H, const uint32_t* ranges, const uint32
                         const real dl[3] = {dp[1] * kk[2] - dp[2] * kk[1], dp[2] * kk[0] - dp[0] * kk[2], dp[0] * kk[1] - dp[1] * kk[0]};
                         const real dz_dTw[3] = {h.sx, h.sy, RC(1)};
                         for (int c = 0; c < 3; ++c) {
-                            accum(dL_dtransMat + 9 * j + 0 + c, -dk[c], atomic);
-                            accum(dL_dtransMat + 9 * j + 3 + c, -dl[c], atomic);
-                            accum(dL_dtransMat + 9 * j + 6 + c, pxf * dk[c] + pyf * dl[c] + dL_dz * dz_dTw[c], atomic);
+                            blk[NS * k + 0 + c] += -dk[c];
+                            blk[NS * k + 3 + c] += -dl[c];
+                            blk[NS * k + 6 + c] += pxf * dk[c] + pyf * dl[c] + dL_dz * dz_dTw[c];
                         }
-                        accum(dL_dmean2D + 4 * j + 2, R_FABS(dk[2]), atomic);
-                        accum(dL_dmean2D + 4 * j + 3, R_FABS(dl[2]), atomic);
+                        blk[NS * k + 11] += R_FABS(dk[2]);
+                        blk[NS * k + 12] += R_FABS(dl[2]);
                     } else {
                         const real dG_ddelx = -G * FILTER_INV_SQUARE * h.dx, dG_ddely = -G * FILTER_INV_SQUARE * h.dy;
-                        accum(dL_dmean2D + 4 * j + 0, dL_dG * dG_ddelx, atomic);
-                        accum(dL_dmean2D + 4 * j + 1, dL_dG * dG_ddely, atomic);
-                        accum(dL_dtransMat + 9 * j + 8, dL_dz, atomic);
+                        blk[NS * k + 9] += dL_dG * dG_ddelx;
+                        blk[NS * k + 10] += dL_dG * dG_ddely;
+                        blk[NS * k + 8] += dL_dz;
                     }
-                    accum(dL_dopacity + j, G * dL_dalpha, atomic);
+                    blk[NS * k + 19] += G * dL_dalpha;
                 }
             }
+            for (uint32_t k = 0; k < kmax; ++k) {   /* block totals -> the surfel's accumulators */
+                real* a = blk + (size_t)NS * k;
+                const uint32_t j = point_list[r0 + k];
+                for (int s_ = 0; s_ < NS; ++s_) {
+                    if (a[s_] == RC(0)) continue;
+                    real* dst = s_ < 9 ? dL_dtransMat + 9 * j + s_ : s_ < 13 ? dL_dmean2D + 4 * j + (s_ - 9)
+                              : s_ < 16 ? dL_dnormal + 3 * j + (s_ - 13) : s_ < 19 ? dL_dcolor + 3 * j + (s_ - 16) : dL_dopacity + j;
+                    accum(dst, a[s_], atomic);
+                    a[s_] = RC(0);
+                }
+            }
+        }
+        free(blk);
     }
 }
 

@@ -1,4 +1,4 @@
-"""Tile list length classes of the bench workloads (tile sort classes: <= 2048, <= 4096, <= 8192, beyond)."""
+"""Tile list length classes of the bench workloads (tile sort classes: <= 2048, <= 4096, <= 16384, beyond)."""
 import sys, torch
 sys.path.insert(0, ".")
 
@@ -23,4 +23,4 @@ for name, n, hw, views, deg, sig, layout in (("c4", 2_000_000, 800, 4, 3, (0.000
         r = st.tensors()["ranges"].long()
         L = (r[:, 1] - r[:, 0])
         print(name, layout, "view", v, "D", st.D, "max", int(L.max()), "<=2048:", int((L <= 2048).sum()), "2049-4096:", int(((L > 2048) & (L <= 4096)).sum()),
-              "4097-8192:", int(((L > 4096) & (L <= 8192)).sum()), ">8192:", int((L > 8192).sum()))
+              "4097-16384:", int(((L > 4096) & (L <= 16384)).sum()), ">16384:", int((L > 16384).sum()))

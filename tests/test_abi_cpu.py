@@ -29,7 +29,8 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/*.h but not exported"
         assert n in L.EXPORTED_SYMBOLS, f"{n} has no ctypes prototype"
-    assert lib.gdr_abi_version() == 11
+    assert lib.gdr_abi_version() == 12
+    assert lib.gdr_build_tag() == b"release"
 
 
 def test_workspace_sizes_and_carving_without_gpu():
@@ -163,31 +164,28 @@ def test_host_policy_helpers_without_gpu():
         assert R.side_count(800, 800) == 0
         R.BIN_STREAM = 4
         assert R.side_count(64, 64) == 4
-        b = L.GdrBinning()
-        b.seg_len = 2048
         R.SEG_LEN = None
-        R._apply_seg_len(b, 10_000)
-        assert b.seg_len == 2048
-        # the automatic choice: 512 on large images whose tiles are all busy with long lists, the carved 256 otherwise
+        assert R._seg_len_for(10_000) == 256
+        # the automatic choice: 512 on large images whose tiles are all busy with long lists, 256 otherwise
         for D, tiles, busy, want in ((3_400_000, 2500, None, 512), (3_400_000, 2500, 2000, 512), (3_400_000, 2500, 330, 256),
                                      (730_000, 2500, 2500, 256), (1_070_000, 1024, 1024, 256)):
-            b.seg_len = 256
-            R._apply_seg_len(b, D, tiles, busy)
-            assert b.seg_len == want, (D, tiles, busy)
-        b.seg_len = 2048
+            assert R._seg_len_for(D, tiles, busy) == want, (D, tiles, busy)
         R.SEG_LEN = 4096
-        R._apply_seg_len(b, 10_000)
-        assert b.seg_len == 4096
-        b.seg_len = 2048
-        R.SEG_LEN = 512          # shorter than carved: the tables would overflow -> ignored
-        R._apply_seg_len(b, 10_000)
-        assert b.seg_len == 2048
-        R.SEG_LEN = 0
-        R._apply_seg_len(b, 10_000)
-        assert b.seg_len == 0
+        assert R._seg_len_for(10_000) == 4096
+        R.SEG_LEN = 700           # rounded down to a multiple of 256
+        assert R._seg_len_for(10_000) == 512
+        R.SEG_LEN = 0             # lists are never cut
+        assert R._seg_len_for(3_400_000, 2500, None) == 0
     finally:
         R.BIN_STREAM, R.SEG_LEN = saved
     lib = L.load()
+    # the cut-list tables are carved for the segment length the caller is going to use (80 / 40 / 0 bytes per duplicate)
+    b256, b512, b0 = (lib.gdr_binning_bytes_seg(4_000_000, sl) for sl in (256, 512, 0))
+    assert b256 == lib.gdr_binning_bytes(4_000_000) and b256 - b512 >= 4_000_000 * 39 and b512 - b0 >= 4_000_000 * 39
+    bb = L.GdrBinning()
+    assert lib.gdr_binning_carve_seg(C.c_void_p(0x10000000), 4_000_000, 512, C.byref(bb)) == 0
+    assert bb.seg_len == 512 and bb.seg_cap == 4_000_000 // 512 + 1
+    assert lib.gdr_binning_carve_seg(C.c_void_p(0x10000000), 4_000_000, 0, C.byref(bb)) == 0 and bb.seg_len == 0 and bb.seg_cap == 0
     small, big = lib.gdr_binning_bytes(1000), lib.gdr_binning_bytes(4_000_000)
     assert big > small and big >= 4_000_000 * (8 + 8 + 4 + 4 + 8) + 2 * (4_000_000 // 2048) * 10 * 256 * 4
 

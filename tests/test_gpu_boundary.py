@@ -152,11 +152,24 @@ def test_device_topk_of_the_densification_score_matches_torch_topk():
     assert int(mask.sum()) == 50 and bool(mask[250:300].all()) and not bool(mask[~cand].any())
     mask = topk_absgrad(grad, 12_000, candidates=cand)
     assert bool((mask == cand).all())
-    # NaN scores never win
+    # candidates != None with #candidates <= k < N (the library cannot know the candidate count up front: pass 0 counts)
+    mask, idx = topk_absgrad(grad, 300, candidates=cand, return_indices=True)
+    assert bool((mask == cand).all()) and sorted(idx.tolist()) == list(range(100, 400))
+    mask = topk_absgrad(grad, 400, candidates=cand)
+    assert bool((mask == cand).all())
+    # NaN scores follow the reference's two branches (network.py:885-890): with >= k candidates torch.topk ranks NaN
+    # above every number — they are selected first; with fewer than k the mask is `score >= 0`, false for NaN
     grad = torch.rand(1000, 4, device=dev)
     grad[::7, 2] = float("nan")
-    mask = topk_absgrad(grad, 100)
-    assert int(mask.sum()) == 100 and not bool(mask[::7].any())
+    n_nan = len(range(0, 1000, 7))
+    mask = topk_absgrad(grad, 200)
+    ref = torch.zeros(1000, dtype=torch.bool, device=dev)
+    ref[torch.topk(grad[:, 2:4].norm(dim=-1), 200).indices] = True
+    assert int(mask.sum()) == 200 and bool(mask[::7].all()) and bool((mask == ref).all())
+    mask = topk_absgrad(grad, 100)            # fewer than the NaN count: only NaN scores are selected
+    assert int(mask.sum()) == 100 and not bool(mask[~torch.isnan(grad[:, 2])].any())
+    mask = topk_absgrad(grad, 5000)           # k > N: `score >= 0`
+    assert int(mask.sum()) == 1000 - n_nan and not bool(mask[::7].any())
 
 
 @pytest.mark.parametrize("group", [2, 8])

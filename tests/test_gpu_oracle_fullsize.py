@@ -150,15 +150,16 @@ def test_surfel_hip_vs_oracle_at_c5_size(oracle_built):
     assert U.psnr(np.clip(h["color"][:, mask], 0, 1), np.clip(o["color"][:, mask], 0, 1)) > 60.0
     g = torch.Generator().manual_seed(9)
     grads = [torch.randn(3, H, W, generator=g) * torch.from_numpy(mask), torch.randn(7, H, W, generator=g) * torch.from_numpy(mask)]
-    grads[1][6] = 0     # the distortion channel is ill-conditioned in fp32: checked at small size
+    # (the distortion channel's upstream gradient is NOT zeroed any more: the reference weights that channel by 1000,
+    # /root/reference/lightning/loss.py:50-53)
     _, hg = U.run_surfel_hip(case, grads)
     o64 = SurfelOracle("f64", nthreads=THREADS)
     f64 = o64.forward(U._np(case["means3D"]), U._np(case["opacities"]), U.settings_np(case), tiles=tiles, **kw)
     g64 = o64.backward(f64, *[U._np(x) for x in grads])
     g32 = SurfelOracle("f32", nthreads=1).backward(o, *[U._np(x) for x in grads])
-    # (the 2DGS ray-splat intersection cancels in fp32 for sub-pixel surfels away from the image origin, DESIGN §9: the
-    # f32 oracle is ~2e-3 from f64 here; the bar is again the f32 oracle)
-    _assert_grads(hg, g64, g32, GRAD_KEYS, "c5", bar32=False, max_outside=2e-3)   # measured 7e-4 (f32 oracle 8e-4)
+    # per element against the f32 oracle, with the outside fraction / max-norm bound the ill-conditioned fp32 2DGS
+    # formulation forces (reason + measurements at util.assert_grads_surfel)
+    U.assert_grads_surfel(hg, g64, g32, GRAD_KEYS, "c5")
 
 
 # --------------------------------------------------------------------------------------------------------------------
@@ -293,8 +294,8 @@ def test_screenspace_absgrad_and_topk_vs_oracle(oracle_built):
 def test_surfel_render_views_backward_vs_oracle(oracle_built):
     """The 2DGS multi-view node (K1s / K9s for all views, activations folded in) against torch autograd through the
     SURFEL ORACLE stand-in, one call per view (renderer_2dgs.py:92-96, 224-234 semantics) — round 1 only compared it
-    with the per-view HIP sequence.  Upstream: random gradients on the colour and on allmap channels 0..5 (the
-    distortion channel is ill-conditioned in fp32, DESIGN §9, and checked at single-view size in test_gpu_surfel.py)."""
+    with the per-view HIP sequence.  Upstream: random gradients on the colour and on all seven allmap channels
+    (the distortion channel included: the reference weights it by 1000, loss.py:50-53)."""
     from generativedensification_amd.camera import build_rays, orbit_cameras
     from generativedensification_amd.renderer_2dgs import Renderer
     from generativedensification_amd.synthetic import make_scene
@@ -307,8 +308,6 @@ def test_surfel_render_views_backward_vs_oracle(oracle_built):
     g = torch.Generator().manual_seed(5)
     gc = [torch.randn(3, h, w, generator=g) for _ in range(V)]
     ga = [torch.randn(7, h, w, generator=g) for _ in range(V)]
-    for a in ga:
-        a[6] = 0
 
     def oracle_ref(precision):
         mod = make_surfel_standin_module(precision, nthreads=1 if precision == "f32" else THREADS)
@@ -346,4 +345,4 @@ def test_surfel_render_views_backward_vs_oracle(oracle_built):
         total = total + (o["color"] * gc[v].to(dev)).sum() + (o["allmap"] * ga[v].to(dev)).sum()
     grads = torch.autograd.grad(total, list(leaves.values()) + [ssp])
     g_hip = {k: x.cpu().numpy() for k, x in zip(list(leaves) + ["ssp"], grads)}
-    _assert_grads(g_hip, g64, g32, list(g32), "surfel render_views", bar32=False, max_outside=2e-3)
+    U.assert_grads_surfel(g_hip, g64, g32, list(g32), "surfel render_views")

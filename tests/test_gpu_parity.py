@@ -212,52 +212,60 @@ def test_vjp_and_no_grad_and_autocast_contracts():
 
 
 @pytest.mark.parametrize("V", [3, 10])   # 10 > GDR_MAX_VIEWS = 8: two kernel groups, the second accumulating
-def test_fused_multiview_entry_matches_per_view_reference_sequence(V):
-    """render_views (activations inside K1/K9, grads summed over views inside K9, one D read-back)
-    == the reference's sequence (torch activations + one rasterizer call per view + autograd sum)."""
+def test_fused_multiview_node_equals_per_view_sequence_on_identical_inputs(V):
+    """The multi-view node (one K1 / K9 launch per <= 8 views, grads summed over the views inside K9, one D read-back,
+    views on side streams) against the reference's sequence — one rasterizer call per view, autograd summing the
+    gradients — on the SAME activated tensors (flags = 0: no in-kernel activations), so both run identical arithmetic
+    per view: images, depth, alpha bit-equal; gradients differ by the order of fp32 sums only and meet the per-element
+    bar with no allowance.  (The in-kernel activations of the RAW entry are compared with the ORACLE in
+    test_gpu_oracle_fullsize.py::test_render_views_backward_vs_oracle — round 2's version of this test compared two HIP
+    paths with different activations and loosened its bar when an alpha-threshold decision flipped.)"""
+    import diff_gaussian_rasterization as D
+    from generativedensification_amd import rasterizer as R
     from generativedensification_amd.camera import orbit_cameras
     from generativedensification_amd.renderer import Renderer
-    from generativedensification_amd.synthetic import make_scene, make_targets, view_loss
+    from generativedensification_amd.synthetic import make_scene, make_targets
 
     dev = torch.device("cuda:0")
     n, h, w = 30_000, 160, 208
     sc = make_scene(n, 77, sh_degree=3, sigma0=(0.0052, 0.00065, 0.02))
     cams = orbit_cameras(V, w, h, device=dev)
-    tg = make_targets(V, h, w, 77).to(dev)
+    tg = make_targets(V, h, w, 77).to(dev).permute(0, 3, 1, 2)
     three = ([1.0, 1.0, 1.0], [0.5, 0.5, 0.5], [0.0, 0.0, 0.0])   # gobjverse.py:112-117
-    bgs = [torch.tensor(three[j % 3], device=dev) for j in range(V)]
+    r = Renderer(sh_degree=3)
+    sets = []
+    for j, c in enumerate(cams):
+        r.set_bg_color(torch.tensor(three[j % 3], device=dev))
+        sets.append(r.set_rasterizer(c, device=dev).raster_settings)
+    act = dict(means3D=sc["centers"].to(dev), shs=sc["shs"].to(dev), opacities=torch.sigmoid(sc["opacity"]).to(dev),
+               scales=torch.exp(sc["scales"]).to(dev), rotations=torch.nn.functional.normalize(sc["rotations"]).to(dev))
+
+    def loss_of(colors, depths, alphas):
+        return sum(((c.clamp(0, 1) - tg[j]) ** 2).mean() + 0.1 * d.mean() + 0.1 * a.mean()
+                   for j, (c, d, a) in enumerate(zip(colors, depths, alphas)))
 
     def run(fused):
-        r = Renderer(sh_degree=3, fused=fused)
-        leaves = {k: v.to(dev).clone().requires_grad_(True) for k, v in sc.items()}
+        leaves = {k: v.clone().requires_grad_(True) for k, v in act.items()}
         ssp = torch.zeros(n, 4, device=dev, requires_grad=True)
         if fused:
-            outs = r.render_views(cams, bgs, leaves["centers"], leaves["shs"], leaves["opacity"], leaves["scales"],
-                                  leaves["rotations"], dev, screenspace_points=ssp)
+            colors, radii, depths, alphas = R.render_views_raw(leaves["means3D"], ssp, leaves["shs"], leaves["opacities"],
+                                                               leaves["scales"], leaves["rotations"], sets, flags=0)
         else:
-            outs = []
-            for c, b in zip(cams, bgs):
-                r.set_bg_color(b)
-                outs.append(r.render_img(c, None, leaves["centers"], leaves["shs"], leaves["opacity"], leaves["scales"],
-                                         leaves["rotations"], dev, screenspace_points=ssp))
-        loss = sum(view_loss(o, tg[j]) for j, o in enumerate(outs))
-        grads = torch.autograd.grad(loss, list(leaves.values()) + [ssp])
-        return outs, {k: g_.cpu().numpy() for k, g_ in zip(list(leaves) + ["ssp"], grads)}
+            outs = [D.GaussianRasterizer(rs)(means3D=leaves["means3D"], means2D=ssp, shs=leaves["shs"],
+                                             opacities=leaves["opacities"], scales=leaves["scales"],
+                                             rotations=leaves["rotations"]) for rs in sets]
+            colors, depths, alphas = [o[0] for o in outs], [o[2] for o in outs], [o[3] for o in outs]
+        grads = torch.autograd.grad(loss_of(colors, depths, alphas), list(leaves.values()) + [ssp])
+        imgs = [torch.cat([c, d, a]).detach().cpu().numpy() for c, d, a in zip(colors, depths, alphas)]
+        return imgs, {k: g_.cpu().numpy() for k, g_ in zip(list(leaves) + ["ssp"], grads)}
 
     o_ref, g_ref = run(False)
     o_fus, g_fus = run(True)
     for a, b in zip(o_fus, o_ref):
-        for k in ("image", "depth", "acc_map"):
-            assert a[k].shape == b[k].shape
-            assert U.outlier_fraction(a[k].detach().cpu().numpy(), b[k].detach().cpu().numpy(), 1e-4, 1e-5) < 1e-4, k
-    # The two sequences agree to ~3e-7 per view.  The in-kernel activations differ from torch's by an ulp, which can
-    # flip ONE marginal alpha >= 1/255 decision in a view (10 views: one pixel each in two of them, |d image| 7e-4,
-    # scripts/mv_diag.py); the Gaussians under such a pixel then differ by that pixel's gradient.  Counted, not hidden:
-    flips = sum(int(((a["image"] - b["image"]).abs() > 1e-4).any(-1).sum()) for a, b in zip(o_fus, o_ref))
-    assert flips <= V // 3
+        np.testing.assert_array_equal(a, b)
     for k in g_ref:
-        assert U.rel_inf(g_fus[k], g_ref[k]) < (1e-4 if flips == 0 else 1e-3), (k, flips)
-        assert U.outlier_fraction(g_fus[k], g_ref[k], 1e-3, 1e-5 * np.abs(g_ref[k]).max()) < 1e-3, k
+        out, worst, maxn = U.elem_stats(g_fus[k], g_ref[k])
+        assert out < U.MAX_OUTSIDE and maxn < 1e-4, (k, out, worst, maxn)
     assert g_fus["ssp"].shape == (n, 4) and (g_fus["ssp"][:, 2:] >= 0).all()
 
 
@@ -669,10 +677,7 @@ def test_tiny_and_odd_image_sizes_both_paths(oracle_built, H, W):
     for k in ("radii", "rect", "tiles_touched", "point_list", "ranges"):
         np.testing.assert_array_equal(np.asarray(ship[k]).astype(np.asarray(sora[k]).dtype).reshape(np.asarray(sora[k]).shape), sora[k], err_msg=k)
     assert U.outlier_fraction(ship["color"], sora["color"], 1e-4, 1e-4) < 2e-3
-    for k in ("means3D", "shs", "opacities", "scales", "rotations"):
-        ref = sg64[k]
-        e_hip, e_o32 = U.rel_inf(shg[k].reshape(ref.shape), ref), U.rel_inf(sg32[k].reshape(ref.shape), ref)
-        assert e_hip <= 2.0 * e_o32 + 2e-4, (k, e_hip, e_o32)
+    U.assert_grads_surfel(shg, sg64, sg32, ("means3D", "shs", "opacities", "scales", "rotations"), "surfel tiny")
 
 
 @pytest.mark.parametrize("n,band", [(30_000, 0.7), (70_000, 0.0), (50_000, 1.0), (90_000, 1.0)])
@@ -801,9 +806,9 @@ def test_cut_tile_lists_give_the_gradients_of_the_uncut_walk(oracle_built):
 
 
 def test_one_tile_with_a_very_long_list_takes_the_global_sort_path(oracle_built):
-    """20k Gaussians stacked on one spot: a single tile list beyond the 16384-entry LDS classes of the per-tile
+    """40k Gaussians stacked on one spot: a single tile list beyond the 16384-entry LDS classes of the per-tile
     depth sort (tile_sort_long's global ping-pong), equal depths included; sorted list bit-exact, image within tolerance."""
-    case = U.make_case(20_000, 48, 48, 37, deg=0, sigma0=(0.01,))
+    case = U.make_case(40_000, 48, 48, 37, deg=0, sigma0=(0.01,))
     case["means3D"] = (case["means3D"] * 0.02).contiguous()          # all inside one or two tiles at the image centre
     case["means3D"][::7] = case["means3D"][0]                         # exact depth ties
     case["opacities"] = (case["opacities"] * 0.02).contiguous()       # keep transmittance alive through the long list
@@ -811,7 +816,7 @@ def test_one_tile_with_a_very_long_list_takes_the_global_sort_path(oracle_built)
     hip, hg = U.run_hip(case, grads)
     ora, _ = U.run_oracle(case, "f32")
     lens = ora["ranges"][:, 1].astype(np.int64) - ora["ranges"][:, 0].astype(np.int64)
-    assert lens.max() > 8192
+    assert lens.max() > 16384   # GDR_TSORT_LARGE (gdr_common.h): beyond the long class LDS capacity -> the TOP/global route
     np.testing.assert_array_equal(hip["point_list"], ora["point_list"])
     np.testing.assert_array_equal(hip["ranges"], ora["ranges"])
     assert U.outlier_fraction(hip["color"], ora["color"], 1e-3, 1e-4) < 1e-3

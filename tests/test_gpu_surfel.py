@@ -1,8 +1,9 @@
 """GPU (-m gpu): the 2DGS surfel path (include/gsr.h -> libgdr_hip.so) against the CPU oracle (oracle/gsr_oracle.c).
 Bar: every per-surfel intermediate, the duplicate list, the tile ranges and n_contrib bit-exact against the f32
-oracle; image and allmap within 1e-4 of the f32 oracle (PSNR > 100 dB); gradients within 1e-4 relative of the f64
-oracle where the 2DGS formulation itself is well conditioned in fp32, and no further from it than twice the f32
-oracle's own distance (+1e-4) where it is not (k = x Tw - Tu cancels for small surfels far from the image origin)."""
+oracle; image and allmap within 1e-4 of the f32 oracle (PSNR > 100 dB); gradients PER ELEMENT within
+1e-4 |ref| + 1e-6 max|ref| of the f32 oracle (util.assert_grads_surfel: the 3DGS bar with the outside fraction and the
+max-norm bound the ill-conditioned fp32 formulation forces — k = x Tw - Tu cancels for small surfels far from the image
+origin — both stated and measured there), and no further from float64 than the f32 oracle is."""
 import numpy as np
 import pytest
 import torch
@@ -33,14 +34,9 @@ def _check_forward(hip, o32):
 
 
 def _check_grads(hg, g32, g64, keys):
-    """1e-4 relative of the f64 oracle, or — where the fp32 formulation itself is further than that from f64 — no
-    further than twice the f32 oracle's own distance; never more than 0.1 % of entries off by > 1e-3."""
-    for k in keys:
-        ref = g64[k]
-        e_hip = U.rel_inf(hg[k].reshape(ref.shape), ref)
-        e_o32 = U.rel_inf(g32[k].reshape(ref.shape), ref)
-        assert e_hip <= 2.0 * e_o32 + 1e-4, (k, e_hip, e_o32)
-        assert U.outlier_fraction(hg[k].reshape(ref.shape), ref, 1e-3, 1e-4 * np.abs(ref).max()) < 1e-3, k
+    """The per-element bar of the 3DGS path with the two numbers the fp32 2DGS formulation forces (util.assert_grads_surfel,
+    reason and measurements written there)."""
+    U.assert_grads_surfel(hg, g64, g32, keys, "surfel")
 
 
 @pytest.mark.parametrize("N,H,W,seed,deg,sigma0", [

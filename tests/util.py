@@ -217,10 +217,12 @@ def pick_tiles(ranges, n_long=16, n_rand=32, seed=0):
 MAX_OUTSIDE = 1e-4
 
 
-def assert_grads(hg, g64, g32, keys, what, max_outside=MAX_OUTSIDE, rtol=1e-4, atol_rel=1e-6, maxnorm=1e-4, bar32=True):
-    """hg: HIP; g32: float32 oracle (the bar); g64: float64 oracle (the arbiter).  bar32=False (2DGS path only): the
-    fp32 formulation is ill-conditioned enough that two fp32 evaluations differ from each other by more than either
-    does from float64 in places — only the arbiter comparison is asserted there."""
+def assert_grads(hg, g64, g32, keys, what, max_outside=MAX_OUTSIDE, rtol=1e-4, atol_rel=1e-6, maxnorm=1e-4):
+    """hg: HIP; g32: float32 oracle (the bar); g64: float64 oracle (printed next to it, and a second assertion).
+    Per ELEMENT: |hip - f32 oracle| <= rtol |ref| + atol_rel max|ref| with at most `max_outside` of the elements
+    outside, max-norm relative error < maxnorm; and HIP no further from float64 than the f32 oracle is (x 1.25).
+    No escape hatch: round 2's `or closer to float64` clause was never taken (0 elements outside at every BASELINE
+    size, profiles/r02_fullsize_parity.log) and is gone."""
     for k in keys:
         r32 = np.asarray(g32[k]).reshape(hg[k].shape)
         r64 = np.asarray(g64[k]).reshape(hg[k].shape)
@@ -230,16 +232,38 @@ def assert_grads(hg, g64, g32, keys, what, max_outside=MAX_OUTSIDE, rtol=1e-4, a
         print(f"[{what}] {k:10s} vs f32 oracle: outside {out:.2e} worst/tol {worst:.1f} max-norm rel {maxn:.2e} | "
               f"vs f64: hip {o_h64:.2e} / {m_h64:.2e}, f32 oracle {o_3264:.2e} / {m_3264:.2e}")
         assert np.isfinite(hg[k]).all(), (what, k)
-        if bar32:
-            # where HIP and the f32 oracle disagree beyond the bar, float64 arbitrates: HIP passes only if it is at
-            # least as close to float64 as the f32 oracle is (long sequential fp32 sums of the one-thread oracle lose
-            # more than the GPU's partial sums: 3000 screen-filling Gaussians, 65 k terms per sum)
-            closer = o_h64 <= o_3264 and m_h64 <= m_3264
-            assert out < max_outside or closer, (what, k, out, o_h64, o_3264)
-            assert maxn < maxnorm, (what, k, maxn)
-        else:   # (the relation to the f32 oracle below is the assertion; this is a sanity bound on top)
-            assert o_h64 < max(max_outside, 1.25 * o_3264), (what, k, o_h64, o_3264)
+        assert out < max_outside, (what, k, out, o_h64, o_3264)
+        assert maxn < maxnorm, (what, k, maxn)
         # as accurate as the fp32 algorithm allows: no further from float64 than the f32 oracle
         assert m_h64 <= 1.25 * m_3264 + 1e-6 and o_h64 <= 1.25 * o_3264 + 1e-4, (what, k, m_h64, m_3264, o_h64, o_3264)
 
 
+# ---- 2DGS: the same per-element bar, with the two numbers the fp32 2DGS formulation itself forces ---------------------
+# The published 2DGS ray-splat intersection evaluates k = x Tw - Tu, l = y Tw - Tv per pixel in fp32: for a small surfel
+# far from the image origin ~800 * 2 cancels against ~1600 (condition number ~1e3..1e4), so ANY two fp32 evaluations of
+# the reference's program that differ by an ulp in exp / rcp / the order of one fma differ from each other at the 1e-4
+# level in a few 1e-4 of the gradient elements.  Measured on MI355X at C5 size (500 k surfels, 800x800,
+# profiles/r02_fullsize_parity.log): HIP vs the f32 oracle 5e-6 .. 1.5e-4 of the elements outside 1e-4 |ref| + 1e-6 max,
+# max-norm relative 2e-5 .. 4e-3 (means2D, rotations) — while the f32 ORACLE ITSELF is 1.3e-4 .. 1.3e-3 / 2e-3 .. 4e-3
+# from float64 on the same elements.  The bar below is therefore the 3DGS bar with max_outside 4e-4 (2.7 x the
+# measured worst) and the max-norm bound tied to the f32 oracle's own distance from float64 (HIP must not be further
+# from the f32 oracle than 2 x that distance + 1e-4) instead of an absolute 1e-4; the float64 arbitration
+# (no further from float64 than the f32 oracle x 1.25) is asserted unchanged.
+SURFEL_MAX_OUTSIDE = 4e-4
+
+
+def assert_grads_surfel(hg, g64, g32, keys, what, max_outside=SURFEL_MAX_OUTSIDE, rtol=1e-4, atol_rel=1e-6):
+    for k in keys:
+        r32 = np.asarray(g32[k]).reshape(hg[k].shape)
+        r64 = np.asarray(g64[k]).reshape(hg[k].shape)
+        out, worst, maxn = elem_stats(hg[k], r32, rtol, atol_rel)
+        o_h64, _, m_h64 = elem_stats(hg[k], r64, rtol, atol_rel)
+        o_3264, _, m_3264 = elem_stats(r32, r64, rtol, atol_rel)
+        print(f"[{what}] {k:10s} vs f32 oracle: outside {out:.2e} worst/tol {worst:.1f} max-norm rel {maxn:.2e} | "
+              f"vs f64: hip {o_h64:.2e} / {m_h64:.2e}, f32 oracle {o_3264:.2e} / {m_3264:.2e}")
+        assert np.isfinite(hg[k]).all(), (what, k)
+        # per element, against the f32 oracle (arrays of < 2500 elements: one element may be outside — the fraction
+        # bar is finer than 1 / size there)
+        assert out < max(max_outside, 1.01 / max(r32.size, 1)), (what, k, out, o_h64, o_3264)
+        assert maxn <= 2.0 * m_3264 + 1e-4, (what, k, maxn, m_3264)         # max-norm, conditioned (see above)
+        assert m_h64 <= 1.25 * m_3264 + 1e-6 and o_h64 <= 1.25 * o_3264 + 1e-4, (what, k, m_h64, m_3264, o_h64, o_3264)
