@@ -140,8 +140,14 @@ def test_bench_line_contract_on_one_gpu():
     rf = out["roofline"]
     assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and rf["unit"] == "GB/s"
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and rf["avg_launch_us"] > 0
-    assert rf["kernel"] in out["kernels"] and 0 < rf["path_frac_measured"] < 1 and rf["pairs_per_s"] > 0
+    assert rf["kernel"] in out["kernels"] and 0 < rf["path_frac"] < 1 and rf["pairs_per_s"] > 0
     assert all("avg_us" in k for k in out["kernels"].values())
+    # a scene the PMC table was not recorded on (n = 20 000): no counter-derived figure at all, never a wrong one
+    assert rf["traffic"] is None and "path_frac_measured" not in rf
+    assert all(k.get("frac", 0) <= 1 and k.get("frac_serial", 0) <= 1 for k in out["kernels"].values())
+    pv = out["per_view"]     # second headline: the unchanged caller's pattern, timed in the same run
+    assert pv["value"] > 0 and pv["unit"] == "views/s" and "render_img" in pv["entry"] and 0 < pv["of_fused"] < 1.5
+    assert "spread" in out
     cb = out["cpu_baseline"]
     assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and "oracle" in cb["sample"]
     assert out["psnr_vs_oracle"]["psnr_db"] > 60 and out["psnr_vs_oracle"]["max_abs_rgb"] < 5e-3   # "PSNR vs ref" of the metric
