@@ -340,6 +340,12 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
+    # Python's cyclic collector is off inside the timed regions (the `timeit` convention): one generation-2 pass over this
+    # process's ~170 k objects takes 35 ms — 10 steps of the C4 workload — and whether one lands in a 30-60 ms timed region
+    # is chance (measured: the same per-view run 790 or 1380 views/s).  Collected right before, re-enabled right after.
+    import gc
+    gc.collect()
+    gc.disable()
     prof_host = None
     if args.host_profile:
         import cProfile
@@ -350,6 +356,7 @@ def main():
         last_losses = step()
     barrier()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     if prof_host is not None:
         import io
         import pstats
@@ -524,11 +531,14 @@ def main():
             pv_step()
         barrier()
         k_pv = max(1, min(args.steps, 10))
+        gc.collect()
+        gc.disable()
         t1 = time.perf_counter()
         for _ in range(k_pv):
             pv_step()
         barrier()
         el = time.perf_counter() - t1
+        gc.enable()
         if use_dist:
             t = torch.tensor([el], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -638,6 +648,7 @@ def main():
                                 else "folded into K6 epilogue / K7 prologue (clamp+MSE+0.1 mean depth+0.1 mean alpha)")},
             "roofline": roofline, "per_view": per_view,
             "spread": "same box run-to-run +-0.3 %, box-to-box +-4 % (BASELINE.md section 4: measured over 6 boxes)",
+            "gc": "Python's cyclic collector disabled inside the timed regions (timeit convention; collected right before)",
             "cpu_baseline": cpu_baseline, "cpu_baseline_torch": cpu_baseline_torch,
             "psnr_vs_oracle": psnr_vs_oracle, "kernels": kernels,
             "loss_mean": float(last_losses.mean()),

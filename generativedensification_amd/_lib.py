@@ -110,6 +110,7 @@ _PROTOS = {
     "gdr_binning_bytes_seg": (C.c_size_t, [C.c_uint64, C.c_int32]),
     "gdr_binning_carve_seg": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int32, C.POINTER(GdrBinning)]),
     "gdr_build_tag": (C.c_char_p, []),
+    "gdr_words_differ": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
     "gdr_image_carve": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(GdrImage)]),
     "gdr_preprocess_forward": (C.c_int, [C.POINTER(GdrSettings), C.POINTER(GdrInputs), C.POINTER(GdrGeom),
                                          C.c_void_p, C.POINTER(C.c_uint32), C.c_void_p]),

@@ -332,6 +332,17 @@ int gdr_composite_forward_lossgrad(const gdr_settings* s, const gdr_geom* geom, 
     return debug_sync(s, "render_fwd_lossgrad", st);
 }
 
+int gdr_words_differ(const void* a, const void* b, uint64_t n_bytes, uint32_t* flag, void* stream) {
+    if (!flag || (n_bytes && (!a || !b)) || (n_bytes & 3u) || (((uintptr_t)a | (uintptr_t)b) & 15u)) {
+        set_error("words_differ: NULL / unaligned argument", hipSuccess);
+        return GDR_ERR_INVALID_ARG;
+    }
+    if (n_bytes == 0) return GDR_OK;
+    hipError_t e = launch_words_differ(a, b, n_bytes, flag, (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail("words_differ", e);
+    return GDR_OK;
+}
+
 size_t gdr_topk_workspace_bytes(void) { return select_workspace_bytes(); }
 
 int gdr_topk_absgrad(int32_t N, const float* grad, const uint8_t* candidates, int32_t k, void* workspace, uint8_t* mask,

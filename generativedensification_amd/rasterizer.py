@@ -143,13 +143,6 @@ _FORCE_GLOBAL_SORT = False
 RENDER_SIDE = int(_os.environ.get("GDR_RENDER_SIDE", "1"))
 # streams that carry the views' forward chains (binning + K6) of a multi-view node, the caller's stream included
 FWD_STREAMS = int(_os.environ.get("GDR_FWD_STREAMS", "4"))
-# views per binning chain of a multi-view node (gdr_binning_forward_views covers a group of views with every launch)
-BIN_GROUP = int(_os.environ.get("GDR_BIN_GROUP", "1"))
-# views per K9 launch of a multi-view node's backward.  Smaller groups let the K9 of a group (HBM-bound) run under the
-# next group's K7 (VALU-bound) on a stream of its own (_SideViews) — measured on MI355X and NOT the default: every K9
-# launch re-reads the inputs and read-modify-writes the gradients, and K7's gathers lose bandwidth to it
-# (views/s, groups of 8 / 2 / 1: C4 1234 / 1112 / 916, C3 2918 / 2865 / 2825, C2 2957 / 2879 / 2764, C5 1067 / 1056 / 1010).
-BWD_GROUP = int(_os.environ.get("GDR_BWD_GROUP", str(L.GDR_MAX_VIEWS)))
 # side streams of the backward (K7 of the views); unset = side_count()
 BWD_STREAMS = int(_os.environ["GDR_BWD_STREAMS"]) if _os.environ.get("GDR_BWD_STREAMS") else None
 _BIN_STREAM_ENV = _os.environ.get("GDR_BIN_STREAM")
@@ -208,9 +201,9 @@ class _SideViews:
     """Streams of the backward of a multi-view node.  K7 of the views runs round-robin on side streams: the views are
     independent, one view's kernel leaves CUs idle whenever its tile lists are skewed (an object in front of an empty
     background: a few hundred busy tiles for 256 CUs) and at its tail, and another view's workgroups fill them.  K9 (one
-    launch per group of BWD_GROUP views, summing their records into the per-Gaussian gradients; every launch after the
-    first accumulates) follows its group's K7; with more than one group it goes onto a stream of its own, so that a
-    group's K9 can run under the next group's K7 (see BWD_GROUP for what that measured).
+    launch per <= GDR_MAX_VIEWS views, summing their records into the per-Gaussian gradients; every launch after the
+    first accumulates) follows on the caller's stream.  (K9 per pair of views on a stream of its own under the next
+    pair's K7 was measured in round 2 and lost 3-10 %: DESIGN §3.)
     Everything on the caller's stream when GDR_RENDER_SIDE=0 or for a single view.
 
         sides = _SideViews(dev, V, H, W)      # after all torch-side preparation: the side streams wait for this point
@@ -223,36 +216,25 @@ class _SideViews:
     def __init__(self, dev, n, H, W):
         self.main = torch.cuda.current_stream()
         self.n = n
-        ns = side_count(H, W) if BWD_STREAMS is None else BWD_STREAMS
-        self.group = max(1, min(BWD_GROUP, L.GDR_MAX_VIEWS))
-        on = bool(RENDER_SIDE and ns > 0 and n > 1)
-        self.pipelined = on and n > self.group and self.group < L.GDR_MAX_VIEWS   # (off by default: see BWD_GROUP)
-        if self.pipelined:      # caller's + 2 x K7 + K9 = the four hardware queues of a process
-            pool = _view_streams(dev, 3)
-            self.side, self.k9 = pool[:min(ns, 2)], pool[2]
-        else:
-            self.side, self.k9 = (_view_streams(dev, min(ns, n)) if on else None), None
+        self.side = self.k7_streams(dev, n, H, W, unique=True)
         if self.side:
             ready = torch.cuda.Event()
             ready.record(self.main)
-            for sd in self.side + ([self.k9] if self.k9 is not None else []):
+            for sd in self.side:
                 sd.wait_event(ready)
 
     @staticmethod
-    def k7_streams(dev, n, H, W):
-        """The torch stream K7 of each of n views will run on (what __init__ sets up), or None: caller's stream only."""
+    def k7_streams(dev, n, H, W, unique=False):
+        """The torch stream K7 of each of n views will run on, or None: caller's stream only.  unique: the distinct streams."""
         ns = side_count(H, W) if BWD_STREAMS is None else BWD_STREAMS
         if not (RENDER_SIDE and ns > 0 and n > 1):
             return None
-        group = max(1, min(BWD_GROUP, L.GDR_MAX_VIEWS))
-        pipelined = n > group and group < L.GDR_MAX_VIEWS
-        side = _view_streams(dev, 3)[:min(ns, 2)] if pipelined else _view_streams(dev, min(ns, n))
-        return [side[k % len(side)] for k in range(n)]
+        side = _view_streams(dev, min(ns, n))
+        return side if unique else [side[k % len(side)] for k in range(n)]
 
     def groups(self):
         """(first view, views) of every K9 launch."""
-        step = self.group if self.pipelined else L.GDR_MAX_VIEWS
-        return [(lo, min(step, self.n - lo)) for lo in range(0, self.n, step)]
+        return [(lo, min(L.GDR_MAX_VIEWS, self.n - lo)) for lo in range(0, self.n, L.GDR_MAX_VIEWS)]
 
     def _side_of(self, k):
         return self.side[k % len(self.side)]
@@ -263,27 +245,28 @@ class _SideViews:
         return C.c_void_p(self.main.cuda_stream)
 
     def k9_stream(self, lo, n):
-        """The stream for K9 of views [lo, lo+n), made to wait for their K7."""
-        if not self.side:
-            return C.c_void_p(self.main.cuda_stream)
-        target = self.k9 if self.pipelined else self.main
-        for sd in {self._side_of(k) for k in range(lo, lo + n)}:
-            done = torch.cuda.Event()
-            done.record(sd)
-            target.wait_event(done)
-        return C.c_void_p(target.cuda_stream)
+        """The stream for K9 of views [lo, lo+n) (the caller's), made to wait for their K7."""
+        if self.side:
+            for sd in {self._side_of(k) for k in range(lo, lo + n)}:
+                done = torch.cuda.Event()
+                done.record(sd)
+                self.main.wait_event(done)
+        return C.c_void_p(self.main.cuda_stream)
 
     def join(self):
         if self.side:
-            for sd in self.side + ([self.k9] if self.k9 is not None else []):
+            for sd in self.side:
                 done = torch.cuda.Event()
                 done.record(sd)
                 self.main.wait_event(done)
 
 
 def forward_raw(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                raster_settings):
-    """Un-differentiated forward. Returns (color, radii, depth, alpha, state, keep)."""
+                raster_settings, same_as=None):
+    """Un-differentiated forward. Returns (color, radii, depth, alpha, state, keep).
+    same_as: optional [(tensor, reference tensor)] pairs a render group wants verified equal bit for bit (viewgroup.py):
+    compared on the device next to K1, the verdict travels with the duplicate count (the spare word behind
+    gdr_geom.num_rendered, same 8-byte copy) — no extra copy, no extra synchronisation; a difference raises here."""
     lib = L.load()
     _require_hip(means3D, "means3D")
     dev = means3D.device
@@ -329,26 +312,42 @@ def forward_raw(means3D, sh, colors_precomp, opacities, scales, rotations, cov3D
             L.check(lib.gdr_render_forward(C.byref(s), C.byref(inp), C.byref(st.geom), C.byref(st.bin),
                                            C.byref(st.img), st.D, C.byref(out), stream), "gdr_render_forward")
 
+        # [duplicate count, spare word]: the geometry workspace keeps a 256-byte slot behind num_rendered
+        st.counters = st._view(st.geom_buf, st.geom.num_rendered, torch.int32, 2)
+        if same_as:
+            st.counters[1:2].zero_()
+            for t, ref in same_as:
+                L.check(lib.gdr_words_differ(C.c_void_p(t.data_ptr()), C.c_void_p(ref.data_ptr()), t.numel() * 4,
+                                             C.c_void_p(st.geom.num_rendered + 4), stream), "gdr_words_differ")
+        differ = 0
         if cap is None:   # first call of this shape: the read-back upstream performs in every call
             d_host = C.c_uint32(0)
             L.check(lib.gdr_preprocess_forward(C.byref(s), C.byref(inp), C.byref(st.geom), _ptr(radii),
                                                C.byref(d_host), stream), "gdr_preprocess_forward")
             d = int(d_host.value)
+            if same_as:
+                differ = _CountReadback(st.counters).wait()[1]
             _carve_binning(lib, st, d, tiles, stats=srow, hints=hints)
             render()
         else:             # device-sized call (DEFER_D above): nothing waits for K1 until everything is enqueued
             L.check(lib.gdr_preprocess_forward(C.byref(s), C.byref(inp), C.byref(st.geom), _ptr(radii), None, stream),
                     "gdr_preprocess_forward")
-            st.counters = st._view(st.geom_buf, st.geom.num_rendered, torch.int32, 1)
             readback = _CountReadback(st.counters)
             _carve_binning(lib, st, cap, tiles, d_dev=st.geom.num_rendered, stats=srow, hints=hints)
             render()
-            d = readback.wait()[0]
+            d, differ = readback.wait()
+            differ = differ if same_as else 0
             if d > cap:
                 _carve_binning(lib, st, d, tiles, stats=srow, hints=hints)
                 render()
             st.D = d
         _d_record(key, [d], N)
+        if differ:
+            raise RuntimeError(
+                "diff_gaussian_rasterization: this call's opacities / scales / rotations have the autograd provenance of "
+                "an earlier call's (same ops on the same sources) but different values — a source tensor was modified in "
+                "place between the calls, outside autograd's view.  Set GDR_GROUP_VIEWS=0 to render every call as an "
+                "independent node.")
     return color, radii, depth, alpha, st, keep
 
 
@@ -603,21 +602,6 @@ def _carve_binning(lib, st, entries, tiles, d_dev=None, stats=None, hints=None):
         st.bin.stats_out = stats.data_ptr()
 
 
-def binning_views(lib, s_arr, N, g_arr, states, radii, lo, hi, stream, fn="gdr_binning_forward_views"):
-    """K3..K5 + tile sort of views [lo, hi) in shared launches (<= GDR_MAX_VIEWS views per chain)."""
-    for a in range(lo, hi, L.GDR_MAX_VIEWS):
-        n = min(L.GDR_MAX_VIEWS, hi - a)
-        sub_s = (L.GdrSettings * n)(*[s_arr[a + k] for k in range(n)])
-        sub_g = (L.GdrGeom * n)(*[g_arr[a + k] for k in range(n)])
-        b_arr = (L.GdrBinning * n)(*[states[a + k].bin for k in range(n)])
-        i_arr = (L.GdrImage * n)(*[states[a + k].img for k in range(n)])
-        d_arr = (C.c_uint64 * n)(*[states[a + k].D for k in range(n)])
-        r_arr = (C.c_void_p * n)(*[(radii[a + k].data_ptr() if N else None) for k in range(n)])
-        L.check(getattr(lib, fn)(n, sub_s, N, sub_g, b_arr, i_arr, d_arr, r_arr, stream), fn)
-        for k in range(n):
-            states[a + k].bin.sorted = b_arr[k].sorted
-
-
 def _forward_views_impl(means3D, means2D, sh, opacities, scales, rotations, settings_list, flags, loss_spec=None):
     """K1 for all views (one launch per <= 8 views), then every view's chain binning -> K6 on one of FWD_STREAMS
     streams; the duplicate counts are read back without stalling either side (see DEFER_D above).
@@ -722,26 +706,15 @@ def _forward_views_impl(means3D, means2D, sh, opacities, scales, rotations, sett
                                                        float(w_alpha), losses[v:v + 1].data_ptr(), sv),
                         "gdr_composite_forward_loss")
 
-        def chain(lo, hi, fs):   # binning of views [lo, hi) in shared launches on stream fs, then their K6
-            sp = C.c_void_p(fs.cuda_stream)
-            if hi - lo == 1:
-                st = states[lo]
-                L.check(lib.gdr_binning_forward(C.byref(s_arr[lo]), N, C.byref(g_arr[lo]), C.byref(st.bin),
-                                                C.byref(st.img), st.D, _ptr(radii[lo]), sp), "gdr_binning_forward")
-                composite(lo, sp)
-                return
-            binning_views(lib, s_arr, N, g_arr, states, radii, lo, hi, sp)
-            binned = torch.cuda.Event()
-            binned.record(fs)
-            for v in range(lo, hi):      # the group's K6 spread over the streams again
-                ks = fstreams[v % nfs] if fs in fstreams else fs
-                if ks is not fs:
-                    ks.wait_event(binned)
-                composite(v, C.c_void_p(ks.cuda_stream))
+        def chain(v, fs):   # binning of view v on stream fs, then its K6 (batched chains for several views were measured in
+            sp = C.c_void_p(fs.cuda_stream)                       # round 2 and lost 5-10 %: DESIGN §3)
+            st = states[v]
+            L.check(lib.gdr_binning_forward(C.byref(s_arr[v]), N, C.byref(g_arr[v]), C.byref(st.bin),
+                                            C.byref(st.img), st.D, _ptr(radii[v]), sp), "gdr_binning_forward")
+            composite(v, sp)
 
-        grp = max(1, min(BIN_GROUP, L.GDR_MAX_VIEWS))
-        for c, lo in enumerate(range(0, V, grp)):
-            chain(lo, min(V, lo + grp), fstreams[c % nfs])
+        for v in range(V):
+            chain(v, fstreams[v % nfs])
         for fs in fstreams[1:]:   # the caller's stream continues only after every view is rendered
             done = torch.cuda.Event()
             done.record(fs)
@@ -753,7 +726,7 @@ def _forward_views_impl(means3D, means2D, sh, opacities, scales, rotations, sett
                 _carve_binning(lib, states[v], d_host[v], tiles, stats=srow(v), hints=hints)
                 if loss_spec is not None:
                     loss_spec[-1][v:v + 1].zero_()
-                chain(v, v + 1, main)
+                chain(v, main)
             for v, st in enumerate(states):
                 st.D = d_host[v]
         _d_record(key, d_host, N)
@@ -1025,6 +998,12 @@ def screenspace_absgrad_raw(means3D, sh, opacities, scales, rotations, settings_
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
                         cov3Ds_precomp, raster_settings):
+    """The reference boundary.  Calls that are provably handed the same Gaussians as earlier ones (the per-view loops of
+    network.py:827-838, 848-856, 964-972) join a render group: one preprocess-backward for all of them (viewgroup.py);
+    everything else is one independent autograd node per call."""
+    from . import viewgroup
+    if viewgroup.eligible(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp):
+        return viewgroup.grouped_call(means3D, means2D, sh, opacities, scales, rotations, raster_settings)
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
                                      cov3Ds_precomp, raster_settings)
 

@@ -371,6 +371,11 @@ int gdr_view_loss_backward(const float* color, const float* target, int32_t H, i
                            float w_alpha, const float* g, float* dL_dcolor, float* dL_ddepth, float* dL_dalpha,
                            void* stream);
 
+/* ---- host-boundary helper: *flag |= 1 if the n_bytes (a multiple of 4; a, b 16-byte aligned) at a and b differ in any
+ * 32-bit word.  Used by the Python boundary to verify that two calls of one render group were handed the same activated
+ * tensors (see generativedensification_amd/viewgroup.py); one read of both buffers, no host synchronisation. */
+int gdr_words_differ(const void* a, const void* b, uint64_t n_bytes, uint32_t* flag, void* stream);
+
 /* ---- K10: visibility mask (upstream markVisible; unused by the reference) -------- */
 int gdr_mark_visible(int32_t N, const float* means3D, const float* viewmatrix,
                      const float* projmatrix, uint8_t* present, void* stream);

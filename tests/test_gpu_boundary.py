@@ -172,42 +172,6 @@ def test_device_topk_of_the_densification_score_matches_torch_topk():
     assert int(mask.sum()) == 1000 - n_nan and not bool(mask[::7].any())
 
 
-@pytest.mark.parametrize("group", [2, 8])
-def test_batched_binning_chain_gives_the_same_lists_and_images(group):
-    """gdr_binning_forward_views (every binning launch covers a group of views, view = blockIdx.y) against one chain per
-    view (the default): sorted keys / values, ranges and tile order state bit-identical, images identical."""
-    from generativedensification_amd import rasterizer as R
-    from generativedensification_amd.camera import orbit_cameras
-    from generativedensification_amd.renderer import Renderer
-    from generativedensification_amd.synthetic import make_scene
-    dev = torch.device(DEV)
-    V = 5
-    scene = make_scene(60_000, 17, sh_degree=1, sigma0=(0.01, 0.002), device=dev)
-    cams = orbit_cameras(V, 208, 160, device=dev)
-    sets = [Renderer(sh_degree=1).set_rasterizer(c, device=dev).raster_settings for c in cams]
-
-    def run(g):
-        saved = R.BIN_GROUP
-        R.BIN_GROUP = g
-        try:
-            with torch.no_grad():
-                colors, radii, depths, alphas, states, keep, _ = R._forward_views_impl(
-                    scene["centers"], torch.empty(0, 4, device=dev), scene["shs"], scene["opacity"], scene["scales"],
-                    scene["rotations"], tuple(sets), R.RAW_ALL)
-            torch.cuda.synchronize()
-            return colors, [st.tensors() for st in states]
-        finally:
-            R.BIN_GROUP = saved
-
-    c1, t1 = run(1)
-    cg, tg = run(group)
-    for v in range(V):
-        assert t1[v]["num_rendered"] == tg[v]["num_rendered"] > 0
-        for k in ("keys_sorted", "point_list", "ranges", "n_contrib"):
-            assert torch.equal(t1[v][k], tg[v][k]), (v, k)
-        assert torch.equal(c1[v], cg[v])
-
-
 @pytest.mark.parametrize("surfel", [False, True])
 def test_device_sized_binning_equals_the_read_back_and_an_overflow_repeats_the_view(surfel):
     """rasterizer.DEFER_D: the first call of a shape reads the duplicate count back before binning (upstream's flow);
@@ -300,56 +264,6 @@ def test_device_sized_binning_equals_the_read_back_and_an_overflow_repeats_the_v
         R.DEFER_D = saved_defer
         R._D_HINT.clear()
         R._D_HINT.update(saved)
-
-
-@pytest.mark.parametrize("surfel", [False, True])
-@pytest.mark.parametrize("group", [1, 2])
-def test_backward_in_k9_groups_on_their_own_stream_gives_the_same_gradients(surfel, group):
-    """rasterizer.BWD_GROUP < V: K9 per group of views on its own stream behind the group's K7, later groups accumulating
-    (_SideViews) — same gradients as one K9 over all views, up to the order of the float sums over views."""
-    from generativedensification_amd import rasterizer as R
-    from generativedensification_amd.camera import build_rays, orbit_cameras
-    from generativedensification_amd.synthetic import make_scene, make_targets
-    dev = torch.device(DEV)
-    V, H, W, N = 5, 128, 160, 30_000
-    scene = make_scene(N, 31, sh_degree=1, sigma0=(0.01, 0.003), device=dev)
-    if surfel:
-        scene["scales"] = scene["scales"][:, :2].contiguous()
-    cams = orbit_cameras(V, W, H, device=dev)
-    targets = make_targets(V, H, W, 9).to(dev).permute(0, 3, 1, 2).contiguous()
-    if surfel:
-        from generativedensification_amd.renderer_2dgs import Renderer
-        r = Renderer(sh_degree=1)
-        rays = [build_rays(torch.inverse(c.world_view_transform.T.cpu()), 0.75, 0.75, H, W).to(dev) for c in cams]
-    else:
-        from generativedensification_amd.renderer import Renderer
-        r = Renderer(sh_degree=1, white_background=True)
-        r.set_bg_color(torch.ones(3, device=dev))
-
-    def grads(fused_loss):
-        p = {k: v.clone().requires_grad_(True) for k, v in scene.items()}
-        a = (p["centers"], p["shs"], p["opacity"], p["scales"], p["rotations"], dev)
-        if fused_loss:
-            lv = r.render_views_loss(cams, rays, None, targets, *a) if surfel else r.render_views_loss(cams, None, targets, *a)
-        else:
-            outs = r.render_views(cams, rays, None, *a) if surfel else r.render_views(cams, None, *a)
-            lv = torch.stack([((o["image"].permute(2, 0, 1) - targets[j]) ** 2).mean() for j, o in enumerate(outs)])
-        lv.sum().backward()
-        torch.cuda.synchronize()
-        return {k: v.grad.cpu().numpy() for k, v in p.items()}
-
-    saved = R.BWD_GROUP
-    try:
-        for fused_loss in (True, False):
-            R.BWD_GROUP = saved
-            g0 = grads(fused_loss)
-            R.BWD_GROUP = group
-            g1 = grads(fused_loss)
-            for k in g0:
-                tol = 1e-4 * np.abs(g0[k]) + 1e-6 * np.abs(g0[k]).max()
-                assert (np.abs(g1[k] - g0[k]) > tol).mean() < 1e-4, (fused_loss, k)
-    finally:
-        R.BWD_GROUP = saved
 
 
 def test_launch_hints_only_size_launches():

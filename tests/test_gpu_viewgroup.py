@@ -1,0 +1,154 @@
+"""-m gpu: render groups (generativedensification_amd/viewgroup.py) — the fast path of the UNCHANGED caller.
+
+The reference renders the views of one Gaussian set one `render_img` at a time and back-propagates once
+(/root/reference/lightning/network.py:827-838, 848-856, 964-972; renderer.py:225-259).  Grouped, those calls share ONE
+preprocess-backward; the results must be what independent calls give: images bit for bit (the forward is the same code),
+leaf gradients within the per-element bar (only the order of fp32 sums over the views changes)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import util as U
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _setup(V=4, n=20_000, h=128, w=160, deg=1, B=2, seed=5):
+    from generativedensification_amd.camera import orbit_cameras
+    from generativedensification_amd.rasterizer import GaussianRasterizationSettings
+    from generativedensification_amd.synthetic import make_scene, make_targets
+    dev = torch.device(DEV)
+    scenes = [make_scene(n, seed + b, sh_degree=deg, sigma0=(0.0052, 0.02), device=dev) for b in range(B)]
+    base = {k: torch.stack([sc[k] for sc in scenes]) for k in scenes[0]}       # (B, N, ...) like the decoder's outputs
+    cams = orbit_cameras(V, w, h, device=dev)
+    three = ([1.0, 1.0, 1.0], [0.5, 0.5, 0.5], [0.0, 0.0, 0.0])
+    sets = [GaussianRasterizationSettings(
+        image_height=h, image_width=w, tanfovx=math.tan(0.375), tanfovy=math.tan(0.375),
+        bg=torch.tensor(three[j % 3], device=dev), scale_modifier=1.0, viewmatrix=c.world_view_transform,
+        projmatrix=c.full_proj_transform, sh_degree=deg, campos=c.camera_center, prefiltered=False, debug=False)
+        for j, c in enumerate(cams)]
+    tg = make_targets(V, h, w, seed).to(dev).permute(0, 3, 1, 2)
+    return dev, base, sets, tg, n
+
+
+def _reference_loop(leaves, sets, tg, n, dev, i=1, carriers=None):
+    """What network.py + renderer.py do for sample i: per view new slices, new activations, a new carrier, one call."""
+    import diff_gaussian_rasterization as D
+    centers = leaves["centers"][i]                      # (taken once, network.py:821)
+    imgs, losses, ssps = [], [], []
+    for j, rs in enumerate(sets):
+        ssp = (torch.zeros(n, 4, device=dev, requires_grad=True) + 0) if carriers is None else carriers[j]
+        ssp.retain_grad()
+        color, radii, depth, alpha = D.GaussianRasterizer(rs)(
+            means3D=centers, means2D=ssp, shs=leaves["shs"][i], opacities=torch.sigmoid(leaves["opacity"][i]),
+            scales=torch.exp(leaves["scales"][i]), rotations=torch.nn.functional.normalize(leaves["rotations"][i]))
+        imgs.append(torch.cat([color, depth, alpha]))
+        losses.append(((color.clamp(0, 1) - tg[j]) ** 2).mean() + 0.1 * depth.mean() + 0.1 * alpha.mean())
+        ssps.append(ssp)
+    return imgs, losses, ssps
+
+
+def _run(grouped, base, sets, tg, n, dev, per_view_backward=False):
+    from generativedensification_amd import _lib as L
+    from generativedensification_amd import viewgroup as G
+    saved = G.GROUP_VIEWS
+    G.GROUP_VIEWS = grouped
+    try:
+        leaves = {k: v.clone().requires_grad_(True) for k, v in base.items()}
+        L.profile_enable(True)
+        L.profile_collect(reset=True)
+        imgs, losses, ssps = _reference_loop(leaves, sets, tg, n, dev)
+        if per_view_backward:
+            for l in losses:
+                l.backward(retain_graph=True)
+        else:
+            sum(losses).backward()
+        torch.cuda.synchronize()
+        prof = L.profile_collect(reset=True)
+        L.profile_enable(False)
+    finally:
+        G.GROUP_VIEWS = saved
+    return ([x.detach().cpu().numpy() for x in imgs], {k: v.grad.cpu().numpy() for k, v in leaves.items()},
+            [s.grad.cpu().numpy() for s in ssps], prof)
+
+
+@pytest.mark.parametrize("per_view_backward", [False, True])
+def test_grouped_calls_equal_independent_calls(per_view_backward):
+    dev, base, sets, tg, n = _setup()
+    i0, g0, m0, p0 = _run(False, base, sets, tg, n, dev, per_view_backward)
+    i1, g1, m1, p1 = _run(True, base, sets, tg, n, dev, per_view_backward)
+    V = len(sets)
+    assert p0["preprocess_bwd"][1] == V                                   # independent: one K8+K9 per view
+    assert p1["preprocess_bwd"][1] == (V if per_view_backward else 1)     # grouped: one per backward pass
+    assert p1["render_bwd"][1] == V and p1["preprocess_fwd"][1] == V
+    for a, b in zip(i1, i0):
+        np.testing.assert_array_equal(a, b)
+    for k in g0:
+        out, worst, maxn = U.elem_stats(g1[k], g0[k])
+        assert out < U.MAX_OUTSIDE and maxn < 1e-4, (k, out, worst, maxn)
+        assert np.abs(g0[k][0]).max() == 0 and np.abs(g1[k][0]).max() == 0      # sample 0 was never rendered
+    for a, b in zip(m1, m0):      # every call's own (N,4) carrier gradient: K7's records, no reordering at all
+        out, worst, maxn = U.elem_stats(a, b)
+        assert a.shape == (n, 4) and out < U.MAX_OUTSIDE and maxn < 1e-4 and (a[:, 2:] >= 0).all()
+
+
+def test_vjp_pass_then_main_pass_and_a_second_gaussian_set():
+    """network.py's sequence on one sample: coarse renders, `vjp` w.r.t. a shared carrier through renders of the SAME set
+    (network.py:843-872: the hub is not part of that pass, its K7 results must not leak into the next), renders of a
+    DIFFERENT set (another group), one backward through everything."""
+    from torch.autograd.functional import vjp
+    from generativedensification_amd import viewgroup as G
+    dev, base, sets, tg, n = _setup(V=3)
+
+    def run(grouped):
+        saved = G.GROUP_VIEWS
+        G.GROUP_VIEWS = grouped
+        try:
+            leaves = {k: v.clone().requires_grad_(True) for k, v in base.items()}
+            _, losses, _ = _reference_loop(leaves, sets, tg, n, dev, i=1)
+
+            def fn(ssp):
+                _, l2, _ = _reference_loop(leaves, sets[:2], tg, n, dev, i=1, carriers=[ssp, ssp])
+                return sum(l2)
+            with torch.no_grad():
+                val, grad = vjp(fn, torch.zeros(n, 4, device=dev))
+            _, losses_b, _ = _reference_loop(leaves, sets, tg, n, dev, i=0)
+            (sum(losses) + sum(losses_b)).backward()
+            return grad.cpu().numpy(), {k: v.grad.cpu().numpy() for k, v in leaves.items()}
+        finally:
+            G.GROUP_VIEWS = saved
+
+    a0, g0 = run(False)
+    a1, g1 = run(True)
+    out, _, maxn = U.elem_stats(a1, a0)
+    assert out < U.MAX_OUTSIDE and maxn < 1e-4 and np.abs(a0[:, 2:]).max() > 0
+    for k in g0:
+        out, worst, maxn = U.elem_stats(g1[k], g0[k])
+        assert out < U.MAX_OUTSIDE and maxn < 1e-4, (k, out, worst, maxn)
+        assert np.abs(g0[k][0]).max() > 0 and np.abs(g0[k][1]).max() > 0
+
+
+def test_values_that_changed_behind_autograds_back_raise():
+    """Equal provenance, different values: a source edited in place under no_grad between two calls.  Views of the edited
+    tensor carry its version counter (a new group, correct gradients); the activated copies do not — the device-side
+    comparison next to K1 catches them and the offending call raises instead of joining the group."""
+    import diff_gaussian_rasterization as D
+    dev, base, sets, tg, n = _setup(V=2, B=1)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in base.items()}
+    mid = {k: v * 1.0 for k, v in leaves.items()}        # non-leaf sources, like a decoder's outputs
+
+    def call(rs):
+        ssp = torch.zeros(n, 4, device=dev, requires_grad=True)
+        return D.GaussianRasterizer(rs)(means3D=mid["centers"][0], means2D=ssp, shs=mid["shs"][0],
+                                        opacities=torch.sigmoid(mid["opacity"][0]), scales=torch.exp(mid["scales"][0]),
+                                        rotations=torch.nn.functional.normalize(mid["rotations"][0]))[0]
+    a = call(sets[0])
+    with torch.no_grad():
+        mid["opacity"].add_(0.5)
+    with pytest.raises(RuntimeError, match="different values"):
+        call(sets[1])
+    a.mean().backward()        # the first call is unaffected
+    assert all(torch.isfinite(v.grad).all() for v in leaves.values())
