@@ -52,6 +52,13 @@ WORKLOADS = {
                     "statistics of network.py's decoder output, 8 views 512x512, SH1 (configs/base.yaml), fwd+bwd"),
     "c2": dict(n=200_000, sigma0=(0.0052, 0.00065), seed=1, views_per_gpu=4, h=800, w=800, deg=3,
                desc="BASELINE configs[1]: 200k Gaussians (50/50 sigma0 mix), 4 views 800x800, SH3, fwd+bwd"),
+    "c3step": dict(n=262_144, n_fine=81_600, k_num=12_000, samples=3, sigma0=(0.0052,), seed=2, views_per_gpu=8, v_sel=4,
+                   h=512, w=512, deg=1,
+                   desc="BASELINE configs[2] call pattern: the reference's train-step render sequence per sample "
+                        "(network.py:826-972): 8 coarse renders of 262144 Gaussians -> vjp of the image MSE over 4 views "
+                        "w.r.t. the (N,4) carrier + top-k 12000 -> 8 fine renders of 81600 new + the unselected coarse "
+                        "Gaussians; B = 3 samples (configs/base.yaml:122), 512x512, SH1; loss on image + image_fine with "
+                        "the coarse depth / alpha carrying gradient; ONE backward per step"),
     "c5": dict(n=500_000, sigma0=(0.0052, 0.00065), seed=5, views_per_gpu=4, h=800, w=800, deg=3, surfel=True,
                desc="BASELINE configs[4]: 2DGS surfel path (renderer_2dgs.render_img: image + depth/normal/distortion "
                     "maps), 500k surfels (50/50 sigma0 mix), 4 views 800x800, SH3, fwd+bwd"),
@@ -109,6 +116,152 @@ def surfel_algorithmic_bytes(n, d, p, m, tiles, v=1):
     out["_bytes_view"] = (out["preprocess_fwd"] + n * 28 + d * K + d * (8 + passes * 2 * K) + d * 8 + out["render_fwd"]
                           + out["render_bwd"] + n * (A + S + 128) + n * (A + 16))   # (path level: the SURVEY-style formula)
     return out
+
+
+def run_c3step(args, wl, dev, rank, world, use_dist, barrier_fn):
+    """The reference's per-sample render sequence as a timed workload (see WORKLOADS["c3step"]); every rank runs its own
+    B samples (the reference's own strategy: DDP over scenes, train_lightning.py:71-76).  Reported through the fused entry
+    points (`value`) and through the unchanged caller's pattern (`per_view`): renders/s, a render = one view forward +
+    backward (the 4 vjp views of a sample count: they are rendered and differentiated)."""
+    import gc
+    from torch.autograd.functional import vjp
+    from generativedensification_amd import _lib as L
+    from generativedensification_amd.camera import orbit_cameras
+    from generativedensification_amd.renderer import Renderer
+    from generativedensification_amd.synthetic import make_scene, make_targets
+
+    B, V, VS, K = wl["samples"], wl["views_per_gpu"], wl["v_sel"], wl["k_num"]
+    n, nf, h, w, deg = args.n or wl["n"], wl["n_fine"], wl["h"], wl["w"], wl["deg"]
+    keys = ("centers", "shs", "opacity", "scales", "rotations")
+    coarse = [make_scene(n, wl["seed"] + 10 * (rank * B + b), sh_degree=deg, sigma0=wl["sigma0"], device=dev, layout=args.layout)
+              for b in range(B)]
+    fine = [make_scene(nf, wl["seed"] + 10 * (rank * B + b) + 1, sh_degree=deg, sigma0=(0.00065,), device=dev, layout=args.layout)
+            for b in range(B)]
+    # the decoder's outputs are batched tensors the loops index per sample (network.py:821-836)
+    lc = {k: torch.stack([c[k] for c in coarse]).requires_grad_(True) for k in keys}
+    lf = {k: torch.stack([f[k] for f in fine]).requires_grad_(True) for k in keys}
+    leaves = list(lc.values()) + list(lf.values())
+    cams = orbit_cameras(V, w, h, device=dev)
+    tg = make_targets(V, h, w, wl["seed"]).to(dev)
+    tg_chw = tg.permute(0, 3, 1, 2).contiguous()
+    three = ([1.0, 1.0, 1.0], [0.5, 0.5, 0.5], [0.0, 0.0, 0.0])      # dataLoader/gobjverse.py:112-117
+    bgs = [torch.tensor(three[j % 3], device=dev) for j in range(V)]
+    r_caller = Renderer(sh_degree=deg, fused=False)
+    r_fused = Renderer(sh_degree=deg)
+    L.load()
+
+    def caller_step():      # lightning/network.py:813-972 + renderer.py:209-272, op for op
+        for p in leaves:
+            p.grad = None
+        total = 0
+        for i in range(B):
+            centers = lc["centers"][i]
+            oc = []
+            for j in range(V):
+                r_caller.set_bg_color(bgs[j])
+                oc.append(r_caller.render_img(cams[j], None, centers, lc["shs"][i], lc["opacity"][i], lc["scales"][i],
+                                              lc["rotations"][i], dev))
+
+            def fn(ssp):
+                fr = []
+                for j in range(VS):
+                    r_caller.set_bg_color(bgs[j])
+                    fr.append(r_caller.render_img(cams[j], None, centers, lc["shs"][i], lc["opacity"][i], lc["scales"][i],
+                                                  lc["rotations"][i], dev, screenspace_points=ssp))
+                return ((torch.stack([f["image"] for f in fr]) - tg[:VS]) ** 2).mean()
+            _, grad = vjp(fn, torch.zeros(n, 4, device=dev))
+            score = torch.norm(grad[:, 2:4], dim=-1)
+            sel = torch.zeros(n, dtype=torch.bool, device=dev)
+            sel[torch.topk(score, K, dim=0).indices] = True
+            fs = [torch.cat([lf[k][i], lc[k][i][~sel]], dim=0) for k in keys]
+            of = []
+            for j in range(V):
+                r_caller.set_bg_color(bgs[j])
+                of.append(r_caller.render_img(cams[j], None, *fs, dev, prex="_fine"))
+            img_c = torch.cat([o["image"] for o in oc], dim=1)          # views concatenated along the width (network.py:974)
+            img_f = torch.cat([o["image_fine"] for o in of], dim=1)
+            gt = torch.cat(list(tg), dim=1)
+            total = total + ((img_c - gt) ** 2).mean() + ((img_f - gt) ** 2).mean() \
+                + 0.1 * torch.cat([o["depth"] for o in oc], dim=1).mean() + 0.1 * torch.cat([o["acc_map"] for o in oc], dim=1).mean()
+        total.backward()
+        return total.detach()
+
+    def fused_step():       # the same sample through the multi-view entries: 3 nodes per sample instead of 20
+        for p in leaves:
+            p.grad = None
+        total = 0
+        for i in range(B):
+            a = [lc[k][i] for k in keys]
+            lv_c = r_fused.render_views_loss(cams, bgs, tg_chw, *a, dev, w_depth=0.1, w_alpha=0.1)
+            _, grad, idx = r_fused.screenspace_absgrad(cams[:VS], bgs[:VS], tg[:VS], *[x.detach() for x in a], dev, topk=K)
+            sel = torch.zeros(n, dtype=torch.bool, device=dev)
+            sel[idx] = True
+            fs = [torch.cat([lf[k][i], lc[k][i][~sel]], dim=0) for k in keys]
+            lv_f = r_fused.render_views_loss(cams, bgs, tg_chw, *fs, dev, w_depth=0.0, w_alpha=0.0)
+            total = total + (lv_c.sum() + lv_f.sum()) / V
+        total.backward()
+        return total.detach()
+
+    renders = B * (2 * V + VS) * world
+
+    def timed(fn, k, warm):
+        for _ in range(warm):
+            fn()
+        barrier_fn()
+        gc.collect()
+        gc.disable()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            last = fn()
+        barrier_fn()
+        el = time.perf_counter() - t0
+        gc.enable()
+        if use_dist:
+            t = torch.tensor([el], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el, float(last)
+
+    el_f, loss_f = timed(fused_step, args.steps, args.warmup)
+    el_c, loss_c = timed(caller_step, max(1, min(args.steps, 10)), max(1, min(args.warmup, 3)))
+    k_c = max(1, min(args.steps, 10))
+    kernels = {}
+    roofline = None
+    if not args.no_roofline:
+        L.profile_enable(True)
+        L.profile_collect(reset=True)
+        for _ in range(min(args.steps, 3)):
+            fused_step()
+        torch.cuda.synchronize()
+        prof = L.profile_collect(reset=True)
+        L.profile_enable(False)
+        ks = min(args.steps, 3)
+        kernels = {nm: dict(avg_us=round(1e3 * ms / c, 2), launches_per_step=round(c / ks, 1), ms_per_step=round(ms / ks, 3))
+                   for nm, (ms, c) in prof.items() if c}
+        if kernels:
+            dom = max(kernels, key=lambda q: kernels[q]["ms_per_step"])
+            roofline = dict(bound="hbm", kernel=dom, peak=HBM_PEAK_GBS, unit="GB/s", achieved=None, frac=None, traffic=None,
+                            avg_launch_us=kernels[dom]["avg_us"],
+                            note="mixed Gaussian sets per launch: per-kernel algorithmic bytes are reported by the c3 / c4 workloads")
+    v_f = renders * args.steps / el_f
+    v_c = renders * k_c / el_c
+    return {
+        "metric": "renders/sec fwd+bwd @ 512x512, reference train-step sequence", "value": round(v_f, 2), "unit": "renders/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * el_f / args.steps, 3),
+        "ms_per_sample": round(1e3 * el_f / args.steps / B, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic (seeded random Gaussians with the decoder's statistics, random targets)",
+        "config": {"workload": f"c3step: {wl['desc']}", "n_coarse": n, "n_fine_new": nf, "k_num": K, "samples_per_step": B,
+                   "renders_per_sample": 2 * V + VS, "image": [h, w], "sh_degree": deg, "layout": args.layout,
+                   "parallelism": f"scene-sharded x{world} (the reference's DDP)", "peak_mem_gb": round(torch.cuda.max_memory_allocated(dev) / 2**30, 2),
+                   "entry": "render_views_loss (coarse, fine) + screenspace_absgrad(topk) per sample: 3 rasterizer nodes"},
+        "per_view": {"value": round(v_c, 2), "unit": "renders/s", "ms_per_step": round(1e3 * el_c / k_c, 3),
+                     "ms_per_sample": round(1e3 * el_c / k_c / B, 3), "steps": k_c, "of_fused": round(v_c / v_f, 3),
+                     "entry": "the unchanged caller: render_img per view (torch activations, new settings + carrier per call), "
+                              "torch.autograd.functional.vjp + torch.topk, losses on the width-concatenated views, one backward"},
+        "loss_fused": loss_f, "loss_per_view": loss_c, "roofline": roofline, "cpu_baseline": None, "kernels": kernels,
+        "spread": "same box run-to-run +-0.3 %, box-to-box +-4 % (BASELINE.md section 4)",
+        "gc": "Python's cyclic collector disabled inside the timed regions (timeit convention; collected right before)",
+    }
 
 
 def main():
@@ -224,6 +377,14 @@ def main():
     from generativedensification_amd.synthetic import make_scene, make_targets, view_loss, views_loss
 
     wl = dict(WORKLOADS[args.workload])
+    if args.workload == "c3step":
+        out = run_c3step(args, wl, dev, rank, world, use_dist, barrier_fn=lambda: (dist.barrier() if use_dist else None,
+                                                                                    torch.cuda.synchronize()))
+        if rank == 0:
+            os.write(result_fd, (json.dumps(out) + "\n").encode())
+        if use_dist:
+            dist.destroy_process_group()
+        return
     if args.n:
         wl["n"] = args.n
     if args.views_per_gpu:
