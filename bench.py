@@ -525,10 +525,14 @@ def main():
         buf = io.StringIO()
         pstats.Stats(prof_host, stream=buf).sort_stats("tottime").print_stats(40)
         print(buf.getvalue(), file=sys.stderr)
-    if use_dist:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    rank_ms = None
+    if use_dist:     # the slowest rank is the job's time; every rank's own time is reported so that a straggler shows
+        mine_t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        all_t = [torch.zeros_like(mine_t) for _ in range(dist.get_world_size())]
+        dist.all_gather(all_t, mine_t)
+        per_rank = [float(x.item()) for x in all_t]
+        elapsed = max(per_rank)
+        rank_ms = [round(1e3 * x / args.steps, 3) for x in per_rank]
     views_per_sec = total_views * args.steps / elapsed
     ms_per_step = 1e3 * elapsed / args.steps
 
@@ -786,7 +790,7 @@ def main():
             "metric": "views/sec fwd+bwd @ 800x800", "value": round(views_per_sec, 2), "unit": "views/s",
             "n_gpus": world, "world_size": dist.get_world_size() if use_dist else 1,
             "dist_backend": (dist.get_backend() if use_dist else None), "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "ms_per_step_ranks": rank_ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic (seeded random Gaussians with the decoder's statistics, random targets)",
             "config": {"workload": f"{args.workload}: {wl['desc']}", "n_gaussians": n, "layout": args.layout, "order": args.order,
                        "views_per_gpu": vpg, "image": [h, w], "sh_degree": deg,

@@ -121,6 +121,23 @@ def test_bench_gpus2_spawns_two_ranks_by_itself():
     assert out["config"]["views_per_gpu"] == 4 and out["value"] > 0
 
 
+def test_bench_gpus8_on_one_device():
+    """The driver's 8-rank launch shape on a 1-GPU box: `bench.py --gpus 8 --single-device` becomes 8 ranks (gloo, all on
+    cuda:0, reduced N) — port / launcher / pinned-memory / side-stream-table problems that two ranks do not show would show
+    here; every rank's own step time is in the line (a straggler is visible)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--single-device", "--workload", "c2",
+                        "--n", "20000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-roofline",
+                        "--no-per-view-leg", "--grad-allreduce"], env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["world_size"] == 8 and out["dist_backend"] == "gloo" and out["value"] > 0
+    assert len(out["ms_per_step_ranks"]) == 8 and max(out["ms_per_step_ranks"]) == out["ms_per_step"]
+    assert out["config"]["views_per_gpu"] == 4 and out["config"]["grad_allreduce"] is True
+
+
 def test_bench_line_contract_on_one_gpu():
     """The JSON line the driver parses: contract fields, the `roofline` object (dominant kernel timed with HIP events on
     its launch stream, per-kernel fractions, measured path fraction, pairs/s) and both CPU baselines — on a reduced C2 so

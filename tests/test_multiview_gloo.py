@@ -51,7 +51,18 @@ def _worker(rank, world, port, n_views, q):
             losses = torch.empty(0)
         allv = gather_view_losses(losses.detach(), n_views)
         allreduce_gaussian_grads(list(g.values()))
-        q.put((rank, allv.tolist(), g["centers"].grad[0, 0].item(), float(g["rotations"].grad.abs().sum())))
+        first = (g["centers"].grad[0, 0].item(), float(g["rotations"].grad.abs().sum()))
+        # second step of a loop that KEEPS its gradients (zero_grad(set_to_none=False)): the gradients are views of the
+        # persistent packed buffer, autograd accumulates straight into it, the call moves it without a single copy
+        ptrs = [p.grad.data_ptr() for p in g.values()]
+        for p in g.values():
+            p.grad.zero_()
+        (g["centers"].sum() * float(rank + 1)).backward()
+        assert [p.grad.data_ptr() for p in g.values()] == ptrs
+        allreduce_gaussian_grads(list(g.values()))
+        assert [p.grad.data_ptr() for p in g.values()] == ptrs
+        assert g["centers"].grad[0, 0].item() == float(sum(range(1, world + 1))) and float(g["shs"].grad.abs().sum()) == 0.0
+        q.put((rank, allv.tolist(), first[0], first[1]))
     finally:
         dist.destroy_process_group()
 
