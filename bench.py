@@ -82,7 +82,12 @@ def algorithmic_bytes(n, d, p, m, tiles, v=1):
         sort_scatter=d * 2 * K,         # per pass
         tile_ranges=d * 8,
         tile_order=tiles * 12,
-        tile_sort=d * (12 + 12),        # (split over the size-class launches by the entries each handles: class_bytes())
+        # direct tile binning (round 3; replaces duplicate + 2 x (hist, row scan, scatter) + ranges): a counting sort on the
+        # tile id straight from the rects.  W = workgroups of the count / scatter kernels = columns of the count matrix
+        tile_count=n * 24 + tiles * min(1024, -(-n // 512)) * 4,
+        tile_scan=2 * tiles * min(1024, -(-n // 512)) * 4 + tiles * 12,
+        tile_scatter=n * 28 + d * 8 + tiles * min(1024, -(-n // 512)) * 4,
+        tile_sort=d * (8 + 4),          # (split over the size-class launches by the entries each handles)
         tile_sort_long=0,
         render_fwd=d * 44 + p * 28,
         render_bwd=d * (44 + G) + p * 28,
@@ -573,8 +578,8 @@ def main():
     alg = (surfel_algorithmic_bytes if surfel else algorithmic_bytes)(n, d_mean, h * w, m, tiles, min(vpg, 8))
     if sum(class_entries):   # the tile sort's D * 24 bytes split over its launches by the entries each size class handles:
         # `tile_sort` = the <= 2048-entry class (one launch per view), `tile_sort_long` = the medium + long class launches
-        alg["tile_sort"] = class_entries[0] / len(d_views) * 24
-        alg["tile_sort_long"] = (class_entries[1] + class_entries[2]) / len(d_views) * 24 / 2
+        alg["tile_sort"] = class_entries[0] / len(d_views) * 12
+        alg["tile_sort_long"] = (class_entries[1] + class_entries[2]) / len(d_views) * 12 / 2
 
     # ---- roofline: per-kernel HIP-event timing, second pass of the same K steps -----------
     roofline = None

@@ -50,7 +50,8 @@ class GdrBinning(C.Structure):
                 ("seg_extra", C.c_void_p), ("seg_count", C.c_void_p), ("seg_state", C.c_void_p),
                 ("seg_len", C.c_int32), ("seg_cap", C.c_int32), ("deep_max_busy", C.c_int32), ("reserved0", C.c_int32),
                 ("d_dev", C.c_void_p), ("stats_out", C.c_void_p), ("hint_long", C.c_int32), ("hint_medium", C.c_int32),
-                ("hint_no_deep", C.c_int32), ("grad_rec_cleared", C.c_int32)]
+                ("hint_no_deep", C.c_int32), ("grad_rec_cleared", C.c_int32), ("tile_hist", C.c_void_p),
+                ("hist_width", C.c_int32), ("reserved1", C.c_int32)]
 
 
 class GdrImage(C.Structure):
@@ -107,8 +108,8 @@ _PROTOS = {
     "gdr_image_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
     "gdr_geom_carve": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(GdrGeom)]),
     "gdr_binning_carve": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(GdrBinning)]),
-    "gdr_binning_bytes_seg": (C.c_size_t, [C.c_uint64, C.c_int32]),
-    "gdr_binning_carve_seg": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int32, C.POINTER(GdrBinning)]),
+    "gdr_binning_bytes_for": (C.c_size_t, [C.c_uint64, C.c_int32, C.c_int32, C.c_int32]),
+    "gdr_binning_carve_for": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int32, C.c_int32, C.c_int32, C.POINTER(GdrBinning)]),
     "gdr_build_tag": (C.c_char_p, []),
     "gdr_words_differ": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
     "gdr_image_carve": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(GdrImage)]),
@@ -119,9 +120,6 @@ _PROTOS = {
                                      C.POINTER(GdrOutputs), C.c_void_p]),
     "gdr_binning_forward": (C.c_int, [C.POINTER(GdrSettings), C.c_int32, C.POINTER(GdrGeom), C.POINTER(GdrBinning),
                                       C.POINTER(GdrImage), C.c_uint64, C.c_void_p, C.c_void_p]),
-    "gdr_binning_forward_views": (C.c_int, [C.c_int32, C.POINTER(GdrSettings), C.c_int32, C.POINTER(GdrGeom),
-                                            C.POINTER(GdrBinning), C.POINTER(GdrImage), C.POINTER(C.c_uint64),
-                                            C.POINTER(C.c_void_p), C.c_void_p]),
     "gdr_composite_forward": (C.c_int, [C.POINTER(GdrSettings), C.POINTER(GdrGeom), C.POINTER(GdrBinning),
                                         C.POINTER(GdrImage), C.POINTER(GdrOutputs), C.c_void_p]),
     "gdr_composite_forward_loss": (C.c_int, [C.POINTER(GdrSettings), C.POINTER(GdrGeom), C.POINTER(GdrBinning),

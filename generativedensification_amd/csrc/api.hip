@@ -83,7 +83,8 @@ static size_t carve_geom(void* base, int64_t N, gdr_geom* g) {
     return c.off;
 }
 
-static size_t carve_binning(void* base, uint64_t D, gdr_binning* b, int32_t seg_len = GDR_DEFAULT_SEG_LEN) {
+static size_t carve_binning(void* base, uint64_t D, gdr_binning* b, int32_t seg_len = GDR_DEFAULT_SEG_LEN, int32_t N = 0,
+                            int32_t tiles = 0) {
     Carver c(base);
     gdr_binning t;
     const size_t d = (size_t)(D > 0 ? D : 1);
@@ -105,6 +106,14 @@ static size_t carve_binning(void* base, uint64_t D, gdr_binning* b, int32_t seg_
     t.seg_extra = c.take<uint32_t>(2 * (size_t)(t.seg_cap ? t.seg_cap : 1));
     t.seg_count = c.take<uint32_t>(4);
     t.seg_state = c.take<float>(t.seg_cap ? (size_t)2 * t.seg_cap * GDR_SEG_STATE_FLOATS : 1);
+    t.tile_hist = nullptr;
+    t.hist_width = 0;
+    t.reserved1 = 0;
+    if (N > 0 && tiles > 0 && tiles <= GDR_BIN_MAX_TILES) {   // direct tile binning: (width rows x tiles) counts + a totals row
+        int w = (N + 1023) / 1024;
+        t.hist_width = w > GDR_BIN_MAX_WIDTH ? GDR_BIN_MAX_WIDTH : w;
+        t.tile_hist = c.take<uint32_t>((size_t)(t.hist_width + 1) * ((tiles + 63) / 64 * 64));
+    }
     if (b) *b = t;
     return c.off;
 }
@@ -193,10 +202,15 @@ int gdr_binning_carve(void* base, uint64_t D, gdr_binning* out) {
     carve_binning(base, D, out);
     return GDR_OK;
 }
-size_t gdr_binning_bytes_seg(uint64_t D, int32_t seg_len) { return carve_binning(nullptr, D, nullptr, seg_len); }
-int gdr_binning_carve_seg(void* base, uint64_t D, int32_t seg_len, gdr_binning* out) {
-    if (!base || !out || ((uintptr_t)base & 255u) || seg_len < 0) { set_error("binning base NULL/unaligned or seg_len < 0", hipSuccess); return GDR_ERR_INVALID_ARG; }
-    carve_binning(base, D, out, seg_len);
+size_t gdr_binning_bytes_for(uint64_t D, int32_t seg_len, int32_t N, int32_t tiles) {
+    return carve_binning(nullptr, D, nullptr, seg_len, N, tiles);
+}
+int gdr_binning_carve_for(void* base, uint64_t D, int32_t seg_len, int32_t N, int32_t tiles, gdr_binning* out) {
+    if (!base || !out || ((uintptr_t)base & 255u) || seg_len < 0 || N < 0 || tiles < 0) {
+        set_error("binning base NULL/unaligned or negative seg_len / N / tiles", hipSuccess);
+        return GDR_ERR_INVALID_ARG;
+    }
+    carve_binning(base, D, out, seg_len, N, tiles);
     return GDR_OK;
 }
 int gdr_image_carve(void* base, int32_t H, int32_t W, gdr_image* out) {
@@ -227,72 +241,66 @@ int gdr_preprocess_forward(const gdr_settings* s, const gdr_inputs* in, const gd
     return GDR_OK;
 }
 
-// K3..K5 + tile sort: everything between K1 and K6, for V views at once (every launch covers all views: BinViews);
-// shared by the 3DGS and the surfel path (only the geometry's depths / rects / tiles_touched / block offsets and the
-// radii are read).  All views share one image size.
-static int binning_stage_views(int V, const gdr_settings* s, int32_t N, const gdr_geom* geoms, gdr_binning* bins,
-                               const gdr_image* imgs, const uint64_t* D, const int32_t* const* radii, hipStream_t st) {
-    int rc;
-    const int W = s[0].image_width, H = s[0].image_height;
-    const int tiles = tile_grid_x(W) * tile_grid_y(H);
-    hipError_t e;
-    const bool global_sort = bins[0].global_sort != 0;
-    if (global_sort) {  // stable global sort: duplicates must be emitted in Gaussian order
-        for (int v = 0; v < V; ++v) {
-            e = launch_scan_block_sums(&geoms[v], N, st);
-            if (e != hipSuccess) return hip_fail("scan_block_sums", e);
-        }
-    }
-    BinViews vs;
-    fill_bin_views(&vs, V, geoms, bins, imgs, D, radii);
-    e = launch_duplicate_views(vs, V, N, W, H, st);
-    if (e != hipSuccess) return hip_fail("duplicate", e);
-    if ((rc = debug_sync(&s[0], "duplicate", st))) return rc;
-    int sorted = 0;
-    // global_sort: one stable LSD radix sort over all key bits; default: stable partition by tile (the tile bits only)
-    e = launch_sort_views(vs, V, global_sort ? 0 : 32, key_bits(tiles), &sorted, st);
-    if (e != hipSuccess) return hip_fail("sort", e);
-    if ((rc = debug_sync(&s[0], "sort", st))) return rc;
-    e = launch_ranges_views(vs, V, sorted, tiles, st);
-    if (e != hipSuccess) return hip_fail("ranges", e);
-    if ((rc = debug_sync(&s[0], "ranges", st))) return rc;
-    e = launch_tile_order_views(vs, V, tiles, st);  // longest list first: launch order of tile_sort, K6, K7
-    if (e != hipSuccess) return hip_fail("tile_order", e);
-    if ((rc = debug_sync(&s[0], "tile_order", st))) return rc;
-    if (!global_sort) {  // per-tile LDS depth sort of the partitioned lists
-        e = launch_tile_sort_views(vs, V, sorted, tiles, st);
-        if (e != hipSuccess) return hip_fail("tile_sort", e);
-        if ((rc = debug_sync(&s[0], "tile_sort", st))) return rc;
-        sorted ^= 1;
-    }
-    for (int v = 0; v < V; ++v) bins[v].sorted = sorted;
-    return GDR_OK;
-}
-
+// Everything between K1 and K6 for one view; shared by the 3DGS and the surfel path (only the geometry's depths / rects /
+// tiles_touched and the radii are read).  Default: direct tile binning (count / scan / scatter) -> tile order -> per-tile
+// LDS depth sort.  Without a count matrix (gdr_binning_carve, or > 16384 tiles): duplicate + stable radix partition on
+// the tile bits -> ranges -> the same tile order and sort.  global_sort: one stable LSD radix sort over all key bits.
 static int binning_stage(const gdr_settings* s, int32_t N, const gdr_geom* geom, gdr_binning* bin, const gdr_image* img,
                          uint64_t D, const int32_t* radii, hipStream_t st) {
-    return binning_stage_views(1, s, N, geom, bin, img, &D, &radii, st);
+    int rc;
+    const int W = s->image_width, H = s->image_height;
+    const int tiles = tile_grid_x(W) * tile_grid_y(H);
+    hipError_t e;
+    const bool global_sort = bin->global_sort != 0;
+    const bool direct = !global_sort && bin->tile_hist && bin->hist_width > 0 && tiles <= GDR_BIN_MAX_TILES;
+    if (global_sort) {  // stable global sort: duplicates must be emitted in Gaussian order
+        e = launch_scan_block_sums(geom, N, st);
+        if (e != hipSuccess) return hip_fail("scan_block_sums", e);
+    }
+    BinViews vs;
+    fill_bin_views(&vs, 1, geom, bin, img, &D, &radii);
+    int sorted = 0;
+    if (direct && (N == 0 || D == 0)) {   // nothing to bin: only the ranges are cleared (ranges_clear inside)
+        e = launch_duplicate_views(vs, 1, 0, W, H, st);
+        if (e != hipSuccess) return hip_fail("ranges_clear", e);
+    } else if (direct) {
+        e = launch_tile_count_scan(vs.v[0], N, W, H, st);
+        if (e != hipSuccess) return hip_fail("tile_count_scan", e);
+        if ((rc = debug_sync(s, "tile_count_scan", st))) return rc;
+        vs.v[0].from_totals = 1;
+    } else {
+        e = launch_duplicate_views(vs, 1, N, W, H, st);
+        if (e != hipSuccess) return hip_fail("duplicate", e);
+        if ((rc = debug_sync(s, "duplicate", st))) return rc;
+        e = launch_sort_views(vs, 1, global_sort ? 0 : 32, key_bits(tiles), &sorted, st);
+        if (e != hipSuccess) return hip_fail("sort", e);
+        if ((rc = debug_sync(s, "sort", st))) return rc;
+        e = launch_ranges_views(vs, 1, sorted, tiles, st);
+        if (e != hipSuccess) return hip_fail("ranges", e);
+        if ((rc = debug_sync(s, "ranges", st))) return rc;
+    }
+    e = launch_tile_order_views(vs, 1, tiles, st);  // (totals -> ranges first;) longest list first: launch order of tile_sort, K6, K7
+    if (e != hipSuccess) return hip_fail("tile_order", e);
+    if ((rc = debug_sync(s, "tile_order", st))) return rc;
+    if (vs.v[0].from_totals) {
+        e = launch_tile_scatter(vs.v[0], N, W, H, st);
+        if (e != hipSuccess) return hip_fail("tile_scatter", e);
+        if ((rc = debug_sync(s, "tile_scatter", st))) return rc;
+    }
+    if (!global_sort) {  // per-tile LDS depth sort of the partitioned lists
+        e = launch_tile_sort_views(vs, 1, sorted, tiles, direct, st);
+        if (e != hipSuccess) return hip_fail("tile_sort", e);
+        if ((rc = debug_sync(s, "tile_sort", st))) return rc;
+        sorted ^= 1;
+    }
+    bin->sorted = sorted;
+    return GDR_OK;
 }
 
 int gdr_binning_forward(const gdr_settings* s, int32_t N, const gdr_geom* geom, gdr_binning* bin, const gdr_image* img,
                         uint64_t D, const int32_t* radii, void* stream) {
     if (!s || !geom || !bin || !img || N < 0 || (N > 0 && !radii)) { set_error("binning_forward: bad argument", hipSuccess); return GDR_ERR_INVALID_ARG; }
     return binning_stage(s, N, geom, bin, img, D, radii, (hipStream_t)stream);
-}
-
-int gdr_binning_forward_views(int32_t V, const gdr_settings* s, int32_t N, const gdr_geom* geoms, gdr_binning* bins,
-                              const gdr_image* imgs, const uint64_t* D, const int32_t* const* radii, void* stream) {
-    if (V < 1 || V > GDR_MAX_VIEWS) { set_error("binning_forward_views: V out of range", hipSuccess); return GDR_ERR_UNSUPPORTED; }
-    if (!s || !geoms || !bins || !imgs || !D || !radii || N < 0) { set_error("binning_forward_views: bad argument", hipSuccess); return GDR_ERR_INVALID_ARG; }
-    for (int v = 0; v < V; ++v) {
-        if (s[v].image_width != s[0].image_width || s[v].image_height != s[0].image_height ||
-            bins[v].global_sort != bins[0].global_sort) {
-            set_error("binning_forward_views: image size / sort mode must match", hipSuccess);
-            return GDR_ERR_INVALID_ARG;
-        }
-        if (N > 0 && !radii[v]) { set_error("binning_forward_views: radii NULL", hipSuccess); return GDR_ERR_INVALID_ARG; }
-    }
-    return binning_stage_views(V, s, N, geoms, bins, imgs, D, radii, (hipStream_t)stream);
 }
 
 int gdr_composite_forward(const gdr_settings* s, const gdr_geom* geom, const gdr_binning* bin, const gdr_image* img,
@@ -580,7 +588,7 @@ const char* gdr_kernel_name(int32_t id) {
     static const char* names[GDR_K_COUNT] = {"preprocess_fwd", "scan_block_sums", "duplicate_with_keys",
         "sort_hist", "sort_rowscan", "sort_scatter", "tile_ranges", "render_fwd", "render_bwd",
         "preprocess_bwd", "mark_visible", "tile_order", "tile_sort", "tile_sort_long", "view_loss", "surfel_maps", "knn",
-        "topk_select", "render_fwd_deep"};
+        "topk_select", "render_fwd_deep", "tile_count", "tile_scan", "tile_scatter"};
     return (id >= 0 && id < GDR_K_COUNT) ? names[id] : "";
 }
 int gdr_kernel_count(void) { return GDR_K_COUNT; }

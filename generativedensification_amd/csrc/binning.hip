@@ -324,6 +324,102 @@ __global__ __launch_bounds__(GDR_BLOCK) void ranges_kernel(const BinViews vs, in
 
 
 // =================================================================================
+// Direct tile binning (round 3, the default for images of <= GDR_BIN_MAX_TILES tiles).  The list only has to end up
+// PARTITIONED by tile — the per-tile depth sort that follows orders every list by (depth, id) whatever order it
+// arrives in — so the partition is a counting sort on the tile id done straight from the Gaussians' tile rects, with
+// no (key, value) stream written and re-read:
+//   tile_count    every workgroup takes a fixed chunk of Gaussians, counts the tiles their rects cover in an LDS
+//                 histogram (ds_add_u32: 4 cycles, integer LDS atomics are the fast kind) and writes it as one
+//                 column of the (tiles x workgroups) count matrix;
+//   tile_scan     exclusive scan over the workgroups in place + the tiles' totals (tile_order_kernel, the one-workgroup
+//                 kernel that follows anyway, scans the totals into the ranges: empty tiles read (0,0), as the reference's);
+//   tile_scatter  the same chunks again: LDS cursor per tile = range start + this workgroup's prefix; every rect
+//                 cell draws a position with ds_add_rtn and writes ONE 8-byte word (id << 32 | depth bits).
+// 3 launches and ~52 bytes per Gaussian + 8 per entry instead of duplicate + 2 x (hist, row scan, scatter) + ranges =
+// 8 launches and 20 + 12 + 2 x 32 + 8 bytes per entry.  Capacity-guarded like the old path (device-sized calls).
+// =================================================================================
+#define GDR_BIN_THREADS 1024
+
+__device__ __forceinline__ bool bin_gaussian(const BinView& bv, int i, int4& r) {
+    if (bv.tiles_touched[i] == 0u || bv.radii[i] <= 0) return false;
+    r = bv.rect[i];
+    return true;
+}
+
+// count matrix layout: row w = workgroup w of tile_count / tile_scatter, `tstride` words (tiles rounded up to 64): every
+// access below is coalesced — the workgroups write / read their own row, the scan walks the rows with one thread per tile
+__global__ __launch_bounds__(GDR_BIN_THREADS) void tile_count_kernel(const BinView bv, int N, int gx, int tiles, int chunk,
+                                                                      int tstride) {
+    extern __shared__ uint32_t cnt[];
+    for (int t = threadIdx.x; t < tiles; t += GDR_BIN_THREADS) cnt[t] = 0u;
+    __syncthreads();
+    const int lo = blockIdx.x * chunk, hi = min(N, lo + chunk);
+    for (int i = lo + (int)threadIdx.x; i < hi; i += GDR_BIN_THREADS) {
+        int4 r;
+        if (!bin_gaussian(bv, i, r)) continue;
+        for (int y = r.y; y < r.w; ++y)
+            for (int x = r.x; x < r.z; ++x) atomicAdd(&cnt[y * gx + x], 1u);
+    }
+    __syncthreads();
+    uint32_t* __restrict__ row = bv.tile_hist + (size_t)blockIdx.x * tstride;
+    for (int t = threadIdx.x; t < tiles; t += GDR_BIN_THREADS) row[t] = cnt[t];
+}
+
+// Exclusive scan down the columns (over the workgroups) in place + column totals.  A workgroup takes 64 tiles x 16
+// segments of the workgroup axis: thread (segment, tile) sums its segment, the segment sums are exchanged in LDS, a second
+// sweep writes the prefixes.  totals: (tiles) words behind the matrix; tile_order_kernel turns them into the ranges.
+#define GDR_BIN_SEGS 16
+__global__ __launch_bounds__(64 * GDR_BIN_SEGS) void tile_scan_kernel(const BinView bv, int tiles, int nwg, int tstride) {
+    __shared__ uint32_t segsum[GDR_BIN_SEGS][64];
+    const int tl = threadIdx.x & 63, seg = threadIdx.x >> 6;
+    const int t = blockIdx.x * 64 + tl;
+    const int per = (nwg + GDR_BIN_SEGS - 1) / GDR_BIN_SEGS;
+    const int w0 = min(nwg, seg * per), w1 = min(nwg, w0 + per);
+    uint32_t* __restrict__ col = bv.tile_hist + t;
+    uint32_t s = 0u;
+    if (t < tiles)
+        for (int w = w0; w < w1; ++w) s += col[(size_t)w * tstride];
+    segsum[seg][tl] = s;
+    __syncthreads();
+    uint32_t run = 0u, total = 0u;
+#pragma unroll
+    for (int k = 0; k < GDR_BIN_SEGS; ++k) {
+        const uint32_t v = segsum[k][tl];
+        run += k < seg ? v : 0u;
+        total += v;
+    }
+    if (t >= tiles) return;
+    for (int w = w0; w < w1; ++w) {
+        const uint32_t v = col[(size_t)w * tstride];
+        col[(size_t)w * tstride] = run;
+        run += v;
+    }
+    if (seg == 0) bv.tile_hist[(size_t)bv.hist_width * tstride + t] = total;
+}
+
+__global__ __launch_bounds__(GDR_BIN_THREADS) void tile_scatter_kernel(const BinView bv, int N, int gx, int tiles, int chunk,
+                                                                        int tstride) {
+    extern __shared__ uint32_t cur[];
+    const uint2* __restrict__ ranges = bv.ranges;
+    const uint32_t* __restrict__ row = bv.tile_hist + (size_t)blockIdx.x * tstride;
+    for (int t = threadIdx.x; t < tiles; t += GDR_BIN_THREADS) cur[t] = ranges[t].x + row[t];
+    __syncthreads();
+    uint64_t* __restrict__ out = bv.keys[0];
+    const uint64_t cap = bv.D;
+    const int lo = blockIdx.x * chunk, hi = min(N, lo + chunk);
+    for (int i = lo + (int)threadIdx.x; i < hi; i += GDR_BIN_THREADS) {
+        int4 r;
+        if (!bin_gaussian(bv, i, r)) continue;
+        const uint64_t word = ((uint64_t)(uint32_t)i << 32) | (uint64_t)__float_as_uint(bv.depths[i]);
+        for (int y = r.y; y < r.w; ++y)
+            for (int x = r.x; x < r.z; ++x) {
+                const uint32_t pos = atomicAdd(&cur[y * gx + x], 1u);
+                if (pos < cap) out[pos] = word;   // capacity guard: never write past the caller's buffers
+            }
+    }
+}
+
+// =================================================================================
 // Tile-binned sort (default path).  The sort key is (tile, depth).  Instead of 6 global radix
 // passes over the 12-byte pairs, the pairs are first partitioned by TILE with the stable
 // passes above run on the tile bits only (2 passes at 800x800), K5 reads the tile segments off
@@ -526,13 +622,15 @@ __device__ __forceinline__ void tile_sort_ties(const uint32_t* kA, uint32_t* vA,
 // ordered buckets, then runs of whole buckets that fit are sorted in LDS like short lists (a single bucket
 // larger than CAP — thousands of near-identical depths in one tile — is finished by LSD passes on the global
 // buffers).  3 reads + 2 writes of the list instead of one global round trip per 8 key bits.
-template <int CAP, int LMIN, int NW, bool TOP>
+// PACKED: the partitioned list is one word per entry, (id << 32) | depth bits (direct tile binning); otherwise keys
+// (tile << 32 | depth bits) + values in two arrays (radix partition).  Output: the sorted ids only — the sorted keys are
+// a function of (ranges, ids, depths) and nothing downstream reads them (the parity tests rebuild them from those).
+template <int CAP, int LMIN, int NW, bool TOP, bool PACKED>
 __global__ __launch_bounds__(NW * GDR_WAVE) void tile_sort_kernel(const BinViews vs, int in, int ntiles) {
     const BinView& bv = vs.v[blockIdx.y];
     const uint2* __restrict__ ranges = bv.ranges;
     const uint64_t* __restrict__ keys_part = bv.keys[in];
     uint32_t* __restrict__ vals_part = bv.vals[in];
-    uint64_t* __restrict__ keys_out = bv.keys[in ^ 1];
     uint32_t* __restrict__ vals_out = bv.vals[in ^ 1];
     uint32_t* __restrict__ scratch32 = bv.scratch32;
     const uint64_t D = bv.D;   // offset of the second scratch half: the carved size, not the live count
@@ -560,8 +658,7 @@ __global__ __launch_bounds__(NW * GDR_WAVE) void tile_sort_kernel(const BinViews
         for (int k = 0; k < NW; ++k) { kmin = min(kmin, mm[k]); kmax = max(kmax, mm[NW + k]); }
     };
     // Lc <= CAP pairs (key_at(i), vsrc[i]) -> sorted at keys_out / vals_out [o, o + Lc)
-    auto sort_in_lds = [&](auto key_at, const uint32_t* vsrc, uint32_t tile, uint32_t o, uint32_t Lc)
-                           __attribute__((always_inline)) {
+    auto sort_in_lds = [&](auto key_at, auto val_at, uint32_t o, uint32_t Lc) __attribute__((always_inline)) {
         __syncthreads();  // LDS reuse
         constexpr int EPT = CAP / (int)NT;
         uint32_t* const kA = lds_elems;
@@ -570,7 +667,7 @@ __global__ __launch_bounds__(NW * GDR_WAVE) void tile_sort_kernel(const BinViews
         for (uint32_t i = threadIdx.x; i < Lc; i += NT) {
             const uint32_t k = key_at(i);
             kA[i] = k;
-            vA[i] = vsrc[i];
+            vA[i] = val_at(i);
             kmin = min(kmin, k);
             kmax = max(kmax, k);
         }
@@ -580,10 +677,7 @@ __global__ __launch_bounds__(NW * GDR_WAVE) void tile_sort_kernel(const BinViews
         for (int shift = 0; shift < nbits; shift += GDR_RADIX_BITS)
             tile_sort_pass_lds<NW, EPT>(kA, vA, Lc, kmin, shift, cnt, misc);
         tile_sort_ties<NW, EPT>(kA, vA, nullptr, Lc, cnt, misc, tie_runs);
-        for (uint32_t i = threadIdx.x; i < Lc; i += NT) {
-            vals_out[o + i] = vA[i];
-            keys_out[o + i] = ((uint64_t)tile << 32) | (uint64_t)kA[i];
-        }
+        for (uint32_t i = threadIdx.x; i < Lc; i += NT) vals_out[o + i] = vA[i];
     };
 
     // LMIN > 0 (long-list class): a small grid walks the tiles longest-first (tile_order is sorted by
@@ -596,7 +690,11 @@ __global__ __launch_bounds__(NW * GDR_WAVE) void tile_sort_kernel(const BinViews
         if (L <= (uint32_t)LMIN || (!TOP && L > (uint32_t)CAP)) continue;  // other size class
         if (L <= (uint32_t)CAP) {
             const uint64_t* kp = keys_part + rg.x;
-            sort_in_lds([kp](uint32_t i) { return (uint32_t)kp[i]; }, vals_part + rg.x, tile, rg.x, L);
+            const uint32_t* vp = vals_part + rg.x;
+            if constexpr (PACKED)
+                sort_in_lds([kp](uint32_t i) { return (uint32_t)kp[i]; }, [kp](uint32_t i) { return (uint32_t)(kp[i] >> 32); }, rg.x, L);
+            else
+                sort_in_lds([kp](uint32_t i) { return (uint32_t)kp[i]; }, [vp](uint32_t i) { return vp[i]; }, rg.x, L);
             continue;
         }
         if constexpr (TOP) {
@@ -608,8 +706,10 @@ __global__ __launch_bounds__(NW * GDR_WAVE) void tile_sort_kernel(const BinViews
             __syncthreads();  // mm / bstart reuse
             uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
             for (uint32_t i = threadIdx.x; i < L; i += NT) {
-                const uint32_t k = (uint32_t)keys_part[rg.x + i];
+                const uint64_t w = keys_part[rg.x + i];
+                const uint32_t k = (uint32_t)w;
                 kA[i] = k;
+                if constexpr (PACKED) vA[i] = (uint32_t)(w >> 32);   // (the values buffer [in] is free in the packed layout)
                 kmin = min(kmin, k);
                 kmax = max(kmax, k);
             }
@@ -626,11 +726,8 @@ __global__ __launch_bounds__(NW * GDR_WAVE) void tile_sort_kernel(const BinViews
                     t = g.vA; g.vA = g.vB; g.vB = t;
                 }
                 tile_sort_ties<NW>(g.kA, g.vA, g.vB, Lc, cnt, misc, tie_runs);
-                const bool in_place = g.vA == vals_out + o;
-                for (uint32_t i = threadIdx.x; i < Lc; i += NT) {
-                    if (!in_place) vals_out[o + i] = g.vA[i];
-                    keys_out[o + i] = ((uint64_t)tile << 32) | (uint64_t)g.kA[i];
-                }
+                if (g.vA != vals_out + o)
+                    for (uint32_t i = threadIdx.x; i < Lc; i += NT) vals_out[o + i] = g.vA[i];
             };
             const int sh1 = nbits > GDR_RADIX_BITS ? nbits - GDR_RADIX_BITS : 0;
             {
@@ -648,7 +745,8 @@ __global__ __launch_bounds__(NW * GDR_WAVE) void tile_sort_kernel(const BinViews
                 if (Lc == 0) continue;
                 if (Lc <= (uint32_t)CAP) {
                     const uint32_t* kc = kB + s0;
-                    sort_in_lds([kc](uint32_t i) { return kc[i]; }, vB + s0, tile, rg.x + s0, Lc);
+                    const uint32_t* vc = vB + s0;
+                    sort_in_lds([kc](uint32_t i) { return kc[i]; }, [vc](uint32_t i) { return vc[i]; }, rg.x + s0, Lc);
                     continue;
                 }
                 TileSortBufs g;  // one bucket longer than CAP
@@ -668,7 +766,8 @@ __global__ __launch_bounds__(NW * GDR_WAVE) void tile_sort_kernel(const BinViews
                     if (Lcc == 0) continue;
                     if (Lcc <= (uint32_t)CAP) {
                         const uint32_t* kc = kA + s0 + s1;
-                        sort_in_lds([kc](uint32_t i) { return kc[i]; }, vA + s0 + s1, tile, rg.x + s0 + s1, Lcc);
+                        const uint32_t* vc = vA + s0 + s1;
+                        sort_in_lds([kc](uint32_t i) { return kc[i]; }, [vc](uint32_t i) { return vc[i]; }, rg.x + s0 + s1, Lcc);
                         continue;
                     }
                     TileSortBufs h;
@@ -706,7 +805,8 @@ void fill_bin_views(BinViews* vs, int V, const gdr_geom* geoms, const gdr_binnin
         b.depths = g.depths; b.rect = (const int4*)g.rect; b.tiles_touched = g.tiles_touched;
         b.block_offs = bn.global_sort ? g.block_sums : g.block_offs;
         b.keys[0] = bn.keys[0]; b.keys[1] = bn.keys[1]; b.vals[0] = bn.values[0]; b.vals[1] = bn.values[1];
-        b.hist = bn.hist; b.scratch32 = bn.scratch32;
+        b.hist = bn.hist; b.scratch32 = bn.scratch32; b.tile_hist = bn.tile_hist; b.hist_width = bn.hist_width;
+        b.from_totals = 0;
         b.ranges = (uint2*)imgs[v].ranges; b.tile_order = imgs[v].tile_order; b.seg_base = imgs[v].seg_base;
         b.seg_extra = (uint2*)bn.seg_extra; b.seg_count = bn.seg_count;
         b.D = D[v]; b.nblk = (uint32_t)((D[v] + GDR_SORT_TILE - 1) / GDR_SORT_TILE);
@@ -772,8 +872,39 @@ static int merged_hint(const BinViews& vs, int V, bool long_class) {
     return h;
 }
 
-// per-tile depth sort; input = buffers [in] (tile-partitioned), output = the other pair
-hipError_t launch_tile_sort_views(const BinViews& vs, int V, int in, int tiles, hipStream_t st) {
+// direct tile binning of ONE view: count -> scan -> [tile_order_kernel: totals -> ranges, issued by the caller] -> scatter
+static void bin_geometry(const BinView& bv, int N, int tiles, int* nwg, int* chunk, int* tstride) {
+    int w = div_up(N, GDR_BIN_THREADS);
+    if (w > bv.hist_width) w = bv.hist_width;
+    if (w < 1) w = 1;
+    *chunk = div_up(div_up(N, w), GDR_BIN_THREADS) * GDR_BIN_THREADS;
+    *nwg = div_up(N, *chunk);
+    *tstride = div_up(tiles, 64) * 64;
+}
+hipError_t launch_tile_count_scan(const BinView& bv, int N, int W, int H, hipStream_t st) {
+    const int gx = tile_grid_x(W), tiles = gx * tile_grid_y(H);
+    int nwg, chunk, tstride;
+    bin_geometry(bv, N, tiles, &nwg, &chunk, &tstride);
+    const size_t lds = (size_t)tiles * sizeof(uint32_t);
+    prof_begin(GDR_K_TILE_COUNT, st);
+    hipLaunchKernelGGL(tile_count_kernel, dim3(nwg), dim3(GDR_BIN_THREADS), lds, st, bv, N, gx, tiles, chunk, tstride);
+    prof_end(GDR_K_TILE_COUNT, st);
+    GDR_LAUNCH(GDR_K_TILE_SCAN, tile_scan_kernel, dim3(div_up(tiles, 64)), dim3(64 * GDR_BIN_SEGS), st, bv, tiles, nwg, tstride);
+    return hipGetLastError();
+}
+hipError_t launch_tile_scatter(const BinView& bv, int N, int W, int H, hipStream_t st) {
+    const int gx = tile_grid_x(W), tiles = gx * tile_grid_y(H);
+    int nwg, chunk, tstride;
+    bin_geometry(bv, N, tiles, &nwg, &chunk, &tstride);
+    prof_begin(GDR_K_TILE_SCATTER, st);
+    hipLaunchKernelGGL(tile_scatter_kernel, dim3(nwg), dim3(GDR_BIN_THREADS), (size_t)tiles * sizeof(uint32_t), st, bv, N, gx,
+                       tiles, chunk, tstride);
+    prof_end(GDR_K_TILE_SCATTER, st);
+    return hipGetLastError();
+}
+
+// per-tile depth sort; input = buffers [in] (tile-partitioned; packed: one word per entry), output = values [in ^ 1]
+hipError_t launch_tile_sort_views(const BinViews& vs, int V, int in, int tiles, bool packed, hipStream_t st) {
     if (max_D(vs, V) == 0) return hipSuccess;
     // long lists: 16 waves per workgroup so that the few heavy tiles finish quickly; a two-class scheme (everything
     // beyond the short class bucketed and sorted in short-class chunks) measured slower at 2 M - 8 M Gaussians and equal
@@ -786,12 +917,21 @@ hipError_t launch_tile_sort_views(const BinViews& vs, int V, int in, int tiles, 
     const int h_long = merged_hint(vs, V, true), h_medium = merged_hint(vs, V, false);
     if (h_long > 0 && h_long < g_long) g_long = h_long;
     if (h_medium > 0 && h_medium < g_medium) g_medium = h_medium;
-    GDR_LAUNCH(GDR_K_TILE_SORT_LONG, (tile_sort_kernel<GDR_TSORT_LARGE, GDR_TSORT_MEDIUM, 16, true>),
+    if (packed) {
+        GDR_LAUNCH(GDR_K_TILE_SORT_LONG, (tile_sort_kernel<GDR_TSORT_LARGE, GDR_TSORT_MEDIUM, 16, true, true>),
+                   dim3(g_long, V), dim3(16 * GDR_WAVE), st, vs, in, tiles);
+        GDR_LAUNCH(GDR_K_TILE_SORT_LONG, (tile_sort_kernel<GDR_TSORT_MEDIUM, GDR_TSORT_SMALL, 8, false, true>),
+                   dim3(g_medium, V), dim3(8 * GDR_WAVE), st, vs, in, tiles);
+        GDR_LAUNCH(GDR_K_TILE_SORT, (tile_sort_kernel<GDR_TSORT_SMALL, 0, 4, false, true>), dim3(tiles, V), dim3(GDR_BLOCK), st,
+                   vs, in, tiles);
+        return hipGetLastError();
+    }
+    GDR_LAUNCH(GDR_K_TILE_SORT_LONG, (tile_sort_kernel<GDR_TSORT_LARGE, GDR_TSORT_MEDIUM, 16, true, false>),
                dim3(g_long, V), dim3(16 * GDR_WAVE), st, vs, in, tiles);
-    GDR_LAUNCH(GDR_K_TILE_SORT_LONG, (tile_sort_kernel<GDR_TSORT_MEDIUM, GDR_TSORT_SMALL, 8, false>),
+    GDR_LAUNCH(GDR_K_TILE_SORT_LONG, (tile_sort_kernel<GDR_TSORT_MEDIUM, GDR_TSORT_SMALL, 8, false, false>),
                dim3(g_medium, V), dim3(8 * GDR_WAVE), st, vs, in, tiles);
-    GDR_LAUNCH(GDR_K_TILE_SORT, (tile_sort_kernel<GDR_TSORT_SMALL, 0, 4, false>), dim3(tiles, V), dim3(GDR_BLOCK), st, vs, in,
-               tiles);
+    GDR_LAUNCH(GDR_K_TILE_SORT, (tile_sort_kernel<GDR_TSORT_SMALL, 0, 4, false, false>), dim3(tiles, V), dim3(GDR_BLOCK), st, vs,
+               in, tiles);
     return hipGetLastError();
 }
 

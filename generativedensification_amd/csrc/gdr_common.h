@@ -38,6 +38,9 @@ enum {
     GDR_K_KNN,
     GDR_K_SELECT,
     GDR_K_RENDER_FWD_DEEP,
+    GDR_K_TILE_COUNT,
+    GDR_K_TILE_SCAN,
+    GDR_K_TILE_SCATTER,
     GDR_K_COUNT
 };
 
@@ -94,7 +97,11 @@ struct BinView {
     const uint32_t* d_dev;   // gdr_binning.d_dev: the duplicate count stays on the device, D/nblk above are CAPACITIES
     uint32_t* stats_out;     // gdr_binning.stats_out (tile_order_kernel writes it)
     int32_t hint_long, hint_medium;   // host side only: grid sizes of the tile sort's long / medium class
+    uint32_t* tile_hist; int32_t hist_width;   // direct tile binning: (hist_width rows, tiles rounded up to 64) counts + a totals row
+    int32_t from_totals;                       // tile_order_kernel: ranges are formed from the totals row first
 };
+#define GDR_BIN_MAX_TILES 16384     // LDS histogram of the direct tile binning: 64 KB (beyond: radix partition on the tile bits)
+#define GDR_BIN_MAX_WIDTH 256       // workgroups of tile_count / tile_scatter = rows of the count matrix
 // tile sort size classes (list entries): one workgroup per tile up to SMALL, small grids walking the longer tiles
 #define GDR_TSORT_SMALL 2048
 #define GDR_TSORT_MEDIUM 4096
@@ -105,7 +112,9 @@ void fill_bin_views(BinViews* vs, int V, const gdr_geom* geoms, const gdr_binnin
 hipError_t launch_duplicate_views(const BinViews& vs, int V, int N, int W, int H, hipStream_t st);
 hipError_t launch_sort_views(const BinViews& vs, int V, int lo, int hi, int* sorted, hipStream_t st);
 hipError_t launch_ranges_views(const BinViews& vs, int V, int cur, int tiles, hipStream_t st);
-hipError_t launch_tile_sort_views(const BinViews& vs, int V, int in, int tiles, hipStream_t st);
+hipError_t launch_tile_sort_views(const BinViews& vs, int V, int in, int tiles, bool packed, hipStream_t st);
+hipError_t launch_tile_count_scan(const BinView& bv, int N, int W, int H, hipStream_t st);
+hipError_t launch_tile_scatter(const BinView& bv, int N, int W, int H, hipStream_t st);
 hipError_t launch_tile_order_views(const BinViews& vs, int V, int tiles, hipStream_t st);
 // per-pixel compositing state saved at a cut of a long tile list, 256 pixels each: 3DGS T, colour x3, depth, alpha
 // sums (6 used); surfels T, colour x3, normal x3, depth, M1, M2 (10)

@@ -106,7 +106,7 @@ __device__ __forceinline__ void block_masks(const SliceLds& s, int g, float XA, 
 __global__ __launch_bounds__(GDR_ORDER_THREADS) void tile_order_kernel(const BinViews vs, int ntiles) {
     constexpr int TB = GDR_ORDER_THREADS, NWV = TB / GDR_WAVE;
     const BinView& bv = vs.v[blockIdx.y];   // one workgroup per view
-    const uint2* __restrict__ ranges = bv.ranges;
+    const uint2* ranges = bv.ranges;        // (not __restrict__: with from_totals this kernel writes them first)
     uint32_t* __restrict__ order = bv.tile_order;
     const int seg_len = bv.seg_len, seg_cap = bv.seg_cap;
     uint32_t* __restrict__ seg_base = bv.seg_base;
@@ -115,6 +115,35 @@ __global__ __launch_bounds__(GDR_ORDER_THREADS) void tile_order_kernel(const Bin
     const uint32_t deep_max_busy = bv.deep_max_busy;
     __shared__ uint32_t cnt[GDR_ORDER_BUCKETS];
     __shared__ uint32_t wsum[NWV];
+    if (bv.from_totals) {   // direct tile binning: the per-tile totals (behind the count matrix) -> ranges, empty tiles (0,0);
+        // clamped to the capacity of a device-sized call
+        const uint32_t* __restrict__ totals = bv.tile_hist + (size_t)bv.hist_width * (size_t)((ntiles + 63) / 64 * 64);
+        const uint32_t cap = (uint32_t)(bv.D < 0xFFFFFFFFull ? bv.D : 0xFFFFFFFFull);
+        uint2* __restrict__ rw = bv.ranges;
+        uint32_t carry = 0u;
+        for (int t0 = 0; t0 < ntiles; t0 += TB) {
+            const int t = t0 + (int)threadIdx.x;
+            const uint32_t c = t < ntiles ? totals[t] : 0u;
+            uint32_t incl = c;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t u = __shfl_up(incl, off, 64);
+                if ((int)lane_id() >= off) incl += u;
+            }
+            __syncthreads();
+            if (lane_id() == 63) wsum[threadIdx.x >> 6] = incl;
+            __syncthreads();
+            uint32_t base = carry + incl - c, tot = 0u;
+            for (uint32_t w = 0; w < (uint32_t)NWV; ++w) {
+                if (w < (threadIdx.x >> 6)) base += wsum[w];
+                tot += wsum[w];
+            }
+            if (t < ntiles) rw[t] = c ? make_uint2(min(base, cap), min(base + c, cap)) : make_uint2(0u, 0u);
+            carry += tot;
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
     for (int k = threadIdx.x; k < GDR_ORDER_BUCKETS; k += TB) cnt[k] = 0;
     __syncthreads();
     for (int t = threadIdx.x; t < ntiles; t += TB) {

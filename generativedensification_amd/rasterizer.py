@@ -94,12 +94,25 @@ class _State:
         out["seg_count"] = self._view(bb, b.seg_count, torch.int32, 3)  # rows of seg_extra, state slots (filled by K6)
         out["xy"], out["conic_opacity"], out["rgb"] = out["rec"][:, 0:2], out["rec"][:, 4:8], out["rec"][:, 8:12]
         if D > 0:
-            out["keys_sorted"] = self._view(bb, b.keys[s], torch.int64, D)
             out["point_list"] = self._view(bb, b.values[s], torch.int32, D)
+            out["keys_sorted"] = sorted_keys(out["ranges"], out["point_list"], out["depths"])
         else:
             out["keys_sorted"] = torch.empty(0, dtype=torch.int64, device=gb.device)
             out["point_list"] = torch.empty(0, dtype=torch.int32, device=gb.device)
         return out
+
+
+def sorted_keys(ranges, point_list, depths):
+    """The reference's sorted key list (tile << 32 | float bits of the depth) of a binned view, rebuilt
+    from what the binning stage keeps: the per-tile ranges, the sorted ids and the per-Gaussian depths.  The kernels sort
+    (depth bits, id) per tile and never materialise the 64-bit keys; the parity tests compare this list with the oracle's."""
+    D = int(point_list.numel())
+    r = ranges.long()
+    tile_of = torch.repeat_interleave(torch.arange(r.shape[0], device=r.device), (r[:, 1] - r[:, 0]).clamp_min(0))
+    if tile_of.numel() != D:       # (a truncated device-sized call: the caller repeats the view)
+        tile_of = torch.cat([tile_of, tile_of.new_zeros(max(0, D - tile_of.numel()))])[:D]
+    bits = depths.view(torch.int32)[point_list.long()].long() & 0xFFFFFFFF
+    return (tile_of << 32) | bits
 
 
 def _settings_struct(rs: GaussianRasterizationSettings, dev, keep: list) -> L.GdrSettings:
@@ -126,8 +139,10 @@ def _inputs_struct(N, M, means3D, opacities, sh, colors_precomp, scales, rotatio
                        _ptr(rotations), _ptr(cov3Ds), flags, 0)
 
 
-# test / A-B hook: one global radix sort instead of tile partition + per-tile LDS sort
+# test / A-B hooks: one global radix sort instead of tile partition + per-tile LDS sort; the radix partition on the tile
+# bits (the fallback of images with > 16384 tiles) instead of the direct tile binning
 _FORCE_GLOBAL_SORT = False
+_FORCE_RADIX_PARTITION = False
 
 # Streams of a multi-view node.  Forward: every view's chain binning -> K6 on one of FWD_STREAMS streams, the caller's
 # included (_forward_views_impl).  Backward: K7 of the views round-robin on side_count() side streams (_SideViews; 2 at
@@ -587,10 +602,13 @@ def _carve_binning(lib, st, entries, tiles, d_dev=None, stats=None, hints=None):
     """Workspace of one view for `entries` duplicates (exact count, or a capacity with d_dev = the device counter);
     stats / hints: this view's row of the report tensor and the call's launch hints (_launch_stats)."""
     seg_len = _seg_len_for(entries if d_dev is None else int(entries / D_SLACK), tiles, None if hints is None else hints[3])
-    need = lib.gdr_binning_bytes_seg(entries, seg_len)
+    need = lib.gdr_binning_bytes_for(entries, seg_len, st.N, tiles)
     if st.bin_buf is None or st.bin_buf.numel() < need:
         st.bin_buf = torch.empty(need, dtype=torch.uint8, device=st.geom_buf.device)
-    L.check(lib.gdr_binning_carve_seg(st.bin_buf.data_ptr(), entries, seg_len, C.byref(st.bin)), "gdr_binning_carve_seg")
+    L.check(lib.gdr_binning_carve_for(st.bin_buf.data_ptr(), entries, seg_len, st.N, tiles, C.byref(st.bin)),
+            "gdr_binning_carve_for")
+    if _FORCE_RADIX_PARTITION:
+        st.bin.tile_hist, st.bin.hist_width = None, 0
     st.bin.global_sort = int(_FORCE_GLOBAL_SORT)
     st.bin.d_dev = d_dev
     st.D = entries

@@ -50,8 +50,8 @@ class _SurfelState(_State):
             seg_count=self._view(bb, b.seg_count, torch.int32, 2))
         s = b.sorted
         if D > 0:
-            out["keys_sorted"] = self._view(bb, b.keys[s], torch.int64, D)
             out["point_list"] = self._view(bb, b.values[s], torch.int32, D)
+            out["keys_sorted"] = _R.sorted_keys(out["ranges"], out["point_list"], out["depths"])
         else:
             out["keys_sorted"] = torch.empty(0, dtype=torch.int64, device=gb.device)
             out["point_list"] = torch.empty(0, dtype=torch.int32, device=gb.device)

@@ -172,6 +172,11 @@ typedef struct gdr_binning {
     int32_t grad_rec_cleared; /* != 0: the caller has already zero-filled the gradient record it passes to the K7 entry points
                           * for this view (e.g. early, on a side stream, while the forward still runs): they skip their own
                           * clear of N*64 bytes */
+    uint32_t* tile_hist; /* direct tile binning (gdr_binning_carve_for): the (tiles x hist_width) count matrix of the
+                          * counting sort on the tile id + tiles totals + 1 ticket word; NULL (gdr_binning_carve, or an image
+                          * of more than 16384 tiles): the radix partition on the tile bits is used instead (same lists) */
+    int32_t hist_width;  /* columns of tile_hist = workgroups of the count / scatter kernels, <= 1024 */
+    int32_t reserved1;
 } gdr_binning;
 
 /* Image state (upstream "imgBuffer"). */
@@ -229,11 +234,13 @@ size_t gdr_image_bytes(int32_t H, int32_t W);
 /* base must be 256-byte aligned and at least gdr_*_bytes(...) long. */
 int gdr_geom_carve(void* base, int32_t N, gdr_geom* out);
 int gdr_binning_carve(void* base, uint64_t D, gdr_binning* out);
-/* The same with the cut-list tables (seg_extra, seg_state: 2 * (D / seg_len + 1) slots of 10 KB — 80 bytes per
- * duplicate at seg_len = 256, 40 at 512) sized for the segment length the caller is going to use: seg_len = a multiple
- * of 256, or 0 (lists are never cut: no tables).  out->seg_len = seg_len. */
-size_t gdr_binning_bytes_seg(uint64_t D, int32_t seg_len);
-int gdr_binning_carve_seg(void* base, uint64_t D, int32_t seg_len, gdr_binning* out);
+/* The same for a known scene shape: the cut-list tables (seg_extra, seg_state: 2 * (D / seg_len + 1) slots of 10 KB —
+ * 80 bytes per duplicate at seg_len = 256, 40 at 512) sized for the segment length the caller is going to use (seg_len =
+ * a multiple of 256, or 0: lists are never cut, no tables; out->seg_len = seg_len), and — given N Gaussians and the
+ * image's tile count — the count matrix of the direct tile binning (min(256, N / 1024) + 1 rows of tiles words; tiles = 0 or
+ * > 16384: none, the radix partition is used). */
+size_t gdr_binning_bytes_for(uint64_t D, int32_t seg_len, int32_t N, int32_t tiles);
+int gdr_binning_carve_for(void* base, uint64_t D, int32_t seg_len, int32_t N, int32_t tiles, gdr_binning* out);
 int gdr_image_carve(void* base, int32_t H, int32_t W, gdr_image* out);
 
 /* ---- forward ---------------------------------------------------------------------
@@ -265,8 +272,6 @@ int gdr_binning_forward(const gdr_settings* s, int32_t N, const gdr_geom* geom, 
 /* the same for V <= GDR_MAX_VIEWS views of ONE image size in the same launches (every binning kernel covers all the views,
  * view = blockIdx.y): the chain is ~13 short dependent launches whatever the number of views.  geoms / bins / imgs / D /
  * radii: arrays of V. */
-int gdr_binning_forward_views(int32_t V, const gdr_settings* s, int32_t N, const gdr_geom* geoms, gdr_binning* bins,
-                              const gdr_image* imgs, const uint64_t* D, const int32_t* const* radii, void* stream);
 int gdr_composite_forward(const gdr_settings* s, const gdr_geom* geom, const gdr_binning* bin, const gdr_image* img,
                           const gdr_outputs* out, void* stream);
 

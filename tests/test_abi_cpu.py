@@ -180,12 +180,18 @@ def test_host_policy_helpers_without_gpu():
         R.BIN_STREAM, R.SEG_LEN = saved
     lib = L.load()
     # the cut-list tables are carved for the segment length the caller is going to use (80 / 40 / 0 bytes per duplicate)
-    b256, b512, b0 = (lib.gdr_binning_bytes_seg(4_000_000, sl) for sl in (256, 512, 0))
+    b256, b512, b0 = (lib.gdr_binning_bytes_for(4_000_000, sl, 0, 0) for sl in (256, 512, 0))
     assert b256 == lib.gdr_binning_bytes(4_000_000) and b256 - b512 >= 4_000_000 * 39 and b512 - b0 >= 4_000_000 * 39
     bb = L.GdrBinning()
-    assert lib.gdr_binning_carve_seg(C.c_void_p(0x10000000), 4_000_000, 512, C.byref(bb)) == 0
-    assert bb.seg_len == 512 and bb.seg_cap == 4_000_000 // 512 + 1
-    assert lib.gdr_binning_carve_seg(C.c_void_p(0x10000000), 4_000_000, 0, C.byref(bb)) == 0 and bb.seg_len == 0 and bb.seg_cap == 0
+    assert lib.gdr_binning_carve_for(C.c_void_p(0x10000000), 4_000_000, 512, 0, 0, C.byref(bb)) == 0
+    assert bb.seg_len == 512 and bb.seg_cap == 4_000_000 // 512 + 1 and not bb.tile_hist and bb.hist_width == 0
+    assert lib.gdr_binning_carve_for(C.c_void_p(0x10000000), 4_000_000, 0, 0, 0, C.byref(bb)) == 0 and bb.seg_len == 0 and bb.seg_cap == 0
+    # the count matrix of the direct tile binning: min(256, N / 1024) rows of tiles words (+ a totals row); none beyond 16384 tiles
+    assert lib.gdr_binning_carve_for(C.c_void_p(0x10000000), 4_000_000, 256, 2_000_000, 2500, C.byref(bb)) == 0
+    assert bb.tile_hist and bb.hist_width == 256
+    assert lib.gdr_binning_bytes_for(4_000_000, 256, 2_000_000, 2500) - b256 >= 2500 * 257 * 4
+    assert lib.gdr_binning_carve_for(C.c_void_p(0x10000000), 4_000_000, 256, 100_000, 2500, C.byref(bb)) == 0 and bb.hist_width == 98
+    assert lib.gdr_binning_carve_for(C.c_void_p(0x10000000), 4_000_000, 256, 2_000_000, 32_400, C.byref(bb)) == 0 and not bb.tile_hist
     small, big = lib.gdr_binning_bytes(1000), lib.gdr_binning_bytes(4_000_000)
     assert big > small and big >= 4_000_000 * (8 + 8 + 4 + 4 + 8) + 2 * (4_000_000 // 2048) * 10 * 256 * 4
 

@@ -475,6 +475,19 @@ def test_global_sort_fallback_paths(oracle_built):
     np.testing.assert_array_equal(h["point_list"].view(np.uint32), o["point_list"])
     np.testing.assert_array_equal(h["keys_sorted"].view(np.uint64), o["keys_sorted"])
     np.testing.assert_array_equal(h["ranges"].view(np.uint32), o["ranges"])
+    # (a') the radix partition on the tile bits (the path of images with > 16384 tiles, where the LDS histogram of the
+    # direct tile binning does not fit) instead of the direct tile binning: same lists
+    for cc in (case, U.make_case(40_000, 250, 190, 5, deg=1, sigma0=(0.02, 0.003))):
+        oo, _ = U.run_oracle(cc, "f32")
+        R._FORCE_RADIX_PARTITION = True
+        try:
+            h, _ = U.run_hip(cc)
+        finally:
+            R._FORCE_RADIX_PARTITION = False
+        np.testing.assert_array_equal(h["point_list"].view(np.uint32), oo["point_list"])
+        np.testing.assert_array_equal(h["keys_sorted"].view(np.uint64), oo["keys_sorted"])
+        np.testing.assert_array_equal(h["ranges"].view(np.uint32), oo["ranges"])
+        assert U.outlier_fraction(h["color"], oo["color"], 1e-4, 1e-5) < 1e-4
     # (b) 16 tiles, ~15k entries per tile (> LDS capacity of ~9.7k)
     case = U.make_case(60_000, 64, 64, 23, deg=0, sigma0=(0.03,))
     o, _ = U.run_oracle(case, "f32")
