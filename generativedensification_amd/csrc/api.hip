@@ -241,60 +241,75 @@ int gdr_preprocess_forward(const gdr_settings* s, const gdr_inputs* in, const gd
     return GDR_OK;
 }
 
-// Everything between K1 and K6 for one view; shared by the 3DGS and the surfel path (only the geometry's depths / rects /
-// tiles_touched and the radii are read).  Default: direct tile binning (count / scan / scatter) -> tile order -> per-tile
-// LDS depth sort.  Without a count matrix (gdr_binning_carve, or > 16384 tiles): duplicate + stable radix partition on
-// the tile bits -> ranges -> the same tile order and sort.  global_sort: one stable LSD radix sort over all key bits.
-static int binning_stage(const gdr_settings* s, int32_t N, const gdr_geom* geom, gdr_binning* bin, const gdr_image* img,
-                         uint64_t D, const int32_t* radii, hipStream_t st) {
+// Everything between K1 and K6 for V views (every launch covers all of them: view = blockIdx.y); shared by the 3DGS and the
+// surfel path (only the geometry's depths / rects / tiles_touched and the radii are read).  All views share one image
+// size, N and workspace shape.  Default: direct tile binning (count / scan / scatter) -> tile order -> per-tile LDS depth
+// sort.  Without a count matrix (gdr_binning_carve, or > 16384 tiles): duplicate + stable radix partition on the tile
+// bits -> ranges -> the same tile order and sort.  global_sort: one stable LSD radix sort over all key bits.
+static int binning_stage_views(int V, const gdr_settings* s, int32_t N, const gdr_geom* geoms, gdr_binning* bins,
+                               const gdr_image* imgs, const uint64_t* D, const int32_t* const* radii, hipStream_t st) {
     int rc;
     const int W = s->image_width, H = s->image_height;
     const int tiles = tile_grid_x(W) * tile_grid_y(H);
     hipError_t e;
-    const bool global_sort = bin->global_sort != 0;
-    const bool direct = !global_sort && bin->tile_hist && bin->hist_width > 0 && tiles <= GDR_BIN_MAX_TILES;
+    const bool global_sort = bins[0].global_sort != 0;
+    bool direct = !global_sort && tiles <= GDR_BIN_MAX_TILES;
+    uint64_t dmax = 0;
+    for (int v = 0; v < V; ++v) {
+        direct = direct && bins[v].tile_hist && bins[v].hist_width > 0 && bins[v].hist_width == bins[0].hist_width;
+        dmax = D[v] > dmax ? D[v] : dmax;
+    }
     if (global_sort) {  // stable global sort: duplicates must be emitted in Gaussian order
-        e = launch_scan_block_sums(geom, N, st);
-        if (e != hipSuccess) return hip_fail("scan_block_sums", e);
+        for (int v = 0; v < V; ++v) {
+            e = launch_scan_block_sums(&geoms[v], N, st);
+            if (e != hipSuccess) return hip_fail("scan_block_sums", e);
+        }
     }
     BinViews vs;
-    fill_bin_views(&vs, 1, geom, bin, img, &D, &radii);
+    fill_bin_views(&vs, V, geoms, bins, imgs, D, radii);
     int sorted = 0;
-    if (direct && (N == 0 || D == 0)) {   // nothing to bin: only the ranges are cleared (ranges_clear inside)
-        e = launch_duplicate_views(vs, 1, 0, W, H, st);
+    bool from_totals = false;
+    if (direct && (N == 0 || dmax == 0)) {   // nothing to bin: only the ranges are cleared (ranges_clear inside)
+        e = launch_duplicate_views(vs, V, 0, W, H, st);
         if (e != hipSuccess) return hip_fail("ranges_clear", e);
     } else if (direct) {
-        e = launch_tile_count_scan(vs.v[0], N, W, H, st);
+        e = launch_tile_count_scan(vs, V, N, W, H, st);
         if (e != hipSuccess) return hip_fail("tile_count_scan", e);
         if ((rc = debug_sync(s, "tile_count_scan", st))) return rc;
-        vs.v[0].from_totals = 1;
+        from_totals = true;
+        for (int v = 0; v < V; ++v) vs.v[v].from_totals = 1;
     } else {
-        e = launch_duplicate_views(vs, 1, N, W, H, st);
+        e = launch_duplicate_views(vs, V, N, W, H, st);
         if (e != hipSuccess) return hip_fail("duplicate", e);
         if ((rc = debug_sync(s, "duplicate", st))) return rc;
-        e = launch_sort_views(vs, 1, global_sort ? 0 : 32, key_bits(tiles), &sorted, st);
+        e = launch_sort_views(vs, V, global_sort ? 0 : 32, key_bits(tiles), &sorted, st);
         if (e != hipSuccess) return hip_fail("sort", e);
         if ((rc = debug_sync(s, "sort", st))) return rc;
-        e = launch_ranges_views(vs, 1, sorted, tiles, st);
+        e = launch_ranges_views(vs, V, sorted, tiles, st);
         if (e != hipSuccess) return hip_fail("ranges", e);
         if ((rc = debug_sync(s, "ranges", st))) return rc;
     }
-    e = launch_tile_order_views(vs, 1, tiles, st);  // (totals -> ranges first;) longest list first: launch order of tile_sort, K6, K7
+    e = launch_tile_order_views(vs, V, tiles, st);  // (totals -> ranges first;) longest list first: launch order of tile_sort, K6, K7
     if (e != hipSuccess) return hip_fail("tile_order", e);
     if ((rc = debug_sync(s, "tile_order", st))) return rc;
-    if (vs.v[0].from_totals) {
-        e = launch_tile_scatter(vs.v[0], N, W, H, st);
+    if (from_totals) {
+        e = launch_tile_scatter(vs, V, N, W, H, st);
         if (e != hipSuccess) return hip_fail("tile_scatter", e);
         if ((rc = debug_sync(s, "tile_scatter", st))) return rc;
     }
     if (!global_sort) {  // per-tile LDS depth sort of the partitioned lists
-        e = launch_tile_sort_views(vs, 1, sorted, tiles, direct, st);
+        e = launch_tile_sort_views(vs, V, sorted, tiles, direct, st);
         if (e != hipSuccess) return hip_fail("tile_sort", e);
         if ((rc = debug_sync(s, "tile_sort", st))) return rc;
         sorted ^= 1;
     }
-    bin->sorted = sorted;
+    for (int v = 0; v < V; ++v) bins[v].sorted = sorted;
     return GDR_OK;
+}
+
+static int binning_stage(const gdr_settings* s, int32_t N, const gdr_geom* geom, gdr_binning* bin, const gdr_image* img,
+                         uint64_t D, const int32_t* radii, hipStream_t st) {
+    return binning_stage_views(1, s, N, geom, bin, img, &D, &radii, st);
 }
 
 int gdr_binning_forward(const gdr_settings* s, int32_t N, const gdr_geom* geom, gdr_binning* bin, const gdr_image* img,

@@ -348,8 +348,9 @@ __device__ __forceinline__ bool bin_gaussian(const BinView& bv, int i, int4& r) 
 
 // count matrix layout: row w = workgroup w of tile_count / tile_scatter, `tstride` words (tiles rounded up to 64): every
 // access below is coalesced — the workgroups write / read their own row, the scan walks the rows with one thread per tile
-__global__ __launch_bounds__(GDR_BIN_THREADS) void tile_count_kernel(const BinView bv, int N, int gx, int tiles, int chunk,
+__global__ __launch_bounds__(GDR_BIN_THREADS) void tile_count_kernel(const BinViews vs, int N, int gx, int tiles, int chunk,
                                                                       int tstride) {
+    const BinView& bv = vs.v[blockIdx.y];
     extern __shared__ uint32_t cnt[];
     for (int t = threadIdx.x; t < tiles; t += GDR_BIN_THREADS) cnt[t] = 0u;
     __syncthreads();
@@ -369,7 +370,8 @@ __global__ __launch_bounds__(GDR_BIN_THREADS) void tile_count_kernel(const BinVi
 // segments of the workgroup axis: thread (segment, tile) sums its segment, the segment sums are exchanged in LDS, a second
 // sweep writes the prefixes.  totals: (tiles) words behind the matrix; tile_order_kernel turns them into the ranges.
 #define GDR_BIN_SEGS 16
-__global__ __launch_bounds__(64 * GDR_BIN_SEGS) void tile_scan_kernel(const BinView bv, int tiles, int nwg, int tstride) {
+__global__ __launch_bounds__(64 * GDR_BIN_SEGS) void tile_scan_kernel(const BinViews vs, int tiles, int nwg, int tstride) {
+    const BinView& bv = vs.v[blockIdx.y];
     __shared__ uint32_t segsum[GDR_BIN_SEGS][64];
     const int tl = threadIdx.x & 63, seg = threadIdx.x >> 6;
     const int t = blockIdx.x * 64 + tl;
@@ -397,8 +399,9 @@ __global__ __launch_bounds__(64 * GDR_BIN_SEGS) void tile_scan_kernel(const BinV
     if (seg == 0) bv.tile_hist[(size_t)bv.hist_width * tstride + t] = total;
 }
 
-__global__ __launch_bounds__(GDR_BIN_THREADS) void tile_scatter_kernel(const BinView bv, int N, int gx, int tiles, int chunk,
+__global__ __launch_bounds__(GDR_BIN_THREADS) void tile_scatter_kernel(const BinViews vs, int N, int gx, int tiles, int chunk,
                                                                         int tstride) {
+    const BinView& bv = vs.v[blockIdx.y];
     extern __shared__ uint32_t cur[];
     const uint2* __restrict__ ranges = bv.ranges;
     const uint32_t* __restrict__ row = bv.tile_hist + (size_t)blockIdx.x * tstride;
@@ -872,7 +875,8 @@ static int merged_hint(const BinViews& vs, int V, bool long_class) {
     return h;
 }
 
-// direct tile binning of ONE view: count -> scan -> [tile_order_kernel: totals -> ranges, issued by the caller] -> scatter
+// direct tile binning of V views (view = blockIdx.y; all views share N, the image size and hist_width):
+// count -> scan -> [tile_order_kernel: totals -> ranges, issued by the caller] -> scatter
 static void bin_geometry(const BinView& bv, int N, int tiles, int* nwg, int* chunk, int* tstride) {
     int w = div_up(N, GDR_BIN_THREADS);
     if (w > bv.hist_width) w = bv.hist_width;
@@ -881,23 +885,23 @@ static void bin_geometry(const BinView& bv, int N, int tiles, int* nwg, int* chu
     *nwg = div_up(N, *chunk);
     *tstride = div_up(tiles, 64) * 64;
 }
-hipError_t launch_tile_count_scan(const BinView& bv, int N, int W, int H, hipStream_t st) {
+hipError_t launch_tile_count_scan(const BinViews& vs, int V, int N, int W, int H, hipStream_t st) {
     const int gx = tile_grid_x(W), tiles = gx * tile_grid_y(H);
     int nwg, chunk, tstride;
-    bin_geometry(bv, N, tiles, &nwg, &chunk, &tstride);
+    bin_geometry(vs.v[0], N, tiles, &nwg, &chunk, &tstride);
     const size_t lds = (size_t)tiles * sizeof(uint32_t);
     prof_begin(GDR_K_TILE_COUNT, st);
-    hipLaunchKernelGGL(tile_count_kernel, dim3(nwg), dim3(GDR_BIN_THREADS), lds, st, bv, N, gx, tiles, chunk, tstride);
+    hipLaunchKernelGGL(tile_count_kernel, dim3(nwg, V), dim3(GDR_BIN_THREADS), lds, st, vs, N, gx, tiles, chunk, tstride);
     prof_end(GDR_K_TILE_COUNT, st);
-    GDR_LAUNCH(GDR_K_TILE_SCAN, tile_scan_kernel, dim3(div_up(tiles, 64)), dim3(64 * GDR_BIN_SEGS), st, bv, tiles, nwg, tstride);
+    GDR_LAUNCH(GDR_K_TILE_SCAN, tile_scan_kernel, dim3(div_up(tiles, 64), V), dim3(64 * GDR_BIN_SEGS), st, vs, tiles, nwg, tstride);
     return hipGetLastError();
 }
-hipError_t launch_tile_scatter(const BinView& bv, int N, int W, int H, hipStream_t st) {
+hipError_t launch_tile_scatter(const BinViews& vs, int V, int N, int W, int H, hipStream_t st) {
     const int gx = tile_grid_x(W), tiles = gx * tile_grid_y(H);
     int nwg, chunk, tstride;
-    bin_geometry(bv, N, tiles, &nwg, &chunk, &tstride);
+    bin_geometry(vs.v[0], N, tiles, &nwg, &chunk, &tstride);
     prof_begin(GDR_K_TILE_SCATTER, st);
-    hipLaunchKernelGGL(tile_scatter_kernel, dim3(nwg), dim3(GDR_BIN_THREADS), (size_t)tiles * sizeof(uint32_t), st, bv, N, gx,
+    hipLaunchKernelGGL(tile_scatter_kernel, dim3(nwg, V), dim3(GDR_BIN_THREADS), (size_t)tiles * sizeof(uint32_t), st, vs, N, gx,
                        tiles, chunk, tstride);
     prof_end(GDR_K_TILE_SCATTER, st);
     return hipGetLastError();
@@ -917,11 +921,24 @@ hipError_t launch_tile_sort_views(const BinViews& vs, int V, int in, int tiles, 
     const int h_long = merged_hint(vs, V, true), h_medium = merged_hint(vs, V, false);
     if (h_long > 0 && h_long < g_long) g_long = h_long;
     if (h_medium > 0 && h_medium < g_medium) g_medium = h_medium;
+    // hint_long < 0 (every view): the previous calls of this scene shape saw no list beyond the medium class.  The long
+    // class is then not launched at all — a 16-wave workgroup with 144 KB of LDS needs a whole CU to itself, and in a
+    // multi-view node, with other views' K6 workgroups resident everywhere, the EMPTY launch waited ~240 us for one
+    // (kernel timeline of a C4 step, profiles/r03_timeline_c4.txt) and stalled its view's chain behind it.  The medium
+    // class takes the lists beyond its LDS capacity instead (TOP: bucket pass through global memory, then LDS-sized
+    // runs) — slower for such a list, identical result, so a wrong hint only costs time.
+    bool no_long = true;
+    for (int v = 0; v < V; ++v) no_long = no_long && vs.v[v].hint_long < 0;
     if (packed) {
-        GDR_LAUNCH(GDR_K_TILE_SORT_LONG, (tile_sort_kernel<GDR_TSORT_LARGE, GDR_TSORT_MEDIUM, 16, true, true>),
-                   dim3(g_long, V), dim3(16 * GDR_WAVE), st, vs, in, tiles);
-        GDR_LAUNCH(GDR_K_TILE_SORT_LONG, (tile_sort_kernel<GDR_TSORT_MEDIUM, GDR_TSORT_SMALL, 8, false, true>),
-                   dim3(g_medium, V), dim3(8 * GDR_WAVE), st, vs, in, tiles);
+        if (!no_long)
+            GDR_LAUNCH(GDR_K_TILE_SORT_LONG, (tile_sort_kernel<GDR_TSORT_LARGE, GDR_TSORT_MEDIUM, 16, true, true>),
+                       dim3(g_long, V), dim3(16 * GDR_WAVE), st, vs, in, tiles);
+        if (no_long)
+            GDR_LAUNCH(GDR_K_TILE_SORT_LONG, (tile_sort_kernel<GDR_TSORT_MEDIUM, GDR_TSORT_SMALL, 8, true, true>),
+                       dim3(g_medium, V), dim3(8 * GDR_WAVE), st, vs, in, tiles);
+        else
+            GDR_LAUNCH(GDR_K_TILE_SORT_LONG, (tile_sort_kernel<GDR_TSORT_MEDIUM, GDR_TSORT_SMALL, 8, false, true>),
+                       dim3(g_medium, V), dim3(8 * GDR_WAVE), st, vs, in, tiles);
         GDR_LAUNCH(GDR_K_TILE_SORT, (tile_sort_kernel<GDR_TSORT_SMALL, 0, 4, false, true>), dim3(tiles, V), dim3(GDR_BLOCK), st,
                    vs, in, tiles);
         return hipGetLastError();

@@ -113,8 +113,8 @@ hipError_t launch_duplicate_views(const BinViews& vs, int V, int N, int W, int H
 hipError_t launch_sort_views(const BinViews& vs, int V, int lo, int hi, int* sorted, hipStream_t st);
 hipError_t launch_ranges_views(const BinViews& vs, int V, int cur, int tiles, hipStream_t st);
 hipError_t launch_tile_sort_views(const BinViews& vs, int V, int in, int tiles, bool packed, hipStream_t st);
-hipError_t launch_tile_count_scan(const BinView& bv, int N, int W, int H, hipStream_t st);
-hipError_t launch_tile_scatter(const BinView& bv, int N, int W, int H, hipStream_t st);
+hipError_t launch_tile_count_scan(const BinViews& vs, int V, int N, int W, int H, hipStream_t st);
+hipError_t launch_tile_scatter(const BinViews& vs, int V, int N, int W, int H, hipStream_t st);
 hipError_t launch_tile_order_views(const BinViews& vs, int V, int tiles, hipStream_t st);
 // per-pixel compositing state saved at a cut of a long tile list, 256 pixels each: 3DGS T, colour x3, depth, alpha
 // sums (6 used); surfels T, colour x3, normal x3, depth, M1, M2 (10)

@@ -595,7 +595,9 @@ def _launch_stats(key, V):
     st = _HINT_STATE.setdefault(key, [0, 0, 0])
     st[0], st[1] = max(n_long, st[0] * 9 // 10), max(n_medium, st[1] * 9 // 10)
     st[2] = 8 if deep else max(0, st[2] - 1)
-    return t, (max(16, st[0] + st[0] // 4 + 1), max(32, st[1] + st[1] // 4 + 1), int(st[2] == 0), max(r[3] for r in seen))
+    # (long class: -1 = "no list beyond the medium class in the recent calls" -> the 144 KB launch is skipped, binning.hip)
+    return t, (-1 if st[0] == 0 else max(16, st[0] + st[0] // 4 + 1), max(32, st[1] + st[1] // 4 + 1), int(st[2] == 0),
+               max(r[3] for r in seen))
 
 
 def _carve_binning(lib, st, entries, tiles, d_dev=None, stats=None, hints=None):
@@ -724,8 +726,10 @@ def _forward_views_impl(means3D, means2D, sh, opacities, scales, rotations, sett
                                                        float(w_alpha), losses[v:v + 1].data_ptr(), sv),
                         "gdr_composite_forward_loss")
 
-        def chain(v, fs):   # binning of view v on stream fs, then its K6 (batched chains for several views were measured in
-            sp = C.c_void_p(fs.cuda_stream)                       # round 2 and lost 5-10 %: DESIGN §3)
+        def chain(v, fs):   # binning of view v on stream fs, then its K6.  (One chain for a GROUP of views — every binning
+            # launch covering 2 / 4 / 8 views, view = blockIdx.y — was measured again with the direct tile binning of round 3:
+            # C4 1262 -> 1194 / 1227 / 1235, C3 3008 -> 2819 / 2908 / 3023, C2 2957 -> 2780 / 2855 / 2887 views/s: DESIGN §3.)
+            sp = C.c_void_p(fs.cuda_stream)
             st = states[v]
             L.check(lib.gdr_binning_forward(C.byref(s_arr[v]), N, C.byref(g_arr[v]), C.byref(st.bin),
                                             C.byref(st.img), st.D, _ptr(radii[v]), sp), "gdr_binning_forward")

@@ -166,7 +166,9 @@ typedef struct gdr_binning {
      * the binning stage reports what it found, the caller passes it back into the next call of that shape. */
     uint32_t* stats_out; /* NULL, or 4 device-writable words (pinned host memory works): {tiles in the tile sort's long
                           * class (> 4096 entries), tiles in its medium class (2049..4096), "deep forward" flag, busy tiles} */
-    int32_t hint_long;   /* > 0: workgroups for the tile sort's long class; 0 = sized for the worst case.  Every value >= 1 */
+    int32_t hint_long;   /* > 0: workgroups for the tile sort's long class; 0 = sized for the worst case; < 0: the long class
+                          * (16 waves, 144 KB of LDS per workgroup) is not launched, the medium class takes any longer list
+                          * through its global-memory bucket pass (same result, slower for such a list).  Every value >= 1 */
     int32_t hint_medium; /*      is correct (the classes walk their tiles with a grid stride), a wrong one only costs time   */
     int32_t hint_no_deep;/* != 0: the deep forward is not launched; K6 renders every tile the standard way (same images)     */
     int32_t grad_rec_cleared; /* != 0: the caller has already zero-filled the gradient record it passes to the K7 entry points
