@@ -18,6 +18,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os as _os
+import threading
 from typing import NamedTuple, Optional
 
 import torch
@@ -146,7 +147,7 @@ _FORCE_RADIX_PARTITION = False
 
 # Streams of a multi-view node.  Forward: every view's chain binning -> K6 on one of FWD_STREAMS streams, the caller's
 # included (_forward_views_impl).  Backward: K7 of the views round-robin on side_count() side streams (_SideViews; 2 at
-# 800x800, 3 for smaller images; GDR_BIN_STREAM=n / GDR_BWD_STREAMS=n override, 0 = the caller's stream only).
+# 800x800, 3 for smaller images; GDR_BWD_STREAMS=n overrides, 0 = the caller's stream only).
 # GDR_RENDER_SIDE=0: everything on the caller's stream (bench.py's serial pass for per-kernel durations).
 # Measured on MI355X (views/s; K7 of the views on n side streams, one box, round 2):
 #   n   C4 cube  C4 shell  C3 cube  C3 shell  C2 cube  C2 shell  C5 cube  C5 shell
@@ -160,8 +161,7 @@ RENDER_SIDE = int(_os.environ.get("GDR_RENDER_SIDE", "1"))
 FWD_STREAMS = int(_os.environ.get("GDR_FWD_STREAMS", "4"))
 # side streams of the backward (K7 of the views); unset = side_count()
 BWD_STREAMS = int(_os.environ["GDR_BWD_STREAMS"]) if _os.environ.get("GDR_BWD_STREAMS") else None
-_BIN_STREAM_ENV = _os.environ.get("GDR_BIN_STREAM")
-BIN_STREAM = None if _BIN_STREAM_ENV is None else max(0, int(_BIN_STREAM_ENV))
+BIN_STREAM = None     # tests: force side_count() (None = by image size)
 
 
 # Segment length of cut tile lists (include/gdr.h gdr_binning.seg_len): None = the library default
@@ -172,7 +172,7 @@ SEG_LEN = int(_os.environ["GDR_SEG_LEN"]) if _os.environ.get("GDR_SEG_LEN") else
 
 
 # K6 "deep" forward (include/gdr.h gdr_binning.deep_max_busy): None = library default (768 busy tiles), 0 = never.
-DEEP_MAX_BUSY = int(_os.environ["GDR_DEEP_MAX_BUSY"]) if _os.environ.get("GDR_DEEP_MAX_BUSY") else None
+DEEP_MAX_BUSY = None
 
 
 def _seg_len_for(D, tiles=None, busy=None):
@@ -202,10 +202,11 @@ _side_streams: dict = {}
 
 
 def _view_streams(dev, n):
-    pool = _side_streams.setdefault(dev.index, [])
-    while len(pool) < n:
-        pool.append(torch.cuda.Stream(device=dev))
-    return pool[:n]
+    with _HIST_LOCK:
+        pool = _side_streams.setdefault(dev.index, [])
+        while len(pool) < n:
+            pool.append(torch.cuda.Stream(device=dev))
+        return pool[:n]
 
 
 def _stream():
@@ -400,7 +401,7 @@ def backward_raw(st: _State, keep, raster_settings, radii, grad_color, grad_dept
     return g
 
 
-EARLY_CLEAR = _os.environ.get("GDR_EARLY_CLEAR", "1") != "0"
+EARLY_CLEAR = True
 
 
 def _early_records(ctx, dev, V, N, H, W, floats):
@@ -507,9 +508,11 @@ RAW_ALL = L.GDR_IN_RAW_OPACITY | L.GDR_IN_RAW_SCALES | L.GDR_IN_RAW_ROTATIONS
 # that did not fit (nothing was written out of bounds, but its lists are truncated) is repeated with an exactly sized
 # workspace before the call returns, so the results never depend on the guess.
 DEFER_D = _os.environ.get("GDR_DEFER_D", "1") != "0"
-D_SLACK = float(_os.environ.get("GDR_D_SLACK", "1.5"))   # capacity = slack x the largest recent count of the shape (measured:
+D_SLACK = 1.5   # capacity = slack x the largest recent count of the shape (measured:
 # 1.02 / 1.25 / 2.0 run at the same speed — surplus workgroups leave at once —, so the slack only costs memory)
 _D_HINT: dict = {}   # shape key -> decaying maximum of duplicates PER GAUSSIAN of one view of that shape
+_HIST_LOCK = threading.Lock()   # the per-shape histories (_D_HINT, _LAUNCH_STATS, _HINT_STATE, _side_streams) are process-wide:
+# two host threads driving distinct workspaces (include/gdr.h: the library below is thread-safe for those) may share them
 
 
 def shape_key(N, *rest):
@@ -521,15 +524,17 @@ def shape_key(N, *rest):
 
 def _d_capacity(key, N):
     """Entries to carve each view's binning workspace for, or None: no history yet (or GDR_DEFER_D=0) -> read D back."""
-    h = _D_HINT.get(key) if DEFER_D else None
+    with _HIST_LOCK:
+        h = _D_HINT.get(key) if DEFER_D else None
     return None if h is None else int(h * N * D_SLACK) + 4096
 
 
 def _d_record(key, d_host, N):
-    prev = _D_HINT.pop(key, 0.0)     # (re-inserted at the end: the dict doubles as an LRU of 64 shapes)
-    _D_HINT[key] = max(max(d_host, default=0) / max(N, 1), prev * 0.97)
-    if len(_D_HINT) > 64:
-        _D_HINT.pop(next(iter(_D_HINT)))
+    with _HIST_LOCK:
+        prev = _D_HINT.pop(key, 0.0)     # (re-inserted at the end: the dict doubles as an LRU of 64 shapes)
+        _D_HINT[key] = max(max(d_host, default=0) / max(N, 1), prev * 0.97)
+        if len(_D_HINT) > 64:
+            _D_HINT.pop(next(iter(_D_HINT)))
 
 
 class _CountReadback:
@@ -563,7 +568,7 @@ class _CountReadback:
 # on it: the classes walk their tiles with a grid stride, and K6 renders every tile the standard way without the deep
 # launch.  The words live in pinned host memory the kernels write directly (4 words per view and shape, kept for the
 # life of the process: the GPU may still be writing when a shape is last used).
-LAUNCH_HINTS = _os.environ.get("GDR_LAUNCH_HINTS", "1") != "0"
+LAUNCH_HINTS = True
 _LAUNCH_STATS: dict = {}
 
 
@@ -579,22 +584,24 @@ def _launch_stats(key, V):
     if not LAUNCH_HINTS:
         return None, None
     key = (torch.cuda.current_device(),) + tuple(key)   # one report tensor per device and shape
-    t = _LAUNCH_STATS.get(key)
-    if t is None:
-        if len(_LAUNCH_STATS) >= 1024:
-            return None, None
-        try:
-            t = torch.full((V, 4), -1, dtype=torch.int32).pin_memory()
-        except RuntimeError:    # no page-locked memory to be had: the feedback is an optimisation, not a requirement
-            return None, None
-        _LAUNCH_STATS[key] = t
-    seen = [r for r in t.tolist() if r[0] >= 0]
-    if not seen:
-        return t, None
-    n_long, n_medium, deep = max(r[0] for r in seen), max(r[1] for r in seen), any(r[2] for r in seen)
-    st = _HINT_STATE.setdefault(key, [0, 0, 0])
-    st[0], st[1] = max(n_long, st[0] * 9 // 10), max(n_medium, st[1] * 9 // 10)
-    st[2] = 8 if deep else max(0, st[2] - 1)
+    with _HIST_LOCK:
+        t = _LAUNCH_STATS.get(key)
+        if t is None:
+            if len(_LAUNCH_STATS) >= 1024:
+                return None, None
+            try:
+                t = torch.full((V, 4), -1, dtype=torch.int32).pin_memory()
+            except RuntimeError:    # no page-locked memory to be had: the feedback is an optimisation, not a requirement
+                return None, None
+            _LAUNCH_STATS[key] = t
+        seen = [r for r in t.tolist() if r[0] >= 0]
+        if not seen:
+            return t, None
+        n_long, n_medium, deep = max(r[0] for r in seen), max(r[1] for r in seen), any(r[2] for r in seen)
+        st = _HINT_STATE.setdefault(key, [0, 0, 0])
+        st[0], st[1] = max(n_long, st[0] * 9 // 10), max(n_medium, st[1] * 9 // 10)
+        st[2] = 8 if deep else max(0, st[2] - 1)
+        st = list(st)
     # (long class: -1 = "no list beyond the medium class in the recent calls" -> the 144 KB launch is skipped, binning.hip)
     return t, (-1 if st[0] == 0 else max(16, st[0] + st[0] // 4 + 1), max(32, st[1] + st[1] // 4 + 1), int(st[2] == 0),
                max(r[3] for r in seen))

@@ -1,16 +1,20 @@
 #!/bin/bash
-# End-of-round evidence run on the GPU box: tests, smoke, bench lines (with cpu_baseline), rocprofv3 kernel stats,
-# PMC traffic, 2-rank smoke.  Everything lands in gpurun_out/final/ (copied into profiles/ by hand afterwards).
+# End-of-round evidence run on the GPU box: smoke + tests (with the parity statistics), bench lines of every workload
+# (each carries its `per_view` second headline), the reference train-step sequence, rocprofv3 kernel stats, PMC traffic
+# (-> profiles/pmc_traffic.json), a kernel timeline, the scene-size sweep, 2- and 8-rank smoke.  Everything lands in
+# gpurun_out/final/ (copied into profiles/ afterwards).   bash scripts/gpu_final.sh r03
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 R=$PWD; O=$R/gpurun_out/final; mkdir -p $O
-TAG=${1:-r02}
-bash scripts/gpu_check.sh > $O/check.log 2>&1; tail -3 $O/check.log
+TAG=${1:-r03}
+timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?"; tail -2 $O/smoke.log
+timeout 1500 python -m pytest tests -m gpu -q -rP > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -1 $O/pytest_gpu.log
+grep -E "^\[" $O/pytest_gpu.log > $O/${TAG}_fullsize_parity.log
 b() { name=$1; shift; timeout 1200 python bench.py "$@" > $O/${TAG}_bench_$name.json 2> $O/bench_$name.err || tail -3 $O/bench_$name.err
   python - <<PY
 import json
 try:
-    d = json.load(open("$O/${TAG}_bench_$name.json")); r = d["roofline"] or {}
-    print("$name", d["value"], "views/s", d["ms_per_step"], "ms/step D", d["config"]["num_rendered_per_view"], "dom", r.get("kernel"), r.get("frac"), "path", r.get("path_frac"), "cpu", (d["cpu_baseline"] or {}).get("value"))
+    d = json.load(open("$O/${TAG}_bench_$name.json")); r = d["roofline"] or {}; pv = d.get("per_view") or {}
+    print("$name", d["value"], d["unit"], d["ms_per_step"], "ms/step | per_view", pv.get("value"), "| D", d["config"].get("num_rendered_per_view"), "dom", r.get("kernel"), r.get("frac"), r.get("frac_serial"), "path", r.get("path_frac"), r.get("path_frac_measured"), "cpu", (d["cpu_baseline"] or {}).get("value"))
 except Exception as e: print("$name FAILED", e)
 PY
 }
@@ -18,35 +22,39 @@ b default
 b c2 --workload c2
 b c3 --workload c3
 b c5 --workload c5
-b c4_perview --per-view --unfused --no-cpu-baseline
-b c4_torchloss --torch-loss --no-cpu-baseline
-b c2_perview --workload c2 --per-view --unfused --no-cpu-baseline
-b c5_perview --workload c5 --per-view --unfused --no-cpu-baseline
+b c3step --workload c3step --steps 6 --warmup 2
+b c4_backward_per_view --backward-per-view --unfused --no-cpu-baseline
+b c4_ungrouped_perview --per-view --unfused --no-cpu-baseline
 b c4_shell --layout shell --no-cpu-baseline
 b c2_shell --workload c2 --layout shell --no-cpu-baseline
 b c3_shell --workload c3 --layout shell --no-cpu-baseline
 b c5_shell --workload c5 --layout shell --no-cpu-baseline
-for wl in c4 c2 c5; do
-  (cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$wl -o $wl -- python $R/bench.py --workload $wl --steps 3 --warmup 1 --no-cpu-baseline --no-roofline > $O/prof_$wl.log 2>&1)
+b c3step_shell --workload c3step --layout shell --steps 6 --warmup 2
+GDR_GROUP_VIEWS=0 timeout 600 python bench.py --per-view --unfused --no-cpu-baseline --no-roofline 2>/dev/null | python -c "import json,sys; d=json.load(sys.stdin); print('c4 per-view, render groups OFF', d['value'])"
+for wl in c4 c3 c2 c5; do
+  (cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$wl -o $wl -- python $R/bench.py --workload $wl --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-per-view-leg > $O/prof_$wl.log 2>&1)
   f=$(find $O/prof_$wl -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/${TAG}_${wl}_kernel_stats.csv && python scripts/stats_print.py $f 3 8
   rm -rf $O/prof_$wl
 done
-for wl in c4 c2 c5; do
-  BENCH_ARGS="--workload $wl" bash scripts/gpu_pmc.sh pmc_$wl > $O/pmc_$wl.log 2>&1
+for wl in c4 c3 c2 c5; do
+  BENCH_ARGS="--workload $wl --no-per-view-leg" bash scripts/gpu_pmc.sh pmc_$wl > $O/pmc_$wl.log 2>&1
   cp gpurun_out/pmc_${wl}_summary.json $O/${TAG}_${wl}_pmc_summary.json 2>/dev/null; rm -rf gpurun_out/pmc_${wl}_[0-9]*
   tail -4 $O/pmc_$wl.log | cut -c1-300
 done
-echo "--- idle gaps (kernel timeline of bench steps)"
-for wl in c4 c2 c3; do
-  (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv -d $O/trace_$wl -o t -- python $R/bench.py --workload $wl --steps 4 --warmup 2 --no-cpu-baseline --no-roofline > $O/trace_$wl.log 2>&1)
-  f=$(find $O/trace_$wl -name "*kernel_trace.csv" | head -1); python scripts/trace_gaps.py $f > $O/${TAG}_trace_gaps_$wl.txt; grep "^step" $O/${TAG}_trace_gaps_$wl.txt | head -3; rm -rf $O/trace_$wl
-done
+echo "--- kernel timeline of a C4 step + idle gaps"
+bash scripts/gpu_timeline.sh c4 --no-per-view-leg > /dev/null 2>&1; cp gpurun_out/timeline_c4.txt $O/${TAG}_timeline_c4.txt; head -12 $O/${TAG}_timeline_c4.txt | grep "^step"
 echo "--- abs-grad entry + device top-k"
 python scripts/absgrad_bench.py 2>/dev/null | tee $O/${TAG}_absgrad.txt
-echo "--- issue-rate microbenchmarks"
-[ -x build/valu_rate ] && build/valu_rate > $O/${TAG}_valu_rate.txt && tail -9 $O/${TAG}_valu_rate.txt
-[ -x build/valu_rate2 ] && build/valu_rate2 > $O/${TAG}_valu_rate2.txt
-echo "--- 2 ranks on one GPU"
-for wl in c2 c5; do for be in gloo; do  # (RCCL refuses two ranks on one device)
-  timeout 600 python bench.py --gpus 2 --steps 3 --warmup 1 --workload $wl --single-device --no-roofline 2>/dev/null | tail -1 | tee $O/${TAG}_bench_2ranks_$wl.json | cut -c1-260
-done; done
+echo "--- size sweep (every frac must stay <= 1; traffic null off the recorded scene)"
+for n in 500000 2000000 8000000 32000000; do
+  timeout 900 python bench.py --n $n --steps 4 --warmup 2 --no-cpu-baseline --no-per-view-leg > $O/n$n.json 2> $O/n$n.err || { echo "N=$n FAILED"; tail -3 $O/n$n.err; continue; }
+  python -c "
+import json; d=json.load(open('$O/n$n.json')); r=d['roofline'] or {}
+fr=[k.get('frac',0) for k in d['kernels'].values()]+[k.get('frac_serial',0) or 0 for k in d['kernels'].values()]
+print(json.dumps(dict(n=$n, views_per_s=d['value'], ms_per_step=d['ms_per_step'], D=d['config']['num_rendered_per_view'], path_frac=r.get('path_frac'), path_frac_measured=r.get('path_frac_measured'), traffic=r.get('traffic'), max_kernel_frac=max(fr), mem_gb=d['config'].get('peak_mem_gb'))))" | tee -a $O/${TAG}_size_sweep.json
+done
+echo "--- RCCL, one rank, collectives forced"
+timeout 600 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-per-view-leg --force-dist --grad-allreduce 2>/dev/null | tail -1 | tee $O/${TAG}_bench_rccl_1rank.json | cut -c1-200
+echo "--- 2 and 8 ranks on one GPU (gloo)"
+timeout 600 python bench.py --gpus 2 --steps 3 --warmup 1 --workload c2 --single-device --no-roofline --no-per-view-leg 2>/dev/null | tail -1 | tee $O/${TAG}_bench_2ranks_c2.json | cut -c1-260
+timeout 900 python bench.py --gpus 8 --steps 3 --warmup 1 --workload c2 --single-device --no-roofline --no-per-view-leg --no-cpu-baseline 2>/dev/null | tail -1 | tee $O/${TAG}_bench_8ranks_c2.json | cut -c1-360

@@ -151,8 +151,8 @@ def test_settings_record_has_the_reference_fields_in_order():
 
 
 def test_host_policy_helpers_without_gpu():
-    """Host-side policy of the multi-view nodes: side-stream count by tile count, the GDR_BIN_STREAM override, and the
-    per-call segment-length override of the cut lists (only lengths the carved tables can hold)."""
+    """Host-side policy of the multi-view nodes: side-stream count by tile count, its test override, and the
+    per-call segment-length choice of the cut lists."""
     from generativedensification_amd import _lib as L
     from generativedensification_amd import rasterizer as R
 
