@@ -9,6 +9,13 @@ TAG=${1:-r03}
 timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?"; tail -2 $O/smoke.log
 timeout 1500 python -m pytest tests -m gpu -q -rP > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -1 $O/pytest_gpu.log
 grep -E "^\[" $O/pytest_gpu.log > $O/${TAG}_fullsize_parity.log
+echo "--- PMC passes first: the bench lines below read the traffic table they produce"
+for wl in c4 c3 c2 c5; do
+  BENCH_ARGS="--workload $wl --no-per-view-leg" bash scripts/gpu_pmc.sh pmc_$wl > $O/pmc_$wl.log 2>&1
+  cp gpurun_out/pmc_${wl}_summary.json $O/${TAG}_${wl}_pmc_summary.json 2>/dev/null; rm -rf gpurun_out/pmc_${wl}_[0-9]*
+  tail -4 $O/pmc_$wl.log | cut -c1-300
+done
+python scripts/make_pmc_traffic.py $O/${TAG} && cp $O/pmc_traffic.json profiles/pmc_traffic.json
 b() { name=$1; shift; timeout 1200 python bench.py "$@" > $O/${TAG}_bench_$name.json 2> $O/bench_$name.err || tail -3 $O/bench_$name.err
   python - <<PY
 import json
@@ -24,7 +31,7 @@ b c3 --workload c3
 b c5 --workload c5
 b c3step --workload c3step --steps 6 --warmup 2
 b c4_backward_per_view --backward-per-view --unfused --no-cpu-baseline
-b c4_ungrouped_perview --per-view --unfused --no-cpu-baseline
+b c4_perview --per-view --unfused --no-cpu-baseline
 b c4_shell --layout shell --no-cpu-baseline
 b c2_shell --workload c2 --layout shell --no-cpu-baseline
 b c3_shell --workload c3 --layout shell --no-cpu-baseline
@@ -35,11 +42,6 @@ for wl in c4 c3 c2 c5; do
   (cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$wl -o $wl -- python $R/bench.py --workload $wl --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-per-view-leg > $O/prof_$wl.log 2>&1)
   f=$(find $O/prof_$wl -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/${TAG}_${wl}_kernel_stats.csv && python scripts/stats_print.py $f 3 8
   rm -rf $O/prof_$wl
-done
-for wl in c4 c3 c2 c5; do
-  BENCH_ARGS="--workload $wl --no-per-view-leg" bash scripts/gpu_pmc.sh pmc_$wl > $O/pmc_$wl.log 2>&1
-  cp gpurun_out/pmc_${wl}_summary.json $O/${TAG}_${wl}_pmc_summary.json 2>/dev/null; rm -rf gpurun_out/pmc_${wl}_[0-9]*
-  tail -4 $O/pmc_$wl.log | cut -c1-300
 done
 echo "--- kernel timeline of a C4 step + idle gaps"
 bash scripts/gpu_timeline.sh c4 --no-per-view-leg > /dev/null 2>&1; cp gpurun_out/timeline_c4.txt $O/${TAG}_timeline_c4.txt; head -12 $O/${TAG}_timeline_c4.txt | grep "^step"
