@@ -576,6 +576,8 @@ def main():
     tiles = ((w + 15) // 16) * ((h + 15) // 16)
     m = (deg + 1) ** 2
     alg = (surfel_algorithmic_bytes if surfel else algorithmic_bytes)(n, d_mean, h * w, m, tiles, min(vpg, 8))
+    # the deep forward takes the cut tiles of an object-like scene (nearly every pair where it runs at all): K6's bytes
+    alg["render_fwd_deep"] = alg["render_fwd"]
     if sum(class_entries):   # the tile sort's D * 24 bytes split over its launches by the entries each size class handles:
         # `tile_sort` = the <= 2048-entry class (one launch per view), `tile_sort_long` = the medium + long class launches
         alg["tile_sort"] = class_entries[0] / len(d_views) * 12

@@ -449,17 +449,30 @@ struct TileSortBufs {
 // one stable 8-bit pass over [0,L) from (kA,vA) to (kB,vB); cnt: [NW][256] LDS counters (NW waves).
 // bstart (optional, 257 entries): receives the exclusive scan of the digit totals (= where each digit's run
 // starts in the output) and L at [256].
-template <int NW>
-__device__ __forceinline__ void tile_sort_pass(const TileSortBufs& b, uint32_t L, uint32_t kmin, int shift,
-                                               uint32_t (*cnt)[GDR_RADIX], uint32_t* scan_lds,
-                                               uint32_t* bstart = nullptr) {
+// The source is an accessor, kv_at(i) -> (key, value): two arrays, or the packed 64-bit words of the direct tile binning.
+// These passes run on lists that do not fit in LDS — one workgroup, a few dozen iterations per lane, every one a trip to
+// HBM: B elements per lane are loaded before the first is used (C4 `shell`, 22 lists of 16-20 k entries: the long-class
+// launch 175 -> see DESIGN.md §3).
+template <int NW, int B, class KV>
+__device__ __forceinline__ void tile_sort_pass_kv(KV kv_at, uint32_t* kB, uint32_t* vB, uint32_t L,
+                                                  uint32_t kmin, int shift, uint32_t (*cnt)[GDR_RADIX], uint32_t* scan_lds,
+                                                  uint32_t* bstart = nullptr) {
     const uint32_t w = threadIdx.x >> 6, lane = lane_id();
     const uint32_t Lw = ((L + NW * GDR_WAVE - 1) / (NW * GDR_WAVE)) * GDR_WAVE;
     const uint32_t c0 = min(L, w * Lw), c1 = min(L, c0 + Lw);
     for (int k = threadIdx.x; k < NW * GDR_RADIX; k += NW * GDR_WAVE) (&cnt[0][0])[k] = 0;
     __syncthreads();
-    for (uint32_t i = c0 + lane; i < c1; i += GDR_WAVE)
-        atomicAdd(&cnt[w][((b.kA[i] - kmin) >> shift) & (GDR_RADIX - 1)], 1u);
+    for (uint32_t i0 = c0; i0 < c1; i0 += GDR_WAVE * B) {
+        uint32_t k[B];
+#pragma unroll
+        for (int j = 0; j < B; ++j) {
+            const uint32_t i = i0 + (uint32_t)j * GDR_WAVE + lane;
+            k[j] = i < c1 ? kv_at(i).x : 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < B; ++j)
+            if (i0 + (uint32_t)j * GDR_WAVE + lane < c1) atomicAdd(&cnt[w][((k[j] - kmin) >> shift) & (GDR_RADIX - 1)], 1u);
+    }
     __syncthreads();
     {   // the first 256 threads own one digit each: per-wave offsets + exclusive scan of the digit totals
         const uint32_t d = threadIdx.x & (GDR_RADIX - 1);
@@ -481,28 +494,46 @@ __device__ __forceinline__ void tile_sort_pass(const TileSortBufs& b, uint32_t L
         }
     }
     __syncthreads();
-    for (uint32_t i0 = c0; i0 < c1; i0 += GDR_WAVE) {
-        const uint32_t i = i0 + lane;
-        const bool valid = i < c1;
-        const uint32_t key = valid ? b.kA[i] : 0u, val = valid ? b.vA[i] : 0u;
-        const uint32_t d = ((key - kmin) >> shift) & (GDR_RADIX - 1);
-        uint64_t m = __ballot(valid);
+    for (uint32_t i0 = c0; i0 < c1; i0 += GDR_WAVE * B) {
+        uint2 e[B];
 #pragma unroll
-        for (int bit = 0; bit < GDR_RADIX_BITS; ++bit) {
-            const uint64_t bal = __ballot((d >> bit) & 1u);
-            m &= ((d >> bit) & 1u) ? bal : ~bal;
+        for (int j = 0; j < B; ++j) {
+            const uint32_t i = i0 + (uint32_t)j * GDR_WAVE + lane;
+            e[j] = i < c1 ? kv_at(i) : make_uint2(0u, 0u);
         }
-        uint32_t prior = 0;
-        if (valid) prior = cnt[w][d];
-        const uint32_t below = (uint32_t)__popcll(m & lanemask_lt());
-        if (valid) {
-            b.kB[prior + below] = key;
-            b.vB[prior + below] = val;
-            if ((m >> lane) == 1ull) cnt[w][d] = prior + below + 1u;
+#pragma unroll
+        for (int j = 0; j < B; ++j) {
+            if (i0 + (uint32_t)j * GDR_WAVE >= c1) break;   // uniform over the wave
+            const bool valid = i0 + (uint32_t)j * GDR_WAVE + lane < c1;
+            const uint32_t d = ((e[j].x - kmin) >> shift) & (GDR_RADIX - 1);
+            uint64_t m = __ballot(valid);
+#pragma unroll
+            for (int bit = 0; bit < GDR_RADIX_BITS; ++bit) {
+                const uint64_t bal = __ballot((d >> bit) & 1u);
+                m &= ((d >> bit) & 1u) ? bal : ~bal;
+            }
+            uint32_t prior = 0;
+            if (valid) prior = cnt[w][d];
+            const uint32_t below = (uint32_t)__popcll(m & lanemask_lt());
+            if (valid) {
+                kB[prior + below] = e[j].x;
+                vB[prior + below] = e[j].y;
+                if ((m >> lane) == 1ull) cnt[w][d] = prior + below + 1u;
+            }
+            __builtin_amdgcn_wave_barrier();
         }
-        __builtin_amdgcn_wave_barrier();
     }
-    __syncthreads();  // (global-memory variant: also the workgroup-scope release/acquire of the stores)
+    __syncthreads();  // (also the workgroup-scope release/acquire of the global stores)
+}
+
+template <int NW>
+__device__ __forceinline__ void tile_sort_pass(const TileSortBufs& b, uint32_t L, uint32_t kmin, int shift,
+                                               uint32_t (*cnt)[GDR_RADIX], uint32_t* scan_lds,
+                                               uint32_t* bstart = nullptr) {
+    const uint32_t* kA = b.kA;
+    const uint32_t* vA = b.vA;
+    tile_sort_pass_kv<NW, 4>([kA, vA](uint32_t i) { return make_uint2(kA[i], vA[i]); }, b.kB, b.vB, L, kmin, shift, cnt,
+                             scan_lds, bstart);
 }
 
 // The same stable 8-bit pass IN PLACE on an LDS-resident list (kA, vA; kA == vA allowed: ids sorted by themselves):
@@ -709,10 +740,8 @@ __global__ __launch_bounds__(NW * GDR_WAVE) void tile_sort_kernel(const BinViews
             __syncthreads();  // mm / bstart reuse
             uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
             for (uint32_t i = threadIdx.x; i < L; i += NT) {
-                const uint64_t w = keys_part[rg.x + i];
-                const uint32_t k = (uint32_t)w;
-                kA[i] = k;
-                if constexpr (PACKED) vA[i] = (uint32_t)(w >> 32);   // (the values buffer [in] is free in the packed layout)
+                const uint32_t k = (uint32_t)keys_part[rg.x + i];
+                if constexpr (!PACKED) kA[i] = k;   // (packed: the bucket pass below reads the packed words themselves)
                 kmin = min(kmin, k);
                 kmax = max(kmax, k);
             }
@@ -733,10 +762,14 @@ __global__ __launch_bounds__(NW * GDR_WAVE) void tile_sort_kernel(const BinViews
                     for (uint32_t i = threadIdx.x; i < Lc; i += NT) vals_out[o + i] = g.vA[i];
             };
             const int sh1 = nbits > GDR_RADIX_BITS ? nbits - GDR_RADIX_BITS : 0;
-            {
+            if constexpr (PACKED) {   // (kB, vB): 256 ordered buckets
+                const uint64_t* kp = keys_part + rg.x;
+                tile_sort_pass_kv<NW, 4>([kp](uint32_t i) { const uint64_t w = kp[i]; return make_uint2((uint32_t)w, (uint32_t)(w >> 32)); },
+                                         kB, vB, L, kmin, sh1, cnt, misc, bstart);
+            } else {
                 TileSortBufs g;
                 g.kA = kA; g.vA = vA; g.kB = kB; g.vB = vB;
-                tile_sort_pass<NW>(g, L, kmin, sh1, cnt, misc, bstart);  // (kB, vB): 256 ordered buckets
+                tile_sort_pass<NW>(g, L, kmin, sh1, cnt, misc, bstart);
             }
             uint32_t d0 = 0;
             while (d0 < GDR_RADIX) {  // uniform over the workgroup: bstart is read-only from here on

@@ -308,7 +308,6 @@ __global__ __launch_bounds__(GDR_BLOCK) void render_fwd_kernel(
     const uint32_t sb = (seg_rounds > 0 && full_rounds > seg_rounds) ? seg_base[tile] : 0xFFFFFFFFu;
     const bool cut = sb != 0xFFFFFFFFu;
     if (cut && deep_flag && *deep_flag) return;  // rendered by render_fwd_deep_kernel (launched in front of this one)
-    const int seg_len = seg_rounds * GDR_BLOCK;
     const int nseg = cut ? (full_rounds + seg_rounds - 1) / seg_rounds : 1;
 
     // a pixel contributes while alpha >= thr; thr = +inf once it is saturated ("done") or outside
@@ -316,107 +315,99 @@ __global__ __launch_bounds__(GDR_BLOCK) void render_fwd_kernel(
     float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f, Wt = 0.f;
     uint32_t last_contributor = 0;
 
-    // composites list positions [pos0, pos0 + count) of the tile; returns true once every pixel of the tile is done
-    auto walk = [&](int pos0, int count) __attribute__((always_inline)) -> bool {
-        const uint32_t first = range.x + (uint32_t)pos0;
-        const int rounds = (count + GDR_BLOCK - 1) / GDR_BLOCK;
-        float4 r_xe = make_float4(0.f, 0.f, 0.f, 0.f), r_co = r_xe, r_cd = r_xe;
-        bool r_valid = (int)threadIdx.x < count;
-        if (r_valid) {
-            const uint32_t id = point_list[first + threadIdx.x];
-            const float4 a0 = rec[4 * (size_t)id], a3 = rec[4 * (size_t)id + 3];
-            r_xe = make_float4(a0.x, a0.y, a3.x, a3.y); r_co = rec[4 * (size_t)id + 1]; r_cd = rec[4 * (size_t)id + 2];
-        }
-        for (int r = 0; r < rounds; ++r) {
-            uint64_t live = __ballot(thr < INFINITY);
-            if (lane == 0) s_done[wave] = live == 0ull ? 1 : 0;
-            __syncthreads();
-            if (s_done[0] + s_done[1] + s_done[2] + s_done[3] == GDR_BLOCK / GDR_WAVE) return true;
-            stage_write(lds, r_valid, r_xe, r_co, r_cd);
-            __syncthreads();
-            {   // prefetch the next slice (lands while this one is composited)
-                const int nxt = (r + 1) * GDR_BLOCK + (int)threadIdx.x;
-                r_valid = nxt < count;
-                if (r_valid) {
-                    const uint32_t id = point_list[first + (uint32_t)nxt];
-                    const float4 a0 = rec[4 * (size_t)id], a3 = rec[4 * (size_t)id + 3];
-                    r_xe = make_float4(a0.x, a0.y, a3.x, a3.y); r_co = rec[4 * (size_t)id + 1]; r_cd = rec[4 * (size_t)id + 2];
-                }
-            }
-            if (live == 0ull) continue;
-            const uint32_t base = (uint32_t)(pos0 + r * GDR_BLOCK) + 1u;
-            // this wave's row lists of the slice (compacted, see RowLists)
-            int n[4] = {0, 0, 0, 0};
-            row_lists_clear(rlists, wave);
-            wave_lds_fence();
-#pragma unroll 1
-            for (int g = 0; g < GDR_BLOCK / GDR_WAVE; ++g) {
-                uint64_t m0, m1, m2, m3;
-                block_masks(lds, g, XA, YA, (live & GDR_ROW_MASK(0)) != 0ull, (live & GDR_ROW_MASK(1)) != 0ull,
-                            (live & GDR_ROW_MASK(2)) != 0ull, (live & GDR_ROW_MASK(3)) != 0ull, m0, m1, m2, m3);
-                row_lists_append(rlists, wave, g, m0, m1, m2, m3, n);
-            }
-            const int nmax = max(max(n[0], n[1]), max(n[2], n[3]));
-            if (nmax == 0) continue;
-            wave_lds_fence();
-            const uint16_t* my_list = &rlists.idx[wave][row][0];
-            bool abort = false;
-            auto fetch = [&](Entry& en, uint32_t e) __attribute__((always_inline)) {
-                en.e = e;
-                en.m = lds.xy[e]; en.co = lds.co[e]; en.cd = lds.cd[e];
-            };
-            auto composite = [&](const Entry& en) __attribute__((always_inline)) {
-                const float dx = en.m.x - pxf, dy = en.m.y - pyf;
-                const float p2 = gauss_power(dx, dy, en.co.x, en.co.y, en.co.z);
-                float alpha = fminf(0.99f, en.co.w * __builtin_amdgcn_exp2f(p2));
-                alpha = (p2 > 0.f) ? 0.f : alpha;        // reference skips power > 0
-                const float a_c = (alpha >= thr) ? alpha : 0.f;
-                const float T_new = fmaf(-a_c, T, T);     // T (1 - alpha); == T when a_c == 0
-                const bool stop = T_new < 0.0001f;        // only possible when a_c > 0 (T >= 1e-4 while live)
-                const float w = stop ? 0.f : a_c * T;
-                T = stop ? T : T_new;
-                thr = stop ? INFINITY : thr;
-                C0 = fmaf(en.cd.x, w, C0);
-                C1 = fmaf(en.cd.y, w, C1);
-                C2 = fmaf(en.cd.z, w, C2);
-                Dp = fmaf(en.cd.w, w, Dp);
-                Wt += w;
-                last_contributor = (w > 0.f) ? base + en.e : last_contributor;
-                if (__ballot(stop) != 0ull) {  // rare: some pixel saturated
-                    live = __ballot(thr < INFINITY);
-                    if (live == 0ull) abort = true;
-                }
-            };
-            // four list positions per 8-byte LDS read; entry k+1 is fetched while entry k is composited
-            Entry A, B;
-            uint2 q = *reinterpret_cast<const uint2*>(my_list);
-            fetch(A, q.x & 0xFFFFu);
-            for (int i = 0; i < nmax && !abort; i += 4) {
-                const uint2 qn = *reinterpret_cast<const uint2*>(my_list + min(i + 4, GDR_BLOCK - 4));
-                fetch(B, q.x >> 16);    // (read-ahead clamped to this row's own list: the last read repeats entries 252..255,
-                composite(A);           //  which are never composited)
-                fetch(A, q.y & 0xFFFFu);
-                composite(B);
-                fetch(B, q.y >> 16);
-                composite(A);
-                fetch(A, qn.x & 0xFFFFu);
-                composite(B);
-                q = qn;
-            }
-            if (abort) continue;
-        }
-        return false;
+    // One loop over the 256-entry rounds of the whole list.  The gather of a slice is two dependent trips to memory
+    // (sorted id -> 64-byte record): the ids are fetched TWO rounds ahead and the records one round ahead, so that neither
+    // is waited for at the top of a round.  (Until round 3 the list was walked segment by segment, each walk with its own
+    // cold gather — with seg_len = 256 that was every round.)
+    auto load_rec = [&](uint32_t id, float4& xe, float4& co, float4& cd) __attribute__((always_inline)) {
+        const float4 a0 = rec[4 * (size_t)id], a3 = rec[4 * (size_t)id + 3];
+        xe = make_float4(a0.x, a0.y, a3.x, a3.y); co = rec[4 * (size_t)id + 1]; cd = rec[4 * (size_t)id + 2];
     };
-
-    for (int sg = 0; sg < nseg; ++sg) {
-        const int pos0 = sg * seg_len;  // (uncut list: one "segment" = the whole list, seg_len unused)
-        const int count = cut ? min(seg_len, full_total - pos0) : full_total;
-        if (cut && sg > 0) {  // cut in front of list position pos0: the state K7 starts the earlier segments from
-            float* st = seg_state + ((size_t)sb + (size_t)(sg - 1)) * GDR_SEG_STATE_FLOATS + threadIdx.x;
+    float4 r_xe = make_float4(0.f, 0.f, 0.f, 0.f), r_co = r_xe, r_cd = r_xe;
+    bool r_valid = (int)threadIdx.x < full_total;
+    if (r_valid) load_rec(point_list[range.x + threadIdx.x], r_xe, r_co, r_cd);
+    bool n_valid = GDR_BLOCK + (int)threadIdx.x < full_total;
+    uint32_t n_id = n_valid ? point_list[range.x + (uint32_t)GDR_BLOCK + threadIdx.x] : 0u;
+    for (int r = 0; r < full_rounds; ++r) {
+        const int pos0 = r * GDR_BLOCK;
+        if (cut && r > 0 && r % seg_rounds == 0) {  // cut in front of list position pos0: the state K7 starts the earlier segments from
+            float* st = seg_state + ((size_t)sb + (size_t)(r / seg_rounds - 1)) * GDR_SEG_STATE_FLOATS + threadIdx.x;
             st[0] = T; st[GDR_BLOCK] = C0; st[2 * GDR_BLOCK] = C1; st[3 * GDR_BLOCK] = C2;
             st[4 * GDR_BLOCK] = Dp; st[5 * GDR_BLOCK] = Wt;
         }
-        if (walk(pos0, count)) break;
+        uint64_t live = __ballot(thr < INFINITY);
+        if (lane == 0) s_done[wave] = live == 0ull ? 1 : 0;
+        __syncthreads();
+        if (s_done[0] + s_done[1] + s_done[2] + s_done[3] == GDR_BLOCK / GDR_WAVE) break;   // every pixel of the tile is done
+        stage_write(lds, r_valid, r_xe, r_co, r_cd);
+        __syncthreads();
+        {   // records of the next slice (their ids arrived a round ago), ids of the one after
+            r_valid = n_valid;
+            if (r_valid) load_rec(n_id, r_xe, r_co, r_cd);
+            const int nn = (r + 2) * GDR_BLOCK + (int)threadIdx.x;
+            n_valid = nn < full_total;
+            if (n_valid) n_id = point_list[range.x + (uint32_t)nn];
+        }
+        if (live == 0ull) continue;
+        const uint32_t base = (uint32_t)pos0 + 1u;
+        // this wave's row lists of the slice (compacted, see RowLists)
+        int n[4] = {0, 0, 0, 0};
+        row_lists_clear(rlists, wave);
+        wave_lds_fence();
+#pragma unroll 1
+        for (int g = 0; g < GDR_BLOCK / GDR_WAVE; ++g) {
+            uint64_t m0, m1, m2, m3;
+            block_masks(lds, g, XA, YA, (live & GDR_ROW_MASK(0)) != 0ull, (live & GDR_ROW_MASK(1)) != 0ull,
+                        (live & GDR_ROW_MASK(2)) != 0ull, (live & GDR_ROW_MASK(3)) != 0ull, m0, m1, m2, m3);
+            row_lists_append(rlists, wave, g, m0, m1, m2, m3, n);
+        }
+        const int nmax = max(max(n[0], n[1]), max(n[2], n[3]));
+        if (nmax == 0) continue;
+        wave_lds_fence();
+        const uint16_t* my_list = &rlists.idx[wave][row][0];
+        bool abort = false;
+        auto fetch = [&](Entry& en, uint32_t e) __attribute__((always_inline)) {
+            en.e = e;
+            en.m = lds.xy[e]; en.co = lds.co[e]; en.cd = lds.cd[e];
+        };
+        auto composite = [&](const Entry& en) __attribute__((always_inline)) {
+            const float dx = en.m.x - pxf, dy = en.m.y - pyf;
+            const float p2 = gauss_power(dx, dy, en.co.x, en.co.y, en.co.z);
+            float alpha = fminf(0.99f, en.co.w * __builtin_amdgcn_exp2f(p2));
+            alpha = (p2 > 0.f) ? 0.f : alpha;        // reference skips power > 0
+            const float a_c = (alpha >= thr) ? alpha : 0.f;
+            const float T_new = fmaf(-a_c, T, T);     // T (1 - alpha); == T when a_c == 0
+            const bool stop = T_new < 0.0001f;        // only possible when a_c > 0 (T >= 1e-4 while live)
+            const float w = stop ? 0.f : a_c * T;
+            T = stop ? T : T_new;
+            thr = stop ? INFINITY : thr;
+            C0 = fmaf(en.cd.x, w, C0);
+            C1 = fmaf(en.cd.y, w, C1);
+            C2 = fmaf(en.cd.z, w, C2);
+            Dp = fmaf(en.cd.w, w, Dp);
+            Wt += w;
+            last_contributor = (w > 0.f) ? base + en.e : last_contributor;
+            if (__ballot(stop) != 0ull) {  // rare: some pixel saturated
+                live = __ballot(thr < INFINITY);
+                if (live == 0ull) abort = true;
+            }
+        };
+        // four list positions per 8-byte LDS read; entry k+1 is fetched while entry k is composited
+        Entry A, B;
+        uint2 q = *reinterpret_cast<const uint2*>(my_list);
+        fetch(A, q.x & 0xFFFFu);
+        for (int i = 0; i < nmax && !abort; i += 4) {
+            const uint2 qn = *reinterpret_cast<const uint2*>(my_list + min(i + 4, GDR_BLOCK - 4));
+            fetch(B, q.x >> 16);    // (read-ahead clamped to this row's own list: the last read repeats entries 252..255,
+            composite(A);           //  which are never composited)
+            fetch(A, q.y & 0xFFFFu);
+            composite(B);
+            fetch(B, q.y >> 16);
+            composite(A);
+            fetch(A, qn.x & 0xFFFFu);
+            composite(B);
+            q = qn;
+        }
     }
     if (cut) {  // totals of the cut list (K7 forms "everything behind a cut" = totals - prefix)
         float* st = seg_state + ((size_t)sb + (size_t)(nseg - 1)) * GDR_SEG_STATE_FLOATS + threadIdx.x;
@@ -499,7 +490,6 @@ __global__ __launch_bounds__(GDR_BLOCK) void render_fwd_deep_kernel(
     const int full_rounds = (full_total + GDR_BLOCK - 1) / GDR_BLOCK;
     const uint32_t sb = (seg_rounds > 0 && full_rounds > seg_rounds) ? seg_base[tile] : 0xFFFFFFFFu;
     if (sb == 0xFFFFFFFFu) return;   // not a cut tile: the standard kernel renders it
-    const int seg_len = seg_rounds * GDR_BLOCK;
     const int nseg = (full_rounds + seg_rounds - 1) / seg_rounds;
 
     const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
@@ -536,113 +526,103 @@ __global__ __launch_bounds__(GDR_BLOCK) void render_fwd_deep_kernel(
         }
     };
 
-    auto walk = [&](int pos0, int count) __attribute__((always_inline)) -> bool {
-        const uint32_t first = range.x + (uint32_t)pos0;
-        const int rounds = (count + GDR_BLOCK - 1) / GDR_BLOCK;
-        float4 r_xe = make_float4(0.f, 0.f, 0.f, 0.f), r_co = r_xe, r_cd = r_xe;
-        bool r_valid = (int)threadIdx.x < count;
-        if (r_valid) {
-            const uint32_t id = point_list[first + threadIdx.x];
-            const float4 a0 = rec[4 * (size_t)id], a3 = rec[4 * (size_t)id + 3];
-            r_xe = make_float4(a0.x, a0.y, a3.x, a3.y); r_co = rec[4 * (size_t)id + 1]; r_cd = rec[4 * (size_t)id + 2];
-        }
-        for (int r = 0; r < rounds; ++r) {
-            uint64_t live = __ballot(thr < INFINITY);
-            if (lane == 0) s_done[wave] = live == 0ull ? 1 : 0;
-            __syncthreads();
-            if (s_done[0] + s_done[1] + s_done[2] + s_done[3] == GDR_BLOCK / GDR_WAVE) return true;
-            stage_write(lds, r_valid, r_xe, r_co, r_cd);
-            __syncthreads();
-            {   // prefetch the next slice
-                const int nxt = (r + 1) * GDR_BLOCK + (int)threadIdx.x;
-                r_valid = nxt < count;
-                if (r_valid) {
-                    const uint32_t id = point_list[first + (uint32_t)nxt];
-                    const float4 a0 = rec[4 * (size_t)id], a3 = rec[4 * (size_t)id + 3];
-                    r_xe = make_float4(a0.x, a0.y, a3.x, a3.y); r_co = rec[4 * (size_t)id + 1]; r_cd = rec[4 * (size_t)id + 2];
-                }
-            }
-            if (live == 0ull) continue;
-            // the block's sub-list of this slice, compacted in list order into clist[wave]
-            int n = 0;
-#pragma unroll
-            for (int g = 0; g < GDR_BLOCK / GDR_WAVE; ++g) {
-                const float2 m = lds.xy[g * GDR_WAVE + (int)lane];
-                const float2 hh = lds.ext[g * GDR_WAVE + (int)lane];
-                const bool ov = hh.x >= 0.f && m.x + hh.x >= BX && m.x - hh.x <= BX + 3.f && m.y + hh.y >= BY &&
-                                m.y - hh.y <= BY + 3.f;
-                const uint64_t mk = __ballot(ov);
-                const int below = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
-                if (ov) clist[wave][n + below] = (uint16_t)(g * GDR_WAVE + (int)lane);
-                n += __popcll(mk);
-            }
-            if (n == 0) continue;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // clist is wave-private: LDS order within the wave
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            const uint32_t base = (uint32_t)(pos0 + r * GDR_BLOCK) + 1u;
-            auto fetch = [&](int i, Entry& en) __attribute__((always_inline)) {
-                const int idx = i + (int)j;
-                en.e = idx < n ? (uint32_t)clist[wave][idx] : (uint32_t)GDR_NULL_ENTRY;
-                en.m = lds.xy[en.e]; en.co = lds.co[en.e]; en.cd = lds.cd[en.e];
-            };
-            Entry cur, nxt;
-            fetch(0, cur);
-            bool all_done = false;
-            for (int i = 0; i < n && !all_done; i += 4) {
-                if (i + 4 < n) fetch(i + 4, nxt);
-                const float dx = cur.m.x - pxf, dy = cur.m.y - pyf;
-                const float p2 = gauss_power(dx, dy, cur.co.x, cur.co.y, cur.co.z);
-                float alpha = fminf(0.99f, cur.co.w * __builtin_amdgcn_exp2f(p2));
-                alpha = (p2 > 0.f) ? 0.f : alpha;         // (null entry: opacity 0 -> alpha 0)
-                float a_c = (alpha >= thr) ? alpha : 0.f;
-                // transmittance in front of this lane's entry: chain through the quad, T_{j+1} = fma(-a_j, T_j, T_j)
-                float Tj = T;
-                float u = fmaf(-a_c, Tj, Tj);
-                float x = dpp_get<0x90, 0xf>(u);          // quad_perm [0,0,1,2]: lane j reads lane j - 1
-                Tj = j >= 1u ? x : Tj;
-                u = fmaf(-a_c, Tj, Tj); x = dpp_get<0x90, 0xf>(u); Tj = j >= 2u ? x : Tj;
-                u = fmaf(-a_c, Tj, Tj); x = dpp_get<0x90, 0xf>(u); Tj = j >= 3u ? x : Tj;
-                u = fmaf(-a_c, Tj, Tj);                   // transmittance behind this lane's entry
-                float w;
-                if (__ballot(u < 0.0001f) == 0ull) {      // nobody saturates in this iteration (the common case)
-                    w = a_c * Tj;
-                    T = dpp_get<0xFF, 0xf>(u);            // quad_perm [3,3,3,3]: behind the fourth entry
-                } else {
-                    // sequential replay of the four entries, exactly the standard kernel's per-entry step
-                    float Tq = T, thr_q = thr;
-                    w = 0.f;
-#pragma unroll
-                    for (uint32_t k = 0; k < 4u; ++k) {
-                        const float ak = (alpha >= thr_q) ? alpha : 0.f;
-                        const float Tn = fmaf(-ak, Tq, Tq);
-                        const bool stop = Tn < 0.0001f;
-                        const float wk = stop ? 0.f : ak * Tq;
-                        const float Ta = stop ? Tq : Tn, tha = stop ? INFINITY : thr_q;
-                        w = j == k ? wk : w;
-                        Tq = k == 0u ? dpp_get<0x00, 0xf>(Ta) : (k == 1u ? dpp_get<0x55, 0xf>(Ta) : (k == 2u ? dpp_get<0xAA, 0xf>(Ta) : dpp_get<0xFF, 0xf>(Ta)));
-                        thr_q = k == 0u ? dpp_get<0x00, 0xf>(tha) : (k == 1u ? dpp_get<0x55, 0xf>(tha) : (k == 2u ? dpp_get<0xAA, 0xf>(tha) : dpp_get<0xFF, 0xf>(tha)));
-                    }
-                    T = Tq; thr = thr_q;
-                    all_done = __ballot(thr < INFINITY) == 0ull;
-                }
-                C0 = fmaf(cur.cd.x, w, C0);
-                C1 = fmaf(cur.cd.y, w, C1);
-                C2 = fmaf(cur.cd.z, w, C2);
-                Dp = fmaf(cur.cd.w, w, Dp);
-                Wt += w;
-                last_contributor = (w > 0.f) ? base + cur.e : last_contributor;
-                cur = nxt;
-            }
-        }
-        return false;
+    // one loop over the rounds of the whole list, ids two rounds and records one round ahead (see render_fwd_kernel)
+    auto load_rec = [&](uint32_t id, float4& xe, float4& co, float4& cd) __attribute__((always_inline)) {
+        const float4 a0 = rec[4 * (size_t)id], a3 = rec[4 * (size_t)id + 3];
+        xe = make_float4(a0.x, a0.y, a3.x, a3.y); co = rec[4 * (size_t)id + 1]; cd = rec[4 * (size_t)id + 2];
     };
-
-    for (int sg = 0; sg < nseg; ++sg) {
-        const int pos0 = sg * seg_len;
-        const int count = min(seg_len, full_total - pos0);
-        if (sg > 0) save_state(sg - 1);
-        if (walk(pos0, count)) break;
+    float4 r_xe = make_float4(0.f, 0.f, 0.f, 0.f), r_co = r_xe, r_cd = r_xe;
+    bool r_valid = (int)threadIdx.x < full_total;
+    if (r_valid) load_rec(point_list[range.x + threadIdx.x], r_xe, r_co, r_cd);
+    bool n_valid = GDR_BLOCK + (int)threadIdx.x < full_total;
+    uint32_t n_id = n_valid ? point_list[range.x + (uint32_t)GDR_BLOCK + threadIdx.x] : 0u;
+    for (int r = 0; r < full_rounds; ++r) {
+        if (r > 0 && r % seg_rounds == 0) save_state(r / seg_rounds - 1);   // a cut in front of this round
+        uint64_t live = __ballot(thr < INFINITY);
+        if (lane == 0) s_done[wave] = live == 0ull ? 1 : 0;
+        __syncthreads();
+        if (s_done[0] + s_done[1] + s_done[2] + s_done[3] == GDR_BLOCK / GDR_WAVE) break;
+        stage_write(lds, r_valid, r_xe, r_co, r_cd);
+        __syncthreads();
+        {
+            r_valid = n_valid;
+            if (r_valid) load_rec(n_id, r_xe, r_co, r_cd);
+            const int nn = (r + 2) * GDR_BLOCK + (int)threadIdx.x;
+            n_valid = nn < full_total;
+            if (n_valid) n_id = point_list[range.x + (uint32_t)nn];
+        }
+        if (live == 0ull) continue;
+        // the block's sub-list of this slice, compacted in list order into clist[wave]
+        int n = 0;
+#pragma unroll
+        for (int g = 0; g < GDR_BLOCK / GDR_WAVE; ++g) {
+            const float2 m = lds.xy[g * GDR_WAVE + (int)lane];
+            const float2 hh = lds.ext[g * GDR_WAVE + (int)lane];
+            const bool ov = hh.x >= 0.f && m.x + hh.x >= BX && m.x - hh.x <= BX + 3.f && m.y + hh.y >= BY &&
+                            m.y - hh.y <= BY + 3.f;
+            const uint64_t mk = __ballot(ov);
+            const int below = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
+            if (ov) clist[wave][n + below] = (uint16_t)(g * GDR_WAVE + (int)lane);
+            n += __popcll(mk);
+        }
+        if (n == 0) continue;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // clist is wave-private: LDS order within the wave
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const uint32_t base = (uint32_t)(r * GDR_BLOCK) + 1u;
+        auto fetch = [&](int i, Entry& en) __attribute__((always_inline)) {
+            const int idx = i + (int)j;
+            en.e = idx < n ? (uint32_t)clist[wave][idx] : (uint32_t)GDR_NULL_ENTRY;
+            en.m = lds.xy[en.e]; en.co = lds.co[en.e]; en.cd = lds.cd[en.e];
+        };
+        Entry cur, nxt;
+        fetch(0, cur);
+        bool all_done = false;
+        for (int i = 0; i < n && !all_done; i += 4) {
+            if (i + 4 < n) fetch(i + 4, nxt);
+            const float dx = cur.m.x - pxf, dy = cur.m.y - pyf;
+            const float p2 = gauss_power(dx, dy, cur.co.x, cur.co.y, cur.co.z);
+            float alpha = fminf(0.99f, cur.co.w * __builtin_amdgcn_exp2f(p2));
+            alpha = (p2 > 0.f) ? 0.f : alpha;         // (null entry: opacity 0 -> alpha 0)
+            float a_c = (alpha >= thr) ? alpha : 0.f;
+            // transmittance in front of this lane's entry: chain through the quad, T_{j+1} = fma(-a_j, T_j, T_j)
+            float Tj = T;
+            float u = fmaf(-a_c, Tj, Tj);
+            float x = dpp_get<0x90, 0xf>(u);          // quad_perm [0,0,1,2]: lane j reads lane j - 1
+            Tj = j >= 1u ? x : Tj;
+            u = fmaf(-a_c, Tj, Tj); x = dpp_get<0x90, 0xf>(u); Tj = j >= 2u ? x : Tj;
+            u = fmaf(-a_c, Tj, Tj); x = dpp_get<0x90, 0xf>(u); Tj = j >= 3u ? x : Tj;
+            u = fmaf(-a_c, Tj, Tj);                   // transmittance behind this lane's entry
+            float w;
+            if (__ballot(u < 0.0001f) == 0ull) {      // nobody saturates in this iteration (the common case)
+                w = a_c * Tj;
+                T = dpp_get<0xFF, 0xf>(u);            // quad_perm [3,3,3,3]: behind the fourth entry
+            } else {
+                // sequential replay of the four entries, exactly the standard kernel's per-entry step
+                float Tq = T, thr_q = thr;
+                w = 0.f;
+#pragma unroll
+                for (uint32_t k = 0; k < 4u; ++k) {
+                    const float ak = (alpha >= thr_q) ? alpha : 0.f;
+                    const float Tn = fmaf(-ak, Tq, Tq);
+                    const bool stop = Tn < 0.0001f;
+                    const float wk = stop ? 0.f : ak * Tq;
+                    const float Ta = stop ? Tq : Tn, tha = stop ? INFINITY : thr_q;
+                    w = j == k ? wk : w;
+                    Tq = k == 0u ? dpp_get<0x00, 0xf>(Ta) : (k == 1u ? dpp_get<0x55, 0xf>(Ta) : (k == 2u ? dpp_get<0xAA, 0xf>(Ta) : dpp_get<0xFF, 0xf>(Ta)));
+                    thr_q = k == 0u ? dpp_get<0x00, 0xf>(tha) : (k == 1u ? dpp_get<0x55, 0xf>(tha) : (k == 2u ? dpp_get<0xAA, 0xf>(tha) : dpp_get<0xFF, 0xf>(tha)));
+                }
+                T = Tq; thr = thr_q;
+                all_done = __ballot(thr < INFINITY) == 0ull;
+            }
+            C0 = fmaf(cur.cd.x, w, C0);
+            C1 = fmaf(cur.cd.y, w, C1);
+            C2 = fmaf(cur.cd.z, w, C2);
+            Dp = fmaf(cur.cd.w, w, Dp);
+            Wt += w;
+            last_contributor = (w > 0.f) ? base + cur.e : last_contributor;
+            cur = nxt;
+        }
     }
     save_state(nseg - 1);
     {

@@ -8,7 +8,7 @@ from generativedensification_amd.camera import orbit_cameras
 from generativedensification_amd.synthetic import make_scene
 import diff_gaussian_rasterization as D
 dev = torch.device("cuda:0")
-N, h, w = 50_000, 256, 256
+N, h, w = int(os.environ.get("HP_N", 50_000)), 256, 256
 sc = {k: v.requires_grad_(True) for k, v in make_scene(N, 1, sh_degree=1, sigma0=(0.0052,), device=dev).items()}
 cams = orbit_cameras(4, w, h, device=dev)
 sets = [R.GaussianRasterizationSettings(h, w, math.tan(.375), math.tan(.375), torch.ones(3, device=dev), 1.0, c.world_view_transform,
@@ -32,4 +32,7 @@ pr = cProfile.Profile(); pr.enable()
 for _ in range(20): step()
 torch.cuda.synchronize()
 pr.disable()
-pstats.Stats(pr).sort_stats("tottime").print_stats(28)
+st = pstats.Stats(pr)
+st.sort_stats("tottime").print_stats(45)
+st.sort_stats("cumtime").print_stats(40)
+st.print_callees("forward_raw")
