@@ -112,6 +112,8 @@ _PROTOS = {
     "gdr_binning_carve_for": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int32, C.c_int32, C.c_int32, C.POINTER(GdrBinning)]),
     "gdr_build_tag": (C.c_char_p, []),
     "gdr_words_differ": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
+    "gdr_host_copy_begin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "gdr_host_copy_wait": (C.c_int, [C.c_void_p]),
     "gdr_image_carve": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(GdrImage)]),
     "gdr_preprocess_forward": (C.c_int, [C.POINTER(GdrSettings), C.POINTER(GdrInputs), C.POINTER(GdrGeom),
                                          C.c_void_p, C.POINTER(C.c_uint32), C.c_void_p]),
@@ -213,7 +215,7 @@ def load():
             fn = getattr(lib, name)  # AttributeError if the symbol is missing
             fn.restype = res
             fn.argtypes = args
-        if lib.gdr_abi_version() != 12:
+        if lib.gdr_abi_version() != 13:
             raise RuntimeError("libgdr_hip.so ABI version mismatch")
         tag = (lib.gdr_build_tag() or b"").decode()
         if tag != "release" and os.environ.get("GDR_ALLOW_EXPERIMENTAL_LIB") != "1":

@@ -366,6 +366,52 @@ int gdr_words_differ(const void* a, const void* b, uint64_t n_bytes, uint32_t* f
     return GDR_OK;
 }
 
+// ---- host-boundary helper: a small device -> pinned-host copy with its own pooled event (the duplicate count of a call) ----
+namespace {
+struct HostCopyTicket { hipEvent_t ev; int dev; };
+std::mutex g_ticket_mu;
+std::vector<HostCopyTicket*> g_ticket_pool;
+}  // namespace
+
+int gdr_host_copy_begin(void* dst_pinned, const void* src_dev, uint64_t n_bytes, void* stream, void** ticket) {
+    if (!dst_pinned || !src_dev || !ticket || n_bytes == 0) { set_error("host_copy_begin: NULL argument", hipSuccess); return GDR_ERR_INVALID_ARG; }
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return hip_fail("host_copy_begin: hipGetDevice", e);
+    HostCopyTicket* t = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_ticket_mu);
+        for (size_t k = 0; k < g_ticket_pool.size(); ++k)
+            if (g_ticket_pool[k]->dev == dev) { t = g_ticket_pool[k]; g_ticket_pool[k] = g_ticket_pool.back(); g_ticket_pool.pop_back(); break; }
+    }
+    if (!t) {
+        t = new HostCopyTicket{nullptr, dev};
+        e = hipEventCreateWithFlags(&t->ev, hipEventDisableTiming);
+        if (e != hipSuccess) { delete t; return hip_fail("host_copy_begin: hipEventCreate", e); }
+    }
+    e = hipMemcpyAsync(dst_pinned, src_dev, n_bytes, hipMemcpyDeviceToHost, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipEventRecord(t->ev, (hipStream_t)stream);
+    if (e != hipSuccess) {
+        std::lock_guard<std::mutex> lk(g_ticket_mu);
+        g_ticket_pool.push_back(t);
+        return hip_fail("host_copy_begin", e);
+    }
+    *ticket = t;
+    return GDR_OK;
+}
+
+int gdr_host_copy_wait(void* ticket) {
+    if (!ticket) { set_error("host_copy_wait: NULL ticket", hipSuccess); return GDR_ERR_INVALID_ARG; }
+    HostCopyTicket* t = (HostCopyTicket*)ticket;
+    const hipError_t e = hipEventSynchronize(t->ev);
+    {
+        std::lock_guard<std::mutex> lk(g_ticket_mu);
+        g_ticket_pool.push_back(t);
+    }
+    if (e != hipSuccess) return hip_fail("host_copy_wait", e);
+    return GDR_OK;
+}
+
 size_t gdr_topk_workspace_bytes(void) { return select_workspace_bytes(); }
 
 int gdr_topk_absgrad(int32_t N, const float* grad, const uint8_t* candidates, int32_t k, void* workspace, uint8_t* mask,

@@ -209,8 +209,11 @@ def _view_streams(dev, n):
         return pool[:n]
 
 
+_raw_stream = torch._C._cuda_getCurrentRawStream   # (torch.cuda.current_stream() builds a Stream object: 9 us per call)
+
+
 def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return C.c_void_p(_raw_stream(torch.cuda.current_device()))
 
 
 class _SideViews:
@@ -540,30 +543,45 @@ def _d_record(key, d_host, N):
 class _CountReadback:
     """The V duplicate counters on their way to pinned host memory, behind K1, on `stream` (default: the caller's).
     A multi-view node puts the copy in front of its last forward chain (that stream waits for K1 anyway) instead of in
-    front of the caller's: same-box A/B C2 +1.2 %, C3 +0.9 %, C4 +0.5 %."""
+    front of the caller's: same-box A/B C2 +1.2 %, C3 +0.9 %, C4 +0.5 %.
+    The copy and its event are two calls into the library (gdr_host_copy_begin / _wait, pooled events) into a pooled pinned
+    buffer: a pinned tensor + copy_ + torch.cuda.Event per call cost 21 us of host time (scripts/host_split2.py)."""
+    _pool: dict = {}     # numel -> [pinned int32 tensors not in flight]
 
     def __init__(self, counters, stream=None):
-        self.counters = counters
-        try:
-            self.host = torch.empty(counters.shape, dtype=counters.dtype, pin_memory=True)
-        except RuntimeError:    # no page-locked memory: a blocking copy when the counts are needed
-            self.host = None
-            return
-        if stream is None:      # (the caller's stream: no stream context to enter and leave — 30 us of Python per call)
-            self.host.copy_(counters, non_blocking=True)
-            self.event = torch.cuda.Event()
-            self.event.record()
-            return
-        with torch.cuda.stream(stream):
-            self.host.copy_(counters, non_blocking=True)
-            self.event = torch.cuda.Event()
-            self.event.record()
+        self.counters, self.ticket = counters, None
+        n = counters.numel()
+        with _HIST_LOCK:
+            free = self._pool.get(n)
+            self.host = free.pop() if free else None
+        if self.host is None:
+            try:
+                self.host = torch.empty(n, dtype=torch.int32, pin_memory=True)
+            except RuntimeError:    # no page-locked memory: a blocking copy when the counts are needed
+                return
+        raw = stream.cuda_stream if stream is not None else _raw_stream(counters.device.index)
+        ticket = C.c_void_p()
+        L.check(L.load().gdr_host_copy_begin(self.host.data_ptr(), counters.data_ptr(), 4 * n, C.c_void_p(raw),
+                                             C.byref(ticket)), "gdr_host_copy_begin")
+        self.ticket = ticket
 
     def wait(self):
         if self.host is None:
             return [int(d) & 0xFFFFFFFF for d in self.counters.cpu().tolist()]
-        self.event.synchronize()
-        return [int(d) & 0xFFFFFFFF for d in self.host.tolist()]
+        ticket, self.ticket = self.ticket, None
+        L.check(L.load().gdr_host_copy_wait(ticket), "gdr_host_copy_wait")
+        vals = [int(d) & 0xFFFFFFFF for d in self.host.tolist()]
+        with _HIST_LOCK:
+            self._pool.setdefault(self.host.numel(), []).append(self.host)
+        self.host = None
+        return vals
+
+    def __del__(self):   # never waited for (an exception in between): the ticket and the buffer go back once the copy is done
+        if getattr(self, "ticket", None) is not None:
+            try:
+                L.load().gdr_host_copy_wait(self.ticket)
+            except Exception:
+                pass
 
 
 # ---- launch-size feedback (gdr_binning.stats_out / hint_*) ----------------------------------------------------

@@ -23,7 +23,8 @@
  *   - matrices are 16 contiguous floats in the reference's row-vector convention
  *     (/root/reference/lightning/utils.py:37-47): p_view = [p,1] @ viewmatrix;
  *   - the caller owns every buffer; the library allocates no device memory and keeps no
- *     state (except the opt-in timing facility at the end of this header) => re-entrant,
+ *     state (except the opt-in timing facility at the end of this header and the pooled events of
+ *     gdr_host_copy_begin / _wait) => re-entrant,
  *     thread-safe for distinct workspaces, one call per stream;
  *   - all work is enqueued on `stream`; the only host synchronisation is the
  *     optional read-back of num_rendered in gdr_preprocess_forward;
@@ -39,7 +40,7 @@
 extern "C" {
 #endif
 
-#define GDR_ABI_VERSION 12
+#define GDR_ABI_VERSION 13
 
 #define GDR_OK 0
 #define GDR_ERR_INVALID_ARG (-1)  /* NULL / inconsistent arguments                     */
@@ -382,6 +383,14 @@ int gdr_view_loss_backward(const float* color, const float* target, int32_t H, i
  * 32-bit word.  Used by the Python boundary to verify that two calls of one render group were handed the same activated
  * tensors (see generativedensification_amd/viewgroup.py); one read of both buffers, no host synchronisation. */
 int gdr_words_differ(const void* a, const void* b, uint64_t n_bytes, uint32_t* flag, void* stream);
+
+/* ---- host-boundary helper: n_bytes from device memory to PINNED host memory behind the work queued on `stream`, with an
+ * event the library pools (v13).  *ticket identifies the copy; gdr_host_copy_wait blocks until it has landed and releases
+ * the ticket (every ticket must be waited for exactly once).  The upstream extension reads `num_rendered` back with a
+ * blocking copy inside rasterize_gaussians; the Python boundary here reads the duplicate count of a device-sized call this
+ * way after everything else of the call is enqueued — two C calls instead of ~20 us of tensor / event objects. */
+int gdr_host_copy_begin(void* dst_pinned, const void* src_dev, uint64_t n_bytes, void* stream, void** ticket);
+int gdr_host_copy_wait(void* ticket);
 
 /* ---- K10: visibility mask (upstream markVisible; unused by the reference) -------- */
 int gdr_mark_visible(int32_t N, const float* means3D, const float* viewmatrix,
