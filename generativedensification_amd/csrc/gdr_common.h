@@ -119,6 +119,7 @@ hipError_t launch_tile_order_views(const BinViews& vs, int V, int tiles, hipStre
 // per-pixel compositing state saved at a cut of a long tile list, 256 pixels each: 3DGS T, colour x3, depth, alpha
 // sums (6 used); surfels T, colour x3, normal x3, depth, M1, M2 (10)
 #define GDR_SEG_STATE_FLOATS (10 * GDR_BLOCK)
+#define GDR_DEEP_MIN_MEAN 2560   /* mean list length of the busy tiles from which the deep forward applies (render.hip) */
 hipError_t launch_render_fwd(const gdr_settings* s, const gdr_geom* g, const gdr_binning* bin,
                              const gdr_image* img, const gdr_outputs* out, hipStream_t st);
 hipError_t launch_render_fwd_loss(const gdr_settings* s, const gdr_geom* g, const gdr_binning* bin,

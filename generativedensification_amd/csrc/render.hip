@@ -176,24 +176,34 @@ __global__ __launch_bounds__(GDR_ORDER_THREADS) void tile_order_kernel(const Bin
     }
     // what the caller may feed back into the next call of this scene shape (gdr_binning.stats_out): tiles in the tile
     // sort's long / medium class, busy tiles (lists of >= 64 entries)
-    uint32_t n_long = 0u, n_medium = 0u, n_busy = 0u;
+    uint32_t n_long = 0u, n_medium = 0u, n_busy = 0u, busy_len = 0u;   // busy_len: entries in the busy tiles' lists, / 16
     for (int t = threadIdx.x; t < ntiles; t += TB) {
         const uint2 r = ranges[t];
         const uint32_t len = r.y - r.x;
         n_long += len > (uint32_t)GDR_TSORT_MEDIUM ? 1u : 0u;
         n_medium += (len > (uint32_t)GDR_TSORT_SMALL && len <= (uint32_t)GDR_TSORT_MEDIUM) ? 1u : 0u;
         n_busy += len >= 64u ? 1u : 0u;
+        busy_len += len >= 64u ? len >> 4 : 0u;
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         n_long += __shfl_xor(n_long, off, 64); n_medium += __shfl_xor(n_medium, off, 64); n_busy += __shfl_xor(n_busy, off, 64);
+        busy_len += __shfl_xor(busy_len, off, 64);
     }
     __syncthreads();   // (cnt is free again: the ordering phase is over)
-    if (lane_id() == 0) { cnt[threadIdx.x >> 6] = n_long; cnt[NWV + (threadIdx.x >> 6)] = n_medium; cnt[2 * NWV + (threadIdx.x >> 6)] = n_busy; }
+    if (lane_id() == 0) {
+        cnt[threadIdx.x >> 6] = n_long; cnt[NWV + (threadIdx.x >> 6)] = n_medium; cnt[2 * NWV + (threadIdx.x >> 6)] = n_busy;
+        cnt[3 * NWV + (threadIdx.x >> 6)] = busy_len;
+    }
     __syncthreads();
-    n_long = n_medium = n_busy = 0u;
-    for (int w = 0; w < NWV; ++w) { n_long += cnt[w]; n_medium += cnt[NWV + w]; n_busy += cnt[2 * NWV + w]; }
-    const uint32_t deep = (seg_base != nullptr && seg_len > 0 && n_busy <= deep_max_busy) ? 1u : 0u;
+    n_long = n_medium = n_busy = busy_len = 0u;
+    for (int w = 0; w < NWV; ++w) { n_long += cnt[w]; n_medium += cnt[NWV + w]; n_busy += cnt[2 * NWV + w]; busy_len += cnt[3 * NWV + w]; }
+    // "deep" forward: few busy tiles AND long lists in them (mean >= GDR_DEEP_MIN_MEAN entries).  Few busy tiles with
+    // short lists (C3: 700 of 1024 tiles with ~1.4 k entries, C2 `shell`: 530 tiles with ~1.3 k) are a handful of rounds per
+    // workgroup, and the standard kernel's half as many instructions win: C3 2995 -> 3110, C2 `shell` 2938 -> 3060 views/s
+    // without the deep launch; with lists of 4 k (C3 `shell`) and 7.6 k (C4 `shell`) it is worth +14 % and +3 %.
+    const uint32_t deep = (seg_base != nullptr && seg_len > 0 && n_busy <= deep_max_busy &&
+                           (uint64_t)busy_len * 16ull >= (uint64_t)n_busy * (uint64_t)GDR_DEEP_MIN_MEAN) ? 1u : 0u;
     if (threadIdx.x == 0 && bv.stats_out) {
         bv.stats_out[0] = n_long; bv.stats_out[1] = n_medium; bv.stats_out[2] = deep; bv.stats_out[3] = n_busy;
     }

@@ -152,9 +152,9 @@ typedef struct gdr_binning {
                           * GDR_DEFAULT_SEG_LEN and sizes the tables for it; a caller may RAISE it or set 0 afterwards */
     int32_t seg_cap;     /* D / seg_len + 1                                                         */
     int32_t deep_max_busy; /* K6 renders the CUT tiles with 16 instead of 64 pixels per wave ("deep" forward, 4 workgroups
-                          * per tile) when at most this many tiles hold >= 64 entries — an object in front of an empty
-                          * background leaves most CUs with one workgroup walking a long list.  gdr_binning_carve sets
-                          * GDR_DEFAULT_DEEP_MAX_BUSY; 0 = never. */
+                          * per tile) when at most this many tiles hold >= 64 entries AND their lists average >= 2560
+                          * entries — an object in front of an empty background leaves most CUs with one workgroup
+                          * walking a long list.  gdr_binning_carve sets GDR_DEFAULT_DEEP_MAX_BUSY; 0 = never. */
     int32_t reserved0;
     const uint32_t* d_dev; /* NULL (gdr_binning_carve): the D passed to the binning entry points is the duplicate count,
                           * read back from geom->num_rendered by the caller.  Non-NULL = a DEVICE-SIZED call: the binning
