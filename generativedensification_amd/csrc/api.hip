@@ -97,7 +97,7 @@ static size_t carve_binning(void* base, uint64_t D, gdr_binning* b, int32_t seg_
     t.sorted = 0;
     t.global_sort = 0;
     t.deep_max_busy = GDR_DEFAULT_DEEP_MAX_BUSY;
-    t.reserved0 = 0;
+    t.deep_min_mean = 0;
     t.d_dev = nullptr;
     t.stats_out = nullptr;
     t.hint_long = t.hint_medium = t.hint_no_deep = t.grad_rec_cleared = 0;

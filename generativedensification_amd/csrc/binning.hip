@@ -850,6 +850,7 @@ void fill_bin_views(BinViews* vs, int V, const gdr_geom* geoms, const gdr_binnin
         b.stats_out = bn.stats_out; b.hint_long = bn.hint_long; b.hint_medium = bn.hint_medium;
         b.seg_len = bn.seg_len; b.seg_cap = bn.seg_cap;
         b.deep_max_busy = (uint32_t)(bn.deep_max_busy > 0 ? bn.deep_max_busy : 0);
+        b.deep_min_mean = (uint32_t)(bn.deep_min_mean > 0 ? bn.deep_min_mean : GDR_DEEP_MIN_MEAN);
     }
 }
 

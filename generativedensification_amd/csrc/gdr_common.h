@@ -93,7 +93,7 @@ struct BinView {
     const int32_t* radii; const float* depths; const int4* rect; const uint32_t* tiles_touched; const uint32_t* block_offs;
     uint64_t* keys[2]; uint32_t* vals[2]; uint32_t* hist; uint32_t* scratch32;
     uint2* ranges; uint32_t* tile_order; uint32_t* seg_base; uint2* seg_extra; uint32_t* seg_count;
-    uint64_t D; uint32_t nblk; int32_t seg_len, seg_cap; uint32_t deep_max_busy;
+    uint64_t D; uint32_t nblk; int32_t seg_len, seg_cap; uint32_t deep_max_busy, deep_min_mean;
     const uint32_t* d_dev;   // gdr_binning.d_dev: the duplicate count stays on the device, D/nblk above are CAPACITIES
     uint32_t* stats_out;     // gdr_binning.stats_out (tile_order_kernel writes it)
     int32_t hint_long, hint_medium;   // host side only: grid sizes of the tile sort's long / medium class

@@ -203,7 +203,7 @@ __global__ __launch_bounds__(GDR_ORDER_THREADS) void tile_order_kernel(const Bin
     // workgroup, and the standard kernel's half as many instructions win: C3 2995 -> 3110, C2 `shell` 2938 -> 3060 views/s
     // without the deep launch; with lists of 4 k (C3 `shell`) and 7.6 k (C4 `shell`) it is worth +14 % and +3 %.
     const uint32_t deep = (seg_base != nullptr && seg_len > 0 && n_busy <= deep_max_busy &&
-                           (uint64_t)busy_len * 16ull >= (uint64_t)n_busy * (uint64_t)GDR_DEEP_MIN_MEAN) ? 1u : 0u;
+                           (uint64_t)busy_len * 16ull >= (uint64_t)n_busy * (uint64_t)bv.deep_min_mean) ? 1u : 0u;
     if (threadIdx.x == 0 && bv.stats_out) {
         bv.stats_out[0] = n_long; bv.stats_out[1] = n_medium; bv.stats_out[2] = deep; bv.stats_out[3] = n_busy;
     }

@@ -173,6 +173,7 @@ SEG_LEN = int(_os.environ["GDR_SEG_LEN"]) if _os.environ.get("GDR_SEG_LEN") else
 
 # K6 "deep" forward (include/gdr.h gdr_binning.deep_max_busy): None = library default (768 busy tiles), 0 = never.
 DEEP_MAX_BUSY = None
+DEEP_MIN_MEAN = int(_os.environ["GDR_DEEP_MIN_MEAN"]) if _os.environ.get("GDR_DEEP_MIN_MEAN") else None   # (gdr_binning.deep_min_mean)
 
 
 def _seg_len_for(D, tiles=None, busy=None):
@@ -646,6 +647,8 @@ def _carve_binning(lib, st, entries, tiles, d_dev=None, stats=None, hints=None):
     st.D = entries
     if DEEP_MAX_BUSY is not None:
         st.bin.deep_max_busy = max(0, int(DEEP_MAX_BUSY))
+    if DEEP_MIN_MEAN is not None:
+        st.bin.deep_min_mean = max(0, int(DEEP_MIN_MEAN))
     if hints is not None:
         st.bin.hint_long, st.bin.hint_medium, st.bin.hint_no_deep = hints[:3]
     if stats is not None:

@@ -155,7 +155,7 @@ typedef struct gdr_binning {
                           * per tile) when at most this many tiles hold >= 64 entries AND their lists average >= 2560
                           * entries — an object in front of an empty background leaves most CUs with one workgroup
                           * walking a long list.  gdr_binning_carve sets GDR_DEFAULT_DEEP_MAX_BUSY; 0 = never. */
-    int32_t reserved0;
+    int32_t deep_min_mean; /* ... and their lists average at least this many entries; <= 0 = the library default (2560) */
     const uint32_t* d_dev; /* NULL (gdr_binning_carve): the D passed to the binning entry points is the duplicate count,
                           * read back from geom->num_rendered by the caller.  Non-NULL = a DEVICE-SIZED call: the binning
                           * kernels read the count from this device word (geom->num_rendered) themselves and the D passed
