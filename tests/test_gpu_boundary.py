@@ -317,6 +317,76 @@ def test_launch_hints_only_size_launches():
             R._HINT_STATE[key] = saved[1]
 
 
+def test_deep_forward_applies_to_few_busy_tiles_with_long_lists_only():
+    """gdr_binning.deep_max_busy / deep_min_mean: the binning stage's report (stats_out[2]) says whether the deep forward
+    applied.  An object-like scene with long lists: yes; the same scene with the threshold above its mean list length, or
+    with short lists (few Gaussians): no — and the image is the same either way up to the deep forward's summation order."""
+    from generativedensification_amd import rasterizer as R
+    from generativedensification_amd.camera import orbit_cameras
+    from generativedensification_amd.renderer import Renderer
+    from generativedensification_amd.synthetic import make_scene
+    dev = torch.device(DEV)
+    H = W = 256
+    cams = orbit_cameras(1, W, H, device=dev)
+    sets = [Renderer(sh_degree=1).set_rasterizer(c, device=dev).raster_settings for c in cams]
+
+    def run(N, min_mean):
+        scene = make_scene(N, 31, sh_degree=1, sigma0=(0.004,), device=dev, layout="shell")
+        key = (torch.cuda.current_device(),) + R.shape_key(N, H, W, 1)
+        saved = R._LAUNCH_STATS.pop(key, None), R._HINT_STATE.pop(key, None), R.DEEP_MIN_MEAN
+        R.DEEP_MIN_MEAN = min_mean
+        try:
+            with torch.no_grad():
+                colors, _, _, _, states, _, _ = R._forward_views_impl(scene["centers"], torch.empty(0, 4, device=dev), scene["shs"],
+                                                                      scene["opacity"], scene["scales"], scene["rotations"],
+                                                                      tuple(sets), R.RAW_ALL)
+            torch.cuda.synchronize()
+            t = states[0].tensors()
+            L_ = (t["ranges"][:, 1] - t["ranges"][:, 0]).long()
+            busy = L_[L_ >= 64]
+            return colors[0], R._LAUNCH_STATS[key][0].tolist(), float(busy.float().mean()), int(busy.numel())
+        finally:
+            R.DEEP_MIN_MEAN = saved[2]
+            R._LAUNCH_STATS.pop(key, None)
+            R._HINT_STATE.pop(key, None)
+            if saved[0] is not None:
+                R._LAUNCH_STATS[key] = saved[0]
+            if saved[1] is not None:
+                R._HINT_STATE[key] = saved[1]
+
+    c_deep, st_deep, mean_long, busy_long = run(400_000, None)
+    assert busy_long <= 768 and mean_long >= 2560, (busy_long, mean_long)    # the premise: few busy tiles, long lists
+    assert st_deep[2] == 1 and st_deep[3] == busy_long, st_deep
+    c_std, st_std, _, _ = run(400_000, int(mean_long) + 1000)                # threshold above this scene's mean: standard K6
+    assert st_std[2] == 0, st_std
+    assert float((c_deep - c_std).abs().max()) < 2e-5
+    _, st_short, mean_short, busy_short = run(40_000, None)                  # same object, a tenth of the Gaussians: short lists
+    assert busy_short <= 768 and mean_short < 2560, (busy_short, mean_short)
+    assert st_short[2] == 0, st_short
+
+
+def test_host_copy_entries_deliver_device_words_to_pinned_memory():
+    """gdr_host_copy_begin / gdr_host_copy_wait (include/gdr.h, v13): the pooled-event read-back the Python boundary uses
+    for the duplicate count; tickets are reusable after the wait, NULL arguments are refused."""
+    import ctypes as C
+    from generativedensification_amd import _lib as L
+    lib = L.load()
+    dev = torch.device(DEV)
+    host = torch.zeros(4, dtype=torch.int32).pin_memory()
+    seen = set()
+    for k in range(5):
+        src = torch.arange(4, dtype=torch.int32, device=dev) + 10 * k
+        ticket = C.c_void_p()
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        assert lib.gdr_host_copy_begin(host.data_ptr(), src.data_ptr(), 16, stream, C.byref(ticket)) == 0
+        assert lib.gdr_host_copy_wait(ticket) == 0
+        assert host.tolist() == [10 * k, 10 * k + 1, 10 * k + 2, 10 * k + 3]
+        seen.add(ticket.value)
+    assert len(seen) == 1                      # the event went back to the pool and was taken again
+    assert lib.gdr_host_copy_wait(None) != 0
+    assert lib.gdr_host_copy_begin(None, None, 16, None, C.byref(C.c_void_p())) != 0
+
+
 def test_history_of_a_shape_carries_over_to_a_neighbouring_gaussian_count():
     """A densifying model renders a different N every step: the histories are keyed by the power-of-two bucket of N and
     hold duplicates PER GAUSSIAN, so a call with 25 % more Gaussians than the last one is already device-sized — and
