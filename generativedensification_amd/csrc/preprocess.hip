@@ -280,7 +280,8 @@ __global__ __launch_bounds__(GDR_BLOCK) void preprocess_bwd_kernel(
     if (vis) {
         const float px_ = means3D[3 * i], py_ = means3D[3 * i + 1], pz_ = means3D[3 * i + 2];
         const float4 g2 = grad_rec[4 * i];          // mean2D x, y, |x|, |y|
-        const float4 gconic = grad_rec[4 * i + 1];  // conic.xyz, ddepth
+        float4 gconic = grad_rec[4 * i + 1];        // conic.xyz (K7 leaves the exact factors -1/2, -1, -1/2 to us), ddepth
+        gconic.x *= -0.5f; gconic.y = -gconic.y; gconic.z *= -0.5f;
         const float4 gcolor = grad_rec[4 * i + 2];  // rgb, opacity
         {
             float dop = gcolor.w;
@@ -762,6 +763,7 @@ __global__ __launch_bounds__(GDR_BLOCK) void preprocess_bwd_views_kernel(
             g2 = bv.grad_rec[4 * i]; gconic = bv.grad_rec[4 * i + 1]; gcolor = bv.grad_rec[4 * i + 2];
             cl_v = bv.clamped[i];
         }
+        gconic.x *= -0.5f; gconic.y = -gconic.y; gconic.z *= -0.5f;   // (K7 leaves these exact factors to us)
         dm2 = make_float4(dm2.x + g2.x, dm2.y + g2.y, dm2.z + g2.z, dm2.w + g2.w);
         dop += gcolor.w;
         const float pvx = cam.v[0] * px_ + cam.v[4] * py_ + cam.v[8] * pz_ + cam.v[12];

@@ -679,7 +679,8 @@ __global__ __launch_bounds__(GDR_BLOCK) void render_fwd_deep_kernel(
 // ---------------------------------------------------------------------------------
 // K7.  grad_rec: (N,16) floats, one 64-byte line per Gaussian (pre-zeroed by the launcher):
 //   [0..3] dL/dmean2D x, y (signed, NDC units), sum|x-term|, sum|y-term|
-//   [4..6] dL/dconic.x, .y, .z   [7] dL/ddepth   [8..10] dL/dcolour   [11] dL/dopacity
+//   [4..6] -2 dL/dconic.x, -dL/dconic.y, -2 dL/dconic.z (sums of q dx dx, q dx dy, q dy dy; K8 scales)   [7] dL/ddepth
+//   [8..10] dL/dcolour   [11] dL/dopacity
 // ---------------------------------------------------------------------------------
 // M2_ONLY: only dL/dmean2D (x, y, |x|, |y|) is produced, accumulated over views straight into an (N,4)
 // buffer — the screen-space gradient the densification step consumes (network.py:865-878); dL/ddepth and
@@ -857,7 +858,7 @@ __global__ __launch_bounds__(GDR_BLOCK) void render_bwd_kernel(
                 const uint64_t hb = __ballot(hit);
                 if (hb == 0ull) return;
                 const float a = hit ? alpha : 0.f;
-                const float hm = hit ? 1.f : 0.f;
+                const float Gh = hit ? G : 0.f;                       // a lane without a hit contributes nothing below
                 const float r_oma = __builtin_amdgcn_rcpf(1.f - a);  // == 1 when a == 0
                 T = T * r_oma;                                        // transmittance in FRONT of this Gaussian
                 const float w = a * T;
@@ -870,22 +871,25 @@ __global__ __launch_bounds__(GDR_BLOCK) void render_bwd_kernel(
                     dL_dalpha = fmaf(d0, gC0, fmaf(d1, gC1, fmaf(d2, gC2, fmaf(dD, gD, dA * gA))));
                     BD = fmaf(a, dD, BD); BA = fmaf(a, dA, BA);
                 }
-                dL_dalpha = fmaf(dL_dalpha, T, bgT * r_oma) * hm;
+                dL_dalpha = fmaf(dL_dalpha, T, bgT * r_oma);
                 B0 = fmaf(a, d0, B0); B1 = fmaf(a, d1, B1); B2 = fmaf(a, d2, B2);
-                const float dL_dG = en.co.w * dL_dalpha;
-                const float gdx = G * dx, gdy = G * dy;
+                // go = G dL/dalpha (the opacity term), q = opacity * go = G dL/dG; everything below is q times a polynomial in
+                // (dx, dy): formed from q dx and q dy, 6 + 6 multiplies for the five geometric terms instead of 11 + 8
+                const float go = Gh * dL_dalpha;
+                const float q = en.co.w * go;
+                const float qdx = q * dx, qdy = q * dy;
                 // co.xyz carry the log2(e) factor; kx, ky carry its inverse
-                const float v_mx = dL_dG * (-gdx * en.co.x - gdy * en.co.y) * kx;
-                const float v_my = dL_dG * (-gdy * en.co.z - gdx * en.co.y) * ky;
+                const float v_mx = fmaf(qdx, en.co.x, qdy * en.co.y) * -kx;
+                const float v_my = fmaf(qdy, en.co.z, qdx * en.co.y) * -ky;
                 if (M2_ONLY) {
                     const float tot4 = row_reduce_scatter4(v_mx, v_my, fabsf(v_mx), fabsf(v_my), li);
                     if ((li & 3u) == 0u && ((hb >> (16 * row)) & 0xFFFFull) != 0ull)
                         atomicAdd(grad_rec + 4 * (size_t)s_id[en.e] + (li >> 2), tot4);
                     return;
                 }
-                const float vals[12] = {v_mx, v_my, fabsf(v_mx), fabsf(v_my),
-                                        -0.5f * gdx * dx * dL_dG, -gdx * dy * dL_dG, -0.5f * gdy * dy * dL_dG,
-                                        w * gD, w * gC0, w * gC1, w * gC2, G * dL_dalpha};
+                // (record words 4..6 = sum of q dx dx, q dx dy, q dy dy: K8 applies the exact factors -1/2, -1, -1/2)
+                const float vals[12] = {v_mx, v_my, fabsf(v_mx), fabsf(v_my), qdx * dx, qdx * dy, qdy * dy,
+                                        w * gD, w * gC0, w * gC1, w * gC2, go};
                 const float tot = row_reduce_scatter12(vals, li);
                 const bool publish = ((hb >> (16 * row)) & 0xFFFFull) != 0ull;
                 // lanes 0..11 of every row that had a hit add the row totals to the Gaussian's
