@@ -405,7 +405,7 @@ __global__ __launch_bounds__(GDR_BLOCK) void surfel_render_bwd_kernel(
                 const bool hit = h.geom_ok && h.alpha >= lim;
                 const uint64_t hb = __ballot(hit);
                 if (hb == 0ull) return;
-                const float a = hit ? h.alpha : 0.f, hm = hit ? 1.f : 0.f;
+                const float a = hit ? h.alpha : 0.f;
                 const float G = hit ? h.G : 0.f, depth = hit ? h.depth : 1.f, rz = hit ? h.rz : 0.f;
                 const bool u3 = hit && h.use3d;
                 const float sx = u3 ? h.sx : 0.f, sy = u3 ? h.sy : 0.f;
@@ -426,7 +426,7 @@ __global__ __launch_bounds__(GDR_BLOCK) void surfel_render_bwd_kernel(
                 BD = fmaf(a, dD, BD); BA = fmaf(a, dA, BA);
                 BN0 = fmaf(a, dn0, BN0); BN1 = fmaf(a, dn1, BN1); BN2 = fmaf(a, dn2, BN2);
                 BW = fmaf(a, dW, BW);
-                dL_dalpha = fmaf(dL_dalpha, T, bgT * r_oma) * hm;
+                dL_dalpha = fmaf(dL_dalpha, T, bgT * r_oma);   // (only used times G below, and G = 0 without a hit)
                 float dL_dz = fmaf(2.f * w * (m_d * final_A - final_D) * gReg, dmd_dd, w * gDepth);
                 dL_dz += (hit && pos + 1 == med_contributor) ? gMed : 0.f;
                 const float dL_dG = en.tw.w * dL_dalpha;
