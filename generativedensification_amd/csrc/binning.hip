@@ -340,10 +340,24 @@ __global__ __launch_bounds__(GDR_BLOCK) void ranges_kernel(const BinViews vs, in
 // =================================================================================
 #define GDR_BIN_THREADS 1024
 
-__device__ __forceinline__ bool bin_gaussian(const BinView& bv, int i, int4& r) {
-    if (bv.tiles_touched[i] == 0u || bv.radii[i] <= 0) return false;
-    r = bv.rect[i];
-    return true;
+// The tile rects of GDR_BIN_BATCH Gaussians of a thread (i0 + j * 1024), an empty rect for a Gaussian that is not binned
+// (culled, or beyond hi).  All loads are issued before the first is used: with "tiles_touched, then radii, then rect" per
+// Gaussian a thread paid three dependent trips to memory per iteration and tile_count was latency, not bandwidth.
+#define GDR_BIN_BATCH 4
+__device__ __forceinline__ void bin_rects(const BinView& bv, int i0, int hi, int4 (&r)[GDR_BIN_BATCH]) {
+    uint32_t tt[GDR_BIN_BATCH];
+    int32_t rad[GDR_BIN_BATCH];
+#pragma unroll
+    for (int j = 0; j < GDR_BIN_BATCH; ++j) {
+        const int i = i0 + j * GDR_BIN_THREADS;
+        const bool in = i < hi;
+        tt[j] = in ? bv.tiles_touched[i] : 0u;
+        rad[j] = in ? bv.radii[i] : 0;
+        r[j] = in ? bv.rect[i] : make_int4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < GDR_BIN_BATCH; ++j)
+        if (tt[j] == 0u || rad[j] <= 0) r[j] = make_int4(0, 0, 0, 0);
 }
 
 // count matrix layout: row w = workgroup w of tile_count / tile_scatter, `tstride` words (tiles rounded up to 64): every
@@ -355,11 +369,13 @@ __global__ __launch_bounds__(GDR_BIN_THREADS) void tile_count_kernel(const BinVi
     for (int t = threadIdx.x; t < tiles; t += GDR_BIN_THREADS) cnt[t] = 0u;
     __syncthreads();
     const int lo = blockIdx.x * chunk, hi = min(N, lo + chunk);
-    for (int i = lo + (int)threadIdx.x; i < hi; i += GDR_BIN_THREADS) {
-        int4 r;
-        if (!bin_gaussian(bv, i, r)) continue;
-        for (int y = r.y; y < r.w; ++y)
-            for (int x = r.x; x < r.z; ++x) atomicAdd(&cnt[y * gx + x], 1u);
+    for (int i0 = lo + (int)threadIdx.x; i0 < hi; i0 += GDR_BIN_BATCH * GDR_BIN_THREADS) {
+        int4 r[GDR_BIN_BATCH];
+        bin_rects(bv, i0, hi, r);
+#pragma unroll
+        for (int j = 0; j < GDR_BIN_BATCH; ++j)
+            for (int y = r[j].y; y < r[j].w; ++y)
+                for (int x = r[j].x; x < r[j].z; ++x) atomicAdd(&cnt[y * gx + x], 1u);
     }
     __syncthreads();
     uint32_t* __restrict__ row = bv.tile_hist + (size_t)blockIdx.x * tstride;
@@ -410,15 +426,24 @@ __global__ __launch_bounds__(GDR_BIN_THREADS) void tile_scatter_kernel(const Bin
     uint64_t* __restrict__ out = bv.keys[0];
     const uint64_t cap = bv.D;
     const int lo = blockIdx.x * chunk, hi = min(N, lo + chunk);
-    for (int i = lo + (int)threadIdx.x; i < hi; i += GDR_BIN_THREADS) {
-        int4 r;
-        if (!bin_gaussian(bv, i, r)) continue;
-        const uint64_t word = ((uint64_t)(uint32_t)i << 32) | (uint64_t)__float_as_uint(bv.depths[i]);
-        for (int y = r.y; y < r.w; ++y)
-            for (int x = r.x; x < r.z; ++x) {
-                const uint32_t pos = atomicAdd(&cur[y * gx + x], 1u);
-                if (pos < cap) out[pos] = word;   // capacity guard: never write past the caller's buffers
-            }
+    for (int i0 = lo + (int)threadIdx.x; i0 < hi; i0 += GDR_BIN_BATCH * GDR_BIN_THREADS) {
+        int4 r[GDR_BIN_BATCH];
+        uint32_t dbits[GDR_BIN_BATCH];
+#pragma unroll
+        for (int j = 0; j < GDR_BIN_BATCH; ++j) {
+            const int i = i0 + j * GDR_BIN_THREADS;
+            dbits[j] = i < hi ? __float_as_uint(bv.depths[i]) : 0u;
+        }
+        bin_rects(bv, i0, hi, r);
+#pragma unroll
+        for (int j = 0; j < GDR_BIN_BATCH; ++j) {
+            const uint64_t word = ((uint64_t)(uint32_t)(i0 + j * GDR_BIN_THREADS) << 32) | (uint64_t)dbits[j];
+            for (int y = r[j].y; y < r[j].w; ++y)
+                for (int x = r[j].x; x < r[j].z; ++x) {
+                    const uint32_t pos = atomicAdd(&cur[y * gx + x], 1u);
+                    if (pos < cap) out[pos] = word;   // capacity guard: never write past the caller's buffers
+                }
+        }
     }
 }
 
