@@ -408,18 +408,22 @@ def backward_raw(st: _State, keep, raster_settings, radii, grad_color, grad_dept
 EARLY_CLEAR = True
 
 
-def _early_records(ctx, dev, V, N, H, W, floats):
-    """Gradient records of the V views (V, N * floats), zero-filled NOW — at the end of the forward — on the streams their
-    K7 will run on, behind whatever those streams still have to do: the clear (64 B per Gaussian and view, 130 us of HBM
-    time per C4 step) then runs under the tail of the forward, the loss and autograd's hand-over instead of in front of
-    every K7.  Only with side streams (otherwise the clear would sit between the forward and the loss) and only if a
-    gradient was asked for; ctx.recs is consumed by the first backward (a second one clears its own)."""
+def _early_records_begin(ctx, dev, V, N, H, W, floats):
+    """Gradient records of the V views (V, N * floats): allocated at the START of the forward, and the streams their K7 will
+    run on (the first side streams, which also carry forward chains) are made to wait for THIS point of the caller's stream.
+    _early_records_clear then zero-fills them on those streams behind the chains queued there — under the tail of the
+    forward (the other views' K6), not in front of every K7 (64 B per Gaussian and view: 130 us of HBM time per C4 step).
+    The event has to be recorded before the caller's stream joins the forward's side streams: recorded after the join (as
+    until round 3) the clears could only start once the whole forward was over (kernel timeline of a C4 step: 90 us of
+    fills between the last K6 and the first K7 with nothing else running).
+    Only with side streams and only if a gradient was asked for; ctx.recs is consumed by the first backward (a second one
+    clears its own).  Returns what _early_records_clear needs."""
     ctx.recs = None
     if not (EARLY_CLEAR and N > 0 and any(ctx.needs_input_grad[:6])):
-        return
+        return None
     streams = _SideViews.k7_streams(dev, V, H, W)
     if streams is None:
-        return
+        return None
     recs = torch.empty(V, N * floats, dtype=torch.float32, device=dev)
     # `recs` comes from the caller's stream's allocator pool: the block may still be in use by kernels queued on that
     # stream, and not every K7 stream is one of the forward's streams — each K7 stream waits for this point of the
@@ -429,10 +433,22 @@ def _early_records(ctx, dev, V, N, H, W, floats):
     for sd in set(streams):
         sd.wait_event(allocated)
         recs.record_stream(sd)
-    for v in range(V):
+    return recs, streams
+
+
+def _early_records_clear(ctx, pending):
+    if pending is None:
+        return
+    recs, streams = pending
+    for v in range(recs.shape[0]):
         with torch.cuda.stream(streams[v]):
             recs[v].zero_()
     ctx.recs = recs
+
+
+def _early_records(ctx, dev, V, N, H, W, floats):
+    """Both steps at the end of a forward (callers whose forward is not split yet)."""
+    _early_records_clear(ctx, _early_records_begin(ctx, dev, V, N, H, W, floats))
 
 
 def _take_records(ctx, lo, n, N, floats, dev):
@@ -791,13 +807,16 @@ def _forward_views_impl(means3D, means2D, sh, opacities, scales, rotations, sett
 class _RenderViews(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, opacities, scales, rotations, settings_list, flags):
+        rs0 = settings_list[0]
+        pending = _early_records_begin(ctx, means3D.device, len(settings_list), int(means3D.shape[0]), int(rs0.image_height),
+                                       int(rs0.image_width), 16)
         colors, radii, depths, alphas, states, keep, in_dtypes = _forward_views_impl(
             means3D, means2D, sh, opacities, scales, rotations, settings_list, flags)
         ctx.states, ctx.settings_list, ctx.flags = states, settings_list, flags
         _save_inputs(ctx, keep)
         ctx.radii, ctx.in_dtypes, ctx.means2D_shape = radii, in_dtypes, tuple(means2D.shape)
         ctx.mark_non_differentiable(radii)
-        _early_records(ctx, means3D.device, len(states), states[0].N, states[0].H, states[0].W, 16)
+        _early_records_clear(ctx, pending)
         return (radii, *colors, *depths, *alphas)
 
     @staticmethod
@@ -874,6 +893,8 @@ class _RenderViewsLoss(torch.autograd.Function):
         V = len(settings_list)
         targets = [t.to(device=dev, dtype=torch.float32).contiguous() for t in targets]
         losses = torch.zeros(V, dtype=torch.float32, device=dev)
+        rs0 = settings_list[0]
+        pending = _early_records_begin(ctx, dev, V, int(means3D.shape[0]), int(rs0.image_height), int(rs0.image_width), 16)
         colors, radii, depths, alphas, states, keep, in_dtypes = _forward_views_impl(
             means3D, means2D, sh, opacities, scales, rotations, settings_list, flags,
             loss_spec=(targets, w_depth, w_alpha, losses))
@@ -882,7 +903,7 @@ class _RenderViewsLoss(torch.autograd.Function):
         ctx.radii, ctx.in_dtypes, ctx.means2D_shape = radii, in_dtypes, tuple(means2D.shape)
         ctx.colors, ctx.targets, ctx.w = colors, targets, (float(w_depth), float(w_alpha))
         ctx.mark_non_differentiable(radii)
-        _early_records(ctx, dev, V, states[0].N, states[0].H, states[0].W, 16)
+        _early_records_clear(ctx, pending)
         return losses, radii
 
     @staticmethod
