@@ -238,6 +238,10 @@ def _surfel_forward_views_impl(ctx, means3D, means2D, sh, opacities, scales, rot
         with torch.cuda.device(dev):
             stream = _stream()
             main = torch.cuda.current_stream()
+            # the gradient records of a same-size call: allocated now, cleared at the end of this forward on the K7 streams
+            # (rasterizer._early_records_begin: the event those streams wait for must precede the join with the side streams)
+            pending_recs = (_R._early_records_begin(ctx, dev, V, N, H, W, L.GSR_GRAD_FLOATS)
+                            if all(int(rs.image_height) == H and int(rs.image_width) == W for rs in settings_list) else None)
             inp = _inputs_struct(N, M, means3D, opacities, sh, e, scales, rotations, e, flags)
             for v, rs in enumerate(settings_list):
                 s = _settings_struct(rs, dev, keep)
@@ -317,10 +321,9 @@ def _surfel_forward_views_impl(ctx, means3D, means2D, sh, opacities, scales, rot
         _R._save_inputs(ctx, keep)
         ctx.means2D_shape, ctx.in_dtypes, ctx.V = tuple(means2D.shape), in_dtypes, V
         ctx.mark_non_differentiable(radii)
-        if same:   # (the records of the fused backward: cleared now, under the tail of the forward — rasterizer._early_records)
-            _R._early_records(ctx, dev, V, N, H, W, L.GSR_GRAD_FLOATS)
-        else:
-            ctx.recs = None
+        ctx.recs = None
+        if same:   # (the records of the fused backward: cleared now, under the tail of the forward)
+            _R._early_records_clear(ctx, pending_recs)
         return radii, colors, allmaps
 
 
