@@ -114,6 +114,7 @@ _PROTOS = {
     "gdr_words_differ": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
     "gdr_host_copy_begin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(C.c_void_p)]),
     "gdr_host_copy_wait": (C.c_int, [C.c_void_p]),
+    "gdr_clear_async": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p]),
     "gdr_image_carve": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(GdrImage)]),
     "gdr_preprocess_forward": (C.c_int, [C.POINTER(GdrSettings), C.POINTER(GdrInputs), C.POINTER(GdrGeom),
                                          C.c_void_p, C.POINTER(C.c_uint32), C.c_void_p]),

@@ -412,6 +412,14 @@ int gdr_host_copy_wait(void* ticket) {
     return GDR_OK;
 }
 
+int gdr_clear_async(void* dst, uint64_t n_bytes, void* stream) {
+    if (n_bytes == 0) return GDR_OK;
+    if (!dst) { set_error("clear_async: NULL argument", hipSuccess); return GDR_ERR_INVALID_ARG; }
+    const hipError_t e = hipMemsetAsync(dst, 0, (size_t)n_bytes, (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail("clear_async", e);
+    return GDR_OK;
+}
+
 size_t gdr_topk_workspace_bytes(void) { return select_workspace_bytes(); }
 
 int gdr_topk_absgrad(int32_t N, const float* grad, const uint8_t* candidates, int32_t k, void* workspace, uint8_t* mask,

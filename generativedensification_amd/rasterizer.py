@@ -440,9 +440,10 @@ def _early_records_clear(ctx, pending):
     if pending is None:
         return
     recs, streams = pending
-    for v in range(recs.shape[0]):
-        with torch.cuda.stream(streams[v]):
-            recs[v].zero_()
+    lib, row = L.load(), recs.shape[1] * 4
+    for v in range(recs.shape[0]):   # (a C call per view on the raw stream handle: a stream context + zero_() cost 25 us each)
+        L.check(lib.gdr_clear_async(C.c_void_p(recs.data_ptr() + v * row), row, C.c_void_p(streams[v].cuda_stream)),
+                "gdr_clear_async")
     ctx.recs = recs
 
 

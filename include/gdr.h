@@ -392,6 +392,11 @@ int gdr_words_differ(const void* a, const void* b, uint64_t n_bytes, uint32_t* f
 int gdr_host_copy_begin(void* dst_pinned, const void* src_dev, uint64_t n_bytes, void* stream, void** ticket);
 int gdr_host_copy_wait(void* ticket);
 
+/* Zero-fill n_bytes of device memory behind the work queued on `stream` (v13): what the caller of the K7 entry points does to
+ * the gradient records when it sets gdr_binning.grad_rec_cleared — one C call on a raw stream handle instead of a stream
+ * context + tensor op per view on the Python side. */
+int gdr_clear_async(void* dst, uint64_t n_bytes, void* stream);
+
 /* ---- K10: visibility mask (upstream markVisible; unused by the reference) -------- */
 int gdr_mark_visible(int32_t N, const float* means3D, const float* viewmatrix,
                      const float* projmatrix, uint8_t* present, void* stream);
