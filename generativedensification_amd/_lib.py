@@ -112,6 +112,8 @@ _PROTOS = {
     "gdr_binning_carve_for": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int32, C.c_int32, C.c_int32, C.POINTER(GdrBinning)]),
     "gdr_build_tag": (C.c_char_p, []),
     "gdr_words_differ": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
+    "gdr_words_differ_multi": (C.c_int, [C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.c_void_p,
+                                         C.c_void_p]),
     "gdr_host_copy_begin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(C.c_void_p)]),
     "gdr_host_copy_wait": (C.c_int, [C.c_void_p]),
     "gdr_clear_async": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p]),

@@ -412,6 +412,23 @@ int gdr_host_copy_wait(void* ticket) {
     return GDR_OK;
 }
 
+int gdr_words_differ_multi(int32_t n, const void* const* a, const void* const* b, const uint64_t* n_bytes, uint32_t* flag,
+                           void* stream) {
+    if (n < 0 || n > GDR_DIFFER_MAX || !flag || (n && (!a || !b || !n_bytes))) {
+        set_error("words_differ_multi: bad argument", hipSuccess);
+        return GDR_ERR_INVALID_ARG;
+    }
+    for (int k = 0; k < n; ++k)
+        if ((n_bytes[k] && (!a[k] || !b[k])) || (n_bytes[k] & 3u) || (((uintptr_t)a[k] | (uintptr_t)b[k]) & 15u)) {
+            set_error("words_differ_multi: NULL / unaligned buffer", hipSuccess);
+            return GDR_ERR_INVALID_ARG;
+        }
+    if (n == 0) return GDR_OK;
+    hipError_t e = launch_words_differ_multi(n, a, b, n_bytes, flag, (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail("words_differ_multi", e);
+    return GDR_OK;
+}
+
 int gdr_clear_async(void* dst, uint64_t n_bytes, void* stream) {
     if (n_bytes == 0) return GDR_OK;
     if (!dst) { set_error("clear_async: NULL argument", hipSuccess); return GDR_ERR_INVALID_ARG; }

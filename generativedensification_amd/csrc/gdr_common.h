@@ -186,5 +186,8 @@ hipError_t launch_knn_mean_dist2(const float* pts_sorted, int N, const float* bb
 
 size_t sort_hist_bytes(uint64_t D);
 hipError_t launch_words_differ(const void* a, const void* b, uint64_t n_bytes, uint32_t* flag, hipStream_t st);
+#define GDR_DIFFER_MAX 4
+hipError_t launch_words_differ_multi(int n, const void* const* a, const void* const* b, const uint64_t* n_bytes, uint32_t* flag,
+                                     hipStream_t st);
 
 }  // namespace gdr

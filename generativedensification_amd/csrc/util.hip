@@ -18,7 +18,43 @@ __global__ __launch_bounds__(GDR_BLOCK) void words_differ_kernel(const uint4* __
     if (__ballot(diff) != 0ull && (threadIdx.x & 63u) == 0u) atomicOr(flag, 1u);
 }
 
+struct DifferPairs { int n; const uint32_t* a[GDR_DIFFER_MAX]; const uint32_t* b[GDR_DIFFER_MAX]; uint64_t words[GDR_DIFFER_MAX]; };
+
+// the same for up to GDR_DIFFER_MAX buffer pairs in one launch (blockIdx.y = pair)
+__global__ __launch_bounds__(GDR_BLOCK) void words_differ_multi_kernel(const DifferPairs p, uint32_t* __restrict__ flag) {
+    const uint32_t* __restrict__ a = p.a[blockIdx.y];
+    const uint32_t* __restrict__ b = p.b[blockIdx.y];
+    const uint64_t n = p.words[blockIdx.y], n16 = n / 4;
+    const uint4* __restrict__ a4 = reinterpret_cast<const uint4*>(a);
+    const uint4* __restrict__ b4 = reinterpret_cast<const uint4*>(b);
+    bool diff = false;
+    for (uint64_t i = (uint64_t)blockIdx.x * GDR_BLOCK + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * GDR_BLOCK) {
+        const uint4 x = a4[i], y = b4[i];
+        diff |= (x.x != y.x) | (x.y != y.y) | (x.z != y.z) | (x.w != y.w);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (uint32_t)(n % 4)) diff |= a[4 * n16 + threadIdx.x] != b[4 * n16 + threadIdx.x];
+    if (__ballot(diff) != 0ull && (threadIdx.x & 63u) == 0u) atomicOr(flag, 1u);
+}
+
 }  // namespace
+
+hipError_t launch_words_differ_multi(int n, const void* const* a, const void* const* b, const uint64_t* n_bytes, uint32_t* flag,
+                                     hipStream_t st) {
+    DifferPairs p;
+    uint64_t most = 0;
+    p.n = n;
+    for (int k = 0; k < GDR_DIFFER_MAX; ++k) {
+        p.a[k] = k < n ? (const uint32_t*)a[k] : nullptr;
+        p.b[k] = k < n ? (const uint32_t*)b[k] : nullptr;
+        p.words[k] = k < n ? n_bytes[k] / 4 : 0;
+        most = p.words[k] > most ? p.words[k] : most;
+    }
+    if (most == 0) return hipSuccess;
+    const uint64_t n16 = most / 4;
+    const int blocks = (int)(n16 / GDR_BLOCK + 1 < 1024 ? n16 / GDR_BLOCK + 1 : 1024);
+    hipLaunchKernelGGL(words_differ_multi_kernel, dim3(blocks, n), dim3(GDR_BLOCK), 0, st, p, flag);
+    return hipGetLastError();
+}
 
 hipError_t launch_words_differ(const void* a, const void* b, uint64_t n_bytes, uint32_t* flag, hipStream_t st) {
     const uint64_t n16 = n_bytes / 16;

@@ -336,9 +336,13 @@ def forward_raw(means3D, sh, colors_precomp, opacities, scales, rotations, cov3D
         st.counters = st._view(st.geom_buf, st.geom.num_rendered, torch.int32, 2)
         if same_as:
             st.counters[1:2].zero_()
-            for t, ref in same_as:
-                L.check(lib.gdr_words_differ(C.c_void_p(t.data_ptr()), C.c_void_p(ref.data_ptr()), t.numel() * 4,
-                                             C.c_void_p(st.geom.num_rendered + 4), stream), "gdr_words_differ")
+            for k0 in range(0, len(same_as), 4):     # (one launch for up to four tensor pairs)
+                part = same_as[k0:k0 + 4]
+                a_arr = (C.c_void_p * len(part))(*[t.data_ptr() for t, _ in part])
+                b_arr = (C.c_void_p * len(part))(*[ref.data_ptr() for _, ref in part])
+                n_arr = (C.c_uint64 * len(part))(*[t.numel() * 4 for t, _ in part])
+                L.check(lib.gdr_words_differ_multi(len(part), a_arr, b_arr, n_arr, C.c_void_p(st.geom.num_rendered + 4),
+                                                   stream), "gdr_words_differ_multi")
         differ = 0
         if cap is None:   # first call of this shape: the read-back upstream performs in every call
             d_host = C.c_uint32(0)

@@ -383,6 +383,9 @@ int gdr_view_loss_backward(const float* color, const float* target, int32_t H, i
  * 32-bit word.  Used by the Python boundary to verify that two calls of one render group were handed the same activated
  * tensors (see generativedensification_amd/viewgroup.py); one read of both buffers, no host synchronisation. */
 int gdr_words_differ(const void* a, const void* b, uint64_t n_bytes, uint32_t* flag, void* stream);
+/* ... for up to 4 buffer pairs in one launch (v13) */
+int gdr_words_differ_multi(int32_t n, const void* const* a, const void* const* b, const uint64_t* n_bytes, uint32_t* flag,
+                           void* stream);
 
 /* ---- host-boundary helper: n_bytes from device memory to PINNED host memory behind the work queued on `stream`, with an
  * event the library pools (v13).  *ticket identifies the copy; gdr_host_copy_wait blocks until it has landed and releases
