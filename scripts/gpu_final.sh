@@ -45,6 +45,11 @@ for wl in c4 c3 c2 c5; do
 done
 echo "--- kernel timeline of a C4 step + idle gaps"
 bash scripts/gpu_timeline.sh c4 --no-per-view-leg > /dev/null 2>&1; cp gpurun_out/timeline_c4.txt $O/${TAG}_timeline_c4.txt; head -12 $O/${TAG}_timeline_c4.txt | grep "^step"
+echo "--- the unchanged caller's loop: kernel timeline + GPU-busy fraction (C4 GPU-bound, C2 host-bound); chain starts without a profiler"
+for wl in c4 c2; do bash scripts/gpu_timeline_pv.sh $wl > /dev/null 2>&1; cp gpurun_out/timeline_pv_$wl.txt $O/${TAG}_timeline_pv_$wl.txt; grep "^step [23]" $O/${TAG}_timeline_pv_$wl.txt; done
+for wl in c4 c3 c2; do echo $wl; python scripts/chain_start_events.py $wl 2>/dev/null | tail -4; done | tee $O/${TAG}_chain_starts.txt | grep "back to back"
+python scripts/host_split.py 2>/dev/null | tail -1 | tee $O/${TAG}_host_split.txt
+python scripts/host_split2.py 2>/dev/null | grep "us per call" | head -16 >> $O/${TAG}_host_split.txt
 echo "--- abs-grad entry + device top-k"
 python scripts/absgrad_bench.py 2>/dev/null | tee $O/${TAG}_absgrad.txt
 echo "--- size sweep (every frac must stay <= 1; traffic null off the recorded scene)"
