@@ -182,15 +182,16 @@ __device__ __forceinline__ void row_lists_clear(RowLists& rl, uint32_t wave) {
 }
 
 // append group g's entries (one per lane) to the row lists; n[r] = list lengths so far (wave-uniform)
+// (mine[r] = this lane's own vote in m[r]: handed over instead of being fished out of the 64-bit mask again)
 __device__ __forceinline__ void row_lists_append(RowLists& rl, uint32_t wave, int g, uint64_t m0, uint64_t m1, uint64_t m2,
-                                                 uint64_t m3, int (&n)[4]) {
+                                                 uint64_t m3, const bool (&mine)[4], int (&n)[4]) {
     const uint32_t lane = lane_id();
     const uint16_t e = (uint16_t)(g * GDR_WAVE + (int)lane);
     const uint64_t m[4] = {m0, m1, m2, m3};
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(m[r] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m[r], (uint32_t)n[r]));
-        if ((m[r] >> lane) & 1ull) rl.idx[wave][r][pos] = e;
+        if (mine[r]) rl.idx[wave][r][pos] = e;
         n[r] += __popcll(m[r]);
     }
 }

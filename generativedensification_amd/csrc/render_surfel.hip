@@ -65,14 +65,15 @@ __device__ __forceinline__ void null_entry(SurfelLds& s) {
 }
 
 __device__ __forceinline__ void block_masks(const SurfelLds& s, int g, float XA, float YA, bool a0, bool a1, bool a2,
-                                            bool a3, uint64_t& m0, uint64_t& m1, uint64_t& m2, uint64_t& m3) {
+                                            bool a3, uint64_t& m0, uint64_t& m1, uint64_t& m2, uint64_t& m3, bool (&mine)[4]) {
     const float4 b = s.box[g * GDR_WAVE + (int)lane_id()];
     const bool x0 = b.z >= XA && b.x <= XA + 3.f, x1 = b.z >= XA + 4.f && b.x <= XA + 7.f;
     const bool y0 = b.w >= YA && b.y <= YA + 3.f, y1 = b.w >= YA + 4.f && b.y <= YA + 7.f;
-    m0 = __ballot(x0 && y0 && a0);
-    m1 = __ballot(x1 && y0 && a1);
-    m2 = __ballot(x0 && y1 && a2);
-    m3 = __ballot(x1 && y1 && a3);
+    mine[0] = x0 && y0 && a0; mine[1] = x1 && y0 && a1; mine[2] = x0 && y1 && a2; mine[3] = x1 && y1 && a3;
+    m0 = __ballot(mine[0]);
+    m1 = __ballot(mine[1]);
+    m2 = __ballot(mine[2]);
+    m3 = __ballot(mine[3]);
 }
 
 // ray-splat intersection and Gaussian weight of one pixel against one staged surfel
@@ -171,9 +172,10 @@ __global__ __launch_bounds__(GDR_BLOCK) void surfel_render_fwd_kernel(
 #pragma unroll 1
         for (int g = 0; g < GDR_BLOCK / GDR_WAVE; ++g) {
             uint64_t m0, m1, m2, m3;
+            bool mine[4];
             block_masks(lds, g, XA, YA, (live & GDR_ROW_MASK(0)) != 0ull, (live & GDR_ROW_MASK(1)) != 0ull,
-                        (live & GDR_ROW_MASK(2)) != 0ull, (live & GDR_ROW_MASK(3)) != 0ull, m0, m1, m2, m3);
-            row_lists_append(rlists, wave, g, m0, m1, m2, m3, n);
+                        (live & GDR_ROW_MASK(2)) != 0ull, (live & GDR_ROW_MASK(3)) != 0ull, m0, m1, m2, m3, mine);
+            row_lists_append(rlists, wave, g, m0, m1, m2, m3, mine, n);
         }
         const int nmax = max(max(n[0], n[1]), max(n[2], n[3]));
         if (nmax == 0) continue;
@@ -384,9 +386,10 @@ __global__ __launch_bounds__(GDR_BLOCK) void surfel_render_bwd_kernel(
             const int gtop = top - g * GDR_WAVE;  // position of this group's entry 0
             if (gtop - (GDR_WAVE - 1) >= wave_last) continue;
             uint64_t m0, m1, m2, m3;
+            bool mine[4];
             const int mypos = gtop - (int)lane;
-            block_masks(lds, g, XA, YA, mypos < rl0, mypos < rl1, mypos < rl2, mypos < rl3, m0, m1, m2, m3);
-            row_lists_append(rlists, wave, g, m0, m1, m2, m3, n);
+            block_masks(lds, g, XA, YA, mypos < rl0, mypos < rl1, mypos < rl2, mypos < rl3, m0, m1, m2, m3, mine);
+            row_lists_append(rlists, wave, g, m0, m1, m2, m3, mine, n);
         }
         const int nmax = max(max(n[0], n[1]), max(n[2], n[3]));
         if (nmax == 0) continue;
