@@ -249,6 +249,39 @@ def test_surfel_hip_vs_oracle_at_c5_size(oracle_built):
     U.assert_grads_surfel(hg, g64, g32, GRAD_KEYS, "c5", max_outside=U.MAX_OUTSIDE)
 
 
+def test_surfel_whole_image_at_c5_size(oracle_built):
+    """The 2DGS path on the WHOLE 800x800 image at C5 size (500 k surfels): colour and the six geometric maps of every pixel,
+    and every gradient element with a random upstream gradient on every pixel and channel (distortion included)."""
+    from oracle.gsr_oracle import SurfelOracle
+    if (os.cpu_count() or 1) < 8:
+        pytest.skip("whole-image oracle runs need a multi-core host")
+    sc, cam, H, W, deg = _scene("c5")
+    case = _case_from_scene(sc, cam, H, W, deg, surfel=True)
+    kw = dict(shs=U._np(case["shs"]), scales=U._np(case["scales"]), rotations=U._np(case["rotations"]))
+    g = torch.Generator().manual_seed(11)
+    grads = [torch.randn(3, H, W, generator=g), torch.randn(7, H, W, generator=g)]
+    h, hg = U.run_surfel_hip(case, grads)
+    out = {}
+    for dt in ("f32", "f64"):
+        ora = SurfelOracle(dt, nthreads=THREADS)
+        f = ora.forward(U._np(case["means3D"]), U._np(case["opacities"]), U.settings_np(case), **kw)
+        out[dt] = ora.backward(f, *[U._np(x) for x in grads])
+        if dt == "f32":
+            o = f
+    assert h["num_rendered"] == o["num_rendered"] > 1_000_000
+    assert U.outlier_fraction(h["color"], o["color"], rtol=1e-4, atol=1e-5) < 1e-4
+    for c in range(6):
+        assert U.outlier_fraction(h["allmap"][c], o["allmap"][c], rtol=1e-4, atol=1e-4) < 2e-4, c
+    p = U.psnr(np.clip(h["color"], 0, 1), np.clip(o["color"], 0, 1))
+    print(f"[c5 whole image] D = {o['num_rendered']}, PSNR {p:.1f} dB")
+    assert p > 60.0
+    # (a), (b) as everywhere (measured: 1.0e-4 .. 1.0e-3 of the elements outside against the f32 oracle, HIP closer to float64
+    # than the oracle in every tensor).  (c), the single worst element of 0.5 M x 59: with a gradient on every pixel and
+    # channel it is one ill-conditioned surfel, a different one for every fp32 evaluation order — the oracle's worst sits
+    # 3.8e-3 .. 5.4e-2 (max-norm) from float64, HIP's 1.0 .. 2.2 x that: asserted within 3 x instead of 1.25 x.
+    U.assert_grads_surfel(hg, out["f64"], out["f32"], GRAD_KEYS, "c5 whole image", worst_factor=3.0)
+
+
 # --------------------------------------------------------------------------------------------------------------------
 # §8f entry points against torch float64 autograd through the f64 oracle
 # --------------------------------------------------------------------------------------------------------------------
