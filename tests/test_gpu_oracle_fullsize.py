@@ -448,7 +448,8 @@ def test_screenspace_absgrad_and_topk_vs_oracle(oracle_built):
     assert len(got) == k and sure_in <= got and not (got & sure_out)
 
 
-def test_surfel_render_views_backward_vs_oracle(oracle_built):
+@pytest.mark.parametrize("size", ["small", "c5"])
+def test_surfel_render_views_backward_vs_oracle(oracle_built, size):
     """The 2DGS multi-view node (K1s / K9s for all views, activations folded in) against torch autograd through the
     SURFEL ORACLE stand-in, one call per view (renderer_2dgs.py:92-96, 224-234 semantics) — round 1 only compared it
     with the per-view HIP sequence.  Upstream: random gradients on the colour and on all seven allmap channels
@@ -458,8 +459,13 @@ def test_surfel_render_views_backward_vs_oracle(oracle_built):
     from generativedensification_amd.synthetic import make_scene
     from oracle.gsr_oracle import make_surfel_standin_module
     dev = torch.device("cuda:0")
-    V, n, h, w, deg = 3, 20_000, 144, 176, 2
-    sc = make_scene(n, 81, sh_degree=deg, sigma0=(0.0052, 0.02))
+    if size == "c5":   # the C5 bench step's node: 500 k surfels, four 800x800 views in one node
+        if (os.cpu_count() or 1) < 16:
+            pytest.skip("eight surfel-oracle passes over 500 k surfels need a many-core host")
+        V, n, h, w, deg, sig, f32_threads = 4, 500_000, 800, 800, 3, (0.0052, 0.00065), THREADS
+    else:
+        V, n, h, w, deg, sig, f32_threads = 3, 20_000, 144, 176, 2, (0.0052, 0.02), 1
+    sc = make_scene(n, 81 if size == "small" else 5, sh_degree=deg, sigma0=sig)
     sc["scales"] = sc["scales"][:, :2].contiguous()
     cams = orbit_cameras(V, w, h)
     g = torch.Generator().manual_seed(5)
@@ -467,7 +473,7 @@ def test_surfel_render_views_backward_vs_oracle(oracle_built):
     ga = [torch.randn(7, h, w, generator=g) for _ in range(V)]
 
     def oracle_ref(precision):
-        mod = make_surfel_standin_module(precision, nthreads=1 if precision == "f32" else THREADS)
+        mod = make_surfel_standin_module(precision, nthreads=f32_threads if precision == "f32" else THREADS)
         dt = torch.float32 if precision == "f32" else torch.float64
         leaves = {k: v.to(dt).clone().requires_grad_(True) for k, v in sc.items()}
         ssp = torch.zeros(n, 4, dtype=dt, requires_grad=True)
@@ -502,4 +508,8 @@ def test_surfel_render_views_backward_vs_oracle(oracle_built):
         total = total + (o["color"] * gc[v].to(dev)).sum() + (o["allmap"] * ga[v].to(dev)).sum()
     grads = torch.autograd.grad(total, list(leaves.values()) + [ssp])
     g_hip = {k: x.cpu().numpy() for k, x in zip(list(leaves) + ["ssp"], grads)}
-    U.assert_grads_surfel(g_hip, g64, g32, list(g32), "surfel render_views")
+    # (C5 size, four views, unit-variance gradients on every channel of every pixel: (a) and (b) as everywhere — measured
+    # 2.7e-4 .. 1.3e-3 of the elements outside (bar 1.5e-3), HIP closer to float64 than the oracle in every tensor; (c), the
+    # single worst element: the oracle's sits 1e-3 .. 2.7e-2 from float64, HIP's 1.0 .. 3.2 x that — one ill-conditioned surfel,
+    # see test_surfel_whole_image_at_c5_size — within 4 x.)
+    U.assert_grads_surfel(g_hip, g64, g32, list(g32), "surfel render_views " + size, worst_factor=1.25 if size == "small" else 4.0)

@@ -261,6 +261,8 @@ def assert_grads(hg, g64, g32, keys, what, max_outside=MAX_OUTSIDE, rtol=1e-4, a
 #       of 6000 20-50 px surfels) — HIP is as accurate as the reference's fp32 program;
 #   (c) max-norm: HIP no further from the f32 oracle than 2 x the oracle's own distance from float64 (+1e-4), and no
 #       further from float64 than 1.25 x the oracle's (+1e-5) or the north-star's absolute 1e-4.
+#       (`worst_factor`: the whole-image / four-view tests at C5 size, where the single worst of 0.5 M x 59 elements is one
+#       ill-conditioned surfel and a different one for every fp32 evaluation order, state their own factor and measurements.)
 SURFEL_ATOL_REL = 1e-5
 SURFEL_MAX_OUTSIDE = 1.5e-3
 
@@ -284,4 +286,4 @@ def assert_grads_surfel(hg, g64, g32, keys, what, max_outside=SURFEL_MAX_OUTSIDE
         few = 2.01 / max(r32.size, 1)                                        # two elements of a small array
         assert out < max(max_outside, few), (what, k, "(a)", out)
         assert o_h64 <= 1.25 * o_3264 + max(5e-4, few), (what, k, "(b)", o_h64, o_3264)
-        assert maxn <= 2.0 * m_3264 + 1e-4 and m_h64 <= max(worst_factor * m_3264 + 1e-5, 1e-4), (what, k, "(c)", maxn, m_h64, m_3264)
+        assert maxn <= max(2.0, worst_factor) * m_3264 + 1e-4 and m_h64 <= max(worst_factor * m_3264 + 1e-5, 1e-4), (what, k, "(c)", maxn, m_h64, m_3264)
