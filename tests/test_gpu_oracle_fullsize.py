@@ -419,6 +419,28 @@ def test_bench_step_at_c4_size_vs_oracle(oracle_built):
     # Gaussians, sums over four views), HIP and the f32 oracle at the SAME distance (asserted, x 1.25); between the two fp32
     # evaluations the worst element differs by 2e-4 .. 2.0e-3, 8e-6 .. 4.2e-5 of the elements are outside — bars 3e-3 / 3e-4.
     _assert_grads(g_hip, g64, g32, list(g32), "c4 bench step", maxnorm=3e-3, max_outside=3e-4)
+    # ... and the same step through the UNCHANGED caller's loop (bench.py's `per_view`): render_img per view with torch
+    # activations and a new carrier per call, torch loss, one backward — the four calls form a render group (viewgroup.py)
+    from generativedensification_amd import viewgroup as VG
+    r2 = Renderer(sh_degree=deg, fused=False)
+    leaves2 = {k: v.to(dev).clone().requires_grad_(True) for k, v in sc.items()}
+    cams_d, tg_d = _cams_to(cams, dev), tg.to(dev)
+    losses2, carriers = [], []
+    for j, cam in enumerate(cams_d):
+        r2.set_bg_color(bgs[j].to(dev))
+        ssp_j = torch.zeros(N, 4, device=dev, requires_grad=True)
+        out = r2.render_img(cam, None, leaves2["centers"], leaves2["shs"], leaves2["opacity"], leaves2["scales"],
+                            leaves2["rotations"], dev, screenspace_points=ssp_j)
+        losses2.append(view_loss(out, tg_d[j]))
+        carriers.append(ssp_j)
+    lv2 = torch.stack(losses2)
+    live = [g() for g in VG._GROUPS.values()]
+    assert any(g is not None and g.n_views == V for g in live), "the four calls did not form one render group"
+    np.testing.assert_allclose(lv2.detach().cpu().numpy(), l32, rtol=2e-5)
+    grads2 = torch.autograd.grad(lv2.sum(), list(leaves2.values()) + carriers)
+    g_hip2 = {k: g.cpu().numpy() for k, g in zip(list(leaves2), grads2[:len(leaves2)])}
+    g_hip2["ssp"] = sum(g.cpu().numpy() for g in grads2[len(leaves2):])     # (the oracle's one carrier = the sum over the views)
+    _assert_grads(g_hip2, g64, g32, list(g32), "c4 bench step, unchanged caller", maxnorm=3e-3, max_outside=3e-4)
 
 
 def test_screenspace_absgrad_and_topk_vs_oracle(oracle_built):
