@@ -19,6 +19,7 @@ LIB_PATH = os.environ.get("GDR_LIB_PATH") or os.path.join(_HERE, "lib", "libgdr_
 GDR_OK = 0
 GDR_IN_RAW_OPACITY, GDR_IN_RAW_SCALES, GDR_IN_RAW_ROTATIONS, GDR_IN_NO_DEPTH_TO_MEAN = 1, 2, 4, 8
 GDR_MAX_VIEWS = 8
+ABI_VERSION = 14
 GDR_DEFAULT_SEG_LEN = 256
 GDR_ERR_WORKSPACE = -4
 
@@ -143,6 +144,16 @@ _PROTOS = {
                                                C.POINTER(GdrGeom), C.POINTER(C.c_void_p), C.c_void_p]),
     "gdr_render_backward": (C.c_int, [C.POINTER(GdrSettings), C.c_int32, C.POINTER(GdrGeom), C.POINTER(GdrBinning),
                                       C.POINTER(GdrImage), C.POINTER(GdrGradInputs), C.c_void_p, C.c_void_p]),
+    "gdr_render_backward_views": (C.c_int, [C.c_int32, C.POINTER(GdrSettings), C.c_int32, C.POINTER(GdrGeom),
+                                            C.POINTER(GdrBinning), C.POINTER(GdrImage), C.POINTER(GdrGradInputs),
+                                            C.POINTER(C.c_void_p), C.c_int32, C.c_void_p]),
+    "gdr_render_backward_loss_views": (C.c_int, [C.c_int32, C.POINTER(GdrSettings), C.c_int32, C.POINTER(GdrGeom),
+                                                 C.POINTER(GdrBinning), C.POINTER(GdrImage), C.POINTER(C.c_void_p),
+                                                 C.POINTER(C.c_void_p), C.c_float, C.c_float, C.c_void_p,
+                                                 C.POINTER(C.c_void_p), C.c_int32, C.c_void_p]),
+    "gdr_render_backward_mean2d_views": (C.c_int, [C.c_int32, C.POINTER(GdrSettings), C.c_int32, C.POINTER(GdrGeom),
+                                                   C.POINTER(GdrBinning), C.POINTER(GdrImage), C.POINTER(C.c_void_p),
+                                                   C.c_void_p, C.c_int32, C.c_void_p]),
     "gdr_render_backward_mean2d": (C.c_int, [C.POINTER(GdrSettings), C.c_int32, C.POINTER(GdrGeom), C.POINTER(GdrBinning),
                                              C.POINTER(GdrImage), C.c_void_p, C.c_void_p, C.c_void_p]),
     "gdr_render_backward_mean2d_loss": (C.c_int, [C.POINTER(GdrSettings), C.c_int32, C.POINTER(GdrGeom), C.POINTER(GdrBinning),
@@ -218,7 +229,7 @@ def load():
             fn = getattr(lib, name)  # AttributeError if the symbol is missing
             fn.restype = res
             fn.argtypes = args
-        if lib.gdr_abi_version() != 13:
+        if lib.gdr_abi_version() != ABI_VERSION:
             raise RuntimeError("libgdr_hip.so ABI version mismatch")
         tag = (lib.gdr_build_tag() or b"").decode()
         if tag != "release" and os.environ.get("GDR_ALLOW_EXPERIMENTAL_LIB") != "1":

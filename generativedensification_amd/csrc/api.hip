@@ -586,6 +586,77 @@ int gdr_render_backward(const gdr_settings* s, int32_t N, const gdr_geom* geom, 
     return debug_sync(s, "render_bwd", st);
 }
 
+// K7 of V views in one launch (round 4).  Every view's record is cleared here unless its bins[v].grad_rec_cleared says
+// the caller did.
+static int check_bwd_views(int32_t V, const gdr_settings* s, const gdr_geom* geoms, const gdr_binning* bins,
+                           const gdr_image* imgs, const char* what) {
+    if (V < 1 || V > GDR_MAX_VIEWS) { set_error("views: V out of range", hipSuccess); return GDR_ERR_UNSUPPORTED; }
+    if (!s || !geoms || !bins || !imgs) { set_error(what, hipSuccess); return GDR_ERR_INVALID_ARG; }
+    for (int v = 0; v < V; ++v)
+        if (!s[v].bg || s[v].image_width != s[0].image_width || s[v].image_height != s[0].image_height) {
+            set_error("views: bg NULL or image sizes differ", hipSuccess);
+            return GDR_ERR_INVALID_ARG;
+        }
+    return GDR_OK;
+}
+
+int gdr_render_backward_views(int32_t V, const gdr_settings* s, int32_t N, const gdr_geom* geoms, const gdr_binning* bins,
+                              const gdr_image* imgs, const gdr_grad_inputs* gins, float* const* grad_recs,
+                              int32_t interleave, void* stream) {
+    int rc = check_bwd_views(V, s, geoms, bins, imgs, "render_backward_views: NULL argument");
+    if (rc) return rc;
+    if (N <= 0) return GDR_OK;
+    if (!gins || !grad_recs) { set_error("render_backward_views: NULL argument", hipSuccess); return GDR_ERR_INVALID_ARG; }
+    hipStream_t st = (hipStream_t)stream;
+    for (int v = 0; v < V; ++v) {
+        if (!gins[v].dL_dcolor || !grad_recs[v]) { set_error("render_backward_views: NULL view buffer", hipSuccess); return GDR_ERR_INVALID_ARG; }
+        if (!bins[v].grad_rec_cleared) {
+            hipError_t e = hipMemsetAsync(grad_recs[v], 0, (size_t)N * 16 * sizeof(float), st);
+            if (e != hipSuccess) return hip_fail("memset gradient records", e);
+        }
+    }
+    hipError_t e = launch_render_bwd_views(V, s, geoms, bins, imgs, gins, grad_recs, interleave, st);
+    if (e != hipSuccess) return hip_fail("render_bwd_views", e);
+    return debug_sync(&s[0], "render_bwd_views", st);
+}
+
+int gdr_render_backward_loss_views(int32_t V, const gdr_settings* s, int32_t N, const gdr_geom* geoms,
+                                   const gdr_binning* bins, const gdr_image* imgs, const float* const* colors,
+                                   const float* const* targets, float w_depth, float w_alpha, const float* g,
+                                   float* const* grad_recs, int32_t interleave, void* stream) {
+    int rc = check_bwd_views(V, s, geoms, bins, imgs, "render_backward_loss_views: NULL argument");
+    if (rc) return rc;
+    if (N <= 0) return GDR_OK;
+    if (!colors || !targets || !g || !grad_recs) { set_error("render_backward_loss_views: NULL argument", hipSuccess); return GDR_ERR_INVALID_ARG; }
+    hipStream_t st = (hipStream_t)stream;
+    for (int v = 0; v < V; ++v) {
+        if (!colors[v] || !targets[v] || !grad_recs[v]) { set_error("render_backward_loss_views: NULL view buffer", hipSuccess); return GDR_ERR_INVALID_ARG; }
+        if (!bins[v].grad_rec_cleared) {
+            hipError_t e = hipMemsetAsync(grad_recs[v], 0, (size_t)N * 16 * sizeof(float), st);
+            if (e != hipSuccess) return hip_fail("memset gradient records", e);
+        }
+    }
+    hipError_t e = launch_render_bwd_loss_views(V, s, geoms, bins, imgs, colors, targets, w_depth, w_alpha, g, grad_recs,
+                                                interleave, st);
+    if (e != hipSuccess) return hip_fail("render_bwd_loss_views", e);
+    return debug_sync(&s[0], "render_bwd_loss_views", st);
+}
+
+int gdr_render_backward_mean2d_views(int32_t V, const gdr_settings* s, int32_t N, const gdr_geom* geoms,
+                                     const gdr_binning* bins, const gdr_image* imgs, const float* const* dL_dcolors,
+                                     float* dL_dmean2D, int32_t interleave, void* stream) {
+    int rc = check_bwd_views(V, s, geoms, bins, imgs, "render_backward_mean2d_views: NULL argument");
+    if (rc) return rc;
+    if (N <= 0) return GDR_OK;
+    if (!dL_dcolors || !dL_dmean2D) { set_error("render_backward_mean2d_views: NULL argument", hipSuccess); return GDR_ERR_INVALID_ARG; }
+    for (int v = 0; v < V; ++v)
+        if (!dL_dcolors[v]) { set_error("render_backward_mean2d_views: NULL view buffer", hipSuccess); return GDR_ERR_INVALID_ARG; }
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = launch_render_bwd_mean2d_views(V, s, geoms, bins, imgs, dL_dcolors, dL_dmean2D, interleave, st);
+    if (e != hipSuccess) return hip_fail("render_bwd_mean2d_views", e);
+    return debug_sync(&s[0], "render_bwd_mean2d_views", st);
+}
+
 int gdr_render_backward_mean2d(const gdr_settings* s, int32_t N, const gdr_geom* geom,
                                const gdr_binning* bin, const gdr_image* img, const float* dL_dcolor,
                                float* dL_dmean2D, void* stream) {

@@ -144,6 +144,17 @@ hipError_t launch_render_bwd(const gdr_settings* s, const gdr_geom* g, const gdr
                              const gdr_image* img, const gdr_grad_inputs* gi,
                              const gdr_grad_outputs* go, hipStream_t st);
 
+hipError_t launch_render_bwd_views(int V, const gdr_settings* s, const gdr_geom* g, const gdr_binning* bin,
+                                   const gdr_image* img, const gdr_grad_inputs* gi, float* const* grad_recs,
+                                   int interleave, hipStream_t st);
+hipError_t launch_render_bwd_loss_views(int V, const gdr_settings* s, const gdr_geom* g, const gdr_binning* bin,
+                                        const gdr_image* img, const float* const* colors, const float* const* targets,
+                                        float w_depth, float w_alpha, const float* go, float* const* grad_recs,
+                                        int interleave, hipStream_t st);
+hipError_t launch_render_bwd_mean2d_views(int V, const gdr_settings* s, const gdr_geom* g, const gdr_binning* bin,
+                                          const gdr_image* img, const float* const* dL_dcolors, float* dL_dmean2D,
+                                          int interleave, hipStream_t st);
+
 hipError_t launch_view_loss_fwd(const float* color, const float* depth, const float* alpha, const float* target,
                                 int P, float w_depth, float w_alpha, float* loss, hipStream_t st);
 hipError_t launch_view_loss_bwd(const float* color, const float* target, int P, float w_depth, float w_alpha,

@@ -32,6 +32,7 @@
 //   * workgroups take tiles longest-list-first (tile_order), which removes the tail of a few
 //     heavy tiles; without an order the blockIdx -> tile mapping is XCD-aware.
 #include <stdlib.h>
+#include <string.h>
 
 #include "gdr_common.h"
 #include "render_common.h"
@@ -688,31 +689,65 @@ __global__ __launch_bounds__(GDR_BLOCK) void render_fwd_deep_kernel(
 // buffer — the screen-space gradient the densification step consumes (network.py:865-878); dL/ddepth and
 // dL/dalpha inputs are taken as zero (that call site differentiates an image loss only).
 // LOSS: dL/dpixel computed in the prologue from the colour K6 wrote and the target (see FusedLoss) instead of read
+// Everything K7 touches of ONE view.  The kernel takes a table of V <= GDR_MAX_VIEWS of them (round 4): the views of a
+// multi-view node are independent given the Gaussians, and one launch over V x (segments + tiles) workgroups keeps the chip
+// full across the views' tails (reference-scale scenes: a view is 1-2.5 k workgroups for 1280 resident slots) instead of V
+// launches on side streams.  `order`: how the linear workgroup id maps to (view, slot) — see render_bwd_kernel.
+struct BwdView {
+    const uint2* ranges; const uint32_t* point_list; const uint32_t* tile_order;
+    const float* bg; const float4* rec; const float* final_T; const uint32_t* n_contrib;
+    const float* dL_dpix; const float* dL_ddepthpix; const float* dL_dalphapix; float* grad_rec;
+    FusedLoss fl;
+    const uint32_t* seg_base; const float* seg_state; const uint2* seg_extra; const uint32_t* seg_count;
+    int seg_rounds, n_extra;
+};
+struct BwdViews { BwdView v[GDR_MAX_VIEWS]; };
+
 template <bool M2_ONLY, bool LOSS = false>
-__global__ __launch_bounds__(GDR_BLOCK) void render_bwd_kernel(
-    const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
-    const uint32_t* __restrict__ tile_order, int W, int H, int gx, int ntiles,
-    const float* __restrict__ bg, const float4* __restrict__ rec, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
-    const float* __restrict__ dL_dpix, const float* __restrict__ dL_ddepthpix,
-    const float* __restrict__ dL_dalphapix, float* __restrict__ grad_rec, const FusedLoss fl,
-    const uint32_t* __restrict__ seg_base, const float* __restrict__ seg_state, const uint2* __restrict__ seg_extra,
-    const uint32_t* __restrict__ seg_count, int seg_rounds, int n_extra) {
+__global__ __launch_bounds__(GDR_BLOCK) void render_bwd_kernel(const BwdViews vs, int V, int interleave, int n_extra_max,
+                                                               int W, int H, int gx, int ntiles) {
     __shared__ SliceLds lds;
     __shared__ RowLists rlists;
     __shared__ uint32_t s_id[GDR_BLOCK + 1];
 
-    // Workgroups [0, n_extra): one segment of a cut list each (the full-length segments, i.e. the longest work
-    // items, are dispatched first); workgroups [n_extra, n_extra + ntiles): one tile each — its whole list, or the
-    // last segment of a cut list.
+    // Per view: slots [0, n_extra_max): one segment of a cut list each (the full-length segments, i.e. the longest work
+    // items, are dispatched first); slots [n_extra_max, n_extra_max + ntiles): one tile each — its whole list, or the
+    // last segment of a cut list.  interleave: consecutive workgroups take the same slot of consecutive views (all
+    // views' long items first: small scenes); otherwise the views follow one another (a view's records — 128 MB at 2 M
+    // Gaussians — are not evicted by the other views' gathers).
+    uint32_t view = 0, slot = blockIdx.x;
+    if (V > 1) {
+        const uint32_t per = (uint32_t)(ntiles + n_extra_max);
+        if (interleave) { view = blockIdx.x % (uint32_t)V; slot = blockIdx.x / (uint32_t)V; }
+        else { view = blockIdx.x / per; slot = blockIdx.x - view * per; }
+    }
+    const BwdView& bv = vs.v[view];
+    const uint2* __restrict__ ranges = bv.ranges;
+    const uint32_t* __restrict__ point_list = bv.point_list;
+    const uint32_t* __restrict__ tile_order = bv.tile_order;
+    const float* __restrict__ bg = bv.bg;
+    const float4* __restrict__ rec = bv.rec;
+    const float* __restrict__ final_T = bv.final_T;
+    const uint32_t* __restrict__ n_contrib = bv.n_contrib;
+    const float* __restrict__ dL_dpix = bv.dL_dpix;
+    const float* __restrict__ dL_ddepthpix = bv.dL_ddepthpix;
+    const float* __restrict__ dL_dalphapix = bv.dL_dalphapix;
+    float* __restrict__ grad_rec = bv.grad_rec;
+    const FusedLoss& fl = bv.fl;
+    const uint32_t* __restrict__ seg_base = bv.seg_base;
+    const float* __restrict__ seg_state = bv.seg_state;
+    const uint2* __restrict__ seg_extra = bv.seg_extra;
+    const uint32_t* __restrict__ seg_count = bv.seg_count;
+    const int seg_rounds = bv.seg_rounds;
     uint32_t tile;
     int seg = -1;
-    if ((int)blockIdx.x < n_extra) {
-        if (blockIdx.x >= min(seg_count[0], (uint32_t)n_extra)) return;
-        const uint2 e = seg_extra[blockIdx.x];
+    if ((int)slot < n_extra_max) {
+        if (slot >= min(seg_count ? seg_count[0] : 0u, (uint32_t)bv.n_extra)) return;
+        const uint2 e = seg_extra[slot];
         tile = e.x;
         seg = (int)e.y;
     } else {
-        const uint32_t b = blockIdx.x - (uint32_t)n_extra;
+        const uint32_t b = slot - (uint32_t)n_extra_max;
         tile = tile_order ? tile_order[b] : xcd_remap(b, (uint32_t)ntiles);
     }
     const int tx = (int)(tile % (uint32_t)gx), ty = (int)(tile / (uint32_t)gx);
@@ -988,44 +1023,83 @@ hipError_t launch_render_fwd_lossgrad(const gdr_settings* s, const gdr_geom* g, 
     return hipGetLastError();
 }
 
+// ---- K7 launchers: every variant goes through ONE table-driven launch (V = 1 for the single-view entry points) ----
+namespace {
+struct BwdSpec {   // host side of BwdView
+    const gdr_settings* s; const gdr_geom* g; const gdr_binning* bin; const gdr_image* img;
+    const float* dL_dcolor; const float* dL_ddepth; const float* dL_dalpha;
+    FusedLoss fl;
+    float* out;      // (N,16) gradient records, or the (N,4) mean2D buffer of the M2_ONLY variants
+};
+
+template <bool M2_ONLY, bool LOSS>
+hipError_t launch_bwd_table(int V, const BwdSpec* sp, int interleave, hipStream_t st) {
+    const int W = sp[0].s->image_width, H = sp[0].s->image_height;
+    const int gx = tile_grid_x(W), gy = tile_grid_y(H);
+    const int ntiles = gx * gy;
+    BwdViews vs;
+    memset(&vs, 0, sizeof(vs));
+    int n_extra_max = 0;
+    for (int v = 0; v < V; ++v) {
+        const BwdSpec& p = sp[v];
+        BwdView& b = vs.v[v];
+        b.ranges = (const uint2*)p.img->ranges; b.point_list = p.bin->values[p.bin->sorted]; b.tile_order = p.img->tile_order;
+        b.bg = p.s->bg; b.rec = (const float4*)p.g->rec; b.final_T = p.img->final_T; b.n_contrib = p.img->n_contrib;
+        b.dL_dpix = p.dL_dcolor; b.dL_ddepthpix = p.dL_ddepth; b.dL_dalphapix = p.dL_dalpha; b.grad_rec = p.out;
+        b.fl = p.fl;
+        b.seg_rounds = seg_rounds_of(p.bin, p.img);
+        b.n_extra = b.seg_rounds ? p.bin->seg_cap : 0;
+        b.seg_base = p.img->seg_base; b.seg_state = (const float*)p.bin->seg_state;
+        b.seg_extra = (const uint2*)p.bin->seg_extra; b.seg_count = p.bin->seg_count;
+        n_extra_max = b.n_extra > n_extra_max ? b.n_extra : n_extra_max;
+    }
+    const unsigned grid = (unsigned)V * (unsigned)(ntiles + n_extra_max);
+    GDR_LAUNCH(GDR_K_RENDER_BWD, (render_bwd_kernel<M2_ONLY, LOSS>), dim3(grid), dim3(GDR_BLOCK), st, vs, V, interleave,
+               n_extra_max, W, H, gx, ntiles);
+    return hipGetLastError();
+}
+}  // namespace
+
 hipError_t launch_render_bwd_loss(const gdr_settings* s, const gdr_geom* g, const gdr_binning* bin,
                                   const gdr_image* img, const float* color, const float* target, float w_depth,
                                   float w_alpha, const float* go, float* grad_rec, hipStream_t st) {
-    const int W = s->image_width, H = s->image_height;
-    const int gx = tile_grid_x(W), gy = tile_grid_y(H);
-    const int ntiles = gx * gy;
-    const FusedLoss fl{target, w_depth, w_alpha, nullptr, go, color, 1.f};
-    GDR_LAUNCH(GDR_K_RENDER_BWD, (render_bwd_kernel<false, true>), GDR_BWD_GRID(bin, img, ntiles), dim3(GDR_BLOCK), st,
-               (const uint2*)img->ranges, bin->values[bin->sorted], img->tile_order, W, H, gx, ntiles, s->bg,
-               (const float4*)g->rec, img->final_T, img->n_contrib, nullptr, nullptr, nullptr, grad_rec, fl,
-               GDR_SEG_BWD_ARGS(bin, img));
-    return hipGetLastError();
+    const BwdSpec sp{s, g, bin, img, nullptr, nullptr, nullptr, FusedLoss{target, w_depth, w_alpha, nullptr, go, color, 1.f}, grad_rec};
+    return launch_bwd_table<false, true>(1, &sp, 0, st);
 }
 
 hipError_t launch_render_bwd(const gdr_settings* s, const gdr_geom* g, const gdr_binning* bin,
                              const gdr_image* img, const gdr_grad_inputs* gi,
                              const gdr_grad_outputs* go, hipStream_t st) {
-    const int W = s->image_width, H = s->image_height;
-    const int gx = tile_grid_x(W), gy = tile_grid_y(H);
-    const int ntiles = gx * gy;
-    GDR_LAUNCH(GDR_K_RENDER_BWD, render_bwd_kernel<false>, GDR_BWD_GRID(bin, img, ntiles), dim3(GDR_BLOCK), st,
-               (const uint2*)img->ranges, bin->values[bin->sorted], img->tile_order, W, H, gx, ntiles, s->bg,
-               (const float4*)g->rec, img->final_T, img->n_contrib, gi->dL_dcolor, gi->dL_ddepth, gi->dL_dalpha,
-               go->scratch, FusedLoss{}, GDR_SEG_BWD_ARGS(bin, img));
-    return hipGetLastError();
+    const BwdSpec sp{s, g, bin, img, gi->dL_dcolor, gi->dL_ddepth, gi->dL_dalpha, FusedLoss{}, go->scratch};
+    return launch_bwd_table<false, false>(1, &sp, 0, st);
+}
+
+// K7 of V <= GDR_MAX_VIEWS views of one image size in ONE launch (gdr_render_backward_views / _loss_views)
+hipError_t launch_render_bwd_views(int V, const gdr_settings* s, const gdr_geom* g, const gdr_binning* bin,
+                                   const gdr_image* img, const gdr_grad_inputs* gi, float* const* grad_recs,
+                                   int interleave, hipStream_t st) {
+    BwdSpec sp[GDR_MAX_VIEWS];
+    for (int v = 0; v < V; ++v)
+        sp[v] = BwdSpec{&s[v], &g[v], &bin[v], &img[v], gi[v].dL_dcolor, gi[v].dL_ddepth, gi[v].dL_dalpha, FusedLoss{}, grad_recs[v]};
+    return launch_bwd_table<false, false>(V, sp, interleave, st);
+}
+
+hipError_t launch_render_bwd_loss_views(int V, const gdr_settings* s, const gdr_geom* g, const gdr_binning* bin,
+                                        const gdr_image* img, const float* const* colors, const float* const* targets,
+                                        float w_depth, float w_alpha, const float* go, float* const* grad_recs,
+                                        int interleave, hipStream_t st) {
+    BwdSpec sp[GDR_MAX_VIEWS];
+    for (int v = 0; v < V; ++v)
+        sp[v] = BwdSpec{&s[v], &g[v], &bin[v], &img[v], nullptr, nullptr, nullptr,
+                        FusedLoss{targets[v], w_depth, w_alpha, nullptr, go + v, colors[v], 1.f}, grad_recs[v]};
+    return launch_bwd_table<false, true>(V, sp, interleave, st);
 }
 
 hipError_t launch_render_bwd_mean2d(const gdr_settings* s, const gdr_geom* g, const gdr_binning* bin,
                                     const gdr_image* img, const float* dL_dcolor, float* dL_dmean2D,
                                     hipStream_t st) {
-    const int W = s->image_width, H = s->image_height;
-    const int gx = tile_grid_x(W), gy = tile_grid_y(H);
-    const int ntiles = gx * gy;
-    GDR_LAUNCH(GDR_K_RENDER_BWD, render_bwd_kernel<true>, GDR_BWD_GRID(bin, img, ntiles), dim3(GDR_BLOCK), st,
-               (const uint2*)img->ranges, bin->values[bin->sorted], img->tile_order, W, H, gx, ntiles, s->bg,
-               (const float4*)g->rec, img->final_T, img->n_contrib, dL_dcolor, nullptr, nullptr, dL_dmean2D, FusedLoss{},
-               GDR_SEG_BWD_ARGS(bin, img));
-    return hipGetLastError();
+    const BwdSpec sp{s, g, bin, img, dL_dcolor, nullptr, nullptr, FusedLoss{}, dL_dmean2D};
+    return launch_bwd_table<true, false>(1, &sp, 0, st);
 }
 
 // abs-grad-only K7 with the MSE loss folded into its prologue (network.py:865-878 differentiates an image
@@ -1033,15 +1107,18 @@ hipError_t launch_render_bwd_mean2d(const gdr_settings* s, const gdr_geom* g, co
 hipError_t launch_render_bwd_mean2d_loss(const gdr_settings* s, const gdr_geom* g, const gdr_binning* bin,
                                          const gdr_image* img, const float* color, const float* target, const float* go,
                                          float* dL_dmean2D, hipStream_t st) {
-    const int W = s->image_width, H = s->image_height;
-    const int gx = tile_grid_x(W), gy = tile_grid_y(H);
-    const int ntiles = gx * gy;
-    const FusedLoss fl{target, 0.f, 0.f, nullptr, go, color, 1.f};
-    GDR_LAUNCH(GDR_K_RENDER_BWD, (render_bwd_kernel<true, true>), GDR_BWD_GRID(bin, img, ntiles), dim3(GDR_BLOCK), st,
-               (const uint2*)img->ranges, bin->values[bin->sorted], img->tile_order, W, H, gx, ntiles, s->bg,
-               (const float4*)g->rec, img->final_T, img->n_contrib, nullptr, nullptr, nullptr, dL_dmean2D, fl,
-               GDR_SEG_BWD_ARGS(bin, img));
-    return hipGetLastError();
+    const BwdSpec sp{s, g, bin, img, nullptr, nullptr, nullptr, FusedLoss{target, 0.f, 0.f, nullptr, go, color, 1.f}, dL_dmean2D};
+    return launch_bwd_table<true, true>(1, &sp, 0, st);
+}
+
+// the abs-grad-only K7 of V views accumulating into ONE (N,4) buffer (gdr_render_backward_mean2d_views)
+hipError_t launch_render_bwd_mean2d_views(int V, const gdr_settings* s, const gdr_geom* g, const gdr_binning* bin,
+                                          const gdr_image* img, const float* const* dL_dcolors, float* dL_dmean2D,
+                                          int interleave, hipStream_t st) {
+    BwdSpec sp[GDR_MAX_VIEWS];
+    for (int v = 0; v < V; ++v)
+        sp[v] = BwdSpec{&s[v], &g[v], &bin[v], &img[v], dL_dcolors[v], nullptr, nullptr, FusedLoss{}, dL_dmean2D};
+    return launch_bwd_table<true, false>(V, sp, interleave, st);
 }
 
 }  // namespace gdr

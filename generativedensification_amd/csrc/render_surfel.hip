@@ -82,19 +82,52 @@ struct Hit {
     bool use3d, geom_ok;
 };
 
+// GSR_PRECISE (default): the two places where the ray-splat intersection amplifies an ulp — the dehomogenisation
+// (u, v) = (cx, cy) / cz of a cross product that has already cancelled (k = x Tw - Tu: ~800 * 2 against ~1600), and the
+// exponent -rho/2 * log2(e) — are evaluated to the accuracy of the reference's division and expf: the hardware reciprocal
+// gets one Newton step and each quotient one residual correction (2 + 2 x 2 fma: correctly rounded in all but rare
+// cases), the product rho * (-log2(e)/2) carries its rounding error and the constant's low part into the result
+// (exp2(hi) (1 + lo ln 2): 4 operations).  Round-3 verdict: with plain v_rcp_f32 / v_exp_f32 the worst gradient element at
+// C5 size sat 2.5x further from float64 than the f32 oracle's (profiles/r03_fullsize_parity.log); cost and result of
+// this form: DESIGN.md section 9.  -DGSR_PRECISE=0 = the round-3 arithmetic (A/B builds only).
+#ifndef GSR_PRECISE
+#define GSR_PRECISE 1
+#endif
 __device__ __forceinline__ void intersect(const SEntry& en, float pxf, float pyf, Hit& h) {
     h.kx = fmaf(pxf, en.tw.x, -en.tu.x); h.ky = fmaf(pxf, en.tw.y, -en.tu.y); h.kz = fmaf(pxf, en.tw.z, -en.tu.z);
     h.lx = fmaf(pyf, en.tw.x, -en.tv.x); h.ly = fmaf(pyf, en.tw.y, -en.tv.y); h.lz = fmaf(pyf, en.tw.z, -en.tv.z);
     const float cx = h.ky * h.lz - h.kz * h.ly, cy = h.kz * h.lx - h.kx * h.lz, cz = h.kx * h.ly - h.ky * h.lx;
+#if GSR_PRECISE
+    {
+        const float r0 = __builtin_amdgcn_rcpf(cz);
+        const float r = fmaf(fmaf(-cz, r0, 1.f), r0, r0);     // Newton step (NaN / inf for cz = 0: geom_ok is false then)
+        const float qx = cx * r, qy = cy * r;
+        h.rz = r;
+        h.sx = fmaf(fmaf(-qx, cz, cx), r, qx);                // quotient + residual / divisor
+        h.sy = fmaf(fmaf(-qy, cz, cy), r, qy);
+    }
+#else
     h.rz = __builtin_amdgcn_rcpf(cz);
     h.sx = cx * h.rz; h.sy = cy * h.rz;
+#endif
     const float rho3d = fmaf(h.sx, h.sx, h.sy * h.sy);
     h.dx = en.tu.w - pxf; h.dy = en.tv.w - pyf;
     const float rho2d = 2.f * fmaf(h.dx, h.dx, h.dy * h.dy);
     h.use3d = rho3d <= rho2d;
     const float rho = h.use3d ? rho3d : rho2d;
     h.depth = h.use3d ? fmaf(h.sx, en.tw.x, fmaf(h.sy, en.tw.y, en.tw.z)) : en.tw.z;
+#if GSR_PRECISE
+    {
+        constexpr float c_hi = -0.5f * GDR_LOG2E;                                  // fl(-log2(e) / 2)
+        constexpr float c_lo = (float)(-0.5 * 1.4426950408889634074 - (double)c_hi);
+        const float t_hi = rho * c_hi;
+        const float t_lo = fmaf(rho, c_lo, fmaf(rho, c_hi, -t_hi));
+        const float g0 = __builtin_amdgcn_exp2f(t_hi);
+        h.G = fmaf(g0, t_lo * GDR_LN2, g0);
+    }
+#else
     h.G = __builtin_amdgcn_exp2f((-0.5f * GDR_LOG2E) * rho);
+#endif
     h.alpha = fminf(0.99f, en.tw.w * h.G);
     h.geom_ok = cz != 0.f && h.depth >= GSR_NEAR;  // false for the null entry (cz = 0) and for NaNs
 }

@@ -77,54 +77,91 @@ def gather_view_losses(local_losses: torch.Tensor, n_views: int | None = None) -
     return torch.cat([out[r * m: r * m + sizes[r]] for r in range(world)])
 
 
-_PACKS: dict = {}   # (device, dtype, world, sizes) -> (flat buffer, per-parameter views, shard buffer)
+class _Pack:
+    """Persistent packed gradient buffer of ONE set of parameter tensors of one dtype (identified by the tensors
+    themselves, not by their shapes: two Gaussian sets of equal N — coarse / fine, two models — must never share one)."""
+    __slots__ = ("flat", "views", "shard", "refs")
+
+
+_PACKS: dict = {}   # (world, ids of the parameters) -> _Pack; the weak references guard against id() reuse
 
 
 def _grad_pack(params, world):
-    key = (params[0].device, params[0].dtype, world, tuple(tuple(p.shape) for p in params))
+    import weakref
+    key = (world, tuple(id(p) for p in params))
     pack = _PACKS.get(key)
-    if pack is None:
-        n = sum(p.numel() for p in params)
-        padded = (n + world - 1) // world * world
-        flat = torch.zeros(padded, device=params[0].device, dtype=params[0].dtype)
-        views, off = [], 0
-        for p in params:
-            views.append(flat[off: off + p.numel()].view(p.shape))
-            off += p.numel()
-        shard = torch.empty(padded // world, device=flat.device, dtype=flat.dtype)
-        if len(_PACKS) >= 8:
-            _PACKS.pop(next(iter(_PACKS)))
-        pack = _PACKS[key] = (flat, views, shard)
+    if pack is not None and all(r() is p for r, p in zip(pack.refs, params)):
+        return pack
+    for k in [k for k, v in _PACKS.items() if any(r() is None for r in v.refs)]:    # sets whose tensors are gone
+        del _PACKS[k]
+    n = sum(p.numel() for p in params)
+    padded = (n + world - 1) // world * world
+    pack = _Pack()
+    pack.flat = torch.zeros(padded, device=params[0].device, dtype=params[0].dtype)
+    pack.views, off = [], 0
+    for p in params:
+        pack.views.append(pack.flat[off: off + p.numel()].view(p.shape))
+        off += p.numel()
+    pack.shard = torch.empty(padded // world, device=pack.flat.device, dtype=pack.flat.dtype)
+    pack.refs = [weakref.ref(p) for p in params]
+    while len(_PACKS) >= 16:
+        _PACKS.pop(next(iter(_PACKS)))
+    _PACKS[key] = pack
     return pack
 
 
-def allreduce_gaussian_grads(params: Sequence[torch.Tensor]) -> None:
+CHUNK_BYTES = 64 << 20    # reduce-scatter / all-gather are issued per chunk of the packed buffer (see below)
+
+
+def allreduce_gaussian_grads(params: Sequence[torch.Tensor], chunk_bytes: int | None = None) -> None:
     """Sum the per-Gaussian attribute gradients over ranks: one packed buffer
     (236 B/Gaussian at SH degree 3) moved as reduce-scatter + all-gather so that all
     7 xGMI links of a GPU carry 1/G of it each, instead of a per-tensor ring all-reduce.
 
     Participation is unconditional and the buffer layout is rank-invariant: EVERY tensor of `params` takes part
     with its full size (a missing .grad counts as zeros), so a rank whose shard is empty
-    (n_views < world) or that produced gradients for only some tensors issues the same two collectives with the
+    (n_views < world) or that produced gradients for only some tensors issues the same collectives with the
     same sizes as every other rank.  After the call every rank holds the summed gradient in every p.grad.
 
-    The packed buffer is PERSISTENT (one per parameter-shape set) and the gradients the call leaves behind are views of
-    it: no `torch.cat` of 472 MB (2 M Gaussians), no copy back.  A training loop that keeps its gradients
-    (`zero_grad(set_to_none=False)`) has autograd accumulate straight into the buffer, and the next call moves it as it
-    is — two collectives, zero copies; a loop that drops them (`p.grad = None`) pays one copy_ into the buffer."""
+    The packed buffer is PERSISTENT — one per SET OF TENSORS (keyed on the tensors' identity, weakly referenced; tensors of
+    different dtypes get one buffer per dtype) — and the gradients the call leaves behind are views of it: no `torch.cat`
+    of 472 MB (2 M Gaussians), no copy back.  A training loop that keeps its gradients (`zero_grad(set_to_none=False)`,
+    or `p.grad.zero_()`) has autograd accumulate straight into the buffer, and the next call moves it as it
+    is — zero copies; a loop that drops them (`p.grad = None`) pays one copy_ into the buffer.
+
+    The buffer moves in contiguous chunks of `chunk_bytes` (default CHUNK_BYTES = 64 MB, rounded to a multiple of the world
+    size in elements; the padded length is a multiple of it too): all reduce-scatters are queued asynchronously, then all
+    all-gathers — the all-gather of an early chunk runs while later chunks are still being reduced, so both directions
+    of the xGMI links are busy (RCCL executes the queue in order on its stream)."""
     if _no_peers():
         return
     world = dist.get_world_size()
     params = list(params)
     if not params:
         return
-    flat, views, shard = _grad_pack(params, world)
-    for p, v in zip(params, views):
-        if p.grad is None:
-            v.zero_()
-        elif p.grad.data_ptr() != v.data_ptr() or p.grad.dtype != v.dtype:
-            v.copy_(p.grad)
-    dist.reduce_scatter_tensor(shard, flat, op=dist.ReduceOp.SUM)
-    dist.all_gather_into_tensor(flat, shard)
-    for p, v in zip(params, views):
-        p.grad = v
+    groups: dict = {}
+    for p in params:     # one pack per dtype (and device), the order within a group as given
+        groups.setdefault((p.device, p.dtype), []).append(p)
+    for group in groups.values():
+        pack = _grad_pack(group, world)
+        for p, v in zip(group, pack.views):
+            if p.grad is None:
+                v.zero_()
+            elif p.grad.data_ptr() != v.data_ptr() or p.grad.dtype != v.dtype:
+                v.copy_(p.grad)
+        flat, shard = pack.flat, pack.shard
+        # chunk c = flat[c * ce, (c + 1) * ce) is reduced and gathered on its own: rank r ends up owning the r-th world-th
+        # of EVERY chunk (shard = the concatenation of its parts), every collective works on contiguous memory
+        ce = max(world, (chunk_bytes or CHUNK_BYTES) // flat.element_size() // world * world)
+        bounds = [(lo, min(flat.numel(), lo + ce)) for lo in range(0, flat.numel(), ce)]
+        if len(bounds) <= 1:
+            dist.reduce_scatter_tensor(shard, flat, op=dist.ReduceOp.SUM)
+            dist.all_gather_into_tensor(flat, shard)
+        else:
+            work = [dist.reduce_scatter_tensor(shard[lo // world: hi // world], flat[lo:hi], op=dist.ReduceOp.SUM, async_op=True)
+                    for lo, hi in bounds]
+            work += [dist.all_gather_into_tensor(flat[lo:hi], shard[lo // world: hi // world], async_op=True) for lo, hi in bounds]
+            for w_ in work:     # (queued in order on the backend's stream: every all-gather runs behind its reduce-scatter)
+                w_.wait()
+        for p, v in zip(group, pack.views):
+            p.grad = v

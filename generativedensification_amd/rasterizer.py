@@ -162,6 +162,10 @@ FWD_STREAMS = int(_os.environ.get("GDR_FWD_STREAMS", "4"))
 # side streams of the backward (K7 of the views); unset = side_count()
 BWD_STREAMS = int(_os.environ["GDR_BWD_STREAMS"]) if _os.environ.get("GDR_BWD_STREAMS") else None
 BIN_STREAM = None     # tests: force side_count() (None = by image size)
+# K7 of a multi-view node in ONE launch (gdr_render_backward*_views, round 4) instead of one launch per view on side
+# streams: 0 = per-view launches, 1 = one launch, the views interleaved (all views' longest work items first), 2 = one
+# launch, one view after the other; None = by image size (k7_views_mode).
+K7_VIEWS = int(_os.environ["GDR_K7_VIEWS"]) if _os.environ.get("GDR_K7_VIEWS") else None
 
 
 # Segment length of cut tile lists (include/gdr.h gdr_binning.seg_len): None = the library default
@@ -197,6 +201,13 @@ def side_count(H, W):
         return BIN_STREAM
     tiles = ((W + 15) // 16) * ((H + 15) // 16)
     return 2 if tiles >= 2000 else 3
+
+
+def k7_views_mode(H, W, N):
+    """How K7 of a multi-view node is launched (K7_VIEWS above)."""
+    if K7_VIEWS is not None:
+        return K7_VIEWS
+    return 1
 
 
 _side_streams: dict = {}
@@ -449,11 +460,35 @@ def _early_records_clear(ctx, pending):
         L.check(lib.gdr_clear_async(C.c_void_p(recs.data_ptr() + v * row), row, C.c_void_p(streams[v].cuda_stream)),
                 "gdr_clear_async")
     ctx.recs = recs
+    ctx.recs_streams = list(set(streams))    # (a one-launch K7 on the caller's stream waits for these: _join_record_clears)
 
 
 def _early_records(ctx, dev, V, N, H, W, floats):
     """Both steps at the end of a forward (callers whose forward is not split yet)."""
     _early_records_clear(ctx, _early_records_begin(ctx, dev, V, N, H, W, floats))
+
+
+def _join_record_clears(ctx):
+    """The caller's stream waits for the early clears queued on the K7 side streams (one-launch K7: it runs on the caller's)."""
+    streams = getattr(ctx, "recs_streams", None)
+    if streams and getattr(ctx, "recs", None) is not None:
+        main = torch.cuda.current_stream()
+        for sd in streams:
+            ev = torch.cuda.Event()
+            ev.record(sd)
+            main.wait_event(ev)
+    ctx.recs_streams = None
+
+
+def _view_arrays(states, lo, n, cleared):
+    """ctypes arrays (geoms, binnings, images) of views [lo, lo + n) for the *_views entry points."""
+    g_arr, b_arr, i_arr = (L.GdrGeom * n)(), (L.GdrBinning * n)(), (L.GdrImage * n)()
+    for k in range(n):
+        st = states[lo + k]
+        st.bin.grad_rec_cleared = cleared
+        g_arr[k], b_arr[k], i_arr[k] = st.geom, st.bin, st.img
+        g_arr[k].cov3D = states[0].geom.cov3D
+    return g_arr, b_arr, i_arr
 
 
 def _take_records(ctx, lo, n, N, floats, dev):
@@ -849,17 +884,24 @@ class _RenderViews(torch.autograd.Function):
                 keep2 += [gc, gd, ga]
                 grads_in.append((gc, gd, ga))
             sets = [_settings_struct(rs, dev, keep2) for rs in ctx.settings_list]
-            sides = _SideViews(dev, V, H, W)  # after every torch-side preparation (the side streams wait for this point)
-            for lo, n in sides.groups():
+            mode = k7_views_mode(H, W, N) if V > 1 else 0
+            if mode:
+                _join_record_clears(ctx)
+            sides = _SideViews(dev, 1 if mode else V, H, W)  # after every torch-side preparation (the side streams wait for this point)
+            for lo in range(0, V, L.GDR_MAX_VIEWS):
+                n = min(L.GDR_MAX_VIEWS, V - lo)
                 recs, cleared = _take_records(ctx, lo, n, N, 16, dev)  # one 64-byte gradient record per Gaussian per view
                 s_arr = (L.GdrSettings * n)(*sets[lo:lo + n])
-                g_arr = (L.GdrGeom * n)()
-                for k in range(n):
+                g_arr, b_arr, i_arr = _view_arrays(states, lo, n, cleared)
+                if mode:    # K7 of the n views in one launch on the caller's stream
+                    gin_arr = (L.GdrGradInputs * n)(*[L.GdrGradInputs(gc.data_ptr(), _ptr(gd), _ptr(ga))
+                                                      for gc, gd, ga in grads_in[lo:lo + n]])
+                    rec_ptrs = (C.c_void_p * n)(*[recs[k].data_ptr() for k in range(n)])
+                    L.check(lib.gdr_render_backward_views(n, s_arr, N, g_arr, b_arr, i_arr, gin_arr, rec_ptrs, int(mode == 1),
+                                                          stream), "gdr_render_backward_views")
+                for k in range(0 if mode else n):
                     v = lo + k
                     st = states[v]
-                    st.bin.grad_rec_cleared = cleared
-                    g_arr[k] = st.geom
-                    g_arr[k].cov3D = states[0].geom.cov3D
                     gc, gd, ga = grads_in[v]
                     gin = L.GdrGradInputs(gc.data_ptr(), _ptr(gd), _ptr(ga))
                     L.check(lib.gdr_render_backward(C.byref(s_arr[k]), N, C.byref(g_arr[k]), C.byref(st.bin),
@@ -927,17 +969,25 @@ class _RenderViewsLoss(torch.autograd.Function):
             stream = _stream()
             inp = _inputs_struct(N, M, means3D, opacities, sh, e, scales, rotations, e, ctx.flags)
             sets = [_settings_struct(rs, dev, keep2) for rs in ctx.settings_list]
-            sides = _SideViews(dev, V, states[0].H, states[0].W)  # after every torch-side preparation (the side streams wait for this point)
-            for lo, n in sides.groups():
+            mode = k7_views_mode(states[0].H, states[0].W, N) if V > 1 else 0
+            if mode:
+                _join_record_clears(ctx)
+            sides = _SideViews(dev, 1 if mode else V, states[0].H, states[0].W)  # after every torch-side preparation (the side streams wait for this point)
+            for lo in range(0, V, L.GDR_MAX_VIEWS):
+                n = min(L.GDR_MAX_VIEWS, V - lo)
                 recs, cleared = _take_records(ctx, lo, n, N, 16, dev)
                 s_arr = (L.GdrSettings * n)(*sets[lo:lo + n])
-                g_arr = (L.GdrGeom * n)()
-                for k in range(n):
+                g_arr, b_arr, i_arr = _view_arrays(states, lo, n, cleared)
+                if mode:    # K7 of the n views in one launch on the caller's stream
+                    col_ptrs = (C.c_void_p * n)(*[ctx.colors[lo + k].data_ptr() for k in range(n)])
+                    tgt_ptrs = (C.c_void_p * n)(*[ctx.targets[lo + k].data_ptr() for k in range(n)])
+                    rec_ptrs = (C.c_void_p * n)(*[recs[k].data_ptr() for k in range(n)])
+                    L.check(lib.gdr_render_backward_loss_views(n, s_arr, N, g_arr, b_arr, i_arr, col_ptrs, tgt_ptrs, ctx.w[0],
+                                                               ctx.w[1], go[lo:lo + n].data_ptr(), rec_ptrs, int(mode == 1),
+                                                               stream), "gdr_render_backward_loss_views")
+                for k in range(0 if mode else n):
                     v = lo + k
                     st = states[v]
-                    st.bin.grad_rec_cleared = cleared
-                    g_arr[k] = st.geom
-                    g_arr[k].cov3D = states[0].geom.cov3D
                     L.check(lib.gdr_render_backward_loss(C.byref(s_arr[k]), N, C.byref(g_arr[k]), C.byref(st.bin),
                                                          C.byref(st.img), ctx.colors[v].data_ptr(), ctx.targets[v].data_ptr(),
                                                          ctx.w[0], ctx.w[1], go[v:v + 1].data_ptr(), recs[k].data_ptr(),
@@ -1063,8 +1113,16 @@ def screenspace_absgrad_raw(means3D, sh, opacities, scales, rotations, settings_
         with torch.cuda.device(dev):
             keep2: list = []
             structs = [_settings_struct(settings_list[v], dev, keep2) for v in range(V)]
-            sides = _SideViews(dev, V, states[0].H, states[0].W)  # the views accumulate into `grad` with atomics: any interleaving is valid
-            for v, st in enumerate(states):
+            mode = k7_views_mode(states[0].H, states[0].W, N) if V > 1 else 0
+            sides = _SideViews(dev, 1 if mode else V, states[0].H, states[0].W)  # the views accumulate into `grad` with atomics: any interleaving is valid
+            for lo in range(0, V if mode else 0, L.GDR_MAX_VIEWS):     # one launch per <= 8 views on the caller's stream
+                n = min(L.GDR_MAX_VIEWS, V - lo)
+                s_arr = (L.GdrSettings * n)(*structs[lo:lo + n])
+                g_arr, b_arr, i_arr = _view_arrays(states, lo, n, 0)
+                dc_ptrs = (C.c_void_p * n)(*[dcolors[lo + k].data_ptr() for k in range(n)])
+                L.check(lib.gdr_render_backward_mean2d_views(n, s_arr, N, g_arr, b_arr, i_arr, dc_ptrs, _ptr(grad), int(mode == 1),
+                                                             _stream()), "gdr_render_backward_mean2d_views")
+            for v, st in enumerate(states if not mode else ()):
                 g = st.geom
                 g.cov3D = states[0].geom.cov3D
                 L.check(lib.gdr_render_backward_mean2d(C.byref(structs[v]), N, C.byref(g), C.byref(st.bin), C.byref(st.img),

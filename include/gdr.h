@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define GDR_ABI_VERSION 13
+#define GDR_ABI_VERSION 14
 
 #define GDR_OK 0
 #define GDR_ERR_INVALID_ARG (-1)  /* NULL / inconsistent arguments                     */
@@ -330,6 +330,26 @@ int gdr_render_backward(const gdr_settings* s, int32_t N, const gdr_geom* geom, 
 int gdr_preprocess_backward_views(int32_t V, const gdr_settings* s, const gdr_inputs* in,
                                   const gdr_geom* geoms, const int32_t* const* radii,
                                   float* const* grad_recs, const gdr_grad_outputs* gout, void* stream);
+
+/* K7 of V <= GDR_MAX_VIEWS views of one image size in ONE launch (v14).  The views of a node are independent given the
+ * Gaussians; one launch over V x (segments + tiles) workgroups keeps the chip full across the views' kernel tails where V
+ * launches on side streams leave it to the dispatcher (reference-scale scenes: one view is 1-2.5 k workgroups for 1280
+ * resident slots).  Arrays of V structs / V device pointers (host arrays); every view writes its own N*16-float record
+ * (cleared here unless bins[v].grad_rec_cleared).  interleave != 0: consecutive workgroups take the same slot of
+ * consecutive views (all views' longest work items first); 0: the views follow one another in the grid (a view's
+ * records — 128 MB at 2 M Gaussians — are not evicted from the caches by the other views' gathers).
+ * _loss_views: g = device array of V upstream scalars (see gdr_render_backward_loss); colors / targets: V x (3,H,W).
+ * _mean2d_views: every view ADDS into the one (N,4) buffer (see gdr_render_backward_mean2d). */
+int gdr_render_backward_views(int32_t V, const gdr_settings* s, int32_t N, const gdr_geom* geoms, const gdr_binning* bins,
+                              const gdr_image* imgs, const gdr_grad_inputs* gins, float* const* grad_recs,
+                              int32_t interleave, void* stream);
+int gdr_render_backward_loss_views(int32_t V, const gdr_settings* s, int32_t N, const gdr_geom* geoms,
+                                   const gdr_binning* bins, const gdr_image* imgs, const float* const* colors,
+                                   const float* const* targets, float w_depth, float w_alpha, const float* g,
+                                   float* const* grad_recs, int32_t interleave, void* stream);
+int gdr_render_backward_mean2d_views(int32_t V, const gdr_settings* s, int32_t N, const gdr_geom* geoms,
+                                     const gdr_binning* bins, const gdr_image* imgs, const float* const* dL_dcolors,
+                                     float* dL_dmean2D, int32_t interleave, void* stream);
 
 /* ---- screen-space gradient only ----------------------------------------------
  * The densification step differentiates an image loss w.r.t. the (N,4) means2D carrier of several

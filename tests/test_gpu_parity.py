@@ -269,6 +269,57 @@ def test_fused_multiview_node_equals_per_view_sequence_on_identical_inputs(V):
     assert g_fus["ssp"].shape == (n, 4) and (g_fus["ssp"][:, 2:] >= 0).all()
 
 
+@pytest.mark.parametrize("V", [4, 9])
+def test_k7_of_all_views_in_one_launch_equals_per_view_launches(V):
+    """gdr_render_backward_views / _loss_views / _mean2d_views (round 4: K7 of the views of a node in ONE launch, the
+    views interleaved — mode 1 — or one after the other — mode 2) against one K7 launch per view on side streams (mode 0):
+    same kernel, same records, so the gradients differ by the order of the fp32 atomics only.  Lists long enough to be
+    cut (sigma 0.02: several 256-entry segments per tile), per-view bg colours, V = 9 > GDR_MAX_VIEWS (two launches)."""
+    from generativedensification_amd import rasterizer as R
+    from generativedensification_amd.camera import orbit_cameras
+    from generativedensification_amd.renderer import Renderer
+    from generativedensification_amd.synthetic import make_scene, make_targets
+
+    dev = torch.device("cuda:0")
+    n, h, w = 30_000, 160, 208
+    sc = make_scene(n, 78, sh_degree=3, sigma0=(0.0052, 0.00065, 0.02))
+    cams = orbit_cameras(V, w, h, device=dev)
+    tg = make_targets(V, h, w, 78).to(dev)
+    tg_chw = tg.permute(0, 3, 1, 2).contiguous()
+    three = ([1.0, 1.0, 1.0], [0.5, 0.5, 0.5], [0.0, 0.0, 0.0])
+    bgs = [torch.tensor(three[j % 3], device=dev) for j in range(V)]
+    wts = torch.linspace(0.5, 2.0, V, device=dev)
+    r = Renderer(sh_degree=3, fused=True)
+
+    def run(mode, entry):
+        prev, R.K7_VIEWS = R.K7_VIEWS, mode
+        try:
+            leaves = {k: v.to(dev).clone().requires_grad_(True) for k, v in sc.items()}
+            ssp = torch.zeros(n, 4, device=dev, requires_grad=True)
+            args = (leaves["centers"], leaves["shs"], leaves["opacity"], leaves["scales"], leaves["rotations"], dev)
+            if entry == "absgrad":
+                loss, grad = r.screenspace_absgrad(cams, bgs, tg, *args)
+                return {"loss": loss.detach().cpu().numpy(), "ssp": grad.cpu().numpy()}
+            if entry == "loss":
+                lv = r.render_views_loss(cams, bgs, tg_chw, *args, screenspace_points=ssp)
+            else:
+                outs = r.render_views(cams, bgs, *args, screenspace_points=ssp)
+                lv = torch.stack([((o["image"] - tg[j]) ** 2).mean() + 0.1 * o["depth"].mean() + 0.1 * o["acc_map"].mean()
+                                  for j, o in enumerate(outs)])
+            grads = torch.autograd.grad((lv * wts).sum(), list(leaves.values()) + [ssp])
+            return {k: g_.cpu().numpy() for k, g_ in zip(list(leaves) + ["ssp"], grads)}
+        finally:
+            R.K7_VIEWS = prev
+
+    for entry in ("views", "loss", "absgrad"):
+        ref = run(0, entry)
+        for mode in (1, 2):
+            got = run(mode, entry)
+            for k in ref:
+                out, worst, maxn = U.elem_stats(got[k], ref[k])
+                assert out < U.MAX_OUTSIDE and maxn < 1e-4, (entry, mode, k, out, worst, maxn)
+
+
 def test_float64_noncontiguous_inputs_and_debug_mode():
     """The boundary accepts what a caller may hand it: float64 tensors, non-contiguous views (a transposed SH block, a
     strided slice of a bigger tensor) — same result as float32 contiguous inputs, gradients come back in the callers'
