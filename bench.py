@@ -244,10 +244,77 @@ def run_c3step(args, wl, dev, rank, world, use_dist, barrier_fn):
         kernels = {nm: dict(avg_us=round(1e3 * ms / c, 2), launches_per_step=round(c / ks, 1), ms_per_step=round(ms / ks, 3))
                    for nm, (ms, c) in prof.items() if c}
         if kernels:
+            # Algorithmic bytes per STEP and kernel: a sample is three nodes over two Gaussian sets — the coarse set (n, V views,
+            # loss folded in), the abs-grad pass over it (VS views, K7 producing the (N,4) carrier gradient only, no K9) and the
+            # fine set (n_f = n_fine_new + n - k_num, V views) — so one kernel id covers launches of different sizes; the
+            # figures below are sums over the step's launches with each set's measured duplicate count
+            from generativedensification_amd import rasterizer as R
+
+            def dups(tensors, cs):
+                out = []
+                with torch.no_grad():
+                    e = torch.empty(0, device=dev)
+                    for cam in cs:
+                        rs = r_caller.set_rasterizer(cam, device=dev).raster_settings
+                        out.append(R.forward_raw(tensors[0], tensors[1], e, torch.sigmoid(tensors[2]), torch.exp(tensors[3]),
+                                                 torch.nn.functional.normalize(tensors[4]), e, rs)[-2].D)
+                return sum(out) / len(out)
+            with torch.no_grad():
+                a0 = [lc[k][0].detach() for k in keys]
+                _, _, idx0 = r_fused.screenspace_absgrad(cams[:VS], bgs[:VS], tg[:VS], *a0, dev, topk=K)
+                sel0 = torch.zeros(n, dtype=torch.bool, device=dev)
+                sel0[idx0] = True
+                f0 = [torch.cat([lf[k][0].detach(), lc[k][0].detach()[~sel0]], dim=0) for k in keys]
+            d_c, d_f, n_f = dups(a0, cams), dups(f0, cams), int(f0[0].shape[0])
+            tiles, m, P = ((w + 15) // 16) * ((h + 15) // 16), (deg + 1) ** 2, h * w
+            ac, af, av = (algorithmic_bytes(n, d_c, P, m, tiles, V), algorithmic_bytes(n_f, d_f, P, m, tiles, V),
+                          algorithmic_bytes(n, d_c, P, m, tiles, VS))
+            per_view_ids = ("tile_count", "tile_scan", "tile_order", "tile_scatter", "tile_sort", "render_fwd")
+            step_bytes = {q: B * ((V + VS) * ac[q] + V * af[q]) for q in per_view_ids}
+            step_bytes["preprocess_fwd"] = B * (ac["preprocess_fwd_views"] + av["preprocess_fwd_views"] + af["preprocess_fwd_views"])
+            step_bytes["preprocess_bwd"] = B * (ac["preprocess_bwd_views"] + af["preprocess_bwd_views"])
+            step_bytes["render_bwd"] = B * (V * ac["render_bwd"] + VS * (d_c * (44 + 16) + P * 20) + V * af["render_bwd"])
+            for q, bts in step_bytes.items():
+                if q in kernels and kernels[q]["ms_per_step"] > 0:
+                    kernels[q]["alg_bytes_per_step"] = int(bts)
+                    kernels[q]["alg_GBs"] = round(bts / (kernels[q]["ms_per_step"] * 1e-3) / 1e9, 1)
+                    kernels[q]["frac"] = round(kernels[q]["alg_GBs"] / HBM_PEAK_GBS, 4)
             dom = max(kernels, key=lambda q: kernels[q]["ms_per_step"])
-            roofline = dict(bound="hbm", kernel=dom, peak=HBM_PEAK_GBS, unit="GB/s", achieved=None, frac=None, traffic=None,
-                            avg_launch_us=kernels[dom]["avg_us"],
-                            note="mixed Gaussian sets per launch: per-kernel algorithmic bytes are reported by the c3 / c4 workloads")
+            built = sum(q.get("alg_bytes_per_step", 0) for q in kernels.values()) + B * (2 * V) * 64 * (n + n_f) // 2
+            roofline = dict(bound="hbm", kernel=dom, peak=HBM_PEAK_GBS, unit="GB/s", achieved=kernels[dom].get("alg_GBs"),
+                            frac=kernels[dom].get("frac"), traffic=None, avg_launch_us=kernels[dom]["avg_us"],
+                            alg_bytes_per_step=kernels[dom].get("alg_bytes_per_step"),
+                            path_bytes_step_built=int(built),
+                            path_frac_built=round(built / (el_f / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
+                            sets={"coarse": {"n": n, "num_rendered_per_view": int(d_c)},
+                                  "fine": {"n": n_f, "num_rendered_per_view": int(d_f)}},
+                            note="achieved / frac: the dominant kernel's algorithmic bytes summed over the step's launches "
+                                 "(two Gaussian sets, three nodes per sample) over its summed launch time")
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        import numpy as np
+        from oracle.gdr_oracle import Oracle, Settings
+        cores = os.cpu_count() or 1
+        o = Oracle("f32", nthreads=cores)
+        cam = cams[0]
+        ss = Settings(h, w, math.tan(0.375), math.tan(0.375), np.ones(3, np.float32), 1.0, cam.world_view_transform.cpu().numpy(),
+                      cam.full_proj_transform.cpu().numpy(), deg, cam.camera_center.cpu().numpy())
+        c0 = {k: lc[k][0].detach().cpu() for k in keys}
+        g = np.random.default_rng(0)
+        gcol, gdep, galp = (g.standard_normal((3, h, w), dtype=np.float32), g.standard_normal((1, h, w), dtype=np.float32),
+                            g.standard_normal((1, h, w), dtype=np.float32))
+        t0, reps = time.perf_counter(), 0
+        while True:
+            ctx = o.forward(c0["centers"].numpy(), torch.sigmoid(c0["opacity"]).numpy(), ss, shs=c0["shs"].numpy(),
+                            scales=torch.exp(c0["scales"]).numpy(), rotations=torch.nn.functional.normalize(c0["rotations"]).numpy())
+            o.backward(ctx, gcol, gdep, galp)
+            reps += 1
+            if time.perf_counter() - t0 > 10.0 or reps >= 8:
+                break
+        tc = (time.perf_counter() - t0) / reps
+        cpu_baseline = dict(value=round(1.0 / tc, 4), unit="renders/s", cores=cores, kind="port",
+                            sample=f"oracle C restatement (OpenMP, {cores} threads), {reps} x fwd+bwd of 1 coarse view {h}x{w}, "
+                                   f"{n} Gaussians ({tc:.3f} s each); a render of the fine set costs about the same")
     v_f = renders * args.steps / el_f
     v_c = renders * k_c / el_c
     return {
@@ -263,8 +330,160 @@ def run_c3step(args, wl, dev, rank, world, use_dist, barrier_fn):
                      "ms_per_sample": round(1e3 * el_c / k_c / B, 3), "steps": k_c, "of_fused": round(v_c / v_f, 3),
                      "entry": "the unchanged caller: render_img per view (torch activations, new settings + carrier per call), "
                               "torch.autograd.functional.vjp + torch.topk, losses on the width-concatenated views, one backward"},
-        "loss_fused": loss_f, "loss_per_view": loss_c, "roofline": roofline, "cpu_baseline": None, "kernels": kernels,
+        "loss_fused": loss_f, "loss_per_view": loss_c, "roofline": roofline, "cpu_baseline": cpu_baseline, "kernels": kernels,
         "spread": "same box run-to-run +-0.3 %, box-to-box +-4 % (BASELINE.md section 4)",
+        "gc": "Python's cyclic collector disabled inside the timed regions (timeit convention; collected right before)",
+    }
+
+
+def run_forward_only(args, wl, dev, rank, world, use_dist, barrier_fn):
+    """Evaluation throughput: the reference renders a turntable of ONE Gaussian set under no_grad, one `render_img` per
+    frame (/root/reference/evaluation.py:169-193: 120 frames; tools/meshExtractor.py:73-106 does the same for its depth
+    maps).  A step = `--eval-views` views of the workload's scene, forward only.  `value` = through `render_views` (chunks of
+    <= 8 views per K1 launch, the inputs read once per chunk); `per_view` = the unchanged caller (`render_img` per view with
+    torch activations: one native gdr_forward_view / gsr_forward_view call each)."""
+    import gc
+    from generativedensification_amd import _lib as L
+    from generativedensification_amd.camera import orbit_cameras
+    from generativedensification_amd.synthetic import make_scene
+
+    n, h, w, deg = args.n or wl["n"], wl["h"], wl["w"], wl["deg"]
+    surfel = bool(wl.get("surfel"))
+    V = args.eval_views
+    if args.workload == "c3" and not args.n:
+        a = make_scene(262_144, wl["seed"], sh_degree=deg, sigma0=(0.0052,), device=dev, layout=args.layout)
+        b = make_scene(81_600, wl["seed"] + 1, sh_degree=deg, sigma0=(0.00065,), device=dev, layout=args.layout)
+        scene = {k: torch.cat([a[k], b[k]]).contiguous() for k in a}
+        n = scene["centers"].shape[0]
+    else:
+        scene = make_scene(n, wl["seed"], sh_degree=deg, sigma0=wl["sigma0"] or (0.0052,), device=dev, layout=args.layout)
+    if surfel:
+        scene["scales"] = scene["scales"][:, :2].contiguous()
+    cams = orbit_cameras(V, w, h, device=dev)
+    rays = [None] * V
+    if surfel:
+        from generativedensification_amd.camera import build_rays
+        from generativedensification_amd.renderer_2dgs import Renderer as Rd
+        rays = [build_rays(torch.inverse(c.world_view_transform.T.cpu()), 0.75, 0.75, h, w).to(dev) for c in cams]
+    else:
+        from generativedensification_amd.renderer import Renderer as Rd
+    r_fused, r_caller = Rd(sh_degree=deg, white_background=True), Rd(sh_degree=deg, white_background=True, fused=False)
+    for r in (r_fused, r_caller):
+        r.set_bg_color(torch.ones(3, device=dev))
+    a = (scene["centers"], scene["shs"], scene["opacity"], scene["scales"], scene["rotations"], dev)
+    L.load()
+
+    def views_step():
+        with torch.no_grad():
+            acc = 0.0
+            for lo in range(0, V, 8):
+                cs = cams[lo:lo + 8]
+                outs = (r_fused.render_views(cs, rays[lo:lo + 8], None, *a) if surfel else r_fused.render_views(cs, None, *a))
+                acc = acc + outs[-1]["image"][0, 0, 0]      # (every frame is consumed, as the video writer does)
+            return acc
+
+    def caller_step():
+        with torch.no_grad():
+            acc = 0.0
+            for j, cam in enumerate(cams):
+                acc = acc + r_caller.render_img(cam, rays[j], *a)["image"][0, 0, 0]
+            return acc
+
+    def timed(fn, k, warm):
+        for _ in range(warm):
+            fn()
+        barrier_fn()
+        gc.collect()
+        gc.disable()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            fn()
+        barrier_fn()
+        el = time.perf_counter() - t0
+        gc.enable()
+        if use_dist:
+            t = torch.tensor([el], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el
+
+    k = max(1, min(args.steps, 5))
+    el_v = timed(views_step, k, max(1, min(args.warmup, 2)))
+    el_c = timed(caller_step, k, 1)
+    v_v, v_c = V * k * world / el_v, V * k * world / el_c
+    # per-kernel times of the fused leg and the algorithmic bytes of the forward kernels
+    kernels, roofline = {}, None
+    if not args.no_roofline:
+        from generativedensification_amd import rasterizer as R
+        from generativedensification_amd import surfel_rasterizer as SR
+        with torch.no_grad():
+            rs = r_caller.set_rasterizer(cams[0], device=dev).raster_settings
+            e = torch.empty(0, device=dev)
+            st = (SR if surfel else R).forward_raw(scene["centers"], scene["shs"], e, torch.sigmoid(scene["opacity"]),
+                                                   torch.exp(scene["scales"]), torch.nn.functional.normalize(scene["rotations"]),
+                                                   e, rs)[-2]
+            d0 = st.D
+            del st
+        tiles = ((w + 15) // 16) * ((h + 15) // 16)
+        alg = (surfel_algorithmic_bytes if surfel else algorithmic_bytes)(n, d0, h * w, (deg + 1) ** 2, tiles, 8)
+        alg["preprocess_fwd"] = alg["preprocess_fwd_views"]
+        alg["render_fwd_deep"] = alg["render_fwd"]
+        L.profile_enable(True)
+        L.profile_collect(reset=True)
+        views_step()
+        torch.cuda.synchronize()
+        prof = L.profile_collect(reset=True)
+        L.profile_enable(False)
+        for nm, (ms, c) in prof.items():
+            if c:
+                kk = dict(avg_us=round(1e3 * ms / c, 2), launches=c, total_ms=round(ms, 3))
+                if alg.get(nm) and nm not in ("tile_sort_long",):
+                    kk["alg_bytes"] = int(alg[nm])
+                    kk["frac"] = round(alg[nm] / (kk["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+                kernels[nm] = kk
+        if kernels:
+            dom = max(kernels, key=lambda q: kernels[q]["total_ms"])
+            ab = kernels[dom].get("alg_bytes", 0)
+            built = sum(q["launches"] * q.get("alg_bytes", 0) for q in kernels.values())
+            roofline = dict(bound="hbm", kernel=dom, achieved=round(ab / (kernels[dom]["avg_us"] * 1e-6) / 1e9, 1), peak=HBM_PEAK_GBS,
+                            unit="GB/s", frac=kernels[dom].get("frac"), traffic=None, alg_bytes_per_launch=ab,
+                            avg_launch_us=kernels[dom]["avg_us"], path_bytes_step_built=int(built),
+                            path_frac_built=round(built / (el_v / k) / 1e9 / HBM_PEAK_GBS, 4), num_rendered_view0=int(d0))
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        import numpy as np
+        from oracle.gdr_oracle import Oracle, Settings
+        from oracle.gsr_oracle import SurfelOracle
+        cores = os.cpu_count() or 1
+        o = (SurfelOracle if surfel else Oracle)("f32", nthreads=cores)
+        cam = cams[0]
+        ss = Settings(h, w, math.tan(0.375), math.tan(0.375), np.ones(3, np.float32), 1.0, cam.world_view_transform.cpu().numpy(),
+                      cam.full_proj_transform.cpu().numpy(), deg, cam.camera_center.cpu().numpy())
+        c = {kk: v.cpu() for kk, v in scene.items()}
+        op, sc = torch.sigmoid(c["opacity"]).numpy(), torch.exp(c["scales"]).numpy()
+        ro = torch.nn.functional.normalize(c["rotations"]).numpy()
+        t0, reps = time.perf_counter(), 0
+        while True:
+            o.forward(c["centers"].numpy(), op, ss, shs=c["shs"].numpy(), scales=sc, rotations=ro)
+            reps += 1
+            if time.perf_counter() - t0 > 10.0 or reps >= 5:
+                break
+        tc = (time.perf_counter() - t0) / reps
+        cpu_baseline = dict(value=round(1.0 / tc, 4), unit="views/s", cores=cores, kind="port",
+                            sample=f"oracle C restatement (OpenMP, {cores} threads), {reps} x forward of 1 view {h}x{w}, all {n} "
+                                   f"Gaussians ({tc:.2f} s each)")
+    return {
+        "metric": f"views/sec forward only (no_grad) @ {h}x{w}", "value": round(v_v, 2), "unit": "views/s", "n_gpus": world,
+        "steps": k, "warmup": args.warmup, "ms_per_step": round(1e3 * el_v / k, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic (seeded random Gaussians with the decoder's statistics)",
+        "config": {"workload": f"{args.workload} forward-only: {V}-frame turntable of one Gaussian set under no_grad "
+                               f"(evaluation.py:169-193), scene of {wl['desc']}", "n_gaussians": n, "views_per_step": V,
+                   "image": [h, w], "sh_degree": deg, "layout": args.layout, "parallelism": f"replicas x{world}",
+                   "entry": "render_views, <= 8 views per K1 launch, activations fused into K1",
+                   "peak_mem_gb": round(torch.cuda.max_memory_allocated(dev) / 2**30, 2)},
+        "per_view": {"value": round(v_c, 2), "unit": "views/s", "ms_per_step": round(1e3 * el_c / k, 3), "of_fused": round(v_c / v_v, 3),
+                     "entry": "the unchanged caller: render_img per frame under no_grad (torch activations, one native forward call)"},
+        "roofline": roofline, "cpu_baseline": cpu_baseline, "kernels": kernels,
         "gc": "Python's cyclic collector disabled inside the timed regions (timeit convention; collected right before)",
     }
 
@@ -311,6 +530,15 @@ def main():
                          "all-reduce calls of the N>1 path on a one-GPU box)")
     ap.add_argument("--single-device", action="store_true",
                     help="developer smoke test of the N>1 code path on a 1-GPU box: every rank uses cuda:0")
+    ap.add_argument("--keep-grads", action="store_true",
+                    help="with --grad-allreduce: keep the Gaussians' .grad tensors (the views of the persistent packed buffer "
+                         "allreduce_gaussian_grads leaves behind) and zero them each step instead of dropping them: autograd then "
+                         "accumulates into the buffer (one fill + one read-modify-write of the gradients) instead of the "
+                         "one copy_ into the buffer that fresh gradients cost")
+    ap.add_argument("--forward-only", action="store_true",
+                    help="evaluation throughput (evaluation.py:169-193: a 120-frame turntable of ONE Gaussian set under no_grad): "
+                         "views/s through render_img per view and through render_views, no backward")
+    ap.add_argument("--eval-views", type=int, default=120)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "pmc_traffic.json"),
@@ -382,6 +610,16 @@ def main():
     from generativedensification_amd.synthetic import make_scene, make_targets, view_loss, views_loss
 
     wl = dict(WORKLOADS[args.workload])
+    if args.forward_only:
+        if args.workload == "c3step":
+            raise SystemExit("bench.py: --forward-only applies to the scene workloads (c2, c3, c4, c5)")
+        out = run_forward_only(args, wl, dev, rank, world, use_dist, barrier_fn=lambda: (dist.barrier() if use_dist else None,
+                                                                                          torch.cuda.synchronize()))
+        if rank == 0:
+            os.write(result_fd, (json.dumps(out) + "\n").encode())
+        if use_dist:
+            dist.destroy_process_group()
+        return
     if args.workload == "c3step":
         out = run_c3step(args, wl, dev, rank, world, use_dist, barrier_fn=lambda: (dist.barrier() if use_dist else None,
                                                                                     torch.cuda.synchronize()))
@@ -445,7 +683,10 @@ def main():
 
         def step():
             for p in plist:
-                p.grad = None
+                if args.keep_grads and p.grad is not None:
+                    p.grad.zero_()
+                else:
+                    p.grad = None
             if per_view:
                 losses = []
                 for j, cam in enumerate(cams):
@@ -489,11 +730,22 @@ def main():
                     lv = views_loss(out, targets)  # (V,) per-view losses on the view-stacked tensors
                 lv.sum().backward()
                 losses = lv.detach()
+            ev = None
+            if comm_events is not None:     # (the timed collectives of the roofline pass: events on the caller's stream)
+                ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+                ev[0].record()
             all_losses = gather_view_losses(losses, total_views)
+            if ev:
+                ev[1].record()
             if args.grad_allreduce:
                 allreduce_gaussian_grads(plist)
+            if ev:
+                ev[2].record()
+                comm_events.append(ev)
             return all_losses
         return step
+
+    comm_events = None      # a list while the collectives are being timed
 
     step = make_step(args.per_view or args.backward_per_view, args.unfused, args.torch_loss, args.loss_kernels,
                      args.stacked_loss, args.backward_per_view)
@@ -546,6 +798,21 @@ def main():
             print(f"[bench] {msg} (t+{time.perf_counter() - t0:.1f}s)", file=sys.stderr, flush=True)
 
     note(f"timed region done: {views_per_sec:.1f} views/s")
+    # ---- the collectives on their own (HIP events around each, a short extra pass; inside `value` they are part of the step)
+    comm_ms = None
+    if use_dist:
+        comm_events = []
+        for _ in range(max(1, min(args.steps, 5))):
+            step()
+        torch.cuda.synchronize()
+        k_ev = len(comm_events)
+        comm_ms = dict(loss_gather=round(sum(e[0].elapsed_time(e[1]) for e in comm_events) / k_ev, 4),
+                       grad_allreduce=(round(sum(e[1].elapsed_time(e[2]) for e in comm_events) / k_ev, 4) if args.grad_allreduce else None),
+                       grads="kept (zeroed each step: autograd accumulates into the packed buffer)" if args.keep_grads
+                       else "dropped each step (one copy_ into the packed buffer per call)",
+                       note="ms per step on this rank, HIP events on the caller's stream around gather_view_losses / "
+                            "allreduce_gaussian_grads (packing included); rank 0")
+        comm_events = None
     # ---- D (num_rendered) per view, measured ----------------------------------------
     from generativedensification_amd import rasterizer as R
     from generativedensification_amd import surfel_rasterizer as SR
@@ -581,7 +848,10 @@ def main():
     if sum(class_entries):   # the tile sort's D * 24 bytes split over its launches by the entries each size class handles:
         # `tile_sort` = the <= 2048-entry class (one launch per view), `tile_sort_long` = the medium + long class launches
         alg["tile_sort"] = class_entries[0] / len(d_views) * 12
-        alg["tile_sort_long"] = (class_entries[1] + class_entries[2]) / len(d_views) * 12 / 2
+        # bytes PER VIEW of the medium + long class launches; per launch = this x views / launches of the step (one launch of
+        # the medium class per view, one of the long class where the shape's recent calls saw lists beyond 4096 entries)
+        alg["_tile_sort_long_view"] = (class_entries[1] + class_entries[2]) / len(d_views) * 12
+        alg["tile_sort_long"] = alg["_tile_sort_long_view"]
 
     # ---- roofline: per-kernel HIP-event timing, second pass of the same K steps -----------
     roofline = None
@@ -626,6 +896,10 @@ def main():
                 if alg.get(name):      # algorithmic bytes per launch against the 8 TB/s HBM peak, per kernel
                     multi = name in ("preprocess_fwd", "preprocess_bwd") and cnt < args.steps * vpg   # views kernels
                     per_launch = alg[name + "_views"] if multi else alg[name]
+                    if name == "tile_sort_long" and alg.get("_tile_sort_long_view") is not None:
+                        per_launch = alg["_tile_sort_long_view"] * vpg * args.steps / cnt
+                    if name == "render_bwd" and cnt < args.steps * vpg:     # K7 of all views in one launch (round 4)
+                        per_launch = alg[name] * vpg * args.steps / cnt
                     k["alg_bytes"] = int(per_launch)
                     k["alg_GBs"] = round(per_launch / (k["avg_us"] * 1e-6) / 1e9, 1)
                     k["frac"] = round(k["alg_GBs"] / HBM_PEAK_GBS, 4)
@@ -644,6 +918,17 @@ def main():
                             avg_launch_us=kernels[dom]["avg_us"],
                             path_bytes_view=int(alg["_bytes_view"]),
                             path_frac=round(views_per_sec / world * alg["_bytes_view"] / 1e9 / HBM_PEAK_GBS, 4))
+            # the path AS BUILT: sum over the kernels of launches x the algorithmic bytes of that launch (the multi-view K1 / K9
+            # read the per-Gaussian inputs once per node, not once per view as the contract formula `path_frac` charges) plus
+            # the gradient-record fills, per step, against the same peak
+            built = sum(k["launches"] * k.get("alg_bytes", 0) for k in kernels.values()) / args.steps
+            if not (args.per_view or args.backward_per_view):
+                built += vpg * n * (128 if surfel else 64)
+            roofline.update(path_bytes_step_built=int(built),
+                            path_frac_built=round(built / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                            path_note="path_frac: SURVEY 8(d)'s per-view formula x views/s (the contract's figure); "
+                                      "path_frac_built: the algorithmic bytes of the kernels as launched; "
+                                      "path_frac_measured: rocprofv3 PMC bytes of the same launches")
             if pmc_ok and tj:
                 # what the counters say the whole path moves per step (sum over kernels of launches x PMC bytes per
                 # launch; kernels without a PMC figure count with their algorithmic bytes), against the same peak: the
@@ -766,8 +1051,30 @@ def main():
         hip_img = hip_img.permute(2, 0, 1).cpu().numpy()
         ref_img = np.clip(ctx["color"], 0.0, 1.0)
         mse = float(((hip_img - ref_img) ** 2).mean())
+        # the threshold flips behind max_abs_rgb, counted (v_exp_f32 against the oracle's expf: an alpha that lands on the other
+        # side of 1/255, or a transmittance on the other side of 1e-4, adds or drops one contributor of one pixel)
+        flips = None
+        try:
+            with torch.no_grad():
+                rs = renderer.set_rasterizer(cam, device=dev).raster_settings
+                e0 = torch.empty(0, device=dev)
+                st0 = (SR if surfel else R).forward_raw(params["centers"].detach(), params["shs"].detach(), e0,
+                                                        torch.sigmoid(params["opacity"].detach()), torch.exp(params["scales"].detach()),
+                                                        torch.nn.functional.normalize(params["rotations"].detach()), e0, rs)[-2]
+                tt = st0.tensors()
+                nc_h = tt["n_contrib"].cpu().numpy().reshape(-1, h, w)[0].astype(np.int64)
+                ft_h = tt["final_T"].cpu().numpy().reshape(-1, h, w)[0]
+            nc_o = np.asarray(ctx["n_contrib"]).reshape(-1, h, w)[0].astype(np.int64)
+            ft_o = np.asarray(ctx["final_T"]).reshape(-1, h, w)[0]
+            d_rgb = np.abs(hip_img - ref_img).max(axis=0)
+            flips = dict(n_contrib_mismatch_pixels=int((nc_h != nc_o).sum()),
+                         final_T_outlier_pixels=int((np.abs(ft_h - ft_o) > 1e-4 * np.abs(ft_o) + 1e-6).sum()),
+                         rgb_outlier_pixels=int((d_rgb > 1e-4).sum()), pixels=int(h * w))
+            del st0, tt
+        except Exception as ex:     # (a statistic: never fails the bench)
+            flips = dict(error=type(ex).__name__)
         psnr_vs_oracle = dict(psnr_db=round(10 * math.log10(1.0 / max(mse, 1e-20)), 1),
-                              max_abs_rgb=float(np.abs(hip_img - ref_img).max()),
+                              max_abs_rgb=float(np.abs(hip_img - ref_img).max()), threshold_flips=flips,
                               view="view 0 of the rank, full size, all Gaussians; oracle = f32 C restatement (parity unpinned: DESIGN 0)")
 
     # ---- the literal "PyTorch-CPU" baseline of north_star: the vectorised torch restatement with autograd
@@ -818,12 +1125,15 @@ def main():
                                 else "torch ops" if (args.per_view or args.backward_per_view or args.stacked_loss or args.torch_loss or args.unfused)
                                 else "fused HIP loss kernels (clamp+MSE+0.1 mean depth+0.1 mean alpha)" if args.loss_kernels
                                 else "folded into K6 epilogue / K7 prologue (clamp+MSE+0.1 mean depth+0.1 mean alpha)")},
-            "roofline": roofline, "per_view": per_view,
+            "roofline": roofline, "per_view": per_view, "comm_ms": comm_ms,
             "spread": "same box run-to-run +-0.3 %, box-to-box +-4 % (BASELINE.md section 4: measured over 6 boxes)",
             "gc": "Python's cyclic collector disabled inside the timed regions (timeit convention; collected right before)",
             "cpu_baseline": cpu_baseline, "cpu_baseline_torch": cpu_baseline_torch,
             "psnr_vs_oracle": psnr_vs_oracle, "kernels": kernels,
             "loss_mean": float(last_losses.mean()),
+            # L1 norms of the Gaussians' gradients after the last step (with --grad-allreduce: of the sum over all ranks'
+            # views) — lets a 2-rank run be compared with one rank rendering the same views (tests/test_gpu_multirank.py)
+            "grad_l1": {k: (float(p.grad.double().abs().sum()) if p.grad is not None else None) for k, p in params.items()},
         }
         os.write(result_fd, (json.dumps(out) + "\n").encode())
     if use_dist:

@@ -76,6 +76,26 @@ class GdrGradOutputs(C.Structure):
                 ("accumulate", C.c_int32), ("reserved", C.c_int32)]
 
 
+class GdrViewPlan(C.Structure):
+    _fields_ = [("capacity", C.c_uint64), ("bytes", C.c_uint64), ("seg_len", C.c_int32), ("deferred", C.c_int32),
+                ("have_binning", C.c_int32), ("reserved", C.c_int32)]
+
+
+class GdrViewOpts(C.Structure):
+    _fields_ = [("seg_len", C.c_int32), ("deep_max_busy", C.c_int32), ("deep_min_mean", C.c_int32),
+                ("global_sort", C.c_int32), ("radix_partition", C.c_int32), ("no_hints", C.c_int32)]
+
+
+class GdrSameAs(C.Structure):
+    _fields_ = [("n", C.c_int32), ("reserved", C.c_int32), ("a", C.c_void_p * 4), ("b", C.c_void_p * 4),
+                ("n_bytes", C.c_uint64 * 4)]
+
+
+class GdrViewState(C.Structure):
+    _fields_ = [("geom", GdrGeom), ("bin", GdrBinning), ("img", GdrImage), ("D", C.c_uint64), ("differ", C.c_uint32),
+                ("reserved", C.c_uint32)]
+
+
 class GsrInputs(C.Structure):   # include/gsr.h
     _fields_ = [("N", C.c_int32), ("M", C.c_int32), ("means3D", C.c_void_p), ("opacities", C.c_void_p),
                 ("shs", C.c_void_p), ("colors_precomp", C.c_void_p), ("scales", C.c_void_p),
@@ -137,6 +157,14 @@ _PROTOS = {
     "gdr_forward": (C.c_int, [C.POINTER(GdrSettings), C.POINTER(GdrInputs), C.POINTER(GdrGeom),
                               C.POINTER(GdrBinning), C.POINTER(GdrImage), C.c_uint64,
                               C.POINTER(GdrOutputs), C.POINTER(C.c_uint32), C.c_void_p]),
+    "gdr_view_plan_for": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_uint64, C.POINTER(GdrViewOpts),
+                                    C.POINTER(GdrViewPlan)]),
+    "gdr_forward_view": (C.c_int, [C.POINTER(GdrSettings), C.POINTER(GdrInputs), C.POINTER(GdrViewPlan), C.c_void_p,
+                                   C.POINTER(GdrViewOpts), C.POINTER(GdrSameAs), C.POINTER(GdrOutputs),
+                                   C.POINTER(GdrViewState), C.c_void_p]),
+    "gdr_view_history_reset": (None, []),
+    "gdr_view_history_get": (C.c_double, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "gdr_view_history_set": (None, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_double]),
     "gdr_backward": (C.c_int, [C.POINTER(GdrSettings), C.POINTER(GdrInputs), C.POINTER(GdrGeom),
                                C.POINTER(GdrBinning), C.POINTER(GdrImage), C.c_uint64, C.c_void_p,
                                C.POINTER(GdrGradInputs), C.POINTER(GdrGradOutputs), C.c_void_p]),
@@ -206,6 +234,11 @@ _PROTOS = {
     "gsr_preprocess_backward_views": (C.c_int, [C.c_int32, C.POINTER(GdrSettings), C.POINTER(GsrInputs), C.POINTER(GdrGeom),
                                                 C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(GsrGradOutputs),
                                                 C.c_void_p]),
+    "gsr_forward_view": (C.c_int, [C.POINTER(GdrSettings), C.POINTER(GsrInputs), C.POINTER(GdrViewPlan), C.c_void_p,
+                                   C.POINTER(GdrViewOpts), C.POINTER(GdrSameAs), C.POINTER(GsrOutputs),
+                                   C.POINTER(GdrViewState), C.c_void_p]),
+    "gsr_means2d_of_view": (C.c_int, [C.POINTER(GdrSettings), C.c_int32, C.POINTER(GdrGeom), C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.c_void_p]),
     "gsr_backward": (C.c_int, [C.POINTER(GdrSettings), C.POINTER(GsrInputs), C.POINTER(GdrGeom), C.POINTER(GdrBinning),
                                C.POINTER(GdrImage), C.c_uint64, C.c_void_p, C.POINTER(GsrGradInputs),
                                C.POINTER(GsrGradOutputs), C.c_void_p]),

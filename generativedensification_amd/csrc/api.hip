@@ -5,6 +5,7 @@
 #include <string.h>
 
 #include <mutex>
+#include <unordered_map>
 #include <vector>
 
 #include "gdr_common.h"
@@ -132,6 +133,36 @@ static size_t carve_image(void* base, int H, int W, gdr_image* im) {
     return c.off;
 }
 
+// 2DGS surfel geometry / image state (include/gsr.h): the same structs, wider records
+static size_t carve_surfel_geom(void* base, int64_t N, gdr_geom* g) {
+    Carver c(base);
+    gdr_geom t;
+    const size_t n = (size_t)(N > 0 ? N : 1);
+    t.depths = c.take<float>(n);
+    t.rec = c.take<float>(GSR_REC_FLOATS * n);
+    t.cov3D = nullptr;
+    t.rect = c.take<int32_t>(4 * n);
+    t.tiles_touched = c.take<uint32_t>(n);
+    t.clamped = c.take<uint8_t>(n);
+    t.block_sums = c.take<uint32_t>((n + GDR_BLOCK - 1) / GDR_BLOCK + 1);
+    t.block_offs = c.take<uint32_t>((n + GDR_BLOCK - 1) / GDR_BLOCK + 1);
+    t.num_rendered = c.take<uint32_t>(1);
+    if (g) *g = t;
+    return c.off;
+}
+static size_t carve_surfel_image(void* base, int H, int W, gdr_image* im) {
+    Carver c(base);
+    gdr_image t;
+    const size_t tiles = (size_t)tile_grid_x(W) * tile_grid_y(H);
+    const size_t P = (size_t)H * W;
+    t.ranges = c.take<uint32_t>(2 * (tiles ? tiles : 1));
+    t.n_contrib = c.take<uint32_t>(2 * (P ? P : 1));
+    t.final_T = c.take<float>(3 * (P ? P : 1));
+    t.tile_order = c.take<uint32_t>(tiles ? tiles : 1);
+    t.seg_base = c.take<uint32_t>(tiles ? tiles : 1);
+    if (im) *im = t;
+    return c.off;
+}
 static int check_common(const gdr_settings* s, const gdr_inputs* in) {
     if (!s || !in) { set_error("NULL settings/inputs", hipSuccess); return GDR_ERR_INVALID_ARG; }
     if (in->N < 0 || s->image_height <= 0 || s->image_width <= 0) {
@@ -762,38 +793,255 @@ int gdr_mark_visible(int32_t N, const float* means3D, const float* viewmatrix,
 }  // extern "C"
 
 // =================================================================================
+// One forward call per view (round 4, v14): gdr_view_plan_for + gdr_forward_view (+ the surfel twins below).
+// The reference's extension does its whole forward in ONE native call (`_C.rasterize_gaussians`, reached from
+// /root/reference/lightning/renderer.py:250-259); until round 3 a call of the Python boundary was ~20 ctypes calls plus
+// Python-side carving, capacity / launch-hint bookkeeping and a pooled read-back.  Here the library does all of that:
+// carving of ONE caller allocation, K1, the duplicate count on its way to pinned host memory, binning + K6 sized by the
+// device counter, the comparison with the capacity, and the per-shape history the next call is planned from.
+// =================================================================================
+namespace gdr {
+namespace {
+
+struct ShapeHist {
+    double d_per_n = 0.0;          // decaying maximum of duplicates per Gaussian of one view of this shape (0: none yet)
+    int64_t n_long = 0, n_medium = 0;   // decaying maxima of the tile sort's long / medium class sizes
+    int deep_ttl = 0;              // calls until the deep forward launch may be dropped
+    uint32_t* stats = nullptr;     // 4 pinned host words the binning stage reports into (kept for the life of the process)
+    bool reported = false;
+};
+std::mutex g_hist_mu;
+std::unordered_map<uint64_t, ShapeHist> g_hist;
+constexpr double kDSlack = 1.5;    // capacity = slack x the largest recent count of the shape (+ 4096)
+
+int bit_length(int64_t v) { int b = 0; while (v > 0) { ++b; v >>= 1; } return b; }
+
+// key of the per-shape histories: device, power-of-two bucket of N (a densifying model renders a different N every step; what
+// carries over between neighbouring N is the number of duplicates PER GAUSSIAN), image size, path (3DGS / surfel)
+uint64_t shape_key(int N, int H, int W, int surfel) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    return ((uint64_t)(dev & 0xFF) << 56) | ((uint64_t)(surfel & 1) << 55) | ((uint64_t)bit_length(N) << 48) |
+           ((uint64_t)(H & 0xFFFFFF) << 24) | (uint64_t)(W & 0xFFFFFF);
+}
+
+struct PinnedWords { uint32_t* p; int dev; };
+std::mutex g_pin_mu;
+std::vector<PinnedWords> g_pin_pool;    // 8-byte pinned buffers for the count read-back
+
+int seg_len_policy(const gdr_view_opts* o, uint64_t d_est, int tiles, int64_t busy) {
+    if (o && o->seg_len >= 0) return o->seg_len / GDR_BLOCK * GDR_BLOCK;
+    // 512-entry segments pay on large images whose tiles are all busy with long lists (C4 +2.5 %, C5 +1.3 % over 256);
+    // scenes with few busy tiles or short lists keep 256
+    if (tiles >= 2000 && d_est >= (uint64_t)500 * (uint64_t)tiles && (busy < 0 || 2 * busy >= tiles)) return 512;
+    return GDR_DEFAULT_SEG_LEN;
+}
+
+}  // namespace
+}  // namespace gdr
+
+extern "C" {
+
+int gdr_view_plan_for(int32_t N, int32_t H, int32_t W, int32_t surfel, uint64_t exact_D, const gdr_view_opts* opts,
+                      gdr_view_plan* plan) {
+    if (!plan || N < 0 || H <= 0 || W <= 0) { set_error("view_plan_for: bad argument", hipSuccess); return GDR_ERR_INVALID_ARG; }
+    const int tiles = tile_grid_x(W) * tile_grid_y(H);
+    uint64_t cap = exact_D;
+    int64_t busy = -1;
+    int deferred = 0;
+    if (!exact_D && N > 0) {
+        std::lock_guard<std::mutex> lk(g_hist_mu);
+        auto it = g_hist.find(shape_key(N, H, W, surfel));
+        if (it != g_hist.end() && it->second.d_per_n > 0.0) {
+            cap = (uint64_t)(it->second.d_per_n * (double)N * kDSlack) + 4096;
+            deferred = 1;
+            if (it->second.reported && it->second.stats && it->second.stats[0] != 0xFFFFFFFFu) busy = it->second.stats[3];
+        }
+    }
+    if (cap > GDR_MAX_RENDERED) cap = GDR_MAX_RENDERED;
+    plan->capacity = cap;
+    plan->deferred = deferred;
+    plan->have_binning = (exact_D || deferred || N == 0) ? 1 : 0;
+    plan->seg_len = seg_len_policy(opts, deferred ? (uint64_t)((double)cap / kDSlack) : cap, tiles, busy);
+    const bool direct = !(opts && (opts->radix_partition || opts->global_sort));
+    size_t geom = surfel ? carve_surfel_geom(nullptr, N, nullptr) : carve_geom(nullptr, N, nullptr);
+    size_t img = surfel ? carve_surfel_image(nullptr, H, W, nullptr) : carve_image(nullptr, H, W, nullptr);
+    size_t bin = plan->have_binning ? carve_binning(nullptr, cap, nullptr, plan->seg_len, direct ? N : 0, direct ? tiles : 0) : 0;
+    plan->bytes = (uint64_t)(geom + img + bin);
+    return GDR_OK;
+}
+
+}  // extern "C"
+
+namespace gdr {
+namespace {
+
+// the forward of one view, shared by the 3DGS and the surfel boundary: K1 and K6 come in as callables
+template <class K1, class K6>
+int forward_view_impl(const gdr_settings* s, int N, int surfel, const gdr_view_plan* plan, void* ws, const gdr_view_opts* opts,
+                      const gdr_same_as* same, int32_t* radii, gdr_view_state* out_st, hipStream_t st, K1 run_k1, K6 run_k6) {
+    const int W = s->image_width, H = s->image_height;
+    const int tiles = tile_grid_x(W) * tile_grid_y(H);
+    if (!ws || ((uintptr_t)ws & 255u)) { set_error("forward_view: workspace NULL / not 256-byte aligned", hipSuccess); return GDR_ERR_INVALID_ARG; }
+    if (key_bits(tiles) > 64) { set_error("image too large", hipSuccess); return GDR_ERR_UNSUPPORTED; }
+    gdr_view_state v;
+    memset(&v, 0, sizeof(v));
+    char* base = (char*)ws;
+    size_t off = surfel ? carve_surfel_geom(base, N, &v.geom) : carve_geom(base, N, &v.geom);
+    off += surfel ? carve_surfel_image(base + off, H, W, &v.img) : carve_image(base + off, H, W, &v.img);
+    const bool direct = !(opts && (opts->radix_partition || opts->global_sort));
+    if (plan->have_binning) {
+        const size_t b = carve_binning(base + off, plan->capacity, &v.bin, plan->seg_len, direct ? N : 0, direct ? tiles : 0);
+        if ((uint64_t)(off + b) > plan->bytes) { set_error("forward_view: plan does not match its byte count", hipSuccess); return GDR_ERR_WORKSPACE; }
+    }
+    // launch-size feedback of the shape (results never depend on it, include/gdr.h gdr_binning.stats_out / hint_*)
+    const uint64_t key = shape_key(N, H, W, surfel);
+    uint32_t* stats = nullptr;
+    int hint_long = 0, hint_medium = 0, hint_no_deep = 0;
+    if (!(opts && opts->no_hints) && N > 0) {
+        std::lock_guard<std::mutex> lk(g_hist_mu);
+        if (g_hist.size() < 4096 || g_hist.count(key)) {
+            ShapeHist& h = g_hist[key];
+            if (!h.stats) {
+                if (hipHostMalloc((void**)&h.stats, 4 * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess)
+                    for (int k = 0; k < 4; ++k) h.stats[k] = 0xFFFFFFFFu;
+                else { h.stats = nullptr; (void)hipGetLastError(); }
+            }
+            stats = h.stats;
+            if (stats && stats[0] != 0xFFFFFFFFu) {
+                h.reported = true;
+                h.n_long = std::max<int64_t>(stats[0], h.n_long * 9 / 10);
+                h.n_medium = std::max<int64_t>(stats[1], h.n_medium * 9 / 10);
+                h.deep_ttl = stats[2] ? 8 : std::max(0, h.deep_ttl - 1);
+                hint_long = h.n_long == 0 ? -1 : (int)std::max<int64_t>(16, h.n_long + h.n_long / 4 + 1);
+                hint_medium = (int)std::max<int64_t>(32, h.n_medium + h.n_medium / 4 + 1);
+                hint_no_deep = h.deep_ttl == 0 ? 1 : 0;
+            }
+        }
+    }
+    auto apply_opts = [&](gdr_binning& b) {
+        b.global_sort = (opts && opts->global_sort) ? 1 : 0;
+        if (opts && opts->deep_max_busy >= 0) b.deep_max_busy = opts->deep_max_busy;
+        if (opts && opts->deep_min_mean >= 0) b.deep_min_mean = opts->deep_min_mean;
+        b.hint_long = hint_long; b.hint_medium = hint_medium; b.hint_no_deep = hint_no_deep;
+        b.stats_out = stats;
+    };
+    hipError_t e = hipMemsetAsync(v.geom.num_rendered, 0, 2 * sizeof(uint32_t), st);   // [count, same_as verdict]
+    if (e != hipSuccess) return hip_fail("memset num_rendered", e);
+    if (same && same->n > 0) {
+        if (same->n > GDR_DIFFER_MAX) { set_error("forward_view: more than 4 same_as pairs", hipSuccess); return GDR_ERR_INVALID_ARG; }
+        e = launch_words_differ_multi(same->n, same->a, same->b, same->n_bytes, v.geom.num_rendered + 1, st);
+        if (e != hipSuccess) return hip_fail("words_differ_multi", e);
+    }
+    int rc = run_k1(v.geom);
+    if (rc) return rc;
+    // the count (and the verdict word behind it) on its way to pinned host memory
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    uint32_t* pin = nullptr;
+    HostCopyTicket* ticket = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_pin_mu);
+        for (size_t k = 0; k < g_pin_pool.size(); ++k)
+            if (g_pin_pool[k].dev == dev) { pin = g_pin_pool[k].p; g_pin_pool[k] = g_pin_pool.back(); g_pin_pool.pop_back(); break; }
+    }
+    if (!pin && hipHostMalloc((void**)&pin, 2 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) return hip_fail("hipHostMalloc", hipGetLastError());
+    auto release_pin = [&]() { std::lock_guard<std::mutex> lk(g_pin_mu); g_pin_pool.push_back({pin, dev}); };
+    rc = gdr_host_copy_begin(pin, v.geom.num_rendered, 2 * sizeof(uint32_t), (void*)st, (void**)&ticket);
+    if (rc) { release_pin(); return rc; }
+    auto finish = [&](int code) { *out_st = v; return code; };
+    uint64_t D = 0;
+    if (plan->have_binning && plan->deferred) {   // device-sized call: binning + K6 are enqueued behind K1 without waiting for it
+        apply_opts(v.bin);
+        v.bin.d_dev = v.geom.num_rendered;
+        rc = binning_stage(s, N, &v.geom, &v.bin, &v.img, plan->capacity, radii, st);
+        if (!rc) rc = run_k6(v.geom, v.bin, v.img);
+        const int wrc = gdr_host_copy_wait(ticket);
+        D = pin[0]; v.differ = pin[1];
+        release_pin();
+        if (rc) return rc;
+        if (wrc) return wrc;
+    } else {
+        rc = gdr_host_copy_wait(ticket);
+        D = pin[0]; v.differ = pin[1];
+        release_pin();
+        if (rc) return rc;
+        if (plan->have_binning && D <= plan->capacity) {
+            apply_opts(v.bin);
+            v.bin.d_dev = nullptr;
+            rc = binning_stage(s, N, &v.geom, &v.bin, &v.img, D, radii, st);
+            if (!rc) rc = run_k6(v.geom, v.bin, v.img);
+            if (rc) return rc;
+        }
+    }
+    v.D = D;
+    if (N > 0) {   // the history the next call of this shape is planned from
+        std::lock_guard<std::mutex> lk(g_hist_mu);
+        if (g_hist.size() < 4096 || g_hist.count(key)) {
+            ShapeHist& h = g_hist[key];
+            h.d_per_n = std::max((double)D / (double)std::max(N, 1), h.d_per_n * 0.97);
+            if (h.d_per_n <= 0.0) h.d_per_n = 1e-9;    // "seen": a shape without duplicates still gets device-sized calls
+        }
+    }
+    if (!plan->have_binning || D > plan->capacity) {
+        set_error("forward_view: binning workspace too small for num_rendered (plan again with exact_D = state.D)", hipSuccess);
+        return finish(GDR_ERR_WORKSPACE);
+    }
+    return finish(GDR_OK);
+}
+
+}  // namespace
+}  // namespace gdr
+
+extern "C" {
+
+int gdr_forward_view(const gdr_settings* s, const gdr_inputs* in, const gdr_view_plan* plan, void* workspace,
+                     const gdr_view_opts* opts, const gdr_same_as* same, const gdr_outputs* out, gdr_view_state* state,
+                     void* stream) {
+    int rc = check_common(s, in);
+    if (rc) return rc;
+    if (!plan || !out || !state || !out->color || !out->depth || !out->alpha || (in->N > 0 && !out->radii)) {
+        set_error("forward_view: NULL argument", hipSuccess);
+        return GDR_ERR_INVALID_ARG;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    return forward_view_impl(
+        s, in->N, 0, plan, workspace, opts, same, out->radii, state, st,
+        [&](const gdr_geom& g) -> int {
+            hipError_t e = launch_preprocess_fwd(s, in, &g, out->radii, st);
+            if (e != hipSuccess) return hip_fail("preprocess_fwd", e);
+            return debug_sync(s, "preprocess_fwd", st);
+        },
+        [&](const gdr_geom& g, const gdr_binning& b, const gdr_image& im) -> int {
+            return gdr_composite_forward(s, &g, &b, &im, out, stream);
+        });
+}
+
+double gdr_view_history_get(int32_t N, int32_t H, int32_t W, int32_t surfel) {
+    std::lock_guard<std::mutex> lk(g_hist_mu);
+    auto it = g_hist.find(shape_key(N, H, W, surfel));
+    return it == g_hist.end() ? 0.0 : it->second.d_per_n;
+}
+
+void gdr_view_history_set(int32_t N, int32_t H, int32_t W, int32_t surfel, double d_per_n) {
+    std::lock_guard<std::mutex> lk(g_hist_mu);
+    g_hist[shape_key(N, H, W, surfel)].d_per_n = d_per_n > 0.0 ? d_per_n : 0.0;
+}
+
+void gdr_view_history_reset(void) {
+    std::lock_guard<std::mutex> lk(g_hist_mu);
+    for (auto& kv : g_hist) {     // (the pinned report words stay: a kernel in flight may still write them)
+        kv.second.d_per_n = 0.0; kv.second.n_long = kv.second.n_medium = 0; kv.second.deep_ttl = 0; kv.second.reported = false;
+        if (kv.second.stats) for (int k = 0; k < 4; ++k) kv.second.stats[k] = 0xFFFFFFFFu;
+    }
+}
+
+}  // extern "C"
+
+// =================================================================================
 // 2DGS surfel path (include/gsr.h)
 // =================================================================================
 namespace gdr {
-static size_t carve_surfel_geom(void* base, int64_t N, gdr_geom* g) {
-    Carver c(base);
-    gdr_geom t;
-    const size_t n = (size_t)(N > 0 ? N : 1);
-    t.depths = c.take<float>(n);
-    t.rec = c.take<float>(GSR_REC_FLOATS * n);
-    t.cov3D = nullptr;
-    t.rect = c.take<int32_t>(4 * n);
-    t.tiles_touched = c.take<uint32_t>(n);
-    t.clamped = c.take<uint8_t>(n);
-    t.block_sums = c.take<uint32_t>((n + GDR_BLOCK - 1) / GDR_BLOCK + 1);
-    t.block_offs = c.take<uint32_t>((n + GDR_BLOCK - 1) / GDR_BLOCK + 1);
-    t.num_rendered = c.take<uint32_t>(1);
-    if (g) *g = t;
-    return c.off;
-}
-static size_t carve_surfel_image(void* base, int H, int W, gdr_image* im) {
-    Carver c(base);
-    gdr_image t;
-    const size_t tiles = (size_t)tile_grid_x(W) * tile_grid_y(H);
-    const size_t P = (size_t)H * W;
-    t.ranges = c.take<uint32_t>(2 * (tiles ? tiles : 1));
-    t.n_contrib = c.take<uint32_t>(2 * (P ? P : 1));
-    t.final_T = c.take<float>(3 * (P ? P : 1));
-    t.tile_order = c.take<uint32_t>(tiles ? tiles : 1);
-    t.seg_base = c.take<uint32_t>(tiles ? tiles : 1);
-    if (im) *im = t;
-    return c.off;
-}
 static int check_surfel(const gdr_settings* s, const gsr_inputs* in) {
     if (!s || !in) { set_error("NULL settings/inputs", hipSuccess); return GDR_ERR_INVALID_ARG; }
     if (in->N < 0 || s->image_height <= 0 || s->image_width <= 0) { set_error("negative N or empty image", hipSuccess); return GDR_ERR_INVALID_ARG; }
@@ -888,6 +1136,29 @@ int gsr_forward(const gdr_settings* s, const gsr_inputs* in, const gdr_geom* geo
     return gsr_render_forward(s, in, geom, bin, img, *num_rendered_host, out, stream);
 }
 
+// one forward call per view for the surfel boundary (see gdr_forward_view)
+int gsr_forward_view(const gdr_settings* s, const gsr_inputs* in, const gdr_view_plan* plan, void* workspace,
+                     const gdr_view_opts* opts, const gdr_same_as* same, const gsr_outputs* out, gdr_view_state* state,
+                     void* stream) {
+    int rc = check_surfel(s, in);
+    if (rc) return rc;
+    if (!plan || !out || !state || !out->color || !out->allmap || (in->N > 0 && !out->radii)) {
+        set_error("surfel forward_view: NULL argument", hipSuccess);
+        return GDR_ERR_INVALID_ARG;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    return forward_view_impl(
+        s, in->N, 1, plan, workspace, opts, same, out->radii, state, st,
+        [&](const gdr_geom& g) -> int {
+            hipError_t e = launch_surfel_preprocess_fwd(s, in, &g, out->radii, st);
+            if (e != hipSuccess) return hip_fail("surfel_preprocess_fwd", e);
+            return debug_sync(s, "surfel_preprocess_fwd", st);
+        },
+        [&](const gdr_geom& g, const gdr_binning& b, const gdr_image& im) -> int {
+            return gsr_composite_forward(s, &g, &b, &im, out, stream);
+        });
+}
+
 int gsr_backward(const gdr_settings* s, const gsr_inputs* in, const gdr_geom* geom, const gdr_binning* bin,
                  const gdr_image* img, uint64_t D, const int32_t* radii, const gsr_grad_inputs* gin,
                  const gsr_grad_outputs* gout, void* stream) {
@@ -969,6 +1240,15 @@ int gsr_render_backward(const gdr_settings* s, int32_t N, const gdr_geom* geom, 
     e = launch_surfel_render_bwd(s, geom, bin, img, gin, grad_rec, st);
     if (e != hipSuccess) return hip_fail("surfel_render_bwd", e);
     return debug_sync(s, "surfel_render_bwd", st);
+}
+
+int gsr_means2d_of_view(const gdr_settings* s, int32_t N, const gdr_geom* geom, const int32_t* radii,
+                        const float* grad_rec, float* dL_dmean2D, void* stream) {
+    if (N <= 0) return GDR_OK;
+    if (!s || !geom || !radii || !grad_rec || !dL_dmean2D) { set_error("means2d_of_view: NULL argument", hipSuccess); return GDR_ERR_INVALID_ARG; }
+    hipError_t e = launch_surfel_means2d_view(N, s, geom, radii, grad_rec, dL_dmean2D, (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail("surfel_means2d_view", e);
+    return GDR_OK;
 }
 
 int gsr_preprocess_backward_views(int32_t V, const gdr_settings* s, const gsr_inputs* in, const gdr_geom* geoms,

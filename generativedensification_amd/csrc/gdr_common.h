@@ -176,6 +176,9 @@ hipError_t launch_surfel_render_bwd(const gdr_settings* s, const gdr_geom* g, co
                                     const gdr_image* img, const gsr_grad_inputs* gi, float* grad_rec,
                                     hipStream_t st);
 
+hipError_t launch_surfel_means2d_view(int N, const gdr_settings* s, const gdr_geom* g, const int32_t* radii,
+                                      const float* grad_rec, float* out, hipStream_t st);
+
 hipError_t launch_surfel_maps_fwd(const float* allmap, const float* rays, const float* view, int H, int W, float r,
                                   float* depth, float* acc, float* rend_normal, float* depth_normal, float* rend_dist,
                                   hipStream_t st);

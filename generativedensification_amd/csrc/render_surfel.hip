@@ -82,50 +82,62 @@ struct Hit {
     bool use3d, geom_ok;
 };
 
-// GSR_PRECISE (default): the two places where the ray-splat intersection amplifies an ulp — the dehomogenisation
-// (u, v) = (cx, cy) / cz of a cross product that has already cancelled (k = x Tw - Tu: ~800 * 2 against ~1600), and the
-// exponent -rho/2 * log2(e) — are evaluated to the accuracy of the reference's division and expf: the hardware reciprocal
-// gets one Newton step and each quotient one residual correction (2 + 2 x 2 fma: correctly rounded in all but rare
-// cases), the product rho * (-log2(e)/2) carries its rounding error and the constant's low part into the result
-// (exp2(hi) (1 + lo ln 2): 4 operations).  Round-3 verdict: with plain v_rcp_f32 / v_exp_f32 the worst gradient element at
-// C5 size sat 2.5x further from float64 than the f32 oracle's (profiles/r03_fullsize_parity.log); cost and result of
-// this form: DESIGN.md section 9.  -DGSR_PRECISE=0 = the round-3 arithmetic (A/B builds only).
-#ifndef GSR_PRECISE
-#define GSR_PRECISE 1
+// The ray-splat intersection of one pixel against one staged surfel (oracle/gsr_oracle.c surfel_eval).
+// The published formulation is ill-conditioned in fp32: k = x Tw - Tu cancels (~800 * 2 against ~1600 for a small surfel
+// far from the image origin), the cross product cancels again, and (u, v) = (cx, cy) / cz divides by what is left — two
+// fp32 evaluations that differ in ONE rounding (an fma instead of multiply + subtract, a reciprocal instead of a
+// division) differ in their single worst gradient element by as much as either differs from float64, in either direction
+// (round 3: HIP's worst element of a C5 backward sat 2.5x further from float64 than the f32 oracle's in one test and 3x
+// closer in the next; round 4 measured that making the reciprocal and the exponent MORE accurate than the oracle's moves
+// nothing: profiles/r04_surfel_numerics.txt).  GSR_ORACLE_ORDER (default): the geometry is evaluated in the oracle's own
+// operation order — multiply then subtract for k, l and the cross product (no contraction), a correctly rounded quotient
+// (hardware reciprocal + one Newton step + one residual correction per quotient: 6 fma for both instead of two ~10-
+// instruction IEEE divisions), products and sums of rho and depth unfused — so (u, v), rho and the depth of every
+// (pixel, surfel) pair are the f32 oracle's BIT FOR BIT and the two programs differ only where they are well conditioned
+// (exp: <= 2 ulp; the order of fp32 sums).  -DGSR_ORACLE_ORDER=0 = the round-3 arithmetic (A/B builds only).
+#ifndef GSR_ORACLE_ORDER
+#define GSR_ORACLE_ORDER 1
 #endif
 __device__ __forceinline__ void intersect(const SEntry& en, float pxf, float pyf, Hit& h) {
+#if GSR_ORACLE_ORDER
+#pragma clang fp contract(off)
+    h.kx = pxf * en.tw.x - en.tu.x; h.ky = pxf * en.tw.y - en.tu.y; h.kz = pxf * en.tw.z - en.tu.z;
+    h.lx = pyf * en.tw.x - en.tv.x; h.ly = pyf * en.tw.y - en.tv.y; h.lz = pyf * en.tw.z - en.tv.z;
+    const float cx = h.ky * h.lz - h.kz * h.ly, cy = h.kz * h.lx - h.kx * h.lz, cz = h.kx * h.ly - h.ky * h.lx;
+    {
+        const float r0 = __builtin_amdgcn_rcpf(cz);
+        const float r = __builtin_fmaf(__builtin_fmaf(-cz, r0, 1.f), r0, r0);     // Newton step (NaN / inf for cz = 0: geom_ok is false then)
+        const float qx = cx * r, qy = cy * r;
+        h.rz = r;
+        h.sx = __builtin_fmaf(__builtin_fmaf(-qx, cz, cx), r, qx);                // quotient + residual / divisor: cx / cz rounded once
+        h.sy = __builtin_fmaf(__builtin_fmaf(-qy, cz, cy), r, qy);
+    }
+    const float rho3d = h.sx * h.sx + h.sy * h.sy;
+    h.dx = en.tu.w - pxf; h.dy = en.tv.w - pyf;
+    const float rho2d = 2.f * (h.dx * h.dx + h.dy * h.dy);
+    h.use3d = rho3d <= rho2d;
+    const float rho = h.use3d ? rho3d : rho2d;
+    h.depth = h.use3d ? (h.sx * en.tw.x + h.sy * en.tw.y) + en.tw.z : en.tw.z;
+    {   // exp(-rho / 2) = exp2(t), t = rho * (-log2(e) / 2) carried with its rounding error and the constant's low part
+        constexpr float c_hi = -0.5f * GDR_LOG2E;
+        constexpr float c_lo = (float)(-0.5 * 1.4426950408889634074 - (double)c_hi);
+        const float t_hi = rho * c_hi;
+        const float t_lo = __builtin_fmaf(rho, c_lo, __builtin_fmaf(rho, c_hi, -t_hi));
+        const float g0 = __builtin_amdgcn_exp2f(t_hi);
+        h.G = __builtin_fmaf(g0, t_lo * GDR_LN2, g0);
+    }
+#else
     h.kx = fmaf(pxf, en.tw.x, -en.tu.x); h.ky = fmaf(pxf, en.tw.y, -en.tu.y); h.kz = fmaf(pxf, en.tw.z, -en.tu.z);
     h.lx = fmaf(pyf, en.tw.x, -en.tv.x); h.ly = fmaf(pyf, en.tw.y, -en.tv.y); h.lz = fmaf(pyf, en.tw.z, -en.tv.z);
     const float cx = h.ky * h.lz - h.kz * h.ly, cy = h.kz * h.lx - h.kx * h.lz, cz = h.kx * h.ly - h.ky * h.lx;
-#if GSR_PRECISE
-    {
-        const float r0 = __builtin_amdgcn_rcpf(cz);
-        const float r = fmaf(fmaf(-cz, r0, 1.f), r0, r0);     // Newton step (NaN / inf for cz = 0: geom_ok is false then)
-        const float qx = cx * r, qy = cy * r;
-        h.rz = r;
-        h.sx = fmaf(fmaf(-qx, cz, cx), r, qx);                // quotient + residual / divisor
-        h.sy = fmaf(fmaf(-qy, cz, cy), r, qy);
-    }
-#else
     h.rz = __builtin_amdgcn_rcpf(cz);
     h.sx = cx * h.rz; h.sy = cy * h.rz;
-#endif
     const float rho3d = fmaf(h.sx, h.sx, h.sy * h.sy);
     h.dx = en.tu.w - pxf; h.dy = en.tv.w - pyf;
     const float rho2d = 2.f * fmaf(h.dx, h.dx, h.dy * h.dy);
     h.use3d = rho3d <= rho2d;
     const float rho = h.use3d ? rho3d : rho2d;
     h.depth = h.use3d ? fmaf(h.sx, en.tw.x, fmaf(h.sy, en.tw.y, en.tw.z)) : en.tw.z;
-#if GSR_PRECISE
-    {
-        constexpr float c_hi = -0.5f * GDR_LOG2E;                                  // fl(-log2(e) / 2)
-        constexpr float c_lo = (float)(-0.5 * 1.4426950408889634074 - (double)c_hi);
-        const float t_hi = rho * c_hi;
-        const float t_lo = fmaf(rho, c_lo, fmaf(rho, c_hi, -t_hi));
-        const float g0 = __builtin_amdgcn_exp2f(t_hi);
-        h.G = fmaf(g0, t_lo * GDR_LN2, g0);
-    }
-#else
     h.G = __builtin_amdgcn_exp2f((-0.5f * GDR_LOG2E) * rho);
 #endif
     h.alpha = fminf(0.99f, en.tw.w * h.G);
@@ -516,6 +528,36 @@ hipError_t launch_surfel_render_fwd(const gdr_settings* s, const gdr_geom* g, co
     GDR_LAUNCH(GDR_K_RENDER_FWD, surfel_render_fwd_kernel, dim3(ntiles), dim3(GDR_BLOCK), st, (const uint2*)img->ranges,
                bin->values[bin->sorted], img->tile_order, W, H, gx, ntiles, (const float4*)g->rec, s->bg, img->final_T,
                img->n_contrib, out->color, out->allmap, GDR_SEG_FWD_ARGS(bin, img));
+    return hipGetLastError();
+}
+
+// The (N,4) means2D gradient of ONE view from its K7s gradient record (what K9s forms inside its per-view loop:
+// preprocess_surfel.hip): the densification signal dL/dTu.z, dL/dTv.z x depth x W/2 | H/2 in columns 0-1 and its
+// per-pixel-|.| twin (record words 18, 19) in columns 2-3; zero for culled surfels.  Used by the render groups
+// (viewgroup.py): every call of the unchanged caller owns a carrier and gets ITS view's gradient, while the group's one
+// K9s returns the sums over the views for the shared inputs.
+namespace {
+__global__ __launch_bounds__(GDR_BLOCK) void surfel_means2d_view_kernel(int N, const float4* __restrict__ grad_rec,
+                                                                        const float4* __restrict__ rec,
+                                                                        const int32_t* __restrict__ radii, float hw, float hh,
+                                                                        float4* __restrict__ out) {
+    const int i = blockIdx.x * GDR_BLOCK + threadIdx.x;
+    if (i >= N) return;
+    float4 m = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (radii[i] > 0) {
+        const float4 g0 = grad_rec[8 * (size_t)i], g1 = grad_rec[8 * (size_t)i + 1], g4 = grad_rec[8 * (size_t)i + 4];
+        const float depth = rec[6 * (size_t)i + 2].z;
+        m = make_float4(g0.z * depth * hw, g1.y * depth * hh, g4.z * depth * hw, g4.w * depth * hh);
+    }
+    out[i] = m;
+}
+}  // namespace
+
+hipError_t launch_surfel_means2d_view(int N, const gdr_settings* s, const gdr_geom* g, const int32_t* radii,
+                                      const float* grad_rec, float* out, hipStream_t st) {
+    GDR_LAUNCH(GDR_K_SURFEL_MAPS, surfel_means2d_view_kernel, dim3((N + GDR_BLOCK - 1) / GDR_BLOCK), dim3(GDR_BLOCK), st, N,
+               (const float4*)grad_rec, (const float4*)g->rec, radii, 0.5f * (float)s->image_width,
+               0.5f * (float)s->image_height, (float4*)out);
     return hipGetLastError();
 }
 

@@ -46,6 +46,17 @@ def _ptr(t: Optional[torch.Tensor]):
     return None if t is None or t.numel() == 0 else C.c_void_p(t.data_ptr())
 
 
+_EMPTY: dict = {}
+
+
+def empty_f32(dev) -> torch.Tensor:
+    """The (0,) float32 tensor standing for an absent optional input, one per device (never written)."""
+    t = _EMPTY.get(dev)
+    if t is None:
+        t = _EMPTY[dev] = torch.empty(0, dtype=torch.float32, device=dev)
+    return t
+
+
 def _f32(t: torch.Tensor, dev) -> torch.Tensor:
     if t.device != dev:
         t = t.to(dev)
@@ -65,7 +76,7 @@ class _State:
     """Typed views of the three workspaces of one forward call (kept for backward and
     exposed to the parity tests)."""
 
-    __slots__ = ("N", "M", "H", "W", "D", "geom_buf", "bin_buf", "img_buf", "geom", "bin", "img", "counters")
+    __slots__ = ("N", "M", "H", "W", "D", "geom_buf", "bin_buf", "img_buf", "geom", "bin", "img", "counters", "view")
 
     def _view(self, buf, ptr, dtype, count):
         off = ptr - buf.data_ptr()
@@ -292,12 +303,55 @@ class _SideViews:
                 self.main.wait_event(done)
 
 
+class GroupMismatch(RuntimeError):
+    """A later call of a render group was handed values that differ from the group's (viewgroup.py falls back to an
+    independent node for that call)."""
+
+
+def _view_opts():
+    """The test / A-B switches of this module as the library's gdr_view_opts (-1 = the library's policy)."""
+    return L.GdrViewOpts(-1 if SEG_LEN is None else max(0, int(SEG_LEN)) // 256 * 256,
+                         -1 if DEEP_MAX_BUSY is None else max(0, int(DEEP_MAX_BUSY)),
+                         -1 if DEEP_MIN_MEAN is None else max(0, int(DEEP_MIN_MEAN)),
+                         int(_FORCE_GLOBAL_SORT), int(_FORCE_RADIX_PARTITION), int(not LAUNCH_HINTS))
+
+
+def forward_view_native(call, s, inp, N, H, W, surfel, out, same_as, dev, stream):
+    """ONE native call per view (include/gdr.h gdr_forward_view / gsr_forward_view, round 4): the library carves one
+    allocation, runs K1, binning and K6 sized by the device counter, reads the duplicate count back through its pooled
+    pinned buffer and keeps the per-shape history the next call is planned from.  Returns (workspace tensor,
+    GdrViewState).  A GDR_ERR_WORKSPACE answer (first call of a shape, or a scene that outgrew the slack) is followed by
+    an exactly planned second call."""
+    lib = L.load()
+    opts, plan, vs = _view_opts(), L.GdrViewPlan(), L.GdrViewState()
+    same = None
+    if same_as:
+        same = L.GdrSameAs()
+        same.n = len(same_as)
+        for k, (t, ref) in enumerate(same_as):
+            same.a[k], same.b[k], same.n_bytes[k] = t.data_ptr(), ref.data_ptr(), t.numel() * 4
+        same = C.byref(same)
+    exact = 0
+    for _ in range(4):
+        L.check(lib.gdr_view_plan_for(N, H, W, int(surfel), exact, C.byref(opts), C.byref(plan)), "gdr_view_plan_for")
+        if not DEFER_D and not exact:     # upstream's flow: the count is read back before anything is sized
+            plan.have_binning = 0
+        ws = torch.empty(max(int(plan.bytes), 256), dtype=torch.uint8, device=dev)
+        rc = call(s, inp, C.byref(plan), C.c_void_p(ws.data_ptr()), C.byref(opts), same, out, C.byref(vs), stream)
+        if rc == L.GDR_OK:
+            return ws, vs
+        if rc != L.GDR_ERR_WORKSPACE:
+            L.check(rc, "gdr_forward_view")
+        exact = max(1, int(vs.D))
+    raise RuntimeError("gdr_forward_view: the duplicate count kept growing between calls")
+
+
 def forward_raw(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                 raster_settings, same_as=None):
     """Un-differentiated forward. Returns (color, radii, depth, alpha, state, keep).
     same_as: optional [(tensor, reference tensor)] pairs a render group wants verified equal bit for bit (viewgroup.py):
     compared on the device next to K1, the verdict travels with the duplicate count (the spare word behind
-    gdr_geom.num_rendered, same 8-byte copy) — no extra copy, no extra synchronisation; a difference raises here."""
+    gdr_geom.num_rendered, same 8-byte copy) — no extra copy, no extra synchronisation; a difference raises GroupMismatch."""
     lib = L.load()
     _require_hip(means3D, "means3D")
     dev = means3D.device
@@ -317,72 +371,24 @@ def forward_raw(means3D, sh, colors_precomp, opacities, scales, rotations, cov3D
     with torch.cuda.device(dev):
         s = _settings_struct(raster_settings, dev, keep)
         inp = _inputs_struct(N, M, means3D, opacities, sh, colors_precomp, scales, rotations, cov3Ds_precomp)
-        st = _State()
-        st.N, st.M, st.H, st.W = N, M, H, W
-        u8 = dict(dtype=torch.uint8, device=dev)
-        st.geom_buf = torch.empty(lib.gdr_geom_bytes(N), **u8)
-        st.img_buf = torch.empty(lib.gdr_image_bytes(H, W), **u8)
-        st.geom, st.bin, st.img = L.GdrGeom(), L.GdrBinning(), L.GdrImage()
-        L.check(lib.gdr_geom_carve(st.geom_buf.data_ptr(), N, C.byref(st.geom)), "gdr_geom_carve")
-        L.check(lib.gdr_image_carve(st.img_buf.data_ptr(), H, W, C.byref(st.img)), "gdr_image_carve")
         f32 = dict(dtype=torch.float32, device=dev)
         color = torch.empty(3, H, W, **f32)
         depth = torch.empty(1, H, W, **f32)
         alpha = torch.empty(1, H, W, **f32)
         radii = torch.empty(N, dtype=torch.int32, device=dev)
-        stream = _stream()
-        tiles = ((W + 15) // 16) * ((H + 15) // 16)
-        st.bin_buf = None
         out = L.GdrOutputs(color.data_ptr(), depth.data_ptr(), alpha.data_ptr(), _ptr(radii))
-        key = shape_key(N, H, W)
-        cap = _d_capacity(key, N) if N > 0 else None
-        stats, hints = _launch_stats(key, 1)
-        srow = None if stats is None else stats[0]
-
-        def render():    # K3..K6 behind K1 on the caller's stream
-            L.check(lib.gdr_render_forward(C.byref(s), C.byref(inp), C.byref(st.geom), C.byref(st.bin),
-                                           C.byref(st.img), st.D, C.byref(out), stream), "gdr_render_forward")
-
-        # [duplicate count, spare word]: the geometry workspace keeps a 256-byte slot behind num_rendered
-        st.counters = st._view(st.geom_buf, st.geom.num_rendered, torch.int32, 2)
-        if same_as:
-            st.counters[1:2].zero_()
-            for k0 in range(0, len(same_as), 4):     # (one launch for up to four tensor pairs)
-                part = same_as[k0:k0 + 4]
-                a_arr = (C.c_void_p * len(part))(*[t.data_ptr() for t, _ in part])
-                b_arr = (C.c_void_p * len(part))(*[ref.data_ptr() for _, ref in part])
-                n_arr = (C.c_uint64 * len(part))(*[t.numel() * 4 for t, _ in part])
-                L.check(lib.gdr_words_differ_multi(len(part), a_arr, b_arr, n_arr, C.c_void_p(st.geom.num_rendered + 4),
-                                                   stream), "gdr_words_differ_multi")
-        differ = 0
-        if cap is None:   # first call of this shape: the read-back upstream performs in every call
-            d_host = C.c_uint32(0)
-            L.check(lib.gdr_preprocess_forward(C.byref(s), C.byref(inp), C.byref(st.geom), _ptr(radii),
-                                               C.byref(d_host), stream), "gdr_preprocess_forward")
-            d = int(d_host.value)
-            if same_as:
-                differ = _CountReadback(st.counters).wait()[1]
-            _carve_binning(lib, st, d, tiles, stats=srow, hints=hints)
-            render()
-        else:             # device-sized call (DEFER_D above): nothing waits for K1 until everything is enqueued
-            L.check(lib.gdr_preprocess_forward(C.byref(s), C.byref(inp), C.byref(st.geom), _ptr(radii), None, stream),
-                    "gdr_preprocess_forward")
-            readback = _CountReadback(st.counters)
-            _carve_binning(lib, st, cap, tiles, d_dev=st.geom.num_rendered, stats=srow, hints=hints)
-            render()
-            d, differ = readback.wait()
-            differ = differ if same_as else 0
-            if d > cap:
-                _carve_binning(lib, st, d, tiles, stats=srow, hints=hints)
-                render()
-            st.D = d
-        _d_record(key, [d], N)
-        if differ:
-            raise RuntimeError(
+        ws, vs = forward_view_native(lib.gdr_forward_view, C.byref(s), C.byref(inp), N, H, W, False, C.byref(out), same_as,
+                                     dev, _stream())
+        st = _State()
+        st.N, st.M, st.H, st.W, st.D = N, M, H, W, int(vs.D)
+        st.geom_buf = st.bin_buf = st.img_buf = ws      # one allocation, carved by the library
+        st.view, st.geom, st.bin, st.img = vs, vs.geom, vs.bin, vs.img
+        keep.append(s)      # (the backward of this call reuses the struct: its device tensors are in `keep` already)
+        if same_as and vs.differ:
+            raise GroupMismatch(
                 "diff_gaussian_rasterization: this call's opacities / scales / rotations have the autograd provenance of "
                 "an earlier call's (same ops on the same sources) but different values — a source tensor was modified in "
-                "place between the calls, outside autograd's view.  Set GDR_GROUP_VIEWS=0 to render every call as an "
-                "independent node.")
+                "place between the calls, outside autograd's view.")
     return color, radii, depth, alpha, st, keep
 
 
@@ -395,7 +401,7 @@ def backward_raw(st: _State, keep, raster_settings, radii, grad_color, grad_dept
     f32 = dict(dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         keep2: list = []
-        s = _settings_struct(raster_settings, dev, keep2)
+        s = keep[-1] if isinstance(keep[-1], L.GdrSettings) else _settings_struct(raster_settings, dev, keep2)
         inp = _inputs_struct(N, M, means3D, opacities, sh, colors_precomp, scales, rotations, cov3Ds_precomp)
         gc = _f32(grad_color, dev)
         gd = None if grad_depth is None else _f32(grad_depth, dev)
@@ -533,6 +539,8 @@ class _RasterizeGaussians(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_color, grad_radii, grad_depth, grad_alpha):
+        from . import viewgroup
+        viewgroup.note_backward()
         g = backward_raw(ctx.state, _saved_inputs(ctx), ctx.raster_settings, ctx.radii, grad_color, grad_depth,
                          grad_alpha)
         gm2 = g["means2D"]
@@ -1141,8 +1149,12 @@ def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales,
     network.py:827-838, 848-856, 964-972) join a render group: one preprocess-backward for all of them (viewgroup.py);
     everything else is one independent autograd node per call."""
     from . import viewgroup
+    if torch.is_grad_enabled():
+        viewgroup.note_forward()
     if viewgroup.eligible(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp):
-        return viewgroup.grouped_call(means3D, means2D, sh, opacities, scales, rotations, raster_settings)
+        out = viewgroup.grouped_call(viewgroup.PATH_3D, means3D, means2D, sh, opacities, scales, rotations, raster_settings)
+        if out is not None:
+            return out
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
                                      cov3Ds_precomp, raster_settings)
 
@@ -1172,7 +1184,7 @@ class GaussianRasterizer(nn.Module):
         if ((scales is None or rotations is None) and cov3D_precomp is None) or (
                 (scales is not None or rotations is not None) and cov3D_precomp is not None):
             raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
-        e = torch.empty(0, dtype=torch.float32, device=means3D.device)
+        e = empty_f32(means3D.device)
         return rasterize_gaussians(
             means3D, means2D, e if shs is None else shs, e if colors_precomp is None else colors_precomp,
             opacities, e if scales is None else scales, e if rotations is None else rotations,

@@ -63,7 +63,8 @@ def _inputs_struct(N, M, means3D, opacities, sh, colors_precomp, scales, rotatio
                        _ptr(rotations), _ptr(transmat), int(flags), 0)
 
 
-def forward_raw(means3D, sh, colors_precomp, opacities, scales, rotations, transMat_precomp, raster_settings, flags=0):
+def forward_raw(means3D, sh, colors_precomp, opacities, scales, rotations, transMat_precomp, raster_settings, flags=0,
+                same_as=None):
     """Un-differentiated forward.  Returns (color, radii, allmap, state, keep)."""
     lib = L.load()
     _require_hip(means3D, "means3D")
@@ -84,51 +85,22 @@ def forward_raw(means3D, sh, colors_precomp, opacities, scales, rotations, trans
     with torch.cuda.device(dev):
         s = _settings_struct(raster_settings, dev, keep)
         inp = _inputs_struct(N, M, means3D, opacities, sh, colors_precomp, scales, rotations, transMat_precomp, flags)
-        st = _SurfelState()
-        st.N, st.M, st.H, st.W = N, M, H, W
-        u8 = dict(dtype=torch.uint8, device=dev)
-        st.geom_buf = torch.empty(lib.gsr_geom_bytes(N), **u8)
-        st.img_buf = torch.empty(lib.gsr_image_bytes(H, W), **u8)
-        st.geom, st.bin, st.img = L.GdrGeom(), L.GdrBinning(), L.GdrImage()
-        L.check(lib.gsr_geom_carve(st.geom_buf.data_ptr(), N, C.byref(st.geom)), "gsr_geom_carve")
-        L.check(lib.gsr_image_carve(st.img_buf.data_ptr(), H, W, C.byref(st.img)), "gsr_image_carve")
         f32 = dict(dtype=torch.float32, device=dev)
         color = torch.empty(3, H, W, **f32)
         allmap = torch.empty(7, H, W, **f32)
         radii = torch.empty(N, dtype=torch.int32, device=dev)
-        stream = _stream()
-        tiles = ((W + 15) // 16) * ((H + 15) // 16)
-        st.bin_buf = None
         out = L.GsrOutputs(color.data_ptr(), allmap.data_ptr(), _ptr(radii))
-        key = ("surfel",) + _R.shape_key(N, H, W)
-        cap = _R._d_capacity(key, N) if N > 0 else None
-        stats, hints = _R._launch_stats(key, 1)
-        srow = None if stats is None else stats[0]
-
-        def render():    # K3..K6s behind K1s on the caller's stream
-            L.check(lib.gsr_render_forward(C.byref(s), C.byref(inp), C.byref(st.geom), C.byref(st.bin), C.byref(st.img),
-                                           st.D, C.byref(out), stream), "gsr_render_forward")
-
-        if cap is None:   # first call of this shape: read D back, as upstream does in every call
-            d_host = C.c_uint32(0)
-            L.check(lib.gsr_preprocess_forward(C.byref(s), C.byref(inp), C.byref(st.geom), _ptr(radii), C.byref(d_host),
-                                               stream), "gsr_preprocess_forward")
-            d = int(d_host.value)
-            _R._carve_binning(lib, st, d, tiles, stats=srow, hints=hints)
-            render()
-        else:             # device-sized call (rasterizer.DEFER_D): capacity check after everything is enqueued
-            L.check(lib.gsr_preprocess_forward(C.byref(s), C.byref(inp), C.byref(st.geom), _ptr(radii), None, stream),
-                    "gsr_preprocess_forward")
-            st.counters = st._view(st.geom_buf, st.geom.num_rendered, torch.int32, 1)
-            readback = _R._CountReadback(st.counters)
-            _R._carve_binning(lib, st, cap, tiles, d_dev=st.geom.num_rendered, stats=srow, hints=hints)
-            render()
-            d = readback.wait()[0]
-            if d > cap:
-                _R._carve_binning(lib, st, d, tiles, stats=srow, hints=hints)
-                render()
-            st.D = d
-        _R._d_record(key, [d], N)
+        # one native call (include/gsr.h gsr_forward_view): carving, K1s, binning, K6s, the count read-back and the
+        # per-shape history are the library's (rasterizer.forward_view_native)
+        ws, vs = _R.forward_view_native(lib.gsr_forward_view, C.byref(s), C.byref(inp), N, H, W, True, C.byref(out), same_as,
+                                        dev, _stream())
+        st = _SurfelState()
+        st.N, st.M, st.H, st.W, st.D = N, M, H, W, int(vs.D)
+        st.geom_buf = st.bin_buf = st.img_buf = ws
+        st.view, st.geom, st.bin, st.img = vs, vs.geom, vs.bin, vs.img
+        keep.append(s)      # (reused by the backward of this call)
+        if same_as and vs.differ:
+            raise _R.GroupMismatch("diff_surfel_rasterization: equal autograd provenance but different values")
     return color, radii, allmap, st, keep
 
 
@@ -141,7 +113,7 @@ def backward_raw(st, keep, raster_settings, radii, grad_color, grad_allmap):
     f32 = dict(dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         keep2: list = []
-        s = _settings_struct(raster_settings, dev, keep2)
+        s = keep[-1] if isinstance(keep[-1], L.GdrSettings) else _settings_struct(raster_settings, dev, keep2)
         inp = _inputs_struct(N, M, means3D, opacities, sh, colors_precomp, scales, rotations, transmat, flags)
         gc = _f32(grad_color, dev)
         ga = None if grad_allmap is None else _f32(grad_allmap, dev)
@@ -181,6 +153,8 @@ class _RasterizeSurfels(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_color, grad_radii, grad_allmap):
+        from . import viewgroup
+        viewgroup.note_backward()
         g = backward_raw(ctx.state, _R._saved_inputs(ctx), ctx.raster_settings, ctx.radii, grad_color, grad_allmap)
         gm2 = g["means2D"]
         cols = ctx.means2D_shape[1] if len(ctx.means2D_shape) == 2 else 4
@@ -525,6 +499,18 @@ def render_surfel_views_raw(means3D, means2D, sh, opacities, scales, rotations, 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                         raster_settings):
+    """The reference boundary (/root/reference/lightning/renderer_2dgs.py:224-234).  Calls that are provably handed the same
+    surfels as earlier ones join a render group — one K9s for all of them (viewgroup.py, round 4); everything else is one
+    independent autograd node per call."""
+    from . import viewgroup
+    if torch.is_grad_enabled():
+        viewgroup.note_forward()
+    if (viewgroup.eligible(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp)
+            and scales.shape[-1] == 2 and viewgroup.PATH_SURFEL.supports(sh, raster_settings)):
+        out = viewgroup.grouped_call(viewgroup.PATH_SURFEL, means3D, means2D, sh, opacities, scales, rotations,
+                                     raster_settings)
+        if out is not None:
+            return out
     return _RasterizeSurfels.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
                                    cov3Ds_precomp, raster_settings)
 
@@ -544,7 +530,7 @@ class GaussianRasterizer(nn.Module):
         if ((scales is None or rotations is None) and cov3D_precomp is None) or (
                 (scales is not None or rotations is not None) and cov3D_precomp is not None):
             raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
-        e = torch.empty(0, dtype=torch.float32, device=means3D.device)
+        e = _R.empty_f32(means3D.device)
         return rasterize_gaussians(
             means3D, means2D, e if shs is None else shs, e if colors_precomp is None else colors_precomp, opacities,
             e if scales is None else scales, e if rotations is None else rotations,

@@ -299,6 +299,62 @@ int gdr_forward(const gdr_settings* s, const gdr_inputs* in, const gdr_geom* geo
                 gdr_binning* bin, const gdr_image* img, uint64_t D_cap, const gdr_outputs* out,
                 uint32_t* num_rendered_host, void* stream);
 
+/* ---- one forward call per view (v14) ------------------------------------------------------------------------------
+ * The reference's extension does its whole forward in ONE native call (`_C.rasterize_gaussians`, reached from
+ * /root/reference/lightning/renderer.py:250-259 inside the per-view loops of network.py:827-838).  gdr_forward_view is
+ * that call: it carves ONE caller allocation into the geometry / image / binning state, runs K1, starts the duplicate
+ * count on its way to pinned host memory, enqueues binning + K6 sized by the device counter, waits for the count and
+ * compares it with the capacity — everything the Python boundary did with ~20 ABI calls until round 3.
+ *   gdr_view_plan_for   sizes the allocation: capacity = exact_D if given, else 1.5 x the largest recent duplicate count
+ *                       per Gaussian of this scene shape (device, power-of-two bucket of N, H, W) x N + 4096 — the library
+ *                       keeps that small per-shape history (process-wide, mutex-guarded; gdr_view_history_reset clears it)
+ *                       together with the launch-size feedback of gdr_binning.stats_out / hint_*.  No history yet:
+ *                       plan.have_binning = 0 — the forward then stops behind K1 with GDR_ERR_WORKSPACE and state.D set;
+ *   gdr_forward_view    returns GDR_OK with `state` filled (the structs every backward entry point takes, and D), or
+ *                       GDR_ERR_WORKSPACE with state.D = the count: plan again with exact_D = state.D, allocate, call again
+ *                       (the first call of a shape, or a scene that grew past the slack: nothing was written out of bounds).
+ * opts (NULL = defaults): test / A-B overrides, each -1 / 0 = the library's policy.  same (NULL = none): up to 4 buffer
+ * pairs compared bit for bit next to K1 (see gdr_words_differ; state.differ != 0 if any differs) — the equality check of a
+ * render group rides on the count's copy.  Thread-safe for distinct workspaces. */
+typedef struct gdr_view_plan {
+    uint64_t capacity;     /* duplicates the binning state is carved for */
+    uint64_t bytes;        /* size of the one allocation (256-byte aligned base) */
+    int32_t seg_len;       /* gdr_binning.seg_len of the carve */
+    int32_t deferred;      /* != 0: capacity is a guess -> device-sized call */
+    int32_t have_binning;  /* 0: no history and no exact_D: geometry + image state only */
+    int32_t reserved;
+} gdr_view_plan;
+typedef struct gdr_view_opts {
+    int32_t seg_len;         /* >= 0: segment length of cut lists (0 = never cut); -1: policy (256; 512 on busy 800x800 images) */
+    int32_t deep_max_busy;   /* >= 0: gdr_binning.deep_max_busy; -1: default */
+    int32_t deep_min_mean;   /* >= 0: gdr_binning.deep_min_mean; -1: default */
+    int32_t global_sort;     /* != 0: one global radix sort (tested fallback) */
+    int32_t radix_partition; /* != 0: radix partition on the tile bits instead of the direct tile binning (tested fallback) */
+    int32_t no_hints;        /* != 0: no launch-size feedback */
+} gdr_view_opts;
+typedef struct gdr_same_as {
+    int32_t n;               /* <= 4 */
+    int32_t reserved;
+    const void* a[4]; const void* b[4]; uint64_t n_bytes[4];
+} gdr_same_as;
+typedef struct gdr_view_state {
+    gdr_geom geom; gdr_binning bin; gdr_image img;
+    uint64_t D;              /* duplicates of the view (the reference's num_rendered) */
+    uint32_t differ;         /* != 0: a same-as pair differed */
+    uint32_t reserved;
+} gdr_view_state;
+int gdr_view_plan_for(int32_t N, int32_t H, int32_t W, int32_t surfel, uint64_t exact_D, const gdr_view_opts* opts,
+                      gdr_view_plan* plan);
+int gdr_forward_view(const gdr_settings* s, const gdr_inputs* in, const gdr_view_plan* plan, void* workspace,
+                     const gdr_view_opts* opts, const gdr_same_as* same, const gdr_outputs* out, gdr_view_state* state,
+                     void* stream);
+void gdr_view_history_reset(void);
+/* the history behind gdr_view_plan_for, per scene shape: the decaying maximum of duplicates per Gaussian (0 = none yet).
+ * _set seeds or overrides it — a caller that knows its scene statistics skips the read-back of a shape's first call; the
+ * tests force an overflow with a tiny value (the call then answers GDR_ERR_WORKSPACE and is repeated exactly sized). */
+double gdr_view_history_get(int32_t N, int32_t H, int32_t W, int32_t surfel);
+void gdr_view_history_set(int32_t N, int32_t H, int32_t W, int32_t surfel, double duplicates_per_gaussian);
+
 /* ---- backward (K7 + K8/K9) --------------------------------------------------------
  * Replaces `_C.rasterize_gaussians_backward`, reached through autograd from the losses on the render outputs
  * (/root/reference/lightning/network.py:746-752, 836, 854, 971) and through `vjp` w.r.t. the (N,4) means2D carrier

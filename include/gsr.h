@@ -96,6 +96,18 @@ int gsr_composite_forward(const gdr_settings* s, const gdr_geom* geom, const gdr
 int gsr_forward(const gdr_settings* s, const gsr_inputs* in, const gdr_geom* geom, gdr_binning* bin,
                 const gdr_image* img, uint64_t D_cap, const gsr_outputs* out, uint32_t* num_rendered_host,
                 void* stream);
+/* The (N,4) means2D gradient of ONE view from its K7s record (v14): columns 0-1 = dL/dTu.z, dL/dTv.z x depth x W/2 | H/2
+ * (the densification signal K9s returns summed over the views), columns 2-3 its per-pixel-|.| twin; zero where radii <= 0.
+ * For callers that give every view its own means2D carrier (/root/reference/lightning/renderer_2dgs.py:209-222) while one
+ * gsr_preprocess_backward_views serves all the views. */
+int gsr_means2d_of_view(const gdr_settings* s, int32_t N, const gdr_geom* geom, const int32_t* radii,
+                        const float* grad_rec, float* dL_dmean2D, void* stream);
+/* one forward call per view (v14): the surfel twin of gdr_forward_view — plan with gdr_view_plan_for(N, H, W, 1, ...);
+ * replaces the forward of `diff_surfel_rasterization._C.rasterize_gaussians` reached from
+ * /root/reference/lightning/renderer_2dgs.py:224-234 in one native call */
+int gsr_forward_view(const gdr_settings* s, const gsr_inputs* in, const gdr_view_plan* plan, void* workspace,
+                     const gdr_view_opts* opts, const gdr_same_as* same, const gsr_outputs* out, gdr_view_state* state,
+                     void* stream);
 int gsr_backward(const gdr_settings* s, const gsr_inputs* in, const gdr_geom* geom, const gdr_binning* bin,
                  const gdr_image* img, uint64_t D, const int32_t* radii, const gsr_grad_inputs* gin,
                  const gsr_grad_outputs* gout, void* stream);

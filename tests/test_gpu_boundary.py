@@ -208,32 +208,49 @@ def test_device_sized_binning_equals_the_read_back_and_an_overflow_repeats_the_v
         fused = lambda: r.render_views_loss(cams, None, targets, *args)
         single = lambda: r.render_img(cams[1], None, *args)
 
+    # the boundary's own single call (GaussianRasterizer of either package): ONE native call, gdr_forward_view /
+    # gsr_forward_view, whose per-shape history lives in the library (gdr_view_history_*)
+    r_plain = Renderer(sh_degree=1) if surfel else Renderer(sh_degree=1, white_background=True, fused=False)
+    plain = (lambda: r_plain.render_img(cams[1], rays[1], *args)) if surfel else (lambda: r_plain.render_img(cams[1], None, *args))
+    from generativedensification_amd import _lib as L
+    lib = L.load()
+
     def run(hint):
         def prep():
             if hint == "none":
                 R._D_HINT.clear()
+                lib.gdr_view_history_reset()
             elif hint == "small":       # capacity ~4100 entries: every view overflows and is repeated
                 R._D_HINT[key], R._D_HINT[key1] = 1e-4, 1e-4
+                lib.gdr_view_history_set(N, H, W, int(surfel), 1e-4)
         res = []
         with torch.no_grad():
-            for fn in (views, fused, single):
+            for fn in (views, fused, single, plain):
                 prep()
                 res.append(fn())
         torch.cuda.synchronize()
-        return [o["image"].clone() for o in res[0]], res[1].clone(), res[2]["image"].clone()
+        return [o["image"].clone() for o in res[0]], res[1].clone(), res[2]["image"].clone(), res[3]["image"].clone()
 
     saved, saved_defer = dict(R._D_HINT), R.DEFER_D
     R.DEFER_D = True
     try:
-        img0, loss0, one0 = run("none")                 # no history: read-back flow
+        img0, loss0, one0, pl0 = run("none")                 # no history: read-back flow
         views()
-        assert key in R._D_HINT and key1 in R._D_HINT and R._d_capacity(key, N) > R._D_HINT[key] * N > 0
-        img1, loss1, one1 = run("history")              # device-sized calls
-        img2, loss2, one2 = run("small")
-        assert R._D_HINT[key1] > 1e-2    # (the last call of the run was the one-view node: its history is real again)
-        for imgs, losses, one in ((img1, loss1, one1), (img2, loss2, one2)):
-            assert all(torch.equal(a, b) for a, b in zip(imgs, img0)) and torch.equal(one, one0)
+        assert key in R._D_HINT and R._d_capacity(key, N) > R._D_HINT[key] * N > 0
+        assert lib.gdr_view_history_get(N, H, W, int(surfel)) > 1e-2      # (the library's history of the single-call shape)
+        img1, loss1, one1, pl1 = run("history")              # device-sized calls
+        img2, loss2, one2, pl2 = run("small")
+        assert lib.gdr_view_history_get(N, H, W, int(surfel)) > 1e-2    # (the overflow call recorded the real count)
+        for imgs, losses, one, pl in ((img1, loss1, one1, pl1), (img2, loss2, one2, pl2)):
+            assert all(torch.equal(a, b) for a, b in zip(imgs, img0)) and torch.equal(one, one0) and torch.equal(pl, pl0)
             np.testing.assert_allclose(losses.cpu().numpy(), loss0.cpu().numpy(), rtol=2e-6)   # (atomic order)
+        saved_d = R.DEFER_D
+        R.DEFER_D = False          # upstream's flow in every call: the count is read back before anything is sized
+        try:
+            with torch.no_grad():
+                assert torch.equal(plain()["image"], pl0)
+        finally:
+            R.DEFER_D = saved_d
         # the state of a device-sized call holds the exact count and the same sorted lists
         if not surfel:
             sets = [Renderer(sh_degree=1).set_rasterizer(c, device=dev).raster_settings for c in cams]

@@ -121,6 +121,30 @@ def test_bench_gpus2_spawns_two_ranks_by_itself():
     assert out["config"]["views_per_gpu"] == 4 and out["value"] > 0
 
 
+def test_bench_two_ranks_with_grad_allreduce_equal_one_rank_with_all_views():
+    """`bench.py --gpus 2 --single-device --grad-allreduce` (4 views per rank, gradients of the shared Gaussians summed with
+    reduce-scatter + all-gather of the packed buffer) against ONE rank rendering the same 8 views: per-view losses identical,
+    gradient L1 norms equal up to the order of fp32 sums; the collectives' own times are in the line (`comm_ms`); the
+    --keep-grads variant (gradients accumulated into the persistent packed buffer) gives the same sums."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    common = ["--workload", "c2", "--n", "40000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-roofline",
+              "--no-per-view-leg"]
+
+    def run(extra):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + common + extra, env=env, capture_output=True,
+                           text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    one = run(["--views-per-gpu", "8"])
+    two = run(["--gpus", "2", "--single-device", "--grad-allreduce"])
+    kept = run(["--gpus", "2", "--single-device", "--grad-allreduce", "--keep-grads"])
+    assert one["comm_ms"] is None and two["comm_ms"]["grad_allreduce"] > 0 and two["comm_ms"]["loss_gather"] > 0
+    assert abs(two["loss_mean"] - one["loss_mean"]) <= 2e-6 * abs(one["loss_mean"])
+    for res in (two, kept):
+        for k, v in one["grad_l1"].items():
+            assert v > 0 and abs(res["grad_l1"][k] - v) <= 1e-4 * v, (k, v, res["grad_l1"][k])
+
+
 def test_bench_gpus8_on_one_device():
     """The driver's 8-rank launch shape on a 1-GPU box: `bench.py --gpus 8 --single-device` becomes 8 ranks (gloo, all on
     cuda:0, reduced N) — port / launcher / pinned-memory / side-stream-table problems that two ranks do not show would show

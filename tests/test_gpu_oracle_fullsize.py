@@ -279,7 +279,7 @@ def test_surfel_whole_image_at_c5_size(oracle_built):
     # than the oracle in every tensor).  (c), the single worst element of 0.5 M x 59: with a gradient on every pixel and
     # channel it is one ill-conditioned surfel, a different one for every fp32 evaluation order — the oracle's worst sits
     # 3.8e-3 .. 5.4e-2 (max-norm) from float64, HIP's 1.0 .. 2.2 x that: asserted within 3 x instead of 1.25 x.
-    U.assert_grads_surfel(hg, out["f64"], out["f32"], GRAD_KEYS, "c5 whole image", worst_factor=3.0)
+    U.assert_grads_surfel(hg, out["f64"], out["f32"], GRAD_KEYS, "c5 whole image", worst_factor=1.25)
 
 
 # --------------------------------------------------------------------------------------------------------------------
@@ -534,4 +534,4 @@ def test_surfel_render_views_backward_vs_oracle(oracle_built, size):
     # 2.7e-4 .. 1.3e-3 of the elements outside (bar 1.5e-3), HIP closer to float64 than the oracle in every tensor; (c), the
     # single worst element: the oracle's sits 1e-3 .. 2.7e-2 from float64, HIP's 1.0 .. 3.2 x that — one ill-conditioned surfel,
     # see test_surfel_whole_image_at_c5_size — within 4 x.)
-    U.assert_grads_surfel(g_hip, g64, g32, list(g32), "surfel render_views " + size, worst_factor=1.25 if size == "small" else 4.0)
+    U.assert_grads_surfel(g_hip, g64, g32, list(g32), "surfel render_views " + size, worst_factor=1.25)
