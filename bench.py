@@ -956,12 +956,12 @@ def main():
             # The kernels of different views run on side streams, several launches at a time: each launch then takes
             # longer than it does alone, and the per-launch figures above shrink although the work per second does not.
             # A short extra pass with every kernel on ONE stream gives each kernel's duration on its own.
-            if R.RENDER_SIDE and vpg > 1 and not (args.per_view or args.backward_per_view or args.torch_loss and surfel):
-                R.RENDER_SIDE = 0
+            if R.K.RENDER_SIDE and vpg > 1 and not (args.per_view or args.backward_per_view or args.torch_loss and surfel):
+                R.K.RENDER_SIDE = 0
                 try:
                     prof1 = profiled(step, min(args.steps, 3))
                 finally:
-                    R.RENDER_SIDE = 1
+                    R.K.RENDER_SIDE = 1
                 for name, (ms1, cnt1) in prof1.items():
                     if cnt1 and name in kernels:
                         a1 = 1e3 * ms1 / cnt1

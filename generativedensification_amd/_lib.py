@@ -52,7 +52,7 @@ class GdrBinning(C.Structure):
                 ("seg_len", C.c_int32), ("seg_cap", C.c_int32), ("deep_max_busy", C.c_int32), ("deep_min_mean", C.c_int32),
                 ("d_dev", C.c_void_p), ("stats_out", C.c_void_p), ("hint_long", C.c_int32), ("hint_medium", C.c_int32),
                 ("hint_no_deep", C.c_int32), ("grad_rec_cleared", C.c_int32), ("tile_hist", C.c_void_p),
-                ("hist_width", C.c_int32), ("reserved1", C.c_int32)]
+                ("hist_width", C.c_int32), ("hist_tiles", C.c_int32)]
 
 
 class GdrImage(C.Structure):

@@ -109,11 +109,12 @@ static size_t carve_binning(void* base, uint64_t D, gdr_binning* b, int32_t seg_
     t.seg_state = c.take<float>(t.seg_cap ? (size_t)2 * t.seg_cap * GDR_SEG_STATE_FLOATS : 1);
     t.tile_hist = nullptr;
     t.hist_width = 0;
-    t.reserved1 = 0;
+    t.hist_tiles = 0;
     if (N > 0 && tiles > 0 && tiles <= GDR_BIN_MAX_TILES) {   // direct tile binning: (width rows x tiles) counts + a totals row
         int w = (N + 1023) / 1024;
         t.hist_width = w > GDR_BIN_MAX_WIDTH ? GDR_BIN_MAX_WIDTH : w;
-        t.tile_hist = c.take<uint32_t>((size_t)(t.hist_width + 1) * ((tiles + 63) / 64 * 64));
+        t.hist_tiles = (tiles + 63) / 64 * 64;
+        t.tile_hist = c.take<uint32_t>((size_t)(t.hist_width + 1) * (size_t)t.hist_tiles);
     }
     if (b) *b = t;
     return c.off;
@@ -287,7 +288,9 @@ static int binning_stage_views(int V, const gdr_settings* s, int32_t N, const gd
     bool direct = !global_sort && tiles <= GDR_BIN_MAX_TILES;
     uint64_t dmax = 0;
     for (int v = 0; v < V; ++v) {
-        direct = direct && bins[v].tile_hist && bins[v].hist_width > 0 && bins[v].hist_width == bins[0].hist_width;
+        // (a count matrix carved for a smaller image cannot take this one: the radix partition produces the same lists)
+        direct = direct && bins[v].tile_hist && bins[v].hist_width > 0 && bins[v].hist_width == bins[0].hist_width &&
+                 bins[v].hist_tiles >= (tiles + 63) / 64 * 64;
         dmax = D[v] > dmax ? D[v] : dmax;
     }
     if (global_sort) {  // stable global sort: duplicates must be emitted in Gaussian order

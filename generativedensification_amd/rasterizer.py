@@ -24,6 +24,7 @@ from typing import NamedTuple, Optional
 import torch
 from torch import nn
 
+from . import _debug as K
 from . import _lib as L
 
 
@@ -151,46 +152,6 @@ def _inputs_struct(N, M, means3D, opacities, sh, colors_precomp, scales, rotatio
                        _ptr(rotations), _ptr(cov3Ds), flags, 0)
 
 
-# test / A-B hooks: one global radix sort instead of tile partition + per-tile LDS sort; the radix partition on the tile
-# bits (the fallback of images with > 16384 tiles) instead of the direct tile binning
-_FORCE_GLOBAL_SORT = False
-_FORCE_RADIX_PARTITION = False
-
-# Streams of a multi-view node.  Forward: every view's chain binning -> K6 on one of FWD_STREAMS streams, the caller's
-# included (_forward_views_impl).  Backward: K7 of the views round-robin on side_count() side streams (_SideViews; 2 at
-# 800x800, 3 for smaller images; GDR_BWD_STREAMS=n overrides, 0 = the caller's stream only).
-# GDR_RENDER_SIDE=0: everything on the caller's stream (bench.py's serial pass for per-kernel durations).
-# Measured on MI355X (views/s; K7 of the views on n side streams, one box, round 2):
-#   n   C4 cube  C4 shell  C3 cube  C3 shell  C2 cube  C2 shell  C5 cube  C5 shell
-#   0    1220      877      2724     2578      2877     2521      1009      948
-#   2    1237      929      2770     3113      2977     2641      1073     1029
-#   3    1220      925      2889     3062      2898     2717      1055     1023
-# Two concurrent views fill the CUs that one view's skewed tile lists and kernel tails leave idle; four evict each
-# other's records from L2 (one view's records + gradient records are 2 x 128 MB at 2 M Gaussians).
-RENDER_SIDE = int(_os.environ.get("GDR_RENDER_SIDE", "1"))
-# streams that carry the views' forward chains (binning + K6) of a multi-view node, the caller's stream included
-FWD_STREAMS = int(_os.environ.get("GDR_FWD_STREAMS", "4"))
-# side streams of the backward (K7 of the views); unset = side_count()
-BWD_STREAMS = int(_os.environ["GDR_BWD_STREAMS"]) if _os.environ.get("GDR_BWD_STREAMS") else None
-BIN_STREAM = None     # tests: force side_count() (None = by image size)
-# K7 of a multi-view node in ONE launch (gdr_render_backward*_views, round 4) instead of one launch per view on side
-# streams: 0 = per-view launches, 1 = one launch, the views interleaved (all views' longest work items first), 2 = one
-# launch, one view after the other; None = by image size (k7_views_mode).
-K7_VIEWS = int(_os.environ["GDR_K7_VIEWS"]) if _os.environ.get("GDR_K7_VIEWS") else None
-
-
-# Segment length of cut tile lists (include/gdr.h gdr_binning.seg_len): None = the library default
-# (GDR_DEFAULT_SEG_LEN = 256, raised to 512 for images of >= 2000 tiles), 0 = lists are never cut, otherwise a multiple
-# of 256.  Tests switch it per call; GDR_SEG_LEN in the environment presets it (host-side policy: the library itself
-# reads no environment variable).
-SEG_LEN = int(_os.environ["GDR_SEG_LEN"]) if _os.environ.get("GDR_SEG_LEN") else None
-
-
-# K6 "deep" forward (include/gdr.h gdr_binning.deep_max_busy): None = library default (768 busy tiles), 0 = never.
-DEEP_MAX_BUSY = None
-DEEP_MIN_MEAN = int(_os.environ["GDR_DEEP_MIN_MEAN"]) if _os.environ.get("GDR_DEEP_MIN_MEAN") else None   # (gdr_binning.deep_min_mean)
-
-
 def _seg_len_for(D, tiles=None, busy=None):
     """Host-side policy of the cut lists: the segment length a view's binning workspace is carved for
     (gdr_binning_carve_seg sizes the cut-list tables for it: 80 bytes per duplicate at 256, 40 at 512).  D: duplicates
@@ -198,8 +159,8 @@ def _seg_len_for(D, tiles=None, busy=None):
     segments pay on large images whose tiles are all busy with long lists (C4 +2.5 %, C5 +1.3 % over 256); scenes with
     few busy tiles (an object in front of a background) or short lists keep 256 (C2 shell +5 %, C5 shell +4 %, C4 shell
     +1.2 %, C2 +0.5 % over 512)."""
-    if SEG_LEN is not None:
-        return max(0, int(SEG_LEN)) // 256 * 256
+    if K.SEG_LEN is not None:
+        return max(0, int(K.SEG_LEN)) // 256 * 256
     if tiles is not None and tiles >= 2000 and D >= 500 * tiles and (busy is None or 2 * busy >= tiles):
         return 512
     return L.GDR_DEFAULT_SEG_LEN
@@ -208,16 +169,16 @@ def _seg_len_for(D, tiles=None, busy=None):
 def side_count(H, W):
     """Side streams for the views of one node: 2 at >= 2000 tiles per view (800x800), 3 for smaller images whose
     single view cannot fill 256 CUs (512x512 = 1024 tiles)."""
-    if BIN_STREAM is not None:
-        return BIN_STREAM
+    if K.BIN_STREAM is not None:
+        return K.BIN_STREAM
     tiles = ((W + 15) // 16) * ((H + 15) // 16)
     return 2 if tiles >= 2000 else 3
 
 
 def k7_views_mode(H, W, N):
-    """How K7 of a multi-view node is launched (K7_VIEWS above)."""
-    if K7_VIEWS is not None:
-        return K7_VIEWS
+    """How K7 of a multi-view node is launched (K.K7_VIEWS above)."""
+    if K.K7_VIEWS is not None:
+        return K.K7_VIEWS
     return 1
 
 
@@ -268,8 +229,8 @@ class _SideViews:
     @staticmethod
     def k7_streams(dev, n, H, W, unique=False):
         """The torch stream K7 of each of n views will run on, or None: caller's stream only.  unique: the distinct streams."""
-        ns = side_count(H, W) if BWD_STREAMS is None else BWD_STREAMS
-        if not (RENDER_SIDE and ns > 0 and n > 1):
+        ns = side_count(H, W) if K.BWD_STREAMS is None else K.BWD_STREAMS
+        if not (K.RENDER_SIDE and ns > 0 and n > 1):
             return None
         side = _view_streams(dev, min(ns, n))
         return side if unique else [side[k % len(side)] for k in range(n)]
@@ -310,10 +271,10 @@ class GroupMismatch(RuntimeError):
 
 def _view_opts():
     """The test / A-B switches of this module as the library's gdr_view_opts (-1 = the library's policy)."""
-    return L.GdrViewOpts(-1 if SEG_LEN is None else max(0, int(SEG_LEN)) // 256 * 256,
-                         -1 if DEEP_MAX_BUSY is None else max(0, int(DEEP_MAX_BUSY)),
-                         -1 if DEEP_MIN_MEAN is None else max(0, int(DEEP_MIN_MEAN)),
-                         int(_FORCE_GLOBAL_SORT), int(_FORCE_RADIX_PARTITION), int(not LAUNCH_HINTS))
+    return L.GdrViewOpts(-1 if K.SEG_LEN is None else max(0, int(K.SEG_LEN)) // 256 * 256,
+                         -1 if K.DEEP_MAX_BUSY is None else max(0, int(K.DEEP_MAX_BUSY)),
+                         -1 if K.DEEP_MIN_MEAN is None else max(0, int(K.DEEP_MIN_MEAN)),
+                         int(K.FORCE_GLOBAL_SORT), int(K.FORCE_RADIX_PARTITION), int(not K.LAUNCH_HINTS))
 
 
 def forward_view_native(call, s, inp, N, H, W, surfel, out, same_as, dev, stream):
@@ -334,7 +295,7 @@ def forward_view_native(call, s, inp, N, H, W, surfel, out, same_as, dev, stream
     exact = 0
     for _ in range(4):
         L.check(lib.gdr_view_plan_for(N, H, W, int(surfel), exact, C.byref(opts), C.byref(plan)), "gdr_view_plan_for")
-        if not DEFER_D and not exact:     # upstream's flow: the count is read back before anything is sized
+        if not K.DEFER_D and not exact:     # upstream's flow: the count is read back before anything is sized
             plan.have_binning = 0
         ws = torch.empty(max(int(plan.bytes), 256), dtype=torch.uint8, device=dev)
         rc = call(s, inp, C.byref(plan), C.c_void_p(ws.data_ptr()), C.byref(opts), same, out, C.byref(vs), stream)
@@ -426,9 +387,6 @@ def backward_raw(st: _State, keep, raster_settings, radii, grad_color, grad_dept
     return g
 
 
-EARLY_CLEAR = True
-
-
 def _early_records_begin(ctx, dev, V, N, H, W, floats):
     """Gradient records of the V views (V, N * floats): allocated at the START of the forward, and the streams their K7 will
     run on (the first side streams, which also carry forward chains) are made to wait for THIS point of the caller's stream.
@@ -440,7 +398,7 @@ def _early_records_begin(ctx, dev, V, N, H, W, floats):
     Only with side streams and only if a gradient was asked for; ctx.recs is consumed by the first backward (a second one
     clears its own).  Returns what _early_records_clear needs."""
     ctx.recs = None
-    if not (EARLY_CLEAR and N > 0 and any(ctx.needs_input_grad[:6])):
+    if not (K.EARLY_CLEAR and N > 0 and any(ctx.needs_input_grad[:6])):
         return None
     streams = _SideViews.k7_streams(dev, V, H, W)
     if streams is None:
@@ -575,7 +533,6 @@ RAW_ALL = L.GDR_IN_RAW_OPACITY | L.GDR_IN_RAW_SCALES | L.GDR_IN_RAW_ROTATIONS
 # counts travel to pinned host memory meanwhile and are compared with the capacity once everything is enqueued.  A view
 # that did not fit (nothing was written out of bounds, but its lists are truncated) is repeated with an exactly sized
 # workspace before the call returns, so the results never depend on the guess.
-DEFER_D = _os.environ.get("GDR_DEFER_D", "1") != "0"
 D_SLACK = 1.5   # capacity = slack x the largest recent count of the shape (measured:
 # 1.02 / 1.25 / 2.0 run at the same speed — surplus workgroups leave at once —, so the slack only costs memory)
 _D_HINT: dict = {}   # shape key -> decaying maximum of duplicates PER GAUSSIAN of one view of that shape
@@ -593,7 +550,7 @@ def shape_key(N, *rest):
 def _d_capacity(key, N):
     """Entries to carve each view's binning workspace for, or None: no history yet (or GDR_DEFER_D=0) -> read D back."""
     with _HIST_LOCK:
-        h = _D_HINT.get(key) if DEFER_D else None
+        h = _D_HINT.get(key) if K.DEFER_D else None
     return None if h is None else int(h * N * D_SLACK) + 4096
 
 
@@ -656,7 +613,6 @@ class _CountReadback:
 # on it: the classes walk their tiles with a grid stride, and K6 renders every tile the standard way without the deep
 # launch.  The words live in pinned host memory the kernels write directly (4 words per view and shape, kept for the
 # life of the process: the GPU may still be writing when a shape is last used).
-LAUNCH_HINTS = True
 _LAUNCH_STATS: dict = {}
 
 
@@ -669,7 +625,7 @@ def _launch_stats(key, V):
     busy tiles) or None).  The hints are the decaying maximum over the views and the recent calls of the shape (cameras change from
     step to step) plus 25 %, and never below 16 / 32 workgroups: a scene that suddenly has a hundred long lists costs a
     few rounds on a small grid, not one workgroup sorting them all."""
-    if not LAUNCH_HINTS:
+    if not K.LAUNCH_HINTS:
         return None, None
     key = (torch.cuda.current_device(),) + tuple(key)   # one report tensor per device and shape
     with _HIST_LOCK:
@@ -704,15 +660,15 @@ def _carve_binning(lib, st, entries, tiles, d_dev=None, stats=None, hints=None):
         st.bin_buf = torch.empty(need, dtype=torch.uint8, device=st.geom_buf.device)
     L.check(lib.gdr_binning_carve_for(st.bin_buf.data_ptr(), entries, seg_len, st.N, tiles, C.byref(st.bin)),
             "gdr_binning_carve_for")
-    if _FORCE_RADIX_PARTITION:
+    if K.FORCE_RADIX_PARTITION:
         st.bin.tile_hist, st.bin.hist_width = None, 0
-    st.bin.global_sort = int(_FORCE_GLOBAL_SORT)
+    st.bin.global_sort = int(K.FORCE_GLOBAL_SORT)
     st.bin.d_dev = d_dev
     st.D = entries
-    if DEEP_MAX_BUSY is not None:
-        st.bin.deep_max_busy = max(0, int(DEEP_MAX_BUSY))
-    if DEEP_MIN_MEAN is not None:
-        st.bin.deep_min_mean = max(0, int(DEEP_MIN_MEAN))
+    if K.DEEP_MAX_BUSY is not None:
+        st.bin.deep_max_busy = max(0, int(K.DEEP_MAX_BUSY))
+    if K.DEEP_MIN_MEAN is not None:
+        st.bin.deep_min_mean = max(0, int(K.DEEP_MIN_MEAN))
     if hints is not None:
         st.bin.hint_long, st.bin.hint_medium, st.bin.hint_no_deep = hints[:3]
     if stats is not None:
@@ -720,8 +676,8 @@ def _carve_binning(lib, st, entries, tiles, d_dev=None, stats=None, hints=None):
 
 
 def _forward_views_impl(means3D, means2D, sh, opacities, scales, rotations, settings_list, flags, loss_spec=None):
-    """K1 for all views (one launch per <= 8 views), then every view's chain binning -> K6 on one of FWD_STREAMS
-    streams; the duplicate counts are read back without stalling either side (see DEFER_D above).
+    """K1 for all views (one launch per <= 8 views), then every view's chain binning -> K6 on one of K.FWD_STREAMS
+    streams; the duplicate counts are read back without stalling either side (see K.DEFER_D above).
     Returns (colors, radii, depths, alphas, states, keep, in_dtypes)."""
     lib = L.load()
     _require_hip(means3D, "means3D")
@@ -780,11 +736,11 @@ def _forward_views_impl(means3D, means2D, sh, opacities, scales, rotations, sett
                     sub_g[k].cov3D = g_arr[0].cov3D
             L.check(lib.gdr_preprocess_forward_views(n, sub_s, C.byref(inp), sub_g, r_arr, stream),
                     "gdr_preprocess_forward_views")
-        # The views' chains (binning -> K6) round-robin over FWD_STREAMS streams, the caller's included: the binning is
+        # The views' chains (binning -> K6) round-robin over K.FWD_STREAMS streams, the caller's included: the binning is
         # ~12 short, latency-bound kernels per view that overlap the VALU-bound K6 of other views, and two concurrent K6
         # fill the CUs that one view's skewed tile lists and kernel tails leave idle.  Four streams = the number of
         # hardware queues a process gets by default (more alias onto the same queues and serialise).
-        nfs = max(1, min(FWD_STREAMS, V)) if RENDER_SIDE and V > 1 and side_count(H, W) > 0 else 1
+        nfs = max(1, min(K.FWD_STREAMS, V)) if K.RENDER_SIDE and V > 1 and side_count(H, W) > 0 else 1
         fstreams = [main] + _view_streams(dev, nfs - 1)
         if nfs > 1:   # the side streams start waiting for K1 now, before the host does anything else
             ready = torch.cuda.Event()

@@ -20,6 +20,7 @@ from torch import nn
 from . import _lib as L
 from .rasterizer import (GaussianRasterizationSettings, _f32, _ptr, _require_hip, _settings_struct, _State,
                          _stream)
+from . import _debug as _K
 from . import rasterizer as _R
 
 
@@ -246,7 +247,7 @@ def _surfel_forward_views_impl(ctx, means3D, means2D, sh, opacities, scales, rot
                                                        None, stream), "gsr_preprocess_forward")
             # every view's chain (binning -> K6s -> fused loss kernel) on one of the forward streams, the caller's
             # included (rasterizer._forward_views_impl)
-            nfs = max(1, min(_R.FWD_STREAMS, V)) if _R.RENDER_SIDE and V > 1 and _R.side_count(H, W) > 0 else 1
+            nfs = max(1, min(_K.FWD_STREAMS, V)) if _K.RENDER_SIDE and V > 1 and _R.side_count(H, W) > 0 else 1
             fstreams = [main] + _R._view_streams(dev, nfs - 1)
             if nfs > 1:
                 ready = torch.cuda.Event()

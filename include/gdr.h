@@ -133,7 +133,11 @@ typedef struct gdr_geom {
 
 /* Binning state (upstream "binningBuffer"): D (key,value) pairs, double-buffered. */
 typedef struct gdr_binning {
-    uint64_t* keys[2];   /* (D) (tile << 32) | float_bits(depth)            */
+    uint64_t* keys[2];   /* (D) each.  Direct tile binning (default): keys[0] holds ONE packed word per entry of the partitioned
+                          * list, id << 32 | float_bits(depth), which the per-tile depth sort consumes; keys[1] is unused.  Radix
+                          * partition / global sort: the (tile << 32) | float_bits(depth) keys, double-buffered.  The sorted
+                          * 64-bit keys of the reference are never materialised on the default path (the parity tests rebuild
+                          * them from ranges + sorted ids + depths) */
     uint32_t* values[2]; /* (D) Gaussian index                              */
     uint32_t* hist;      /* radix-sort scratch                              */
     int32_t sorted;      /* which of the two buffers holds the sorted list  */
@@ -175,11 +179,12 @@ typedef struct gdr_binning {
     int32_t grad_rec_cleared; /* != 0: the caller has already zero-filled the gradient record it passes to the K7 entry points
                           * for this view (e.g. early, on a side stream, while the forward still runs): they skip their own
                           * clear of N*64 bytes */
-    uint32_t* tile_hist; /* direct tile binning (gdr_binning_carve_for): the (tiles x hist_width) count matrix of the
-                          * counting sort on the tile id + tiles totals + 1 ticket word; NULL (gdr_binning_carve, or an image
+    uint32_t* tile_hist; /* direct tile binning (gdr_binning_carve_for): the (hist_width rows x hist_tiles columns) count matrix of
+                          * the counting sort on the tile id + one row of tile totals; NULL (gdr_binning_carve, or an image
                           * of more than 16384 tiles): the radix partition on the tile bits is used instead (same lists) */
-    int32_t hist_width;  /* columns of tile_hist = workgroups of the count / scatter kernels, <= 1024 */
-    int32_t reserved1;
+    int32_t hist_width;  /* rows of tile_hist = workgroups of the count / scatter kernels, <= 256 */
+    int32_t hist_tiles;  /* columns of tile_hist = the tile count it was carved for, rounded up to 64; a binning call on an image
+                          * with more tiles than that uses the radix partition instead (same lists) — was reserved1 until v14 */
 } gdr_binning;
 
 /* Image state (upstream "imgBuffer"). */
@@ -272,9 +277,6 @@ int gdr_render_forward(const gdr_settings* s, const gdr_inputs* in, const gdr_ge
  * and every backward entry point below reads the seg_state of the LATEST compositing call on that (bin, img) pair. */
 int gdr_binning_forward(const gdr_settings* s, int32_t N, const gdr_geom* geom, gdr_binning* bin, const gdr_image* img,
                         uint64_t D, const int32_t* radii, void* stream);
-/* the same for V <= GDR_MAX_VIEWS views of ONE image size in the same launches (every binning kernel covers all the views,
- * view = blockIdx.y): the chain is ~13 short dependent launches whatever the number of views.  geoms / bins / imgs / D /
- * radii: arrays of V. */
 int gdr_composite_forward(const gdr_settings* s, const gdr_geom* geom, const gdr_binning* bin, const gdr_image* img,
                           const gdr_outputs* out, void* stream);
 

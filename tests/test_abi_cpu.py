@@ -156,28 +156,28 @@ def test_host_policy_helpers_without_gpu():
     from generativedensification_amd import _lib as L
     from generativedensification_amd import rasterizer as R
 
-    saved = R.BIN_STREAM, R.SEG_LEN
+    saved = R.K.BIN_STREAM, R.K.SEG_LEN
     try:
-        R.BIN_STREAM = None
+        R.K.BIN_STREAM = None
         assert R.side_count(800, 800) == 2 and R.side_count(512, 512) == 3 and R.side_count(1080, 1920) == 2
-        R.BIN_STREAM = 0
+        R.K.BIN_STREAM = 0
         assert R.side_count(800, 800) == 0
-        R.BIN_STREAM = 4
+        R.K.BIN_STREAM = 4
         assert R.side_count(64, 64) == 4
-        R.SEG_LEN = None
+        R.K.SEG_LEN = None
         assert R._seg_len_for(10_000) == 256
         # the automatic choice: 512 on large images whose tiles are all busy with long lists, 256 otherwise
         for D, tiles, busy, want in ((3_400_000, 2500, None, 512), (3_400_000, 2500, 2000, 512), (3_400_000, 2500, 330, 256),
                                      (730_000, 2500, 2500, 256), (1_070_000, 1024, 1024, 256)):
             assert R._seg_len_for(D, tiles, busy) == want, (D, tiles, busy)
-        R.SEG_LEN = 4096
+        R.K.SEG_LEN = 4096
         assert R._seg_len_for(10_000) == 4096
-        R.SEG_LEN = 700           # rounded down to a multiple of 256
+        R.K.SEG_LEN = 700           # rounded down to a multiple of 256
         assert R._seg_len_for(10_000) == 512
-        R.SEG_LEN = 0             # lists are never cut
+        R.K.SEG_LEN = 0             # lists are never cut
         assert R._seg_len_for(3_400_000, 2500, None) == 0
     finally:
-        R.BIN_STREAM, R.SEG_LEN = saved
+        R.K.BIN_STREAM, R.K.SEG_LEN = saved
     lib = L.load()
     # the cut-list tables are carved for the segment length the caller is going to use (80 / 40 / 0 bytes per duplicate)
     b256, b512, b0 = (lib.gdr_binning_bytes_for(4_000_000, sl, 0, 0) for sl in (256, 512, 0))

@@ -231,8 +231,8 @@ def test_device_sized_binning_equals_the_read_back_and_an_overflow_repeats_the_v
         torch.cuda.synchronize()
         return [o["image"].clone() for o in res[0]], res[1].clone(), res[2]["image"].clone(), res[3]["image"].clone()
 
-    saved, saved_defer = dict(R._D_HINT), R.DEFER_D
-    R.DEFER_D = True
+    saved, saved_defer = dict(R._D_HINT), R.K.DEFER_D
+    R.K.DEFER_D = True
     try:
         img0, loss0, one0, pl0 = run("none")                 # no history: read-back flow
         views()
@@ -244,13 +244,13 @@ def test_device_sized_binning_equals_the_read_back_and_an_overflow_repeats_the_v
         for imgs, losses, one, pl in ((img1, loss1, one1, pl1), (img2, loss2, one2, pl2)):
             assert all(torch.equal(a, b) for a, b in zip(imgs, img0)) and torch.equal(one, one0) and torch.equal(pl, pl0)
             np.testing.assert_allclose(losses.cpu().numpy(), loss0.cpu().numpy(), rtol=2e-6)   # (atomic order)
-        saved_d = R.DEFER_D
-        R.DEFER_D = False          # upstream's flow in every call: the count is read back before anything is sized
+        saved_d = R.K.DEFER_D
+        R.K.DEFER_D = False          # upstream's flow in every call: the count is read back before anything is sized
         try:
             with torch.no_grad():
                 assert torch.equal(plain()["image"], pl0)
         finally:
-            R.DEFER_D = saved_d
+            R.K.DEFER_D = saved_d
         # the state of a device-sized call holds the exact count and the same sorted lists
         if not surfel:
             sets = [Renderer(sh_degree=1).set_rasterizer(c, device=dev).raster_settings for c in cams]
@@ -278,7 +278,7 @@ def test_device_sized_binning_equals_the_read_back_and_an_overflow_repeats_the_v
                     for k in ("keys_sorted", "point_list", "ranges", "n_contrib"):
                         assert torch.equal(a[k], b[k]), k
     finally:
-        R.DEFER_D = saved_defer
+        R.K.DEFER_D = saved_defer
         R._D_HINT.clear()
         R._D_HINT.update(saved)
 
@@ -350,8 +350,8 @@ def test_deep_forward_applies_to_few_busy_tiles_with_long_lists_only():
     def run(N, min_mean):
         scene = make_scene(N, 31, sh_degree=1, sigma0=(0.004,), device=dev, layout="shell")
         key = (torch.cuda.current_device(),) + R.shape_key(N, H, W, 1)
-        saved = R._LAUNCH_STATS.pop(key, None), R._HINT_STATE.pop(key, None), R.DEEP_MIN_MEAN
-        R.DEEP_MIN_MEAN = min_mean
+        saved = R._LAUNCH_STATS.pop(key, None), R._HINT_STATE.pop(key, None), R.K.DEEP_MIN_MEAN
+        R.K.DEEP_MIN_MEAN = min_mean
         try:
             with torch.no_grad():
                 colors, _, _, _, states, _, _ = R._forward_views_impl(scene["centers"], torch.empty(0, 4, device=dev), scene["shs"],
@@ -363,7 +363,7 @@ def test_deep_forward_applies_to_few_busy_tiles_with_long_lists_only():
             busy = L_[L_ >= 64]
             return colors[0], R._LAUNCH_STATS[key][0].tolist(), float(busy.float().mean()), int(busy.numel())
         finally:
-            R.DEEP_MIN_MEAN = saved[2]
+            R.K.DEEP_MIN_MEAN = saved[2]
             R._LAUNCH_STATS.pop(key, None)
             R._HINT_STATE.pop(key, None)
             if saved[0] is not None:
@@ -427,11 +427,11 @@ def test_history_of_a_shape_carries_over_to_a_neighbouring_gaussian_count():
         return colors, states
 
     assert R.shape_key(40_000, H, W, V) == R.shape_key(N, H, W, V)
-    saved, saved_defer = dict(R._D_HINT), R.DEFER_D
+    saved, saved_defer = dict(R._D_HINT), R.K.DEFER_D
     try:
-        R.DEFER_D = False
+        R.K.DEFER_D = False
         c_ref, s_ref = run(N)
-        R.DEFER_D = True
+        R.K.DEFER_D = True
         R._D_HINT.clear()
         _, s0 = run(40_000)
         assert not any(st.bin.d_dev for st in s0)            # first call of the shape: read-back
@@ -444,7 +444,7 @@ def test_history_of_a_shape_carries_over_to_a_neighbouring_gaussian_count():
                 assert torch.equal(a[k], b[k]), k
             assert torch.equal(c_ref[v], c1[v])
     finally:
-        R.DEFER_D = saved_defer
+        R.K.DEFER_D = saved_defer
         R._D_HINT.clear()
         R._D_HINT.update(saved)
 

@@ -244,9 +244,8 @@ def test_surfel_hip_vs_oracle_at_c5_size(oracle_built):
     f64 = o64.forward(U._np(case["means3D"]), U._np(case["opacities"]), U.settings_np(case), tiles=tiles, **kw)
     g64 = o64.backward(f64, *[U._np(x) for x in grads])
     g32 = SurfelOracle("f32", nthreads=1).backward(o, *[U._np(x) for x in grads])
-    # per element against the f32 oracle, with the outside fraction / max-norm bound the ill-conditioned fp32 2DGS
-    # formulation forces (reason + measurements at util.assert_grads_surfel)
-    U.assert_grads_surfel(hg, g64, g32, GRAD_KEYS, "c5", max_outside=U.MAX_OUTSIDE)
+    # per element against the f32 oracle at the single-call floor (reason + measurements at util.assert_grads_surfel)
+    U.assert_grads_surfel(hg, g64, g32, GRAD_KEYS, "c5")
 
 
 def test_surfel_whole_image_at_c5_size(oracle_built):
@@ -275,10 +274,10 @@ def test_surfel_whole_image_at_c5_size(oracle_built):
     p = U.psnr(np.clip(h["color"], 0, 1), np.clip(o["color"], 0, 1))
     print(f"[c5 whole image] D = {o['num_rendered']}, PSNR {p:.1f} dB")
     assert p > 60.0
-    # (a), (b) as everywhere (measured: 1.0e-4 .. 1.0e-3 of the elements outside against the f32 oracle, HIP closer to float64
-    # than the oracle in every tensor).  (c), the single worst element of 0.5 M x 59: with a gradient on every pixel and
-    # channel it is one ill-conditioned surfel, a different one for every fp32 evaluation order — the oracle's worst sits
-    # 3.8e-3 .. 5.4e-2 (max-norm) from float64, HIP's 1.0 .. 2.2 x that: asserted within 3 x instead of 1.25 x.
+    # (a), (b), (c) as everywhere, at the single-call floor (atol_rel 3e-6, 1e-4 of the elements).  Round 4: the intersection
+    # runs in the oracle's operation order, so the single worst element of 0.5 M x 59 — one ill-conditioned surfel, which in
+    # rounds 1-3 was a different one for every fp32 evaluation order and needed worst_factor 3 — is the oracle's own:
+    # measured outside <= 3.5e-6, max-norm vs the f32 oracle <= 2.5e-5, hip-f64 / oracle-f64 = 1.00 (profiles/r04_surfel_stats.txt)
     U.assert_grads_surfel(hg, out["f64"], out["f32"], GRAD_KEYS, "c5 whole image", worst_factor=1.25)
 
 
@@ -530,8 +529,9 @@ def test_surfel_render_views_backward_vs_oracle(oracle_built, size):
         total = total + (o["color"] * gc[v].to(dev)).sum() + (o["allmap"] * ga[v].to(dev)).sum()
     grads = torch.autograd.grad(total, list(leaves.values()) + [ssp])
     g_hip = {k: x.cpu().numpy() for k, x in zip(list(leaves) + ["ssp"], grads)}
-    # (C5 size, four views, unit-variance gradients on every channel of every pixel: (a) and (b) as everywhere — measured
-    # 2.7e-4 .. 1.3e-3 of the elements outside (bar 1.5e-3), HIP closer to float64 than the oracle in every tensor; (c), the
-    # single worst element: the oracle's sits 1e-3 .. 2.7e-2 from float64, HIP's 1.0 .. 3.2 x that — one ill-conditioned surfel,
-    # see test_surfel_whole_image_at_c5_size — within 4 x.)
-    U.assert_grads_surfel(g_hip, g64, g32, list(g32), "surfel render_views " + size, worst_factor=1.25)
+    # (the RAW entry: sigmoid / exp / normalize run inside K1s and differ from torch's in the last bit, which the
+    # ill-conditioned geometry amplifies — the 1e-5 floor and 2e-4 of the elements outside, util.py; the single worst element
+    # is within 1.25 x of the f32 oracle's own distance from float64 since the intersection runs in the oracle's order,
+    # round 4: measured ratio 1.00 at both sizes, profiles/r04_surfel_stats.txt)
+    U.assert_grads_surfel(g_hip, g64, g32, list(g32), "surfel render_views " + size, worst_factor=1.25,
+                          max_outside=U.SURFEL_RAW_MAX_OUTSIDE, atol_rel=U.SURFEL_RAW_ATOL_REL)

@@ -292,7 +292,7 @@ def test_k7_of_all_views_in_one_launch_equals_per_view_launches(V):
     r = Renderer(sh_degree=3, fused=True)
 
     def run(mode, entry):
-        prev, R.K7_VIEWS = R.K7_VIEWS, mode
+        prev, R.K.K7_VIEWS = R.K.K7_VIEWS, mode
         try:
             leaves = {k: v.to(dev).clone().requires_grad_(True) for k, v in sc.items()}
             ssp = torch.zeros(n, 4, device=dev, requires_grad=True)
@@ -309,7 +309,7 @@ def test_k7_of_all_views_in_one_launch_equals_per_view_launches(V):
             grads = torch.autograd.grad((lv * wts).sum(), list(leaves.values()) + [ssp])
             return {k: g_.cpu().numpy() for k, g_ in zip(list(leaves) + ["ssp"], grads)}
         finally:
-            R.K7_VIEWS = prev
+            R.K.K7_VIEWS = prev
 
     for entry in ("views", "loss", "absgrad"):
         ref = run(0, entry)
@@ -518,11 +518,11 @@ def test_global_sort_fallback_paths(oracle_built):
 
     case = U.make_case(10_000, 256, 256, 0, deg=3)
     o, _ = U.run_oracle(case, "f32")
-    R._FORCE_GLOBAL_SORT = True
+    R.K.FORCE_GLOBAL_SORT = True
     try:
         h, _ = U.run_hip(case)
     finally:
-        R._FORCE_GLOBAL_SORT = False
+        R.K.FORCE_GLOBAL_SORT = False
     np.testing.assert_array_equal(h["point_list"].view(np.uint32), o["point_list"])
     np.testing.assert_array_equal(h["keys_sorted"].view(np.uint64), o["keys_sorted"])
     np.testing.assert_array_equal(h["ranges"].view(np.uint32), o["ranges"])
@@ -530,11 +530,11 @@ def test_global_sort_fallback_paths(oracle_built):
     # direct tile binning does not fit) instead of the direct tile binning: same lists
     for cc in (case, U.make_case(40_000, 250, 190, 5, deg=1, sigma0=(0.02, 0.003))):
         oo, _ = U.run_oracle(cc, "f32")
-        R._FORCE_RADIX_PARTITION = True
+        R.K.FORCE_RADIX_PARTITION = True
         try:
             h, _ = U.run_hip(cc)
         finally:
-            R._FORCE_RADIX_PARTITION = False
+            R.K.FORCE_RADIX_PARTITION = False
         np.testing.assert_array_equal(h["point_list"].view(np.uint32), oo["point_list"])
         np.testing.assert_array_equal(h["keys_sorted"].view(np.uint64), oo["keys_sorted"])
         np.testing.assert_array_equal(h["ranges"].view(np.uint32), oo["ranges"])
@@ -828,14 +828,14 @@ def test_cut_tile_lists_give_the_gradients_of_the_uncut_walk(oracle_built):
     grads = U.rand_grads(case)
     res = {}
     try:
-        R.DEEP_MAX_BUSY = 0     # (the deep forward of cut tiles is compared with this one below)
+        R.K.DEEP_MAX_BUSY = 0     # (the deep forward of cut tiles is compared with this one below)
         for sl in (0, 2048, 4096):
-            R.SEG_LEN = sl
+            R.K.SEG_LEN = sl
             res[sl] = U.run_hip(case, grads)
-        R.DEEP_MAX_BUSY, R.SEG_LEN = None, 2048
+        R.K.DEEP_MAX_BUSY, R.K.SEG_LEN = None, 2048
         deep = U.run_hip(case, grads)
     finally:
-        R.SEG_LEN, R.DEEP_MAX_BUSY = None, None
+        R.K.SEG_LEN, R.K.DEEP_MAX_BUSY = None, None
     (h0, g0) = res[0]
     if res[2048][0]["seg_len"] == 0:
         pytest.skip("cut lists disabled in this process (GDR_SEG_LEN=0)")

@@ -1,9 +1,9 @@
 """GPU (-m gpu): the 2DGS surfel path (include/gsr.h -> libgdr_hip.so) against the CPU oracle (oracle/gsr_oracle.c).
 Bar: every per-surfel intermediate, the duplicate list, the tile ranges and n_contrib bit-exact against the f32
 oracle; image and allmap within 1e-4 of the f32 oracle (PSNR > 100 dB); gradients PER ELEMENT within
-1e-4 |ref| + 1e-5 max|ref| of the f32 oracle (util.assert_grads_surfel: the 3DGS comparison with the absolute floor the
-ill-conditioned fp32 formulation forces — k = x Tw - Tu cancels for small surfels far from the image origin — stated and
-measured there), and no further from float64 than the f32 oracle is."""
+1e-4 |ref| + 3e-6 max|ref| of the f32 oracle (util.assert_grads_surfel: the 3DGS comparison at three times the 3DGS floor —
+round 4: the ill-conditioned ray-splat intersection runs in the oracle's own operation order; the entries that take RAW
+tensors keep the 1e-5 floor — stated and measured there), and no further from float64 than the f32 oracle is."""
 import numpy as np
 import pytest
 import torch
@@ -112,10 +112,10 @@ def test_cut_surfel_lists_give_the_gradients_of_the_uncut_walk(oracle_built):
     res = {}
     try:
         for sl in (0, 2048, 4096):
-            R.SEG_LEN = sl
+            R.K.SEG_LEN = sl
             res[sl] = U.run_surfel_hip(case, grads)
     finally:
-        R.SEG_LEN = None
+        R.K.SEG_LEN = None
     h0, g0 = res[0]
     if res[2048][0]["seg_len"] == 0:
         pytest.skip("cut lists disabled in this process (GDR_SEG_LEN=0)")

@@ -240,31 +240,36 @@ def assert_grads(hg, g64, g32, keys, what, max_outside=MAX_OUTSIDE, rtol=1e-4, a
         assert m_h64 <= 1.25 * m_3264 + 1e-5 and o_h64 <= 1.25 * o_3264 + 1e-4, (what, k, m_h64, m_3264, o_h64, o_3264)
 
 
-# ---- 2DGS: the same per-element comparison with the conditioning of the fp32 2DGS formulation stated -------------------
+# ---- 2DGS: the same per-element comparison; what the fp32 2DGS formulation forces is stated here -------------------------
 # The published 2DGS ray-splat intersection evaluates k = x Tw - Tu, l = y Tw - Tv per pixel in fp32: for a small surfel
-# far from the image origin ~800 * 2 cancels against ~1600, and the textbook distortion sum w (m^2 A + M2 - 2 m M1)
-# cancels to ~1e-4 of its terms.  Two fp32 evaluations of the reference's program that differ by an ulp in exp / rcp (K6s /
-# K7s use v_exp_f32 / v_rcp_f32, the CPU oracle correctly rounded expf / division) or in the order of one fma then differ
-# from each other, per element, about as much as each differs from float64.  Measured on MI355X, round 3, all seven
-# allmap channels carrying upstream gradient (gpurun_out/surfel_stats.txt -> profiles/r03_surfel_stats.txt), fraction of
-# elements outside rtol 1e-4 |ref| + atol_rel max|ref|:
-#                                  atol_rel 1e-6 (the 3DGS floor)            atol_rel 1e-5
-#                                  hip-f32   hip-f64   f32-f64               hip-f32   hip-f64   f32-f64
-#   C5 (500 k surfels, 800x800)    <= 2.3e-4  <= 1.2e-3  <= 1.3e-3            <= 5.5e-5  <= 1.1e-4  <= 1.2e-4
-#   3000-6000 surfels, random      <= 3.6e-3  <= 6.3e-3  <= 6.4e-3            <= 9.4e-4  <= 1.3e-3  <= 1.6e-3
-#   3-view node, 20 k surfels      <= 4.6e-3  <= 1.2e-2  <= 1.3e-2            <= 1.1e-3  <= 3.0e-3  <= 3.2e-3
-# i.e. at the 3DGS floor the f32 ORACLE ITSELF misses float64 in 0.1-1.3 % of the elements.  The surfel bar therefore uses
-# an absolute floor ten times the 3DGS one (atol_rel 1e-5: the conditioning factor, stated here) and then asserts:
-#   (a) vs the f32 oracle: fraction outside < max_outside — 1e-4 (= the 3DGS MAX_OUTSIDE) at C5 size, 1.5e-3 for the small
-#       scenes whose every channel carries a unit-variance random gradient (measured worst 1.1e-3);
-#   (b) vs float64: HIP's fraction outside <= 1.25 x the f32 oracle's own + 5e-4 (measured worst excess 3.4e-4: dL/dopacity
-#       of 6000 20-50 px surfels) — HIP is as accurate as the reference's fp32 program;
+# far from the image origin ~800 * 2 cancels against ~1600, the cross product cancels again and (u, v) divides by what is
+# left.  Two fp32 evaluations that differ in ONE rounding there differ from each other, per element, about as much as each
+# differs from float64 (the f32 ORACLE ITSELF misses float64 in 0.1-3 % of the elements at the 3DGS floor, table below).
+# Rounds 1-3: K6s / K7s used fma for k, l and v_rcp_f32 / v_exp_f32; the bar needed an absolute floor of 1e-5 (ten times the
+# 3DGS one), 1.5e-3 of the elements outside on small scenes, and `worst_factor` 3-4 on the whole-image tests (HIP's single
+# worst element up to 2.5x further from float64 than the oracle's — or 3x closer: luck of one ill-conditioned surfel).
+# Round 4: the intersection runs in the oracle's own operation order with a correctly rounded quotient
+# (render_surfel.hip GSR_ORACLE_ORDER), so (u, v), rho and depth of every (pixel, surfel) pair are the oracle's bit for bit.
+# Measured on MI355X (profiles/r04_surfel_stats.txt), fraction of elements outside rtol 1e-4 |ref| + atol_rel max|ref|:
+#                                              atol_rel 1e-6      3e-6       1e-5      | max-norm hip-f32 | hip-f64 / f32-f64
+#   C5 sampled tiles (single call)              0                 0          0         | 1.2e-6           | 1.00
+#   C5 whole image (single call)                3.5e-6            3.5e-6     2.0e-6    | 2.5e-5           | 1.00
+#   small random scenes (single call)           5.0e-5            0          0         | 5.6e-6           | <= 1.75 (at 1e-6 level)
+#   render_views, RAW inputs, 20 k surfels      3.0e-4            1.2e-4     3.8e-5    | 5.1e-5           | 1.00
+#   render_views, RAW inputs, C5                3.9e-4            2.1e-4     7.8e-5    | 8.1e-4           | 1.00
+#   (f32 oracle vs float64, same scenes:        8e-4 .. 3e-2      3e-4..1e-2)
+# The RAW entries (multi-view node: sigmoid / exp / normalize inside K1s) start from activations that differ from torch's in
+# the last bit, which the ill-conditioned geometry amplifies — they keep the 1e-5 floor; everything fed activated tensors
+# meets the 3DGS bar at three times the 3DGS floor.  Asserted:
+#   (a) vs the f32 oracle: fraction outside < max_outside — MAX_OUTSIDE = 1e-4 at atol_rel 3e-6 (single calls), 2e-4 at
+#       atol_rel 1e-5 for the RAW multi-view entries;
+#   (b) vs float64: HIP's fraction outside <= 1.25 x the f32 oracle's own + 5e-4;
 #   (c) max-norm: HIP no further from the f32 oracle than 2 x the oracle's own distance from float64 (+1e-4), and no
-#       further from float64 than 1.25 x the oracle's (+1e-5) or the north-star's absolute 1e-4.
-#       (`worst_factor`: the whole-image / four-view tests at C5 size, where the single worst of 0.5 M x 59 elements is one
-#       ill-conditioned surfel and a different one for every fp32 evaluation order, state their own factor and measurements.)
-SURFEL_ATOL_REL = 1e-5
-SURFEL_MAX_OUTSIDE = 1.5e-3
+#       further from float64 than worst_factor = 1.25 x the oracle's (+1e-5) or the north-star's absolute 1e-4.
+SURFEL_ATOL_REL = 3e-6
+SURFEL_MAX_OUTSIDE = MAX_OUTSIDE
+SURFEL_RAW_ATOL_REL = 1e-5        # entries that take RAW tensors (activations inside K1s)
+SURFEL_RAW_MAX_OUTSIDE = 2e-4
 
 
 def assert_grads_surfel(hg, g64, g32, keys, what, max_outside=SURFEL_MAX_OUTSIDE, rtol=1e-4, atol_rel=SURFEL_ATOL_REL,
