@@ -96,6 +96,11 @@ class GdrViewState(C.Structure):
                 ("reserved", C.c_uint32)]
 
 
+class GdrViewsPlan(C.Structure):
+    _fields_ = [("view", GdrViewPlan), ("bytes_view", C.c_uint64), ("bytes_shared", C.c_uint64), ("bytes", C.c_uint64),
+                ("V", C.c_int32), ("reserved", C.c_int32)]
+
+
 class GsrInputs(C.Structure):   # include/gsr.h
     _fields_ = [("N", C.c_int32), ("M", C.c_int32), ("means3D", C.c_void_p), ("opacities", C.c_void_p),
                 ("shs", C.c_void_p), ("colors_precomp", C.c_void_p), ("scales", C.c_void_p),
@@ -151,6 +156,9 @@ _PROTOS = {
     "gdr_composite_forward_loss": (C.c_int, [C.POINTER(GdrSettings), C.POINTER(GdrGeom), C.POINTER(GdrBinning),
                                              C.POINTER(GdrImage), C.POINTER(GdrOutputs), C.c_void_p, C.c_float, C.c_float,
                                              C.c_void_p, C.c_void_p]),
+    "gdr_composite_forward_views": (C.c_int, [C.c_int32, C.POINTER(GdrSettings), C.POINTER(GdrGeom), C.POINTER(GdrBinning),
+                                              C.POINTER(GdrImage), C.POINTER(GdrOutputs), C.c_int32, C.POINTER(C.c_void_p),
+                                              C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_int32, C.c_void_p]),
     "gdr_render_backward_loss": (C.c_int, [C.POINTER(GdrSettings), C.c_int32, C.POINTER(GdrGeom), C.POINTER(GdrBinning),
                                            C.POINTER(GdrImage), C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p,
                                            C.c_void_p, C.c_void_p]),
@@ -162,7 +170,14 @@ _PROTOS = {
     "gdr_forward_view": (C.c_int, [C.POINTER(GdrSettings), C.POINTER(GdrInputs), C.POINTER(GdrViewPlan), C.c_void_p,
                                    C.POINTER(GdrViewOpts), C.POINTER(GdrSameAs), C.POINTER(GdrOutputs),
                                    C.POINTER(GdrViewState), C.c_void_p]),
+    "gdr_views_plan_for": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_uint64, C.POINTER(GdrViewOpts),
+                                     C.POINTER(GdrViewsPlan)]),
+    "gdr_forward_views": (C.c_int, [C.c_int32, C.POINTER(GdrSettings), C.POINTER(GdrInputs), C.POINTER(GdrViewsPlan), C.c_void_p,
+                                    C.POINTER(GdrViewOpts), C.POINTER(GdrOutputs), C.c_int32, C.POINTER(C.c_void_p), C.c_float,
+                                    C.c_float, C.c_float, C.c_void_p, C.POINTER(C.c_void_p), C.c_int32,
+                                    C.POINTER(GdrViewState)]),
     "gdr_view_history_reset": (None, []),
+    "gdr_view_history_report": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_uint32), C.c_int32]),
     "gdr_view_history_get": (C.c_double, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "gdr_view_history_set": (None, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_double]),
     "gdr_backward": (C.c_int, [C.POINTER(GdrSettings), C.POINTER(GdrInputs), C.POINTER(GdrGeom),

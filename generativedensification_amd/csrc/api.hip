@@ -389,6 +389,30 @@ int gdr_composite_forward_lossgrad(const gdr_settings* s, const gdr_geom* geom, 
     return debug_sync(s, "render_fwd_lossgrad", st);
 }
 
+// K6 of V views in one launch (round 4)
+int gdr_composite_forward_views(int32_t V, const gdr_settings* s, const gdr_geom* geoms, const gdr_binning* bins,
+                                const gdr_image* imgs, const gdr_outputs* outs, int32_t loss_mode,
+                                const float* const* targets, float w_depth, float w_alpha, float go_scale, float* losses,
+                                int32_t interleave, void* stream) {
+    if (V < 1 || V > GDR_MAX_VIEWS) { set_error("views: V out of range", hipSuccess); return GDR_ERR_UNSUPPORTED; }
+    if (!s || !geoms || !bins || !imgs || !outs || loss_mode < 0 || loss_mode > 2 || (loss_mode && (!targets || !losses))) {
+        set_error("composite_forward_views: bad argument", hipSuccess);
+        return GDR_ERR_INVALID_ARG;
+    }
+    for (int v = 0; v < V; ++v) {
+        if (!s[v].bg || s[v].image_width != s[0].image_width || s[v].image_height != s[0].image_height || !outs[v].color ||
+            (loss_mode != 2 && (!outs[v].depth || !outs[v].alpha)) || (loss_mode && !targets[v])) {
+            set_error("composite_forward_views: NULL view buffer or image sizes differ", hipSuccess);
+            return GDR_ERR_INVALID_ARG;
+        }
+    }
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = launch_render_fwd_views(V, s, geoms, bins, imgs, outs, loss_mode, targets, w_depth, w_alpha, go_scale, losses,
+                                           interleave, st);
+    if (e != hipSuccess) return hip_fail("render_fwd_views", e);
+    return debug_sync(&s[0], "render_fwd_views", st);
+}
+
 int gdr_words_differ(const void* a, const void* b, uint64_t n_bytes, uint32_t* flag, void* stream) {
     if (!flag || (n_bytes && (!a || !b)) || (n_bytes & 3u) || (((uintptr_t)a | (uintptr_t)b) & 15u)) {
         set_error("words_differ: NULL / unaligned argument", hipSuccess);
@@ -810,12 +834,14 @@ struct ShapeHist {
     double d_per_n = 0.0;          // decaying maximum of duplicates per Gaussian of one view of this shape (0: none yet)
     int64_t n_long = 0, n_medium = 0;   // decaying maxima of the tile sort's long / medium class sizes
     int deep_ttl = 0;              // calls until the deep forward launch may be dropped
-    uint32_t* stats = nullptr;     // 4 pinned host words the binning stage reports into (kept for the life of the process)
+    uint32_t* stats = nullptr;     // kStatViews x 4 pinned host words the binning stages of a call's views report into (kept for
+                                   // the life of the process: a kernel in flight may still write them)
     bool reported = false;
 };
 std::mutex g_hist_mu;
 std::unordered_map<uint64_t, ShapeHist> g_hist;
 constexpr double kDSlack = 1.5;    // capacity = slack x the largest recent count of the shape (+ 4096)
+constexpr int kStatViews = 64;     // report rows per shape (views beyond share the last row)
 
 int bit_length(int64_t v) { int b = 0; while (v > 0) { ++b; v >>= 1; } return b; }
 
@@ -830,7 +856,23 @@ uint64_t shape_key(int N, int H, int W, int surfel) {
 
 struct PinnedWords { uint32_t* p; int dev; };
 std::mutex g_pin_mu;
-std::vector<PinnedWords> g_pin_pool;    // 8-byte pinned buffers for the count read-back
+std::vector<PinnedWords> g_pin_pool;    // pinned buffers of kPinWords words for the count read-back (never freed: a handful)
+constexpr int kPinWords = 256;          // >= GDR_MAX_NODE_VIEWS
+uint32_t* pin_get(int dev) {
+    {
+        std::lock_guard<std::mutex> lk(g_pin_mu);
+        for (size_t k = 0; k < g_pin_pool.size(); ++k)
+            if (g_pin_pool[k].dev == dev) { uint32_t* p = g_pin_pool[k].p; g_pin_pool[k] = g_pin_pool.back(); g_pin_pool.pop_back(); return p; }
+    }
+    uint32_t* p = nullptr;
+    if (hipHostMalloc((void**)&p, kPinWords * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return p;
+}
+void pin_put(uint32_t* p, int dev) {
+    if (!p) return;
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    g_pin_pool.push_back({p, dev});
+}
 
 int seg_len_policy(const gdr_view_opts* o, uint64_t d_est, int tiles, int64_t busy) {
     if (o && o->seg_len >= 0) return o->seg_len / GDR_BLOCK * GDR_BLOCK;
@@ -879,6 +921,69 @@ int gdr_view_plan_for(int32_t N, int32_t H, int32_t W, int32_t surfel, uint64_t 
 namespace gdr {
 namespace {
 
+// launch-size feedback of a scene shape: the report words of its previous call(s) -> this call's hints (decaying maxima over
+// the views and the recent calls + 25 %, never below 16 / 32 workgroups: a scene that suddenly has a hundred long lists costs a
+// few rounds on a small grid, not one workgroup sorting them all); stats = the kStatViews x 4 pinned words this call reports into
+struct ShapeHints { uint32_t* stats; int hint_long, hint_medium, hint_no_deep; };
+ShapeHints shape_hints(uint64_t key, int N, const gdr_view_opts* opts) {
+    ShapeHints out{nullptr, 0, 0, 0};
+    if ((opts && opts->no_hints) || N <= 0) return out;
+    std::lock_guard<std::mutex> lk(g_hist_mu);
+    if (g_hist.size() >= 4096 && !g_hist.count(key)) return out;
+    ShapeHist& h = g_hist[key];
+    if (!h.stats) {
+        if (hipHostMalloc((void**)&h.stats, kStatViews * 4 * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess)
+            for (int k = 0; k < kStatViews * 4; ++k) h.stats[k] = 0xFFFFFFFFu;
+        else { h.stats = nullptr; (void)hipGetLastError(); }
+    }
+    out.stats = h.stats;
+    if (!h.stats) return out;
+    int64_t n_long = -1, n_medium = 0;
+    bool deep = false;
+    for (int r = 0; r < kStatViews; ++r) {
+        const uint32_t* w = h.stats + 4 * r;
+        if (w[0] == 0xFFFFFFFFu) continue;
+        n_long = std::max<int64_t>(n_long, w[0]); n_medium = std::max<int64_t>(n_medium, w[1]); deep = deep || w[2] != 0;
+    }
+    if (n_long < 0) return out;       // nothing reported yet
+    h.reported = true;
+    h.n_long = std::max<int64_t>(n_long, h.n_long * 9 / 10);
+    h.n_medium = std::max<int64_t>(n_medium, h.n_medium * 9 / 10);
+    h.deep_ttl = deep ? 8 : std::max(0, h.deep_ttl - 1);
+    out.hint_long = h.n_long == 0 ? -1 : (int)std::max<int64_t>(16, h.n_long + h.n_long / 4 + 1);
+    out.hint_medium = (int)std::max<int64_t>(32, h.n_medium + h.n_medium / 4 + 1);
+    out.hint_no_deep = h.deep_ttl == 0 ? 1 : 0;
+    return out;
+}
+
+void record_duplicates(uint64_t key, int N, uint64_t d_max) {   // the history the next call of this shape is planned from
+    if (N <= 0) return;
+    std::lock_guard<std::mutex> lk(g_hist_mu);
+    if (g_hist.size() >= 4096 && !g_hist.count(key)) return;
+    ShapeHist& h = g_hist[key];
+    h.d_per_n = std::max((double)d_max / (double)std::max(N, 1), h.d_per_n * 0.97);
+    if (h.d_per_n <= 0.0) h.d_per_n = 1e-9;    // "seen": a shape without duplicates still gets device-sized calls
+}
+
+// pooled events (no timing): cross-stream ordering inside gdr_forward_views.  An event goes back to the pool as soon as the
+// waits on it are enqueued (a wait refers to the record that preceded it; a later re-record does not disturb it).
+std::mutex g_ev_mu;
+std::vector<hipEvent_t> g_ev_pool;
+hipEvent_t event_get() {
+    {
+        std::lock_guard<std::mutex> lk(g_ev_mu);
+        if (!g_ev_pool.empty()) { hipEvent_t e = g_ev_pool.back(); g_ev_pool.pop_back(); return e; }
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
+    return e;
+}
+void event_put(hipEvent_t e) {
+    if (!e) return;
+    std::lock_guard<std::mutex> lk(g_ev_mu);
+    g_ev_pool.push_back(e);
+}
+
 // the forward of one view, shared by the 3DGS and the surfel boundary: K1 and K6 come in as callables
 template <class K1, class K6>
 int forward_view_impl(const gdr_settings* s, int N, int surfel, const gdr_view_plan* plan, void* ws, const gdr_view_opts* opts,
@@ -899,29 +1004,9 @@ int forward_view_impl(const gdr_settings* s, int N, int surfel, const gdr_view_p
     }
     // launch-size feedback of the shape (results never depend on it, include/gdr.h gdr_binning.stats_out / hint_*)
     const uint64_t key = shape_key(N, H, W, surfel);
-    uint32_t* stats = nullptr;
-    int hint_long = 0, hint_medium = 0, hint_no_deep = 0;
-    if (!(opts && opts->no_hints) && N > 0) {
-        std::lock_guard<std::mutex> lk(g_hist_mu);
-        if (g_hist.size() < 4096 || g_hist.count(key)) {
-            ShapeHist& h = g_hist[key];
-            if (!h.stats) {
-                if (hipHostMalloc((void**)&h.stats, 4 * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess)
-                    for (int k = 0; k < 4; ++k) h.stats[k] = 0xFFFFFFFFu;
-                else { h.stats = nullptr; (void)hipGetLastError(); }
-            }
-            stats = h.stats;
-            if (stats && stats[0] != 0xFFFFFFFFu) {
-                h.reported = true;
-                h.n_long = std::max<int64_t>(stats[0], h.n_long * 9 / 10);
-                h.n_medium = std::max<int64_t>(stats[1], h.n_medium * 9 / 10);
-                h.deep_ttl = stats[2] ? 8 : std::max(0, h.deep_ttl - 1);
-                hint_long = h.n_long == 0 ? -1 : (int)std::max<int64_t>(16, h.n_long + h.n_long / 4 + 1);
-                hint_medium = (int)std::max<int64_t>(32, h.n_medium + h.n_medium / 4 + 1);
-                hint_no_deep = h.deep_ttl == 0 ? 1 : 0;
-            }
-        }
-    }
+    const ShapeHints hn = shape_hints(key, N, opts);
+    uint32_t* stats = hn.stats;
+    const int hint_long = hn.hint_long, hint_medium = hn.hint_medium, hint_no_deep = hn.hint_no_deep;
     auto apply_opts = [&](gdr_binning& b) {
         b.global_sort = (opts && opts->global_sort) ? 1 : 0;
         if (opts && opts->deep_max_busy >= 0) b.deep_max_busy = opts->deep_max_busy;
@@ -941,15 +1026,10 @@ int forward_view_impl(const gdr_settings* s, int N, int surfel, const gdr_view_p
     // the count (and the verdict word behind it) on its way to pinned host memory
     int dev = 0;
     (void)hipGetDevice(&dev);
-    uint32_t* pin = nullptr;
     HostCopyTicket* ticket = nullptr;
-    {
-        std::lock_guard<std::mutex> lk(g_pin_mu);
-        for (size_t k = 0; k < g_pin_pool.size(); ++k)
-            if (g_pin_pool[k].dev == dev) { pin = g_pin_pool[k].p; g_pin_pool[k] = g_pin_pool.back(); g_pin_pool.pop_back(); break; }
-    }
-    if (!pin && hipHostMalloc((void**)&pin, 2 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) return hip_fail("hipHostMalloc", hipGetLastError());
-    auto release_pin = [&]() { std::lock_guard<std::mutex> lk(g_pin_mu); g_pin_pool.push_back({pin, dev}); };
+    uint32_t* pin = pin_get(dev);
+    if (!pin) return hip_fail("hipHostMalloc", hipErrorOutOfMemory);
+    auto release_pin = [&]() { pin_put(pin, dev); };
     rc = gdr_host_copy_begin(pin, v.geom.num_rendered, 2 * sizeof(uint32_t), (void*)st, (void**)&ticket);
     if (rc) { release_pin(); return rc; }
     auto finish = [&](int code) { *out_st = v; return code; };
@@ -978,14 +1058,7 @@ int forward_view_impl(const gdr_settings* s, int N, int surfel, const gdr_view_p
         }
     }
     v.D = D;
-    if (N > 0) {   // the history the next call of this shape is planned from
-        std::lock_guard<std::mutex> lk(g_hist_mu);
-        if (g_hist.size() < 4096 || g_hist.count(key)) {
-            ShapeHist& h = g_hist[key];
-            h.d_per_n = std::max((double)D / (double)std::max(N, 1), h.d_per_n * 0.97);
-            if (h.d_per_n <= 0.0) h.d_per_n = 1e-9;    // "seen": a shape without duplicates still gets device-sized calls
-        }
-    }
+    record_duplicates(key, N, D);
     if (!plan->have_binning || D > plan->capacity) {
         set_error("forward_view: binning workspace too small for num_rendered (plan again with exact_D = state.D)", hipSuccess);
         return finish(GDR_ERR_WORKSPACE);
@@ -1031,11 +1104,171 @@ void gdr_view_history_set(int32_t N, int32_t H, int32_t W, int32_t surfel, doubl
     g_hist[shape_key(N, H, W, surfel)].d_per_n = d_per_n > 0.0 ? d_per_n : 0.0;
 }
 
+// ---- all views of one Gaussian set in ONE native call (the forward of the multi-view node) -------------------------------
+int gdr_views_plan_for(int32_t V, int32_t N, int32_t H, int32_t W, uint64_t exact_D, const gdr_view_opts* opts,
+                       gdr_views_plan* plan) {
+    if (!plan || V < 1 || V > GDR_MAX_NODE_VIEWS) { set_error("views_plan_for: bad argument", hipSuccess); return GDR_ERR_INVALID_ARG; }
+    gdr_view_plan one;
+    int rc = gdr_view_plan_for(N, H, W, 0, exact_D, opts, &one);
+    if (rc) return rc;
+    plan->view = one;
+    plan->V = V;
+    plan->bytes_view = (one.bytes + 255) / 256 * 256;
+    plan->bytes_shared = 256 + (uint64_t)((V * sizeof(uint32_t) + 255) / 256 * 256);     // the V packed duplicate counters
+    plan->bytes = (uint64_t)V * plan->bytes_view + plan->bytes_shared;
+    return GDR_OK;
+}
+
+int gdr_forward_views(int32_t V, const gdr_settings* s, const gdr_inputs* in, const gdr_views_plan* plan, void* workspace,
+                      const gdr_view_opts* opts, const gdr_outputs* outs, int32_t loss_mode, const float* const* targets,
+                      float w_depth, float w_alpha, float go_scale, float* losses, void* const* streams, int32_t n_streams,
+                      gdr_view_state* states) {
+    if (!plan || V < 1 || V != plan->V || V > GDR_MAX_NODE_VIEWS || !s || !in || !outs || !states || !streams || n_streams < 1 ||
+        loss_mode < 0 || loss_mode > 2 || (loss_mode && (!targets || !losses))) {
+        set_error("forward_views: bad argument", hipSuccess);
+        return GDR_ERR_INVALID_ARG;
+    }
+    if (!workspace || ((uintptr_t)workspace & 255u)) { set_error("forward_views: workspace NULL / not 256-byte aligned", hipSuccess); return GDR_ERR_INVALID_ARG; }
+    const int N = in->N, W = s[0].image_width, H = s[0].image_height;
+    const int tiles = tile_grid_x(W) * tile_grid_y(H);
+    for (int v = 0; v < V; ++v) {
+        int rc = check_common(&s[v], in);
+        if (rc) return rc;
+        if (s[v].image_width != W || s[v].image_height != H || s[v].sh_degree != s[0].sh_degree || s[v].scale_modifier != s[0].scale_modifier) {
+            set_error("forward_views: image size / sh_degree / scale_modifier must match", hipSuccess);
+            return GDR_ERR_INVALID_ARG;
+        }
+        if (!outs[v].color || (loss_mode != 2 && (!outs[v].depth || !outs[v].alpha)) || (N > 0 && !outs[v].radii) || (loss_mode && !targets[v])) {
+            set_error("forward_views: NULL view buffer", hipSuccess);
+            return GDR_ERR_INVALID_ARG;
+        }
+    }
+    if (N > 0 && (!in->shs || !in->scales || !in->rotations)) { set_error("views: needs shs + scales + rotations", hipSuccess); return GDR_ERR_UNSUPPORTED; }
+    if (key_bits(tiles) > 64) { set_error("image too large", hipSuccess); return GDR_ERR_UNSUPPORTED; }
+    const gdr_view_plan& pv = plan->view;
+    const bool direct = !(opts && (opts->radix_partition || opts->global_sort));
+    char* base = (char*)workspace;
+    uint32_t* counters = (uint32_t*)(base + (size_t)V * plan->bytes_view + 256);
+    std::vector<gdr_geom> geoms((size_t)V);
+    for (int v = 0; v < V; ++v) {
+        gdr_view_state& st = states[v];
+        memset(&st, 0, sizeof(st));
+        char* b = base + (size_t)v * plan->bytes_view;
+        size_t off = carve_geom(b, N, &st.geom);
+        off += carve_image(b + off, H, W, &st.img);
+        if (pv.have_binning) carve_binning(b + off, pv.capacity, &st.bin, pv.seg_len, direct ? N : 0, direct ? tiles : 0);
+        st.geom.cov3D = states[0].geom.cov3D;          // view-independent: one copy
+        st.geom.num_rendered = counters + v;
+        geoms[(size_t)v] = st.geom;
+    }
+    hipStream_t s0 = (hipStream_t)streams[0];
+    hipError_t e = hipMemsetAsync(counters, 0, (size_t)V * sizeof(uint32_t), s0);
+    if (e != hipSuccess) return hip_fail("memset num_rendered", e);
+    for (int lo = 0; lo < V; lo += GDR_MAX_VIEWS) {     // K1: inputs read once per <= 8 views
+        const int n = V - lo < GDR_MAX_VIEWS ? V - lo : GDR_MAX_VIEWS;
+        int32_t* rad[GDR_MAX_VIEWS];
+        for (int k = 0; k < n; ++k) rad[k] = outs[lo + k].radii;
+        e = launch_preprocess_fwd_views(n, s + lo, in, geoms.data() + lo, rad, s0);
+        if (e != hipSuccess) return hip_fail("preprocess_fwd_views", e);
+    }
+    int rc = debug_sync(&s[0], "preprocess_fwd_views", s0);
+    if (rc) return rc;
+    const int ns = n_streams < V ? n_streams : V;
+    if (ns > 1) {       // the side streams start behind K1
+        hipEvent_t ready = event_get();
+        e = hipEventRecord(ready, s0);
+        for (int k = 1; k < ns && e == hipSuccess; ++k) e = hipStreamWaitEvent((hipStream_t)streams[k], ready, 0);
+        event_put(ready);
+        if (e != hipSuccess) return hip_fail("forward_views: stream fork", e);
+    }
+    // the V counts on their way to pinned host memory, in front of the LAST chain (the caller's stream goes straight on)
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::vector<uint32_t> d_host((size_t)V);
+    uint32_t* pin = pin_get(dev);
+    if (!pin) return hip_fail("hipHostMalloc", hipErrorOutOfMemory);
+    struct PinBack { uint32_t* p; int dev; ~PinBack() { pin_put(p, dev); } } pin_back{pin, dev};
+    static_assert(GDR_MAX_NODE_VIEWS <= kPinWords, "count read-back buffer");
+    HostCopyTicket* ticket = nullptr;
+    rc = gdr_host_copy_begin(pin, counters, (uint64_t)V * sizeof(uint32_t), streams[ns - 1], (void**)&ticket);
+    if (rc) return rc;
+    const uint64_t key = shape_key(N, H, W, 0);
+    const ShapeHints hn = shape_hints(key, N, opts);
+    auto chain = [&](int v, hipStream_t st, uint64_t D, bool deferred) -> int {
+        gdr_view_state& vs = states[v];
+        vs.bin.global_sort = (opts && opts->global_sort) ? 1 : 0;
+        if (opts && opts->deep_max_busy >= 0) vs.bin.deep_max_busy = opts->deep_max_busy;
+        if (opts && opts->deep_min_mean >= 0) vs.bin.deep_min_mean = opts->deep_min_mean;
+        vs.bin.hint_long = hn.hint_long; vs.bin.hint_medium = hn.hint_medium; vs.bin.hint_no_deep = hn.hint_no_deep;
+        vs.bin.stats_out = hn.stats ? hn.stats + 4 * (v < kStatViews ? v : kStatViews - 1) : nullptr;
+        vs.bin.d_dev = deferred ? vs.geom.num_rendered : nullptr;
+        int r = binning_stage(&s[v], N, &vs.geom, &vs.bin, &vs.img, D, outs[v].radii, st);
+        if (r) return r;
+        if (loss_mode == 1) return gdr_composite_forward_loss(&s[v], &vs.geom, &vs.bin, &vs.img, &outs[v], targets[v], w_depth, w_alpha, losses + v, (void*)st);
+        if (loss_mode == 2) return gdr_composite_forward_lossgrad(&s[v], &vs.geom, &vs.bin, &vs.img, targets[v], go_scale, losses + v, outs[v].color, (void*)st);
+        return gdr_composite_forward(&s[v], &vs.geom, &vs.bin, &vs.img, &outs[v], (void*)st);
+    };
+    auto join = [&]() -> hipError_t {      // the caller's stream continues only after every view is rendered
+        hipError_t er = hipSuccess;
+        for (int k = 1; k < ns && er == hipSuccess; ++k) {
+            hipEvent_t done = event_get();
+            er = hipEventRecord(done, (hipStream_t)streams[k]);
+            if (er == hipSuccess) er = hipStreamWaitEvent(s0, done, 0);
+            event_put(done);
+        }
+        return er;
+    };
+    bool fits = pv.have_binning != 0;
+    if (pv.have_binning && pv.deferred) {     // device-sized: every chain is enqueued without waiting for K1
+        for (int v = 0; v < V && !rc; ++v) rc = chain(v, (hipStream_t)streams[v % ns], pv.capacity, true);
+        e = join();
+        const int wrc = gdr_host_copy_wait(ticket);
+        if (rc) return rc;
+        if (e != hipSuccess) return hip_fail("forward_views: stream join", e);
+        if (wrc) return wrc;
+        for (int v = 0; v < V; ++v) { d_host[(size_t)v] = pin[v]; fits = fits && pin[v] <= pv.capacity; }
+    } else {
+        rc = gdr_host_copy_wait(ticket);
+        if (rc) return rc;
+        for (int v = 0; v < V; ++v) { d_host[(size_t)v] = pin[v]; fits = fits && pin[v] <= pv.capacity; }
+        if (fits) {
+            for (int v = 0; v < V && !rc; ++v) rc = chain(v, (hipStream_t)streams[v % ns], d_host[(size_t)v], false);
+            e = join();
+            if (rc) return rc;
+            if (e != hipSuccess) return hip_fail("forward_views: stream join", e);
+        } else if (ns > 1) {
+            e = join();
+            if (e != hipSuccess) return hip_fail("forward_views: stream join", e);
+        }
+    }
+    uint64_t d_max = 0;
+    for (int v = 0; v < V; ++v) { states[v].D = d_host[(size_t)v]; d_max = d_max > d_host[(size_t)v] ? d_max : d_host[(size_t)v]; }
+    record_duplicates(key, N, d_max);
+    if (!fits) {
+        set_error("forward_views: binning workspace too small for num_rendered (plan again with exact_D = the largest state.D)", hipSuccess);
+        return GDR_ERR_WORKSPACE;
+    }
+    return GDR_OK;
+}
+
+int gdr_view_history_report(int32_t N, int32_t H, int32_t W, int32_t surfel, int32_t row, uint32_t* words, int32_t set) {
+    if (row < 0 || row >= kStatViews || !words) { set_error("view_history_report: bad argument", hipSuccess); return GDR_ERR_INVALID_ARG; }
+    std::lock_guard<std::mutex> lk(g_hist_mu);
+    auto it = g_hist.find(shape_key(N, H, W, surfel));
+    if (it == g_hist.end() || !it->second.stats) { for (int k = 0; k < 4 && !set; ++k) words[k] = 0xFFFFFFFFu; return set ? GDR_ERR_INVALID_ARG : GDR_OK; }
+    for (int k = 0; k < 4; ++k) {
+        if (set) it->second.stats[4 * row + k] = words[k];
+        else words[k] = it->second.stats[4 * row + k];
+    }
+    if (set) { it->second.n_long = it->second.n_medium = 0; it->second.deep_ttl = 0; }    // (the decaying maxima restart from the words)
+    return GDR_OK;
+}
+
 void gdr_view_history_reset(void) {
     std::lock_guard<std::mutex> lk(g_hist_mu);
     for (auto& kv : g_hist) {     // (the pinned report words stay: a kernel in flight may still write them)
         kv.second.d_per_n = 0.0; kv.second.n_long = kv.second.n_medium = 0; kv.second.deep_ttl = 0; kv.second.reported = false;
-        if (kv.second.stats) for (int k = 0; k < 4; ++k) kv.second.stats[k] = 0xFFFFFFFFu;
+        if (kv.second.stats) for (int k = 0; k < kStatViews * 4; ++k) kv.second.stats[k] = 0xFFFFFFFFu;
     }
 }
 

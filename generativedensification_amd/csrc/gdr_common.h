@@ -128,6 +128,9 @@ hipError_t launch_render_fwd_loss(const gdr_settings* s, const gdr_geom* g, cons
 hipError_t launch_render_fwd_lossgrad(const gdr_settings* s, const gdr_geom* g, const gdr_binning* bin,
                                       const gdr_image* img, const float* target, float go_scale, float* loss,
                                       float* dL_dcolor, hipStream_t st);
+hipError_t launch_render_fwd_views(int V, const gdr_settings* s, const gdr_geom* g, const gdr_binning* bin, const gdr_image* img,
+                                   const gdr_outputs* outs, int loss_mode, const float* const* targets, float w_depth,
+                                   float w_alpha, float go_scale, float* losses, int interleave, hipStream_t st);
 hipError_t launch_topk_absgrad(int N, const float* grad, const uint8_t* cand, int k, void* workspace,
                                uint8_t* mask, int32_t* idx, hipStream_t st);
 size_t select_workspace_bytes();

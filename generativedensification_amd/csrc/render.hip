@@ -286,17 +286,45 @@ struct FusedLoss {
 // LOSS = 2 (the abs-grad-only path of network.py:865-878): the MSE is folded in as for LOSS = 1 but NO image
 // leaves the kernel — instead of colour / depth / alpha it writes d loss / d colour of the pixel (times go_scale) into
 // out_color, which the mean2D-only K7 reads as its upstream gradient; per pixel 12 + 8 bytes instead of 20 + 8.
+// Everything K6 touches of ONE view; the kernel takes a table of V <= GDR_MAX_VIEWS of them (round 4, as K7's BwdViews:
+// the workgroups of all views of a node in one grid).
+struct FwdView {
+    const uint2* ranges; const uint32_t* point_list; const uint32_t* tile_order;
+    const float4* rec; const float* bg; float* final_T; uint32_t* n_contrib;
+    float* out_color; float* out_depth; float* out_alpha;
+    FusedLoss fl;
+    const uint32_t* seg_base; float* seg_state; const uint32_t* deep_flag;
+    int seg_rounds, pad;
+};
+struct FwdViews { FwdView v[GDR_MAX_VIEWS]; };
+
 template <int LOSS>
-__global__ __launch_bounds__(GDR_BLOCK) void render_fwd_kernel(
-    const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
-    const uint32_t* __restrict__ tile_order, int W, int H, int gx, int ntiles,
-    const float4* __restrict__ rec, const float* __restrict__ bg, float* __restrict__ final_T,
-    uint32_t* __restrict__ n_contrib, float* __restrict__ out_color, float* __restrict__ out_depth,
-    float* __restrict__ out_alpha, const FusedLoss fl, const uint32_t* __restrict__ seg_base,
-    float* __restrict__ seg_state, int seg_rounds, const uint32_t* __restrict__ deep_flag) {
+__global__ __launch_bounds__(GDR_BLOCK) void render_fwd_kernel(const FwdViews vs, int V, int interleave, int W, int H, int gx,
+                                                               int ntiles) {
     __shared__ SliceLds lds;
     __shared__ RowLists rlists;
     __shared__ int s_done[GDR_BLOCK / GDR_WAVE];
+    uint32_t view = 0, slot = blockIdx.x;     // (view, slot): as render_bwd_kernel
+    if (V > 1) {
+        if (interleave) { view = blockIdx.x % (uint32_t)V; slot = blockIdx.x / (uint32_t)V; }
+        else { view = blockIdx.x / (uint32_t)ntiles; slot = blockIdx.x - view * (uint32_t)ntiles; }
+    }
+    const FwdView& fv = vs.v[view];
+    const uint2* __restrict__ ranges = fv.ranges;
+    const uint32_t* __restrict__ point_list = fv.point_list;
+    const uint32_t* __restrict__ tile_order = fv.tile_order;
+    const float4* __restrict__ rec = fv.rec;
+    const float* __restrict__ bg = fv.bg;
+    float* __restrict__ final_T = fv.final_T;
+    uint32_t* __restrict__ n_contrib = fv.n_contrib;
+    float* __restrict__ out_color = fv.out_color;
+    float* __restrict__ out_depth = fv.out_depth;
+    float* __restrict__ out_alpha = fv.out_alpha;
+    const FusedLoss& fl = fv.fl;
+    const uint32_t* __restrict__ seg_base = fv.seg_base;
+    float* __restrict__ seg_state = fv.seg_state;
+    const int seg_rounds = fv.seg_rounds;
+    const uint32_t* __restrict__ deep_flag = fv.deep_flag;
 
     const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
     const uint32_t row = lane >> 4, li = lane & 15u;
@@ -307,7 +335,7 @@ __global__ __launch_bounds__(GDR_BLOCK) void render_fwd_kernel(
     }
     if (threadIdx.x < 8) rlists.pad[threadIdx.x] = (uint16_t)GDR_NULL_ENTRY;
 
-    const uint32_t tile = tile_order ? tile_order[blockIdx.x] : xcd_remap(blockIdx.x, (uint32_t)ntiles);
+    const uint32_t tile = tile_order ? tile_order[slot] : xcd_remap(slot, (uint32_t)ntiles);
     const int tx = (int)(tile % (uint32_t)gx), ty = (int)(tile / (uint32_t)gx);
     const int sx0 = tx * GDR_TILE + (int)(wave & 1u) * 8, sy0 = ty * GDR_TILE + (int)(wave >> 1) * 8;
     const int px = sx0 + (int)(row & 1u) * 4 + (int)(li & 3u), py = sy0 + (int)(row >> 1) * 4 + (int)(li >> 2);
@@ -978,49 +1006,74 @@ hipError_t launch_tile_order_views(const BinViews& vs, int V, int ntiles, hipStr
         }                                                                                                                 \
     } while (0)
 
-hipError_t launch_render_fwd(const gdr_settings* s, const gdr_geom* g, const gdr_binning* bin,
-                             const gdr_image* img, const gdr_outputs* out, hipStream_t st) {
-    const int W = s->image_width, H = s->image_height;
+// ---- K6 launchers: the deep launch of every view that may need one, then ONE table-driven standard launch ----
+namespace {
+struct FwdSpec {   // host side of FwdView
+    const gdr_settings* s; const gdr_geom* g; const gdr_binning* bin; const gdr_image* img;
+    float* color; float* depth; float* alpha;
+    FusedLoss fl;
+};
+
+template <int LOSS>
+hipError_t launch_fwd_table(int V, const FwdSpec* sp, int interleave, hipStream_t st) {
+    const int W = sp[0].s->image_width, H = sp[0].s->image_height;
     const int gx = tile_grid_x(W), gy = tile_grid_y(H);
     const int ntiles = gx * gy;
-    GDR_DEEP_LAUNCH(0, out->color, out->depth, out->alpha, FusedLoss{});
-    GDR_LAUNCH(GDR_K_RENDER_FWD, render_fwd_kernel<0>, dim3(ntiles), dim3(GDR_BLOCK), st,
-               (const uint2*)img->ranges, bin->values[bin->sorted], img->tile_order, W, H, gx, ntiles,
-               (const float4*)g->rec, s->bg, img->final_T, img->n_contrib, out->color, out->depth, out->alpha,
-               FusedLoss{}, GDR_SEG_FWD_ARGS(bin, img), img->tile_order ? GDR_DEEP_FLAG(bin, img) : nullptr);
+    FwdViews vs;
+    memset(&vs, 0, sizeof(vs));
+    for (int v = 0; v < V; ++v) {
+        const gdr_settings* s = sp[v].s; const gdr_geom* g = sp[v].g; const gdr_binning* bin = sp[v].bin; const gdr_image* img = sp[v].img;
+        GDR_DEEP_LAUNCH(LOSS, sp[v].color, sp[v].depth, sp[v].alpha, sp[v].fl);
+        FwdView& f = vs.v[v];
+        f.ranges = (const uint2*)img->ranges; f.point_list = bin->values[bin->sorted]; f.tile_order = img->tile_order;
+        f.rec = (const float4*)g->rec; f.bg = s->bg; f.final_T = img->final_T; f.n_contrib = img->n_contrib;
+        f.out_color = sp[v].color; f.out_depth = sp[v].depth; f.out_alpha = sp[v].alpha; f.fl = sp[v].fl;
+        f.seg_base = img->seg_base; f.seg_state = bin->seg_state; f.seg_rounds = seg_rounds_of(bin, img);
+        f.deep_flag = img->tile_order ? GDR_DEEP_FLAG(bin, img) : nullptr;
+    }
+    GDR_LAUNCH(GDR_K_RENDER_FWD, render_fwd_kernel<LOSS>, dim3((unsigned)V * (unsigned)ntiles), dim3(GDR_BLOCK), st, vs, V, interleave,
+               W, H, gx, ntiles);
     return hipGetLastError();
+}
+}  // namespace
+
+hipError_t launch_render_fwd(const gdr_settings* s, const gdr_geom* g, const gdr_binning* bin,
+                             const gdr_image* img, const gdr_outputs* out, hipStream_t st) {
+    const FwdSpec sp{s, g, bin, img, out->color, out->depth, out->alpha, FusedLoss{}};
+    return launch_fwd_table<0>(1, &sp, 0, st);
 }
 
 hipError_t launch_render_fwd_loss(const gdr_settings* s, const gdr_geom* g, const gdr_binning* bin,
                                   const gdr_image* img, const gdr_outputs* out, const float* target, float w_depth,
                                   float w_alpha, float* loss, hipStream_t st) {
-    const int W = s->image_width, H = s->image_height;
-    const int gx = tile_grid_x(W), gy = tile_grid_y(H);
-    const int ntiles = gx * gy;
-    const FusedLoss fl{target, w_depth, w_alpha, loss, nullptr, nullptr, 1.f};
-    GDR_DEEP_LAUNCH(1, out->color, out->depth, out->alpha, fl);
-    GDR_LAUNCH(GDR_K_RENDER_FWD, render_fwd_kernel<1>, dim3(ntiles), dim3(GDR_BLOCK), st,
-               (const uint2*)img->ranges, bin->values[bin->sorted], img->tile_order, W, H, gx, ntiles,
-               (const float4*)g->rec, s->bg, img->final_T, img->n_contrib, out->color, out->depth, out->alpha, fl,
-               GDR_SEG_FWD_ARGS(bin, img), img->tile_order ? GDR_DEEP_FLAG(bin, img) : nullptr);
-    return hipGetLastError();
+    const FwdSpec sp{s, g, bin, img, out->color, out->depth, out->alpha, FusedLoss{target, w_depth, w_alpha, loss, nullptr, nullptr, 1.f}};
+    return launch_fwd_table<1>(1, &sp, 0, st);
 }
 
 // K6 of the abs-grad-only path: loss accumulated, d loss / d colour written instead of any image (LOSS = 2)
 hipError_t launch_render_fwd_lossgrad(const gdr_settings* s, const gdr_geom* g, const gdr_binning* bin,
                                       const gdr_image* img, const float* target, float go_scale, float* loss,
                                       float* dL_dcolor, hipStream_t st) {
-    const int W = s->image_width, H = s->image_height;
-    const int gx = tile_grid_x(W), gy = tile_grid_y(H);
-    const int ntiles = gx * gy;
-    const FusedLoss fl{target, 0.f, 0.f, loss, nullptr, nullptr, go_scale};
-    float* const none = nullptr;
-    GDR_DEEP_LAUNCH(2, dL_dcolor, none, none, fl);
-    GDR_LAUNCH(GDR_K_RENDER_FWD, render_fwd_kernel<2>, dim3(ntiles), dim3(GDR_BLOCK), st,
-               (const uint2*)img->ranges, bin->values[bin->sorted], img->tile_order, W, H, gx, ntiles,
-               (const float4*)g->rec, s->bg, img->final_T, img->n_contrib, dL_dcolor, none, none, fl,
-               GDR_SEG_FWD_ARGS(bin, img), img->tile_order ? GDR_DEEP_FLAG(bin, img) : nullptr);
-    return hipGetLastError();
+    const FwdSpec sp{s, g, bin, img, dL_dcolor, nullptr, nullptr, FusedLoss{target, 0.f, 0.f, loss, nullptr, nullptr, go_scale}};
+    return launch_fwd_table<2>(1, &sp, 0, st);
+}
+
+// K6 of V <= GDR_MAX_VIEWS views of one image size in ONE launch (gdr_composite_forward_views).  loss_mode 0: images only;
+// 1: images + the folded loss (losses[v] accumulated); 2: loss + d loss / d colour into outs[v].color, no image
+hipError_t launch_render_fwd_views(int V, const gdr_settings* s, const gdr_geom* g, const gdr_binning* bin, const gdr_image* img,
+                                   const gdr_outputs* outs, int loss_mode, const float* const* targets, float w_depth,
+                                   float w_alpha, float go_scale, float* losses, int interleave, hipStream_t st) {
+    FwdSpec sp[GDR_MAX_VIEWS];
+    for (int v = 0; v < V; ++v) {
+        FusedLoss fl{};
+        if (loss_mode == 1) fl = FusedLoss{targets[v], w_depth, w_alpha, losses + v, nullptr, nullptr, 1.f};
+        if (loss_mode == 2) fl = FusedLoss{targets[v], 0.f, 0.f, losses + v, nullptr, nullptr, go_scale};
+        sp[v] = FwdSpec{&s[v], &g[v], &bin[v], &img[v], outs[v].color, loss_mode == 2 ? nullptr : outs[v].depth,
+                        loss_mode == 2 ? nullptr : outs[v].alpha, fl};
+    }
+    if (loss_mode == 1) return launch_fwd_table<1>(V, sp, interleave, st);
+    if (loss_mode == 2) return launch_fwd_table<2>(V, sp, interleave, st);
+    return launch_fwd_table<0>(V, sp, interleave, st);
 }
 
 // ---- K7 launchers: every variant goes through ONE table-driven launch (V = 1 for the single-view entry points) ----

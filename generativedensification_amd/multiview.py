@@ -110,10 +110,7 @@ def _grad_pack(params, world):
     return pack
 
 
-CHUNK_BYTES = 64 << 20    # reduce-scatter / all-gather are issued per chunk of the packed buffer (see below)
-
-
-def allreduce_gaussian_grads(params: Sequence[torch.Tensor], chunk_bytes: int | None = None) -> None:
+def allreduce_gaussian_grads(params: Sequence[torch.Tensor]) -> None:
     """Sum the per-Gaussian attribute gradients over ranks: one packed buffer
     (236 B/Gaussian at SH degree 3) moved as reduce-scatter + all-gather so that all
     7 xGMI links of a GPU carry 1/G of it each, instead of a per-tensor ring all-reduce.
@@ -125,14 +122,16 @@ def allreduce_gaussian_grads(params: Sequence[torch.Tensor], chunk_bytes: int | 
 
     The packed buffer is PERSISTENT — one per SET OF TENSORS (keyed on the tensors' identity, weakly referenced; tensors of
     different dtypes get one buffer per dtype) — and the gradients the call leaves behind are views of it: no `torch.cat`
-    of 472 MB (2 M Gaussians), no copy back.  A training loop that keeps its gradients (`zero_grad(set_to_none=False)`,
-    or `p.grad.zero_()`) has autograd accumulate straight into the buffer, and the next call moves it as it
-    is — zero copies; a loop that drops them (`p.grad = None`) pays one copy_ into the buffer.
+    of 472 MB (2 M Gaussians), no copy back.  A training loop that drops its gradients between steps (`p.grad = None`) pays
+    ONE copy_ of the fresh gradients into the buffer (a read and a write of the 472 MB); a loop that keeps them
+    (`zero_grad(set_to_none=False)`) pays no copy here but a fill plus autograd's accumulate-in-place (read, read, write)
+    instead — measured at 2 M Gaussians, one rank with the collectives forced (`bench.py --force-dist --grad-allreduce
+    [--keep-grads]`, profiles/r04_bench_rccl_1rank*.json): 4.28 ms per step dropped, 4.55 ms kept: dropping is the cheaper
+    loop, and what `bench.py` does.
 
-    The buffer moves in contiguous chunks of `chunk_bytes` (default CHUNK_BYTES = 64 MB, rounded to a multiple of the world
-    size in elements; the padded length is a multiple of it too): all reduce-scatters are queued asynchronously, then all
-    all-gathers — the all-gather of an early chunk runs while later chunks are still being reduced, so both directions
-    of the xGMI links are busy (RCCL executes the queue in order on its stream)."""
+    (Not chunked: the six gradient tensors of a Gaussian set come out of ONE kernel launch (K8+K9 writes every output), so
+    there is no earlier point at which part of the buffer is final, and collectives queued on one communicator run in order —
+    chunks would neither start sooner nor overlap each other.)"""
     if _no_peers():
         return
     world = dist.get_world_size()
@@ -149,19 +148,7 @@ def allreduce_gaussian_grads(params: Sequence[torch.Tensor], chunk_bytes: int | 
                 v.zero_()
             elif p.grad.data_ptr() != v.data_ptr() or p.grad.dtype != v.dtype:
                 v.copy_(p.grad)
-        flat, shard = pack.flat, pack.shard
-        # chunk c = flat[c * ce, (c + 1) * ce) is reduced and gathered on its own: rank r ends up owning the r-th world-th
-        # of EVERY chunk (shard = the concatenation of its parts), every collective works on contiguous memory
-        ce = max(world, (chunk_bytes or CHUNK_BYTES) // flat.element_size() // world * world)
-        bounds = [(lo, min(flat.numel(), lo + ce)) for lo in range(0, flat.numel(), ce)]
-        if len(bounds) <= 1:
-            dist.reduce_scatter_tensor(shard, flat, op=dist.ReduceOp.SUM)
-            dist.all_gather_into_tensor(flat, shard)
-        else:
-            work = [dist.reduce_scatter_tensor(shard[lo // world: hi // world], flat[lo:hi], op=dist.ReduceOp.SUM, async_op=True)
-                    for lo, hi in bounds]
-            work += [dist.all_gather_into_tensor(flat[lo:hi], shard[lo // world: hi // world], async_op=True) for lo, hi in bounds]
-            for w_ in work:     # (queued in order on the backend's stream: every all-gather runs behind its reduce-scatter)
-                w_.wait()
+        dist.reduce_scatter_tensor(pack.shard, pack.flat, op=dist.ReduceOp.SUM)
+        dist.all_gather_into_tensor(pack.flat, pack.shard)
         for p, v in zip(group, pack.views):
             p.grad = v

@@ -465,6 +465,19 @@ def _take_records(ctx, lo, n, N, floats, dev):
     return torch.empty(n, max(N, 1) * floats, dtype=torch.float32, device=dev), 0
 
 
+def _grad_buffers(N, M, f32):
+    return dict(means3D=torch.empty(N, 3, **f32), means2D=torch.empty(N, 4, **f32), shs=torch.empty(N, M, 3, **f32),
+                opacities=torch.empty(N, 1, **f32), scales=torch.empty(N, 3, **f32), rotations=torch.empty(N, 4, **f32))
+
+
+def _kept_settings(ctx, dev, keep2):
+    """The V settings structs of a multi-view node's forward (kept behind its device tensors), or fresh ones."""
+    arr = ctx.keep_rest[-1] if ctx.keep_rest else None
+    if isinstance(arr, C.Array) and len(arr) == len(ctx.settings_list) and isinstance(arr[0], L.GdrSettings):
+        return list(arr)
+    return [_settings_struct(rs, dev, keep2) for rs in ctx.settings_list]
+
+
 def _save_inputs(ctx, keep, n=7):
     """The n f32 input tensors of a node go through ctx.save_for_backward, as in the upstream extension: autograd's
     version counters then turn an in-place update between forward and backward (an optimizer step, a densification
@@ -676,8 +689,11 @@ def _carve_binning(lib, st, entries, tiles, d_dev=None, stats=None, hints=None):
 
 
 def _forward_views_impl(means3D, means2D, sh, opacities, scales, rotations, settings_list, flags, loss_spec=None):
-    """K1 for all views (one launch per <= 8 views), then every view's chain binning -> K6 on one of K.FWD_STREAMS
-    streams; the duplicate counts are read back without stalling either side (see K.DEFER_D above).
+    """The forward of a multi-view node in ONE native call (include/gdr.h gdr_forward_views, round 4): K1 for all views (one
+    launch per <= 8 views), then every view's chain binning -> K6 on one of K.FWD_STREAMS streams, the caller's included; the
+    duplicate counts are read back once, after everything is enqueued; one allocation for all views, carved by the library.
+    (Until round 3 this was ~15 ABI calls per view from Python: at reference-scale scenes the chains of the four streams started
+    60-100 us apart, the host being the slower side — kernel timeline of a C2 step, profiles/r04_timeline_c2.txt.)
     Returns (colors, radii, depths, alphas, states, keep, in_dtypes)."""
     lib = L.load()
     _require_hip(means3D, "means3D")
@@ -689,10 +705,9 @@ def _forward_views_impl(means3D, means2D, sh, opacities, scales, rotations, sett
     H, W = int(settings_list[0].image_height), int(settings_list[0].image_width)
     if any(int(rs.image_height) != H or int(rs.image_width) != W for rs in settings_list):
         raise RuntimeError("render_views: all views must share one image size")
-    tiles = ((W + 15) // 16) * ((H + 15) // 16)
-    e = torch.empty(0, dtype=torch.float32, device=dev)
+    e = empty_f32(dev)
     keep = [means3D, opacities, sh, e, scales, rotations, e]
-    f32, u8 = dict(dtype=torch.float32, device=dev), dict(dtype=torch.uint8, device=dev)
+    f32 = dict(dtype=torch.float32, device=dev)
     # one tensor per view (not slices of a stacked buffer): a per-view loss then back-propagates straight into
     # that view's gradient, without autograd's select-backward zero-fill + add of the whole stack per view
     lossgrad = loss_spec is not None and loss_spec[0] == "lossgrad"   # abs-grad-only path: no image leaves K6
@@ -700,111 +715,57 @@ def _forward_views_impl(means3D, means2D, sh, opacities, scales, rotations, sett
     depths = [None if lossgrad else torch.empty(1, H, W, **f32) for _ in range(V)]
     alphas = [None if lossgrad else torch.empty(1, H, W, **f32) for _ in range(V)]
     radii = torch.empty(V, N, dtype=torch.int32, device=dev)
-    # the V duplicate counters in one array: one fill before K1, one copy to the host (no gather kernel)
-    counters = torch.empty(V, dtype=torch.int32, device=dev)
-    key = shape_key(N, H, W, V)
-    states = []
     with torch.cuda.device(dev):
-        stream = _stream()
         main = torch.cuda.current_stream()
         inp = _inputs_struct(N, M, means3D, opacities, sh, e, scales, rotations, e, flags)
-        s_arr = (L.GdrSettings * V)()
-        g_arr = (L.GdrGeom * V)()
-        for v, rs in enumerate(settings_list):
-            s_arr[v] = _settings_struct(rs, dev, keep)
-            st = _State()
-            st.N, st.M, st.H, st.W = N, M, H, W
-            st.geom_buf = torch.empty(lib.gdr_geom_bytes(N), **u8)
-            st.img_buf = torch.empty(lib.gdr_image_bytes(H, W), **u8)
-            st.bin_buf = None
-            st.geom, st.bin, st.img = L.GdrGeom(), L.GdrBinning(), L.GdrImage()
-            L.check(lib.gdr_geom_carve(st.geom_buf.data_ptr(), N, C.byref(st.geom)), "gdr_geom_carve")
-            L.check(lib.gdr_image_carve(st.img_buf.data_ptr(), H, W, C.byref(st.img)), "gdr_image_carve")
-            st.geom.cov3D = states[0].geom.cov3D if states else st.geom.cov3D  # view-independent: shared
-            st.geom.num_rendered = counters.data_ptr() + 4 * v
-            st.counters = counters
-            g_arr[v] = st.geom
-            states.append(st)
-        # K1 for all views in groups of <= GDR_MAX_VIEWS launches (inputs read once per group)
-        for lo in range(0, V, L.GDR_MAX_VIEWS):
-            n = min(L.GDR_MAX_VIEWS, V - lo)
-            r_arr = (C.c_void_p * n)(*[radii[lo + k].data_ptr() if N else None for k in range(n)])
-            sub_s = (L.GdrSettings * n).from_address(C.addressof(s_arr) + lo * C.sizeof(L.GdrSettings))
-            sub_g = (L.GdrGeom * n).from_address(C.addressof(g_arr) + lo * C.sizeof(L.GdrGeom))
-            if lo > 0:  # the shared cov3D of group 0 is what every later stage reads
-                for k in range(n):
-                    sub_g[k].cov3D = g_arr[0].cov3D
-            L.check(lib.gdr_preprocess_forward_views(n, sub_s, C.byref(inp), sub_g, r_arr, stream),
-                    "gdr_preprocess_forward_views")
-        # The views' chains (binning -> K6) round-robin over K.FWD_STREAMS streams, the caller's included: the binning is
-        # ~12 short, latency-bound kernels per view that overlap the VALU-bound K6 of other views, and two concurrent K6
-        # fill the CUs that one view's skewed tile lists and kernel tails leave idle.  Four streams = the number of
-        # hardware queues a process gets by default (more alias onto the same queues and serialise).
+        s_arr = (L.GdrSettings * V)(*[_settings_struct(rs, dev, keep) for rs in settings_list])
+        o_arr = (L.GdrOutputs * V)(*[L.GdrOutputs(colors[v].data_ptr(), _ptr(depths[v]), _ptr(alphas[v]), _ptr(radii[v]))
+                                     for v in range(V)])
+        mode_, tg_arr, wd_, wa_, gs_, ls_ = 0, None, 0.0, 0.0, 1.0, None
+        if lossgrad:
+            _, targets, go_scale, losses = loss_spec
+            mode_, gs_, ls_ = 2, float(go_scale), losses
+        elif loss_spec is not None:
+            targets, w_depth, w_alpha, losses = loss_spec
+            mode_, wd_, wa_, ls_ = 1, float(w_depth), float(w_alpha), losses
+        if mode_:
+            tg_arr = (C.c_void_p * V)(*[targets[v].data_ptr() for v in range(V)])
+        # The views' chains round-robin over K.FWD_STREAMS streams, the caller's included: the binning is ~6 short,
+        # latency-bound kernels per view that overlap the VALU-bound K6 of other views, and two concurrent K6 fill the CUs that
+        # one view's skewed tile lists and kernel tails leave idle.  Four streams = the number of hardware queues a process
+        # gets by default (more alias onto the same queues and serialise).
         nfs = max(1, min(K.FWD_STREAMS, V)) if K.RENDER_SIDE and V > 1 and side_count(H, W) > 0 else 1
         fstreams = [main] + _view_streams(dev, nfs - 1)
-        if nfs > 1:   # the side streams start waiting for K1 now, before the host does anything else
-            ready = torch.cuda.Event()
-            ready.record(main)
+        st_arr = (C.c_void_p * nfs)(*[fs.cuda_stream for fs in fstreams])
+        opts, plan, vs_arr = _view_opts(), L.GdrViewsPlan(), (L.GdrViewState * V)()
+        exact, ws = 0, None
+        for _ in range(4):
+            L.check(lib.gdr_views_plan_for(V, N, H, W, exact, C.byref(opts), C.byref(plan)), "gdr_views_plan_for")
+            if not K.DEFER_D and not exact:     # upstream's flow: the counts are read back before anything is sized
+                plan.view.have_binning = 0
+            ws = torch.empty(max(int(plan.bytes), 256), dtype=torch.uint8, device=dev)
             for fs in fstreams[1:]:
-                fs.wait_event(ready)
-        readback = _CountReadback(counters, fstreams[-1])   # (in front of the LAST chain: the caller's stream goes straight on)
-        cap = _d_capacity(key, N) if N > 0 else None
-        stats, hints = _launch_stats(key, V)
-        srow = (lambda v: None) if stats is None else (lambda v: stats[v])
-        if cap is None:         # first call of this shape: D decides the workspace sizes, as upstream
-            d_host = readback.wait()
-            for v, st in enumerate(states):
-                _carve_binning(lib, st, d_host[v], tiles, stats=srow(v), hints=hints)
+                ws.record_stream(fs)
+            if mode_ and exact:
+                ls_.zero_()          # (a repeated call accumulates its losses again)
+            rc = lib.gdr_forward_views(V, s_arr, C.byref(inp), C.byref(plan), C.c_void_p(ws.data_ptr()), C.byref(opts), o_arr,
+                                       mode_, tg_arr, wd_, wa_, gs_, None if ls_ is None else C.c_void_p(ls_.data_ptr()), st_arr,
+                                       nfs, vs_arr)
+            if rc == L.GDR_OK:
+                break
+            if rc != L.GDR_ERR_WORKSPACE:
+                L.check(rc, "gdr_forward_views")
+            exact = max(1, max(int(vs_arr[v].D) for v in range(V)))
         else:
-            for v, st in enumerate(states):
-                _carve_binning(lib, st, cap, tiles, d_dev=st.geom.num_rendered, stats=srow(v), hints=hints)
-
-        def composite(v, sv):  # K6 of view v (with the loss folded into its epilogue when loss_spec is given)
-            st = states[v]
-            if lossgrad:
-                _, targets, go_scale, losses = loss_spec
-                L.check(lib.gdr_composite_forward_lossgrad(C.byref(s_arr[v]), C.byref(g_arr[v]), C.byref(st.bin),
-                                                           C.byref(st.img), targets[v].data_ptr(), float(go_scale),
-                                                           losses[v:v + 1].data_ptr(), colors[v].data_ptr(), sv),
-                        "gdr_composite_forward_lossgrad")
-                return
-            out = L.GdrOutputs(colors[v].data_ptr(), depths[v].data_ptr(), alphas[v].data_ptr(), _ptr(radii[v]))
-            if loss_spec is None:
-                L.check(lib.gdr_composite_forward(C.byref(s_arr[v]), C.byref(g_arr[v]), C.byref(st.bin), C.byref(st.img),
-                                                  C.byref(out), sv), "gdr_composite_forward")
-            else:
-                targets, w_depth, w_alpha, losses = loss_spec
-                L.check(lib.gdr_composite_forward_loss(C.byref(s_arr[v]), C.byref(g_arr[v]), C.byref(st.bin),
-                                                       C.byref(st.img), C.byref(out), targets[v].data_ptr(), float(w_depth),
-                                                       float(w_alpha), losses[v:v + 1].data_ptr(), sv),
-                        "gdr_composite_forward_loss")
-
-        def chain(v, fs):   # binning of view v on stream fs, then its K6.  (One chain for a GROUP of views — every binning
-            # launch covering 2 / 4 / 8 views, view = blockIdx.y — was measured again with the direct tile binning of round 3:
-            # C4 1262 -> 1194 / 1227 / 1235, C3 3008 -> 2819 / 2908 / 3023, C2 2957 -> 2780 / 2855 / 2887 views/s: DESIGN §3.)
-            sp = C.c_void_p(fs.cuda_stream)
-            st = states[v]
-            L.check(lib.gdr_binning_forward(C.byref(s_arr[v]), N, C.byref(g_arr[v]), C.byref(st.bin),
-                                            C.byref(st.img), st.D, _ptr(radii[v]), sp), "gdr_binning_forward")
-            composite(v, sp)
-
+            raise RuntimeError("gdr_forward_views: the duplicate counts kept growing between calls")
+        states = []
         for v in range(V):
-            chain(v, fstreams[v % nfs])
-        for fs in fstreams[1:]:   # the caller's stream continues only after every view is rendered
-            done = torch.cuda.Event()
-            done.record(fs)
-            main.wait_event(done)
-        if cap is not None:
-            d_host = readback.wait()     # (K1 finished long ago: the host has enqueued ~15 launches per view since)
-            for v in [v for v in range(V) if d_host[v] > cap]:
-                # the guess was too small for this view: again, exactly sized, behind everything else
-                _carve_binning(lib, states[v], d_host[v], tiles, stats=srow(v), hints=hints)
-                if loss_spec is not None:
-                    loss_spec[-1][v:v + 1].zero_()
-                chain(v, main)
-            for v, st in enumerate(states):
-                st.D = d_host[v]
-        _d_record(key, d_host, N)
+            st = _State()
+            st.N, st.M, st.H, st.W, st.D = N, M, H, W, int(vs_arr[v].D)
+            st.geom_buf = st.bin_buf = st.img_buf = ws
+            st.view, st.geom, st.bin, st.img = vs_arr, vs_arr[v].geom, vs_arr[v].bin, vs_arr[v].img
+            states.append(st)
+    keep.append(s_arr)     # the V settings structs: the backward reuses them (their device tensors are in `keep` already)
     return colors, radii, depths, alphas, states, keep, in_dtypes
 
 
@@ -833,12 +794,10 @@ class _RenderViews(torch.autograd.Function):
         H, W = states[0].H, states[0].W
         g_colors, g_depths, g_alphas = g_views[:V], g_views[V:2 * V], g_views[2 * V:3 * V]
         f32 = dict(dtype=torch.float32, device=dev)
-        g = dict(means3D=torch.empty(N, 3, **f32), means2D=torch.empty(N, 4, **f32), shs=torch.empty(N, M, 3, **f32),
-                 opacities=torch.empty(N, 1, **f32), scales=torch.empty(N, 3, **f32), rotations=torch.empty(N, 4, **f32))
+        g = inp = None      # (allocated behind the K7 launch)
         with torch.cuda.device(dev):
             keep2: list = []
             stream = _stream()
-            inp = _inputs_struct(N, M, means3D, opacities, sh, e, scales, rotations, e, ctx.flags)
             grads_in = []
             for v in range(V):  # torch-side preparation stays on the caller's stream
                 gc = (_f32(g_colors[v], dev) if g_colors[v] is not None
@@ -847,7 +806,7 @@ class _RenderViews(torch.autograd.Function):
                 ga = None if g_alphas[v] is None else _f32(g_alphas[v], dev)
                 keep2 += [gc, gd, ga]
                 grads_in.append((gc, gd, ga))
-            sets = [_settings_struct(rs, dev, keep2) for rs in ctx.settings_list]
+            sets = _kept_settings(ctx, dev, keep2)
             mode = k7_views_mode(H, W, N) if V > 1 else 0
             if mode:
                 _join_record_clears(ctx)
@@ -871,6 +830,8 @@ class _RenderViews(torch.autograd.Function):
                     L.check(lib.gdr_render_backward(C.byref(s_arr[k]), N, C.byref(g_arr[k]), C.byref(st.bin),
                                                     C.byref(st.img), C.byref(gin), recs[k].data_ptr(), sides.stream(v)),
                             "gdr_render_backward")
+                if g is None:
+                    g, inp = _grad_buffers(N, M, f32), _inputs_struct(N, M, means3D, opacities, sh, e, scales, rotations, e, ctx.flags)
                 r_arr = (C.c_void_p * n)(*[ctx.radii[lo + k].data_ptr() if N else None for k in range(n)])
                 rec_arr = (C.c_void_p * n)(*[recs[k].data_ptr() for k in range(n)])
                 gout = L.GdrGradOutputs(_ptr(g["means3D"]), _ptr(g["means2D"]), _ptr(g["shs"]), None,
@@ -925,14 +886,12 @@ class _RenderViewsLoss(torch.autograd.Function):
         states = ctx.states
         N, M, V = states[0].N, states[0].M, len(states)
         f32 = dict(dtype=torch.float32, device=dev)
-        g = dict(means3D=torch.empty(N, 3, **f32), means2D=torch.empty(N, 4, **f32), shs=torch.empty(N, M, 3, **f32),
-                 opacities=torch.empty(N, 1, **f32), scales=torch.empty(N, 3, **f32), rotations=torch.empty(N, 4, **f32))
+        g = inp = None      # (allocated behind the K7 launch: the GPU idles between the loss and K7, kernel timeline of a C2 step)
         go = g_losses.to(torch.float32).contiguous()
         with torch.cuda.device(dev):
             keep2: list = []
             stream = _stream()
-            inp = _inputs_struct(N, M, means3D, opacities, sh, e, scales, rotations, e, ctx.flags)
-            sets = [_settings_struct(rs, dev, keep2) for rs in ctx.settings_list]
+            sets = _kept_settings(ctx, dev, keep2)
             mode = k7_views_mode(states[0].H, states[0].W, N) if V > 1 else 0
             if mode:
                 _join_record_clears(ctx)
@@ -956,6 +915,8 @@ class _RenderViewsLoss(torch.autograd.Function):
                                                          C.byref(st.img), ctx.colors[v].data_ptr(), ctx.targets[v].data_ptr(),
                                                          ctx.w[0], ctx.w[1], go[v:v + 1].data_ptr(), recs[k].data_ptr(),
                                                          sides.stream(v)), "gdr_render_backward_loss")
+                if g is None:
+                    g, inp = _grad_buffers(N, M, f32), _inputs_struct(N, M, means3D, opacities, sh, e, scales, rotations, e, ctx.flags)
                 r_arr = (C.c_void_p * n)(*[ctx.radii[lo + k].data_ptr() if N else None for k in range(n)])
                 rec_arr = (C.c_void_p * n)(*[recs[k].data_ptr() for k in range(n)])
                 gout = L.GdrGradOutputs(_ptr(g["means3D"]), _ptr(g["means2D"]), _ptr(g["shs"]), None,
@@ -1105,8 +1066,9 @@ def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales,
     network.py:827-838, 848-856, 964-972) join a render group: one preprocess-backward for all of them (viewgroup.py);
     everything else is one independent autograd node per call."""
     from . import viewgroup
-    if torch.is_grad_enabled():
-        viewgroup.note_forward()
+    if not torch.is_grad_enabled():     # evaluation (evaluation.py:169-193, tools/meshExtractor.py:73-106): no autograd node at all
+        return forward_raw(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings)[:4]
+    viewgroup.note_forward()
     if viewgroup.eligible(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp):
         out = viewgroup.grouped_call(viewgroup.PATH_3D, means3D, means2D, sh, opacities, scales, rotations, raster_settings)
         if out is not None:

@@ -504,8 +504,9 @@ def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales,
     surfels as earlier ones join a render group — one K9s for all of them (viewgroup.py, round 4); everything else is one
     independent autograd node per call."""
     from . import viewgroup
-    if torch.is_grad_enabled():
-        viewgroup.note_forward()
+    if not torch.is_grad_enabled():     # evaluation: no autograd node at all
+        return forward_raw(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings)[:3]
+    viewgroup.note_forward()
     if (viewgroup.eligible(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp)
             and scales.shape[-1] == 2 and viewgroup.PATH_SURFEL.supports(sh, raster_settings)):
         out = viewgroup.grouped_call(viewgroup.PATH_SURFEL, means3D, means2D, sh, opacities, scales, rotations,

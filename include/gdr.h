@@ -294,6 +294,16 @@ int gdr_render_backward_loss(const gdr_settings* s, int32_t N, const gdr_geom* g
                              const gdr_image* img, const float* color, const float* target, float w_depth, float w_alpha,
                              const float* g, float* grad_rec, void* stream);
 
+/* K6 of V <= GDR_MAX_VIEWS views of one image size in ONE launch (v14; SURVEY section 7 step 5 "grid.z = view"): the
+ * workgroups of all views in one grid (interleave != 0: the same launch-order slot of consecutive views next to each other).
+ * Every view must have finished its binning stage on `stream`'s dependencies.  loss_mode 0 = gdr_composite_forward,
+ * 1 = gdr_composite_forward_loss (losses[v] accumulated: the caller zeroes the V floats), 2 = gdr_composite_forward_lossgrad
+ * (outs[v].color receives d loss / d colour, depth / alpha are not written and may be NULL). */
+int gdr_composite_forward_views(int32_t V, const gdr_settings* s, const gdr_geom* geoms, const gdr_binning* bins,
+                                const gdr_image* imgs, const gdr_outputs* outs, int32_t loss_mode,
+                                const float* const* targets, float w_depth, float w_alpha, float go_scale, float* losses,
+                                int32_t interleave, void* stream);
+
 /* Stages 1+2 with a caller-provided binning capacity D_cap.  Synchronises once to
  * read D; returns GDR_ERR_WORKSPACE (and *num_rendered_host = required D) if
  * D > D_cap, in which case only stage 1 has run. */
@@ -350,10 +360,36 @@ int gdr_view_plan_for(int32_t N, int32_t H, int32_t W, int32_t surfel, uint64_t 
 int gdr_forward_view(const gdr_settings* s, const gdr_inputs* in, const gdr_view_plan* plan, void* workspace,
                      const gdr_view_opts* opts, const gdr_same_as* same, const gdr_outputs* out, gdr_view_state* state,
                      void* stream);
+/* The same for ALL views of one Gaussian set (the forward of the multi-view node, v14): V <= GDR_MAX_NODE_VIEWS views of one
+ * image size; K1 in launches of <= GDR_MAX_VIEWS views (inputs read once each), then every view's chain binning -> K6 on
+ * streams[v % n_streams] (streams[0] = the caller's: it is made to wait for the others before the call returns), the V
+ * duplicate counts read back with ONE pooled pinned copy after everything is enqueued.  ONE allocation for all views
+ * (gdr_views_plan_for: V x the per-view state + the packed counters).  loss_mode / targets / w_* / go_scale / losses as in
+ * gdr_composite_forward_views.  states: V structs, filled (cov3D of every view points at view 0's copy).  Returns GDR_OK, or
+ * GDR_ERR_WORKSPACE with every states[v].D set: plan again with exact_D = the largest of them and call again. */
+#define GDR_MAX_NODE_VIEWS 256
+typedef struct gdr_views_plan {
+    gdr_view_plan view;      /* the per-view plan (capacity, seg_len, deferred, have_binning) */
+    uint64_t bytes_view;     /* stride between the views' state in the allocation */
+    uint64_t bytes_shared;
+    uint64_t bytes;          /* V x bytes_view + bytes_shared */
+    int32_t V;
+    int32_t reserved;
+} gdr_views_plan;
+int gdr_views_plan_for(int32_t V, int32_t N, int32_t H, int32_t W, uint64_t exact_D, const gdr_view_opts* opts,
+                       gdr_views_plan* plan);
+int gdr_forward_views(int32_t V, const gdr_settings* s, const gdr_inputs* in, const gdr_views_plan* plan, void* workspace,
+                      const gdr_view_opts* opts, const gdr_outputs* outs, int32_t loss_mode, const float* const* targets,
+                      float w_depth, float w_alpha, float go_scale, float* losses, void* const* streams, int32_t n_streams,
+                      gdr_view_state* states);
 void gdr_view_history_reset(void);
 /* the history behind gdr_view_plan_for, per scene shape: the decaying maximum of duplicates per Gaussian (0 = none yet).
  * _set seeds or overrides it — a caller that knows its scene statistics skips the read-back of a shape's first call; the
  * tests force an overflow with a tiny value (the call then answers GDR_ERR_WORKSPACE and is repeated exactly sized). */
+/* the launch-size report words of a shape's previous call (row = view of the call, < 64): {tiles in the tile sort's long class,
+ * in its medium class, "deep forward applied", busy tiles}, 0xFFFFFFFF = nothing reported yet; set != 0 overwrites them (tests:
+ * wrong hints must only cost time) */
+int gdr_view_history_report(int32_t N, int32_t H, int32_t W, int32_t surfel, int32_t row, uint32_t* words, int32_t set);
 double gdr_view_history_get(int32_t N, int32_t H, int32_t W, int32_t surfel);
 void gdr_view_history_set(int32_t N, int32_t H, int32_t W, int32_t surfel, double duplicates_per_gaussian);
 

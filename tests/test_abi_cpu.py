@@ -195,3 +195,53 @@ def test_host_policy_helpers_without_gpu():
     small, big = lib.gdr_binning_bytes(1000), lib.gdr_binning_bytes(4_000_000)
     assert big > small and big >= 4_000_000 * (8 + 8 + 4 + 4 + 8) + 2 * (4_000_000 // 2048) * 10 * 256 * 4
 
+
+
+def test_view_plan_and_shape_history_without_gpu():
+    """gdr_view_plan_for / gdr_view_history_* (include/gdr.h, v14): sizing of the one allocation of a native forward call
+    from the per-shape history the library keeps; no device work."""
+    import ctypes as C
+    from generativedensification_amd import _lib as L
+    lib = L.load()
+    N, H, W = 50_000, 160, 208
+    lib.gdr_view_history_reset()
+    plan = L.GdrViewPlan()
+    assert lib.gdr_view_plan_for(N, H, W, 0, 0, None, C.byref(plan)) == 0
+    assert plan.have_binning == 0 and plan.deferred == 0 and plan.capacity == 0      # no history: K1 + read-back first
+    fixed = plan.bytes
+    assert fixed >= lib.gdr_geom_bytes(N) + lib.gdr_image_bytes(H, W)
+    assert lib.gdr_view_plan_for(N, H, W, 0, 123_456, None, C.byref(plan)) == 0      # exactly sized
+    assert plan.have_binning == 1 and plan.deferred == 0 and plan.capacity == 123_456 and plan.seg_len == 256
+    assert plan.bytes > fixed
+    lib.gdr_view_history_set(N, H, W, 0, 2.0)
+    assert lib.gdr_view_history_get(N, H, W, 0) == 2.0 and lib.gdr_view_history_get(N, H, W, 1) == 0.0   # (surfel: own history)
+    assert lib.gdr_view_history_get(40_000, H, W, 0) == 2.0        # same power-of-two bucket of N
+    assert lib.gdr_view_plan_for(N, H, W, 0, 0, None, C.byref(plan)) == 0
+    assert plan.deferred == 1 and plan.have_binning == 1 and plan.capacity == int(2.0 * N * 1.5) + 4096
+    opts = L.GdrViewOpts(1024, -1, -1, 0, 1, 0)                     # segment length override, radix partition (no count matrix)
+    big = plan.bytes
+    assert lib.gdr_view_plan_for(N, H, W, 0, 0, C.byref(opts), C.byref(plan)) == 0
+    assert plan.seg_len == 1024 and plan.bytes < big
+    # 800x800 with long lists everywhere: the policy raises the segment length to 512
+    lib.gdr_view_history_set(2_000_000, 800, 800, 0, 1.8)
+    assert lib.gdr_view_plan_for(2_000_000, 800, 800, 0, 0, None, C.byref(plan)) == 0 and plan.seg_len == 512
+    lib.gdr_view_history_reset()
+    assert lib.gdr_view_history_get(N, H, W, 0) == 0.0
+    assert lib.gdr_view_plan_for(-1, H, W, 0, 0, None, C.byref(plan)) == -1
+
+
+def test_debug_knobs_map_to_view_opts():
+    from generativedensification_amd import rasterizer as R
+    K = R.K
+    saved = K.SEG_LEN, K.DEEP_MAX_BUSY, K.DEEP_MIN_MEAN, K.FORCE_GLOBAL_SORT, K.FORCE_RADIX_PARTITION, K.LAUNCH_HINTS
+    try:
+        K.SEG_LEN = K.DEEP_MAX_BUSY = K.DEEP_MIN_MEAN = None
+        K.FORCE_GLOBAL_SORT = K.FORCE_RADIX_PARTITION = False
+        K.LAUNCH_HINTS = True
+        o = R._view_opts()
+        assert (o.seg_len, o.deep_max_busy, o.deep_min_mean, o.global_sort, o.radix_partition, o.no_hints) == (-1, -1, -1, 0, 0, 0)
+        K.SEG_LEN, K.DEEP_MAX_BUSY, K.DEEP_MIN_MEAN, K.FORCE_GLOBAL_SORT, K.LAUNCH_HINTS = 700, 0, 4000, True, False
+        o = R._view_opts()
+        assert (o.seg_len, o.deep_max_busy, o.deep_min_mean, o.global_sort, o.radix_partition, o.no_hints) == (512, 0, 4000, 1, 0, 1)
+    finally:
+        K.SEG_LEN, K.DEEP_MAX_BUSY, K.DEEP_MIN_MEAN, K.FORCE_GLOBAL_SORT, K.FORCE_RADIX_PARTITION, K.LAUNCH_HINTS = saved

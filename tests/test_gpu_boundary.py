@@ -188,10 +188,10 @@ def test_device_sized_binning_equals_the_read_back_and_an_overflow_repeats_the_v
     targets = make_targets(V, H, W, 5).to(dev).permute(0, 3, 1, 2).contiguous()
     if surfel:
         from generativedensification_amd.renderer_2dgs import Renderer
-        key, key1 = ("surfel",) + R.shape_key(N, H, W, V), ("surfel",) + R.shape_key(N, H, W)   # (render_img = the single-view rasterizer)
+        key = ("surfel",) + R.shape_key(N, H, W, V)       # (the surfel multi-view node keeps its history on the Python side)
     else:
         from generativedensification_amd.renderer import Renderer
-        key, key1 = R.shape_key(N, H, W, V), R.shape_key(N, H, W, 1)        # (render_img = a one-view node)
+        key = None                                        # (3DGS: every entry's history lives in the library)
     sc = scene["scales"][:, :2].contiguous() if surfel else scene["scales"]
     args = (scene["centers"], scene["shs"], scene["opacity"], sc, scene["rotations"], dev)
     if surfel:
@@ -221,8 +221,10 @@ def test_device_sized_binning_equals_the_read_back_and_an_overflow_repeats_the_v
                 R._D_HINT.clear()
                 lib.gdr_view_history_reset()
             elif hint == "small":       # capacity ~4100 entries: every view overflows and is repeated
-                R._D_HINT[key], R._D_HINT[key1] = 1e-4, 1e-4
+                if key is not None:
+                    R._D_HINT[key] = 1e-4
                 lib.gdr_view_history_set(N, H, W, int(surfel), 1e-4)
+                lib.gdr_view_history_set(N, H, W, 0, 1e-4)
         res = []
         with torch.no_grad():
             for fn in (views, fused, single, plain):
@@ -236,8 +238,8 @@ def test_device_sized_binning_equals_the_read_back_and_an_overflow_repeats_the_v
     try:
         img0, loss0, one0, pl0 = run("none")                 # no history: read-back flow
         views()
-        assert key in R._D_HINT and R._d_capacity(key, N) > R._D_HINT[key] * N > 0
-        assert lib.gdr_view_history_get(N, H, W, int(surfel)) > 1e-2      # (the library's history of the single-call shape)
+        assert key is None or (key in R._D_HINT and R._d_capacity(key, N) > R._D_HINT[key] * N > 0)
+        assert lib.gdr_view_history_get(N, H, W, int(surfel)) > 1e-2      # (the library's history of the shape)
         img1, loss1, one1, pl1 = run("history")              # device-sized calls
         img2, loss2, one2, pl2 = run("small")
         assert lib.gdr_view_history_get(N, H, W, int(surfel)) > 1e-2    # (the overflow call recorded the real count)
@@ -255,23 +257,18 @@ def test_device_sized_binning_equals_the_read_back_and_an_overflow_repeats_the_v
         if not surfel:
             sets = [Renderer(sh_degree=1).set_rasterizer(c, device=dev).raster_settings for c in cams]
             res = []
-            for hint in (None, 1e-4):
+            for hint in (None, 1e-4, "real"):
                 if hint is None:
-                    R._D_HINT.pop(key, None)
-                else:
-                    R._D_HINT[key] = hint
+                    lib.gdr_view_history_reset()
+                elif hint != "real":
+                    lib.gdr_view_history_set(N, H, W, 0, hint)
                 with torch.no_grad():
                     states = R._forward_views_impl(scene["centers"], torch.empty(0, 4, device=dev), scene["shs"],
                                                    scene["opacity"], scene["scales"], scene["rotations"], tuple(sets),
                                                    R.RAW_ALL)[4]
                 torch.cuda.synchronize()
+                assert bool(states[0].bin.d_dev) == (hint == "real")     # read-back / exact repeat / device-sized with a capacity that fits
                 res.append([st.tensors() for st in states])
-            with torch.no_grad():   # and once more with a capacity that fits
-                states = R._forward_views_impl(scene["centers"], torch.empty(0, 4, device=dev), scene["shs"],
-                                               scene["opacity"], scene["scales"], scene["rotations"], tuple(sets),
-                                               R.RAW_ALL)[4]
-            assert all(st.bin.d_dev for st in states)
-            res.append([st.tensors() for st in states])
             for other in res[1:]:
                 for a, b in zip(res[0], other):
                     assert a["num_rendered"] == b["num_rendered"] > 0
@@ -283,21 +280,29 @@ def test_device_sized_binning_equals_the_read_back_and_an_overflow_repeats_the_v
         R._D_HINT.update(saved)
 
 
+def _report(lib, N, H, W, row=0, words=None):
+    import ctypes as C
+    buf = (C.c_uint32 * 4)(*(words or (0, 0, 0, 0)))
+    assert lib.gdr_view_history_report(N, H, W, 0, row, buf, int(words is not None)) == 0
+    return [int(x) for x in buf]
+
+
 def test_launch_hints_only_size_launches():
-    """gdr_binning.stats_out / hint_* (rasterizer._launch_stats): the binning stage reports its tile classes and the
-    next call of the shape sizes the long / medium tile-sort grids and skips the deep-forward launch from that.  Wrong
-    hints (an object-like scene after hints that say "no long lists, no deep forward") must give the same sorted lists and
-    contributor counts, and the same image up to the deep forward's summation order."""
+    """gdr_binning.stats_out / hint_* (the library's per-shape history, gdr_view_history_report): the binning stage reports
+    its tile classes and the next call of the shape sizes the long / medium tile-sort grids and skips the deep-forward launch
+    from that.  Wrong hints (an object-like scene after hints that say "no long lists, no deep forward") must give the same
+    sorted lists and contributor counts, and the same image up to the deep forward's summation order."""
+    from generativedensification_amd import _lib as L
     from generativedensification_amd import rasterizer as R
     from generativedensification_amd.camera import orbit_cameras
     from generativedensification_amd.renderer import Renderer
     from generativedensification_amd.synthetic import make_scene
     dev = torch.device(DEV)
+    lib = L.load()
     V, H, W, N = 2, 256, 256, 400_000
     scene = make_scene(N, 29, sh_degree=1, sigma0=(0.004,), device=dev, layout="shell")   # long lists at the silhouette
     cams = orbit_cameras(V, W, H, device=dev)
     sets = [Renderer(sh_degree=1).set_rasterizer(c, device=dev).raster_settings for c in cams]
-    key = (torch.cuda.current_device(),) + R.shape_key(N, H, W, V)
 
     def run():
         with torch.no_grad():
@@ -307,31 +312,29 @@ def test_launch_hints_only_size_launches():
         torch.cuda.synchronize()
         return colors, [st.tensors() for st in states], [(st.bin.hint_long, st.bin.hint_medium, st.bin.hint_no_deep) for st in states]
 
-    saved = R._LAUNCH_STATS.pop(key, None), R._HINT_STATE.pop(key, None)
+    lib.gdr_view_history_reset()
     try:
-        c0, t0, h0 = run()                                   # no history: worst-case grids
-        assert all(h == (0, 0, 0) for h in h0)
-        stats = R._LAUNCH_STATS[key]
-        assert (stats >= 0).all() and int(stats[:, 0].max()) > 0, stats   # the scene does have lists > 4096 entries
+        run()                                                # first call of the shape: read-back flow, worst-case grids ...
+        c0, t0, h0 = run()                                   # ... and the reference result (hints from the first report)
+        stats = [_report(lib, N, H, W, v) for v in range(V)]
+        assert all(w != 0xFFFFFFFF for st in stats for w in st) and max(st[0] for st in stats) > 0, stats   # lists > 4096 entries exist
+        n_long = max(st[0] for st in stats)
         c1, t1, h1 = run()                                   # sized from the report: max over the views + 25 %, floors 16 / 32
-        n_long = int(stats[:, 0].max())
-        assert all(h[0] == max(16, n_long + n_long // 4 + 1) and h[1] >= 32 for h in h1)
-        stats.zero_()                                        # "no long / medium lists, no deep forward": all wrong
-        R._HINT_STATE[key] = [0, 0, 0]
+        assert all(h[0] == max(16, n_long + n_long // 4 + 1) and h[1] >= 32 for h in h1), (h1, n_long)
+        for v in range(V):                                   # "no long / medium lists, no deep forward": all wrong
+            _report(lib, N, H, W, v, (0, 0, 0, 0))
         c2, t2, h2 = run()
         # hint_long = -1: the long class (144 KB of LDS per workgroup) is not launched at all; the medium class sorts the
         # lists beyond its capacity through its global-memory bucket pass — same lists
-        assert all(h == (-1, 32, 1) for h in h2) and int(stats[:, 0].max()) > 0   # (and the report is right again)
+        assert all(h == (-1, 32, 1) for h in h2), h2
+        assert max(_report(lib, N, H, W, v)[0] for v in range(V)) > 0       # (and the report is right again)
         for cs, ts in ((c1, t1), (c2, t2)):
             for v in range(V):
                 for k in ("keys_sorted", "point_list", "ranges", "n_contrib"):
                     assert torch.equal(ts[v][k], t0[v][k]), k
                 assert float((cs[v] - c0[v]).abs().max()) < 2e-5
     finally:
-        if saved[0] is not None:
-            R._LAUNCH_STATS[key] = saved[0]
-        if saved[1] is not None:
-            R._HINT_STATE[key] = saved[1]
+        lib.gdr_view_history_reset()
 
 
 def test_deep_forward_applies_to_few_busy_tiles_with_long_lists_only():
@@ -347,11 +350,14 @@ def test_deep_forward_applies_to_few_busy_tiles_with_long_lists_only():
     cams = orbit_cameras(1, W, H, device=dev)
     sets = [Renderer(sh_degree=1).set_rasterizer(c, device=dev).raster_settings for c in cams]
 
+    from generativedensification_amd import _lib as L
+    lib = L.load()
+
     def run(N, min_mean):
         scene = make_scene(N, 31, sh_degree=1, sigma0=(0.004,), device=dev, layout="shell")
-        key = (torch.cuda.current_device(),) + R.shape_key(N, H, W, 1)
-        saved = R._LAUNCH_STATS.pop(key, None), R._HINT_STATE.pop(key, None), R.K.DEEP_MIN_MEAN
+        saved = R.K.DEEP_MIN_MEAN
         R.K.DEEP_MIN_MEAN = min_mean
+        lib.gdr_view_history_reset()
         try:
             with torch.no_grad():
                 colors, _, _, _, states, _, _ = R._forward_views_impl(scene["centers"], torch.empty(0, 4, device=dev), scene["shs"],
@@ -361,15 +367,10 @@ def test_deep_forward_applies_to_few_busy_tiles_with_long_lists_only():
             t = states[0].tensors()
             L_ = (t["ranges"][:, 1] - t["ranges"][:, 0]).long()
             busy = L_[L_ >= 64]
-            return colors[0], R._LAUNCH_STATS[key][0].tolist(), float(busy.float().mean()), int(busy.numel())
+            return colors[0], _report(lib, N, H, W), float(busy.float().mean()), int(busy.numel())
         finally:
-            R.K.DEEP_MIN_MEAN = saved[2]
-            R._LAUNCH_STATS.pop(key, None)
-            R._HINT_STATE.pop(key, None)
-            if saved[0] is not None:
-                R._LAUNCH_STATS[key] = saved[0]
-            if saved[1] is not None:
-                R._HINT_STATE[key] = saved[1]
+            R.K.DEEP_MIN_MEAN = saved
+            lib.gdr_view_history_reset()
 
     c_deep, st_deep, mean_long, busy_long = run(400_000, None)
     assert busy_long <= 768 and mean_long >= 2560, (busy_long, mean_long)    # the premise: few busy tiles, long lists
@@ -426,15 +427,17 @@ def test_history_of_a_shape_carries_over_to_a_neighbouring_gaussian_count():
         torch.cuda.synchronize()
         return colors, states
 
-    assert R.shape_key(40_000, H, W, V) == R.shape_key(N, H, W, V)
-    saved, saved_defer = dict(R._D_HINT), R.K.DEFER_D
+    from generativedensification_amd import _lib as L
+    lib = L.load()
+    saved_defer = R.K.DEFER_D
     try:
         R.K.DEFER_D = False
         c_ref, s_ref = run(N)
         R.K.DEFER_D = True
-        R._D_HINT.clear()
+        lib.gdr_view_history_reset()
         _, s0 = run(40_000)
-        assert not any(st.bin.d_dev for st in s0)            # first call of the shape: read-back
+        assert not any(st.bin.d_dev for st in s0)            # first call of the shape: read-back, then exactly sized
+        assert lib.gdr_view_history_get(N, H, W, 0) == lib.gdr_view_history_get(40_000, H, W, 0) > 0   # one bucket of N
         c1, s1 = run(N)
         assert all(st.bin.d_dev for st in s1)                # 25 % more Gaussians: device-sized from the ratio
         for v in range(V):
@@ -445,8 +448,7 @@ def test_history_of_a_shape_carries_over_to_a_neighbouring_gaussian_count():
             assert torch.equal(c_ref[v], c1[v])
     finally:
         R.K.DEFER_D = saved_defer
-        R._D_HINT.clear()
-        R._D_HINT.update(saved)
+        lib.gdr_view_history_reset()
 
 
 @pytest.mark.parametrize("surfel", [False, True])

@@ -320,6 +320,49 @@ def test_k7_of_all_views_in_one_launch_equals_per_view_launches(V):
                 assert out < U.MAX_OUTSIDE and maxn < 1e-4, (entry, mode, k, out, worst, maxn)
 
 
+@pytest.mark.parametrize("interleave", [0, 1])
+def test_k6_of_all_views_in_one_launch_reproduces_the_per_view_images(interleave):
+    """gdr_composite_forward_views (include/gdr.h, v14; SURVEY section 7 step 5 "grid.z = view"): K6 of V views in ONE launch
+    on the binning state a multi-view forward left behind — images, final T and contributor counts bit for bit those of the
+    per-view launches (same kernel, same lists; measured on MI355X the one-launch form is not faster than per-view K6 behind
+    each view's own binning chain — C4 +-0, C3 +1.3 %, C2 -1..-3 % — so the node keeps the chains)."""
+    import ctypes as C
+    from generativedensification_amd import _lib as L
+    from generativedensification_amd import rasterizer as R
+    from generativedensification_amd.camera import orbit_cameras
+    from generativedensification_amd.renderer import Renderer
+    from generativedensification_amd.synthetic import make_scene
+
+    dev = torch.device("cuda:0")
+    lib = L.load()
+    V, n, h, w = 5, 30_000, 160, 208
+    sc = make_scene(n, 79, sh_degree=2, sigma0=(0.0052, 0.00065, 0.02), device=dev)
+    cams = orbit_cameras(V, w, h, device=dev)
+    r = Renderer(sh_degree=2)
+    sets = [r.set_rasterizer(c, device=dev).raster_settings for c in cams]
+    with torch.no_grad():
+        colors, radii, depths, alphas, states, keep, _ = R._forward_views_impl(
+            sc["centers"], torch.empty(0, 4, device=dev), sc["shs"], sc["opacity"], sc["scales"], sc["rotations"], tuple(sets), R.RAW_ALL)
+        torch.cuda.synchronize()
+        ref = [(c.clone(), d.clone(), a.clone(), st.tensors()["n_contrib"].clone(), st.tensors()["final_T"].clone())
+               for c, d, a, st in zip(colors, depths, alphas, states)]
+        for st in states:     # wipe what K6 wrote
+            st.tensors()["n_contrib"].zero_()
+            st.tensors()["final_T"].zero_()
+        out = [(torch.zeros_like(c), torch.zeros_like(d), torch.zeros_like(a)) for c, d, a in zip(colors, depths, alphas)]
+        s_arr = keep[-1]
+        g_arr, b_arr, i_arr = R._view_arrays(states, 0, V, 0)
+        o_arr = (L.GdrOutputs * V)(*[L.GdrOutputs(c.data_ptr(), d.data_ptr(), a.data_ptr(), radii[v].data_ptr())
+                                     for v, (c, d, a) in enumerate(out)])
+        L.check(lib.gdr_composite_forward_views(V, s_arr, g_arr, b_arr, i_arr, o_arr, 0, None, 0.0, 0.0, 1.0, None, interleave,
+                                                R._stream()), "gdr_composite_forward_views")
+        torch.cuda.synchronize()
+    for v in range(V):
+        t = states[v].tensors()
+        for got, want in zip(out[v] + (t["n_contrib"], t["final_T"]), ref[v]):
+            assert torch.equal(got, want), v
+
+
 def test_float64_noncontiguous_inputs_and_debug_mode():
     """The boundary accepts what a caller may hand it: float64 tensors, non-contiguous views (a transposed SH block, a
     strided slice of a bigger tensor) — same result as float32 contiguous inputs, gradients come back in the callers'

@@ -63,11 +63,11 @@ def _worker(rank, world, port, n_views, q):
         assert [p.grad.data_ptr() for p in g.values()] == ptrs
         assert g["centers"].grad[0, 0].item() == float(sum(range(1, world + 1))) and float(g["shs"].grad.abs().sum()) == 0.0
         # a second Gaussian set of the SAME shapes (coarse / fine sets of equal N) must not share the first one's buffer
-        # (round-3 advisor finding), and a mixed-dtype set gets one buffer per dtype; chunked collectives (chunk = 16 bytes)
+        # (round-3 advisor finding), and a mixed-dtype set gets one buffer per dtype
         h = {k: torch.ones(5, 3, requires_grad=True) for k in ("centers", "shs")}
         h["wide"] = torch.ones(7, dtype=torch.float64, requires_grad=True)
         (h["centers"].sum() * 10.0 + h["wide"].sum() * float(rank + 1)).backward()
-        allreduce_gaussian_grads(list(h.values()), chunk_bytes=16)
+        allreduce_gaussian_grads(list(h.values()))
         assert h["centers"].grad[0, 0].item() == 10.0 * world and float(h["shs"].grad.abs().sum()) == 0.0
         assert h["wide"].grad.dtype == torch.float64 and h["wide"].grad[3].item() == float(sum(range(1, world + 1)))
         assert g["centers"].grad[0, 0].item() == float(sum(range(1, world + 1)))      # the first set's result is intact
