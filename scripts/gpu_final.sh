@@ -5,7 +5,7 @@
 # gpurun_out/final/ (copied into profiles/ afterwards).   bash scripts/gpu_final.sh r03
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 R=$PWD; O=$R/gpurun_out/final; mkdir -p $O
-TAG=${1:-r03}
+TAG=${1:-r04}
 timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?"; tail -2 $O/smoke.log
 timeout 1500 python -m pytest tests -m gpu -q -rP > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -1 $O/pytest_gpu.log
 grep -E "^\[" $O/pytest_gpu.log > $O/${TAG}_fullsize_parity.log
@@ -30,6 +30,10 @@ b c2 --workload c2
 b c3 --workload c3
 b c5 --workload c5
 b c3step --workload c3step --steps 6 --warmup 2
+b c4_fwd --forward-only
+b c2_fwd --workload c2 --forward-only
+b c3_fwd --workload c3 --forward-only
+b c5_fwd --workload c5 --forward-only
 b c4_backward_per_view --backward-per-view --unfused --no-cpu-baseline
 b c4_perview --per-view --unfused --no-cpu-baseline
 b c4_shell --layout shell --no-cpu-baseline
@@ -45,23 +49,26 @@ for wl in c4 c3 c2 c5; do
 done
 echo "--- kernel timeline of a C4 step + idle gaps"
 bash scripts/gpu_timeline.sh c4 --no-per-view-leg > /dev/null 2>&1; cp gpurun_out/timeline_c4.txt $O/${TAG}_timeline_c4.txt; head -12 $O/${TAG}_timeline_c4.txt | grep "^step"
-echo "--- the unchanged caller's loop: kernel timeline + GPU-busy fraction (C4 GPU-bound, C2 host-bound); chain starts without a profiler"
-for wl in c4 c2; do bash scripts/gpu_timeline_pv.sh $wl > /dev/null 2>&1; cp gpurun_out/timeline_pv_$wl.txt $O/${TAG}_timeline_pv_$wl.txt; grep "^step [23]" $O/${TAG}_timeline_pv_$wl.txt; done
-for wl in c4 c3 c2; do echo $wl; python scripts/chain_start_events.py $wl 2>/dev/null | tail -4; done | tee $O/${TAG}_chain_starts.txt | grep "back to back"
+echo "--- the unchanged caller's loop: kernel timeline + GPU-busy fraction (C4 GPU-bound, C2 80 % busy)"
+for wl in c4 c2 c5; do bash scripts/gpu_timeline_pv.sh $wl > /dev/null 2>&1; cp gpurun_out/timeline_pv_$wl.txt $O/${TAG}_timeline_pv_$wl.txt; grep "^step [23]" $O/${TAG}_timeline_pv_$wl.txt; done
 python scripts/host_split.py 2>/dev/null | tail -1 | tee $O/${TAG}_host_split.txt
 python scripts/host_split2.py 2>/dev/null | grep "us per call" | head -16 >> $O/${TAG}_host_split.txt
 echo "--- abs-grad entry + device top-k"
 python scripts/absgrad_bench.py 2>/dev/null | tee $O/${TAG}_absgrad.txt
 echo "--- size sweep (every frac must stay <= 1; traffic null off the recorded scene)"
 for n in 500000 2000000 8000000 32000000; do
-  timeout 900 python bench.py --n $n --steps 4 --warmup 2 --no-cpu-baseline --no-per-view-leg > $O/n$n.json 2> $O/n$n.err || { echo "N=$n FAILED"; tail -3 $O/n$n.err; continue; }
+  timeout 900 python bench.py --n $n --steps 20 --warmup 3 --no-cpu-baseline --no-per-view-leg > $O/n$n.json 2> $O/n$n.err || { echo "N=$n FAILED"; tail -3 $O/n$n.err; continue; }
   python -c "
 import json; d=json.load(open('$O/n$n.json')); r=d['roofline'] or {}
 fr=[k.get('frac',0) for k in d['kernels'].values()]+[k.get('frac_serial',0) or 0 for k in d['kernels'].values()]
 print(json.dumps(dict(n=$n, views_per_s=d['value'], ms_per_step=d['ms_per_step'], D=d['config']['num_rendered_per_view'], path_frac=r.get('path_frac'), path_frac_measured=r.get('path_frac_measured'), traffic=r.get('traffic'), max_kernel_frac=max(fr), mem_gb=d['config'].get('peak_mem_gb'))))" | tee -a $O/${TAG}_size_sweep.json
 done
-echo "--- RCCL, one rank, collectives forced"
+echo "--- RCCL, one rank, collectives forced (gradients dropped between steps = default; kept = accumulated into the packed buffer)"
 timeout 600 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-per-view-leg --force-dist --grad-allreduce 2>/dev/null | tail -1 | tee $O/${TAG}_bench_rccl_1rank.json | cut -c1-200
+timeout 600 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-per-view-leg --force-dist --grad-allreduce --keep-grads 2>/dev/null | tail -1 | tee $O/${TAG}_bench_rccl_1rank_keepgrads.json | cut -c1-200
+echo "--- 2DGS parity statistics at other absolute floors (tests/util.py assert_grads_surfel)"
+GDR_TEST_STATS=1 timeout 1200 python -m pytest tests/test_gpu_oracle_fullsize.py tests/test_gpu_surfel.py -q -rP -k "surfel" 2>&1 | grep -E "^\[|passed|failed" | cut -c1-200 > $O/${TAG}_surfel_stats.txt; tail -1 $O/${TAG}_surfel_stats.txt
+bash scripts/gpu_timeline.sh c2 --no-per-view-leg > /dev/null 2>&1; cp gpurun_out/timeline_c2.txt $O/${TAG}_timeline_c2.txt; grep "^step [45]" $O/${TAG}_timeline_c2.txt
 echo "--- 2 and 8 ranks on one GPU (gloo)"
 timeout 600 python bench.py --gpus 2 --steps 3 --warmup 1 --workload c2 --single-device --no-roofline --no-per-view-leg 2>/dev/null | tail -1 | tee $O/${TAG}_bench_2ranks_c2.json | cut -c1-260
 timeout 900 python bench.py --gpus 8 --steps 3 --warmup 1 --workload c2 --single-device --no-roofline --no-per-view-leg --no-cpu-baseline 2>/dev/null | tail -1 | tee $O/${TAG}_bench_8ranks_c2.json | cut -c1-360
