@@ -878,7 +878,8 @@ def main():
             pmc = {}
         meta = pmc.get(args.workload + "_meta", {})
         pmc_ok = (meta.get("n") == n and meta.get("layout", "cube") == args.layout and meta.get("order", "random") == args.order
-                  and meta.get("views_per_gpu") == vpg and not (args.per_view or args.backward_per_view or args.unfused))
+                  and meta.get("views_per_gpu") == vpg and meta.get("abi") == L.ABI_VERSION
+                  and not (args.per_view or args.backward_per_view or args.unfused))
         tj, vj = (pmc.get(args.workload, {}), pmc.get(args.workload + "_valu", {})) if pmc_ok else ({}, {})
 
         def pmc_name(name):   # bench kernel id -> kernel symbol in the rocprofv3 summaries
@@ -906,8 +907,27 @@ def main():
                 if pmc_name(name) in tj and name != "tile_sort_long":   # (the PMC summary merges the tile-sort classes)
                     k["traffic"] = tj[pmc_name(name)]
                 kernels[name] = k
+        # The kernels of different views run on side streams, several launches at a time: each launch then takes
+        # longer than it does alone (its event pair brackets time it shares with the other views' kernels), and the
+        # per-launch figures shrink although the work per second does not.  A short extra pass with every kernel on ONE
+        # stream gives each kernel's duration on its own.
+        if kernels and R.K.RENDER_SIDE and vpg > 1 and not (args.per_view or args.backward_per_view or args.torch_loss and surfel):
+            R.K.RENDER_SIDE = 0
+            try:
+                prof1 = profiled(step, min(args.steps, 3))
+            finally:
+                R.K.RENDER_SIDE = 1
+            for name, (ms1, cnt1) in prof1.items():
+                if cnt1 and name in kernels:
+                    a1 = 1e3 * ms1 / cnt1
+                    kernels[name]["avg_us_serial"] = round(a1, 2)
+                    if kernels[name].get("alg_bytes"):
+                        kernels[name]["frac_serial"] = round(kernels[name]["alg_bytes"] / (a1 * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
         if kernels:
-            dom = max(kernels, key=lambda k: kernels[k]["total_ms"])
+            # dominant = the largest share of the step's GPU time.  Summed event time overstates kernels that run several at
+            # a time (four concurrent K6 on four streams: 4 x 354 us of events for 4 x 138 us of work), so a kernel's share
+            # is launches x its duration ALONE where the serial pass measured it
+            dom = max(kernels, key=lambda k: kernels[k]["launches"] * kernels[k].get("avg_us_serial", kernels[k]["avg_us"]))
             avg_s = kernels[dom]["avg_us"] * 1e-6
             achieved = kernels[dom].get("alg_bytes", alg[dom]) / avg_s / 1e9
             traffic = kernels[dom].get("traffic")
@@ -953,28 +973,12 @@ def main():
                                 valu_note="SQ_INSTS_VALU x 2 cycles / (launch time x 1024 SIMDs x 2.4 GHz): fraction of the "
                                           "peak VALU issue rate; the kernel's own mix (DPP, compares, 3-source fma, exp: "
                                           "3.5-8 cycles each) averages ~3.6 cycles per instruction")
-            # The kernels of different views run on side streams, several launches at a time: each launch then takes
-            # longer than it does alone, and the per-launch figures above shrink although the work per second does not.
-            # A short extra pass with every kernel on ONE stream gives each kernel's duration on its own.
-            if R.K.RENDER_SIDE and vpg > 1 and not (args.per_view or args.backward_per_view or args.torch_loss and surfel):
-                R.K.RENDER_SIDE = 0
-                try:
-                    prof1 = profiled(step, min(args.steps, 3))
-                finally:
-                    R.K.RENDER_SIDE = 1
-                for name, (ms1, cnt1) in prof1.items():
-                    if cnt1 and name in kernels:
-                        a1 = 1e3 * ms1 / cnt1
-                        kernels[name]["avg_us_serial"] = round(a1, 2)
-                        if kernels[name].get("alg_bytes"):
-                            kernels[name]["frac_serial"] = round(kernels[name]["alg_bytes"] / (a1 * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
-                if kernels[dom].get("avg_us_serial"):
-                    avg1 = kernels[dom]["avg_us_serial"]
-                    if roofline.get("valu_insts_per_launch"):
-                        roofline["valu_issue_frac_serial"] = round(roofline["valu_insts_per_launch"] * 2 / (avg1 * 1e-6 * 1024 * 2.4e9), 4)
-                    roofline.update(avg_launch_us_serial=avg1, frac_serial=kernels[dom].get("frac_serial"),
-                                    launch_overlap=round(kernels[dom]["avg_us"] / avg1, 2))
-
+            if kernels[dom].get("avg_us_serial"):
+                avg1 = kernels[dom]["avg_us_serial"]
+                if roofline.get("valu_insts_per_launch"):
+                    roofline["valu_issue_frac_serial"] = round(roofline["valu_insts_per_launch"] * 2 / (avg1 * 1e-6 * 1024 * 2.4e9), 4)
+                roofline.update(avg_launch_us_serial=avg1, frac_serial=kernels[dom].get("frac_serial"),
+                                launch_overlap=round(kernels[dom]["avg_us"] / avg1, 2))
     note("roofline pass done")
     # ---- second headline: the UNCHANGED caller's pattern, timed in the same run ------------------------------------------
     # lightning/network.py:827-838 renders the views one `render_img` at a time (torch activations, a new settings tuple

@@ -252,6 +252,9 @@ _PROTOS = {
     "gsr_forward_view": (C.c_int, [C.POINTER(GdrSettings), C.POINTER(GsrInputs), C.POINTER(GdrViewPlan), C.c_void_p,
                                    C.POINTER(GdrViewOpts), C.POINTER(GdrSameAs), C.POINTER(GsrOutputs),
                                    C.POINTER(GdrViewState), C.c_void_p]),
+    "gsr_render_backward_views": (C.c_int, [C.c_int32, C.POINTER(GdrSettings), C.c_int32, C.POINTER(GdrGeom),
+                                            C.POINTER(GdrBinning), C.POINTER(GdrImage), C.POINTER(GsrGradInputs),
+                                            C.POINTER(C.c_void_p), C.c_int32, C.c_void_p]),
     "gsr_means2d_of_view": (C.c_int, [C.POINTER(GdrSettings), C.c_int32, C.POINTER(GdrGeom), C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_void_p]),
     "gsr_backward": (C.c_int, [C.POINTER(GdrSettings), C.POINTER(GsrInputs), C.POINTER(GdrGeom), C.POINTER(GdrBinning),

@@ -1478,6 +1478,26 @@ int gsr_render_backward(const gdr_settings* s, int32_t N, const gdr_geom* geom, 
     return debug_sync(s, "surfel_render_bwd", st);
 }
 
+int gsr_render_backward_views(int32_t V, const gdr_settings* s, int32_t N, const gdr_geom* geoms, const gdr_binning* bins,
+                              const gdr_image* imgs, const gsr_grad_inputs* gins, float* const* grad_recs,
+                              int32_t interleave, void* stream) {
+    int rc = check_bwd_views(V, s, geoms, bins, imgs, "surfel render_backward_views: NULL argument");
+    if (rc) return rc;
+    if (N <= 0) return GDR_OK;
+    if (!gins || !grad_recs) { set_error("surfel render_backward_views: NULL argument", hipSuccess); return GDR_ERR_INVALID_ARG; }
+    hipStream_t st = (hipStream_t)stream;
+    for (int v = 0; v < V; ++v) {
+        if (!gins[v].dL_dcolor || !grad_recs[v]) { set_error("surfel render_backward_views: NULL view buffer", hipSuccess); return GDR_ERR_INVALID_ARG; }
+        if (!bins[v].grad_rec_cleared) {
+            hipError_t e = hipMemsetAsync(grad_recs[v], 0, (size_t)N * GSR_GRAD_FLOATS * sizeof(float), st);
+            if (e != hipSuccess) return hip_fail("memset gradient records", e);
+        }
+    }
+    hipError_t e = launch_surfel_render_bwd_views(V, s, geoms, bins, imgs, gins, grad_recs, interleave, st);
+    if (e != hipSuccess) return hip_fail("surfel_render_bwd_views", e);
+    return debug_sync(&s[0], "surfel_render_bwd_views", st);
+}
+
 int gsr_means2d_of_view(const gdr_settings* s, int32_t N, const gdr_geom* geom, const int32_t* radii,
                         const float* grad_rec, float* dL_dmean2D, void* stream) {
     if (N <= 0) return GDR_OK;

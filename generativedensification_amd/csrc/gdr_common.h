@@ -179,6 +179,9 @@ hipError_t launch_surfel_render_bwd(const gdr_settings* s, const gdr_geom* g, co
                                     const gdr_image* img, const gsr_grad_inputs* gi, float* grad_rec,
                                     hipStream_t st);
 
+hipError_t launch_surfel_render_bwd_views(int V, const gdr_settings* s, const gdr_geom* g, const gdr_binning* bin,
+                                          const gdr_image* img, const gsr_grad_inputs* gi, float* const* grad_recs, int interleave,
+                                          hipStream_t st);
 hipError_t launch_surfel_means2d_view(int N, const gdr_settings* s, const gdr_geom* g, const int32_t* radii,
                                       const float* grad_rec, float* out, hipStream_t st);
 

@@ -17,6 +17,8 @@
 // reached 578 us and was dropped for it).
 #include <stdlib.h>
 
+#include <string.h>
+
 #include "gdr_common.h"
 #include "render_common.h"
 #include "../../include/gsr.h"
@@ -304,28 +306,56 @@ __global__ __launch_bounds__(GDR_BLOCK) void surfel_render_fwd_kernel(
 // ---------------------------------------------------------------------------------
 // K7s.  grad_rec: (N,32) floats, pre-zeroed by the launcher; layout in include/gsr.h.
 // ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(GDR_BLOCK) void surfel_render_bwd_kernel(
-    const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, const uint32_t* __restrict__ tile_order,
-    int W, int H, int gx, int ntiles, const float* __restrict__ bg, const float4* __restrict__ rec,
-    const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
-    const float* __restrict__ dL_dothers, float* __restrict__ grad_rec, const uint32_t* __restrict__ seg_base,
-    const float* __restrict__ seg_state, const uint2* __restrict__ seg_extra, const uint32_t* __restrict__ seg_count,
-    int seg_rounds, int n_extra) {
+// Everything K7s touches of ONE view; the kernel takes a table of V <= GDR_MAX_VIEWS of them (round 4, as render.hip's BwdViews:
+// the workgroups of all views of a node in one grid, interleaved or view after view).
+struct SBwdView {
+    const uint2* ranges; const uint32_t* point_list; const uint32_t* tile_order;
+    const float* bg; const float4* rec; const float* final_T; const uint32_t* n_contrib;
+    const float* dL_dpix; const float* dL_dothers; float* grad_rec;
+    const uint32_t* seg_base; const float* seg_state; const uint2* seg_extra; const uint32_t* seg_count;
+    int seg_rounds, n_extra;
+};
+struct SBwdViews { SBwdView v[GDR_MAX_VIEWS]; };
+
+__global__ __launch_bounds__(GDR_BLOCK) void surfel_render_bwd_kernel(const SBwdViews vs, int V, int interleave, int n_extra_max,
+                                                                      int W, int H, int gx, int ntiles) {
     __shared__ SurfelLds lds;
     __shared__ RowLists rlists;
     __shared__ uint32_t s_id[GDR_BLOCK + 1];
 
-    // workgroups [0, n_extra): one segment of a cut list each; [n_extra, n_extra + ntiles): one tile each — its whole
-    // list, or the last segment of a cut list (same scheme as render_bwd_kernel in render.hip)
+    uint32_t view = 0, slot = blockIdx.x;      // (view, slot): as render_bwd_kernel in render.hip
+    if (V > 1) {
+        const uint32_t per = (uint32_t)(ntiles + n_extra_max);
+        if (interleave) { view = blockIdx.x % (uint32_t)V; slot = blockIdx.x / (uint32_t)V; }
+        else { view = blockIdx.x / per; slot = blockIdx.x - view * per; }
+    }
+    const SBwdView& bv = vs.v[view];
+    const uint2* __restrict__ ranges = bv.ranges;
+    const uint32_t* __restrict__ point_list = bv.point_list;
+    const uint32_t* __restrict__ tile_order = bv.tile_order;
+    const float* __restrict__ bg = bv.bg;
+    const float4* __restrict__ rec = bv.rec;
+    const float* __restrict__ final_T = bv.final_T;
+    const uint32_t* __restrict__ n_contrib = bv.n_contrib;
+    const float* __restrict__ dL_dpix = bv.dL_dpix;
+    const float* __restrict__ dL_dothers = bv.dL_dothers;
+    float* __restrict__ grad_rec = bv.grad_rec;
+    const uint32_t* __restrict__ seg_base = bv.seg_base;
+    const float* __restrict__ seg_state = bv.seg_state;
+    const uint2* __restrict__ seg_extra = bv.seg_extra;
+    const uint32_t* __restrict__ seg_count = bv.seg_count;
+    const int seg_rounds = bv.seg_rounds;
+    // per view: slots [0, n_extra_max): one segment of a cut list each; [n_extra_max, n_extra_max + ntiles): one tile each —
+    // its whole list, or the last segment of a cut list (same scheme as render_bwd_kernel in render.hip)
     uint32_t tile;
     int seg = -1;
-    if ((int)blockIdx.x < n_extra) {
-        if (blockIdx.x >= min(seg_count[0], (uint32_t)n_extra)) return;
-        const uint2 e = seg_extra[blockIdx.x];
+    if ((int)slot < n_extra_max) {
+        if (slot >= min(seg_count ? seg_count[0] : 0u, (uint32_t)bv.n_extra)) return;
+        const uint2 e = seg_extra[slot];
         tile = e.x;
         seg = (int)e.y;
     } else {
-        const uint32_t b = blockIdx.x - (uint32_t)n_extra;
+        const uint32_t b = slot - (uint32_t)n_extra_max;
         tile = tile_order ? tile_order[b] : xcd_remap(b, (uint32_t)ntiles);
     }
     const int tx = (int)(tile % (uint32_t)gx), ty = (int)(tile / (uint32_t)gx);
@@ -561,16 +591,36 @@ hipError_t launch_surfel_means2d_view(int N, const gdr_settings* s, const gdr_ge
     return hipGetLastError();
 }
 
+// K7s of V <= GDR_MAX_VIEWS views of one image size in ONE launch (gsr_render_backward_views); V = 1: the single-view entry
+hipError_t launch_surfel_render_bwd_views(int V, const gdr_settings* s, const gdr_geom* g, const gdr_binning* bin,
+                                          const gdr_image* img, const gsr_grad_inputs* gi, float* const* grad_recs, int interleave,
+                                          hipStream_t st) {
+    const int W = s[0].image_width, H = s[0].image_height;
+    const int gx = tile_grid_x(W), gy = tile_grid_y(H);
+    const int ntiles = gx * gy;
+    SBwdViews vs;
+    memset(&vs, 0, sizeof(vs));
+    int n_extra_max = 0;
+    for (int v = 0; v < V; ++v) {
+        SBwdView& b = vs.v[v];
+        b.ranges = (const uint2*)img[v].ranges; b.point_list = bin[v].values[bin[v].sorted]; b.tile_order = img[v].tile_order;
+        b.bg = s[v].bg; b.rec = (const float4*)g[v].rec; b.final_T = img[v].final_T; b.n_contrib = img[v].n_contrib;
+        b.dL_dpix = gi[v].dL_dcolor; b.dL_dothers = gi[v].dL_dallmap; b.grad_rec = grad_recs[v];
+        b.seg_rounds = seg_rounds_of(&bin[v], &img[v]);
+        b.n_extra = b.seg_rounds ? bin[v].seg_cap : 0;
+        b.seg_base = img[v].seg_base; b.seg_state = (const float*)bin[v].seg_state;
+        b.seg_extra = (const uint2*)bin[v].seg_extra; b.seg_count = bin[v].seg_count;
+        n_extra_max = b.n_extra > n_extra_max ? b.n_extra : n_extra_max;
+    }
+    GDR_LAUNCH(GDR_K_RENDER_BWD, surfel_render_bwd_kernel, dim3((unsigned)V * (unsigned)(ntiles + n_extra_max)), dim3(GDR_BLOCK), st,
+               vs, V, interleave, n_extra_max, W, H, gx, ntiles);
+    return hipGetLastError();
+}
+
 hipError_t launch_surfel_render_bwd(const gdr_settings* s, const gdr_geom* g, const gdr_binning* bin,
                                     const gdr_image* img, const gsr_grad_inputs* gi, float* grad_rec,
                                     hipStream_t st) {
-    const int W = s->image_width, H = s->image_height;
-    const int gx = tile_grid_x(W), gy = tile_grid_y(H);
-    const int ntiles = gx * gy;
-    GDR_LAUNCH(GDR_K_RENDER_BWD, surfel_render_bwd_kernel, GDR_BWD_GRID(bin, img, ntiles), dim3(GDR_BLOCK), st, (const uint2*)img->ranges,
-               bin->values[bin->sorted], img->tile_order, W, H, gx, ntiles, s->bg, (const float4*)g->rec, img->final_T,
-               img->n_contrib, gi->dL_dcolor, gi->dL_dallmap, grad_rec, GDR_SEG_BWD_ARGS(bin, img));
-    return hipGetLastError();
+    return launch_surfel_render_bwd_views(1, s, g, bin, img, gi, &grad_rec, 0, st);
 }
 
 }  // namespace gdr

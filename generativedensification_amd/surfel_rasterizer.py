@@ -336,15 +336,28 @@ class _RenderSurfelViews(torch.autograd.Function):
                     ga = None if g[V + v] is None else _f32(g[V + v], dev)
                     keep2 += [gc, ga]
                     gins.append(L.GsrGradInputs(gc.data_ptr(), _ptr(ga)))
-                sides = _R._SideViews(dev, V, ctx.states[0].H, ctx.states[0].W)
-                for lo, n in sides.groups():   # K7s per view, K9s per group behind its views' K7s (rasterizer._SideViews)
+                # K7s of the views: ONE launch per <= 8 views on the caller's stream (round 4, as the 3DGS node: K.K7_VIEWS), or
+                # one launch per view on side streams (mode 0); K9s per group behind its views' K7s
+                mode = _R.k7_views_mode(ctx.states[0].H, ctx.states[0].W, N) if V > 1 else 0
+                if mode:
+                    _R._join_record_clears(ctx)
+                sides = _R._SideViews(dev, 1 if mode else V, ctx.states[0].H, ctx.states[0].W)
+                for lo in range(0, V, L.GDR_MAX_VIEWS):
+                    n = min(L.GDR_MAX_VIEWS, V - lo)
                     recs, cleared = _R._take_records(ctx, lo, n, N, L.GSR_GRAD_FLOATS, dev)
                     s_arr = (L.GdrSettings * n)(*sets[lo:lo + n])
-                    g_arr = (L.GdrGeom * n)()
+                    g_arr, b_arr, i_arr = (L.GdrGeom * n)(), (L.GdrBinning * n)(), (L.GdrImage * n)()
                     for k in range(n):
                         st = ctx.states[lo + k]
                         st.bin.grad_rec_cleared = cleared
-                        g_arr[k] = st.geom
+                        g_arr[k], b_arr[k], i_arr[k] = st.geom, st.bin, st.img
+                    if mode:
+                        gin_arr = (L.GsrGradInputs * n)(*gins[lo:lo + n])
+                        rec_ptrs = (C.c_void_p * n)(*[recs[k].data_ptr() for k in range(n)])
+                        L.check(lib.gsr_render_backward_views(n, s_arr, N, g_arr, b_arr, i_arr, gin_arr, rec_ptrs, int(mode == 1),
+                                                              stream), "gsr_render_backward_views")
+                    for k in range(0 if mode else n):
+                        st = ctx.states[lo + k]
                         L.check(lib.gsr_render_backward(C.byref(s_arr[k]), N, C.byref(g_arr[k]), C.byref(st.bin),
                                                         C.byref(st.img), C.byref(gins[lo + k]), recs[k].data_ptr(),
                                                         sides.stream(lo + k)), "gsr_render_backward")
@@ -435,6 +448,9 @@ class _RenderSurfelViewsLoss(torch.autograd.Function):
             keep2: list = []
             inp = _inputs_struct(N, M, means3D, opacities, sh, e, scales, rotations, e, flags)
             sets = [_settings_struct(rs, dev, keep2) for rs in ctx.settings_list]
+            # the loss-backward kernels of the views run on side streams (they overlap each other); K7s of the views then
+            # in ONE launch per <= 8 views on the caller's stream behind them (round 4; mode 0: per view on the side streams)
+            mode = _R.k7_views_mode(H, W, N) if V > 1 else 0
             sides = _R._SideViews(dev, V, H, W)  # after every torch-side preparation
             for lo, n in sides.groups():
                 recs, cleared = _R._take_records(ctx, lo, n, N, L.GSR_GRAD_FLOATS, dev)
@@ -442,21 +458,28 @@ class _RenderSurfelViewsLoss(torch.autograd.Function):
                 das = [torch.empty(7, H, W, **f32) for _ in range(n)]
                 scr = [torch.empty(9, H, W, **f32) for _ in range(n)]
                 s_arr = (L.GdrSettings * n)(*sets[lo:lo + n])
-                g_arr = (L.GdrGeom * n)()
+                g_arr, b_arr, i_arr = (L.GdrGeom * n)(), (L.GdrBinning * n)(), (L.GdrImage * n)()
+                gin_arr = (L.GsrGradInputs * n)()
                 for k in range(n):
                     v = lo + k
                     st = ctx.states[v]
                     st.bin.grad_rec_cleared = cleared
-                    g_arr[k] = st.geom
+                    g_arr[k], b_arr[k], i_arr[k] = st.geom, st.bin, st.img
                     sv = sides.stream(v)
                     L.check(lib.gsr_view_loss_backward(colors[v].data_ptr(), allmaps[v].data_ptr(), rays[v].data_ptr(),
                                                        views[v].data_ptr(), targets[v].data_ptr(), H, W, *wts,
                                                        go[v:v + 1].data_ptr(), scr[k].data_ptr(), dcs[k].data_ptr(),
                                                        das[k].data_ptr(), sv), "gsr_view_loss_backward")
-                    gin = L.GsrGradInputs(dcs[k].data_ptr(), das[k].data_ptr())
-                    L.check(lib.gsr_render_backward(C.byref(s_arr[k]), N, C.byref(g_arr[k]), C.byref(st.bin),
-                                                    C.byref(st.img), C.byref(gin), recs[k].data_ptr(), sv),
-                            "gsr_render_backward")
+                    gin_arr[k] = L.GsrGradInputs(dcs[k].data_ptr(), das[k].data_ptr())
+                    if not mode:
+                        L.check(lib.gsr_render_backward(C.byref(s_arr[k]), N, C.byref(g_arr[k]), C.byref(st.bin),
+                                                        C.byref(st.img), C.byref(gin_arr[k]), recs[k].data_ptr(), sv),
+                                "gsr_render_backward")
+                if mode:   # (k9_stream: the caller's stream, made to wait for the side streams — the early record clears
+                    # queued there before the loss kernels included)
+                    rec_ptrs = (C.c_void_p * n)(*[recs[k].data_ptr() for k in range(n)])
+                    L.check(lib.gsr_render_backward_views(n, s_arr, N, g_arr, b_arr, i_arr, gin_arr, rec_ptrs, int(mode == 1),
+                                                          sides.k9_stream(lo, n)), "gsr_render_backward_views")
                 r_arr = (C.c_void_p * n)(*[ctx.radii[lo + k].data_ptr() if N else None for k in range(n)])
                 rec_arr = (C.c_void_p * n)(*[recs[k].data_ptr() for k in range(n)])
                 gout = L.GsrGradOutputs(_ptr(out["means3D"]), _ptr(out["means2D"]), _ptr(out["shs"]), None,

@@ -96,6 +96,11 @@ int gsr_composite_forward(const gdr_settings* s, const gdr_geom* geom, const gdr
 int gsr_forward(const gdr_settings* s, const gsr_inputs* in, const gdr_geom* geom, gdr_binning* bin,
                 const gdr_image* img, uint64_t D_cap, const gsr_outputs* out, uint32_t* num_rendered_host,
                 void* stream);
+/* K7s of V <= GDR_MAX_VIEWS views of one image size in ONE launch (v14; see gdr_render_backward_views): every view writes its
+ * own N*GSR_GRAD_FLOATS record (cleared here unless bins[v].grad_rec_cleared). */
+int gsr_render_backward_views(int32_t V, const gdr_settings* s, int32_t N, const gdr_geom* geoms, const gdr_binning* bins,
+                              const gdr_image* imgs, const gsr_grad_inputs* gins, float* const* grad_recs,
+                              int32_t interleave, void* stream);
 /* The (N,4) means2D gradient of ONE view from its K7s record (v14): columns 0-1 = dL/dTu.z, dL/dTv.z x depth x W/2 | H/2
  * (the densification signal K9s returns summed over the views), columns 2-3 its per-pixel-|.| twin; zero where radii <= 0.
  * For callers that give every view its own means2D carrier (/root/reference/lightning/renderer_2dgs.py:209-222) while one

@@ -442,6 +442,58 @@ def test_bench_step_at_c4_size_vs_oracle(oracle_built):
     _assert_grads(g_hip2, g64, g32, list(g32), "c4 bench step, unchanged caller", maxnorm=3e-3, max_outside=3e-4)
 
 
+def test_ten_views_at_c2_size_chunked_launches_vs_oracle(oracle_built):
+    """V = 10 > GDR_MAX_VIEWS at a BASELINE size (C2: 200 k Gaussians, 800x800, SH 3; round-3 verdict: the <= 8-views-per-
+    launch chunking with the accumulate flag was only tested on small scenes): the fused node (K1 in two launches, K7 of the
+    views in two launches, K8+K9 in two launches, the second accumulating) and the unchanged caller's loop (one render group
+    of ten calls: the hub's K8+K9 in two launches) against the oracle run through the reference adaptor's op sequence."""
+    from generativedensification_amd import viewgroup as VG
+    from generativedensification_amd.camera import orbit_cameras
+    from generativedensification_amd.renderer import Renderer
+    from generativedensification_amd.synthetic import make_scene, make_targets, view_loss
+    if (os.cpu_count() or 1) < 16:
+        pytest.skip("twenty oracle passes at 800x800 need a many-core host")
+    dev = torch.device("cuda:0")
+    N, H, W, deg, V = 200_000, 800, 800, 3, 10
+    sc = make_scene(N, 1, sh_degree=deg, sigma0=(0.0052, 0.00065))
+    cams = orbit_cameras(V, W, H)
+    tg = make_targets(V, H, W, 1)
+    three = ([1.0, 1.0, 1.0], [0.5, 0.5, 0.5], [0.0, 0.0, 0.0])
+    bgs = [torch.tensor(three[j % 3]) for j in range(V)]
+    loss_fn = lambda outs, dt: torch.stack([view_loss(o, tg[j].to(dt)) for j, o in enumerate(outs)])
+    l32, g32, _ = _oracle_views(sc, cams, bgs, loss_fn, "f32", H, W, deg, f32_threads=THREADS)
+    l64, g64, _ = _oracle_views(sc, cams, bgs, loss_fn, "f64", H, W, deg)
+    cams_d, tg_d = _cams_to(cams, dev), tg.to(dev)
+    leaves = {k: v.to(dev).clone().requires_grad_(True) for k, v in sc.items()}
+    ssp = torch.zeros(N, 4, device=dev, requires_grad=True)
+    r = Renderer(sh_degree=deg)
+    lv = r.render_views_loss(cams_d, [b.to(dev) for b in bgs], tg.permute(0, 3, 1, 2).contiguous().to(dev), leaves["centers"],
+                             leaves["shs"], leaves["opacity"], leaves["scales"], leaves["rotations"], dev, screenspace_points=ssp)
+    np.testing.assert_allclose(lv.detach().cpu().numpy(), l32, rtol=2e-5)
+    grads = torch.autograd.grad(lv.sum(), list(leaves.values()) + [ssp])
+    g_hip = {k: g.cpu().numpy() for k, g in zip(list(leaves) + ["ssp"], grads)}
+    _assert_grads(g_hip, g64, g32, list(g32), "c2 ten views, fused", maxnorm=3e-3, max_outside=3e-4)
+    VG._solo_passes = 0
+    r2 = Renderer(sh_degree=deg, fused=False)
+    leaves2 = {k: v.to(dev).clone().requires_grad_(True) for k, v in sc.items()}
+    losses2, carriers = [], []
+    for j, cam in enumerate(cams_d):
+        r2.set_bg_color(bgs[j].to(dev))
+        ssp_j = torch.zeros(N, 4, device=dev, requires_grad=True)
+        out = r2.render_img(cam, None, leaves2["centers"], leaves2["shs"], leaves2["opacity"], leaves2["scales"],
+                            leaves2["rotations"], dev, screenspace_points=ssp_j)
+        losses2.append(view_loss(out, tg_d[j]))
+        carriers.append(ssp_j)
+    lv2 = torch.stack(losses2)
+    live = [g() for g in VG._GROUPS.values()]
+    assert any(g is not None and g.n_views == V for g in live), "the ten calls did not form one render group"
+    np.testing.assert_allclose(lv2.detach().cpu().numpy(), l32, rtol=2e-5)
+    grads2 = torch.autograd.grad(lv2.sum(), list(leaves2.values()) + carriers)
+    g_hip2 = {k: g.cpu().numpy() for k, g in zip(list(leaves2), grads2[:len(leaves2)])}
+    g_hip2["ssp"] = sum(g.cpu().numpy() for g in grads2[len(leaves2):])
+    _assert_grads(g_hip2, g64, g32, list(g32), "c2 ten views, unchanged caller", maxnorm=3e-3, max_outside=3e-4)
+
+
 def test_screenspace_absgrad_and_topk_vs_oracle(oracle_built):
     """SURVEY §8f-2 (network.py:843-893): MSE over 4 views differentiated w.r.t. the (N,4) carrier only, then the
     top-k of ||grad[:, 2:4]||.  Reference = sum over the views of the f64 oracle's mean2D gradients."""
@@ -534,4 +586,32 @@ def test_surfel_render_views_backward_vs_oracle(oracle_built, size):
     # is within 1.25 x of the f32 oracle's own distance from float64 since the intersection runs in the oracle's order,
     # round 4: measured ratio 1.00 at both sizes, profiles/r04_surfel_stats.txt)
     U.assert_grads_surfel(g_hip, g64, g32, list(g32), "surfel render_views " + size, worst_factor=1.25,
+                          max_outside=U.SURFEL_RAW_MAX_OUTSIDE, atol_rel=U.SURFEL_RAW_ATOL_REL)
+    # ... and the same views through the UNCHANGED caller's loop of renderer_2dgs.py:224-234 — torch activations, one
+    # `diff_surfel_rasterization.GaussianRasterizer` call per view, one backward: the calls form a render group (round 4), one
+    # K9s for all of them; activated inputs, so the single-call bar (3e-6 floor, 1e-4 of the elements) applies
+    import diff_surfel_rasterization as DS
+    from generativedensification_amd import viewgroup as VG
+    VG._solo_passes = 0
+    leaves2 = {k: v.to(dev).clone().requires_grad_(True) for k, v in sc.items()}
+    ssp2 = [torch.zeros(n, 4, device=dev, requires_grad=True) for _ in range(V)]
+    total2 = 0
+    for v, cam in enumerate(cams_d):
+        rs = DS.GaussianRasterizationSettings(
+            image_height=h, image_width=w, tanfovx=math.tan(0.375), tanfovy=math.tan(0.375), bg=torch.ones(3, device=dev),
+            scale_modifier=1.0, viewmatrix=cam.world_view_transform, projmatrix=cam.full_proj_transform, sh_degree=deg,
+            campos=cam.camera_center, prefiltered=False, debug=False)
+        color, radii, allmap = DS.GaussianRasterizer(rs)(
+            means3D=leaves2["centers"], means2D=ssp2[v], shs=leaves2["shs"], opacities=torch.sigmoid(leaves2["opacity"]),
+            scales=torch.exp(leaves2["scales"]), rotations=torch.nn.functional.normalize(leaves2["rotations"]))
+        total2 = total2 + (color * gc[v].to(dev)).sum() + (allmap * ga[v].to(dev)).sum()
+    live = [g_() for g_ in VG._GROUPS.values()]
+    assert any(g_ is not None and g_.path.name == "surfel" and g_.n_views == V for g_ in live), "no surfel render group formed"
+    grads2 = torch.autograd.grad(total2, list(leaves2.values()) + ssp2)
+    g_grp = {k: x.cpu().numpy() for k, x in zip(list(leaves2), grads2[:len(leaves2)])}
+    g_grp["ssp"] = sum(x.cpu().numpy() for x in grads2[len(leaves2):])       # (the oracle's one carrier = the sum over the views)
+    # (sums over the V views of per-view gradients of mixed sign — the opacity logits' above all — in another order than the
+    # oracle's autograd adds them: the multi-view bars, as for the fused node above; measured at C5: <= 1.2e-4 outside at the
+    # 3e-6 floor, <= 8e-5 at 1e-5)
+    U.assert_grads_surfel(g_grp, g64, g32, list(g32), "surfel group " + size, worst_factor=1.25,
                           max_outside=U.SURFEL_RAW_MAX_OUTSIDE, atol_rel=U.SURFEL_RAW_ATOL_REL)

@@ -419,6 +419,53 @@ def test_surfel_multiview_node_and_fused_loss_match_the_per_view_sequence(V):
         assert g["ssp"].shape == (n, 4) and (g["ssp"][:, 2:] >= 0).all()
 
 
+@pytest.mark.parametrize("V", [4, 9])
+def test_k7s_of_all_views_in_one_launch_equals_per_view_launches(V):
+    """gsr_render_backward_views (round 4: K7s of the views of a surfel node in ONE launch, interleaved — mode 1 — or view after
+    view — mode 2) against one K7s launch per view on side streams (mode 0), for render_views (torch loss) and for
+    render_views_loss (the loss-backward kernels of the views on side streams in front of the joint launch): same kernel, same
+    records — the gradients differ by the order of the fp32 atomics only.  V = 9 > GDR_MAX_VIEWS: two launches."""
+    from generativedensification_amd import rasterizer as R
+    from generativedensification_amd.camera import build_rays, orbit_cameras
+    from generativedensification_amd.renderer_2dgs import Renderer
+    from generativedensification_amd.synthetic import make_scene, make_targets, surfel_loss
+
+    dev = torch.device("cuda:0")
+    n, h, w = 20_000, 144, 176
+    sc = make_scene(n, 78, sh_degree=3, sigma0=(0.0052, 0.02))
+    sc["scales"] = sc["scales"][:, :2].contiguous()
+    cams = orbit_cameras(V, w, h, device=dev)
+    rays = [build_rays(torch.inverse(c.world_view_transform.T.cpu()), 0.75, 0.75, h, w).to(dev) for c in cams]
+    tg = make_targets(V, h, w, 78).to(dev)
+    tg_chw = tg.permute(0, 3, 1, 2).contiguous()
+    wts = torch.linspace(0.5, 2.0, V, device=dev)
+    r = Renderer(sh_degree=3)
+
+    def run(mode, entry):
+        prev, R.K.K7_VIEWS = R.K.K7_VIEWS, mode
+        try:
+            leaves = {k: v.to(dev).clone().requires_grad_(True) for k, v in sc.items()}
+            ssp = torch.zeros(n, 4, device=dev, requires_grad=True)
+            args = (leaves["centers"], leaves["shs"], leaves["opacity"], leaves["scales"], leaves["rotations"], dev)
+            if entry == "loss":
+                lv = r.render_views_loss(cams, rays, None, tg_chw, *args, screenspace_points=ssp)
+            else:
+                outs = r.render_views(cams, rays, None, *args, screenspace_points=ssp)
+                lv = torch.stack([surfel_loss(o, tg[j]) for j, o in enumerate(outs)])
+            grads = torch.autograd.grad((lv * wts).sum(), list(leaves.values()) + [ssp])
+            return {k: g_.cpu().numpy() for k, g_ in zip(list(leaves) + ["ssp"], grads)}
+        finally:
+            R.K.K7_VIEWS = prev
+
+    for entry in ("views", "loss"):
+        ref = run(0, entry)
+        for mode in (1, 2):
+            got = run(mode, entry)
+            for k in ref:
+                out, worst, maxn = U.elem_stats(got[k], ref[k], 1e-4, U.SURFEL_ATOL_REL)
+                assert out < U.MAX_OUTSIDE and maxn < 2e-4, (entry, mode, k, out, worst, maxn)
+
+
 @pytest.mark.parametrize("kind,N", [("uniform", 50_000), ("clustered", 30_000), ("plane", 20_000), ("tiny", 5), ("three", 3)])
 def test_simple_knn_distcuda2_matches_brute_force(oracle_built, kind, N):
     """simple_knn._C.distCUDA2 (HIP grid search, csrc/knn.hip) == the brute-force oracle: exact neighbours, fp32
