@@ -743,9 +743,10 @@ def _forward_views_impl(means3D, means2D, sh, opacities, scales, rotations, sett
             L.check(lib.gdr_views_plan_for(V, N, H, W, exact, C.byref(opts), C.byref(plan)), "gdr_views_plan_for")
             if not K.DEFER_D and not exact:     # upstream's flow: the counts are read back before anything is sized
                 plan.view.have_binning = 0
+            # (no record_stream for the side streams: the call makes the caller's stream wait for every one of them before it
+            # returns, and the backward's streams start from the caller's — every use of the block is ordered before
+            # anything the caller's stream does later, which is all the caching allocator needs)
             ws = torch.empty(max(int(plan.bytes), 256), dtype=torch.uint8, device=dev)
-            for fs in fstreams[1:]:
-                ws.record_stream(fs)
             if mode_ and exact:
                 ls_.zero_()          # (a repeated call accumulates its losses again)
             rc = lib.gdr_forward_views(V, s_arr, C.byref(inp), C.byref(plan), C.c_void_p(ws.data_ptr()), C.byref(opts), o_arr,
