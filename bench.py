@@ -43,6 +43,7 @@ import torch
 import torch.distributed as dist
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s achievable
+ATOMIC_PEAK_LINES = 21.0e9   # float-atomic 64-byte record lines / s the device sustains (measured: scripts/atomic_probe.hip)
 
 WORKLOADS = {
     "c4": dict(n=2_000_000, sigma0=(0.00065,), seed=3, views_per_gpu=4, h=800, w=800, deg=3,
@@ -881,6 +882,7 @@ def main():
                   and meta.get("views_per_gpu") == vpg and meta.get("abi") == L.ABI_VERSION
                   and not (args.per_view or args.backward_per_view or args.unfused))
         tj, vj = (pmc.get(args.workload, {}), pmc.get(args.workload + "_valu", {})) if pmc_ok else ({}, {})
+        aj = pmc.get(args.workload + "_atomic", {}) if pmc_ok else {}
 
         def pmc_name(name):   # bench kernel id -> kernel symbol in the rocprofv3 summaries
             alias = {"duplicate_with_keys": "duplicate", "tile_ranges": "ranges", "tile_sort_long": "tile_sort"}
@@ -973,10 +975,20 @@ def main():
                                 valu_note="SQ_INSTS_VALU x 2 cycles / (launch time x 1024 SIMDs x 2.4 GHz): fraction of the "
                                           "peak VALU issue rate; the kernel's own mix (DPP, compares, 3-source fma, exp: "
                                           "3.5-8 cycles each) averages ~3.6 cycles per instruction")
+            ia = aj.get(pmc_name(dom))
+            if ia:      # K7: one float-atomic record line per (entry, 4x4 block) hit; they execute outside the L2s
+                roofline.update(atomic_lines_per_launch=int(ia), atomic_peak_lines_per_s=ATOMIC_PEAK_LINES,
+                                atomic_frac=round(ia / (kernels[dom]["avg_us"] * 1e-6) / ATOMIC_PEAK_LINES, 4),
+                                atomic_note="TCC_EA0_ATOMIC per launch (rocprofv3 --pmc; == TCC_ATOMIC: every float atomic "
+                                            "leaves the L2) / launch time, against the device's measured rate of 64-byte "
+                                            "atomic lines (scripts/atomic_probe.hip, profiles/r04_atomic_probe.txt: 20.9-21.0 G/s "
+                                            "whatever the lanes per line; hidden behind VALU work when there is enough of it)")
             if kernels[dom].get("avg_us_serial"):
                 avg1 = kernels[dom]["avg_us_serial"]
                 if roofline.get("valu_insts_per_launch"):
                     roofline["valu_issue_frac_serial"] = round(roofline["valu_insts_per_launch"] * 2 / (avg1 * 1e-6 * 1024 * 2.4e9), 4)
+                if roofline.get("atomic_lines_per_launch"):
+                    roofline["atomic_frac_serial"] = round(roofline["atomic_lines_per_launch"] / (avg1 * 1e-6) / ATOMIC_PEAK_LINES, 4)
                 roofline.update(avg_launch_us_serial=avg1, frac_serial=kernels[dom].get("frac_serial"),
                                 launch_overlap=round(kernels[dom]["avg_us"] / avg1, 2))
     note("roofline pass done")

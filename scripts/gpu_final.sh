@@ -9,6 +9,10 @@ TAG=${1:-r04}
 timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?"; tail -2 $O/smoke.log
 timeout 1500 python -m pytest tests -m gpu -q -rP > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -1 $O/pytest_gpu.log
 grep -E "^\[" $O/pytest_gpu.log > $O/${TAG}_fullsize_parity.log
+echo "--- float-atomic rate of the device (scripts/ubench/atomic_probe.hip): what bounds K7"
+P=generativedensification_amd/lib/atomic_probe
+[ -x $P ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -munsafe-fp-atomics scripts/ubench/atomic_probe.hip -o $P 2>/dev/null
+timeout 120 $P | tee $O/${TAG}_atomic_probe.txt
 echo "--- PMC passes first: the bench lines below read the traffic table they produce"
 for wl in c4 c3 c2 c5; do
   BENCH_ARGS="--workload $wl --no-per-view-leg" bash scripts/gpu_pmc.sh pmc_$wl > $O/pmc_$wl.log 2>&1
@@ -21,7 +25,7 @@ b() { name=$1; shift; timeout 1200 python bench.py "$@" > $O/${TAG}_bench_$name.
 import json
 try:
     d = json.load(open("$O/${TAG}_bench_$name.json")); r = d["roofline"] or {}; pv = d.get("per_view") or {}
-    print("$name", d["value"], d["unit"], d["ms_per_step"], "ms/step | per_view", pv.get("value"), "| D", d["config"].get("num_rendered_per_view"), "dom", r.get("kernel"), r.get("frac"), r.get("frac_serial"), "path", r.get("path_frac"), r.get("path_frac_measured"), "cpu", (d["cpu_baseline"] or {}).get("value"))
+    print("$name", d["value"], d["unit"], d["ms_per_step"], "ms/step | per_view", pv.get("value"), "| D", d["config"].get("num_rendered_per_view"), "dom", r.get("kernel"), r.get("frac"), r.get("frac_serial"), "atomic", r.get("atomic_frac_serial"), "path", r.get("path_frac"), r.get("path_frac_measured"), "cpu", (d["cpu_baseline"] or {}).get("value"))
 except Exception as e: print("$name FAILED", e)
 PY
 }

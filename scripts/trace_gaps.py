@@ -37,6 +37,8 @@ for si in range(1, len(starts) - 1):
 if "--timeline" in sys.argv and len(starts) > 2:   # one step, kernel by kernel: start (us from the step's K1), duration, queue
     qcol = next((c for c in ("Queue_Id", "Stream_Id", "Correlation_Id") if c in rows[0]), None)
     full = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"]), r.get(qcol, "")) for r in rows))
-    a, b = full[starts[1]][0], full[starts[2]][0]
-    for s, e, n, q in full[starts[1]:starts[2]]:
+    i0 = max(1, len(starts) - 3)     # a steady-state step (the last complete one but one), not the first after warm-up
+    a, b = full[starts[i0]][0], full[starts[i0 + 1]][0]
+    print(f"timeline of step {i0}:")
+    for s, e, n, q in full[starts[i0]:starts[i0 + 1]]:
         print(f"{(s - a) / 1e3:8.1f} +{(e - s) / 1e3:7.1f}  q{q}  {n}")
