@@ -540,6 +540,10 @@ def main():
                     help="evaluation throughput (evaluation.py:169-193: a 120-frame turntable of ONE Gaussian set under no_grad): "
                          "views/s through render_img per view and through render_views, no backward")
     ap.add_argument("--eval-views", type=int, default=120)
+    ap.add_argument("--image-loss", action="store_true",
+                    help="the loss of the reference's fine-stage renders and of its first 1000 iterations "
+                         "(lightning/loss.py:35-50): image MSE only, in torch — no gradient reaches depth / alpha / the 2DGS "
+                         "maps, and the surfel backward takes the image-only K7s")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "pmc_traffic.json"),
@@ -692,7 +696,8 @@ def main():
                 losses = []
                 for j, cam in enumerate(cams):
                     out = rnd.render_img(cam, rays[j] if surfel else None, *a)
-                    loss = (surfel_loss if surfel else view_loss)(out, targets[j])
+                    loss = (((out["image"] - targets[j]) ** 2).mean() if args.image_loss
+                            else (surfel_loss if surfel else view_loss)(out, targets[j]))
                     if backward_per_view:
                         loss.backward()
                         loss = loss.detach()
@@ -701,6 +706,12 @@ def main():
                 if not backward_per_view:
                     losses.sum().backward()
                     losses = losses.detach()
+            elif args.image_loss:
+                outs = (rnd.render_views(cams, rays, None, *a, raw=True) if surfel
+                        else render_views(rnd, cams, None, params, dev, raw=True))
+                lv = torch.stack([((o["color"] - targets_chw[j]) ** 2).mean() for j, o in enumerate(outs)])
+                lv.sum().backward()
+                losses = lv.detach()
             elif surfel:
                 if not (torch_loss or unfused or loss_kernels):
                     # all views of the shard AND their fused loss kernels in one surfel node (the loss kernels of a view
@@ -1131,7 +1142,9 @@ def main():
                                  else "renderer_2dgs.render_img per view" if surfel else ("render_img per view, backward per view" if args.backward_per_view else "render_img per view, one backward") if (args.per_view or args.backward_per_view)
                                  else "render_views (all views of the shard, one node)")
                        + (", torch activations" if args.unfused else ", activations fused into K1/K9"),
-                       "loss": ("fused HIP kernels inside the render node, on the views' side streams "
+                       "loss": ("torch image MSE only (the reference's fine-stage / first-1000-iterations loss: no gradient for "
+                                "depth, alpha or the 2DGS maps)" if args.image_loss else
+                                "fused HIP kernels inside the render node, on the views' side streams "
                                 "(MSE + 1000 distortion + 0.2 normal consistency + 0.1 depth + 0.1 alpha)"
                                 if surfel and not (args.per_view or args.backward_per_view or args.torch_loss or args.unfused or args.loss_kernels)
                                 else "fused HIP kernels, one autograd node per view "

@@ -19,7 +19,7 @@ LIB_PATH = os.environ.get("GDR_LIB_PATH") or os.path.join(_HERE, "lib", "libgdr_
 GDR_OK = 0
 GDR_IN_RAW_OPACITY, GDR_IN_RAW_SCALES, GDR_IN_RAW_ROTATIONS, GDR_IN_NO_DEPTH_TO_MEAN = 1, 2, 4, 8
 GDR_MAX_VIEWS = 8
-ABI_VERSION = 14
+ABI_VERSION = 15
 GDR_DEFAULT_SEG_LEN = 256
 GDR_ERR_WORKSPACE = -4
 

@@ -282,8 +282,9 @@ __global__ __launch_bounds__(GDR_BLOCK) void surfel_preprocess_bwd_kernel(
     float dT[9] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w, g2.x};
     float dop = g2.y;
     const float gcol[3] = {g2.z, g2.w, g3.x};
-    const float gnrm[3] = {g3.y, g3.z, g3.w};
-    const float glx = g4.x, gly = g4.y, gax = g4.z, gay = g4.w;
+    const float gax = g3.y, gay = g3.z, glx = g3.w;       // record words 13..15 (include/gsr.h)
+    const float gnrm[3] = {g4.x, g4.y, g4.z};
+    const float gly = g4.w;
     const float4 r0 = g_rec[6 * (size_t)i], r1 = g_rec[6 * (size_t)i + 1], r2 = g_rec[6 * (size_t)i + 2];
     const float Tu[3] = {r0.x, r0.y, r0.z}, Tv[3] = {r1.x, r1.y, r1.z}, Tw[3] = {r2.x, r2.y, r2.z};
     const float depth = Tw[2];
@@ -673,8 +674,9 @@ __global__ __launch_bounds__(GDR_BLOCK) void surfel_preprocess_bwd_views_kernel(
             const float4 g0 = gr[0], g1 = gr[1], g2 = gr[2], g3 = gr[3], g4 = gr[4];
             float dT[9] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w, g2.x};
             const float gcol[3] = {g2.z, g2.w, g3.x};
-            const float gnrm[3] = {g3.y, g3.z, g3.w};
-            const float glx = g4.x, gly = g4.y, gax = g4.z, gay = g4.w;
+            const float gax = g3.y, gay = g3.z, glx = g3.w;       // record words 13..15 (include/gsr.h)
+            const float gnrm[3] = {g4.x, g4.y, g4.z};
+            const float gly = g4.w;
             const float4 r0 = bv.rec[6 * (size_t)i], r1 = bv.rec[6 * (size_t)i + 1], r2 = bv.rec[6 * (size_t)i + 2];
             const float Tu[3] = {r0.x, r0.y, r0.z}, Tv[3] = {r1.x, r1.y, r1.z}, Tw[3] = {r2.x, r2.y, r2.z};
             const float depth = Tw[2];

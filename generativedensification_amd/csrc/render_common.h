@@ -129,6 +129,15 @@ __device__ __forceinline__ float row_reduce_scatter4(float v0, float v1, float v
     return t;
 }
 
+// row total of one value, on every lane of the row
+__device__ __forceinline__ float row_sum(float x) {
+    x += dpp_get<0x140, 0xf>(x);   // row_mirror
+    x += dpp_get<0x141, 0xf>(x);   // row_half_mirror
+    x += dpp_get<0x1B, 0xf>(x);    // quad reverse
+    x += dpp_get<0xB1, 0xf>(x);    // quad xor-1
+    return x;
+}
+
 // Slice-wide row lists.  A 256-entry slice is culled in four 64-entry groups; every lane keeps its row's four 64-bit
 // sub-list masks (q0..q3) and walks them back to back: `mr` = the rest of the current group's mask, `gi` = its index.
 // Rows only re-synchronise at slice boundaries, so a block with few entries in one group does not wait for the other

@@ -317,6 +317,14 @@ struct SBwdView {
 };
 struct SBwdViews { SBwdView v[GDR_MAX_VIEWS]; };
 
+// MAPS = false: NO view of the launch has an upstream gradient for the seven maps (dL_dothers == NULL everywhere: the
+// reference's fine-stage renders and its first 1000 iterations differentiate the image only, lightning/loss.py:35-50) —
+// the depth / coverage / normal / distortion recurrences and their partials drop out of the loop, dL/dz is zero.
+// Record lines: a pair publishes words 0..15 with one atomic instruction and words 16..19 (normal, low-pass y) with a
+// second one ONLY where a total is non-zero — the device retires ~21 G float-atomic record lines per second whatever
+// they carry (scripts/ubench/atomic_probe.hip), and with two lines per pair that rate, not the VALU, bounded K7s (C5:
+// 34.3 M lines per launch = 1.63 ms of 2.0; without atomics 1.57 ms).
+template <bool MAPS>
 __global__ __launch_bounds__(GDR_BLOCK) void surfel_render_bwd_kernel(const SBwdViews vs, int V, int interleave, int n_extra_max,
                                                                       int W, int H, int gx, int ntiles) {
     __shared__ SurfelLds lds;
@@ -401,7 +409,7 @@ __global__ __launch_bounds__(GDR_BLOCK) void surfel_render_bwd_kernel(const SBwd
     // and alpha channels of empty pixels (renderer_2dgs.py:253-254 backward), which must not leak into a row reduction
     if (inside && last_contributor > 0) {
         gC0 = dL_dpix[pix]; gC1 = dL_dpix[P + pix]; gC2 = dL_dpix[2 * P + pix];
-        if (dL_dothers) {
+        if (MAPS && dL_dothers) {
             gDepth = dL_dothers[pix]; gAlpha = dL_dothers[P + pix];
             gN0 = dL_dothers[2 * P + pix]; gN1 = dL_dothers[3 * P + pix]; gN2 = dL_dothers[4 * P + pix];
             gMed = dL_dothers[5 * P + pix]; gReg = dL_dothers[6 * P + pix];
@@ -417,15 +425,17 @@ __global__ __launch_bounds__(GDR_BLOCK) void surfel_render_bwd_kernel(const SBwd
         B0 = (to[GDR_BLOCK] - cu[GDR_BLOCK]) * rT;
         B1 = (to[2 * GDR_BLOCK] - cu[2 * GDR_BLOCK]) * rT;
         B2 = (to[3 * GDR_BLOCK] - cu[3 * GDR_BLOCK]) * rT;
-        BN0 = (to[4 * GDR_BLOCK] - cu[4 * GDR_BLOCK]) * rT;
-        BN1 = (to[5 * GDR_BLOCK] - cu[5 * GDR_BLOCK]) * rT;
-        BN2 = (to[6 * GDR_BLOCK] - cu[6 * GDR_BLOCK]) * rT;
-        BD = (to[7 * GDR_BLOCK] - cu[7 * GDR_BLOCK]) * rT;
-        const float dWs = T - T_final;                                  // alpha weight behind the cut
-        BA = dWs * rT;
-        // distortion weights dLw_j = (m_j^2 A + D2 - 2 m_j D) gReg summed with w_j over the entries behind the cut
-        const float dM1 = to[8 * GDR_BLOCK] - cu[8 * GDR_BLOCK], dM2 = to[9 * GDR_BLOCK] - cu[9 * GDR_BLOCK];
-        BW = (fmaf(final_A, dM2, final_D2 * dWs) - 2.f * final_D * dM1) * gReg * rT;
+        if (MAPS) {
+            BN0 = (to[4 * GDR_BLOCK] - cu[4 * GDR_BLOCK]) * rT;
+            BN1 = (to[5 * GDR_BLOCK] - cu[5 * GDR_BLOCK]) * rT;
+            BN2 = (to[6 * GDR_BLOCK] - cu[6 * GDR_BLOCK]) * rT;
+            BD = (to[7 * GDR_BLOCK] - cu[7 * GDR_BLOCK]) * rT;
+            const float dWs = T - T_final;                                  // alpha weight behind the cut
+            BA = dWs * rT;
+            // distortion weights dLw_j = (m_j^2 A + D2 - 2 m_j D) gReg summed with w_j over the entries behind the cut
+            const float dM1 = to[8 * GDR_BLOCK] - cu[8 * GDR_BLOCK], dM2 = to[9 * GDR_BLOCK] - cu[9 * GDR_BLOCK];
+            BW = (fmaf(final_A, dM2, final_D2 * dWs) - 2.f * final_D * dM1) * gReg * rT;
+        }
     }
 
     int row_last = last_contributor;
@@ -490,23 +500,26 @@ __global__ __launch_bounds__(GDR_BLOCK) void surfel_render_bwd_kernel(const SBwd
                 const float r_oma = __builtin_amdgcn_rcpf(1.f - a);
                 T = T * r_oma;
                 const float w = a * T;
-                const float rd = __builtin_amdgcn_rcpf(depth);
-                const float m_d = (GSR_FARK * GSR_NEAR) * (r_ref - rd);
-                const float dmd_dd = (GSR_FARK * GSR_NEAR) * rd * rd;
-                const float dLw = (fmaf(m_d * m_d, final_A, final_D2) - 2.f * m_d * final_D) * gReg;
                 const float d0 = en.nr.w - B0, d1 = en.gb.x - B1, d2 = en.gb.y - B2;
-                const float dD = depth - BD, dA = 1.f - BA;
-                const float dn0 = en.nr.x - BN0, dn1 = en.nr.y - BN1, dn2 = en.nr.z - BN2;
-                const float dW = dLw - BW;
-                float dL_dalpha = fmaf(d0, gC0, fmaf(d1, gC1, fmaf(d2, gC2, fmaf(dD, gDepth, dA * gAlpha))));
-                dL_dalpha += fmaf(dn0, gN0, fmaf(dn1, gN1, fmaf(dn2, gN2, dW)));
+                float dL_dalpha = fmaf(d0, gC0, fmaf(d1, gC1, d2 * gC2)), dL_dz = 0.f;
                 B0 = fmaf(a, d0, B0); B1 = fmaf(a, d1, B1); B2 = fmaf(a, d2, B2);
-                BD = fmaf(a, dD, BD); BA = fmaf(a, dA, BA);
-                BN0 = fmaf(a, dn0, BN0); BN1 = fmaf(a, dn1, BN1); BN2 = fmaf(a, dn2, BN2);
-                BW = fmaf(a, dW, BW);
+                if (MAPS) {
+                    const float rd = __builtin_amdgcn_rcpf(depth);
+                    const float m_d = (GSR_FARK * GSR_NEAR) * (r_ref - rd);
+                    const float dmd_dd = (GSR_FARK * GSR_NEAR) * rd * rd;
+                    const float dLw = (fmaf(m_d * m_d, final_A, final_D2) - 2.f * m_d * final_D) * gReg;
+                    const float dD = depth - BD, dA = 1.f - BA;
+                    const float dn0 = en.nr.x - BN0, dn1 = en.nr.y - BN1, dn2 = en.nr.z - BN2;
+                    const float dW = dLw - BW;
+                    dL_dalpha = fmaf(d0, gC0, fmaf(d1, gC1, fmaf(d2, gC2, fmaf(dD, gDepth, dA * gAlpha))));
+                    dL_dalpha += fmaf(dn0, gN0, fmaf(dn1, gN1, fmaf(dn2, gN2, dW)));
+                    BD = fmaf(a, dD, BD); BA = fmaf(a, dA, BA);
+                    BN0 = fmaf(a, dn0, BN0); BN1 = fmaf(a, dn1, BN1); BN2 = fmaf(a, dn2, BN2);
+                    BW = fmaf(a, dW, BW);
+                    dL_dz = fmaf(2.f * w * (m_d * final_A - final_D) * gReg, dmd_dd, w * gDepth);
+                    dL_dz += (hit && pos + 1 == med_contributor) ? gMed : 0.f;
+                }
                 dL_dalpha = fmaf(dL_dalpha, T, bgT * r_oma);   // (only used times G below, and G = 0 without a hit)
-                float dL_dz = fmaf(2.f * w * (m_d * final_A - final_D) * gReg, dmd_dd, w * gDepth);
-                dL_dz += (hit && pos + 1 == med_contributor) ? gMed : 0.f;
                 const float dL_dG = en.tw.w * dL_dalpha;
                 const float mG = -G * dL_dG;
                 // object-space branch (zero when the screen-space low-pass was taken)
@@ -517,16 +530,21 @@ __global__ __launch_bounds__(GDR_BLOCK) void surfel_render_bwd_kernel(const SBwd
                 const float dlx = py_ * h.kz - pz_ * h.ky, dly = pz_ * h.kx - px_ * h.kz, dlz = px_ * h.ky - py_ * h.kx;
                 const bool lp = hit && !h.use3d;
                 const float lowx = lp ? mG * 2.f * h.dx : 0.f, lowy = lp ? mG * 2.f * h.dy : 0.f;
+                // record words (include/gsr.h): 0..8 dL/dT, 9 opacity, 10..12 colour, 13..14 |dTu.z|, |dTv.z|, 15 low-pass x
                 const float vals[16] = {-dkx, -dky, -dkz, -dlx, -dly, -dlz,
                                         fmaf(pxf, dkx, fmaf(pyf, dlx, dL_dz * sx)), fmaf(pxf, dky, fmaf(pyf, dly, dL_dz * sy)),
                                         fmaf(pxf, dkz, fmaf(pyf, dlz, dL_dz)),
-                                        G * dL_dalpha, w * gC0, w * gC1, w * gC2, w * gN0, w * gN1, w * gN2};
+                                        G * dL_dalpha, w * gC0, w * gC1, w * gC2, fabsf(dkz), fabsf(dlz), lowx};
                 const float tot = row_reduce_scatter16(vals, li);
-                const float tot4 = row_reduce_scatter4(lowx, lowy, fabsf(dkz), fabsf(dlz), li);
+                // second line, words 16..19: normal (3), low-pass y — only the lanes whose total is not zero
+                float tot4;
+                if (MAPS) tot4 = row_reduce_scatter4(w * gN0, w * gN1, w * gN2, lowy, li);
+                else tot4 = row_sum(lowy);
                 if (((hb >> (16 * row)) & 0xFFFFull) != 0ull) {
                     float* g = grad_rec + GSR_GRAD_FLOATS * (size_t)s_id[en.e];
                     atomicAdd(g + li, tot);
-                    if ((li & 3u) == 0u) atomicAdd(g + 16 + (li >> 2), tot4);
+                    if (MAPS) { if ((li & 3u) == 0u && tot4 != 0.f) atomicAdd(g + 16 + (li >> 2), tot4); }
+                    else if (li == 0u && tot4 != 0.f) atomicAdd(g + 19, tot4);
                 }
             };
             SEntry A, B;
@@ -563,7 +581,7 @@ hipError_t launch_surfel_render_fwd(const gdr_settings* s, const gdr_geom* g, co
 
 // The (N,4) means2D gradient of ONE view from its K7s gradient record (what K9s forms inside its per-view loop:
 // preprocess_surfel.hip): the densification signal dL/dTu.z, dL/dTv.z x depth x W/2 | H/2 in columns 0-1 and its
-// per-pixel-|.| twin (record words 18, 19) in columns 2-3; zero for culled surfels.  Used by the render groups
+// per-pixel-|.| twin (record words 13, 14) in columns 2-3; zero for culled surfels.  Used by the render groups
 // (viewgroup.py): every call of the unchanged caller owns a carrier and gets ITS view's gradient, while the group's one
 // K9s returns the sums over the views for the shared inputs.
 namespace {
@@ -575,9 +593,9 @@ __global__ __launch_bounds__(GDR_BLOCK) void surfel_means2d_view_kernel(int N, c
     if (i >= N) return;
     float4 m = make_float4(0.f, 0.f, 0.f, 0.f);
     if (radii[i] > 0) {
-        const float4 g0 = grad_rec[8 * (size_t)i], g1 = grad_rec[8 * (size_t)i + 1], g4 = grad_rec[8 * (size_t)i + 4];
+        const float4 g0 = grad_rec[8 * (size_t)i], g1 = grad_rec[8 * (size_t)i + 1], g3 = grad_rec[8 * (size_t)i + 3];
         const float depth = rec[6 * (size_t)i + 2].z;
-        m = make_float4(g0.z * depth * hw, g1.y * depth * hh, g4.z * depth * hw, g4.w * depth * hh);
+        m = make_float4(g0.z * depth * hw, g1.y * depth * hh, g3.y * depth * hw, g3.z * depth * hh);
     }
     out[i] = m;
 }
@@ -612,8 +630,14 @@ hipError_t launch_surfel_render_bwd_views(int V, const gdr_settings* s, const gd
         b.seg_extra = (const uint2*)bin[v].seg_extra; b.seg_count = bin[v].seg_count;
         n_extra_max = b.n_extra > n_extra_max ? b.n_extra : n_extra_max;
     }
-    GDR_LAUNCH(GDR_K_RENDER_BWD, surfel_render_bwd_kernel, dim3((unsigned)V * (unsigned)(ntiles + n_extra_max)), dim3(GDR_BLOCK), st,
-               vs, V, interleave, n_extra_max, W, H, gx, ntiles);
+    bool maps = false;
+    for (int v = 0; v < V; ++v) maps = maps || gi[v].dL_dallmap != nullptr;
+    if (maps)
+        GDR_LAUNCH(GDR_K_RENDER_BWD, surfel_render_bwd_kernel<true>, dim3((unsigned)V * (unsigned)(ntiles + n_extra_max)),
+                   dim3(GDR_BLOCK), st, vs, V, interleave, n_extra_max, W, H, gx, ntiles);
+    else
+        GDR_LAUNCH(GDR_K_RENDER_BWD, surfel_render_bwd_kernel<false>, dim3((unsigned)V * (unsigned)(ntiles + n_extra_max)),
+                   dim3(GDR_BLOCK), st, vs, V, interleave, n_extra_max, W, H, gx, ntiles);
     return hipGetLastError();
 }
 

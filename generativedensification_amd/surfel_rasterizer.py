@@ -150,12 +150,17 @@ class _RasterizeSurfels(torch.autograd.Function):
         ctx.in_dtypes = tuple(t.dtype for t in (means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
                                                 transMat_precomp))
         ctx.mark_non_differentiable(radii)
+        # an output the loss does not use arrives as None instead of a zero tensor: a missing allmap gradient (the reference's
+        # fine-stage renders, lightning/loss.py:35-50) selects the image-only K7s
+        ctx.set_materialize_grads(False)
         return color, radii, allmap
 
     @staticmethod
     def backward(ctx, grad_color, grad_radii, grad_allmap):
         from . import viewgroup
         viewgroup.note_backward()
+        if grad_color is None:
+            grad_color = torch.zeros(3, ctx.state.H, ctx.state.W, dtype=torch.float32, device=ctx.radii.device)
         g = backward_raw(ctx.state, _R._saved_inputs(ctx), ctx.raster_settings, ctx.radii, grad_color, grad_allmap)
         gm2 = g["means2D"]
         cols = ctx.means2D_shape[1] if len(ctx.means2D_shape) == 2 else 4

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define GDR_ABI_VERSION 14
+#define GDR_ABI_VERSION 15
 
 #define GDR_OK 0
 #define GDR_ERR_INVALID_ARG (-1)  /* NULL / inconsistent arguments                     */

@@ -64,7 +64,9 @@ typedef struct gsr_grad_inputs {
 /* Every buffer is fully written (zeros for culled surfels) unless accumulate != 0.  dL_dmeans2D is (N,4):
  * columns 0-1 = dL/dTu.z, dL/dTv.z scaled by depth * 0.5 W (resp. H) — the densification signal of the lineage —
  * columns 2-3 the same with per-pixel |.| accumulation.  scratch: N * GSR_GRAD_FLOATS floats (128-byte records:
- * [0..8] dL/dT, [9] opacity, [10..12] colour, [13..15] normal, [16..17] low-pass centre, [18..19] |dTu.z|, |dTv.z|). */
+ * [0..8] dL/dT, [9] opacity, [10..12] colour, [13..14] |dTu.z|, |dTv.z|, [15] low-pass centre x | [16..18] normal,
+ * [19] low-pass centre y — v15: the first 64-byte line holds everything an image-only loss produces; K7s touches the second
+ * line only where a total is non-zero). */
 typedef struct gsr_grad_outputs {
     float* dL_dmeans3D;   /* (N,3) */
     float* dL_dmeans2D;   /* (N,4) */

@@ -34,6 +34,8 @@ b c2 --workload c2
 b c3 --workload c3
 b c5 --workload c5
 b c3step --workload c3step --steps 6 --warmup 2
+b c5_imageloss --workload c5 --image-loss --no-cpu-baseline
+b c5_imageloss_perview --workload c5 --image-loss --per-view --unfused --no-cpu-baseline
 b c4_fwd --forward-only
 b c2_fwd --workload c2 --forward-only
 b c3_fwd --workload c3 --forward-only

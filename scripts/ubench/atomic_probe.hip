@@ -16,7 +16,7 @@ __device__ __forceinline__ uint32_t mix(uint32_t x) {
 // the workgroup (no other workgroup touches them), 0: from the whole buffer
 template <int LDS>
 __global__ __launch_bounds__(256) void probe(float* buf, uint32_t nrec, int iters, int group, int act, int same, int twice,
-                                             int local, int valu) {
+                                             int local, int valu, int wide) {
     __shared__ float lacc[LDS ? 256 * 12 : 1];
     if (LDS) for (int k = threadIdx.x; k < 256 * 12; k += 256) lacc[k] = 0.f;
     __syncthreads();
@@ -31,8 +31,13 @@ __global__ __launch_bounds__(256) void probe(float* buf, uint32_t nrec, int iter
             if (LDS) {
                 atomicAdd(&lacc[(h & 255u) * 12u + li % 12u], x);
             } else {
+                if (wide) {   // 128-byte records: one instruction over `act` <= 32 adjacent words, or (twice) 16 + 4 in two
+                    if (!twice) atomicAdd(buf + 32 * (size_t)(rec >> 1) + li, x);
+                    else { if (li < 16u) atomicAdd(buf + 32 * (size_t)(rec >> 1) + li, x); if (li < 4u) atomicAdd(buf + 32 * (size_t)(rec >> 1) + 16u + li, x); }
+                } else {
                 atomicAdd(buf + 16 * (size_t)rec + li, x);
                 if (twice) atomicAdd(buf + 16 * (size_t)rec + (li + 4u) % 16u, x);
+                }
             }
         }
     }
@@ -45,7 +50,7 @@ int main() {
     float* buf; hipMalloc(&buf, (size_t)nrec * 64); hipMemset(buf, 0, (size_t)nrec * 64);
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
     const int blocks = 2500 * 4, iters = 200;
-    struct P { const char* name; int lds, group, act, same, twice, local, valu; } ps[] = {
+    struct P { const char* name; int lds, group, act, same, twice, local, valu, wide; } ps[] = {
         {"rows16 x12 lanes, 4 records / instr", 0, 16, 12, 0, 0, 0, 0},
         {"rows16 x12, 4 records, +90 VALU", 0, 16, 12, 0, 0, 0, 90},
         {"rows16 x12, all rows ONE record", 0, 16, 12, 1, 0, 0, 0},
@@ -60,6 +65,9 @@ int main() {
         {"rows16 x4 lanes, 4 records", 0, 16, 4, 0, 0, 0, 0},
         {"rows16 x1 lane, 4 records", 0, 16, 1, 0, 0, 0, 0},
         {"64 lanes, 64 records (group 1)", 0, 1, 1, 0, 0, 0, 0},
+        {"128 B records: 32 lanes x 32 adjacent words, 2 / instr", 0, 32, 32, 0, 0, 0, 0, 1},
+        {"128 B records: 32-lane groups, 20 adjacent words", 0, 32, 20, 0, 0, 0, 0, 1},
+        {"128 B records: rows16, 16 words + 4 words (2 instr)", 0, 16, 16, 0, 1, 0, 0, 1},
         {"only VALU 90", 0, 16, 0, 0, 0, 0, 90},
         {"no atomics, no VALU (loop overhead)", 0, 16, 0, 0, 0, 0, 0},
         {"LDS ds_add rows16 x12, 4 entries, +90 VALU", 1, 16, 12, 0, 0, 0, 90},
@@ -73,8 +81,8 @@ int main() {
     for (auto& p : ps) {
         for (int rep = 0; rep < 2; ++rep) {
             hipEventRecord(a);
-            if (p.lds) hipLaunchKernelGGL(probe<1>, dim3(blocks), dim3(256), 0, 0, buf, nrec, iters, p.group, p.act, p.same, p.twice, p.local, p.valu);
-            else hipLaunchKernelGGL(probe<0>, dim3(blocks), dim3(256), 0, 0, buf, nrec, iters, p.group, p.act, p.same, p.twice, p.local, p.valu);
+            if (p.lds) hipLaunchKernelGGL(probe<1>, dim3(blocks), dim3(256), 0, 0, buf, nrec, iters, p.group, p.act, p.same, p.twice, p.local, p.valu, p.wide);
+            else hipLaunchKernelGGL(probe<0>, dim3(blocks), dim3(256), 0, 0, buf, nrec, iters, p.group, p.act, p.same, p.twice, p.local, p.valu, p.wide);
             hipEventRecord(b); hipEventSynchronize(b);
             float ms; hipEventElapsedTime(&ms, a, b);
             if (rep == 1) {

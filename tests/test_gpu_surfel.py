@@ -59,6 +59,57 @@ def test_surfel_forward_and_backward_vs_oracle(oracle_built, N, H, W, seed, deg,
     assert e_hip < max(5e-5, e_o32), (e_hip, e_o32)
 
 
+@pytest.mark.parametrize("N,H,W,seed,deg,sigma0", [
+    (3000, 128, 144, 1, 3, (0.0052, 0.02)),
+    (2000, 64, 64, 3, 0, (0.2,)),
+])
+def test_surfel_image_only_backward_vs_oracle(oracle_built, N, H, W, seed, deg, sigma0):
+    """No upstream gradient for the seven maps — the reference's fine-stage renders and its first 1000 iterations
+    differentiate the image only (/root/reference/lightning/loss.py:35-50), autograd then hands None for `allmap`: the
+    image-only K7s (render_surfel.hip, MAPS = false: no depth / normal / distortion recurrences, the record's second line
+    only where the low-pass branch was taken) against the oracle fed zero map gradients, and against the general kernel
+    fed explicit zeros."""
+    case = U.make_surfel_case(N, H, W, seed, deg=deg, sigma0=sigma0, bg=(1.0, 0.5, 0.2))
+    gc, gm = U.rand_surfel_grads(case)
+    zeros = torch.zeros_like(gm)
+    keys = ("means3D", "means2D", "shs", "opacities", "scales", "rotations")
+    _, hg = U.run_surfel_hip(case, (gc, None))
+    _, hz = U.run_surfel_hip(case, (gc, zeros))
+    _, g32 = U.run_surfel_oracle(case, "f32", (gc, zeros))
+    _, g64 = U.run_surfel_oracle(case, "f64", (gc, zeros), nthreads=8)
+    _check_grads(hg, g32, g64, keys)
+    _check_grads(hz, g32, g64, keys)
+    for k in keys:   # the two kernels differ by the order of the float atomics only
+        assert U.rel_inf(hg[k], hz[k]) < 2e-5, (k, U.rel_inf(hg[k], hz[k]))
+
+
+def test_surfel_autograd_without_map_gradients_uses_the_image_only_kernel():
+    """`loss = f(color)` through the module: autograd passes no gradient for `allmap` (not a zero tensor) and the gradients
+    equal those of a loss that touches the maps with weight zero."""
+    from generativedensification_amd import surfel_rasterizer as S
+
+    dev = torch.device("cuda:0")
+    case = U.make_surfel_case(4000, 96, 80, 9, deg=1, sigma0=(0.01, 0.03), bg=(0.0, 0.0, 0.0))
+    rs = U.settings_torch(case, dev)
+    names = ("means3D", "shs", "opacities", "scales", "rotations")
+
+    def run(touch_maps):
+        leaves = {k: case[k].to(dev).clone().requires_grad_(True) for k in names}
+        m2 = torch.zeros(case["means3D"].shape[0], 4, device=dev, requires_grad=True)
+        color, radii, allmap = S.GaussianRasterizer(rs)(means3D=leaves["means3D"], means2D=m2, shs=leaves["shs"],
+                                                         opacities=leaves["opacities"], scales=leaves["scales"],
+                                                         rotations=leaves["rotations"])
+        w = torch.linspace(0.5, 1.5, color.numel(), device=dev).reshape(color.shape)
+        loss = (color * w).sum() + (allmap.sum() * 0.0 if touch_maps else 0.0)
+        loss.backward()
+        return {k: v.grad.detach().cpu().numpy() for k, v in leaves.items()} | {"means2D": m2.grad.cpu().numpy()}
+
+    a, b = run(False), run(True)
+    for k in a:
+        assert np.isfinite(a[k]).all() and np.abs(a[k]).max() > 0, k
+        assert U.rel_inf(a[k], b[k]) < 2e-5, (k, U.rel_inf(a[k], b[k]))
+
+
 def test_surfel_views_of_different_sizes_fall_back_to_per_view_kernels():
     """render_surfel_views_raw with views of different image sizes (no shared K1s/K9s launch): same result as one
     rasterizer call per view."""
@@ -133,6 +184,16 @@ def test_cut_surfel_lists_give_the_gradients_of_the_uncut_walk(oracle_built):
     o64, g64 = U.run_surfel_oracle(case, "f64", grads, nthreads=8)
     for sl in (0, 2048):
         _check_grads(res[sl][1], g32, g64, ("means3D", "shs", "opacities", "scales", "rotations"))
+    # the image-only K7s starts the colour sums behind a cut from the same saved state
+    try:
+        R.K.SEG_LEN = 2048
+        _, gi_cut = U.run_surfel_hip(case, (grads[0], None))
+        R.K.SEG_LEN = 0
+        _, gi_0 = U.run_surfel_hip(case, (grads[0], None))
+    finally:
+        R.K.SEG_LEN = None
+    for k in ("means3D", "means2D", "shs", "opacities", "scales", "rotations"):
+        assert U.rel_inf(gi_cut[k], gi_0[k]) < 5e-5, (k, U.rel_inf(gi_cut[k], gi_0[k]))
 
 
 def test_subpixel_surfels_are_no_worse_than_the_fp32_formulation(oracle_built):

@@ -164,7 +164,7 @@ def run_surfel_hip(case, grads=None, dev="cuda:0"):
     out.update(color=color.cpu().numpy(), radii=radii.cpu().numpy(), allmap=allmap.cpu().numpy())
     g = None
     if grads is not None:
-        gg = S.backward_raw(st, keep, rs, radii, grads[0].to(dev), grads[1].to(dev))
+        gg = S.backward_raw(st, keep, rs, radii, grads[0].to(dev), None if grads[1] is None else grads[1].to(dev))
         torch.cuda.synchronize()
         g = {k: (None if v is None else v.cpu().numpy()) for k, v in gg.items()}
     return out, g
