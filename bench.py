@@ -493,7 +493,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=13,
+                    help="untimed steps (default 13: the library settles on a K7 variant per scene shape after timing launches "
+                         "8..11 of the shape, include/gdr.h gdr_k7_tune_get)")
     ap.add_argument("--workload", default="c4", choices=sorted(WORKLOADS))
     ap.add_argument("--n", type=int, default=0, help="override the number of Gaussians")
     ap.add_argument("--views-per-gpu", type=int, default=0)
@@ -893,9 +895,23 @@ def main():
                   and meta.get("views_per_gpu") == vpg and meta.get("abi") == L.ABI_VERSION
                   and not (args.per_view or args.backward_per_view or args.unfused))
         tj, vj = (pmc.get(args.workload, {}), pmc.get(args.workload + "_valu", {})) if pmc_ok else ({}, {})
+        # which K7 the library settled on for this shape (include/gdr.h gdr_k7_tune_get: rows, or row pairs where they pay)
+        k7_variant = None
+        if not surfel:
+            import ctypes as _C
+            ch, u0, u1 = _C.c_int32(0), _C.c_float(0), _C.c_float(0)
+            for kind in (1, 0, 2):
+                if L.load().gdr_k7_tune_get(n, h, w, min(vpg, 8), kind, _C.byref(ch), _C.byref(u0), _C.byref(u1)) == 0:
+                    k7_variant = dict(chosen="pairs" if ch.value else "rows", us_rows=round(u0.value, 1), us_pairs=round(u1.value, 1),
+                                      note="render_bwd_kernel (one record line per 4x4 block) or render_bwd_pairs_kernel (8x4 where "
+                                           "that saves lines): timed per scene shape by the library, the faster serves")
+                    break
         aj = pmc.get(args.workload + "_atomic", {}) if pmc_ok else {}
 
         def pmc_name(name):   # bench kernel id -> kernel symbol in the rocprofv3 summaries
+            if name == "render_bwd" and k7_variant and k7_variant["chosen"] == "pairs" and \
+                    ("render_bwd_pairs_kernel" in tj or "render_bwd_pairs_kernel" in vj):
+                return "render_bwd_pairs_kernel"
             alias = {"duplicate_with_keys": "duplicate", "tile_ranges": "ranges", "tile_sort_long": "tile_sort"}
             base = ("surfel_" if surfel and name in ("preprocess_fwd", "preprocess_bwd", "render_fwd", "render_bwd") else "") \
                 + alias.get(name, name)
@@ -986,6 +1002,8 @@ def main():
                                 valu_note="SQ_INSTS_VALU x 2 cycles / (launch time x 1024 SIMDs x 2.4 GHz): fraction of the "
                                           "peak VALU issue rate; the kernel's own mix (DPP, compares, 3-source fma, exp: "
                                           "3.5-8 cycles each) averages ~3.6 cycles per instruction")
+            if dom == "render_bwd" and k7_variant:
+                roofline["k7_variant"] = k7_variant
             ia = aj.get(pmc_name(dom))
             if ia:      # K7: one float-atomic record line per (entry, 4x4 block) hit; they execute outside the L2s
                 roofline.update(atomic_lines_per_launch=int(ia), atomic_peak_lines_per_s=ATOMIC_PEAK_LINES,

@@ -177,6 +177,9 @@ _PROTOS = {
                                     C.c_float, C.c_float, C.c_void_p, C.POINTER(C.c_void_p), C.c_int32,
                                     C.POINTER(GdrViewState)]),
     "gdr_view_history_reset": (None, []),
+    "gdr_k7_tune_override": (None, [C.c_int32]),
+    "gdr_k7_tune_get": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32),
+                                  C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "gdr_view_history_report": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_uint32), C.c_int32]),
     "gdr_view_history_get": (C.c_double, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "gdr_view_history_set": (None, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_double]),
@@ -286,6 +289,8 @@ def load():
         if tag != "release" and os.environ.get("GDR_ALLOW_EXPERIMENTAL_LIB") != "1":
             raise RuntimeError(f"{LIB_PATH} is a '{tag}' build of the library (measurement-only, results may be wrong); "
                                "set GDR_ALLOW_EXPERIMENTAL_LIB=1 to load it anyway")
+        if os.environ.get("GDR_K7_PAIRS") is not None:     # developer A/B: pin the K7 variant (include/gdr.h gdr_k7_tune_override)
+            lib.gdr_k7_tune_override(int(os.environ["GDR_K7_PAIRS"]))
         _lib = lib
     return _lib
 

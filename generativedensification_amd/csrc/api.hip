@@ -4,6 +4,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <atomic>
 #include <mutex>
 #include <unordered_map>
 #include <vector>
@@ -54,6 +55,86 @@ void prof_end(int id, hipStream_t st) {
 }
 
 static inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+
+// ---- which K7 for a scene shape: rows, or row pairs where they pay (render.hip: render_bwd_pairs_kernel) ---------------
+// K7 is bound by the device's float-atomic line rate wherever the Gaussians span several 4x4 blocks; merging the two rows of
+// an 8x4 area saves lines and costs iterations, and which side wins depends on the scene (C2 -16 %, object-like scenes and
+// sub-pixel Gaussians +3-30 %).  Results are the same sums in another order.  Per (device, N bucket, image size, views per
+// launch, entry): four consecutive launches are timed with events (rows / pairs / rows / pairs, the better try of each), first
+// after the shape's first kK7First launches and then every kK7Period launches, and the faster variant (by > 3 %) serves until the next round.  gdr_k7_tune_override pins a variant (tests, A/B).
+struct K7Tune {
+    float us[2] = {0.f, 0.f};      // this round's best time per variant (0 = not in yet; negated once the round is decided)
+    uint32_t calls = 0;
+    int chosen = 0, got = 0;
+    struct Pend { hipEvent_t a = nullptr, b = nullptr; int state = 0; } pend[4];   // state: 0 idle, 1 begun, 2 ended
+};
+static std::mutex g_k7_mu;
+static std::unordered_map<uint64_t, K7Tune> g_k7;
+static std::atomic<int> g_k7_override{-1};    // -1 measure and choose, 0 rows, 1 row pairs
+// a round = four consecutive launches, rows / pairs / rows / pairs (the faster of two tries counts); the first round after
+// kK7First launches of the shape — K7's duration drifts down over the first ten or so launches of a shape (C3: pairs 1332 ->
+// 1202 us, rows 1335 -> 1277, profiles/r04_ab_k7_blocks.txt section 10), a round at launch 0 chose wrongly — then every
+// kK7Period launches
+constexpr uint32_t kK7Period = 256, kK7Round = 4, kK7First = 8;
+
+static uint64_t k7_key(int N, int H, int W, int V, int kind) {
+    int dev = 0, nb = 0;
+    (void)hipGetDevice(&dev);
+    for (int64_t v = N; v > 0; v >>= 1) ++nb;
+    return ((uint64_t)(dev & 0xFF) << 56) | ((uint64_t)(kind & 3) << 54) | ((uint64_t)(V & 0x3F) << 48) |
+           ((uint64_t)(nb & 0x3F) << 42) | ((uint64_t)(H & 0x1FFFFF) << 21) | (uint64_t)(W & 0x1FFFFF);
+}
+static void k7_harvest(K7Tune& k) {   // (g_k7_mu held)
+    for (uint32_t ph = 0; ph < kK7Round; ++ph) {
+        K7Tune::Pend& p = k.pend[ph];
+        if (p.state != 2 || hipEventQuery(p.b) != hipSuccess) continue;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess && ms > 0.f) {
+            float& u = k.us[ph & 1u];
+            u = (u > 0.f && u < ms * 1e3f) ? u : ms * 1e3f;
+            ++k.got;
+        }
+        p.state = 0;
+    }
+    if (k.got == (int)kK7Round && k.us[0] > 0.f && k.us[1] > 0.f) {
+        k.chosen = k.us[1] < 0.97f * k.us[0] ? 1 : 0;
+        k.us[0] = -k.us[0]; k.us[1] = -k.us[1];   // (kept, negated, for gdr_k7_tune_get)
+        k.got = 0;
+    }
+}
+// brackets ONE K7 launch: sets the calling thread's variant, times the launch when it is this shape's turn
+struct K7Scope {
+    K7Tune* t = nullptr;
+    int slot = -1;
+    hipStream_t st;
+    K7Scope(int N, int H, int W, int V, int kind, hipStream_t stream) : st(stream) {
+        int variant = g_k7_override.load();
+        if (variant < 0) {
+            std::lock_guard<std::mutex> lk(g_k7_mu);
+            K7Tune& k = g_k7[k7_key(N, H, W, V, kind)];
+            k7_harvest(k);
+            const uint32_t phase = (k.calls++ % kK7Period) - kK7First;     // (wraps for the launches before the round)
+            variant = k.chosen;
+            if (phase < kK7Round && k.pend[phase].state == 0) {
+                K7Tune::Pend& p = k.pend[phase];
+                if (phase == 0) { k.us[0] = k.us[1] = 0.f; k.got = 0; }
+                if (!p.a && (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess)) p.a = p.b = nullptr;
+                if (p.a && hipEventRecord(p.a, st) == hipSuccess) { p.state = 1; t = &k; slot = (int)phase; }
+                variant = (int)(phase & 1u);
+            }
+        }
+        render_bwd_set_pairs(variant > 0 ? 1 : 0);
+    }
+    ~K7Scope() {
+        render_bwd_set_pairs(0);
+        if (slot < 0) return;
+        const bool ok = hipEventRecord(t->pend[slot].b, st) == hipSuccess;
+        std::lock_guard<std::mutex> lk(g_k7_mu);
+        t->pend[slot].state = ok ? 2 : 0;
+    }
+    K7Scope(const K7Scope&) = delete;
+    K7Scope& operator=(const K7Scope&) = delete;
+};
 
 struct Carver {
     char* base;
@@ -517,7 +598,8 @@ int gdr_render_backward_loss(const gdr_settings* s, int32_t N, const gdr_geom* g
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = bin->grad_rec_cleared ? hipSuccess : hipMemsetAsync(grad_rec, 0, (size_t)N * 16 * sizeof(float), st);
     if (e != hipSuccess) return hip_fail("memset gradient records", e);
-    e = launch_render_bwd_loss(s, geom, bin, img, color, target, w_depth, w_alpha, g, grad_rec, st);
+    { K7Scope k7(N, s->image_height, s->image_width, 1, 1, st);
+      e = launch_render_bwd_loss(s, geom, bin, img, color, target, w_depth, w_alpha, g, grad_rec, st); }
     if (e != hipSuccess) return hip_fail("render_bwd_loss", e);
     return debug_sync(s, "render_bwd_loss", st);
 }
@@ -531,7 +613,9 @@ int gdr_render_backward_mean2d_loss(const gdr_settings* s, int32_t N, const gdr_
     }
     if (N <= 0) return GDR_OK;
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = launch_render_bwd_mean2d_loss(s, geom, bin, img, color, target, g, dL_dmean2D, st);
+    hipError_t e;
+    { K7Scope k7(N, s->image_height, s->image_width, 1, 2, st);
+      e = launch_render_bwd_mean2d_loss(s, geom, bin, img, color, target, g, dL_dmean2D, st); }
     if (e != hipSuccess) return hip_fail("render_bwd_mean2d_loss", e);
     return debug_sync(s, "render_bwd_mean2d_loss", st);
 }
@@ -585,7 +669,8 @@ int gdr_backward(const gdr_settings* s, const gdr_inputs* in, const gdr_geom* ge
     if (N == 0) return GDR_OK;
     hipError_t e = hipMemsetAsync(gout->scratch, 0, N * 16 * sizeof(float), st);
     if (e != hipSuccess) return hip_fail("memset gradient records", e);
-    e = launch_render_bwd(s, geom, bin, img, gin, gout, st);
+    { K7Scope k7((int)N, s->image_height, s->image_width, 1, 0, st);
+      e = launch_render_bwd(s, geom, bin, img, gin, gout, st); }
     if (e != hipSuccess) return hip_fail("render_bwd", e);
     if ((rc = debug_sync(s, "render_bwd", st))) return rc;
     e = launch_preprocess_bwd(s, in, geom, radii, gout, st);
@@ -639,7 +724,8 @@ int gdr_render_backward(const gdr_settings* s, int32_t N, const gdr_geom* geom, 
     gdr_grad_outputs go;
     memset(&go, 0, sizeof(go));
     go.scratch = grad_rec;
-    e = launch_render_bwd(s, geom, bin, img, gin, &go, st);
+    { K7Scope k7(N, s->image_height, s->image_width, 1, 0, st);
+      e = launch_render_bwd(s, geom, bin, img, gin, &go, st); }
     if (e != hipSuccess) return hip_fail("render_bwd", e);
     return debug_sync(s, "render_bwd", st);
 }
@@ -673,7 +759,9 @@ int gdr_render_backward_views(int32_t V, const gdr_settings* s, int32_t N, const
             if (e != hipSuccess) return hip_fail("memset gradient records", e);
         }
     }
-    hipError_t e = launch_render_bwd_views(V, s, geoms, bins, imgs, gins, grad_recs, interleave, st);
+    hipError_t e;
+    { K7Scope k7(N, s[0].image_height, s[0].image_width, V, 0, st);
+      e = launch_render_bwd_views(V, s, geoms, bins, imgs, gins, grad_recs, interleave, st); }
     if (e != hipSuccess) return hip_fail("render_bwd_views", e);
     return debug_sync(&s[0], "render_bwd_views", st);
 }
@@ -694,8 +782,9 @@ int gdr_render_backward_loss_views(int32_t V, const gdr_settings* s, int32_t N, 
             if (e != hipSuccess) return hip_fail("memset gradient records", e);
         }
     }
-    hipError_t e = launch_render_bwd_loss_views(V, s, geoms, bins, imgs, colors, targets, w_depth, w_alpha, g, grad_recs,
-                                                interleave, st);
+    hipError_t e;
+    { K7Scope k7(N, s[0].image_height, s[0].image_width, V, 1, st);
+      e = launch_render_bwd_loss_views(V, s, geoms, bins, imgs, colors, targets, w_depth, w_alpha, g, grad_recs, interleave, st); }
     if (e != hipSuccess) return hip_fail("render_bwd_loss_views", e);
     return debug_sync(&s[0], "render_bwd_loss_views", st);
 }
@@ -710,7 +799,9 @@ int gdr_render_backward_mean2d_views(int32_t V, const gdr_settings* s, int32_t N
     for (int v = 0; v < V; ++v)
         if (!dL_dcolors[v]) { set_error("render_backward_mean2d_views: NULL view buffer", hipSuccess); return GDR_ERR_INVALID_ARG; }
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = launch_render_bwd_mean2d_views(V, s, geoms, bins, imgs, dL_dcolors, dL_dmean2D, interleave, st);
+    hipError_t e;
+    { K7Scope k7(N, s[0].image_height, s[0].image_width, V, 2, st);
+      e = launch_render_bwd_mean2d_views(V, s, geoms, bins, imgs, dL_dcolors, dL_dmean2D, interleave, st); }
     if (e != hipSuccess) return hip_fail("render_bwd_mean2d_views", e);
     return debug_sync(&s[0], "render_bwd_mean2d_views", st);
 }
@@ -724,7 +815,9 @@ int gdr_render_backward_mean2d(const gdr_settings* s, int32_t N, const gdr_geom*
     }
     if (N <= 0) return GDR_OK;
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = launch_render_bwd_mean2d(s, geom, bin, img, dL_dcolor, dL_dmean2D, st);
+    hipError_t e;
+    { K7Scope k7(N, s->image_height, s->image_width, 1, 2, st);
+      e = launch_render_bwd_mean2d(s, geom, bin, img, dL_dcolor, dL_dmean2D, st); }
     if (e != hipSuccess) return hip_fail("render_bwd_mean2d", e);
     return debug_sync(s, "render_bwd_mean2d", st);
 }
@@ -1264,7 +1357,24 @@ int gdr_view_history_report(int32_t N, int32_t H, int32_t W, int32_t surfel, int
     return GDR_OK;
 }
 
+void gdr_k7_tune_override(int32_t mode) { g_k7_override.store(mode < 0 ? -1 : (mode ? 1 : 0)); }
+
+int gdr_k7_tune_get(int32_t N, int32_t H, int32_t W, int32_t V, int32_t kind, int32_t* chosen, float* us_rows, float* us_pairs) {
+    std::lock_guard<std::mutex> lk(g_k7_mu);
+    auto it = g_k7.find(k7_key(N, H, W, V, kind));
+    if (it == g_k7.end()) { set_error("k7_tune_get: no launch of this shape yet", hipSuccess); return GDR_ERR_INVALID_ARG; }
+    k7_harvest(it->second);
+    if (chosen) *chosen = it->second.chosen;
+    if (us_rows) *us_rows = it->second.us[0] < 0.f ? -it->second.us[0] : it->second.us[0];
+    if (us_pairs) *us_pairs = it->second.us[1] < 0.f ? -it->second.us[1] : it->second.us[1];
+    return GDR_OK;
+}
+
 void gdr_view_history_reset(void) {
+    {   // (the K7 choices start over as well; events of measurements in flight are left to finish)
+        std::lock_guard<std::mutex> lk7(g_k7_mu);
+        for (auto& kv : g_k7) { kv.second.calls = 0; kv.second.chosen = 0; kv.second.got = 0; kv.second.us[0] = kv.second.us[1] = 0.f; }
+    }
     std::lock_guard<std::mutex> lk(g_hist_mu);
     for (auto& kv : g_hist) {     // (the pinned report words stay: a kernel in flight may still write them)
         kv.second.d_per_n = 0.0; kv.second.n_long = kv.second.n_medium = 0; kv.second.deep_ttl = 0; kv.second.reported = false;

@@ -731,9 +731,18 @@ struct BwdView {
 };
 struct BwdViews { BwdView v[GDR_MAX_VIEWS]; };
 
-template <bool M2_ONLY, bool LOSS = false>
-__global__ __launch_bounds__(GDR_BLOCK) void render_bwd_kernel(const BwdViews vs, int V, int interleave, int n_extra_max,
-                                                               int W, int H, int gx, int ntiles) {
+// PAIRS (round 4, render_bwd_pairs_kernel).  The float atomics execute outside the L2s (TCC_EA0_ATOMIC == TCC_ATOMIC) at a
+// fixed ~21 G record lines / s for the whole device, whatever a line carries (scripts/ubench/atomic_probe.hip): one line per
+// (entry, 4x4 block) hit is what bounds K7 (C4: 20.5 M lines per launch = 0.98 ms of 1.10; C2 0.49 of 0.60).  Where the
+// entries of a slice mostly cover BOTH blocks of a row pair (an 8x4 pixel area), the two rows walk the UNION of their
+// lists in step, their totals are summed across the rows (one v_permlane16_swap) and ONE line is published for the pair —
+// decided per wave and slice from the list lengths (GDR_PAIR_W lines saved per extra iteration).  Carrying the second mode
+// costs the row-mode path 5-10 % (registers), so it is a second kernel: the library times both per scene shape and keeps
+// the faster (api.hip, K7Tune); C2 K7 600 -> 505 us, C3 -4 %, sub-pixel Gaussians and object-like scenes stay on this one.
+#define GDR_PAIR_W 6
+template <bool M2_ONLY, bool LOSS, bool PAIRS>
+__device__ __forceinline__ void render_bwd_body(const BwdViews& vs, int V, int interleave, int n_extra_max,
+                                                int W, int H, int gx, int ntiles) {
     __shared__ SliceLds lds;
     __shared__ RowLists rlists;
     __shared__ uint32_t s_id[GDR_BLOCK + 1];
@@ -889,7 +898,7 @@ __global__ __launch_bounds__(GDR_BLOCK) void render_bwd_kernel(const BwdViews vs
         // hold the same four masks).  A row walks them back to back at its own pace — rows only re-synchronise at slice
         // boundaries, so a row whose block has few entries in one group does not wait for the others there.
         // this wave's compacted row lists of the slice (RowLists): entries in front of each block's deepest contributor
-        int n[4] = {0, 0, 0, 0};
+        int n[4] = {0, 0, 0, 0}, un[2] = {0, 0};
         row_lists_clear(rlists, wave);
         wave_lds_fence();
 #pragma unroll 1
@@ -901,9 +910,36 @@ __global__ __launch_bounds__(GDR_BLOCK) void render_bwd_kernel(const BwdViews vs
             const int mypos = gtop - (int)lane;
             block_masks(lds, g, XA, YA, mypos < rl0, mypos < rl1, mypos < rl2, mypos < rl3, m0, m1, m2, m3, mine);
             row_lists_append(rlists, wave, g, m0, m1, m2, m3, mine, n);
+            if (PAIRS) { un[0] += __popcll(m0 | m1); un[1] += __popcll(m2 | m3); }
         }
-        const int nmax = max(max(n[0], n[1]), max(n[2], n[3]));
+        int nmax = max(max(n[0], n[1]), max(n[2], n[3]));
         if (nmax == 0) continue;
+        bool pair_mode = false;
+        if (PAIRS) {
+            const int umax = max(un[0], un[1]);
+            pair_mode = (umax - nmax) * GDR_PAIR_W < (n[0] + n[1] + n[2] + n[3]) - (un[0] + un[1]);
+            if (pair_mode) {   // rebuild: both rows of a pair get the union of their lists
+                nmax = umax;
+                n[0] = n[1] = n[2] = n[3] = 0;
+                wave_lds_fence();
+                row_lists_clear(rlists, wave);
+                wave_lds_fence();
+#pragma unroll 1
+                for (int g = 0; g < GDR_BLOCK / GDR_WAVE; ++g) {
+                    const int gtop = top - g * GDR_WAVE;
+                    if (gtop - (GDR_WAVE - 1) >= wave_last) continue;
+                    uint64_t m0, m1, m2, m3;
+                    bool mine[4];
+                    const int mypos = gtop - (int)lane;
+                    block_masks(lds, g, XA, YA, mypos < rl0, mypos < rl1, mypos < rl2, mypos < rl3, m0, m1, m2, m3, mine);
+                    const bool p01 = mine[0] || mine[1], p23 = mine[2] || mine[3];
+                    const bool minep[4] = {p01, p01, p23, p23};
+                    row_lists_append(rlists, wave, g, m0 | m1, m0 | m1, m2 | m3, m2 | m3, minep, n);
+                }
+            }
+        }
+        // this lane's publishing unit in the hit ballot: its row, or in pair mode its row pair (the even row publishes)
+        const uint64_t unit_mask = !pair_mode ? 0xFFFFull << (16 * row) : ((row & 1u) ? 0ull : 0xFFFFFFFFull << (16 * row));
         wave_lds_fence();
         {
             const uint16_t* my_list = &rlists.idx[wave][row][0];
@@ -947,18 +983,19 @@ __global__ __launch_bounds__(GDR_BLOCK) void render_bwd_kernel(const BwdViews vs
                 // co.xyz carry the log2(e) factor; kx, ky carry its inverse
                 const float v_mx = fmaf(qdx, en.co.x, qdy * en.co.y) * -kx;
                 const float v_my = fmaf(qdy, en.co.z, qdx * en.co.y) * -ky;
+                const bool publish = PAIRS ? (hb & unit_mask) != 0ull : ((hb >> (16 * row)) & 0xFFFFull) != 0ull;
                 if (M2_ONLY) {
-                    const float tot4 = row_reduce_scatter4(v_mx, v_my, fabsf(v_mx), fabsf(v_my), li);
-                    if ((li & 3u) == 0u && ((hb >> (16 * row)) & 0xFFFFull) != 0ull)
-                        atomicAdd(grad_rec + 4 * (size_t)s_id[en.e] + (li >> 2), tot4);
+                    float tot4 = row_reduce_scatter4(v_mx, v_my, fabsf(v_mx), fabsf(v_my), li);
+                    if (PAIRS && pair_mode) tot4 = rows2_sum(tot4);
+                    if ((li & 3u) == 0u && publish) atomicAdd(grad_rec + 4 * (size_t)s_id[en.e] + (li >> 2), tot4);
                     return;
                 }
                 // (record words 4..6 = sum of q dx dx, q dx dy, q dy dy: K8 applies the exact factors -1/2, -1, -1/2)
                 const float vals[12] = {v_mx, v_my, fabsf(v_mx), fabsf(v_my), qdx * dx, qdx * dy, qdy * dy,
                                         w * gD, w * gC0, w * gC1, w * gC2, go};
-                const float tot = row_reduce_scatter12(vals, li);
-                const bool publish = ((hb >> (16 * row)) & 0xFFFFull) != 0ull;
-                // lanes 0..11 of every row that had a hit add the row totals to the Gaussian's
+                float tot = row_reduce_scatter12(vals, li);
+                if (PAIRS && pair_mode) tot = rows2_sum(tot);
+                // lanes 0..11 of every row (pair mode: row pair) that had a hit add the totals to the Gaussian's
                 // 64-byte gradient record: one global_atomic_add_f32 instruction, one cache line
                 // per row (no return value => fire and forget)
                 if (li < 12u && publish)
@@ -984,7 +1021,23 @@ __global__ __launch_bounds__(GDR_BLOCK) void render_bwd_kernel(const BwdViews vs
     }
 }
 
+template <bool M2_ONLY, bool LOSS = false>
+__global__ __launch_bounds__(GDR_BLOCK) void render_bwd_kernel(const BwdViews vs, int V, int interleave, int n_extra_max,
+                                                               int W, int H, int gx, int ntiles) {
+    render_bwd_body<M2_ONLY, LOSS, false>(vs, V, interleave, n_extra_max, W, H, gx, ntiles);
+}
+// (five waves per SIMD as the row-mode kernel: the handful of registers beyond 96 are spilled outside the walk)
+template <bool M2_ONLY, bool LOSS = false>
+__global__ __launch_bounds__(GDR_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 5)))
+void render_bwd_pairs_kernel(const BwdViews vs, int V, int interleave, int n_extra_max, int W, int H, int gx, int ntiles) {
+    render_bwd_body<M2_ONLY, LOSS, true>(vs, V, interleave, n_extra_max, W, H, gx, ntiles);
+}
+
 }  // namespace
+
+// the K7 variant of the calling thread's next launches (api.hip: K7Scope)
+static thread_local int t_bwd_pairs = 0;
+void render_bwd_set_pairs(int pairs) { t_bwd_pairs = pairs; }
 
 hipError_t launch_tile_order_views(const BinViews& vs, int V, int ntiles, hipStream_t st) {
     GDR_LAUNCH(GDR_K_TILE_ORDER, tile_order_kernel, dim3(1, V), dim3(GDR_ORDER_THREADS), st, vs, ntiles);
@@ -1107,8 +1160,12 @@ hipError_t launch_bwd_table(int V, const BwdSpec* sp, int interleave, hipStream_
         n_extra_max = b.n_extra > n_extra_max ? b.n_extra : n_extra_max;
     }
     const unsigned grid = (unsigned)V * (unsigned)(ntiles + n_extra_max);
-    GDR_LAUNCH(GDR_K_RENDER_BWD, (render_bwd_kernel<M2_ONLY, LOSS>), dim3(grid), dim3(GDR_BLOCK), st, vs, V, interleave,
-               n_extra_max, W, H, gx, ntiles);
+    if (t_bwd_pairs)
+        GDR_LAUNCH(GDR_K_RENDER_BWD, (render_bwd_pairs_kernel<M2_ONLY, LOSS>), dim3(grid), dim3(GDR_BLOCK), st, vs, V, interleave,
+                   n_extra_max, W, H, gx, ntiles);
+    else
+        GDR_LAUNCH(GDR_K_RENDER_BWD, (render_bwd_kernel<M2_ONLY, LOSS>), dim3(grid), dim3(GDR_BLOCK), st, vs, V, interleave,
+                   n_extra_max, W, H, gx, ntiles);
     return hipGetLastError();
 }
 }  // namespace

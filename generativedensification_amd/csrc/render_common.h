@@ -116,6 +116,14 @@ __device__ __forceinline__ float row_reduce_scatter16(const float (&v)[16], uint
     return keep + dpp_get<0xB1, 0xf>(send);       // quad_perm [1,0,3,2]: partner i ^ 1
 }
 
+// x of this DPP row + x of the other row of its pair (rows 0/1, 2/3), on both: v_permlane16_swap (gfx950) exchanges the
+// odd rows of its first operand with the even rows of the second
+__device__ __forceinline__ float rows2_sum(float x) {
+    const uint32_t u = __float_as_uint(x);
+    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
 // 4 values over the 16 lanes of a row: lane i returns the row total of value (i >> 2) & 3
 // (two halving exchanges, then two plain butterfly adds inside the quads)
 __device__ __forceinline__ float row_reduce_scatter4(float v0, float v1, float v2, float v3, uint32_t li) {

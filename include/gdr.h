@@ -392,6 +392,18 @@ void gdr_view_history_reset(void);
 int gdr_view_history_report(int32_t N, int32_t H, int32_t W, int32_t surfel, int32_t row, uint32_t* words, int32_t set);
 double gdr_view_history_get(int32_t N, int32_t H, int32_t W, int32_t surfel);
 void gdr_view_history_set(int32_t N, int32_t H, int32_t W, int32_t surfel, double duplicates_per_gaussian);
+/* Which K7 serves a scene shape (v15).  K7 publishes one float-atomic record line per (list entry, 4x4 pixel block) hit and
+ * the device retires ~21 G such lines per second whatever they carry: wherever Gaussians span several blocks that rate, not
+ * the arithmetic, bounds K7.  A second kernel lets the two rows of an 8x4 area walk the union of their lists and publish
+ * ONE line where that saves enough lines per extra iteration — faster for Gaussians of 10+ pixels spread over the image,
+ * slower for sub-pixel Gaussians and object-like scenes.  The gradients are the same sums in another order.  Per (device,
+ * N bucket, image size, views per launch, entry kind) the library times both kernels (events around four consecutive
+ * launches, rows / pairs / rows / pairs, after the shape's first 8 launches and then every 256) and keeps the faster.
+ * kind: 0 gdr_backward / gdr_render_backward(_views), 1 the _loss entries, 2 the mean2D-only entries.
+ * _override: -1 measure and choose (default), 0 rows only, 1 row pairs always (tests, A/B).  _get: the choice and the last
+ * round's times in microseconds (error if the shape has not been launched).  gdr_view_history_reset restarts the choices. */
+void gdr_k7_tune_override(int32_t mode);
+int gdr_k7_tune_get(int32_t N, int32_t H, int32_t W, int32_t V, int32_t kind, int32_t* chosen, float* us_rows, float* us_pairs);
 
 /* ---- backward (K7 + K8/K9) --------------------------------------------------------
  * Replaces `_C.rasterize_gaussians_backward`, reached through autograd from the losses on the render outputs

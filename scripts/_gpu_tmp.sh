@@ -1,19 +1,15 @@
 #!/bin/bash
-cd /root/repo
-timeout 900 python -m pytest tests/test_gpu_surfel.py tests/test_gpu_viewgroup.py -x -q -m gpu 2>&1 | tail -3
-timeout 900 python -m pytest tests/test_gpu_oracle_fullsize.py -x -q -m gpu -k surfel 2>&1 | tail -3
-run() {
-  for a in "" "--image-loss" "--per-view --unfused --image-loss" "--layout shell" "--layout shell --image-loss"; do
-    timeout 300 python bench.py --workload c5 $a --steps 20 --warmup 5 --no-cpu-baseline --no-per-view-leg 2>/dev/null | python3 -c "
-import sys,json
-for l in sys.stdin:
-    if l.startswith('{'):
-        d=json.loads(l); k=d['kernels'].get('render_bwd',{})
-        print('$TAG', 'c5 $a', round(d['value'],1), d['ms_per_step'], 'K7s us', k.get('avg_us'), 'serial', k.get('avg_us_serial'), 'launches', k.get('launches'))
-"
-  done
-}
-for rep in 1 2; do
-export TAG=old GDR_LIB_PATH=$PWD/generativedensification_amd/lib/old/libgdr_hip.so; run
-unset GDR_LIB_PATH; export TAG=new; run
+cd /root/repo; R=$PWD
+for m in 0 1 auto; do
+  if [ $m = auto ]; then unset GDR_K7_PAIRS; else export GDR_K7_PAIRS=$m; fi
+  rm -rf gpurun_out/tr
+  (cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/tr -o t -- python $R/bench.py --workload c3 --steps 8 --warmup 3 --no-cpu-baseline --no-roofline --no-per-view-leg > /dev/null 2>&1)
+  python3 - <<PY
+import csv,glob
+f=glob.glob("gpurun_out/tr/**/*kernel_trace.csv",recursive=True)[0]
+rows=sorted(((int(r["Start_Timestamp"]),int(r["End_Timestamp"]),r["Kernel_Name"]) for r in csv.DictReader(open(f))))
+k7=[(round((e-s)/1e3,1), "pairs" if "pairs" in n else "rows") for s,e,n in rows if "render_bwd" in n]
+print("$m", k7)
+PY
 done
+rm -rf gpurun_out/tr

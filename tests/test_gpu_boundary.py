@@ -492,3 +492,39 @@ def test_second_backward_through_a_node_clears_its_own_records(surfel):
             ref = 2.0 * grads[0][k]
             tol = 1e-4 * np.abs(ref) + 1e-6 * np.abs(ref).max()
             assert (np.abs(grads[1][k] - ref) > tol).mean() < 1e-4, (fused_loss, k)
+
+
+def test_k7_variant_is_measured_per_shape_and_can_be_pinned():
+    """include/gdr.h gdr_k7_tune_override / gdr_k7_tune_get (v15): four backward launches of a scene shape (after its first 8)
+    are timed (rows / pairs / rows / pairs), then one variant serves; an override pins it; the gradients do not depend on any
+    of it beyond the order of the float atomics."""
+    import ctypes as C
+
+    import util as U
+    from generativedensification_amd import _lib as L
+
+    lib = L.load()
+    case = U.make_case(20_000, 96, 112, 23, deg=1, sigma0=(0.03, 0.01))
+    grads = U.rand_grads(case)
+    N, H, W = 20_000, 96, 112
+    chosen, us0, us1 = C.c_int32(-7), C.c_float(0), C.c_float(0)
+    lib.gdr_view_history_reset()
+    try:
+        lib.gdr_k7_tune_override(-1)
+        ref = None
+        for i in range(16):     # (the round of four timed launches starts after the shape's first 8)
+            _, g = U.run_hip(case, grads)
+            ref = ref or g
+            for k in ("means3D", "shs", "opacities"):
+                assert U.rel_inf(g[k], ref[k]) < 5e-5, (i, k)
+        torch.cuda.synchronize()
+        assert lib.gdr_k7_tune_get(N, H, W, 1, 0, C.byref(chosen), C.byref(us0), C.byref(us1)) == 0
+        assert chosen.value in (0, 1) and us0.value > 0 and us1.value > 0, (chosen.value, us0.value, us1.value)
+        assert lib.gdr_k7_tune_get(N, H + 16, W, 1, 0, C.byref(chosen), C.byref(us0), C.byref(us1)) != 0    # no launch of that shape
+        for mode in (0, 1):
+            lib.gdr_k7_tune_override(mode)
+            _, g = U.run_hip(case, grads)
+            for k in ("means3D", "shs", "opacities"):
+                assert U.rel_inf(g[k], ref[k]) < 5e-5, (mode, k)
+    finally:
+        lib.gdr_k7_tune_override(-1)

@@ -320,6 +320,64 @@ def test_k7_of_all_views_in_one_launch_equals_per_view_launches(V):
                 assert out < U.MAX_OUTSIDE and maxn < 1e-4, (entry, mode, k, out, worst, maxn)
 
 
+def test_k7_row_pair_kernel_equals_the_row_kernel_and_the_oracle(oracle_built):
+    """render_bwd_pairs_kernel (round 4, include/gdr.h gdr_k7_tune_override): where the entries of a slice mostly cover both
+    4x4 blocks of a row pair, the two rows walk the union of their lists and publish ONE record line — the same sums in
+    another order.  Gaussians of 10-30 pixels (the regime it is for) mixed with sub-pixel ones (slices that stay in row
+    mode), lists long enough to be cut; the three entries (full records, fused loss, mean2D only), one launch for the
+    views; and the single-view path against the f32 / f64 oracles."""
+    from generativedensification_amd import _lib as L
+    from generativedensification_amd.camera import orbit_cameras
+    from generativedensification_amd.renderer import Renderer
+    from generativedensification_amd.synthetic import make_scene, make_targets
+
+    lib = L.load()
+    dev = torch.device("cuda:0")
+    V, n, h, w = 4, 30_000, 160, 208
+    sc = make_scene(n, 91, sh_degree=3, sigma0=(0.03, 0.0052, 0.06))
+    cams = orbit_cameras(V, w, h, device=dev)
+    tg = make_targets(V, h, w, 91).to(dev)
+    tg_chw = tg.permute(0, 3, 1, 2).contiguous()
+    wts = torch.linspace(0.5, 2.0, V, device=dev)
+    r = Renderer(sh_degree=3, fused=True)
+
+    def run(entry):
+        leaves = {k: v.to(dev).clone().requires_grad_(True) for k, v in sc.items()}
+        ssp = torch.zeros(n, 4, device=dev, requires_grad=True)
+        args = (leaves["centers"], leaves["shs"], leaves["opacity"], leaves["scales"], leaves["rotations"], dev)
+        if entry == "absgrad":
+            loss, grad = r.screenspace_absgrad(cams, None, tg, *args)
+            return {"loss": loss.detach().cpu().numpy(), "ssp": grad.cpu().numpy()}
+        if entry == "loss":
+            lv = r.render_views_loss(cams, None, tg_chw, *args, screenspace_points=ssp)
+        else:
+            outs = r.render_views(cams, None, *args, screenspace_points=ssp)
+            lv = torch.stack([((o["image"] - tg[j]) ** 2).mean() + 0.1 * o["depth"].mean() + 0.1 * o["acc_map"].mean()
+                              for j, o in enumerate(outs)])
+        grads = torch.autograd.grad((lv * wts).sum(), list(leaves.values()) + [ssp])
+        return {k: g_.cpu().numpy() for k, g_ in zip(list(leaves) + ["ssp"], grads)}
+
+    try:
+        for entry in ("views", "loss", "absgrad"):
+            lib.gdr_k7_tune_override(0)
+            ref = run(entry)
+            lib.gdr_k7_tune_override(1)
+            got = run(entry)
+            for k in ref:
+                out, worst, maxn = U.elem_stats(got[k], ref[k])
+                assert out < U.MAX_OUTSIDE and maxn < 1e-4, (entry, k, out, worst, maxn)
+        case = U.make_case(6000, 128, 144, 17, deg=3, sigma0=(0.05, 0.01))
+        grads = U.rand_grads(case)
+        _, g32 = U.run_oracle(case, "f32", grads)
+        _, g64 = U.run_oracle(case, "f64", grads, nthreads=8)
+        for mode in (0, 1):
+            lib.gdr_k7_tune_override(mode)
+            _, hg = U.run_hip(case, grads)
+            U.assert_grads(hg, g64, g32, ("means3D", "means2D", "shs", "opacities", "scales", "rotations"), f"k7 variant {mode}")
+    finally:
+        lib.gdr_k7_tune_override(-1)
+
+
 @pytest.mark.parametrize("interleave", [0, 1])
 def test_k6_of_all_views_in_one_launch_reproduces_the_per_view_images(interleave):
     """gdr_composite_forward_views (include/gdr.h, v14; SURVEY section 7 step 5 "grid.z = view"): K6 of V views in ONE launch
