@@ -124,9 +124,11 @@ struct K7Scope {
             }
         }
         render_bwd_set_pairs(variant > 0 ? 1 : 0);
+        surfel_render_bwd_set_pairs(variant > 0 ? 1 : 0);
     }
     ~K7Scope() {
         render_bwd_set_pairs(0);
+        surfel_render_bwd_set_pairs(0);
         if (slot < 0) return;
         const bool ok = hipEventRecord(t->pend[slot].b, st) == hipSuccess;
         std::lock_guard<std::mutex> lk(g_k7_mu);
@@ -1528,7 +1530,8 @@ int gsr_backward(const gdr_settings* s, const gsr_inputs* in, const gdr_geom* ge
     if (N == 0) return GDR_OK;
     hipError_t e = hipMemsetAsync(gout->scratch, 0, N * GSR_GRAD_FLOATS * sizeof(float), st);
     if (e != hipSuccess) return hip_fail("memset gradient records", e);
-    e = launch_surfel_render_bwd(s, geom, bin, img, gin, gout->scratch, st);
+    { K7Scope k7((int)in->N, s->image_height, s->image_width, 1, 3, st);
+      e = launch_surfel_render_bwd(s, geom, bin, img, gin, gout->scratch, st); }
     if (e != hipSuccess) return hip_fail("surfel_render_bwd", e);
     if ((rc = debug_sync(s, "surfel_render_bwd", st))) return rc;
     e = launch_surfel_preprocess_bwd(s, in, geom, radii, gout, st);
@@ -1583,7 +1586,8 @@ int gsr_render_backward(const gdr_settings* s, int32_t N, const gdr_geom* geom, 
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = bin->grad_rec_cleared ? hipSuccess : hipMemsetAsync(grad_rec, 0, (size_t)N * GSR_GRAD_FLOATS * sizeof(float), st);
     if (e != hipSuccess) return hip_fail("memset gradient records", e);
-    e = launch_surfel_render_bwd(s, geom, bin, img, gin, grad_rec, st);
+    { K7Scope k7(N, s->image_height, s->image_width, 1, 3, st);
+      e = launch_surfel_render_bwd(s, geom, bin, img, gin, grad_rec, st); }
     if (e != hipSuccess) return hip_fail("surfel_render_bwd", e);
     return debug_sync(s, "surfel_render_bwd", st);
 }
@@ -1603,7 +1607,9 @@ int gsr_render_backward_views(int32_t V, const gdr_settings* s, int32_t N, const
             if (e != hipSuccess) return hip_fail("memset gradient records", e);
         }
     }
-    hipError_t e = launch_surfel_render_bwd_views(V, s, geoms, bins, imgs, gins, grad_recs, interleave, st);
+    hipError_t e;
+    { K7Scope k7(N, s[0].image_height, s[0].image_width, V, 3, st);
+      e = launch_surfel_render_bwd_views(V, s, geoms, bins, imgs, gins, grad_recs, interleave, st); }
     if (e != hipSuccess) return hip_fail("surfel_render_bwd_views", e);
     return debug_sync(&s[0], "surfel_render_bwd_views", st);
 }

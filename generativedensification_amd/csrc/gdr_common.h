@@ -134,6 +134,7 @@ hipError_t launch_render_fwd_views(int V, const gdr_settings* s, const gdr_geom*
 hipError_t launch_topk_absgrad(int N, const float* grad, const uint8_t* cand, int k, void* workspace,
                                uint8_t* mask, int32_t* idx, hipStream_t st);
 size_t select_workspace_bytes();
+void surfel_render_bwd_set_pairs(int pairs);
 void render_bwd_set_pairs(int pairs);   // K7 variant of this thread's next launches: 0 rows, 1 row pairs where they pay
 hipError_t launch_render_bwd_loss(const gdr_settings* s, const gdr_geom* g, const gdr_binning* bin,
                                   const gdr_image* img, const float* color, const float* target, float w_depth,

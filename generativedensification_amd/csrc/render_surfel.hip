@@ -324,9 +324,12 @@ struct SBwdViews { SBwdView v[GDR_MAX_VIEWS]; };
 // second one ONLY where a total is non-zero — the device retires ~21 G float-atomic record lines per second whatever
 // they carry (scripts/ubench/atomic_probe.hip), and with two lines per pair that rate, not the VALU, bounded K7s (C5:
 // 34.3 M lines per launch = 1.63 ms of 2.0; without atomics 1.57 ms).
-template <bool MAPS>
-__global__ __launch_bounds__(GDR_BLOCK) void surfel_render_bwd_kernel(const SBwdViews vs, int V, int interleave, int n_extra_max,
-                                                                      int W, int H, int gx, int ntiles) {
+// PAIRS: as render.hip's render_bwd_pairs_kernel — where the entries of a slice mostly cover both 4x4 blocks of a row pair, the
+// two rows walk the union of their lists and publish the pair's totals once.
+#define GSR_PAIR_W 6
+template <bool MAPS, bool PAIRS>
+__device__ __forceinline__ void surfel_render_bwd_body(const SBwdViews& vs, int V, int interleave, int n_extra_max,
+                                                       int W, int H, int gx, int ntiles) {
     __shared__ SurfelLds lds;
     __shared__ RowLists rlists;
     __shared__ uint32_t s_id[GDR_BLOCK + 1];
@@ -463,7 +466,7 @@ __global__ __launch_bounds__(GDR_BLOCK) void surfel_render_bwd_kernel(const SBwd
         }
         const int top = total - 1 - r * GDR_BLOCK;  // list position of LDS entry e: top - e
         if (top - (GDR_BLOCK - 1) >= wave_last) continue;
-        int n[4] = {0, 0, 0, 0};   // this wave's compacted row lists of the slice (render_common.h RowLists)
+        int n[4] = {0, 0, 0, 0}, un[2] = {0, 0};   // this wave's compacted row lists of the slice (render_common.h RowLists)
         row_lists_clear(rlists, wave);
         wave_lds_fence();
 #pragma unroll 1
@@ -475,9 +478,36 @@ __global__ __launch_bounds__(GDR_BLOCK) void surfel_render_bwd_kernel(const SBwd
             const int mypos = gtop - (int)lane;
             block_masks(lds, g, XA, YA, mypos < rl0, mypos < rl1, mypos < rl2, mypos < rl3, m0, m1, m2, m3, mine);
             row_lists_append(rlists, wave, g, m0, m1, m2, m3, mine, n);
+            if (PAIRS) { un[0] += __popcll(m0 | m1); un[1] += __popcll(m2 | m3); }
         }
-        const int nmax = max(max(n[0], n[1]), max(n[2], n[3]));
+        int nmax = max(max(n[0], n[1]), max(n[2], n[3]));
         if (nmax == 0) continue;
+        bool pair_mode = false;
+        if (PAIRS) {
+            const int umax = max(un[0], un[1]);
+            pair_mode = (umax - nmax) * GSR_PAIR_W < (n[0] + n[1] + n[2] + n[3]) - (un[0] + un[1]);
+            if (pair_mode) {   // rebuild: both rows of a pair get the union of their lists
+                nmax = umax;
+                n[0] = n[1] = n[2] = n[3] = 0;
+                wave_lds_fence();
+                row_lists_clear(rlists, wave);
+                wave_lds_fence();
+#pragma unroll 1
+                for (int g = 0; g < GDR_BLOCK / GDR_WAVE; ++g) {
+                    const int gtop = top - g * GDR_WAVE;
+                    if (gtop - (GDR_WAVE - 1) >= wave_last) continue;
+                    uint64_t m0, m1, m2, m3;
+                    bool mine[4];
+                    const int mypos = gtop - (int)lane;
+                    block_masks(lds, g, XA, YA, mypos < rl0, mypos < rl1, mypos < rl2, mypos < rl3, m0, m1, m2, m3, mine);
+                    const bool p01 = mine[0] || mine[1], p23 = mine[2] || mine[3];
+                    const bool minep[4] = {p01, p01, p23, p23};
+                    row_lists_append(rlists, wave, g, m0 | m1, m0 | m1, m2 | m3, m2 | m3, minep, n);
+                }
+            }
+        }
+        // this lane's publishing unit in the hit ballot: its row, or in pair mode its row pair (the even row publishes)
+        const uint64_t unit_mask = !pair_mode ? 0xFFFFull << (16 * row) : ((row & 1u) ? 0ull : 0xFFFFFFFFull << (16 * row));
         wave_lds_fence();
         {
             const uint16_t* my_list = &rlists.idx[wave][row][0];
@@ -535,12 +565,13 @@ __global__ __launch_bounds__(GDR_BLOCK) void surfel_render_bwd_kernel(const SBwd
                                         fmaf(pxf, dkx, fmaf(pyf, dlx, dL_dz * sx)), fmaf(pxf, dky, fmaf(pyf, dly, dL_dz * sy)),
                                         fmaf(pxf, dkz, fmaf(pyf, dlz, dL_dz)),
                                         G * dL_dalpha, w * gC0, w * gC1, w * gC2, fabsf(dkz), fabsf(dlz), lowx};
-                const float tot = row_reduce_scatter16(vals, li);
+                float tot = row_reduce_scatter16(vals, li);
                 // second line, words 16..19: normal (3), low-pass y — only the lanes whose total is not zero
                 float tot4;
                 if (MAPS) tot4 = row_reduce_scatter4(w * gN0, w * gN1, w * gN2, lowy, li);
                 else tot4 = row_sum(lowy);
-                if (((hb >> (16 * row)) & 0xFFFFull) != 0ull) {
+                if (PAIRS && pair_mode) { tot = rows2_sum(tot); tot4 = rows2_sum(tot4); }
+                if (PAIRS ? (hb & unit_mask) != 0ull : ((hb >> (16 * row)) & 0xFFFFull) != 0ull) {
                     float* g = grad_rec + GSR_GRAD_FLOATS * (size_t)s_id[en.e];
                     atomicAdd(g + li, tot);
                     if (MAPS) { if ((li & 3u) == 0u && tot4 != 0.f) atomicAdd(g + 16 + (li >> 2), tot4); }
@@ -566,7 +597,21 @@ __global__ __launch_bounds__(GDR_BLOCK) void surfel_render_bwd_kernel(const SBwd
     }
 }
 
+template <bool MAPS>
+__global__ __launch_bounds__(GDR_BLOCK) void surfel_render_bwd_kernel(const SBwdViews vs, int V, int interleave, int n_extra_max,
+                                                                      int W, int H, int gx, int ntiles) {
+    surfel_render_bwd_body<MAPS, false>(vs, V, interleave, n_extra_max, W, H, gx, ntiles);
+}
+template <bool MAPS>
+__global__ __launch_bounds__(GDR_BLOCK) void surfel_render_bwd_pairs_kernel(const SBwdViews vs, int V, int interleave,
+                                                                            int n_extra_max, int W, int H, int gx, int ntiles) {
+    surfel_render_bwd_body<MAPS, true>(vs, V, interleave, n_extra_max, W, H, gx, ntiles);
+}
+
 }  // namespace
+
+static thread_local int t_sbwd_pairs = 0;
+void surfel_render_bwd_set_pairs(int pairs) { t_sbwd_pairs = pairs; }
 
 hipError_t launch_surfel_render_fwd(const gdr_settings* s, const gdr_geom* g, const gdr_binning* bin,
                                     const gdr_image* img, const gsr_outputs* out, hipStream_t st) {
@@ -632,12 +677,15 @@ hipError_t launch_surfel_render_bwd_views(int V, const gdr_settings* s, const gd
     }
     bool maps = false;
     for (int v = 0; v < V; ++v) maps = maps || gi[v].dL_dallmap != nullptr;
-    if (maps)
-        GDR_LAUNCH(GDR_K_RENDER_BWD, surfel_render_bwd_kernel<true>, dim3((unsigned)V * (unsigned)(ntiles + n_extra_max)),
-                   dim3(GDR_BLOCK), st, vs, V, interleave, n_extra_max, W, H, gx, ntiles);
+    const dim3 grid((unsigned)V * (unsigned)(ntiles + n_extra_max));
+    if (maps && t_sbwd_pairs)
+        GDR_LAUNCH(GDR_K_RENDER_BWD, surfel_render_bwd_pairs_kernel<true>, grid, dim3(GDR_BLOCK), st, vs, V, interleave, n_extra_max, W, H, gx, ntiles);
+    else if (maps)
+        GDR_LAUNCH(GDR_K_RENDER_BWD, surfel_render_bwd_kernel<true>, grid, dim3(GDR_BLOCK), st, vs, V, interleave, n_extra_max, W, H, gx, ntiles);
+    else if (t_sbwd_pairs)
+        GDR_LAUNCH(GDR_K_RENDER_BWD, surfel_render_bwd_pairs_kernel<false>, grid, dim3(GDR_BLOCK), st, vs, V, interleave, n_extra_max, W, H, gx, ntiles);
     else
-        GDR_LAUNCH(GDR_K_RENDER_BWD, surfel_render_bwd_kernel<false>, dim3((unsigned)V * (unsigned)(ntiles + n_extra_max)),
-                   dim3(GDR_BLOCK), st, vs, V, interleave, n_extra_max, W, H, gx, ntiles);
+        GDR_LAUNCH(GDR_K_RENDER_BWD, surfel_render_bwd_kernel<false>, grid, dim3(GDR_BLOCK), st, vs, V, interleave, n_extra_max, W, H, gx, ntiles);
     return hipGetLastError();
 }
 

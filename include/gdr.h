@@ -399,7 +399,8 @@ void gdr_view_history_set(int32_t N, int32_t H, int32_t W, int32_t surfel, doubl
  * slower for sub-pixel Gaussians and object-like scenes.  The gradients are the same sums in another order.  Per (device,
  * N bucket, image size, views per launch, entry kind) the library times both kernels (events around four consecutive
  * launches, rows / pairs / rows / pairs, after the shape's first 8 launches and then every 256) and keeps the faster.
- * kind: 0 gdr_backward / gdr_render_backward(_views), 1 the _loss entries, 2 the mean2D-only entries.
+ * kind: 0 gdr_backward / gdr_render_backward(_views), 1 the _loss entries, 2 the mean2D-only entries, 3 the 2DGS K7s
+ * (gsr_backward / gsr_render_backward(_views): 16 + 4 totals per pair, two record lines).
  * _override: -1 measure and choose (default), 0 rows only, 1 row pairs always (tests, A/B).  _get: the choice and the last
  * round's times in microseconds (error if the shape has not been launched).  gdr_view_history_reset restarts the choices. */
 void gdr_k7_tune_override(int32_t mode);

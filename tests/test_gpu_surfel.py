@@ -83,6 +83,33 @@ def test_surfel_image_only_backward_vs_oracle(oracle_built, N, H, W, seed, deg, 
         assert U.rel_inf(hg[k], hz[k]) < 2e-5, (k, U.rel_inf(hg[k], hz[k]))
 
 
+@pytest.mark.parametrize("maps", [True, False])
+def test_k7s_row_pair_kernel_equals_the_row_kernel_and_the_oracle(oracle_built, maps):
+    """surfel_render_bwd_pairs_kernel (include/gdr.h gdr_k7_tune_override, entry kind 3): the two rows of an 8x4 area walk
+    the union of their lists and publish the pair's 16 + 4 totals once where that saves record lines — the same sums in
+    another order.  Surfels of 10-40 pixels mixed with small ones; with and without map gradients (both instantiations)."""
+    from generativedensification_amd import _lib as L
+
+    lib = L.load()
+    case = U.make_surfel_case(5000, 128, 144, 31, deg=1, sigma0=(0.05, 0.012, 0.1), bg=(1.0, 0.5, 0.2))
+    gc, gm = U.rand_surfel_grads(case)
+    grads = (gc, gm if maps else None)
+    ref_grads = (gc, gm if maps else torch.zeros_like(gm))
+    keys = ("means3D", "means2D", "shs", "opacities", "scales", "rotations")
+    _, g32 = U.run_surfel_oracle(case, "f32", ref_grads)
+    _, g64 = U.run_surfel_oracle(case, "f64", ref_grads, nthreads=8)
+    res = {}
+    try:
+        for mode in (0, 1):
+            lib.gdr_k7_tune_override(mode)
+            _, res[mode] = U.run_surfel_hip(case, grads)
+            _check_grads(res[mode], g32, g64, keys)
+    finally:
+        lib.gdr_k7_tune_override(-1)
+    for k in keys:
+        assert U.rel_inf(res[1][k], res[0][k]) < 2e-5, (k, U.rel_inf(res[1][k], res[0][k]))
+
+
 def test_surfel_autograd_without_map_gradients_uses_the_image_only_kernel():
     """`loss = f(color)` through the module: autograd passes no gradient for `allmap` (not a zero tensor) and the gradients
     equal those of a loss that touches the maps with weight zero."""
