@@ -894,14 +894,14 @@ def main():
         meta = pmc.get(args.workload + "_meta", {})
         pmc_ok = (meta.get("n") == n and meta.get("layout", "cube") == args.layout and meta.get("order", "random") == args.order
                   and meta.get("views_per_gpu") == vpg and meta.get("abi") == L.ABI_VERSION
-                  and not (args.per_view or args.backward_per_view or args.unfused))
+                  and not (args.per_view or args.backward_per_view or args.unfused or args.image_loss))
         tj, vj = (pmc.get(args.workload, {}), pmc.get(args.workload + "_valu", {})) if pmc_ok else ({}, {})
         # which K7 the library settled on for this shape (include/gdr.h gdr_k7_tune_get: rows, or row pairs where they pay)
         k7_variant = None
-        if not surfel:
+        if True:
             import ctypes as _C
             ch, u0, u1 = _C.c_int32(0), _C.c_float(0), _C.c_float(0)
-            for kind in (1, 0, 2):
+            for kind in ((3,) if surfel else (1, 0, 2)):
                 if L.load().gdr_k7_tune_get(n, h, w, min(vpg, 8), kind, _C.byref(ch), _C.byref(u0), _C.byref(u1)) == 0:
                     k7_variant = dict(chosen="pairs" if ch.value else "rows", us_rows=round(u0.value, 1), us_pairs=round(u1.value, 1),
                                       note="render_bwd_kernel (one record line per 4x4 block) or render_bwd_pairs_kernel (8x4 where "
@@ -910,9 +910,10 @@ def main():
         aj = pmc.get(args.workload + "_atomic", {}) if pmc_ok else {}
 
         def pmc_name(name):   # bench kernel id -> kernel symbol in the rocprofv3 summaries
-            if name == "render_bwd" and k7_variant and k7_variant["chosen"] == "pairs" and \
-                    ("render_bwd_pairs_kernel" in tj or "render_bwd_pairs_kernel" in vj):
-                return "render_bwd_pairs_kernel"
+            if name == "render_bwd" and k7_variant and k7_variant["chosen"] == "pairs":
+                pk = ("surfel_" if surfel else "") + "render_bwd_pairs_kernel"
+                if pk in tj or pk in vj:
+                    return pk
             alias = {"duplicate_with_keys": "duplicate", "tile_ranges": "ranges", "tile_sort_long": "tile_sort"}
             base = ("surfel_" if surfel and name in ("preprocess_fwd", "preprocess_bwd", "render_fwd", "render_bwd") else "") \
                 + alias.get(name, name)
