@@ -990,7 +990,8 @@ def main():
                     moved += vpg * n * 64
                 roofline.update(path_bytes_step_measured=int(moved),
                                 path_frac_measured=round(moved / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
-            # K6 / K7 are VALU-issue bound, not HBM bound: pixel-Gaussian evaluations and VALU issue rate
+            # K6 / K7 are not HBM bound: K6 sits against the VALU issue rate, K7 against the VALU issue rate AND the
+            # device's float-atomic line rate (atomic_frac below): pixel-Gaussian evaluations, VALU instructions, atomic lines
             if pair_views:
                 pairs = sum(pair_views) / len(pair_views)
                 roofline.update(pairs_per_view=int(pairs), pairs_per_s=round(2 * pairs * views_per_sec / world, 1),
