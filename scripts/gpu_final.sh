@@ -49,8 +49,8 @@ b c5_shell --workload c5 --layout shell --no-cpu-baseline
 b c3step_shell --workload c3step --layout shell --steps 6 --warmup 2
 GDR_GROUP_VIEWS=0 timeout 600 python bench.py --per-view --unfused --no-cpu-baseline --no-roofline 2>/dev/null | python -c "import json,sys; d=json.load(sys.stdin); print('c4 per-view, render groups OFF', d['value'])"
 for wl in c4 c3 c2 c5; do
-  (cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$wl -o $wl -- python $R/bench.py --workload $wl --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-per-view-leg > $O/prof_$wl.log 2>&1)
-  f=$(find $O/prof_$wl -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/${TAG}_${wl}_kernel_stats.csv && python scripts/stats_print.py $f 3 8
+  (cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$wl -o $wl -- python $R/bench.py --workload $wl --steps 8 --warmup 12 --no-cpu-baseline --no-roofline --no-per-view-leg > $O/prof_$wl.log 2>&1)   # (20 steps: launches 8-11 of a shape time the two K7 kernels, the choice serves from launch 12)
+  f=$(find $O/prof_$wl -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/${TAG}_${wl}_kernel_stats.csv && python scripts/stats_print.py $f 20 8
   rm -rf $O/prof_$wl
 done
 echo "--- kernel timeline of a C4 step + idle gaps"
