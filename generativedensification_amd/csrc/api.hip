@@ -1,6 +1,8 @@
 // api.hip — the C ABI of libgdr_hip.so (include/gdr.h): argument checking, workspace
 // carving and stage sequencing.  Host code only; all kernels live in preprocess.hip,
-// binning.hip and render.hip.  Nothing here allocates device memory or keeps state.
+// binning.hip and render.hip.  Nothing here allocates device memory; the only state kept between calls is the per-scene-shape
+// history (duplicates per Gaussian and launch-size feedback behind gdr_view_plan_for, the K7 variant behind gdr_k7_tune_*) and
+// small pools of pinned host words and events.
 #include <stdio.h>
 #include <string.h>
 
@@ -61,7 +63,8 @@ static inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a
 // an 8x4 area saves lines and costs iterations, and which side wins depends on the scene (C2 -16 %, object-like scenes and
 // sub-pixel Gaussians +3-30 %).  Results are the same sums in another order.  Per (device, N bucket, image size, views per
 // launch, entry): four consecutive launches are timed with events (rows / pairs / rows / pairs, the better try of each), first
-// after the shape's first kK7First launches and then every kK7Period launches, and the faster variant (by > 3 %) serves until the next round.  gdr_k7_tune_override pins a variant (tests, A/B).
+// after the shape's first kK7First launches and then every kK7Period launches, and the faster variant (by > 3 %) serves until
+// the next round.  gdr_k7_tune_override pins a variant (tests, A/B).
 struct K7Tune {
     float us[2] = {0.f, 0.f};      // this round's best time per variant (0 = not in yet; negated once the round is decided)
     uint32_t calls = 0;
