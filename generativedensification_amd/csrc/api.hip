@@ -364,8 +364,17 @@ int gdr_preprocess_forward(const gdr_settings* s, const gdr_inputs* in, const gd
 // size, N and workspace shape.  Default: direct tile binning (count / scan / scatter) -> tile order -> per-tile LDS depth
 // sort.  Without a count matrix (gdr_binning_carve, or > 16384 tiles): duplicate + stable radix partition on the tile
 // bits -> ranges -> the same tile order and sort.  global_sort: one stable LSD radix sort over all key bits.
+// stages (direct tile binning only; anything else runs whole under bit 0): 1 = count, scan, tile order; 2 = scatter; 4 = per-tile
+// sort.  gdr_forward_views issues the stages of its views breadth-first — stage by stage over the views' streams — so that
+// the last view's chain does not start a whole chain's worth of launches (9 x ~4 us of host time per view) after the first.
+static bool binning_is_direct(const gdr_settings* s, const gdr_binning* bin) {
+    const int tiles = tile_grid_x(s->image_width) * tile_grid_y(s->image_height);
+    return !bin->global_sort && tiles <= GDR_BIN_MAX_TILES && bin->tile_hist && bin->hist_width > 0 &&
+           bin->hist_tiles >= (tiles + 63) / 64 * 64;
+}
 static int binning_stage_views(int V, const gdr_settings* s, int32_t N, const gdr_geom* geoms, gdr_binning* bins,
-                               const gdr_image* imgs, const uint64_t* D, const int32_t* const* radii, hipStream_t st) {
+                               const gdr_image* imgs, const uint64_t* D, const int32_t* const* radii, hipStream_t st,
+                               int stages = 7) {
     int rc;
     const int W = s->image_width, H = s->image_height;
     const int tiles = tile_grid_x(W) * tile_grid_y(H);
@@ -389,7 +398,11 @@ static int binning_stage_views(int V, const gdr_settings* s, int32_t N, const gd
     fill_bin_views(&vs, V, geoms, bins, imgs, D, radii);
     int sorted = 0;
     bool from_totals = false;
-    if (direct && (N == 0 || dmax == 0)) {   // nothing to bin: only the ranges are cleared (ranges_clear inside)
+    if (!(stages & 1)) {      // a later stage of the direct path: the state stage 1 left
+        if (!direct) return GDR_OK;
+        from_totals = !(N == 0 || dmax == 0);
+        for (int v = 0; v < V; ++v) vs.v[v].from_totals = from_totals ? 1 : 0;
+    } else if (direct && (N == 0 || dmax == 0)) {   // nothing to bin: only the ranges are cleared (ranges_clear inside)
         e = launch_duplicate_views(vs, V, 0, W, H, st);
         if (e != hipSuccess) return hip_fail("ranges_clear", e);
     } else if (direct) {
@@ -409,14 +422,18 @@ static int binning_stage_views(int V, const gdr_settings* s, int32_t N, const gd
         if (e != hipSuccess) return hip_fail("ranges", e);
         if ((rc = debug_sync(s, "ranges", st))) return rc;
     }
-    e = launch_tile_order_views(vs, V, tiles, st);  // (totals -> ranges first;) longest list first: launch order of tile_sort, K6, K7
-    if (e != hipSuccess) return hip_fail("tile_order", e);
-    if ((rc = debug_sync(s, "tile_order", st))) return rc;
-    if (from_totals) {
+    if (!direct) stages = 7;
+    if (stages & 1) {
+        e = launch_tile_order_views(vs, V, tiles, st);  // (totals -> ranges first;) longest list first: launch order of tile_sort, K6, K7
+        if (e != hipSuccess) return hip_fail("tile_order", e);
+        if ((rc = debug_sync(s, "tile_order", st))) return rc;
+    }
+    if ((stages & 2) && from_totals) {
         e = launch_tile_scatter(vs, V, N, W, H, st);
         if (e != hipSuccess) return hip_fail("tile_scatter", e);
         if ((rc = debug_sync(s, "tile_scatter", st))) return rc;
     }
+    if (!(stages & 4)) return GDR_OK;
     if (!global_sort) {  // per-tile LDS depth sort of the partitioned lists
         e = launch_tile_sort_views(vs, V, sorted, tiles, direct, st);
         if (e != hipSuccess) return hip_fail("tile_sort", e);
@@ -1292,19 +1309,41 @@ int gdr_forward_views(int32_t V, const gdr_settings* s, const gdr_inputs* in, co
     if (rc) return rc;
     const uint64_t key = shape_key(N, H, W, 0);
     const ShapeHints hn = shape_hints(key, N, opts);
-    auto chain = [&](int v, hipStream_t st, uint64_t D, bool deferred) -> int {
+    // stage: 0 = the whole chain of a view; 1 / 2 / 4 = one binning stage (binning_stage_views); 8 = K6
+    auto chain = [&](int v, hipStream_t st, uint64_t D, bool deferred, int stage) -> int {
         gdr_view_state& vs = states[v];
-        vs.bin.global_sort = (opts && opts->global_sort) ? 1 : 0;
-        if (opts && opts->deep_max_busy >= 0) vs.bin.deep_max_busy = opts->deep_max_busy;
-        if (opts && opts->deep_min_mean >= 0) vs.bin.deep_min_mean = opts->deep_min_mean;
-        vs.bin.hint_long = hn.hint_long; vs.bin.hint_medium = hn.hint_medium; vs.bin.hint_no_deep = hn.hint_no_deep;
-        vs.bin.stats_out = hn.stats ? hn.stats + 4 * (v < kStatViews ? v : kStatViews - 1) : nullptr;
-        vs.bin.d_dev = deferred ? vs.geom.num_rendered : nullptr;
-        int r = binning_stage(&s[v], N, &vs.geom, &vs.bin, &vs.img, D, outs[v].radii, st);
-        if (r) return r;
+        if (stage == 0 || stage == 1) {
+            vs.bin.global_sort = (opts && opts->global_sort) ? 1 : 0;
+            if (opts && opts->deep_max_busy >= 0) vs.bin.deep_max_busy = opts->deep_max_busy;
+            if (opts && opts->deep_min_mean >= 0) vs.bin.deep_min_mean = opts->deep_min_mean;
+            vs.bin.hint_long = hn.hint_long; vs.bin.hint_medium = hn.hint_medium; vs.bin.hint_no_deep = hn.hint_no_deep;
+            vs.bin.stats_out = hn.stats ? hn.stats + 4 * (v < kStatViews ? v : kStatViews - 1) : nullptr;
+            vs.bin.d_dev = deferred ? vs.geom.num_rendered : nullptr;
+        }
+        if (stage != 8) {
+            const uint64_t Dv = D;
+            const int32_t* rad = outs[v].radii;
+            int r = binning_stage_views(1, &s[v], N, &vs.geom, &vs.bin, &vs.img, &Dv, &rad, st, stage ? stage : 7);
+            if (r || stage) return r;
+        }
         if (loss_mode == 1) return gdr_composite_forward_loss(&s[v], &vs.geom, &vs.bin, &vs.img, &outs[v], targets[v], w_depth, w_alpha, losses + v, (void*)st);
         if (loss_mode == 2) return gdr_composite_forward_lossgrad(&s[v], &vs.geom, &vs.bin, &vs.img, targets[v], go_scale, losses + v, outs[v].color, (void*)st);
         return gdr_composite_forward(&s[v], &vs.geom, &vs.bin, &vs.img, &outs[v], (void*)st);
+    };
+    // the views' chains, issued breadth-first over their streams (stage by stage) when there is more than one stream: a chain
+    // is 9 launches = ~40 us of host time, and issued view after view the last of 8 views starts 300 us after the first
+    // (same-box A/B, profiles/r04_ab_k7_blocks.txt section 15: object-like C3 scenes +5 %, the reference's per-sample sequence on
+    // them +3 %, uniform scenes +-0)
+    auto issue = [&](bool deferred) -> int {
+        int r = 0;
+        if (ns <= 1) {
+            for (int v = 0; v < V && !r; ++v) r = chain(v, (hipStream_t)streams[v % ns], deferred ? pv.capacity : d_host[(size_t)v], deferred, 0);
+            return r;
+        }
+        for (int stage = 1; stage <= 8 && !r; stage <<= 1)
+            for (int v = 0; v < V && !r; ++v)
+                r = chain(v, (hipStream_t)streams[v % ns], deferred ? pv.capacity : d_host[(size_t)v], deferred, stage);
+        return r;
     };
     auto join = [&]() -> hipError_t {      // the caller's stream continues only after every view is rendered
         hipError_t er = hipSuccess;
@@ -1318,7 +1357,7 @@ int gdr_forward_views(int32_t V, const gdr_settings* s, const gdr_inputs* in, co
     };
     bool fits = pv.have_binning != 0;
     if (pv.have_binning && pv.deferred) {     // device-sized: every chain is enqueued without waiting for K1
-        for (int v = 0; v < V && !rc; ++v) rc = chain(v, (hipStream_t)streams[v % ns], pv.capacity, true);
+        rc = issue(true);
         e = join();
         const int wrc = gdr_host_copy_wait(ticket);
         if (rc) return rc;
@@ -1330,7 +1369,7 @@ int gdr_forward_views(int32_t V, const gdr_settings* s, const gdr_inputs* in, co
         if (rc) return rc;
         for (int v = 0; v < V; ++v) { d_host[(size_t)v] = pin[v]; fits = fits && pin[v] <= pv.capacity; }
         if (fits) {
-            for (int v = 0; v < V && !rc; ++v) rc = chain(v, (hipStream_t)streams[v % ns], d_host[(size_t)v], false);
+            rc = issue(false);
             e = join();
             if (rc) return rc;
             if (e != hipSuccess) return hip_fail("forward_views: stream join", e);
