@@ -1340,27 +1340,9 @@ int gdr_forward_views(int32_t V, const gdr_settings* s, const gdr_inputs* in, co
             for (int v = 0; v < V && !r; ++v) r = chain(v, (hipStream_t)streams[v % ns], deferred ? pv.capacity : d_host[(size_t)v], deferred, 0);
             return r;
         }
-        static const bool joint_k6 = getenv("GDR_K6_JOINT") != nullptr;   // (experiment)
-        for (int stage = 1; stage <= (joint_k6 ? 4 : 8) && !r; stage <<= 1)
+        for (int stage = 1; stage <= 8 && !r; stage <<= 1)
             for (int v = 0; v < V && !r; ++v)
                 r = chain(v, (hipStream_t)streams[v % ns], deferred ? pv.capacity : d_host[(size_t)v], deferred, stage);
-        if (joint_k6 && !r) {   // every chain's binning joins the caller's stream, then K6 of <= 8 views per launch
-            hipError_t er = hipSuccess;
-            for (int k = 1; k < ns && er == hipSuccess; ++k) {
-                hipEvent_t done = event_get();
-                er = hipEventRecord(done, (hipStream_t)streams[k]);
-                if (er == hipSuccess) er = hipStreamWaitEvent(s0, done, 0);
-                event_put(done);
-            }
-            if (er != hipSuccess) return hip_fail("forward_views: stream join", er);
-            for (int lo = 0; lo < V && !r; lo += GDR_MAX_VIEWS) {
-                const int n = V - lo < GDR_MAX_VIEWS ? V - lo : GDR_MAX_VIEWS;
-                gdr_geom g[GDR_MAX_VIEWS]; gdr_binning b[GDR_MAX_VIEWS]; gdr_image im[GDR_MAX_VIEWS];
-                for (int k = 0; k < n; ++k) { g[k] = states[lo + k].geom; b[k] = states[lo + k].bin; im[k] = states[lo + k].img; }
-                r = gdr_composite_forward_views(n, s + lo, g, b, im, outs + lo, loss_mode, targets ? targets + lo : nullptr, w_depth,
-                                                w_alpha, go_scale, losses ? losses + lo : nullptr, 1, (void*)s0);
-            }
-        }
         return r;
     };
     auto join = [&]() -> hipError_t {      // the caller's stream continues only after every view is rendered
