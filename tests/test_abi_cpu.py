@@ -228,6 +228,13 @@ def test_view_plan_and_shape_history_without_gpu():
     lib.gdr_view_history_reset()
     assert lib.gdr_view_history_get(N, H, W, 0) == 0.0
     assert lib.gdr_view_plan_for(-1, H, W, 0, 0, None, C.byref(plan)) == -1
+    # the K7 choice of a shape (v15): nothing launched yet -> an error with a message, never a default; the override is a
+    # process-wide setting that takes any value (-1 / 0 / 1) without device work
+    ch, u0, u1 = C.c_int32(-7), C.c_float(-1), C.c_float(-1)
+    assert lib.gdr_k7_tune_get(N, H, W, 1, 0, C.byref(ch), C.byref(u0), C.byref(u1)) == -1
+    assert b"k7_tune_get" in lib.gdr_last_error() and ch.value == -7
+    for mode in (0, 1, -1):
+        lib.gdr_k7_tune_override(mode)
 
 
 def test_debug_knobs_map_to_view_opts():
