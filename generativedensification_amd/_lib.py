@@ -19,7 +19,8 @@ LIB_PATH = os.environ.get("GDR_LIB_PATH") or os.path.join(_HERE, "lib", "libgdr_
 GDR_OK = 0
 GDR_IN_RAW_OPACITY, GDR_IN_RAW_SCALES, GDR_IN_RAW_ROTATIONS, GDR_IN_NO_DEPTH_TO_MEAN = 1, 2, 4, 8
 GDR_MAX_VIEWS = 8
-ABI_VERSION = 15
+ABI_VERSION = 16
+GDR_SAME_AS_MAX, GDR_REUSE_MAX = 8, 32
 GDR_DEFAULT_SEG_LEN = 256
 GDR_ERR_WORKSPACE = -4
 
@@ -87,8 +88,8 @@ class GdrViewOpts(C.Structure):
 
 
 class GdrSameAs(C.Structure):
-    _fields_ = [("n", C.c_int32), ("reserved", C.c_int32), ("a", C.c_void_p * 4), ("b", C.c_void_p * 4),
-                ("n_bytes", C.c_uint64 * 4)]
+    _fields_ = [("n", C.c_int32), ("reserved", C.c_int32), ("a", C.c_void_p * GDR_SAME_AS_MAX),
+                ("b", C.c_void_p * GDR_SAME_AS_MAX), ("n_bytes", C.c_uint64 * GDR_SAME_AS_MAX)]
 
 
 class GdrViewState(C.Structure):
@@ -170,6 +171,8 @@ _PROTOS = {
     "gdr_forward_view": (C.c_int, [C.POINTER(GdrSettings), C.POINTER(GdrInputs), C.POINTER(GdrViewPlan), C.c_void_p,
                                    C.POINTER(GdrViewOpts), C.POINTER(GdrSameAs), C.POINTER(GdrOutputs),
                                    C.POINTER(GdrViewState), C.c_void_p]),
+    "gdr_view_reuse_probe": (C.c_int, [C.POINTER(GdrSettings), C.c_int32, C.POINTER(GdrSettings), C.POINTER(GdrSameAs), C.c_void_p,
+                                       C.POINTER(C.c_int32), C.POINTER(C.c_uint32), C.c_void_p]),
     "gdr_views_plan_for": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_uint64, C.POINTER(GdrViewOpts),
                                      C.POINTER(GdrViewsPlan)]),
     "gdr_forward_views": (C.c_int, [C.c_int32, C.POINTER(GdrSettings), C.POINTER(GdrInputs), C.POINTER(GdrViewsPlan), C.c_void_p,

@@ -1132,7 +1132,7 @@ int forward_view_impl(const gdr_settings* s, int N, int surfel, const gdr_view_p
     hipError_t e = hipMemsetAsync(v.geom.num_rendered, 0, 2 * sizeof(uint32_t), st);   // [count, same_as verdict]
     if (e != hipSuccess) return hip_fail("memset num_rendered", e);
     if (same && same->n > 0) {
-        if (same->n > GDR_DIFFER_MAX) { set_error("forward_view: more than 4 same_as pairs", hipSuccess); return GDR_ERR_INVALID_ARG; }
+        if (same->n > GDR_DIFFER_MAX) { set_error("forward_view: more than GDR_SAME_AS_MAX same_as pairs", hipSuccess); return GDR_ERR_INVALID_ARG; }
         e = launch_words_differ_multi(same->n, same->a, same->b, same->n_bytes, v.geom.num_rendered + 1, st);
         if (e != hipSuccess) return hip_fail("words_differ_multi", e);
     }
@@ -1206,6 +1206,61 @@ int gdr_forward_view(const gdr_settings* s, const gdr_inputs* in, const gdr_view
         [&](const gdr_geom& g, const gdr_binning& b, const gdr_image& im) -> int {
             return gdr_composite_forward(s, &g, &b, &im, out, stream);
         });
+}
+
+int gdr_view_reuse_probe(const gdr_settings* s, int32_t n, const gdr_settings* candidates, const gdr_same_as* same,
+                         uint32_t* scratch, int32_t* match, uint32_t* differ, void* stream) {
+    static_assert(GDR_DIFFER_MAX == GDR_SAME_AS_MAX, "gdr_same_as arrays");
+    static_assert(GDR_REUSE_MAX + 1 <= kPinWords, "reuse probe read-back buffer");
+    if (!s || n < 0 || n > GDR_REUSE_MAX || (n && !candidates) || !scratch || !match || !differ || !s->bg || !s->viewmatrix ||
+        !s->projmatrix || (same && (same->n < 0 || same->n > GDR_SAME_AS_MAX))) {
+        set_error("view_reuse_probe: bad argument", hipSuccess);
+        return GDR_ERR_INVALID_ARG;
+    }
+    *match = -1;
+    *differ = 0;
+    // the host half of the 12 fields; a candidate without a campos tensor only matches a call without one
+    uint64_t eligible = 0;
+    gdr_settings cur = *s;
+    gdr_settings cand[GDR_REUSE_MAX];
+    if (!cur.campos) cur.campos = cur.bg;
+    for (int c = 0; c < n; ++c) {
+        const gdr_settings& k = candidates[c];
+        cand[c] = k;
+        if (!k.bg || !k.viewmatrix || !k.projmatrix || (k.campos == nullptr) != (s->campos == nullptr)) continue;
+        if (!cand[c].campos) cand[c].campos = cand[c].bg;
+        if (k.image_height == s->image_height && k.image_width == s->image_width && k.tanfovx == s->tanfovx &&
+            k.tanfovy == s->tanfovy && k.scale_modifier == s->scale_modifier && k.sh_degree == s->sh_degree &&
+            (k.prefiltered != 0) == (s->prefiltered != 0) && (k.debug != 0) == (s->debug != 0))
+            eligible |= 1ull << c;
+    }
+    const bool pairs = same && same->n > 0;
+    if (!eligible && !pairs) return GDR_OK;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(scratch, 0, (GDR_REUSE_MAX + 1) * sizeof(uint32_t), st);
+    if (e != hipSuccess) return hip_fail("view_reuse_probe: memset", e);
+    if (pairs) {
+        e = launch_words_differ_multi(same->n, same->a, same->b, same->n_bytes, scratch + GDR_REUSE_MAX, st);
+        if (e != hipSuccess) return hip_fail("words_differ_multi", e);
+    }
+    if (eligible) {
+        e = launch_settings_match(&cur, n, cand, eligible, scratch, st);
+        if (e != hipSuccess) return hip_fail("settings_match", e);
+    }
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    uint32_t* pin = pin_get(dev);
+    if (!pin) return hip_fail("hipHostMalloc", hipErrorOutOfMemory);
+    HostCopyTicket* ticket = nullptr;
+    int rc = gdr_host_copy_begin(pin, scratch, (GDR_REUSE_MAX + 1) * sizeof(uint32_t), stream, (void**)&ticket);
+    if (!rc) rc = gdr_host_copy_wait(ticket);
+    if (!rc) {
+        for (int c = 0; c < n; ++c)
+            if (((eligible >> c) & 1ull) && pin[c]) { *match = c; break; }
+        *differ = pin[GDR_REUSE_MAX];
+    }
+    pin_put(pin, dev);
+    return rc;
 }
 
 double gdr_view_history_get(int32_t N, int32_t H, int32_t W, int32_t surfel) {

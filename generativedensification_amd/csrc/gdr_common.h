@@ -208,8 +208,12 @@ hipError_t launch_knn_mean_dist2(const float* pts_sorted, int N, const float* bb
 
 size_t sort_hist_bytes(uint64_t D);
 hipError_t launch_words_differ(const void* a, const void* b, uint64_t n_bytes, uint32_t* flag, hipStream_t st);
-#define GDR_DIFFER_MAX 4
+#define GDR_DIFFER_MAX 8   /* = the arrays of gdr_same_as (include/gdr.h) */
 hipError_t launch_words_differ_multi(int n, const void* const* a, const void* const* b, const uint64_t* n_bytes, uint32_t* flag,
                                      hipStream_t st);
+// out[c] = 1 if the bg / viewmatrix / projmatrix / campos words of candidate c equal those of `cur` bit for bit (c < n <=
+// GDR_REUSE_MAX; candidates whose bit in `eligible` is clear are not read: out[c] = 0)
+hipError_t launch_settings_match(const gdr_settings* cur, int n, const gdr_settings* cand, uint64_t eligible, uint32_t* out,
+                                 hipStream_t st);
 
 }  // namespace gdr

@@ -36,7 +36,44 @@ __global__ __launch_bounds__(GDR_BLOCK) void words_differ_multi_kernel(const Dif
     if (__ballot(diff) != 0ull && (threadIdx.x & 63u) == 0u) atomicOr(flag, 1u);
 }
 
+// the device tensors of one settings record as words: bg (3), viewmatrix (16), projmatrix (16), campos (3)
+struct SettingsWords { const uint32_t* bg; const uint32_t* view; const uint32_t* proj; const uint32_t* campos; };
+struct MatchArgs { SettingsWords cur; SettingsWords cand[GDR_REUSE_MAX]; uint64_t eligible; };
+
+__device__ __forceinline__ const uint32_t* settings_word(const SettingsWords& w, uint32_t t) {
+    return t < 3u ? w.bg + t : t < 19u ? w.view + (t - 3u) : t < 35u ? w.proj + (t - 19u) : w.campos + (t - 35u);
+}
+
+// one wave per candidate; lane t < 38 compares word t (scalar loads: the tensors may sit at any 4-byte alignment —
+// `batch['bg_color'][i, j]` is a 12-byte slice of a larger tensor)
+__global__ __launch_bounds__(64) void settings_match_kernel(const MatchArgs a, uint32_t* __restrict__ out) {
+    const uint32_t c = blockIdx.x, t = threadIdx.x;
+    bool diff = false;
+    if ((a.eligible >> c) & 1ull) {
+        if (t < 38u) diff = *settings_word(a.cur, t) != *settings_word(a.cand[c], t);
+    } else {
+        diff = true;
+    }
+    const bool any = __ballot(diff) != 0ull;
+    if (t == 0u) out[c] = any ? 0u : 1u;
+}
+
 }  // namespace
+
+hipError_t launch_settings_match(const gdr_settings* cur, int n, const gdr_settings* cand, uint64_t eligible, uint32_t* out,
+                                 hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    MatchArgs a;
+    auto words = [](const gdr_settings& s) {
+        return SettingsWords{(const uint32_t*)s.bg, (const uint32_t*)s.viewmatrix, (const uint32_t*)s.projmatrix,
+                             (const uint32_t*)s.campos};
+    };
+    a.cur = words(*cur);
+    for (int c = 0; c < GDR_REUSE_MAX; ++c) a.cand[c] = c < n ? words(cand[c]) : a.cur;
+    a.eligible = eligible;
+    hipLaunchKernelGGL(settings_match_kernel, dim3(n), dim3(64), 0, st, a, out);
+    return hipGetLastError();
+}
 
 hipError_t launch_words_differ_multi(int n, const void* const* a, const void* const* b, const uint64_t* n_bytes, uint32_t* flag,
                                      hipStream_t st) {

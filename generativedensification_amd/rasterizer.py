@@ -26,6 +26,7 @@ from torch import nn
 
 from . import _debug as K
 from . import _lib as L
+from . import viewgroup      # at module import (its torch probe must not wait for a first call under no_grad / in a backward)
 
 
 class GaussianRasterizationSettings(NamedTuple):
@@ -510,7 +511,6 @@ class _RasterizeGaussians(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_color, grad_radii, grad_depth, grad_alpha):
-        from . import viewgroup
         viewgroup.note_backward()
         g = backward_raw(ctx.state, _saved_inputs(ctx), ctx.raster_settings, ctx.radii, grad_color, grad_depth,
                          grad_alpha)
@@ -1066,7 +1066,6 @@ def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales,
     """The reference boundary.  Calls that are provably handed the same Gaussians as earlier ones (the per-view loops of
     network.py:827-838, 848-856, 964-972) join a render group: one preprocess-backward for all of them (viewgroup.py);
     everything else is one independent autograd node per call."""
-    from . import viewgroup
     if not torch.is_grad_enabled():     # evaluation (evaluation.py:169-193, tools/meshExtractor.py:73-106): no autograd node at all
         return forward_raw(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings)[:4]
     viewgroup.note_forward()

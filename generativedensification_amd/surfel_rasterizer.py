@@ -22,6 +22,7 @@ from .rasterizer import (GaussianRasterizationSettings, _f32, _ptr, _require_hip
                          _stream)
 from . import _debug as _K
 from . import rasterizer as _R
+from . import viewgroup
 
 
 class _SurfelState(_State):
@@ -157,7 +158,6 @@ class _RasterizeSurfels(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_color, grad_radii, grad_allmap):
-        from . import viewgroup
         viewgroup.note_backward()
         if grad_color is None:
             grad_color = torch.zeros(3, ctx.state.H, ctx.state.W, dtype=torch.float32, device=ctx.radii.device)
@@ -531,7 +531,6 @@ def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales,
     """The reference boundary (/root/reference/lightning/renderer_2dgs.py:224-234).  Calls that are provably handed the same
     surfels as earlier ones join a render group — one K9s for all of them (viewgroup.py, round 4); everything else is one
     independent autograd node per call."""
-    from . import viewgroup
     if not torch.is_grad_enabled():     # evaluation: no autograd node at all
         return forward_raw(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings)[:3]
     viewgroup.note_forward()

@@ -40,8 +40,9 @@ the activation tensors of LATER calls (their `sigmoid(opacity)` ...) receive non
 hooks or `retain_grad()` is never grouped.  A caller that back-propagates after every single view gains nothing from
 groups and pays their bookkeeping: after two single-view passes in a row grouping pauses until the caller renders several
 views per pass again.  The mechanism leans on two private pieces of torch — `torch._C._current_graph_task_id` and the
-`_saved_*` attributes of autograd nodes; both are probed at import, and if either is missing every call is an ordinary
-node (one warning).  GDR_GROUP_VIEWS=0 switches grouping off.
+`_saved_*` attributes of autograd nodes; both are probed at import (with grad mode forced on for the probe: the import may
+happen under no_grad / inference_mode or inside a backward pass) and again on the first eligible call if that probe could
+not run; if either is missing every call is an ordinary node (one warning).  GDR_GROUP_VIEWS=0 switches grouping off.
 """
 from __future__ import annotations
 
@@ -74,42 +75,76 @@ _OPS = {
 
 
 def _probe_torch() -> str:
-    """'' if the private torch pieces this module leans on behave as expected, else what is missing."""
+    """'' if the private torch pieces this module leans on behave as expected, else what is missing.  The probe builds a
+    tiny CPU graph, so it forces grad mode ON for itself: the package's first import (and its first call) may well happen
+    under `no_grad` / `inference_mode` — Lightning's sanity validation runs before the first training step
+    (/root/reference/train_lightning.py:70-85 leaves num_sanity_val_steps at its default, lightning/system.py:47-53) — or
+    inside a backward pass, where `grad_fn` of everything is None (round 4 read that as "unknown torch" and switched render
+    groups off for the life of the process)."""
     if not hasattr(torch._C, "_current_graph_task_id"):
         return "torch._C._current_graph_task_id is missing"
     try:
-        x = torch.ones(2, 4, requires_grad=True)
-        probes = (torch.sigmoid(x), torch.exp(x), torch.nn.functional.normalize(x), x[0])
-        seen = set()
-        for t in probes:
-            stack = [t.grad_fn]
-            while stack:
-                fn = stack.pop()
-                name = type(fn).__name__
-                if name == "AccumulateGrad":
-                    if fn.variable is not x:
-                        return "AccumulateGrad.variable does not return the leaf"
-                    continue
-                if name not in _OPS:
-                    return f"unknown autograd node {name} behind a reference activation"
-                for a in _OPS[name]:
-                    getattr(fn, a)
-                seen.add(name)
-                stack += [n for n, _ in fn.next_functions if n is not None]
-        if not {"SigmoidBackward0", "ExpBackward0", "DivBackward0", "SelectBackward0"} <= seen:
-            return "the reference activations map to other autograd nodes than expected"
-        if torch._C._current_graph_task_id() != -1:
-            return "_current_graph_task_id() outside a backward pass is not -1"
+        with torch.inference_mode(False), torch.enable_grad():
+            x = torch.ones(2, 4, requires_grad=True)
+            probes = (torch.sigmoid(x), torch.exp(x), torch.nn.functional.normalize(x), x[0])
+            seen = set()
+            for t in probes:
+                if t.grad_fn is None:
+                    return "TRANSIENT: no autograd graph is recorded here although grad mode was switched on"
+                stack = [t.grad_fn]
+                while stack:
+                    fn = stack.pop()
+                    name = type(fn).__name__
+                    if name == "AccumulateGrad":
+                        if fn.variable is not x:
+                            return "AccumulateGrad.variable does not return the leaf"
+                        continue
+                    if name not in _OPS:
+                        return f"unknown autograd node {name} behind a reference activation"
+                    for a in _OPS[name]:
+                        getattr(fn, a)
+                    seen.add(name)
+                    stack += [n for n, _ in fn.next_functions if n is not None]
+            if not {"SigmoidBackward0", "ExpBackward0", "DivBackward0", "SelectBackward0"} <= seen:
+                return "the reference activations map to other autograd nodes than expected"
+        if not isinstance(torch._C._current_graph_task_id(), int):
+            return "_current_graph_task_id() does not return an int"
     except Exception as exc:      # noqa: BLE001 — anything unexpected means: do not lean on it
         return f"{type(exc).__name__}: {exc}"
     return ""
 
 
-_PROBLEM = _probe_torch() if GROUP_VIEWS else ""
-if _PROBLEM:
-    warnings.warn("generativedensification_amd: render groups are off — this torch build does not match what they rely on "
-                  f"({_PROBLEM}); every rasterizer call is an independent autograd node (correct, slower backward).")
-    GROUP_VIEWS = False
+# State of the probe: None = not probed yet (or the last probe hit a TRANSIENT condition: it is repeated on the next eligible
+# call), '' = fine, anything else = what is missing (render groups are off for good, one warning).  An import-time
+# condition is never permanent by itself: `eligible` re-probes on the first call that could open a group.
+_PROBLEM = None
+_PROBES_LEFT = 4
+
+
+def _ensure_probed() -> bool:
+    """True if render groups may be used.  Cheap after the first successful probe."""
+    global _PROBLEM, _PROBES_LEFT, GROUP_VIEWS
+    if _PROBLEM == "":
+        return True
+    if not GROUP_VIEWS:
+        return False
+    with _LOCK:
+        if _PROBLEM is None and _PROBES_LEFT > 0:
+            _PROBES_LEFT -= 1
+            res = _probe_torch()
+            if res.startswith("TRANSIENT") and _PROBES_LEFT > 0:
+                return False              # this call is an ordinary node; the next one probes again
+            _PROBLEM = res
+            if _PROBLEM:
+                warnings.warn("generativedensification_amd: render groups are off — this torch build does not match what "
+                              f"they rely on ({_PROBLEM}); every rasterizer call is an independent autograd node (correct, "
+                              "slower backward).")
+                GROUP_VIEWS = False
+        return _PROBLEM == ""
+
+
+if GROUP_VIEWS:
+    _ensure_probed()
 
 # ---- callers that back-propagate after every single view (no gain, only bookkeeping): pause grouping -------------------
 _calls_since_backward = 0
@@ -176,7 +211,7 @@ def _signature(t: torch.Tensor, hold: list):
 
 class _Group:
     __slots__ = ("path", "key", "hold", "orig", "f32", "hub_out", "token", "one", "n_views", "pending", "dev", "N", "M", "lock",
-                 "closed", "__weakref__")
+                 "closed", "cache", "hub_node", "shape", "__weakref__")
 
     def __init__(self, path, key, hold, orig, dev):
         self.path, self.key, self.hold, self.orig, self.dev = path, key, hold, orig, dev
@@ -186,6 +221,9 @@ class _Group:
         self.pending = {}
         self.lock = threading.RLock()
         self.closed = False       # set by the hub's backward: its graph may be freed, later calls open a new group
+        self.cache = []           # forwards of this group's views a later call with equal settings may be handed again (_reuse_*)
+        self.hub_node = None      # the hub's autograd node (does the running backward pass reach it? _GroupView.backward)
+        self.shape = None         # key of the reuse history (_REUSE_HIST)
 
 
 def _observed(t: torch.Tensor) -> bool:
@@ -195,7 +233,7 @@ def _observed(t: torch.Tensor) -> bool:
 
 def eligible(means3D, sh, colors_precomp, opacities, scales, rotations, precomp) -> bool:
     """Can this call join / open a render group?  (precomp: cov3D_precomp / transMat_precomp)"""
-    if not (GROUP_VIEWS and torch.is_grad_enabled() and means3D.is_cuda and sh.numel() and not colors_precomp.numel()
+    if not (GROUP_VIEWS and torch.is_grad_enabled() and _ensure_probed() and means3D.is_cuda and sh.numel() and not colors_precomp.numel()
             and scales.numel() and rotations.numel() and not precomp.numel() and means3D.shape[0] > 0):
         return False
     ts = (means3D, sh, opacities, scales, rotations)
@@ -233,7 +271,80 @@ def _same_as_pairs(grp, tensors, R):
             raise R.GroupMismatch("render group: equal provenance but different shapes")
         if t32.data_ptr() != ref.data_ptr():
             pairs.append((t32, ref))
+    if len(pairs) > L.GDR_SAME_AS_MAX:       # (cannot happen with five inputs; the struct's arrays are the limit)
+        raise R.GroupMismatch("render group: more same_as pairs than gdr_same_as holds")
     return pairs
+
+
+# ---- a view rendered twice (network.py:827-838, then 848-856 inside `vjp`: same Gaussians, same c2w / bg) ------------------
+# The group already proves "same Gaussians".  If the 12 settings fields are equal too, the forward of the earlier call is the
+# forward of this one bit for bit (K1, the binning and K6 are deterministic) and need not run again: the call gets copies of
+# the earlier images and a node that shares the earlier view's state for its K7.  The settings' device tensors are rebuilt
+# per call by the reference (MiniCam, `bg.to(device)`), so they are compared on the device — one small blocking native call
+# (gdr_view_reuse_probe, which also carries the group's same_as pairs).  A blocking call per render would tax every call of
+# a caller that never repeats a view, so WHICH calls probe is learned per scene shape and call index: an index probes when
+# it is new, when its last probe matched, and every 32nd time otherwise.
+REUSE_FORWARD = os.environ.get("GDR_REUSE_FORWARD", "1") != "0"
+_REUSE_HIST: dict = {}            # (path, H, W, sh_degree, bucket of N) -> {call index: [last probe matched, calls since]}
+_REUSE_STATS = {"probes": 0, "hits": 0}      # (tests, diagnostics)
+_SCRATCH: dict = {}               # device -> the probe's device words
+
+
+def _settings_versions(raster_settings):
+    rs = raster_settings
+    return tuple((t.data_ptr(), t._version) for t in (rs.bg, rs.viewmatrix, rs.projmatrix, rs.campos))
+
+
+def _reuse_should_probe(grp, j):
+    if not REUSE_FORWARD or j == 0 or not grp.cache:
+        return False
+    with _LOCK:
+        if len(_REUSE_HIST) > 256:
+            _REUSE_HIST.clear()
+        h = _REUSE_HIST.setdefault(grp.shape, {}).get(j)
+        if h is None or h[0]:
+            return True
+        h[1] += 1
+        if h[1] >= 32:
+            h[1] = 0
+            return True
+        return False
+
+
+def _reuse_probe(grp, j, raster_settings, same_as, R):
+    """(cache entry whose forward this call repeats or None, the same_as pairs were verified here).  Raises GroupMismatch if a
+    same_as pair differs."""
+    lib, dev = L.load(), grp.dev
+    cands = [e for e in grp.cache[-L.GDR_REUSE_MAX:]
+             if all(a._version == v for a, v in zip(e["outs"], e["out_versions"]))]       # outputs edited in place: not reusable
+    now = _settings_versions(raster_settings)
+    # a candidate built from the very same tensor (same memory) is only equal if that tensor was not written since
+    cands = [e for e in cands if all(p0 != p1 or v0 == v1 for (p0, v0), (p1, v1) in zip(e["set_versions"], now))]
+    keep: list = []
+    with torch.cuda.device(dev):
+        s = R._settings_struct(raster_settings, dev, keep)
+        same = None
+        if same_as:
+            same = L.GdrSameAs()
+            same.n = len(same_as)
+            for k, (t, ref) in enumerate(same_as):
+                same.a[k], same.b[k], same.n_bytes[k] = t.data_ptr(), ref.data_ptr(), t.numel() * 4
+            same = C.byref(same)
+        scratch = _SCRATCH.get(dev)
+        if scratch is None:
+            scratch = _SCRATCH[dev] = torch.zeros(L.GDR_REUSE_MAX + 1, dtype=torch.int32, device=dev)
+        c_arr = (L.GdrSettings * max(1, len(cands)))(*[e["s"] for e in cands])
+        match, differ = C.c_int32(-1), C.c_uint32(0)
+        L.check(lib.gdr_view_reuse_probe(C.byref(s), len(cands), c_arr, same, scratch.data_ptr(), C.byref(match), C.byref(differ),
+                                         R._stream()), "gdr_view_reuse_probe")
+    if differ.value:
+        raise R.GroupMismatch("render group: equal provenance, different values")
+    hit = cands[match.value] if match.value >= 0 else None
+    with _LOCK:
+        _REUSE_STATS["probes"] += 1
+        _REUSE_STATS["hits"] += hit is not None
+        _REUSE_HIST.setdefault(grp.shape, {})[j] = [hit is not None, 0]
+    return hit, True
 
 
 # ---- what differs between the two boundaries ---------------------------------------------------------------------------
@@ -379,6 +490,7 @@ class _Hub(torch.autograd.Function):
         with grp.lock:
             views = [grp.pending[j] for j in sorted(grp.pending) if grp.pending[j]["task"] == task]
             grp.pending.clear()           # (incl. K7 results of passes this hub was not part of)
+            grp.cache = []
         if not views:
             return (None,) * 6
         for t, v in zip(grp.orig, ctx.versions):
@@ -410,16 +522,41 @@ class _Hub(torch.autograd.Function):
         return (None, *grads)
 
 
+_WILL_EXECUTE = getattr(torch._C, "_will_engine_execute_node", None)
+
+
+def _hub_runs_in_this_pass(grp) -> bool:
+    """Does the running backward pass reach the group's hub (i.e. does anybody want the gradients of the Gaussians)?  Not in
+    `vjp(fn, screenspace_point)` (network.py:872: autograd.grad w.r.t. the carrier only) — the engine knows, and says so
+    through torch._C._will_engine_execute_node.  Unknown = yes."""
+    if _WILL_EXECUTE is None or grp.hub_node is None:
+        return True
+    try:
+        return bool(_WILL_EXECUTE(grp.hub_node))
+    except Exception:      # noqa: BLE001 — outside a backward pass, or a torch without the query
+        return True
+
+
 class _GroupView(torch.autograd.Function):
-    """One per call: ONE native forward call (K1 .. K6 of the view); K7 backward."""
+    """One per call: ONE native forward call (K1 .. K6 of the view) — or none, if the call repeats an earlier view of the
+    group (`hit`: that view's cache entry); K7 backward."""
 
     @staticmethod
-    def forward(ctx, grp, j, raster_settings, same_as, means2D, token, m, s, o, sc, r):
-        outs, st, keep_rest = grp.path.forward(grp, raster_settings, same_as)
+    def forward(ctx, grp, j, raster_settings, same_as, hit, means2D, token, m, s, o, sc, r):
+        if hit is None:
+            outs, st, keep_rest = grp.path.forward(grp, raster_settings, same_as)
+            if REUSE_FORWARD:
+                alias = tuple(t.detach() for t in outs)      # (no grad_fn: a cache that held the outputs themselves would close a
+                # reference cycle through the autograd graph — output -> node -> ctx -> group -> cache)
+                grp.cache.append(dict(s=keep_rest[-1], outs=alias, out_versions=tuple(a._version for a in alias), state=st,
+                                      keep_rest=keep_rest, set_versions=_settings_versions(raster_settings)))
+        else:
+            outs, st, keep_rest = tuple(t.clone() for t in hit["outs"]), hit["state"], hit["keep_rest"]
         ctx.grp, ctx.j, ctx.raster_settings, ctx.state, ctx.radii = grp, j, raster_settings, st, outs[1]
         ctx.keep_rest = list(keep_rest)
         ctx.means2D_shape, ctx.means2D_dtype = tuple(means2D.shape), means2D.dtype
         ctx.mark_non_differentiable(outs[1])
+        ctx.set_materialize_grads(False)      # an output the loss does not use arrives as None, not as a zero image
         return outs
 
     @staticmethod
@@ -428,13 +565,26 @@ class _GroupView(torch.autograd.Function):
         note_backward()
         grp, st = ctx.grp, ctx.state
         dev, N, path = grp.dev, grp.N, grp.path
+        hub_runs = _hub_runs_in_this_pass(grp)
+        from . import rasterizer as R
         with torch.cuda.device(dev):
             keep: list = []
             s = ctx.keep_rest[-1]       # the settings struct of the forward (its device tensors are in keep_rest too)
-            recs = torch.empty(N * path.floats, dtype=torch.float32, device=dev)   # one gradient record per Gaussian
-            st.bin.grad_rec_cleared = 0
-            path.k7(lib, s, N, st, grads, st.H, st.W, dev, recs, keep)
-            head = path.view_means2d(lib, s, N, st, ctx.radii, recs, dev)
+            if not hub_runs and path is _Path3D and grads[0] is not None and grads[2] is None and grads[3] is None:
+                # only the carrier's gradient is wanted and only the image carries one (the vjp of network.py:843-872): the
+                # mean2D-only K7 — 4 floats per Gaussian instead of the 13 of the full record, no record at all
+                gc = R._f32(grads[0], dev)
+                head = torch.zeros(N, 4, dtype=torch.float32, device=dev)
+                geom = st.geom
+                L.check(lib.gdr_render_backward_mean2d(C.byref(s), N, C.byref(geom), C.byref(st.bin), C.byref(st.img),
+                                                       gc.data_ptr(), head.data_ptr(), R._stream()), "gdr_render_backward_mean2d")
+                keep += [gc]
+                recs = None
+            else:
+                recs = torch.empty(N * path.floats, dtype=torch.float32, device=dev)   # one gradient record per Gaussian
+                st.bin.grad_rec_cleared = 0
+                path.k7(lib, s, N, st, grads, st.H, st.W, dev, recs, keep)
+                head = path.view_means2d(lib, s, N, st, ctx.radii, recs, dev)
         cols = ctx.means2D_shape[1] if len(ctx.means2D_shape) == 2 else 4
         if cols == 3:     # legacy caller (point_decoder/layers/gaussian_renderer.py): xy signed, z = 0
             gm2 = torch.cat([head[:, :2], torch.zeros_like(head[:, :1])], dim=1)
@@ -446,8 +596,9 @@ class _GroupView(torch.autograd.Function):
         with grp.lock:
             for k in [k for k, e in grp.pending.items() if e["task"] != task]:
                 del grp.pending[k]      # K7 results of an earlier pass no hub collected (a vjp w.r.t. the carrier): free them
-            grp.pending[ctx.j] = dict(recs=recs, state=st, radii=ctx.radii, s=s, keep=(keep, ctx.keep_rest), task=task)
-        return (None, None, None, None, gm2, grp.one, None, None, None, None, None)
+            if hub_runs and recs is not None:
+                grp.pending[ctx.j] = dict(recs=recs, state=st, radii=ctx.radii, s=s, keep=(keep, ctx.keep_rest), task=task)
+        return (None, None, None, None, None, gm2, grp.one if hub_runs else None, None, None, None, None, None)
 
 
 def grouped_call(path, means3D, means2D, sh, opacities, scales, rotations, raster_settings):
@@ -459,7 +610,7 @@ def grouped_call(path, means3D, means2D, sh, opacities, scales, rotations, raste
     dev = means3D.device
     tensors = (means3D, sh, opacities, scales, rotations)
     grp, new = _find_group(path, tensors, dev, raster_settings)
-    same_as = None
+    same_as = hit = None
     try:
         with grp.lock:
             if new:
@@ -467,15 +618,23 @@ def grouped_call(path, means3D, means2D, sh, opacities, scales, rotations, raste
                 grp.N, grp.M = int(means3D.shape[0]), int(sh.shape[1])
                 if grp.f32[2].numel() != grp.N:
                     raise RuntimeError("opacities must have N elements")
+                rs = raster_settings
+                grp.shape = (path.name, int(rs.image_height), int(rs.image_width), int(rs.sh_degree), grp.N.bit_length())
                 *grp.hub_out, grp.token = _Hub.apply(grp, *tensors)
+                grp.hub_node = grp.token.grad_fn
                 grp.one = torch.ones(1, dtype=torch.float32, device=dev)
             else:
                 same_as = _same_as_pairs(grp, tensors, R)
             j = grp.n_views
             grp.n_views += 1
-        return _GroupView.apply(grp, j, raster_settings, same_as, means2D, grp.token, *grp.hub_out)
+            if not new and _reuse_should_probe(grp, j):
+                hit, verified = _reuse_probe(grp, j, raster_settings, same_as, R)
+                if verified:
+                    same_as = None          # (compared next to the settings: the forward need not compare them again)
+        return _GroupView.apply(grp, j, raster_settings, same_as, hit, means2D, grp.token, *grp.hub_out)
     except R.GroupMismatch:
         # equal provenance, different values (a source edited in place outside autograd's view): this call is an ordinary
         # node on its own tensors, as the reference's would be; the group takes no further calls
         grp.closed = True
+        grp.cache = []
         return None

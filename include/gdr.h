@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define GDR_ABI_VERSION 15
+#define GDR_ABI_VERSION 16
 
 #define GDR_OK 0
 #define GDR_ERR_INVALID_ARG (-1)  /* NULL / inconsistent arguments                     */
@@ -325,7 +325,7 @@ int gdr_forward(const gdr_settings* s, const gdr_inputs* in, const gdr_geom* geo
  *   gdr_forward_view    returns GDR_OK with `state` filled (the structs every backward entry point takes, and D), or
  *                       GDR_ERR_WORKSPACE with state.D = the count: plan again with exact_D = state.D, allocate, call again
  *                       (the first call of a shape, or a scene that grew past the slack: nothing was written out of bounds).
- * opts (NULL = defaults): test / A-B overrides, each -1 / 0 = the library's policy.  same (NULL = none): up to 4 buffer
+ * opts (NULL = defaults): test / A-B overrides, each -1 / 0 = the library's policy.  same (NULL = none): up to 8 buffer
  * pairs compared bit for bit next to K1 (see gdr_words_differ; state.differ != 0 if any differs) — the equality check of a
  * render group rides on the count's copy.  Thread-safe for distinct workspaces. */
 typedef struct gdr_view_plan {
@@ -344,10 +344,11 @@ typedef struct gdr_view_opts {
     int32_t radix_partition; /* != 0: radix partition on the tile bits instead of the direct tile binning (tested fallback) */
     int32_t no_hints;        /* != 0: no launch-size feedback */
 } gdr_view_opts;
+#define GDR_SAME_AS_MAX 8
 typedef struct gdr_same_as {
-    int32_t n;               /* <= 4 */
+    int32_t n;               /* <= GDR_SAME_AS_MAX (4 until v15; a caller that re-activates all five inputs per call has 5 pairs) */
     int32_t reserved;
-    const void* a[4]; const void* b[4]; uint64_t n_bytes[4];
+    const void* a[GDR_SAME_AS_MAX]; const void* b[GDR_SAME_AS_MAX]; uint64_t n_bytes[GDR_SAME_AS_MAX];
 } gdr_same_as;
 typedef struct gdr_view_state {
     gdr_geom geom; gdr_binning bin; gdr_image img;
@@ -360,6 +361,20 @@ int gdr_view_plan_for(int32_t N, int32_t H, int32_t W, int32_t surfel, uint64_t 
 int gdr_forward_view(const gdr_settings* s, const gdr_inputs* in, const gdr_view_plan* plan, void* workspace,
                      const gdr_view_opts* opts, const gdr_same_as* same, const gdr_outputs* out, gdr_view_state* state,
                      void* stream);
+/* Does the view about to be rendered repeat an earlier view of the same Gaussians (v16)?  The reference renders the first
+ * n_views_sel views of the coarse Gaussians twice per sample — /root/reference/lightning/network.py:827-838, then again inside
+ * the function `vjp` differentiates at :848-856, with the same c2w / bg_color — and a render group (viewgroup.py) that knows
+ * the Gaussians are the same only has to know that the 12 settings fields are, too, to hand out the first forward's results
+ * instead of running K1, binning and K6 again.  The host scalars of `s` are compared here on the host; bg / viewmatrix /
+ * projmatrix / campos (device tensors the caller rebuilds per call: MiniCam at network.py:851) are compared bit for bit on
+ * the device against up to GDR_REUSE_MAX candidates in one small launch, together with the `same` pairs of the render group
+ * (gdr_same_as: the activated tensors of this call against the group's).  BLOCKING: *match = index of the first candidate
+ * whose 12 fields equal those of `s` (or -1), *differ != 0 if a `same` pair differs — one launch, one pooled pinned copy,
+ * one event wait.  scratch: GDR_REUSE_MAX + 1 device words (the library allocates no device memory). */
+#define GDR_REUSE_MAX 32
+int gdr_view_reuse_probe(const gdr_settings* s, int32_t n, const gdr_settings* candidates, const gdr_same_as* same,
+                         uint32_t* scratch, int32_t* match, uint32_t* differ, void* stream);
+
 /* The same for ALL views of one Gaussian set (the forward of the multi-view node, v14): V <= GDR_MAX_NODE_VIEWS views of one
  * image size; K1 in launches of <= GDR_MAX_VIEWS views (inputs read once each), then every view's chain binning -> K6 on
  * streams[v % n_streams] (streams[0] = the caller's: it is made to wait for the others before the call returns), the V
@@ -510,7 +525,7 @@ int gdr_view_loss_backward(const float* color, const float* target, int32_t H, i
  * 32-bit word.  Used by the Python boundary to verify that two calls of one render group were handed the same activated
  * tensors (see generativedensification_amd/viewgroup.py); one read of both buffers, no host synchronisation. */
 int gdr_words_differ(const void* a, const void* b, uint64_t n_bytes, uint32_t* flag, void* stream);
-/* ... for up to 4 buffer pairs in one launch (v13) */
+/* ... for up to GDR_SAME_AS_MAX buffer pairs in one launch (v13; 4 until v15) */
 int gdr_words_differ_multi(int32_t n, const void* const* a, const void* const* b, const uint64_t* n_bytes, uint32_t* flag,
                            void* stream);
 

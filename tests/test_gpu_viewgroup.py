@@ -283,3 +283,179 @@ def test_surfel_calls_of_one_set_share_one_preprocess_backward(deg):
     for a, b in zip(m1, m0):
         out, worst, maxn = U.elem_stats(a, b, 1e-4, U.SURFEL_ATOL_REL)
         assert a.shape == (n, 4) and out < U.MAX_OUTSIDE and maxn < 2e-4
+
+
+
+# ---- a view rendered twice: the forward the vjp pass repeats (network.py:827-838 vs 848-856) -----------------------------
+def _fresh_settings(rs, bg=None, view=None):
+    """The same 12 fields in NEW device tensors (MiniCam and `bg.to(device)` rebuild them per call in the reference)."""
+    return rs._replace(bg=(rs.bg if bg is None else bg).clone(), viewmatrix=(rs.viewmatrix if view is None else view).clone(),
+                       projmatrix=rs.projmatrix.clone(), campos=rs.campos.clone())
+
+
+def _sample_sequence(leaves, sets, vjp_sets, tg, n, dev):
+    """network.py's sequence on one sample: V coarse renders; `vjp` of the image MSE w.r.t. ONE shared carrier through renders
+    of the same Gaussians with `vjp_sets`; one backward through the coarse renders."""
+    from torch.autograd.functional import vjp
+    imgs, losses, _ = _reference_loop(leaves, sets, tg, n, dev, i=1)
+    seen = []
+
+    def fn(ssp):
+        im2, _, _ = _reference_loop(leaves, vjp_sets, tg, n, dev, i=1, carriers=[ssp] * len(vjp_sets))
+        seen.extend(x.detach() for x in im2)
+        return sum(((x[:3].clamp(0, 1) - tg[j]) ** 2).mean() for j, x in enumerate(im2))
+    val, grad = vjp(fn, torch.zeros(n, 4, device=dev))
+    sum(losses).backward()
+    return ([x.detach().cpu().numpy() for x in imgs], [x.cpu().numpy() for x in seen], float(val), grad.cpu().numpy(),
+            {k: v.grad.cpu().numpy() for k, v in leaves.items()})
+
+
+def _profiled(fn):
+    from generativedensification_amd import _lib as L
+    L.profile_enable(True)
+    L.profile_collect(reset=True)
+    out = fn()
+    torch.cuda.synchronize()
+    prof = L.profile_collect(reset=True)
+    L.profile_enable(False)
+    return out, prof
+
+
+def test_a_view_rendered_twice_runs_its_forward_once():
+    """The vjp pass of network.py:848-856 renders the first n_views_sel views of the SAME coarse Gaussians with the SAME c2w
+    and bg_color that :827-838 rendered moments earlier (new MiniCam / bg tensors, equal values).  The render group hands
+    out the first forward's results: V K1 launches instead of V + 2, the images bit for bit, the carrier gradient and the
+    leaf gradients as without the reuse."""
+    from generativedensification_amd import viewgroup as G
+    dev, base, sets, tg, n = _setup(V=4)
+    G._REUSE_HIST.clear()
+
+    def run(reuse):
+        saved = G.REUSE_FORWARD
+        G.REUSE_FORWARD = reuse
+        G._REUSE_STATS.update(probes=0, hits=0)
+        try:
+            leaves = {k: v.clone().requires_grad_(True) for k, v in base.items()}
+            vjp_sets = [_fresh_settings(rs) for rs in sets[:2]]
+            return _profiled(lambda: _sample_sequence(leaves, sets, vjp_sets, tg, n, dev)), dict(G._REUSE_STATS)
+        finally:
+            G.REUSE_FORWARD = saved
+
+    (r0, p0), s0 = run(False)
+    (r1, p1), s1 = run(True)
+    assert s0 == dict(probes=0, hits=0) and s1["hits"] == 2 and s1["probes"] == 5      # first time: every later call probes
+    assert p0["preprocess_fwd"][1] == 6 and p1["preprocess_fwd"][1] == 4
+    assert p0["render_fwd"][1] == 6 and p1["render_fwd"][1] == 4
+    for a, b in zip(r1[0] + r1[1], r0[0] + r0[1]):
+        np.testing.assert_array_equal(a, b)
+    for j in range(2):
+        np.testing.assert_array_equal(r1[1][j], r1[0][j])         # the repeated views ARE the first renders
+    assert r1[2] == r0[2]
+    out, _, maxn = U.elem_stats(r1[3], r0[3])
+    assert out < U.MAX_OUTSIDE and maxn < 1e-4 and np.abs(r0[3][:, 2:]).max() > 0
+    for k in r0[4]:
+        out, worst, maxn = U.elem_stats(r1[4][k], r0[4][k])
+        assert out < U.MAX_OUTSIDE and maxn < 1e-4, (k, out, worst, maxn)
+    # the second step of the same shape has learned which call indices repeat a view: only those probe
+    (r2, p2), s2 = run(True)
+    assert s2 == dict(probes=2, hits=2) and p2["preprocess_fwd"][1] == 4
+    for a, b in zip(r2[0] + r2[1], r0[0] + r0[1]):
+        np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.parametrize("what", ["bg", "c2w", "inplace_same_tensor"])
+def test_a_changed_setting_between_the_passes_takes_the_ordinary_path(what):
+    """Another bg colour, another camera, a settings tensor written in place between the calls (same memory: no device
+    comparison could tell): no reuse, results equal to the run without it."""
+    from generativedensification_amd import viewgroup as G
+    dev, base, sets, tg, n = _setup(V=3)
+    G._REUSE_HIST.clear()
+
+    def run(reuse):
+        saved = G.REUSE_FORWARD
+        G.REUSE_FORWARD = reuse
+        G._REUSE_STATS.update(probes=0, hits=0)
+        try:
+            leaves = {k: v.clone().requires_grad_(True) for k, v in base.items()}
+            my = [_fresh_settings(rs) for rs in sets]
+            imgs, losses, _ = _reference_loop(leaves, my, tg, n, dev, i=1)
+            if what == "bg":
+                again = _fresh_settings(my[0], bg=1.0 - my[0].bg)
+            elif what == "c2w":
+                again = _fresh_settings(my[0], view=my[0].viewmatrix + 1e-3)
+            else:
+                my[0].bg.mul_(0.5)
+                again = my[0]
+            im2, l2, _ = _reference_loop(leaves, [again], tg, n, dev, i=1)
+            (sum(losses) + l2[0]).backward()
+            return im2[0].detach().cpu().numpy(), {k: v.grad.cpu().numpy() for k, v in leaves.items()}, dict(G._REUSE_STATS)
+        finally:
+            G.REUSE_FORWARD = saved
+
+    i0, g0, _ = run(False)
+    i1, g1, st = run(True)
+    assert st["hits"] == 0 and st["probes"] >= 1
+    np.testing.assert_array_equal(i1, i0)
+    for k in g0:
+        out, worst, maxn = U.elem_stats(g1[k], g0[k])
+        assert out < U.MAX_OUTSIDE and maxn < 1e-4, (k, out, worst, maxn)
+
+
+def test_five_recomputed_inputs_per_call_still_group():
+    """Round-4 advisor finding: a caller that recomputes ALL five inputs per call (means3D and shs through whitelisted ops as
+    well) hands the forward five same_as pairs; the struct held four and the call crashed with an IndexError."""
+    import diff_gaussian_rasterization as D
+    dev, base, sets, tg, n = _setup(V=3, B=1)
+
+    def run(grouped):
+        from generativedensification_amd import viewgroup as G
+        saved = G.GROUP_VIEWS
+        G.GROUP_VIEWS = grouped
+        try:
+            leaves = {k: v.clone().requires_grad_(True) for k, v in base.items()}
+            loss = 0.0
+            for j, rs in enumerate(sets):
+                ssp = torch.zeros(n, 4, device=dev, requires_grad=True)
+                color = D.GaussianRasterizer(rs)(
+                    means3D=torch.sigmoid(leaves["centers"][0]), means2D=ssp, shs=torch.sigmoid(leaves["shs"][0]),
+                    opacities=torch.sigmoid(leaves["opacity"][0]), scales=torch.exp(leaves["scales"][0]),
+                    rotations=torch.nn.functional.normalize(leaves["rotations"][0]))[0]
+                loss = loss + ((color.clamp(0, 1) - tg[j]) ** 2).mean()
+            (_, prof) = _profiled(lambda: loss.backward())
+            return {k: v.grad.cpu().numpy() for k, v in leaves.items()}, prof
+        finally:
+            G.GROUP_VIEWS = saved
+    g0, p0 = run(False)
+    g1, p1 = run(True)
+    assert p0["preprocess_bwd"][1] == 3 and p1["preprocess_bwd"][1] == 1
+    for k in g0:
+        out, worst, maxn = U.elem_stats(g1[k], g0[k])
+        assert out < U.MAX_OUTSIDE and maxn < 1e-4, (k, out, worst, maxn)
+
+
+def test_an_output_edited_in_place_is_not_handed_out_again():
+    """The cache holds aliases of what the first call returned; a caller that edits such an output in place (none of the
+    reference's does) must not see the edit in a later call's result: the version counter rules the entry out."""
+    import diff_gaussian_rasterization as D
+    from generativedensification_amd import viewgroup as G
+    dev, base, sets, tg, n = _setup(V=2, B=1)
+    G._REUSE_HIST.clear()
+    leaves = {k: v.clone().requires_grad_(True) for k, v in base.items()}
+
+    def call(rs):
+        ssp = torch.zeros(n, 4, device=dev, requires_grad=True)
+        return D.GaussianRasterizer(rs)(means3D=leaves["centers"][0], means2D=ssp, shs=leaves["shs"][0],
+                                        opacities=torch.sigmoid(leaves["opacity"][0]), scales=torch.exp(leaves["scales"][0]),
+                                        rotations=torch.nn.functional.normalize(leaves["rotations"][0]))
+    a = call(sets[0])
+    b = call(_fresh_settings(sets[0]))                 # a hit: equal to a, in memory of its own
+    assert G._REUSE_STATS["hits"] >= 1 and b[0].data_ptr() != a[0].data_ptr()
+    np.testing.assert_array_equal(a[0].detach().cpu().numpy(), b[0].detach().cpu().numpy())
+    ref = a[0].detach().clone()
+    with torch.no_grad():
+        a[3].mul_(0.5)                                 # alpha of the first call edited in place
+    hits = G._REUSE_STATS["hits"]
+    c = call(_fresh_settings(sets[0]))
+    np.testing.assert_array_equal(c[0].detach().cpu().numpy(), ref.cpu().numpy())
+    np.testing.assert_array_equal(c[3].detach().cpu().numpy(), b[3].detach().cpu().numpy())
+    assert G._REUSE_STATS["hits"] == hits              # (a's entry was ruled out: c ran its own forward)

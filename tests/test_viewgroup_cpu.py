@@ -1,6 +1,11 @@
 """CPU: the host logic of the render groups (generativedensification_amd/viewgroup.py) that needs no GPU — the provenance
 signature, the import-time probe of the private torch pieces it leans on, the rules that keep a call out of a group, and
 the single-view-pass pause.  (The grouped kernels themselves: tests/test_gpu_viewgroup.py.)"""
+import os
+import subprocess
+import sys
+
+import pytest
 import torch
 
 from generativedensification_amd import viewgroup as G
@@ -32,6 +37,84 @@ def test_probe_accepts_this_torch_and_names_what_is_missing():
         assert "_current_graph_task_id" in G._probe_torch()
     finally:
         torch._C._current_graph_task_id = real
+
+
+def test_probe_does_not_depend_on_the_grad_mode_it_runs_under():
+    """Round 4's probe read `grad_fn is None` (no_grad, inference_mode, inside a backward pass) as "unknown torch"."""
+    with torch.no_grad():
+        assert G._probe_torch() == ""
+    with torch.inference_mode():
+        assert G._probe_torch() == ""
+
+    class InBackward(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            return x.clone()
+
+        @staticmethod
+        def backward(ctx, g):
+            InBackward.seen = G._probe_torch()
+            return g
+    x = torch.ones(2, requires_grad=True)
+    InBackward.apply(x).sum().backward()
+    assert InBackward.seen == ""
+
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_FIRST_IMPORT = """
+import sys, warnings
+warnings.simplefilter("error")          # the "render groups are off" warning fails the test
+import torch
+{prologue}
+    import {package}
+from generativedensification_amd import viewgroup
+assert viewgroup.GROUP_VIEWS is True and viewgroup._PROBLEM == "", (viewgroup.GROUP_VIEWS, viewgroup._PROBLEM)
+assert viewgroup._ensure_probed()
+print("groups-on")
+"""
+_IN_BACKWARD = """
+class F(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return x.clone()
+    @staticmethod
+    def backward(ctx, g):
+        import {package}
+        return g
+F.apply(torch.ones(2, requires_grad=True)).sum().backward()
+if True:"""
+
+
+@pytest.mark.parametrize("package", ["diff_gaussian_rasterization", "diff_surfel_rasterization"])
+@pytest.mark.parametrize("how", ["no_grad", "inference_mode", "backward"])
+def test_first_import_in_the_reference_entry_order_keeps_render_groups_on(package, how):
+    """/root/reference/train_lightning.py:70-85: Lightning's sanity validation (lightning/system.py:47-53, inference mode)
+    makes the first rasterizer import / call of a training process; the smoke's fused renderer first touches the boundary
+    inside loss.backward().  A fresh interpreter each, warnings are errors."""
+    prologue = {"no_grad": "with torch.no_grad():", "inference_mode": "with torch.inference_mode():",
+                "backward": _IN_BACKWARD.format(package=package)}[how]
+    code = _FIRST_IMPORT.format(prologue=prologue, package=package)
+    env = dict(os.environ, PYTHONPATH=_ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    env.pop("GDR_GROUP_VIEWS", None)
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=_ROOT, timeout=300)
+    assert res.returncode == 0 and "groups-on" in res.stdout, res.stderr[-2000:]
+
+
+def test_a_probe_that_could_not_run_is_repeated_on_the_next_eligible_call(monkeypatch):
+    """An import-time condition is never permanent: a TRANSIENT probe result leaves `_PROBLEM` unset and the next call probes
+    again; a real mismatch switches the groups off with ONE warning."""
+    monkeypatch.setattr(G, "_PROBLEM", None)
+    monkeypatch.setattr(G, "_PROBES_LEFT", 4)
+    monkeypatch.setattr(G, "GROUP_VIEWS", True)
+    answers = iter(["TRANSIENT: x", ""])
+    monkeypatch.setattr(G, "_probe_torch", lambda: next(answers))
+    assert G._ensure_probed() is False and G._PROBLEM is None and G.GROUP_VIEWS
+    assert G._ensure_probed() is True and G._PROBLEM == ""
+    monkeypatch.setattr(G, "_PROBLEM", None)
+    monkeypatch.setattr(G, "_probe_torch", lambda: "unknown autograd node X")
+    with pytest.warns(UserWarning, match="render groups are off"):
+        assert G._ensure_probed() is False
+    assert G.GROUP_VIEWS is False
 
 
 def test_signature_equal_for_the_reference_loop_and_different_for_everything_else():
