@@ -19,6 +19,7 @@ LIB_PATH = os.environ.get("GDR_LIB_PATH") or os.path.join(_HERE, "lib", "libgdr_
 GDR_OK = 0
 GDR_IN_RAW_OPACITY, GDR_IN_RAW_SCALES, GDR_IN_RAW_ROTATIONS, GDR_IN_NO_DEPTH_TO_MEAN = 1, 2, 4, 8
 GDR_MAX_VIEWS = 8
+GDR_MAX_NODE_VIEWS = 256
 ABI_VERSION = 16
 GDR_SAME_AS_MAX, GDR_REUSE_MAX = 8, 32
 GDR_DEFAULT_SEG_LEN = 256
@@ -53,7 +54,7 @@ class GdrBinning(C.Structure):
                 ("seg_len", C.c_int32), ("seg_cap", C.c_int32), ("deep_max_busy", C.c_int32), ("deep_min_mean", C.c_int32),
                 ("d_dev", C.c_void_p), ("stats_out", C.c_void_p), ("hint_long", C.c_int32), ("hint_medium", C.c_int32),
                 ("hint_no_deep", C.c_int32), ("grad_rec_cleared", C.c_int32), ("tile_hist", C.c_void_p),
-                ("hist_width", C.c_int32), ("hist_tiles", C.c_int32)]
+                ("hist_width", C.c_int32), ("hist_tiles", C.c_int32), ("k7_class", C.c_int32), ("reserved2", C.c_int32)]
 
 
 class GdrImage(C.Structure):

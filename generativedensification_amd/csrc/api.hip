@@ -7,6 +7,7 @@
 #include <string.h>
 
 #include <atomic>
+#include <cmath>
 #include <mutex>
 #include <unordered_map>
 #include <vector>
@@ -61,31 +62,49 @@ static inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a
 // ---- which K7 for a scene shape: rows, or row pairs where they pay (render.hip: render_bwd_pairs_kernel) ---------------
 // K7 is bound by the device's float-atomic line rate wherever the Gaussians span several 4x4 blocks; merging the two rows of
 // an 8x4 area saves lines and costs iterations, and which side wins depends on the scene (C2 -16 %, object-like scenes and
-// sub-pixel Gaussians +3-30 %).  Results are the same sums in another order.  Per (device, N bucket, image size, views per
-// launch, entry): four consecutive launches are timed with events (rows / pairs / rows / pairs, the better try of each), first
-// after the shape's first kK7First launches and then every kK7Period launches, and the faster variant (by > 3 %) serves until
-// the next round.  gdr_k7_tune_override pins a variant (tests, A/B).
+// sub-pixel Gaussians +3-30 %).  Results are the same sums in another order.  Per (device, N bucket, duplicates-per-Gaussian
+// class of the views, image size, views per launch, entry kind): ONE round of four consecutive launches is timed with events
+// (rows / pairs / rows / pairs, the better try of each) after the key's first kK7First launches, and the faster variant (by
+// > 3 %) serves that key from then on — the choice is made once and kept (round 4 repeated the round every 256 launches: the
+// variant, and with it the order of the float sums, could change in the middle of a run; a scene that drifts — a densifying
+// model — moves to another duplicates-per-Gaussian class, i.e. another key, instead).  gdr_k7_tune_override pins a variant
+// (tests, A/B, bit-reproducible runs).
 struct K7Tune {
-    float us[2] = {0.f, 0.f};      // this round's best time per variant (0 = not in yet; negated once the round is decided)
+    float us[2] = {0.f, 0.f};      // the round's best time per variant (0 = not in yet; negated once the round is decided)
     uint32_t calls = 0;
     int chosen = 0, got = 0;
+    bool decided = false;
+    uint64_t last_use = 0;
     struct Pend { hipEvent_t a = nullptr, b = nullptr; int state = 0; } pend[4];   // state: 0 idle, 1 begun, 2 ended
 };
 static std::mutex g_k7_mu;
 static std::unordered_map<uint64_t, K7Tune> g_k7;
+static uint64_t g_k7_clock = 0;
 static std::atomic<int> g_k7_override{-1};    // -1 measure and choose, 0 rows, 1 row pairs
-// a round = four consecutive launches, rows / pairs / rows / pairs (the faster of two tries counts); the first round after
-// kK7First launches of the shape — K7's duration drifts down over the first ten or so launches of a shape (C3: pairs 1332 ->
-// 1202 us, rows 1335 -> 1277, profiles/r04_ab_k7_blocks.txt section 10), a round at launch 0 chose wrongly — then every
-// kK7Period launches
-constexpr uint32_t kK7Period = 256, kK7Round = 4, kK7First = 8;
+// the round = four consecutive launches, rows / pairs / rows / pairs (the faster of two tries counts), after kK7First launches
+// of the key — K7's duration drifts down over the first ten or so launches of a shape (C3: pairs 1332 -> 1202 us, rows 1335 ->
+// 1277, profiles/r04_ab_k7_blocks.txt section 10), a round at launch 0 chose wrongly
+constexpr uint32_t kK7Round = 4, kK7First = 8;
 
-static uint64_t k7_key(int N, int H, int W, int V, int kind) {
+// duplicates per Gaussian of a view as a quarter-octave class (1..63; 0 = unknown: the state did not come from
+// gdr_forward_view(s)) — what gdr_binning.k7_class carries from the forward to the K7 entry points
+static int k7_class_of(uint64_t D, int N) {
+    if (N <= 0 || D == 0) return 0;
+    const double r = (double)D / (double)N;
+    int c = 17 + (int)std::floor(4.0 * std::log2(r));
+    return c < 1 ? 1 : (c > 63 ? 63 : c);
+}
+static int k7_class_views(int V, const gdr_binning* bins) {
+    int c = 0;
+    for (int v = 0; v < V; ++v) c = bins[v].k7_class > c ? bins[v].k7_class : c;
+    return c & 63;
+}
+static uint64_t k7_key(int N, int H, int W, int V, int kind, int cls) {
     int dev = 0, nb = 0;
     (void)hipGetDevice(&dev);
     for (int64_t v = N; v > 0; v >>= 1) ++nb;
-    return ((uint64_t)(dev & 0xFF) << 56) | ((uint64_t)(kind & 3) << 54) | ((uint64_t)(V & 0x3F) << 48) |
-           ((uint64_t)(nb & 0x3F) << 42) | ((uint64_t)(H & 0x1FFFFF) << 21) | (uint64_t)(W & 0x1FFFFF);
+    return ((uint64_t)(dev & 0xFF) << 55) | ((uint64_t)(kind & 7) << 52) | ((uint64_t)(V & 0xF) << 48) |
+           ((uint64_t)(nb & 0x3F) << 42) | ((uint64_t)(cls & 0x3F) << 36) | ((uint64_t)(H & 0x3FFFF) << 18) | (uint64_t)(W & 0x3FFFF);
 }
 static void k7_harvest(K7Tune& k) {   // (g_k7_mu held)
     for (uint32_t ph = 0; ph < kK7Round; ++ph) {
@@ -99,31 +118,42 @@ static void k7_harvest(K7Tune& k) {   // (g_k7_mu held)
         }
         p.state = 0;
     }
-    if (k.got == (int)kK7Round && k.us[0] > 0.f && k.us[1] > 0.f) {
+    if (!k.decided && k.got == (int)kK7Round && k.us[0] > 0.f && k.us[1] > 0.f) {
         k.chosen = k.us[1] < 0.97f * k.us[0] ? 1 : 0;
         k.us[0] = -k.us[0]; k.us[1] = -k.us[1];   // (kept, negated, for gdr_k7_tune_get)
         k.got = 0;
+        k.decided = true;
     }
 }
-// brackets ONE K7 launch: sets the calling thread's variant, times the launch when it is this shape's turn
+// brackets ONE K7 launch: sets the calling thread's variant, times the launch when it is this key's turn
 struct K7Scope {
     K7Tune* t = nullptr;
     int slot = -1;
     hipStream_t st;
-    K7Scope(int N, int H, int W, int V, int kind, hipStream_t stream) : st(stream) {
+    K7Scope(int N, int H, int W, int V, int kind, int cls, hipStream_t stream) : st(stream) {
         int variant = g_k7_override.load();
         if (variant < 0) {
             std::lock_guard<std::mutex> lk(g_k7_mu);
-            K7Tune& k = g_k7[k7_key(N, H, W, V, kind)];
+            K7Tune& k = g_k7[k7_key(N, H, W, V, kind, cls)];
+            k.last_use = ++g_k7_clock;
             k7_harvest(k);
-            const uint32_t phase = (k.calls++ % kK7Period) - kK7First;     // (wraps for the launches before the round)
             variant = k.chosen;
-            if (phase < kK7Round && k.pend[phase].state == 0) {
-                K7Tune::Pend& p = k.pend[phase];
-                if (phase == 0) { k.us[0] = k.us[1] = 0.f; k.got = 0; }
-                if (!p.a && (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess)) p.a = p.b = nullptr;
-                if (p.a && hipEventRecord(p.a, st) == hipSuccess) { p.state = 1; t = &k; slot = (int)phase; }
-                variant = (int)(phase & 1u);
+            hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+            const bool capturing = hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone;
+            if (capturing) (void)hipGetLastError();
+            if (!k.decided && !capturing) {      // (a timing event cannot be queried on a stream under graph capture)
+                const uint32_t phase = k.calls++ - kK7First;                   // (wraps for the launches before the round)
+                if (phase < kK7Round && k.pend[phase].state == 0) {
+                    K7Tune::Pend& p = k.pend[phase];
+                    if (phase == 0) { k.us[0] = k.us[1] = 0.f; k.got = 0; }
+                    if (!p.a && (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess)) p.a = p.b = nullptr;
+                    if (p.a && hipEventRecord(p.a, st) == hipSuccess) { p.state = 1; t = &k; slot = (int)phase; }
+                    variant = (int)(phase & 1u);
+                } else if (phase >= kK7Round && phase < 0x80000000u && k.got < (int)kK7Round) {
+                    bool open = false;           // a try of the round was lost (an event call failed): start the round over
+                    for (uint32_t ph = 0; ph < kK7Round; ++ph) open = open || k.pend[ph].state != 0;
+                    if (!open) k.calls = kK7First;
+                }
             }
         }
         render_bwd_set_pairs(variant > 0 ? 1 : 0);
@@ -196,6 +226,8 @@ static size_t carve_binning(void* base, uint64_t D, gdr_binning* b, int32_t seg_
     t.tile_hist = nullptr;
     t.hist_width = 0;
     t.hist_tiles = 0;
+    t.k7_class = 0;
+    t.reserved2 = 0;
     if (N > 0 && tiles > 0 && tiles <= GDR_BIN_MAX_TILES) {   // direct tile binning: (width rows x tiles) counts + a totals row
         int w = (N + 1023) / 1024;
         t.hist_width = w > GDR_BIN_MAX_WIDTH ? GDR_BIN_MAX_WIDTH : w;
@@ -367,11 +399,6 @@ int gdr_preprocess_forward(const gdr_settings* s, const gdr_inputs* in, const gd
 // stages (direct tile binning only; anything else runs whole under bit 0): 1 = count, scan, tile order; 2 = scatter; 4 = per-tile
 // sort.  gdr_forward_views issues the stages of its views breadth-first — stage by stage over the views' streams — so that
 // the last view's chain does not start a whole chain's worth of launches (9 x ~4 us of host time per view) after the first.
-static bool binning_is_direct(const gdr_settings* s, const gdr_binning* bin) {
-    const int tiles = tile_grid_x(s->image_width) * tile_grid_y(s->image_height);
-    return !bin->global_sort && tiles <= GDR_BIN_MAX_TILES && bin->tile_hist && bin->hist_width > 0 &&
-           bin->hist_tiles >= (tiles + 63) / 64 * 64;
-}
 static int binning_stage_views(int V, const gdr_settings* s, int32_t N, const gdr_geom* geoms, gdr_binning* bins,
                                const gdr_image* imgs, const uint64_t* D, const int32_t* const* radii, hipStream_t st,
                                int stages = 7) {
@@ -388,7 +415,8 @@ static int binning_stage_views(int V, const gdr_settings* s, int32_t N, const gd
                  bins[v].hist_tiles >= (tiles + 63) / 64 * 64;
         dmax = D[v] > dmax ? D[v] : dmax;
     }
-    if (global_sort) {  // stable global sort: duplicates must be emitted in Gaussian order
+    if (global_sort && (stages & 1)) {  // stable global sort: duplicates must be emitted in Gaussian order (once: the
+        // breadth-first issue of gdr_forward_views calls this function with stages 1, 2 and 4, and the scan is in place)
         for (int v = 0; v < V; ++v) {
             e = launch_scan_block_sums(&geoms[v], N, st);
             if (e != hipSuccess) return hip_fail("scan_block_sums", e);
@@ -620,7 +648,7 @@ int gdr_render_backward_loss(const gdr_settings* s, int32_t N, const gdr_geom* g
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = bin->grad_rec_cleared ? hipSuccess : hipMemsetAsync(grad_rec, 0, (size_t)N * 16 * sizeof(float), st);
     if (e != hipSuccess) return hip_fail("memset gradient records", e);
-    { K7Scope k7(N, s->image_height, s->image_width, 1, 1, st);
+    { K7Scope k7(N, s->image_height, s->image_width, 1, 1, bin->k7_class, st);
       e = launch_render_bwd_loss(s, geom, bin, img, color, target, w_depth, w_alpha, g, grad_rec, st); }
     if (e != hipSuccess) return hip_fail("render_bwd_loss", e);
     return debug_sync(s, "render_bwd_loss", st);
@@ -636,7 +664,7 @@ int gdr_render_backward_mean2d_loss(const gdr_settings* s, int32_t N, const gdr_
     if (N <= 0) return GDR_OK;
     hipStream_t st = (hipStream_t)stream;
     hipError_t e;
-    { K7Scope k7(N, s->image_height, s->image_width, 1, 2, st);
+    { K7Scope k7(N, s->image_height, s->image_width, 1, 4, bin->k7_class, st);
       e = launch_render_bwd_mean2d_loss(s, geom, bin, img, color, target, g, dL_dmean2D, st); }
     if (e != hipSuccess) return hip_fail("render_bwd_mean2d_loss", e);
     return debug_sync(s, "render_bwd_mean2d_loss", st);
@@ -691,7 +719,7 @@ int gdr_backward(const gdr_settings* s, const gdr_inputs* in, const gdr_geom* ge
     if (N == 0) return GDR_OK;
     hipError_t e = hipMemsetAsync(gout->scratch, 0, N * 16 * sizeof(float), st);
     if (e != hipSuccess) return hip_fail("memset gradient records", e);
-    { K7Scope k7((int)N, s->image_height, s->image_width, 1, 0, st);
+    { K7Scope k7((int)N, s->image_height, s->image_width, 1, 0, bin->k7_class, st);
       e = launch_render_bwd(s, geom, bin, img, gin, gout, st); }
     if (e != hipSuccess) return hip_fail("render_bwd", e);
     if ((rc = debug_sync(s, "render_bwd", st))) return rc;
@@ -746,7 +774,7 @@ int gdr_render_backward(const gdr_settings* s, int32_t N, const gdr_geom* geom, 
     gdr_grad_outputs go;
     memset(&go, 0, sizeof(go));
     go.scratch = grad_rec;
-    { K7Scope k7(N, s->image_height, s->image_width, 1, 0, st);
+    { K7Scope k7(N, s->image_height, s->image_width, 1, 0, bin->k7_class, st);
       e = launch_render_bwd(s, geom, bin, img, gin, &go, st); }
     if (e != hipSuccess) return hip_fail("render_bwd", e);
     return debug_sync(s, "render_bwd", st);
@@ -782,7 +810,7 @@ int gdr_render_backward_views(int32_t V, const gdr_settings* s, int32_t N, const
         }
     }
     hipError_t e;
-    { K7Scope k7(N, s[0].image_height, s[0].image_width, V, 0, st);
+    { K7Scope k7(N, s[0].image_height, s[0].image_width, V, 0, k7_class_views(V, bins), st);
       e = launch_render_bwd_views(V, s, geoms, bins, imgs, gins, grad_recs, interleave, st); }
     if (e != hipSuccess) return hip_fail("render_bwd_views", e);
     return debug_sync(&s[0], "render_bwd_views", st);
@@ -805,7 +833,7 @@ int gdr_render_backward_loss_views(int32_t V, const gdr_settings* s, int32_t N, 
         }
     }
     hipError_t e;
-    { K7Scope k7(N, s[0].image_height, s[0].image_width, V, 1, st);
+    { K7Scope k7(N, s[0].image_height, s[0].image_width, V, 1, k7_class_views(V, bins), st);
       e = launch_render_bwd_loss_views(V, s, geoms, bins, imgs, colors, targets, w_depth, w_alpha, g, grad_recs, interleave, st); }
     if (e != hipSuccess) return hip_fail("render_bwd_loss_views", e);
     return debug_sync(&s[0], "render_bwd_loss_views", st);
@@ -822,7 +850,7 @@ int gdr_render_backward_mean2d_views(int32_t V, const gdr_settings* s, int32_t N
         if (!dL_dcolors[v]) { set_error("render_backward_mean2d_views: NULL view buffer", hipSuccess); return GDR_ERR_INVALID_ARG; }
     hipStream_t st = (hipStream_t)stream;
     hipError_t e;
-    { K7Scope k7(N, s[0].image_height, s[0].image_width, V, 2, st);
+    { K7Scope k7(N, s[0].image_height, s[0].image_width, V, 2, k7_class_views(V, bins), st);
       e = launch_render_bwd_mean2d_views(V, s, geoms, bins, imgs, dL_dcolors, dL_dmean2D, interleave, st); }
     if (e != hipSuccess) return hip_fail("render_bwd_mean2d_views", e);
     return debug_sync(&s[0], "render_bwd_mean2d_views", st);
@@ -838,7 +866,7 @@ int gdr_render_backward_mean2d(const gdr_settings* s, int32_t N, const gdr_geom*
     if (N <= 0) return GDR_OK;
     hipStream_t st = (hipStream_t)stream;
     hipError_t e;
-    { K7Scope k7(N, s->image_height, s->image_width, 1, 2, st);
+    { K7Scope k7(N, s->image_height, s->image_width, 1, 2, bin->k7_class, st);
       e = launch_render_bwd_mean2d(s, geom, bin, img, dL_dcolor, dL_dmean2D, st); }
     if (e != hipSuccess) return hip_fail("render_bwd_mean2d", e);
     return debug_sync(s, "render_bwd_mean2d", st);
@@ -1173,6 +1201,7 @@ int forward_view_impl(const gdr_settings* s, int N, int surfel, const gdr_view_p
         }
     }
     v.D = D;
+    v.bin.k7_class = k7_class_of(D, N);
     record_duplicates(key, N, D);
     if (!plan->have_binning || D > plan->capacity) {
         set_error("forward_view: binning workspace too small for num_rendered (plan again with exact_D = state.D)", hipSuccess);
@@ -1434,7 +1463,11 @@ int gdr_forward_views(int32_t V, const gdr_settings* s, const gdr_inputs* in, co
         }
     }
     uint64_t d_max = 0;
-    for (int v = 0; v < V; ++v) { states[v].D = d_host[(size_t)v]; d_max = d_max > d_host[(size_t)v] ? d_max : d_host[(size_t)v]; }
+    for (int v = 0; v < V; ++v) {
+        states[v].D = d_host[(size_t)v];
+        states[v].bin.k7_class = k7_class_of(d_host[(size_t)v], N);
+        d_max = d_max > d_host[(size_t)v] ? d_max : d_host[(size_t)v];
+    }
     record_duplicates(key, N, d_max);
     if (!fits) {
         set_error("forward_views: binning workspace too small for num_rendered (plan again with exact_D = the largest state.D)", hipSuccess);
@@ -1460,19 +1493,26 @@ void gdr_k7_tune_override(int32_t mode) { g_k7_override.store(mode < 0 ? -1 : (m
 
 int gdr_k7_tune_get(int32_t N, int32_t H, int32_t W, int32_t V, int32_t kind, int32_t* chosen, float* us_rows, float* us_pairs) {
     std::lock_guard<std::mutex> lk(g_k7_mu);
-    auto it = g_k7.find(k7_key(N, H, W, V, kind));
-    if (it == g_k7.end()) { set_error("k7_tune_get: no launch of this shape yet", hipSuccess); return GDR_ERR_INVALID_ARG; }
-    k7_harvest(it->second);
-    if (chosen) *chosen = it->second.chosen;
-    if (us_rows) *us_rows = it->second.us[0] < 0.f ? -it->second.us[0] : it->second.us[0];
-    if (us_pairs) *us_pairs = it->second.us[1] < 0.f ? -it->second.us[1] : it->second.us[1];
+    // the most recently used key of this (N bucket, image size, views per launch, kind), whatever its duplicates class
+    const uint64_t probe = k7_key(N, H, W, V, kind, 0), mask = ~((uint64_t)0x3F << 36);
+    K7Tune* best = nullptr;
+    for (auto& kv : g_k7)
+        if ((kv.first & mask) == (probe & mask) && kv.second.last_use && (!best || kv.second.last_use > best->last_use)) best = &kv.second;
+    if (!best) { set_error("k7_tune_get: no launch of this shape yet", hipSuccess); return GDR_ERR_INVALID_ARG; }
+    k7_harvest(*best);
+    if (chosen) *chosen = best->decided ? best->chosen : -1;
+    if (us_rows) *us_rows = best->us[0] < 0.f ? -best->us[0] : best->us[0];
+    if (us_pairs) *us_pairs = best->us[1] < 0.f ? -best->us[1] : best->us[1];
     return GDR_OK;
 }
 
 void gdr_view_history_reset(void) {
     {   // (the K7 choices start over as well; events of measurements in flight are left to finish)
         std::lock_guard<std::mutex> lk7(g_k7_mu);
-        for (auto& kv : g_k7) { kv.second.calls = 0; kv.second.chosen = 0; kv.second.got = 0; kv.second.us[0] = kv.second.us[1] = 0.f; }
+        for (auto& kv : g_k7) {
+            kv.second.calls = 0; kv.second.chosen = 0; kv.second.got = 0; kv.second.us[0] = kv.second.us[1] = 0.f;
+            kv.second.decided = false; kv.second.last_use = 0;
+        }
     }
     std::lock_guard<std::mutex> lk(g_hist_mu);
     for (auto& kv : g_hist) {     // (the pinned report words stay: a kernel in flight may still write them)
@@ -1627,7 +1667,7 @@ int gsr_backward(const gdr_settings* s, const gsr_inputs* in, const gdr_geom* ge
     if (N == 0) return GDR_OK;
     hipError_t e = hipMemsetAsync(gout->scratch, 0, N * GSR_GRAD_FLOATS * sizeof(float), st);
     if (e != hipSuccess) return hip_fail("memset gradient records", e);
-    { K7Scope k7((int)in->N, s->image_height, s->image_width, 1, 3, st);
+    { K7Scope k7((int)in->N, s->image_height, s->image_width, 1, 3, bin->k7_class, st);
       e = launch_surfel_render_bwd(s, geom, bin, img, gin, gout->scratch, st); }
     if (e != hipSuccess) return hip_fail("surfel_render_bwd", e);
     if ((rc = debug_sync(s, "surfel_render_bwd", st))) return rc;
@@ -1683,7 +1723,7 @@ int gsr_render_backward(const gdr_settings* s, int32_t N, const gdr_geom* geom, 
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = bin->grad_rec_cleared ? hipSuccess : hipMemsetAsync(grad_rec, 0, (size_t)N * GSR_GRAD_FLOATS * sizeof(float), st);
     if (e != hipSuccess) return hip_fail("memset gradient records", e);
-    { K7Scope k7(N, s->image_height, s->image_width, 1, 3, st);
+    { K7Scope k7(N, s->image_height, s->image_width, 1, 3, bin->k7_class, st);
       e = launch_surfel_render_bwd(s, geom, bin, img, gin, grad_rec, st); }
     if (e != hipSuccess) return hip_fail("surfel_render_bwd", e);
     return debug_sync(s, "surfel_render_bwd", st);
@@ -1705,7 +1745,7 @@ int gsr_render_backward_views(int32_t V, const gdr_settings* s, int32_t N, const
         }
     }
     hipError_t e;
-    { K7Scope k7(N, s[0].image_height, s[0].image_width, V, 3, st);
+    { K7Scope k7(N, s[0].image_height, s[0].image_width, V, 3, k7_class_views(V, bins), st);
       e = launch_surfel_render_bwd_views(V, s, geoms, bins, imgs, gins, grad_recs, interleave, st); }
     if (e != hipSuccess) return hip_fail("surfel_render_bwd_views", e);
     return debug_sync(&s[0], "surfel_render_bwd_views", st);

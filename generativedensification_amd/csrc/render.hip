@@ -49,6 +49,42 @@ __device__ __forceinline__ float gauss_power(float dx, float dy, float cx, float
     return fmaf(-0.5f, s, -(cy * (dx * dy)));
 }
 
+// ---- threshold guard (round 5; measured, NOT in the product build: GDR_THRESHOLD_GUARD = 0) ------------------------------
+// The fast path evaluates alpha = opacity * v_exp_f32(p2) on a conic pre-scaled by log2(e) with fused multiply-adds; the
+// oracle (oracle/gdr_oracle.c:277-283) evaluates min(0.99, opacity * expf(power)), power = -0.5 (a dx dx + c dy dy) - b dx dy,
+// with glibc's expf.  Two fp32 evaluations of one formula: they differ by a few ulp — irrelevant to the images (4e-7) except
+// where alpha lands within that distance of the 1/255 skip threshold: there they decide differently and a pixel gains or
+// loses a contributor of weight ~1/255 (the 1-5 "threshold pixels" per four 800x800 views: max |dRGB| 1.6e-3 on them).
+// The guard sends a lane whose fast alpha is within GDR_ALPHA_BAND of 1/255 (32 ulp) through a slow path — the Gaussian's
+// record re-read, the oracle's operation order without contraction, the full-precision expf — shared by K6, the deep K6 and
+// K7.  Same-box A/B (profiles/r05_ab_threshold_guard.txt): it settles 2 of the 5 flipped pixels of the four C4 views and
+// costs C4 -2.0 %, C2 -4.0 %, C3 -3.2 % (K6 +5..12 %, K7 +2..4 %: the branch behind every evaluation breaks the
+// fetch / composite interleave of the unrolled walk).  The other 3 are out of its reach: for elongated Gaussians the terms of
+// p2 are ~200 and cancel to ~8, so the two evaluations differ by up to ~2e-5 relative — a band that wide is no longer rare
+// (one tile slice in four) —, and the `T < 1e-4` stop carries the accumulated rounding of all earlier factors.  The CUDA
+// reference's own expf differs from glibc's in the same way; a flip is the difference between two valid fp32 programs, not
+// an error of either.  Compile with -DGDR_THRESHOLD_GUARD=1 to study it.
+#define GDR_ALPHA_BAND 1.5e-8f
+#ifndef GDR_THRESHOLD_GUARD
+#define GDR_THRESHOLD_GUARD 0
+#endif
+#if GDR_THRESHOLD_GUARD
+#define GDR_WALK_WAVES __attribute__((amdgpu_waves_per_eu(5, 5)))   /* the guard's rare path may spill; the walk keeps 5 waves / SIMD */
+__device__ __forceinline__ bool alpha_near_threshold(float alpha) { return fabsf(alpha - GDR_ALPHA_MIN) <= GDR_ALPHA_BAND; }
+#else
+#define GDR_WALK_WAVES
+__device__ __forceinline__ bool alpha_near_threshold(float) { return false; }
+#endif
+__device__ __forceinline__ float2 alpha_exact(const float4* __restrict__ rec, uint32_t id, float pxf, float pyf) {
+#pragma clang fp contract(off)
+    const float4 a0 = rec[4 * (size_t)id], co = rec[4 * (size_t)id + 1];
+    const float dx = a0.x - pxf, dy = a0.y - pyf;
+    const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
+    const float G = expf(power);
+    const float alpha = fminf(0.99f, co.w * G);
+    return make_float2(power > 0.f ? 0.f : alpha, G);     // (alpha, G)
+}
+
 
 struct Entry {  // one staged list entry, in registers
     uint32_t e;
@@ -299,7 +335,8 @@ struct FwdView {
 struct FwdViews { FwdView v[GDR_MAX_VIEWS]; };
 
 template <int LOSS>
-__global__ __launch_bounds__(GDR_BLOCK) void render_fwd_kernel(const FwdViews vs, int V, int interleave, int W, int H, int gx,
+__global__ __launch_bounds__(GDR_BLOCK) GDR_WALK_WAVES
+void render_fwd_kernel(const FwdViews vs, int V, int interleave, int W, int H, int gx,
                                                                int ntiles) {
     __shared__ SliceLds lds;
     __shared__ RowLists rlists;
@@ -416,6 +453,10 @@ __global__ __launch_bounds__(GDR_BLOCK) void render_fwd_kernel(const FwdViews vs
             const float p2 = gauss_power(dx, dy, en.co.x, en.co.y, en.co.z);
             float alpha = fminf(0.99f, en.co.w * __builtin_amdgcn_exp2f(p2));
             alpha = (p2 > 0.f) ? 0.f : alpha;        // reference skips power > 0
+            if (__builtin_expect(__ballot(alpha_near_threshold(alpha)) != 0ull, 0)) {   // threshold guard (rare)
+                if (alpha_near_threshold(alpha))
+                    alpha = alpha_exact(rec, point_list[range.x + (uint32_t)pos0 + en.e], pxf, pyf).x;
+            }
             const float a_c = (alpha >= thr) ? alpha : 0.f;
             const float T_new = fmaf(-a_c, T, T);     // T (1 - alpha); == T when a_c == 0
             const bool stop = T_new < 0.0001f;        // only possible when a_c > 0 (T >= 1e-4 while live)
@@ -625,6 +666,10 @@ __global__ __launch_bounds__(GDR_BLOCK) void render_fwd_deep_kernel(
             const float p2 = gauss_power(dx, dy, cur.co.x, cur.co.y, cur.co.z);
             float alpha = fminf(0.99f, cur.co.w * __builtin_amdgcn_exp2f(p2));
             alpha = (p2 > 0.f) ? 0.f : alpha;         // (null entry: opacity 0 -> alpha 0)
+            if (__builtin_expect(__ballot(alpha_near_threshold(alpha)) != 0ull, 0)) {   // threshold guard (rare)
+                if (alpha_near_threshold(alpha))
+                    alpha = alpha_exact(rec, point_list[range.x + (uint32_t)(r * GDR_BLOCK) + cur.e], pxf, pyf).x;
+            }
             float a_c = (alpha >= thr) ? alpha : 0.f;
             // transmittance in front of this lane's entry: chain through the quad, T_{j+1} = fma(-a_j, T_j, T_j)
             float Tj = T;
@@ -950,9 +995,15 @@ __device__ __forceinline__ void render_bwd_body(const BwdViews& vs, int V, int i
             auto accumulate = [&](const Entry& en) {
                 const float dx = en.m.x - pxf, dy = en.m.y - pyf;
                 const float p2 = gauss_power(dx, dy, en.co.x, en.co.y, en.co.z);
-                const float G = __builtin_amdgcn_exp2f(p2);
+                float G = __builtin_amdgcn_exp2f(p2);
                 float alpha = fminf(0.99f, en.co.w * G);
                 alpha = (p2 > 0.f) ? 0.f : alpha;
+                if (__builtin_expect(__ballot(alpha_near_threshold(alpha)) != 0ull, 0)) {   // threshold guard (rare): as K6
+                    if (alpha_near_threshold(alpha)) {
+                        const float2 ag = alpha_exact(rec, s_id[en.e], pxf, pyf);
+                        alpha = ag.x; G = ag.y;
+                    }
+                }
                 // contributes iff it did in the forward: alpha >= 1/255 and position < last_contributor
                 // (the null entry has opacity 0 -> alpha 0)
                 const float lim = (top - (int)en.e < last_contributor) ? GDR_ALPHA_MIN : INFINITY;
@@ -1022,7 +1073,8 @@ __device__ __forceinline__ void render_bwd_body(const BwdViews& vs, int V, int i
 }
 
 template <bool M2_ONLY, bool LOSS = false>
-__global__ __launch_bounds__(GDR_BLOCK) void render_bwd_kernel(const BwdViews vs, int V, int interleave, int n_extra_max,
+__global__ __launch_bounds__(GDR_BLOCK) GDR_WALK_WAVES
+void render_bwd_kernel(const BwdViews vs, int V, int interleave, int n_extra_max,
                                                                int W, int H, int gx, int ntiles) {
     render_bwd_body<M2_ONLY, LOSS, false>(vs, V, interleave, n_extra_max, W, H, gx, ntiles);
 }

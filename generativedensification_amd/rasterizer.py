@@ -705,6 +705,9 @@ def _forward_views_impl(means3D, means2D, sh, opacities, scales, rotations, sett
     H, W = int(settings_list[0].image_height), int(settings_list[0].image_width)
     if any(int(rs.image_height) != H or int(rs.image_width) != W for rs in settings_list):
         raise RuntimeError("render_views: all views must share one image size")
+    if V > L.GDR_MAX_NODE_VIEWS:
+        raise RuntimeError(f"render_views: {V} views in one node; one native forward call takes at most {L.GDR_MAX_NODE_VIEWS} "
+                           "(include/gdr.h GDR_MAX_NODE_VIEWS) — split the view list")
     e = empty_f32(dev)
     keep = [means3D, opacities, sh, e, scales, rotations, e]
     f32 = dict(dtype=torch.float32, device=dev)

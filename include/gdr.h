@@ -22,10 +22,14 @@
  *   - every pointer is a DEVICE pointer to fp32/int32 data unless it says "host";
  *   - matrices are 16 contiguous floats in the reference's row-vector convention
  *     (/root/reference/lightning/utils.py:37-47): p_view = [p,1] @ viewmatrix;
- *   - the caller owns every buffer; the library allocates no device memory and keeps no
- *     state (except the opt-in timing facility at the end of this header and the pooled events of
- *     gdr_host_copy_begin / _wait) => re-entrant,
- *     thread-safe for distinct workspaces, one call per stream;
+ *   - the caller owns every buffer; the library allocates no device memory.  Process-wide state it DOES keep (all
+ *     mutex-guarded; results never depend on any of it except where said): (1) the per-shape view history behind
+ *     gdr_view_plan_for — duplicates per Gaussian and launch-size reports of recent calls, gdr_view_history_*;
+ *     (2) the K7 choice per launch shape, gdr_k7_tune_* — decided ONCE per shape by timing, so WHICH of two
+ *     kernels sums a gradient (the same terms in another order: differences at the fp32 rounding level) can differ
+ *     between processes unless gdr_k7_tune_override pins it; (3) pooled pinned words / events (gdr_host_copy_*,
+ *     gdr_forward_view(s), gdr_view_reuse_probe); (4) the opt-in timing facility at the end of this header.
+ *     Re-entrant, thread-safe for distinct workspaces, one call per stream;
  *   - all work is enqueued on `stream`; the only host synchronisation is the
  *     optional read-back of num_rendered in gdr_preprocess_forward;
  *   - return value: 0 = GDR_OK, negative = error (never throws across the ABI).
@@ -185,6 +189,10 @@ typedef struct gdr_binning {
     int32_t hist_width;  /* rows of tile_hist = workgroups of the count / scatter kernels, <= 256 */
     int32_t hist_tiles;  /* columns of tile_hist = the tile count it was carved for, rounded up to 64; a binning call on an image
                           * with more tiles than that uses the radix partition instead (same lists) — was reserved1 until v14 */
+    int32_t k7_class;    /* v16: duplicates per Gaussian of the view as a quarter-octave class (1..63), set by gdr_forward_view(s)
+                          * from the exact count; 0 = unknown.  Part of the key under which the library remembers which K7
+                          * serves a scene (gdr_k7_tune_*) — nothing else reads it */
+    int32_t reserved2;
 } gdr_binning;
 
 /* Image state (upstream "imgBuffer"). */
@@ -412,12 +420,17 @@ void gdr_view_history_set(int32_t N, int32_t H, int32_t W, int32_t surfel, doubl
  * the arithmetic, bounds K7.  A second kernel lets the two rows of an 8x4 area walk the union of their lists and publish
  * ONE line where that saves enough lines per extra iteration — faster for Gaussians of 10+ pixels spread over the image,
  * slower for sub-pixel Gaussians and object-like scenes.  The gradients are the same sums in another order.  Per (device,
- * N bucket, image size, views per launch, entry kind) the library times both kernels (events around four consecutive
- * launches, rows / pairs / rows / pairs, after the shape's first 8 launches and then every 256) and keeps the faster.
+ * N bucket, duplicates-per-Gaussian class of the views — gdr_binning.k7_class —, image size, views per launch, entry kind)
+ * the library times both kernels ONCE (events around four consecutive launches, rows / pairs / rows / pairs, after the key's
+ * first 8 launches; never on a stream under graph capture) and keeps the faster for the life of the process (v16; until v15
+ * the round was repeated every 256 launches, so the variant could change mid-run).  A scene that drifts moves to another
+ * class, i.e. another key with a round of its own.
  * kind: 0 gdr_backward / gdr_render_backward(_views), 1 the _loss entries, 2 the mean2D-only entries, 3 the 2DGS K7s
- * (gsr_backward / gsr_render_backward(_views): 16 + 4 totals per pair, two record lines).
- * _override: -1 measure and choose (default), 0 rows only, 1 row pairs always (tests, A/B).  _get: the choice and the last
- * round's times in microseconds (error if the shape has not been launched).  gdr_view_history_reset restarts the choices. */
+ * (gsr_backward / gsr_render_backward(_views): 16 + 4 totals per pair, two record lines), 4 gdr_render_backward_mean2d_loss.
+ * _override: -1 measure and choose (default), 0 rows only, 1 row pairs always (tests, A/B, bit-reproducible runs: the Python
+ * loader maps GDR_K7_PAIRS=0/1 onto it).  _get: the choice (-1 = not decided yet: rows serve meanwhile) and the round's times in
+ * microseconds of the most recently used key of that (N bucket, image size, V, kind) — error if there is none.
+ * gdr_view_history_reset restarts the choices. */
 void gdr_k7_tune_override(int32_t mode);
 int gdr_k7_tune_get(int32_t N, int32_t H, int32_t W, int32_t V, int32_t kind, int32_t* chosen, float* us_rows, float* us_pairs);
 

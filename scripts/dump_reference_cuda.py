@@ -13,7 +13,12 @@ the open conventions listed in INTEGRATION.md §0 are decided by data, not by li
   R3  what do columns 2:4 of the carrier hold -> compared with the oracle's sum |per-pixel term|
   R4  is depth sum_i w_i z_i or normalised    -> depth / alpha against the oracle's two variants
   tie order, 0.99 clamp, 1/255 and 1e-4 thresholds -> n_contrib-equivalent: image exactness on threshold pixels
-`tests/test_golden_cpu.py` picks the file up when present (compares the oracle with it); nothing else changes.
+`tests/test_cuda_reference.py` picks every tests/golden/cuda_reference_*.npz up when present: the oracle (CPU suite) and the
+HIP path (-m gpu) are compared with it under north_star's bars, and the test prints which of R1 / R3 / R4 the data selects
+(tests/cuda_reference.py).  With no file both skip, naming this script.
+
+`--standin oracle` runs the SAME dump code on the repo's oracle stand-in (CPU, no CUDA): that is how the consumer is tested
+here (a synthetic dump in a temporary directory — never committed as a cuda_reference_* fixture, it pins nothing).
 """
 import argparse
 import math
@@ -29,16 +34,26 @@ def main():
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--deg", type=int, default=3)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--standin", choices=["oracle"], default=None,
+                    help="self-test of the consumer: dump the repo's oracle stand-in (CPU) instead of the CUDA extension")
     a = ap.parse_args()
-    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer  # the REAL extension
-
     import os
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    if a.standin:
+        from oracle.gdr_oracle import make_standin_module
+        mod = make_standin_module("f32", nthreads=os.cpu_count() or 1)
+        GaussianRasterizationSettings, GaussianRasterizer = mod.GaussianRasterizationSettings, mod.GaussianRasterizer
+        dev, source = torch.device("cpu"), "oracle-standin (synthetic: pins nothing)"
+    else:
+        from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer  # the REAL extension
+        import diff_gaussian_rasterization as _ext
+        if "generativedensification_amd" in (getattr(_ext, "__file__", "") or "") or hasattr(_ext, "__oracle_standin__"):
+            raise SystemExit("this is the MI355X drop-in package, not the reference's CUDA extension: nothing to pin")
+        dev, source = torch.device("cuda"), "cuda"
     from generativedensification_amd.camera import orbit_cameras      # pure torch: same cameras / scene as our fixtures
     from generativedensification_amd.synthetic import make_scene
 
-    dev = torch.device("cuda")
     sc = make_scene(a.n, a.seed, sh_degree=a.deg)
     cam = orbit_cameras(4, a.size, a.size)[1]
     leaves = dict(means3D=sc["centers"], shs=sc["shs"], opacities=torch.sigmoid(sc["opacity"]),
@@ -61,7 +76,7 @@ def main():
             out[f"grad_{tag}_{k}"] = torch.zeros(1) if v is None else v
     np.savez_compressed(a.out, **{k: v.detach().cpu().numpy() for k, v in out.items()},
                         upstream_color=gc.cpu().numpy(), upstream_depth=gd.cpu().numpy(), upstream_alpha=ga.cpu().numpy(),
-                        n=a.n, size=a.size, deg=a.deg, seed=a.seed)
+                        n=a.n, size=a.size, deg=a.deg, seed=a.seed, source=source)
     print("wrote", a.out)
 
 
