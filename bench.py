@@ -530,6 +530,9 @@ def main():
                     help="memory order of the Gaussians: random (default, the worst case) or 3D Morton order")
     ap.add_argument("--host-profile", action="store_true",
                     help="cProfile of the host side of the timed steps (top entries to stderr; slows the run)")
+    ap.add_argument("--overlap-comm", action="store_true",
+                    help="with --grad-allreduce: issue the reduce-scatter + all-gather asynchronously and join them before the "
+                         "next step's backward (they overlap the next forward)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed even at WORLD_SIZE=1 (exercises the RCCL barrier / all-gather / "
                          "all-reduce calls of the N>1 path on a one-GPU box)")
@@ -703,17 +706,20 @@ def main():
                     loss = (((out["image"] - targets[j]) ** 2).mean() if args.image_loss
                             else (surfel_loss if surfel else view_loss)(out, targets[j]))
                     if backward_per_view:
+                        wait_pending()
                         loss.backward()
                         loss = loss.detach()
                     losses.append(loss)
                 losses = torch.stack(losses)
                 if not backward_per_view:
+                    wait_pending()
                     losses.sum().backward()
                     losses = losses.detach()
             elif args.image_loss:
                 outs = (rnd.render_views(cams, rays, None, *a, raw=True) if surfel
                         else render_views(rnd, cams, None, params, dev, raw=True))
                 lv = torch.stack([((o["color"] - targets_chw[j]) ** 2).mean() for j, o in enumerate(outs)])
+                wait_pending()
                 lv.sum().backward()
                 losses = lv.detach()
             elif surfel:
@@ -728,6 +734,7 @@ def main():
                 else:
                     outs = rnd.render_views(cams, rays, None, *a)
                     lv = torch.stack([surfel_loss(o, targets[j]) for j, o in enumerate(outs)])
+                wait_pending()
                 lv.sum().backward()
                 losses = lv.detach()
             else:               # multi-view entry point: all views of the shard in one rasterizer node
@@ -744,6 +751,7 @@ def main():
                 else:
                     out = render_views(rnd, cams, None, params, dev, stacked=True)
                     lv = views_loss(out, targets)  # (V,) per-view losses on the view-stacked tensors
+                wait_pending()
                 lv.sum().backward()
                 losses = lv.detach()
             ev = None
@@ -754,7 +762,10 @@ def main():
             if ev:
                 ev[1].record()
             if args.grad_allreduce:
-                allreduce_gaussian_grads(plist)
+                if args.overlap_comm:   # RS + AG on the process group's stream, next to the NEXT step's forward; joined before
+                    pending_box["h"] = allreduce_gaussian_grads(plist, async_op=True)     # its backward writes the buffer again
+                else:
+                    allreduce_gaussian_grads(plist)
             if ev:
                 ev[2].record()
                 comm_events.append(ev)
@@ -762,11 +773,18 @@ def main():
         return step
 
     comm_events = None      # a list while the collectives are being timed
+    pending_box: dict = {}
+
+    def wait_pending():
+        h = pending_box.pop("h", None)
+        if h is not None:
+            h.wait()
 
     step = make_step(args.per_view or args.backward_per_view, args.unfused, args.torch_loss, args.loss_kernels,
                      args.stacked_loss, args.backward_per_view)
 
     def barrier():
+        wait_pending()
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
@@ -828,10 +846,21 @@ def main():
             step()
         torch.cuda.synchronize()
         k_ev = len(comm_events)
-        comm_ms = dict(loss_gather=round(sum(e[0].elapsed_time(e[1]) for e in comm_events) / k_ev, 4),
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)                     # how many ranks the collectives really span (1 per process of the group)
+        G_, B_ = dist.get_world_size(), sum(p.numel() * p.element_size() for p in plist)
+        link = 153e9                              # one xGMI link, one direction (MI355X_MICROARCH.md: 7 links x ~153 GB/s per GPU)
+        comm_ms = dict(rccl_ranks_seen=int(ones.item()), backend=dist.get_backend(),
+                       grad_bytes=B_, overlap=bool(args.overlap_comm),
+                       expected_grad_allreduce_ms=(None if G_ < 2 else dict(
+                           direct_all_links=round(2e3 * (B_ / G_) / link, 3), ring_one_link=round(2e3 * B_ * (G_ - 1) / G_ / link, 3),
+                           note="reduce-scatter + all-gather of the packed gradients over xGMI: every peer pair moves 1/G of the "
+                                "buffer per phase when all 7 point-to-point links carry traffic at once; a ring is bound by one link")),
+                       loss_gather=round(sum(e[0].elapsed_time(e[1]) for e in comm_events) / k_ev, 4),
                        grad_allreduce=(round(sum(e[1].elapsed_time(e[2]) for e in comm_events) / k_ev, 4) if args.grad_allreduce else None),
                        grads="kept (zeroed each step: autograd accumulates into the packed buffer)" if args.keep_grads
-                       else "dropped each step (one copy_ into the packed buffer per call)",
+                       else "dropped each step; from the second step on K9 writes them straight into the packed buffer (gradient sinks, "
+                            "rasterizer.register_grad_sink): no copy in front of the collectives",
                        note="ms per step on this rank, HIP events on the caller's stream around gather_view_losses / "
                             "allreduce_gaussian_grads (packing included); rank 0")
         comm_events = None

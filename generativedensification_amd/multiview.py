@@ -110,7 +110,41 @@ def _grad_pack(params, world):
     return pack
 
 
-def allreduce_gaussian_grads(params: Sequence[torch.Tensor]) -> None:
+class _PendingReduce:
+    """Collectives in flight (allreduce_gaussian_grads(async_op=True)).  wait(): the caller's stream waits for them — call it
+    before anything reads the gradients (the optimizer) or writes the packed buffer again (the next backward)."""
+
+    def __init__(self, works):
+        self.works = works
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
+        self.works = []
+
+
+def prepare_grad_sinks(params: Sequence[torch.Tensor], any_device: bool = False) -> None:
+    """Create the packed gradient buffer(s) of `params` now and register every slice as the gradient sink of its tensor
+    (rasterizer.register_grad_sink): from the next backward on, the multi-view nodes' K9 writes the gradients of these leaves
+    straight into the buffer the collectives move — no copy in allreduce_gaussian_grads.  (Called by
+    allreduce_gaussian_grads itself, so the first step pays one copy and the later ones none.)"""
+    if not (dist.is_available() and dist.is_initialized()):
+        return
+    world = dist.get_world_size()
+    groups: dict = {}
+    for p in params:
+        groups.setdefault((p.device, p.dtype), []).append(p)
+    for (dev, dtype), group in groups.items():
+        if dtype != torch.float32 or (dev.type != "cuda" and not any_device):     # (any_device: the CPU tests of the mechanism)
+            continue
+        from . import rasterizer as R
+        pack = _grad_pack(group, world)
+        for p, v in zip(group, pack.views):
+            if p.is_leaf and p.requires_grad and p.is_contiguous():
+                R.register_grad_sink(p, v)
+
+
+def allreduce_gaussian_grads(params: Sequence[torch.Tensor], async_op: bool = False):
     """Sum the per-Gaussian attribute gradients over ranks: one packed buffer
     (236 B/Gaussian at SH degree 3) moved as reduce-scatter + all-gather so that all
     7 xGMI links of a GPU carry 1/G of it each, instead of a per-tensor ring all-reduce.
@@ -131,13 +165,20 @@ def allreduce_gaussian_grads(params: Sequence[torch.Tensor]) -> None:
 
     (Not chunked: the six gradient tensors of a Gaussian set come out of ONE kernel launch (K8+K9 writes every output), so
     there is no earlier point at which part of the buffer is final, and collectives queued on one communicator run in order —
-    chunks would neither start sooner nor overlap each other.)"""
+    chunks would neither start sooner nor overlap each other.)
+
+    Round 5: (a) no copy at all in the steady state — the slices of the packed buffer are registered as the gradient sinks of
+    their tensors (prepare_grad_sinks), the multi-view nodes' K9 writes there directly and `.grad` arrives as a view of the
+    buffer; (b) async_op=True returns a handle instead of making the caller's stream wait: the collectives run on the process
+    group's stream next to whatever the caller enqueues next (the next sample's forward) — handle.wait() before the optimizer
+    reads the gradients or the next backward writes the buffer."""
     if _no_peers():
-        return
+        return _PendingReduce([]) if async_op else None
     world = dist.get_world_size()
     params = list(params)
     if not params:
-        return
+        return _PendingReduce([]) if async_op else None
+    works = []
     groups: dict = {}
     for p in params:     # one pack per dtype (and device), the order within a group as given
         groups.setdefault((p.device, p.dtype), []).append(p)
@@ -148,7 +189,13 @@ def allreduce_gaussian_grads(params: Sequence[torch.Tensor]) -> None:
                 v.zero_()
             elif p.grad.data_ptr() != v.data_ptr() or p.grad.dtype != v.dtype:
                 v.copy_(p.grad)
-        dist.reduce_scatter_tensor(pack.shard, pack.flat, op=dist.ReduceOp.SUM)
-        dist.all_gather_into_tensor(pack.flat, pack.shard)
+        w1 = dist.reduce_scatter_tensor(pack.shard, pack.flat, op=dist.ReduceOp.SUM, async_op=async_op)
+        if async_op and dist.get_backend() != "nccl":
+            w1.wait()      # (RCCL runs a group's collectives in issue order on its stream; gloo's worker threads do not)
+        w2 = dist.all_gather_into_tensor(pack.flat, pack.shard, async_op=async_op)
+        works += [w1, w2] if async_op else []
         for p, v in zip(group, pack.views):
             p.grad = v
+    if params[0].is_cuda:
+        prepare_grad_sinks(params)
+    return _PendingReduce(works) if async_op else None

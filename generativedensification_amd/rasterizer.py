@@ -17,6 +17,7 @@ path: non-HIP tensors raise.
 from __future__ import annotations
 
 import ctypes as C
+import math
 import os as _os
 import threading
 from typing import NamedTuple, Optional
@@ -466,9 +467,78 @@ def _take_records(ctx, lo, n, N, floats, dev):
     return torch.empty(n, max(N, 1) * floats, dtype=torch.float32, device=dev), 0
 
 
-def _grad_buffers(N, M, f32):
-    return dict(means3D=torch.empty(N, 3, **f32), means2D=torch.empty(N, 4, **f32), shs=torch.empty(N, M, 3, **f32),
-                opacities=torch.empty(N, 1, **f32), scales=torch.empty(N, 3, **f32), rotations=torch.empty(N, 4, **f32))
+# ---- gradient sinks: K9 writes a leaf's gradient where the collective needs it ------------------------------------------
+# The reference's DDP reduces gradients in place (/root/reference/train_lightning.py:74).  View-sharded rendering sums the
+# packed per-Gaussian gradients over the ranks (multiview.allreduce_gaussian_grads: reduce-scatter + all-gather of ONE packed
+# buffer); until round 4 the gradients came out of K9 in fresh tensors and were copied into that buffer first (472 MB at 2 M
+# Gaussians: 0.37 ms of a 3 ms step before a byte crossed xGMI).  A registered sink = "the gradient of THIS leaf belongs at
+# THIS address": the multi-view nodes hand the address to K9 as its output pointer (gdr_preprocess_backward_views takes
+# caller-provided outputs) and return an alias of it, which autograd's AccumulateGrad adopts as `.grad` without a copy.
+# Only when that is safe: the node's input IS the registered leaf (same memory, fp32), the leaf has no gradient yet (an
+# existing `.grad` is accumulated into in place — it may be this very memory), and no other node of the running backward
+# pass has taken the sink.
+_GRAD_SINKS: dict = {}      # data_ptr of the leaf -> [weakref(leaf), sink tensor (the leaf's shape), graph task that took it]
+
+
+def register_grad_sink(leaf: torch.Tensor, sink: torch.Tensor):
+    import weakref
+    if sink.shape != leaf.shape or sink.dtype != torch.float32 or leaf.dtype != torch.float32 or sink.device != leaf.device \
+            or not sink.is_contiguous():
+        raise ValueError("register_grad_sink: the sink must be a contiguous fp32 tensor of the leaf's shape on its device")
+    with _HIST_LOCK:
+        for k in [k for k, e in _GRAD_SINKS.items() if e[0]() is None]:
+            del _GRAD_SINKS[k]
+        _GRAD_SINKS[leaf.data_ptr()] = [weakref.ref(leaf), sink, None]
+
+
+def unregister_grad_sinks():
+    with _HIST_LOCK:
+        _GRAD_SINKS.clear()
+
+
+def _sink_for(t: torch.Tensor):
+    """The registered sink for a node input `t`, or None (see above)."""
+    if not _GRAD_SINKS:
+        return None
+    e = _GRAD_SINKS.get(t.data_ptr())
+    if e is None:
+        return None
+    leaf = e[0]()
+    if (leaf is None or leaf.grad is not None or not leaf.is_leaf or not leaf.requires_grad or leaf.data_ptr() != t.data_ptr()
+            or leaf.numel() != t.numel() or t.dtype != torch.float32 or leaf._backward_hooks):
+        return None
+    task = torch._C._current_graph_task_id()
+    with _HIST_LOCK:
+        if e[2] is not None and e[2] == task:
+            return None            # another node of this pass already writes there: this one gets its own buffer
+        e[2] = task
+    return e[1]
+
+
+def _grad_buffers(N, M, f32, inputs=None, scale_cols=3):
+    """Output buffers of one K8+K9 launch.  inputs: the node's (means3D, sh, opacities, scales, rotations) as saved for
+    backward — an input with a registered gradient sink gets the sink as its buffer.  Returns (buffers, keys backed by a sink)."""
+    shapes = dict(means3D=(N, 3), means2D=(N, 4), shs=(N, M, 3), opacities=(N, 1), scales=(N, scale_cols), rotations=(N, 4))
+    g, sunk = {}, set()
+    if inputs is not None and _GRAD_SINKS:
+        for k, t in zip(("means3D", "shs", "opacities", "scales", "rotations"), inputs):
+            s = _sink_for(t)
+            if s is not None and s.numel() == math.prod(shapes[k]):
+                g[k] = s
+                sunk.add(k)
+    for k, shp in shapes.items():
+        if k not in g:
+            g[k] = torch.empty(*shp, **f32)
+    return g, sunk
+
+
+def _returned(g, sunk, key, dtype):
+    """What a node returns for gradient `key`: a sink-backed buffer goes back as a NEW alias of the sink (AccumulateGrad adopts
+    an incoming gradient only if nobody else holds the tensor object; the registry does hold the sink's)."""
+    t = g[key]
+    if key in sunk:
+        return t.detach()
+    return t if t.dtype == dtype else t.to(dtype)
 
 
 def _kept_settings(ctx, dev, keep2):
@@ -835,7 +905,9 @@ class _RenderViews(torch.autograd.Function):
                                                     C.byref(st.img), C.byref(gin), recs[k].data_ptr(), sides.stream(v)),
                             "gdr_render_backward")
                 if g is None:
-                    g, inp = _grad_buffers(N, M, f32), _inputs_struct(N, M, means3D, opacities, sh, e, scales, rotations, e, ctx.flags)
+                    g, sunk = _grad_buffers(N, M, f32, (means3D, sh, opacities, scales, rotations) if all(
+                        dt == torch.float32 for dt in ctx.in_dtypes) else None)
+                    inp = _inputs_struct(N, M, means3D, opacities, sh, e, scales, rotations, e, ctx.flags)
                 r_arr = (C.c_void_p * n)(*[ctx.radii[lo + k].data_ptr() if N else None for k in range(n)])
                 rec_arr = (C.c_void_p * n)(*[recs[k].data_ptr() for k in range(n)])
                 gout = L.GdrGradOutputs(_ptr(g["means3D"]), _ptr(g["means2D"]), _ptr(g["shs"]), None,
@@ -852,8 +924,9 @@ class _RenderViews(torch.autograd.Function):
             gm2 = torch.cat([gm2[:, :2], torch.zeros_like(gm2[:, :1])], dim=1)
         elif cols != 4:
             gm2 = gm2[:, :cols].contiguous()
-        grads = [g["means3D"], gm2, g["shs"], g["opacities"], g["scales"], g["rotations"]]
-        grads = [t if t.dtype == dt else t.to(dt) for t, dt in zip(grads, ctx.in_dtypes)]
+        g["means2D"] = gm2
+        grads = [_returned(g, sunk, k, dt) for k, dt in zip(("means3D", "means2D", "shs", "opacities", "scales", "rotations"),
+                                                            ctx.in_dtypes)]
         return (*grads, None, None)
 
 
@@ -920,7 +993,9 @@ class _RenderViewsLoss(torch.autograd.Function):
                                                          ctx.w[0], ctx.w[1], go[v:v + 1].data_ptr(), recs[k].data_ptr(),
                                                          sides.stream(v)), "gdr_render_backward_loss")
                 if g is None:
-                    g, inp = _grad_buffers(N, M, f32), _inputs_struct(N, M, means3D, opacities, sh, e, scales, rotations, e, ctx.flags)
+                    g, sunk = _grad_buffers(N, M, f32, (means3D, sh, opacities, scales, rotations) if all(
+                        dt == torch.float32 for dt in ctx.in_dtypes) else None)
+                    inp = _inputs_struct(N, M, means3D, opacities, sh, e, scales, rotations, e, ctx.flags)
                 r_arr = (C.c_void_p * n)(*[ctx.radii[lo + k].data_ptr() if N else None for k in range(n)])
                 rec_arr = (C.c_void_p * n)(*[recs[k].data_ptr() for k in range(n)])
                 gout = L.GdrGradOutputs(_ptr(g["means3D"]), _ptr(g["means2D"]), _ptr(g["shs"]), None,
@@ -937,8 +1012,9 @@ class _RenderViewsLoss(torch.autograd.Function):
             gm2 = torch.cat([gm2[:, :2], torch.zeros_like(gm2[:, :1])], dim=1)
         elif cols != 4:
             gm2 = gm2[:, :cols].contiguous()
-        grads = [g["means3D"], gm2, g["shs"], g["opacities"], g["scales"], g["rotations"]]
-        grads = [t if t.dtype == dt else t.to(dt) for t, dt in zip(grads, ctx.in_dtypes)]
+        g["means2D"] = gm2
+        grads = [_returned(g, sunk, k, dt) for k, dt in zip(("means3D", "means2D", "shs", "opacities", "scales", "rotations"),
+                                                            ctx.in_dtypes)]
         return (*grads, None, None, None, None, None)
 
 

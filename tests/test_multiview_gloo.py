@@ -72,9 +72,61 @@ def _worker(rank, world, port, n_views, q):
         assert h["wide"].grad.dtype == torch.float64 and h["wide"].grad[3].item() == float(sum(range(1, world + 1)))
         assert g["centers"].grad[0, 0].item() == float(sum(range(1, world + 1)))      # the first set's result is intact
         assert h["centers"].grad.data_ptr() != g["centers"].grad.data_ptr()
+        _sink_path(rank, world)
         q.put((rank, allv.tolist(), first[0], first[1]))
     finally:
         dist.destroy_process_group()
+
+
+def _sink_path(rank, world):
+    """Round 5: gradients written where the collective needs them (rasterizer.register_grad_sink) + asynchronous collectives.
+    A node shaped like the multi-view nodes' backward takes its output buffers from rasterizer._grad_buffers: with sinks
+    registered its gradients ARE slices of the packed buffer (adopted by autograd without a copy), the reduce moves them
+    in place, and a second node of the same backward pass gets buffers of its own."""
+    from generativedensification_amd import rasterizer as R
+    from generativedensification_amd.multiview import _grad_pack, prepare_grad_sinks
+    N, M = 6, 4
+    keys = ("means3D", "shs", "opacities", "scales", "rotations")
+    shapes = dict(means3D=(N, 3), shs=(N, M, 3), opacities=(N, 1), scales=(N, 3), rotations=(N, 4))
+    leaves = [torch.ones(*shapes[k], requires_grad=True) for k in keys]
+
+    class K9(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, *ins):
+            ctx.save_for_backward(*ins)
+            return sum(t.sum() for t in ins)
+
+        @staticmethod
+        def backward(ctx, go):
+            g, sunk = R._grad_buffers(N, M, dict(dtype=torch.float32), ctx.saved_tensors)
+            K9.sunk.append(set(sunk))
+            for k in keys:
+                g[k].fill_(float(rank + 1))
+            return tuple(R._returned(g, sunk, k, torch.float32) for k in keys)
+    K9.sunk = []
+    prepare_grad_sinks(leaves, any_device=True)
+    pack = _grad_pack(leaves, world)
+    try:
+        K9.apply(*leaves).backward()
+        assert K9.sunk == [set(keys)]
+        assert [p.grad.data_ptr() for p in leaves] == [v.data_ptr() for v in pack.views]      # adopted, not copied
+        h = allreduce_gaussian_grads(leaves, async_op=True)
+        h.wait()
+        want = float(sum(range(1, world + 1)))
+        assert all(bool((p.grad == want).all()) for p in leaves)
+        assert [p.grad.data_ptr() for p in leaves] == [v.data_ptr() for v in pack.views]
+        # two nodes in one pass: the first takes the sinks, the second gets its own buffers; an existing .grad: no sink at all
+        for p in leaves:
+            p.grad = None
+        K9.sunk = []
+        (K9.apply(*leaves) + K9.apply(*leaves)).backward()
+        assert sorted(len(x) for x in K9.sunk) == [0, len(keys)]
+        assert all(bool((p.grad == 2.0 * (rank + 1)).all()) for p in leaves)
+        K9.sunk = []
+        K9.apply(*leaves).backward()          # .grad exists: accumulated into, never aliased by the incoming gradient
+        assert K9.sunk == [set()] and all(bool((p.grad == 3.0 * (rank + 1)).all()) for p in leaves)
+    finally:
+        R.unregister_grad_sinks()
 
 
 @pytest.mark.parametrize("n_views", [4, 5, 1])
