@@ -98,6 +98,8 @@ __global__ __launch_bounds__(GDR_BLOCK) void preprocess_fwd_kernel(
     load_cam(cam, view, proj, campos);
     const int i = blockIdx.x * GDR_BLOCK + threadIdx.x;
     const int gx = (W + GDR_TILE - 1) / GDR_TILE, gy = (H + GDR_TILE - 1) / GDR_TILE;
+    constexpr int REC_STRIDE = 20;
+    __shared__ float rec_out[GDR_BLOCK * REC_STRIDE];
 
     uint32_t tiles = 0;
     if (i < N) {
@@ -204,7 +206,14 @@ __global__ __launch_bounds__(GDR_BLOCK) void preprocess_fwd_kernel(
         }
         radii[i] = rad;
         g_depths[i] = depth;
-        write_rec(g_rec, i, pxy, depth, con_o, rgbd);
+        {   // this lane's record into its wave's OUT slice (stored coalesced below: see preprocess_fwd_views_kernel)
+            const float2 ext = alpha_extent(con_o);
+            float* mine = rec_out + (int)threadIdx.x * REC_STRIDE;
+            *reinterpret_cast<float4*>(mine) = make_float4(pxy.x, pxy.y, depth, 0.f);
+            *reinterpret_cast<float4*>(mine + 4) = con_o;
+            *reinterpret_cast<float4*>(mine + 8) = rgbd;
+            *reinterpret_cast<float4*>(mine + 12) = make_float4(ext.x, ext.y, 0.f, 0.f);
+        }
         if (!cov3D_precomp) {
 #pragma unroll
             for (int k = 0; k < 6; ++k) g_cov3D[6 * i + k] = c6[k];
@@ -212,6 +221,19 @@ __global__ __launch_bounds__(GDR_BLOCK) void preprocess_fwd_kernel(
         g_rect[i] = rect;
         g_tiles[i] = tiles;
         g_clamped[i] = (uint8_t)clampbits;
+    }
+    {   // 64 records = 4 KB contiguous: four coalesced 1 KB stores per wave instead of 64-line-stride float4 stores per lane
+        const int wave0 = (int)(threadIdx.x & ~63u), lane = (int)(threadIdx.x & 63u);
+        const int first = blockIdx.x * GDR_BLOCK + wave0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const int nrec = min(GDR_WAVE, N - first);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int q = lane + GDR_WAVE * j, r = q >> 2, c = q & 3;
+            if (r < nrec) g_rec[4 * (size_t)first + q] = *reinterpret_cast<const float4*>(rec_out + (wave0 + r) * REC_STRIDE + 4 * c);
+        }
     }
     // block partial sum of tiles_touched -> block_sums[blockIdx.x] (feeds the scan, K2)
     uint32_t v = tiles;
@@ -538,7 +560,14 @@ struct FwdView {
 };
 struct FwdViewsArgs { int V; FwdView v[GDR_MAX_VIEWS]; };
 
-template <int DEG>
+// STAGED (M == NB and 3 NB a multiple of 4: degrees 1 and 3; round 5): the per-Gaussian rows move through LDS with
+// coalesced global accesses, as K9's do (device_math.h RowStage).  A thread owns a Gaussian, so its SH row (192 bytes at
+// degree 3) and the 64-byte render record it writes per view are stride accesses: every wave-level float4 load / store touches
+// 64 different cache lines.  IN: the workgroup copies its 256 consecutive SH rows (one contiguous 48 KB span) into LDS with
+// lane-contiguous float4 loads, every thread takes its row into registers, and the same LDS then serves OUT: each wave
+// transposes its 64 records (a contiguous 4 KB span per view) through a wave-private slice and stores them as four fully
+// coalesced 1 KB float4 stores.  Arithmetic untouched: same values, same bits.
+template <int DEG, bool STAGED = false>
 __global__ __launch_bounds__(GDR_BLOCK) void preprocess_fwd_views_kernel(
     int N, int M, const float* __restrict__ means3D, const float* __restrict__ scales,
     float scale_modifier, const float* __restrict__ rotations, const float* __restrict__ opacities,
@@ -546,6 +575,15 @@ __global__ __launch_bounds__(GDR_BLOCK) void preprocess_fwd_views_kernel(
     const FwdViewsArgs a) {
     __shared__ uint32_t wsum[GDR_MAX_VIEWS][GDR_BLOCK / GDR_WAVE];
     constexpr int NB = (DEG + 1) * (DEG + 1);
+    constexpr int ROWF = 3 * NB;
+    using RS = RowStage<STAGED ? ROWF : 4>;
+    constexpr int REC_STRIDE = 20;   // floats per record in the OUT slice: (stride / 4) odd -> 16-byte accesses rotate through the banks
+    // IN staging only where the rows are small (degree 1: 12 floats, 20 KB per workgroup).  At degree 3 the 53 KB it takes
+    // leave two workgroups per CU instead of three and K1 runs 30 % SLOWER than with the strided loads (same-box A/B,
+    // profiles/r05_ab_k1_staged.txt: C4 286 -> 378 us, C2 46 -> 54 us): the OUT staging alone is kept there.
+    constexpr bool STAGE_SH = STAGED && DEG == 1;
+    constexpr int LDS_FLOATS = STAGED ? (STAGE_SH && RS::LDS_FLOATS > GDR_BLOCK * REC_STRIDE ? RS::LDS_FLOATS : GDR_BLOCK * REC_STRIDE) : 1;
+    __shared__ float lds_rows[LDS_FLOATS];
     const int i = blockIdx.x * GDR_BLOCK + threadIdx.x;
     const int gx = (W + GDR_TILE - 1) / GDR_TILE, gy = (H + GDR_TILE - 1) / GDR_TILE;
     const bool valid = i < N;
@@ -553,6 +591,21 @@ __global__ __launch_bounds__(GDR_BLOCK) void preprocess_fwd_views_kernel(
     float c6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float sh[NB * 3];
     bool sh_loaded = false;
+    if (STAGE_SH) {
+        const int row0 = blockIdx.x * GDR_BLOCK;
+        stage_rows_in<STAGED ? ROWF : 4>(shs, row0, min(GDR_BLOCK, N - row0), lds_rows);
+        __syncthreads();
+        if (valid) {
+            const float* my_row = lds_rows + (int)threadIdx.x * RS::STRIDE;
+#pragma unroll
+            for (int c = 0; c < ROWF / 4; ++c) {
+                const float4 t = *reinterpret_cast<const float4*>(my_row + 4 * c);
+                sh[4 * c] = t.x; sh[4 * c + 1] = t.y; sh[4 * c + 2] = t.z; sh[4 * c + 3] = t.w;
+            }
+        }
+        sh_loaded = true;
+        __syncthreads();     // the rows are in registers: the LDS is the waves' OUT slices from here on
+    }
     if (valid) {
         px_ = means3D[3 * i]; py_ = means3D[3 * i + 1]; pz_ = means3D[3 * i + 2];
         op = (flags & GDR_IN_RAW_OPACITY) ? act_sigmoid(opacities[i]) : opacities[i];
@@ -665,10 +718,36 @@ __global__ __launch_bounds__(GDR_BLOCK) void preprocess_fwd_views_kernel(
             }
             fv.radii[i] = rad;
             fv.depths[i] = depth;
-            write_rec(fv.rec, i, pxy, depth, con_o, rgbd);
+            if (!STAGED) write_rec(fv.rec, i, pxy, depth, con_o, rgbd);
             fv.rect[i] = rect;
             fv.tiles[i] = tiles;
             fv.clamped[i] = (uint8_t)clampbits;
+            if (STAGED) {       // this lane's record into the wave's OUT slice
+                const float2 ext = alpha_extent(con_o);
+                float* mine = lds_rows + (int)threadIdx.x * REC_STRIDE;
+                *reinterpret_cast<float4*>(mine) = make_float4(pxy.x, pxy.y, depth, 0.f);
+                *reinterpret_cast<float4*>(mine + 4) = con_o;
+                *reinterpret_cast<float4*>(mine + 8) = rgbd;
+                *reinterpret_cast<float4*>(mine + 12) = make_float4(ext.x, ext.y, 0.f, 0.f);
+            }
+        }
+        if (STAGED) {           // 64 records = 4 KB contiguous in the view's record array: four coalesced 1 KB stores per wave
+            const int wave0 = (int)(threadIdx.x & ~63u), lane = (int)(threadIdx.x & 63u);
+            const int first = blockIdx.x * GDR_BLOCK + wave0;          // first Gaussian of this wave
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            const int nrec = min(GDR_WAVE, N - first);                   // (<= 0 for a wave past the end)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int q = lane + GDR_WAVE * j;                       // float4 index inside the wave's 4 KB span
+                const int r = q >> 2, c = q & 3;
+                if (r < nrec)
+                    fv.rec[4 * (size_t)first + q] = *reinterpret_cast<const float4*>(lds_rows + (wave0 + r) * REC_STRIDE + 4 * c);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();                             // the slice is free for the next view
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         }
         uint32_t t = tiles;
 #pragma unroll
@@ -1035,9 +1114,20 @@ hipError_t launch_preprocess_fwd_views(int V, const gdr_settings* s, const gdr_i
         f.num_rendered = geoms[v].num_rendered;
     }
     const int grid = div_up(N, GDR_BLOCK);
-    LAUNCH_DEG(GDR_K_PREPROCESS_FWD, preprocess_fwd_views_kernel, s[0].sh_degree, grid, st, N, in->M,
-               in->means3D, in->scales, s[0].scale_modifier, in->rotations, in->opacities, in->shs, W, H,
-               geoms[0].cov3D, in->flags, a);
+    const int deg = s[0].sh_degree, nb = (deg + 1) * (deg + 1);
+    static const bool stage = getenv("GDR_K1_STAGED") ? atoi(getenv("GDR_K1_STAGED")) != 0 : true;   // (developer A/B)
+    const bool staged = stage && in->M == nb && (3 * nb) % 4 == 0 && (deg == 1 || deg == 3);
+#define GDR_K1V(DEG_, ST_)                                                                                              \
+    GDR_LAUNCH(GDR_K_PREPROCESS_FWD, (preprocess_fwd_views_kernel<DEG_, ST_>), dim3(grid), dim3(GDR_BLOCK), st, N, in->M,    \
+               in->means3D, in->scales, s[0].scale_modifier, in->rotations, in->opacities, in->shs, W, H, geoms[0].cov3D,   \
+               in->flags, a)
+    if (staged && deg == 3) GDR_K1V(3, true);
+    else if (staged && deg == 1) GDR_K1V(1, true);
+    else
+        LAUNCH_DEG(GDR_K_PREPROCESS_FWD, preprocess_fwd_views_kernel, s[0].sh_degree, grid, st, N, in->M,
+                   in->means3D, in->scales, s[0].scale_modifier, in->rotations, in->opacities, in->shs, W, H,
+                   geoms[0].cov3D, in->flags, a);
+#undef GDR_K1V
     return hipGetLastError();
 }
 
