@@ -84,6 +84,14 @@ def step(sync=True):
     if sync: t = tick("7 backward", t)
 
 
+if "--trace" in sys.argv:     # for rocprofv3 --kernel-trace: a few steady-state samples of the unchanged caller, reuse on
+    G.REUSE_FORWARD = True
+    for _ in range(10):
+        step(sync=False)
+    torch.cuda.synchronize()
+    print("stats", G._REUSE_STATS)
+    sys.exit(0)
+
 for reuse in (False, True):
     G.REUSE_FORWARD = reuse
     for _ in range(4):

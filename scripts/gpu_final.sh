@@ -5,7 +5,7 @@
 # gpurun_out/final/ (copied into profiles/ afterwards).   bash scripts/gpu_final.sh r03
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 R=$PWD; O=$R/gpurun_out/final; mkdir -p $O
-TAG=${1:-r04}
+TAG=${1:-r05}
 timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?"; tail -2 $O/smoke.log
 timeout 1500 python -m pytest tests -m gpu -q -rP > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -1 $O/pytest_gpu.log
 grep -E "^\[" $O/pytest_gpu.log > $O/${TAG}_fullsize_parity.log
@@ -20,6 +20,11 @@ for wl in c4 c3 c2 c5; do
   tail -4 $O/pmc_$wl.log | cut -c1-300
 done
 python scripts/make_pmc_traffic.py $O/${TAG} && cp $O/pmc_traffic.json profiles/pmc_traffic.json
+echo "--- K7 stall breakdown at the reference's own scale (pairs kernel pinned), round-4 verdict next #4"
+for wl in c2 c3 c4; do
+  timeout 600 python bench.py --workload $wl --steps 10 --warmup 3 --no-cpu-baseline --no-per-view-leg > $O/k7line_$wl.json 2>/dev/null
+  python scripts/k7_stalls.py $O/${TAG}_${wl}_pmc_summary.json $O/k7line_$wl.json $O/${TAG}_k7_stalls_$wl.json | cut -c1-400
+done
 b() { name=$1; shift; timeout 1200 python bench.py "$@" > $O/${TAG}_bench_$name.json 2> $O/bench_$name.err || tail -3 $O/bench_$name.err
   python - <<PY
 import json
@@ -42,6 +47,7 @@ b c3_fwd --workload c3 --forward-only
 b c5_fwd --workload c5 --forward-only
 b c4_backward_per_view --backward-per-view --unfused --no-cpu-baseline
 b c4_perview --per-view --unfused --no-cpu-baseline
+b c4_imagesout --torch-loss --no-cpu-baseline --no-per-view-leg
 b c4_shell --layout shell --no-cpu-baseline
 b c2_shell --workload c2 --layout shell --no-cpu-baseline
 b c3_shell --workload c3 --layout shell --no-cpu-baseline
@@ -69,9 +75,16 @@ import json; d=json.load(open('$O/n$n.json')); r=d['roofline'] or {}
 fr=[k.get('frac',0) for k in d['kernels'].values()]+[k.get('frac_serial',0) or 0 for k in d['kernels'].values()]
 print(json.dumps(dict(n=$n, views_per_s=d['value'], ms_per_step=d['ms_per_step'], D=d['config']['num_rendered_per_view'], path_frac=r.get('path_frac'), path_frac_measured=r.get('path_frac_measured'), traffic=r.get('traffic'), max_kernel_frac=max(fr), mem_gb=d['config'].get('peak_mem_gb'))))" | tee -a $O/${TAG}_size_sweep.json
 done
-echo "--- RCCL, one rank, collectives forced (gradients dropped between steps = default; kept = accumulated into the packed buffer)"
-timeout 600 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-per-view-leg --force-dist --grad-allreduce 2>/dev/null | tail -1 | tee $O/${TAG}_bench_rccl_1rank.json | cut -c1-200
-timeout 600 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-per-view-leg --force-dist --grad-allreduce --keep-grads 2>/dev/null | tail -1 | tee $O/${TAG}_bench_rccl_1rank_keepgrads.json | cut -c1-200
+echo "--- RCCL, one rank, collectives forced: plain / K9 writing into the packed buffer (gradient sinks) / the same with the collectives asynchronous / gradients kept"
+timeout 600 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-roofline --no-per-view-leg 2>/dev/null | tail -1 | tee $O/${TAG}_bench_rccl_1rank_plain.json | cut -c1-120
+timeout 600 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-roofline --no-per-view-leg --force-dist --grad-allreduce 2>/dev/null | tail -1 | tee $O/${TAG}_bench_rccl_1rank.json | cut -c1-200
+timeout 600 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-roofline --no-per-view-leg --force-dist --grad-allreduce --overlap-comm 2>/dev/null | tail -1 | tee $O/${TAG}_bench_rccl_1rank_overlap.json | cut -c1-200
+timeout 600 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-roofline --no-per-view-leg --force-dist --grad-allreduce --keep-grads 2>/dev/null | tail -1 | tee $O/${TAG}_bench_rccl_1rank_keepgrads.json | cut -c1-200
+echo "--- the reference's per-sample sequence through the unchanged caller: phases, forward reuse on / off, kernel timeline"
+python scripts/c3step_phases.py 2>/dev/null | tee $O/${TAG}_c3step_phases.txt | grep -E "^---|sum|unsynchronised"
+python scripts/c3step_phases.py --fresh-cams 2>/dev/null | tee -a $O/${TAG}_c3step_phases.txt | grep -E "^---|sum|unsynchronised"
+(cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/trace_c3step -o t -- python $R/scripts/c3step_phases.py --trace > $R/gpurun_out/trace_c3step.log 2>&1)
+f=$(find gpurun_out/trace_c3step -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python scripts/trace_gaps.py $f --every 16 --timeline > $O/${TAG}_timeline_c3step.txt; rm -rf gpurun_out/trace_c3step; head -3 $O/${TAG}_timeline_c3step.txt
 echo "--- 2DGS parity statistics at other absolute floors (tests/util.py assert_grads_surfel)"
 GDR_TEST_STATS=1 timeout 1200 python -m pytest tests/test_gpu_oracle_fullsize.py tests/test_gpu_surfel.py -q -rP -k "surfel" 2>&1 | grep -E "^\[|passed|failed" | cut -c1-200 > $O/${TAG}_surfel_stats.txt; tail -1 $O/${TAG}_surfel_stats.txt
 bash scripts/gpu_timeline.sh c2 --no-per-view-leg > /dev/null 2>&1; cp gpurun_out/timeline_c2.txt $O/${TAG}_timeline_c2.txt; grep "^step [45]" $O/${TAG}_timeline_c2.txt

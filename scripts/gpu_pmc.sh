@@ -15,7 +15,10 @@ for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU S
 done
 # the row-pair K7 (render_bwd_pairs_kernel: the library picks it per scene shape after timing both, which a two-step run never
 # reaches): its instruction, traffic and atomic-line counts from runs that pin it
-for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "FETCH_SIZE" "WRITE_SIZE" "TCC_ATOMIC_sum TCC_EA0_ATOMIC_sum"; do
+# (round 5: also its wave-cycle / stall counters — the per-wave stall breakdown of profiles/rNN_k7_stalls_*.json)
+for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
+           "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT" \
+           "FETCH_SIZE" "WRITE_SIZE" "TCC_ATOMIC_sum TCC_EA0_ATOMIC_sum"; do
   i=$((i+1))
   (cd /tmp && export TMPDIR=/tmp GDR_K7_PAIRS=1 && timeout 600 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $R/gpurun_out/${TAG}_$i -o p -- python $R/bench.py $ARGS > $R/gpurun_out/${TAG}_$i.log 2>&1)
 done
