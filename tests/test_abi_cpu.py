@@ -237,6 +237,26 @@ def test_view_plan_and_shape_history_without_gpu():
         lib.gdr_k7_tune_override(mode)
 
 
+def test_view_reuse_probe_argument_checks_and_host_half_without_a_gpu():
+    """include/gdr.h gdr_view_reuse_probe (v16): bad arguments are errors with a message; with nothing to compare on the
+    device (no candidate whose host scalars match, no same-as pair) the call answers -1 / 0 without touching the GPU."""
+    import ctypes as C
+    from generativedensification_amd import _lib as L
+    lib = L.load()
+    fake = 0x1000                       # never dereferenced on this path
+    s = L.GdrSettings(64, 64, 0.4, 0.4, 1.0, 1, 0, 0, fake, fake, fake, fake)
+    other = L.GdrSettings(64, 80, 0.4, 0.4, 1.0, 1, 0, 0, fake, fake, fake, fake)       # another image width: host half differs
+    cands = (L.GdrSettings * 2)(other, L.GdrSettings(64, 64, 0.4, 0.4, 1.0, 3, 0, 0, fake, fake, fake, fake))
+    match, differ = C.c_int32(7), C.c_uint32(9)
+    assert lib.gdr_view_reuse_probe(None, 0, None, None, fake, C.byref(match), C.byref(differ), None) == -1
+    assert b"view_reuse_probe" in lib.gdr_last_error()
+    assert lib.gdr_view_reuse_probe(C.byref(s), L.GDR_REUSE_MAX + 1, cands, None, fake, C.byref(match), C.byref(differ), None) == -1
+    assert lib.gdr_view_reuse_probe(C.byref(s), 2, cands, None, None, C.byref(match), C.byref(differ), None) == -1     # no scratch
+    assert lib.gdr_view_reuse_probe(C.byref(s), 2, cands, None, fake, C.byref(match), C.byref(differ), None) == 0
+    assert match.value == -1 and differ.value == 0
+    assert lib.gdr_view_reuse_probe(C.byref(s), 0, None, None, fake, C.byref(match), C.byref(differ), None) == 0 and match.value == -1
+
+
 def test_debug_knobs_map_to_view_opts():
     from generativedensification_amd import rasterizer as R
     K = R.K
