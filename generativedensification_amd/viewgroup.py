@@ -147,6 +147,8 @@ if GROUP_VIEWS:
     _ensure_probed()
 
 # ---- callers that back-propagate after every single view (no gain, only bookkeeping): pause grouping -------------------
+# (process-wide counters: the boundary's contract is one Python thread per rank — SURVEY section 8b "Threading"; two threads
+# interleaving forwards and backwards would only make this HEURISTIC pause or resume at the wrong moment, never change a result)
 _calls_since_backward = 0
 _solo_passes = 0          # consecutive backward passes that were preceded by exactly one forward call
 
@@ -594,8 +596,9 @@ class _GroupView(torch.autograd.Function):
             gm2 = gm2.to(ctx.means2D_dtype)
         task = torch._C._current_graph_task_id()
         with grp.lock:
-            for k in [k for k, e in grp.pending.items() if e["task"] != task]:
-                del grp.pending[k]      # K7 results of an earlier pass no hub collected (a vjp w.r.t. the carrier): free them
+            for k in [k for k, e in grp.pending.items() if e["task"] < task]:
+                del grp.pending[k]      # K7 results of an EARLIER pass no hub collected (graph task ids grow): free them; a
+                #                         pass running concurrently on another thread keeps its own (round-4 advisor finding)
             if hub_runs and recs is not None:
                 grp.pending[ctx.j] = dict(recs=recs, state=st, radii=ctx.radii, s=s, keep=(keep, ctx.keep_rest), task=task)
         return (None, None, None, None, None, gm2, grp.one if hub_runs else None, None, None, None, None, None)
