@@ -91,6 +91,7 @@ def _grad_pack(params, world):
     key = (world, tuple(id(p) for p in params))
     pack = _PACKS.get(key)
     if pack is not None and all(r() is p for r, p in zip(pack.refs, params)):
+        _PACKS[key] = _PACKS.pop(key)      # most recently used last: the eviction below drops the LEAST recently used set
         return pack
     for k in [k for k, v in _PACKS.items() if any(r() is None for r in v.refs)]:    # sets whose tensors are gone
         del _PACKS[k]
@@ -104,8 +105,8 @@ def _grad_pack(params, world):
         off += p.numel()
     pack.shard = torch.empty(padded // world, device=pack.flat.device, dtype=pack.flat.dtype)
     pack.refs = [weakref.ref(p) for p in params]
-    while len(_PACKS) >= 16:
-        _PACKS.pop(next(iter(_PACKS)))
+    while len(_PACKS) >= 16:     # (an evicted set's .grad tensors keep their storage alive; its next call builds a new buffer
+        _PACKS.pop(next(iter(_PACKS)))   #  and copies once — LRU, so that only sets not reduced for 16 other sets pay that)
     _PACKS[key] = pack
     return pack
 
