@@ -571,6 +571,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings)
         ctx.raster_settings = raster_settings
         ctx.state = st
+        ctx.pace = viewgroup.pace()
         _save_inputs(ctx, keep)
         ctx.radii = radii
         ctx.means2D_shape = tuple(means2D.shape)
@@ -581,7 +582,7 @@ class _RasterizeGaussians(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_color, grad_radii, grad_depth, grad_alpha):
-        viewgroup.note_backward()
+        viewgroup.note_backward(ctx.pace)
         g = backward_raw(ctx.state, _saved_inputs(ctx), ctx.raster_settings, ctx.radii, grad_color, grad_depth,
                          grad_alpha)
         gm2 = g["means2D"]

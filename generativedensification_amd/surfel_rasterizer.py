@@ -145,6 +145,7 @@ class _RasterizeSurfels(torch.autograd.Function):
         color, radii, allmap, st, keep = forward_raw(means3D, sh, colors_precomp, opacities, scales, rotations,
                                                      transMat_precomp, raster_settings, flags)
         ctx.raster_settings, ctx.state, ctx.radii = raster_settings, st, radii
+        ctx.pace = viewgroup.pace()
         _R._save_inputs(ctx, keep)
         ctx.means2D_shape = tuple(means2D.shape)
         ctx.tm_shape = tuple(transMat_precomp.shape)
@@ -158,7 +159,7 @@ class _RasterizeSurfels(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_color, grad_radii, grad_allmap):
-        viewgroup.note_backward()
+        viewgroup.note_backward(ctx.pace)
         if grad_color is None:
             grad_color = torch.zeros(3, ctx.state.H, ctx.state.W, dtype=torch.float32, device=ctx.radii.device)
         g = backward_raw(ctx.state, _R._saved_inputs(ctx), ctx.raster_settings, ctx.radii, grad_color, grad_allmap)

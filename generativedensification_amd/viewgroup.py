@@ -147,25 +147,43 @@ if GROUP_VIEWS:
     _ensure_probed()
 
 # ---- callers that back-propagate after every single view (no gain, only bookkeeping): pause grouping -------------------
-# (process-wide counters: the boundary's contract is one Python thread per rank — SURVEY section 8b "Threading"; two threads
-# interleaving forwards and backwards would only make this HEURISTIC pause or resume at the wrong moment, never change a result)
-_calls_since_backward = 0
-_solo_passes = 0          # consecutive backward passes that were preceded by exactly one forward call
+# The counters are per HOST THREAD (round-4 advisor finding: two models driven from two threads must not count each other's
+# calls).  The autograd engine runs backward functions on its own worker thread, so a node carries the state object of the
+# thread that ran its forward (ctx.pace) and hands it back to note_backward.
+class _PaceState:
+    __slots__ = ("calls_since_backward", "solo_passes")
+
+    def __init__(self):
+        self.calls_since_backward = 0
+        self.solo_passes = 0          # consecutive backward passes that were preceded by exactly one forward call
 
 
-def note_forward():
+_TLS = threading.local()
+
+
+def pace() -> _PaceState:
+    """The calling thread's counters."""
+    st = getattr(_TLS, "st", None)
+    if st is None:
+        st = _TLS.st = _PaceState()
+    return st
+
+
+def note_forward() -> _PaceState:
     """Called by every differentiable forward call of the boundary (grouped or not)."""
-    global _calls_since_backward
-    _calls_since_backward += 1
+    p = pace()
+    p.calls_since_backward += 1
+    return p
 
 
-def note_backward():
-    """Called by every backward entry of the boundary (grouped or not): closes the count of forward calls of this pass."""
-    global _calls_since_backward, _solo_passes
-    if _calls_since_backward == 0:
+def note_backward(p: _PaceState = None):
+    """Called by every backward entry of the boundary (grouped or not) with the forward thread's state: closes the count of
+    forward calls of this pass."""
+    p = p if p is not None else pace()
+    if p.calls_since_backward == 0:
         return                      # a later node of the same pass
-    _solo_passes = _solo_passes + 1 if _calls_since_backward == 1 else 0
-    _calls_since_backward = 0
+    p.solo_passes = p.solo_passes + 1 if p.calls_since_backward == 1 else 0
+    p.calls_since_backward = 0
 
 
 def _hashable(v):
@@ -241,7 +259,7 @@ def eligible(means3D, sh, colors_precomp, opacities, scales, rotations, precomp)
     ts = (means3D, sh, opacities, scales, rotations)
     if not any(t.requires_grad for t in ts) or any(_observed(t) for t in ts):
         return False
-    return _solo_passes < 2
+    return pace().solo_passes < 2
 
 
 def _find_group(path, tensors, dev, raster_settings):
@@ -555,6 +573,7 @@ class _GroupView(torch.autograd.Function):
         else:
             outs, st, keep_rest = tuple(t.clone() for t in hit["outs"]), hit["state"], hit["keep_rest"]
         ctx.grp, ctx.j, ctx.raster_settings, ctx.state, ctx.radii = grp, j, raster_settings, st, outs[1]
+        ctx.pace = pace()
         ctx.keep_rest = list(keep_rest)
         ctx.means2D_shape, ctx.means2D_dtype = tuple(means2D.shape), means2D.dtype
         ctx.mark_non_differentiable(outs[1])
@@ -564,7 +583,7 @@ class _GroupView(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *grads):
         lib = L.load()
-        note_backward()
+        note_backward(ctx.pace)
         grp, st = ctx.grp, ctx.state
         dev, N, path = grp.dev, grp.N, grp.path
         hub_runs = _hub_runs_in_this_pass(grp)

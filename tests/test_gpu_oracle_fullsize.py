@@ -480,7 +480,7 @@ def test_ten_views_at_c2_size_chunked_launches_vs_oracle(oracle_built):
         L.load().gdr_k7_tune_override(0)
     g_hip = {k: g.cpu().numpy() for k, g in zip(list(leaves) + ["ssp"], grads)}
     _assert_grads(g_hip, g64, g32, list(g32), "c2 ten views, fused, row-pair K7", maxnorm=3e-3, max_outside=3e-4)
-    VG._solo_passes = 0
+    VG.pace().solo_passes = 0
     r2 = Renderer(sh_degree=deg, fused=False)
     leaves2 = {k: v.to(dev).clone().requires_grad_(True) for k, v in sc.items()}
     losses2, carriers = [], []
@@ -602,7 +602,7 @@ def test_surfel_render_views_backward_vs_oracle(oracle_built, size):
     # K9s for all of them; activated inputs, so the single-call bar (3e-6 floor, 1e-4 of the elements) applies
     import diff_surfel_rasterization as DS
     from generativedensification_amd import viewgroup as VG
-    VG._solo_passes = 0
+    VG.pace().solo_passes = 0
     leaves2 = {k: v.to(dev).clone().requires_grad_(True) for k, v in sc.items()}
     ssp2 = [torch.zeros(n, 4, device=dev, requires_grad=True) for _ in range(V)]
     total2 = 0

@@ -206,7 +206,7 @@ def test_watched_activation_tensors_are_never_grouped_and_single_view_passes_pau
         return prof["preprocess_bwd"][1]
 
     seen: list = []
-    G._solo_passes = 0
+    G.pace().solo_passes = 0
 
     def watched():
         (a, _), (b, op_b) = call(sets[0]), call(sets[1], "retain")
@@ -224,9 +224,9 @@ def test_watched_activation_tensors_are_never_grouped_and_single_view_passes_pau
         call(sets[0])[0].mean().backward()
     for _ in range(2):
         solo()
-    assert G._solo_passes >= 2
+    assert G.pace().solo_passes >= 2
     assert k9_launches(two_views) == 2      # paused: this pass still runs as independent nodes ...
-    assert G._solo_passes == 0
+    assert G.pace().solo_passes == 0
     assert k9_launches(two_views) == 1      # ... and grouping is back with the next one
 
 
@@ -247,7 +247,7 @@ def test_surfel_calls_of_one_set_share_one_preprocess_backward(deg):
     def run(grouped):
         saved = G.GROUP_VIEWS
         G.GROUP_VIEWS = grouped
-        G._solo_passes = 0
+        G.pace().solo_passes = 0
         try:
             leaves = {k: v.clone().requires_grad_(True) for k, v in base.items()}
             L.profile_enable(True)

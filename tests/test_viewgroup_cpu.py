@@ -150,7 +150,7 @@ def test_eligibility_rules():
         m, s, o, sc, r = ts
         return G.eligible(m, s, colors, o, sc, r, precomp)
     saved = G.GROUP_VIEWS
-    G.GROUP_VIEWS, G._solo_passes = True, 0
+    G.GROUP_VIEWS, G.pace().solo_passes = True, 0
     try:
         ts = _acts(lv)
         assert not elig(ts)                                   # CPU tensors: never (there is no CPU path at all)
@@ -174,21 +174,44 @@ def test_eligibility_rules():
         h.register_hook(lambda g: g)
         hooked[3] = h
         assert G._observed(h) and not G._observed(lv["scales"])      # hooks on LEAVES are fine (they get the group's sums)
-        G._solo_passes = 2
+        G.pace().solo_passes = 2
         assert not elig(cu)                                   # paused after two single-view passes
         del fake
     finally:
-        G.GROUP_VIEWS, G._solo_passes = saved, 0
+        G.GROUP_VIEWS, G.pace().solo_passes = saved, 0
 
 
 def test_single_view_passes_pause_and_resume():
-    G._calls_since_backward, G._solo_passes = 0, 0
+    G.pace().calls_since_backward, G.pace().solo_passes = 0, 0
     for _ in range(2):
         G.note_forward()
         G.note_backward()
         G.note_backward()            # a second node of the same pass: no effect
-    assert G._solo_passes == 2
+    assert G.pace().solo_passes == 2
     for _ in range(4):               # several views, then one pass
         G.note_forward()
     G.note_backward()
-    assert G._solo_passes == 0 and G._calls_since_backward == 0
+    assert G.pace().solo_passes == 0 and G.pace().calls_since_backward == 0
+
+
+def test_pause_counters_are_per_host_thread():
+    """Round-4 advisor finding: two models driven from two threads must not count each other's forward calls; a backward
+    entry (run by the autograd engine's own thread) is handed the state of the thread that ran the forward."""
+    import threading
+    G.pace().calls_since_backward, G.pace().solo_passes = 0, 0
+    seen = {}
+
+    def other():
+        p = G.note_forward()
+        seen["other"] = (p is not mine, p.calls_since_backward)
+        G.note_backward(p)
+        seen["other_solo"] = p.solo_passes
+    mine = G.note_forward()
+    mine2 = G.note_forward()
+    t = threading.Thread(target=other)
+    t.start()
+    t.join()
+    assert mine is mine2 and mine.calls_since_backward == 2        # untouched by the other thread's call and backward
+    assert seen == {"other": (True, 1), "other_solo": 1}
+    G.note_backward(mine)
+    assert mine.solo_passes == 0 and mine.calls_since_backward == 0
