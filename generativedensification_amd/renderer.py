@@ -49,8 +49,10 @@ class Renderer(nn.Module):
     def set_bg_color(self, bg):
         self.bg_color = bg
 
-    def set_rasterizer(self, viewpoint_camera, scaling_modifier: float = 1.0, device="cuda"):
-        settings = GaussianRasterizationSettings(
+    def raster_settings(self, viewpoint_camera, scaling_modifier: float = 1.0, device="cuda"):
+        """The 12-field settings record of `viewpoint_camera` (what set_rasterizer wraps in a GaussianRasterizer; the
+        multi-view entries only need the record — an nn.Module per view costs ~15 us of host time each)."""
+        return GaussianRasterizationSettings(
             image_height=int(viewpoint_camera.image_height),
             image_width=int(viewpoint_camera.image_width),
             tanfovx=math.tan(viewpoint_camera.FoVx * 0.5),
@@ -64,7 +66,9 @@ class Renderer(nn.Module):
             prefiltered=False,
             debug=False,
         )
-        return GaussianRasterizer(raster_settings=settings)
+
+    def set_rasterizer(self, viewpoint_camera, scaling_modifier: float = 1.0, device="cuda"):
+        return GaussianRasterizer(raster_settings=self.raster_settings(viewpoint_camera, scaling_modifier, device))
 
     def render_views(self, cams, bg_colors, centers, shs, opacity, scales, rotations, device, prex="",
                      screenspace_points=None, stacked=False, raw=False):
@@ -80,7 +84,7 @@ class Renderer(nn.Module):
         for j, cam in enumerate(cams):
             if bg_colors is not None:
                 self.set_bg_color(bg_colors[j] if isinstance(bg_colors, (list, tuple)) else bg_colors)
-            sets.append(self.set_rasterizer(cam, device=device).raster_settings)
+            sets.append(self.raster_settings(cam, device=device))
         if screenspace_points is None:
             screenspace_points = torch.zeros((centers.shape[0], 4), dtype=centers.dtype,
                                              requires_grad=True, device=device) + 0
@@ -112,7 +116,7 @@ class Renderer(nn.Module):
         for j, cam in enumerate(cams):
             if bg_colors is not None:
                 self.set_bg_color(bg_colors[j] if isinstance(bg_colors, (list, tuple)) else bg_colors)
-            sets.append(self.set_rasterizer(cam, device=device).raster_settings)
+            sets.append(self.raster_settings(cam, device=device))
         if screenspace_points is None:
             screenspace_points = torch.zeros((centers.shape[0], 4), dtype=centers.dtype, requires_grad=True, device=device) + 0
         try:
@@ -132,7 +136,7 @@ class Renderer(nn.Module):
         for j, cam in enumerate(cams):
             if bg_colors is not None:
                 self.set_bg_color(bg_colors[j] if isinstance(bg_colors, (list, tuple)) else bg_colors)
-            sets.append(self.set_rasterizer(cam, device=device).raster_settings)
+            sets.append(self.raster_settings(cam, device=device))
         return screenspace_absgrad_raw(centers, shs, opacity, scales, rotations, sets, gt_images.permute(0, 3, 1, 2),
                                        topk=topk)
 

@@ -126,14 +126,17 @@ class Renderer(nn.Module):
     def get_opacity(self, o):
         return self.opacity_activation(o)
 
-    def set_rasterizer(self, viewpoint_camera, scaling_modifier: float = 1.0, device="cuda"):
-        settings = GaussianRasterizationSettings(
+    def raster_settings(self, viewpoint_camera, scaling_modifier: float = 1.0, device="cuda"):
+        """The 12-field settings record (what set_rasterizer wraps in a GaussianRasterizer module)."""
+        return GaussianRasterizationSettings(
             image_height=int(viewpoint_camera.image_height), image_width=int(viewpoint_camera.image_width),
             tanfovx=math.tan(viewpoint_camera.FoVx * 0.5), tanfovy=math.tan(viewpoint_camera.FoVy * 0.5),
             bg=self.bg_color.to(device), scale_modifier=scaling_modifier,
             viewmatrix=viewpoint_camera.world_view_transform, projmatrix=viewpoint_camera.full_proj_transform,
             sh_degree=self.sh_degree, campos=viewpoint_camera.camera_center, prefiltered=False, debug=False)
-        return GaussianRasterizer(raster_settings=settings)
+
+    def set_rasterizer(self, viewpoint_camera, scaling_modifier: float = 1.0, device="cuda"):
+        return GaussianRasterizer(raster_settings=self.raster_settings(viewpoint_camera, scaling_modifier, device))
 
     def render_views(self, cams, rays_list, bg_colors, centers, shs, opacity, scales, rotations, device, prex="",
                      depth_ratio=0.0, screenspace_points=None, raw=False):
@@ -146,7 +149,7 @@ class Renderer(nn.Module):
         for j, cam in enumerate(cams):
             if bg_colors is not None:
                 self.set_bg_color(bg_colors[j] if isinstance(bg_colors, (list, tuple)) else bg_colors)
-            sets.append(self.set_rasterizer(cam, device=device).raster_settings)
+            sets.append(self.raster_settings(cam, device=device))
         if screenspace_points is None:
             screenspace_points = torch.zeros((centers.shape[0], 4), dtype=centers.dtype, requires_grad=True,
                                              device=device) + 0
@@ -181,7 +184,7 @@ class Renderer(nn.Module):
         for j, cam in enumerate(cams):
             if bg_colors is not None:
                 self.set_bg_color(bg_colors[j] if isinstance(bg_colors, (list, tuple)) else bg_colors)
-            sets.append(self.set_rasterizer(cam, device=device).raster_settings)
+            sets.append(self.raster_settings(cam, device=device))
         if screenspace_points is None:
             screenspace_points = torch.zeros((centers.shape[0], 4), dtype=centers.dtype, requires_grad=True,
                                              device=device) + 0
