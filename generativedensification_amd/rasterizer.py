@@ -1165,10 +1165,44 @@ def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales,
                                      cov3Ds_precomp, raster_settings)
 
 
-class GaussianRasterizer(nn.Module):
+class _LazyModule(nn.Module):
+    """An nn.Module whose module machinery is set up on first use.  The reference builds a NEW `GaussianRasterizer` for
+    every render call (lightning/renderer.py:106-126) and uses it once; `nn.Module.__init__` (a dozen ordered dicts) and
+    `nn.Module.__call__` (hook dispatch) cost ~20 us of host time per call on a path that is host-bound at the reference's
+    own scene sizes.  The object IS an nn.Module (isinstance, repr, .to(), state_dict(), hooks ...): whatever touches the
+    machinery initialises it; a plain call of a never-touched instance goes straight to forward (no hook can exist yet)."""
+
     def __init__(self, raster_settings):
-        super().__init__()
-        self.raster_settings = raster_settings
+        object.__setattr__(self, "raster_settings", raster_settings)      # (nn.Module.__init__ deferred: see class doc)
+
+    def _module_init(self):
+        if "_parameters" not in self.__dict__:
+            rs = self.__dict__.get("raster_settings")
+            nn.Module.__init__(self)
+            object.__setattr__(self, "raster_settings", rs)
+
+    def __getattr__(self, name):
+        if "_parameters" not in self.__dict__:      # first touch of the module machinery (nn.Module keeps it in __dict__)
+            self._module_init()
+            return getattr(self, name)
+        return nn.Module.__getattr__(self, name)
+
+    def __setattr__(self, name, value):
+        if name != "raster_settings":
+            self._module_init()
+        nn.Module.__setattr__(self, name, value)
+
+    def __call__(self, *args, **kwargs):
+        if "_parameters" not in self.__dict__:
+            return self.forward(*args, **kwargs)
+        return nn.Module.__call__(self, *args, **kwargs)
+
+    def __setstate__(self, state):
+        self._module_init()
+        nn.Module.__setstate__(self, state)
+
+
+class GaussianRasterizer(_LazyModule):
 
     def markVisible(self, positions):
         lib = L.load()

@@ -545,10 +545,7 @@ def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales,
                                    cov3Ds_precomp, raster_settings)
 
 
-class GaussianRasterizer(nn.Module):
-    def __init__(self, raster_settings):
-        super().__init__()
-        self.raster_settings = raster_settings
+class GaussianRasterizer(_R._LazyModule):      # (an nn.Module set up on first use: rasterizer._LazyModule)
 
     def markVisible(self, positions):
         return _R.GaussianRasterizer(self.raster_settings).markVisible(positions)

@@ -272,3 +272,31 @@ def test_debug_knobs_map_to_view_opts():
         assert (o.seg_len, o.deep_max_busy, o.deep_min_mean, o.global_sort, o.radix_partition, o.no_hints) == (512, 0, 4000, 1, 0, 1)
     finally:
         K.SEG_LEN, K.DEEP_MAX_BUSY, K.DEEP_MIN_MEAN, K.FORCE_GLOBAL_SORT, K.FORCE_RADIX_PARTITION, K.LAUNCH_HINTS = saved
+
+
+def test_gaussian_rasterizer_is_a_real_module_set_up_on_first_use():
+    """The reference builds a new GaussianRasterizer per render call (lightning/renderer.py:106-126); ours defers
+    nn.Module's set-up until something touches the module machinery — and must then behave like any nn.Module."""
+    import copy
+    import pickle
+    import torch
+    from torch import nn
+    import diff_gaussian_rasterization as D
+    import diff_surfel_rasterization as DS
+    rs = D.GaussianRasterizationSettings(8, 8, 1.0, 1.0, torch.ones(3), 1.0, torch.eye(4), torch.eye(4), 1, torch.zeros(3), False, False)
+    for M in (D.GaussianRasterizer, DS.GaussianRasterizer):
+        m = M(raster_settings=rs)
+        assert isinstance(m, nn.Module) and m.raster_settings is rs and "_parameters" not in m.__dict__
+        assert "GaussianRasterizer" in repr(m) and "_parameters" in m.__dict__ and m.raster_settings is rs
+        m2 = M(rs).to("cpu").eval()
+        assert m2.training is False and list(m2.parameters()) == [] and m2.state_dict() == {} and m2.raster_settings is rs
+        m3 = M(rs)
+        m3.register_forward_pre_hook(lambda mod, a: None)
+        m3.extra = 3
+        assert m3.extra == 3 and m3.raster_settings is rs
+        assert len(list(nn.Sequential(M(rs)).modules())) == 2
+        assert isinstance(copy.deepcopy(M(rs)), M) and isinstance(pickle.loads(pickle.dumps(M(rs))), M)
+        with pytest.raises(Exception, match="excatly one"):         # the untouched instance's call goes straight to forward
+            M(rs)(means3D=torch.zeros(1, 3), means2D=torch.zeros(1, 4), opacities=torch.zeros(1, 1))
+        with pytest.raises(AttributeError):
+            M(rs).no_such_attribute
