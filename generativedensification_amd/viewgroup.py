@@ -568,8 +568,9 @@ class _GroupView(torch.autograd.Function):
             if REUSE_FORWARD:
                 alias = tuple(t.detach() for t in outs)      # (no grad_fn: a cache that held the outputs themselves would close a
                 # reference cycle through the autograd graph — output -> node -> ctx -> group -> cache)
-                grp.cache.append(dict(s=keep_rest[-1], outs=alias, out_versions=tuple(a._version for a in alias), state=st,
-                                      keep_rest=keep_rest, set_versions=_settings_versions(raster_settings)))
+                with grp.lock:
+                    grp.cache.append(dict(s=keep_rest[-1], outs=alias, out_versions=tuple(a._version for a in alias), state=st,
+                                          keep_rest=keep_rest, set_versions=_settings_versions(raster_settings)))
         else:
             outs, st, keep_rest = tuple(t.clone() for t in hit["outs"]), hit["state"], hit["keep_rest"]
         ctx.grp, ctx.j, ctx.raster_settings, ctx.state, ctx.radii = grp, j, raster_settings, st, outs[1]
