@@ -528,3 +528,69 @@ def test_k7_variant_is_measured_per_shape_and_can_be_pinned():
                 assert U.rel_inf(g[k], ref[k]) < 5e-5, (mode, k)
     finally:
         lib.gdr_k7_tune_override(-1)
+
+
+def test_gradient_sinks_k9_writes_where_the_collective_needs_it():
+    """Round 5 (multiview.prepare_grad_sinks / rasterizer.register_grad_sink): with the slices of a packed buffer registered as
+    the gradient sinks of the leaves, the multi-view node's K9 writes there directly — `.grad` IS the slice (no copy), bit for
+    bit what the node returns without sinks; an existing `.grad`, a second node in the same pass and a non-leaf input all
+    take ordinary buffers."""
+    from generativedensification_amd import rasterizer as R
+    from generativedensification_amd.camera import orbit_cameras
+    from generativedensification_amd.renderer import Renderer
+    from generativedensification_amd.synthetic import make_scene, make_targets
+    dev = torch.device("cuda:0")
+    N, H, W, V, deg = 20_000, 96, 128, 3, 1
+    sc = make_scene(N, 11, sh_degree=deg, sigma0=(0.0052, 0.02), device=dev)
+    cams = orbit_cameras(V, W, H, device=dev)
+    tg = make_targets(V, H, W, 11).to(dev).permute(0, 3, 1, 2).contiguous()
+    r = Renderer(sh_degree=deg)
+    r.set_bg_color(torch.ones(3, device=dev))
+    keys = ("centers", "shs", "opacity", "scales", "rotations")
+
+    def run(leaves, twice=False):
+        lv = r.render_views_loss(cams, None, tg, *[leaves[k] for k in keys], dev)
+        if twice:
+            lv = lv + r.render_views_loss(cams, None, tg, *[leaves[k] for k in keys], dev)
+        lv.sum().backward()
+        return {k: leaves[k].grad for k in keys}
+
+    def close(a, b):      # (two runs differ in the order of K7's float atomics: the per-element bar of the parity tests)
+        import util as U
+        out, _, maxn = U.elem_stats(a.cpu().numpy(), b.cpu().numpy())
+        return out < U.MAX_OUTSIDE and maxn < 1e-4
+
+    R.unregister_grad_sinks()
+    ref = {k: v.clone() for k, v in run({k: sc[k].clone().requires_grad_(True) for k in keys}).items()}
+    leaves = {k: sc[k].clone().requires_grad_(True) for k in keys}
+    flat = torch.full((sum(v.numel() for v in leaves.values()),), float("nan"), device=dev)
+    sinks, off = {}, 0
+    for k in keys:
+        sinks[k] = flat[off: off + leaves[k].numel()].view(leaves[k].shape)
+        off += leaves[k].numel()
+        R.register_grad_sink(leaves[k], sinks[k])
+    try:
+        g = run(leaves)
+        for k in keys:
+            assert g[k].data_ptr() == sinks[k].data_ptr(), k                 # adopted: the gradient lives in the buffer
+            assert close(g[k], ref[k]), k                                    # and is what the node computes anyway
+        assert not torch.isnan(flat).any()
+        g2 = run(leaves)                                                     # .grad exists: accumulated in place, never aliased
+        for k in keys:
+            assert g2[k].data_ptr() == sinks[k].data_ptr() and close(g2[k], 2 * ref[k]), k
+        for v in leaves.values():
+            v.grad = None
+        g3 = run(leaves, twice=True)                                         # two nodes, one pass: one takes the sinks
+        for k in keys:
+            assert close(g3[k], 2 * ref[k]), k
+        mid = {k: v * 1.0 for k, v in leaves.items()}                        # non-leaf inputs: no sink applies
+        for v in leaves.values():
+            v.grad = None
+        flat.fill_(float("nan"))
+        run_mid = r.render_views_loss(cams, None, tg, *[mid[k] for k in keys], dev)
+        run_mid.sum().backward()
+        assert torch.isnan(flat).all()
+        for k in keys:
+            assert close(leaves[k].grad, ref[k]), k
+    finally:
+        R.unregister_grad_sinks()
