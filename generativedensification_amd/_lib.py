@@ -299,6 +299,41 @@ def load():
     return _lib
 
 
+BOUNDARY_PATH = os.path.join(_HERE, "lib", "_gdr_boundary.so")
+_boundary = None     # the module; False = not available (one warning was given)
+
+
+def boundary():
+    """The compiled host boundary of the per-view render path (csrc/boundary.cpp: provenance key, render-group registry, the
+    hub / view autograd nodes, marshalling — the per-call hot path of viewgroup.py / rasterizer.py in C++) or None.  It is
+    an accelerator of the HOST code only: every kernel is reached through the same C ABI of the same libgdr_hip.so, which
+    the module dlopens by the path given here.  If it was not built, or cannot be imported against this torch (ABI drift
+    between the build and the run-time box), the ctypes path of this package serves — correct, ~2x more host time per
+    call — and says so once.  GDR_COMPILED_BOUNDARY=0 switches it off (A/B, and the tests that pin the Python path)."""
+    global _boundary
+    if _boundary is None:
+        if os.environ.get("GDR_COMPILED_BOUNDARY", "1") == "0":
+            _boundary = False
+            return None
+        try:
+            import importlib.util
+            load()        # (the HIP library first: the module resolves its entry points from the same file)
+            spec = importlib.util.spec_from_file_location("_gdr_boundary", BOUNDARY_PATH)
+            mod = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(mod)
+            if mod.ABI_VERSION != ABI_VERSION:
+                raise RuntimeError("built against another ABI version")
+            mod.init(LIB_PATH)
+            _boundary = mod
+        except Exception as exc:      # noqa: BLE001 — missing file, torch ABI mismatch, missing symbol: all mean "use ctypes"
+            import warnings
+            warnings.warn(f"generativedensification_amd: the compiled host boundary ({BOUNDARY_PATH}) is not usable "
+                          f"({type(exc).__name__}: {exc}); falling back to the ctypes boundary (same kernels, more host time "
+                          "per render call).  Build it with `make -C generativedensification_amd/csrc boundary`.")
+            _boundary = False
+    return _boundary or None
+
+
 def check(rc: int, what: str):
     if rc != GDR_OK:
         msg = load().gdr_last_error()

@@ -1,0 +1,832 @@
+// boundary.cpp — the compiled host boundary of the UNCHANGED caller (round 6; verdict r5 "missing #3", "next #2").
+//
+// Upstream's boundary is a C++ torch extension: `_C.rasterize_gaussians`, installed per /root/reference/README.md:49-53 and
+// reached from /root/reference/lightning/renderer.py:250-259 inside the per-view loops of
+// /root/reference/lightning/network.py:827-838, 848-856, 964-972.  Until round 5 every such call crossed ~140 us of
+// Python here (ctypes marshalling, the provenance walk of viewgroup.py, a Python autograd.Function per view and per
+// group) and ~75 us more in backward — at the reference's own scene sizes that, not the GPU, set the speed of the loop.
+// This module is that per-call hot path in C++17 against libtorch's public headers (plain g++, no .cu, no hipify):
+//
+//   * the provenance key of the five Gaussian tensors (viewgroup._signature: walk grad_fn down to leaves / opaque nodes
+//     through the whitelisted deterministic ops, with their saved scalars) as a byte string,
+//   * the render-group registry, the group's hub node and one view node per call as torch::autograd::Node subclasses
+//     (forward = ONE native call gdr_forward_view / gsr_forward_view, backward = K7 of the view; hub backward = ONE
+//     multi-view K8+K9 — exactly the graph viewgroup.py builds, see its module docstring for why it is sound),
+//   * settings / input marshalling, output allocation, the repeated-view probe (gdr_view_reuse_probe), the per-thread
+//     "does this caller back-propagate after every view" counters.
+//
+// Policy stays in Python (viewgroup.eligible, the GDR_* switches, every fallback): viewgroup.grouped_call hands an
+// eligible call to `grouped_call` below and gets the boundary's outputs back, or None = "render this call as an
+// ordinary node" (equal provenance, different values).  The arithmetic is NOT here: the module dlopens the C-ABI
+// library (include/gdr.h, include/gsr.h) whose path Python passes to `init`.  If this module cannot be built or
+// imported the ctypes path of rasterizer.py / viewgroup.py serves, with one warning (_lib.boundary()).
+#include <dlfcn.h>
+
+#include <array>
+#include <atomic>
+#include <chrono>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include <ATen/ATen.h>
+#include <c10/core/DeviceGuard.h>
+#include <c10/hip/HIPStream.h>
+#include <torch/csrc/autograd/function.h>
+#include <torch/csrc/autograd/functions/accumulate_grad.h>
+#include <torch/csrc/autograd/generated/Functions.h>
+#include <torch/csrc/autograd/graph_task.h>
+#include <torch/csrc/autograd/variable.h>
+#include <torch/csrc/utils/pybind.h>
+
+#include "../../include/gdr.h"
+#include "../../include/gsr.h"
+
+namespace py = pybind11;
+using at::Tensor;
+using torch::autograd::Node;
+using torch::autograd::edge_list;
+using torch::autograd::variable_list;
+
+namespace gdrb {
+
+// ---------------------------------------------------------------------------------------------------------------------
+// the C ABI, resolved from the library Python loaded (same handle: dlopen of an already mapped path)
+// ---------------------------------------------------------------------------------------------------------------------
+struct Abi {
+    int (*view_plan_for)(int32_t, int32_t, int32_t, int32_t, uint64_t, const gdr_view_opts*, gdr_view_plan*) = nullptr;
+    // [0] = 3DGS (gdr_*), [1] = 2DGS surfels (gsr_*): the input / output / gradient structs of the two have one layout
+    // each up to the meaning of their fields (include/gsr.h), so the calls go through void*
+    int (*forward_view[2])(const gdr_settings*, const void*, const gdr_view_plan*, void*, const gdr_view_opts*,
+                           const gdr_same_as*, const void*, gdr_view_state*, void*) = {nullptr, nullptr};
+    int (*render_backward[2])(const gdr_settings*, int32_t, const gdr_geom*, const gdr_binning*, const gdr_image*, const void*,
+                              float*, void*) = {nullptr, nullptr};
+    int (*render_backward_mean2d)(const gdr_settings*, int32_t, const gdr_geom*, const gdr_binning*, const gdr_image*,
+                                  const float*, float*, void*) = nullptr;
+    int (*preprocess_backward_views[2])(int32_t, const gdr_settings*, const void*, const gdr_geom*, const int32_t* const*,
+                                        float* const*, const void*, void*) = {nullptr, nullptr};
+    int (*means2d_of_view)(const gdr_settings*, int32_t, const gdr_geom*, const int32_t*, const float*, float*, void*) = nullptr;
+    int (*view_reuse_probe)(const gdr_settings*, int32_t, const gdr_settings*, const gdr_same_as*, uint32_t*, int32_t*,
+                            uint32_t*, void*) = nullptr;
+    const char* (*last_error)() = nullptr;
+    int (*abi_version)() = nullptr;
+    bool ready = false;
+};
+static Abi g_abi;
+
+template <class F>
+static void resolve(void* h, const char* name, F& fn) {
+    fn = reinterpret_cast<F>(dlsym(h, name));
+    if (!fn) throw std::runtime_error(std::string("compiled boundary: symbol missing in the HIP library: ") + name);
+}
+
+static void init(const std::string& lib_path) {
+    void* h = dlopen(lib_path.c_str(), RTLD_NOW | RTLD_GLOBAL);
+    if (!h) throw std::runtime_error(std::string("compiled boundary: dlopen failed: ") + dlerror());
+    Abi a;
+    resolve(h, "gdr_view_plan_for", a.view_plan_for);
+    resolve(h, "gdr_forward_view", a.forward_view[0]);
+    resolve(h, "gsr_forward_view", a.forward_view[1]);
+    resolve(h, "gdr_render_backward", a.render_backward[0]);
+    resolve(h, "gsr_render_backward", a.render_backward[1]);
+    resolve(h, "gdr_render_backward_mean2d", a.render_backward_mean2d);
+    resolve(h, "gdr_preprocess_backward_views", a.preprocess_backward_views[0]);
+    resolve(h, "gsr_preprocess_backward_views", a.preprocess_backward_views[1]);
+    resolve(h, "gsr_means2d_of_view", a.means2d_of_view);
+    resolve(h, "gdr_view_reuse_probe", a.view_reuse_probe);
+    resolve(h, "gdr_last_error", a.last_error);
+    resolve(h, "gdr_abi_version", a.abi_version);
+    if (a.abi_version() != GDR_ABI_VERSION)
+        throw std::runtime_error("compiled boundary: built against another ABI version of the HIP library");
+    a.ready = true;
+    g_abi = a;
+}
+
+static void check(int rc, const char* what) {
+    if (rc != GDR_OK) {
+        const char* msg = g_abi.last_error ? g_abi.last_error() : "";
+        throw std::runtime_error(std::string(what) + " failed (code " + std::to_string(rc) + "): " + (msg ? msg : ""));
+    }
+}
+
+// the caller's current stream of `dev` (autograd's engine has made it the forward's stream inside a backward node)
+static void* current_stream(const at::Device& dev) {
+    if (!dev.is_cuda()) return nullptr;      // (CPU tensors only reach here through the mock ABI of the CPU tests)
+    return (void*)c10::hip::getCurrentHIPStream(dev.index()).stream();
+}
+
+static Tensor f32_on(const Tensor& t, const at::Device& dev) {   // rasterizer._f32
+    Tensor r = t;
+    if (r.device() != dev) r = r.to(dev);
+    if (r.scalar_type() != at::kFloat) r = r.to(at::kFloat);
+    return r.contiguous();
+}
+static const float* fptr(const Tensor& t) { return (t.defined() && t.numel()) ? t.data_ptr<float>() : nullptr; }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// "does this caller back-propagate after every single view" (viewgroup.py: per host thread; a node carries the state of the
+// thread that ran its forward and hands it back in backward, which runs on the engine's thread)
+// ---------------------------------------------------------------------------------------------------------------------
+struct Pace {
+    std::atomic<int> calls_since_backward{0}, solo_passes{0};
+};
+static std::shared_ptr<Pace> pace() {
+    thread_local std::shared_ptr<Pace> p = std::make_shared<Pace>();
+    return p;
+}
+static std::shared_ptr<Pace> note_forward() {
+    auto p = pace();
+    p->calls_since_backward++;
+    return p;
+}
+static void note_backward(const std::shared_ptr<Pace>& p_in) {
+    auto p = p_in ? p_in : pace();
+    const int c = p->calls_since_backward.load();
+    if (c == 0) return;                      // a later node of the same pass
+    p->solo_passes = (c == 1) ? p->solo_passes.load() + 1 : 0;
+    p->calls_since_backward = 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// provenance key (viewgroup._signature / _node_sig): equal keys => the same function of the same sources
+// ---------------------------------------------------------------------------------------------------------------------
+struct Hold {            // what the key refers to by address: kept alive as long as the key is, so that addresses stay unique
+    std::vector<Tensor> tensors;
+    std::vector<std::shared_ptr<Node>> nodes;
+};
+
+struct KeyBuilder {
+    std::string s;
+    void raw(const void* p, size_t n) { s.append(reinterpret_cast<const char*>(p), n); }
+    template <class T> void pod(const T& v) { raw(&v, sizeof(T)); }
+    void tag(char c) { s.push_back(c); }
+    void str(const std::string& v) { pod<uint32_t>((uint32_t)v.size()); s += v; }
+    void ints(at::IntArrayRef v) { pod<uint32_t>((uint32_t)v.size()); for (auto x : v) pod<int64_t>(x); }
+    void symints(const std::vector<c10::SymInt>& v) {
+        pod<uint32_t>((uint32_t)v.size());
+        for (const auto& x : v) pod<int64_t>(x.guard_int(__FILE__, __LINE__));
+    }
+    void scalar(const at::Scalar& v) {       // repr-stable: the type and the value's bits
+        if (v.isFloatingPoint()) { tag('f'); pod<double>(v.toDouble()); }
+        else if (v.isBoolean()) { tag('b'); pod<int64_t>(v.toBool()); }
+        else if (v.isIntegral(false)) { tag('i'); pod<int64_t>(v.toLong()); }
+        else { tag('c'); auto c = v.toComplexDouble(); pod<double>(c.real()); pod<double>(c.imag()); }
+    }
+};
+
+static void leaf_sig(KeyBuilder& k, const Tensor& v, Hold& hold, char kind) {
+    hold.tensors.push_back(v);
+    k.tag(kind);
+    k.pod<const void*>(v.unsafeGetTensorImpl());
+    k.pod<int64_t>((int64_t)v._version());
+    k.pod<const void*>(v.data_ptr());
+    k.ints(v.sizes());
+    k.ints(v.strides());
+}
+
+// true if `fn` is one of the whitelisted deterministic ops; appends its saved scalars
+static bool op_saved(KeyBuilder& k, Node* fn) {
+    using namespace torch::autograd::generated;
+    if (dynamic_cast<SigmoidBackward0*>(fn) || dynamic_cast<ExpBackward0*>(fn) || dynamic_cast<DivBackward0*>(fn) ||
+        dynamic_cast<MulBackward0*>(fn) || dynamic_cast<AliasBackward0*>(fn))
+        return true;
+    if (auto* n = dynamic_cast<AddBackward0*>(fn)) { k.scalar(n->alpha); return true; }
+    if (auto* n = dynamic_cast<SelectBackward0*>(fn)) {
+        k.pod<int64_t>(n->dim); k.pod<int64_t>(n->index.guard_int(__FILE__, __LINE__)); k.symints(n->self_sym_sizes); return true;
+    }
+    if (auto* n = dynamic_cast<ExpandBackward0*>(fn)) { k.symints(n->self_sym_sizes); return true; }
+    if (auto* n = dynamic_cast<ClampMinBackward0*>(fn)) { k.scalar(n->min); return true; }
+    if (auto* n = dynamic_cast<LinalgVectorNormBackward0*>(fn)) {
+        k.scalar(n->ord);
+        if (n->dim.list.has_value()) { k.tag('1'); k.ints(*n->dim.list); } else k.tag('0');
+        k.pod<int64_t>(n->keepdim);
+        return true;
+    }
+    if (auto* n = dynamic_cast<NormBackward1*>(fn)) {
+        if (n->p.has_value()) { k.tag('1'); k.scalar(*n->p); } else k.tag('0');
+        k.ints(n->dim); k.pod<int64_t>(n->keepdim);
+        return true;
+    }
+    if (auto* n = dynamic_cast<ViewBackward0*>(fn)) { k.symints(n->self_sym_sizes); return true; }
+    if (auto* n = dynamic_cast<UnsafeViewBackward0*>(fn)) { k.symints(n->self_sym_sizes); return true; }
+    if (auto* n = dynamic_cast<ReshapeAliasBackward0*>(fn)) { k.symints(n->self_sym_sizes); return true; }
+    if (auto* n = dynamic_cast<SqueezeBackward1*>(fn)) { k.pod<int64_t>(n->dim); k.symints(n->self_sym_sizes); return true; }
+    if (auto* n = dynamic_cast<UnsqueezeBackward0*>(fn)) { k.pod<int64_t>(n->dim); return true; }
+    return false;
+}
+
+static void node_sig(KeyBuilder& k, const std::shared_ptr<Node>& fn, int depth, Hold& hold) {
+    if (auto* acc = dynamic_cast<torch::autograd::AccumulateGrad*>(fn.get())) {
+        leaf_sig(k, acc->variable, hold, 'L');
+        return;
+    }
+    const edge_list& nxt = fn->next_edges();
+    bool opaque = depth > 8;
+    for (const auto& e : nxt) opaque = opaque || !e.function;
+    if (!opaque) {
+        KeyBuilder sub;
+        try {
+            if (op_saved(sub, fn.get())) {
+                k.tag('O');
+                k.str(fn->name());
+                k.str(sub.s);
+                k.pod<uint32_t>((uint32_t)nxt.size());
+                for (const auto& e : nxt) { node_sig(k, e.function, depth + 1, hold); k.pod<uint32_t>(e.input_nr); }
+                return;
+            }
+        } catch (const std::exception&) {     // a symbolic size that cannot be guarded: treat the node as opaque
+        }
+    }
+    hold.nodes.push_back(fn);                 // opaque: the node's identity (kept alive so that the address stays unique)
+    k.tag('N');
+    k.pod<const void*>(fn.get());
+}
+
+static void signature(KeyBuilder& k, const Tensor& t, Hold& hold) {
+    const auto& fn = t.grad_fn();
+    if (!fn) {
+        leaf_sig(k, t, hold, 'T');
+    } else {
+        node_sig(k, fn, 0, hold);
+        k.pod<uint32_t>(t.output_nr());
+        k.pod<int64_t>((int64_t)t._version());
+    }
+    k.ints(t.sizes());
+    k.pod<int32_t>((int32_t)t.scalar_type());
+    k.pod<int32_t>((int32_t)t.device().index());
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// settings, states, groups
+// ---------------------------------------------------------------------------------------------------------------------
+struct Settings {        // the 12 fields of GaussianRasterizationSettings of ONE call, as the library takes them
+    gdr_settings s{};
+    Tensor bg, view, proj, campos;                       // fp32, on the device, contiguous (what s points at)
+    std::array<std::pair<const void*, int64_t>, 4> src{};   // (address, version) of the caller's four tensors (reuse probe)
+};
+
+static std::shared_ptr<Settings> make_settings(const py::object& rs, const at::Device& dev) {
+    auto st = std::make_shared<Settings>();
+    const Tensor bg = rs.attr("bg").cast<Tensor>(), vm = rs.attr("viewmatrix").cast<Tensor>();
+    const Tensor pm = rs.attr("projmatrix").cast<Tensor>(), cp = rs.attr("campos").cast<Tensor>();
+    st->src = {{{bg.data_ptr(), (int64_t)bg._version()}, {vm.data_ptr(), (int64_t)vm._version()},
+                {pm.data_ptr(), (int64_t)pm._version()}, {cp.data_ptr(), (int64_t)cp._version()}}};
+    st->bg = f32_on(bg, dev); st->view = f32_on(vm, dev); st->proj = f32_on(pm, dev); st->campos = f32_on(cp, dev);
+    gdr_settings& s = st->s;
+    s.image_height = rs.attr("image_height").cast<int32_t>();
+    s.image_width = rs.attr("image_width").cast<int32_t>();
+    s.tanfovx = (float)rs.attr("tanfovx").cast<double>();
+    s.tanfovy = (float)rs.attr("tanfovy").cast<double>();
+    s.scale_modifier = (float)rs.attr("scale_modifier").cast<double>();
+    s.sh_degree = rs.attr("sh_degree").cast<int32_t>();
+    s.prefiltered = py::bool_(rs.attr("prefiltered")) ? 1 : 0;
+    s.debug = py::bool_(rs.attr("debug")) ? 1 : 0;
+    s.bg = st->bg.data_ptr<float>(); s.viewmatrix = st->view.data_ptr<float>();
+    s.projmatrix = st->proj.data_ptr<float>(); s.campos = st->campos.data_ptr<float>();
+    return st;
+}
+
+struct ViewState {       // rasterizer._State: the workspace of one forward call and the structs every backward entry takes
+    int32_t N = 0, M = 0, H = 0, W = 0;
+    gdr_view_state vs{};
+    Tensor ws;
+    std::mutex mu;       // (vs.bin.grad_rec_cleared is written before every K7 of the view)
+};
+
+struct CacheEntry {      // a forward of this group a later call with equal settings may be handed again
+    std::shared_ptr<Settings> s;
+    std::vector<Tensor> outs;                 // detached aliases of the outputs (no grad_fn: no reference cycle through the graph)
+    std::vector<int64_t> out_versions;
+    std::shared_ptr<ViewState> st;
+};
+
+struct PendingView {     // a K7 result parked for the hub of the same backward pass
+    Tensor recs, radii;
+    std::shared_ptr<ViewState> st;
+    std::shared_ptr<Settings> s;
+    std::vector<Tensor> keep;
+    int task = 0;
+};
+
+struct HubNode;
+struct Group {
+    int path = 0;        // 0 = 3DGS, 1 = surfel
+    std::string key;
+    Hold hold;
+    std::array<Tensor, 5> orig, f32;          // the FIRST call's tensors as handed over / as the library reads them
+    std::array<Tensor, 5> hub_out;
+    Tensor token, one;
+    int n_views = 0;
+    std::map<int, PendingView> pending;
+    at::Device dev{at::kCPU};
+    int32_t N = 0, M = 0;
+    uint32_t in_flags = 0;                    // gdr_inputs.flags of the group's calls (parity switch R1)
+    std::recursive_mutex lock;
+    bool closed = false;                      // set by the hub's backward: later calls open a new group
+    std::vector<CacheEntry> cache;
+    Node* hub_node = nullptr;                 // (kept alive by hub_out / token)
+    std::string shape;                        // key of the reuse history
+};
+
+static std::mutex g_lock;
+static std::unordered_map<std::string, std::weak_ptr<Group>> g_groups;
+static const int kMaxViewsPerGroup = 64;
+
+// reuse history / statistics (viewgroup._REUSE_HIST, _REUSE_STATS)
+struct ReuseHist { bool matched = false; int since = 0; };
+static std::unordered_map<std::string, std::map<int, ReuseHist>> g_reuse_hist;
+static int64_t g_probes = 0, g_hits = 0;
+static std::unordered_map<int, Tensor> g_scratch;     // device index -> the probe's device words
+
+struct GroupMismatch : std::runtime_error { using std::runtime_error::runtime_error; };
+
+// host time spent inside the backward nodes below (scripts/host_split.py: "our backward functions"; two clock reads per node)
+static std::atomic<int64_t> g_bwd_ns{0}, g_bwd_calls{0};
+struct BwdTimer {
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    ~BwdTimer() {
+        g_bwd_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+        g_bwd_calls += 1;
+    }
+};
+
+static int floats_of(int path) { return path ? GSR_GRAD_FLOATS : 16; }
+static int scale_cols_of(int path) { return path ? 2 : 3; }
+
+static gdr_inputs inputs_struct(const Group& g) {       // (gsr_inputs has the same layout)
+    gdr_inputs in{};
+    in.N = g.N; in.M = g.M;
+    in.means3D = fptr(g.f32[0]); in.shs = fptr(g.f32[1]); in.opacities = fptr(g.f32[2]);
+    in.scales = fptr(g.f32[3]); in.rotations = fptr(g.f32[4]);
+    in.colors_precomp = nullptr; in.cov3D_precomp = nullptr;
+    in.flags = g.in_flags; in.reserved = 0;
+    return in;
+}
+
+static bool will_engine_execute(Node* node) {            // torch._C._will_engine_execute_node
+    const auto* exec_info = torch::autograd::get_current_graph_task_exec_info();
+    if (!exec_info) return true;                         // not inside a backward pass: unknown = yes
+    const auto* in_graph = torch::autograd::get_current_graph_task_nodes_in_graph();
+    bool ret = in_graph && in_graph->find(node) != in_graph->end();
+    if (ret && !exec_info->empty()) {
+        auto it = exec_info->find(node);
+        ret = it != exec_info->end() && it->second.should_execute();
+    }
+    return ret;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// the hub: one per group; its backward is the group's ONE multi-view K8+K9
+// ---------------------------------------------------------------------------------------------------------------------
+struct HubNode : public Node {
+    std::weak_ptr<Group> grp;
+    std::array<int64_t, 5> versions{};
+    std::array<at::ScalarType, 5> in_dtypes{};
+    std::array<std::vector<int64_t>, 5> in_shapes;
+
+    variable_list apply(variable_list&& grads) override {
+        BwdTimer timer;
+        variable_list none(5);
+        auto g = grp.lock();
+        if (!g) return none;
+        const int task = torch::autograd::get_current_graph_task_id();
+        std::vector<PendingView> views;
+        {
+            std::lock_guard<std::recursive_mutex> lk(g->lock);
+            g->closed = true;
+            for (auto& kv : g->pending)
+                if (kv.second.task == task) views.push_back(std::move(kv.second));
+            g->pending.clear();        // (incl. K7 results of passes this hub was not part of)
+            g->cache.clear();
+        }
+        if (views.empty()) return none;
+        for (int k = 0; k < 5; ++k)
+            if ((int64_t)g->orig[k]._version() != versions[k])
+                throw std::runtime_error("one of the variables needed for gradient computation has been modified by an inplace "
+                                         "operation (render group inputs)");
+        const int path = g->path;
+        const int64_t N = g->N, M = g->M;
+        const auto opt = at::TensorOptions().dtype(at::kFloat).device(g->dev);
+        c10::OptionalDeviceGuard guard;
+        if (g->dev.is_cuda()) guard.reset_device(g->dev);
+        Tensor g_m3 = at::empty({N, 3}, opt), g_m2 = at::empty({N, 4}, opt), g_sh = at::empty({N, M, 3}, opt);
+        Tensor g_op = at::empty({N, 1}, opt), g_sc = at::empty({N, scale_cols_of(path)}, opt), g_ro = at::empty({N, 4}, opt);
+        const gdr_inputs inp = inputs_struct(*g);
+        void* stream = current_stream(g->dev);
+        for (size_t lo = 0; lo < views.size(); lo += GDR_MAX_VIEWS) {
+            const int n = (int)std::min<size_t>(GDR_MAX_VIEWS, views.size() - lo);
+            gdr_settings s_arr[GDR_MAX_VIEWS];
+            gdr_geom g_arr[GDR_MAX_VIEWS];
+            const int32_t* r_arr[GDR_MAX_VIEWS];
+            float* rec_arr[GDR_MAX_VIEWS];
+            for (int k = 0; k < n; ++k) {
+                const PendingView& v = views[lo + k];
+                s_arr[k] = v.s->s;
+                g_arr[k] = v.st->vs.geom;
+                if (path == 0) g_arr[k].cov3D = views[lo].st->vs.geom.cov3D;     // view-independent: any view's copy
+                r_arr[k] = v.radii.data_ptr<int32_t>();
+                rec_arr[k] = v.recs.data_ptr<float>();
+            }
+            gdr_grad_outputs gout{};            // (gsr_grad_outputs has the same layout)
+            gout.dL_dmeans3D = g_m3.data_ptr<float>(); gout.dL_dmeans2D = g_m2.data_ptr<float>();
+            gout.dL_dshs = g_sh.data_ptr<float>(); gout.dL_dcolors = nullptr; gout.dL_dopacities = g_op.data_ptr<float>();
+            gout.dL_dscales = g_sc.data_ptr<float>(); gout.dL_drotations = g_ro.data_ptr<float>(); gout.dL_dcov3D = nullptr;
+            gout.scratch = nullptr; gout.accumulate = lo > 0 ? 1 : 0; gout.reserved = 0;
+            check(g_abi.preprocess_backward_views[path](n, s_arr, &inp, g_arr, r_arr, rec_arr, &gout, stream),
+                  path ? "gsr_preprocess_backward_views" : "gdr_preprocess_backward_views");
+        }
+        Tensor outs[5] = {g_m3, g_sh, g_op, g_sc, g_ro};
+        variable_list res(5);
+        for (int k = 0; k < 5; ++k) {
+            Tensor t = outs[k].reshape(in_shapes[k]);
+            res[k] = t.scalar_type() == in_dtypes[k] ? t : t.to(in_dtypes[k]);
+        }
+        return res;      // (`views` — records, states, settings — die here, behind the launches queued on this stream)
+    }
+    std::string name() const override { return "GdrRenderGroupHub"; }
+};
+
+// ---------------------------------------------------------------------------------------------------------------------
+// one view node per call: backward = K7 of the view
+// ---------------------------------------------------------------------------------------------------------------------
+struct ViewNode : public Node {
+    std::shared_ptr<Group> grp;
+    int j = 0;
+    std::shared_ptr<ViewState> st;
+    std::shared_ptr<Settings> s;
+    Tensor radii;
+    std::shared_ptr<Pace> pace_state;
+    std::vector<int64_t> means2d_shape;
+    at::ScalarType means2d_dtype = at::kFloat;
+
+    variable_list apply(variable_list&& grads) override {
+        BwdTimer timer;
+        note_backward(pace_state);
+        Group& g = *grp;
+        const int path = g.path;
+        const int64_t N = g.N;
+        const at::Device dev = g.dev;
+        const bool hub_runs = g.hub_node ? will_engine_execute(g.hub_node) : true;
+        const auto opt = at::TensorOptions().dtype(at::kFloat).device(dev);
+        c10::OptionalDeviceGuard guard;
+        if (dev.is_cuda()) guard.reset_device(dev);
+        void* stream = current_stream(dev);
+        std::vector<Tensor> keep;
+        Tensor recs, head;
+        const bool only_image = path == 0 && grads.size() == 3 && grads[0].defined() && !grads[1].defined() && !grads[2].defined();
+        if (!hub_runs && only_image) {
+            // only the carrier's gradient is wanted and only the image carries one (the vjp of network.py:843-872): the
+            // mean2D-only K7 — 4 floats per Gaussian instead of the 13 of the full record, no record at all
+            Tensor gc = f32_on(grads[0], dev);
+            head = at::zeros({N, 4}, opt);
+            check(g_abi.render_backward_mean2d(&s->s, (int32_t)N, &st->vs.geom, &st->vs.bin, &st->vs.img, gc.data_ptr<float>(),
+                                               head.data_ptr<float>(), stream), "gdr_render_backward_mean2d");
+            keep.push_back(gc);
+        } else {
+            recs = at::empty({N * floats_of(path)}, opt);       // one gradient record per Gaussian
+            Tensor gc = grads[0].defined() ? f32_on(grads[0], dev) : at::zeros({3, st->H, st->W}, opt);
+            keep.push_back(gc);
+            std::lock_guard<std::mutex> lk(st->mu);
+            st->vs.bin.grad_rec_cleared = 0;
+            if (path == 0) {
+                Tensor gd = grads[1].defined() ? f32_on(grads[1], dev) : Tensor();
+                Tensor ga = grads[2].defined() ? f32_on(grads[2], dev) : Tensor();
+                keep.push_back(gd); keep.push_back(ga);
+                gdr_grad_inputs gin{gc.data_ptr<float>(), fptr(gd), fptr(ga)};
+                check(g_abi.render_backward[0](&s->s, (int32_t)N, &st->vs.geom, &st->vs.bin, &st->vs.img, &gin, recs.data_ptr<float>(),
+                                               stream), "gdr_render_backward");
+                head = recs.view({N, 16}).slice(1, 0, 4);       // K7 accumulates the (N,4) means2D gradient into the record's head
+            } else {
+                Tensor gm = grads[1].defined() ? f32_on(grads[1], dev) : Tensor();
+                keep.push_back(gm);
+                gsr_grad_inputs gin{gc.data_ptr<float>(), fptr(gm)};
+                check(g_abi.render_backward[1](&s->s, (int32_t)N, &st->vs.geom, &st->vs.bin, &st->vs.img, &gin, recs.data_ptr<float>(),
+                                               stream), "gsr_render_backward");
+                head = at::empty({N, 4}, opt);
+                check(g_abi.means2d_of_view(&s->s, (int32_t)N, &st->vs.geom, radii.data_ptr<int32_t>(), recs.data_ptr<float>(),
+                                            head.data_ptr<float>(), stream), "gsr_means2d_of_view");
+            }
+        }
+        const int64_t cols = means2d_shape.size() == 2 ? means2d_shape[1] : 4;
+        Tensor gm2;
+        if (cols == 3)   // legacy caller (point_decoder/layers/gaussian_renderer.py): xy signed, z = 0
+            gm2 = at::cat({head.slice(1, 0, 2), at::zeros_like(head.slice(1, 0, 1))}, 1);
+        else
+            gm2 = head.slice(1, 0, std::min<int64_t>(cols, 4)).contiguous();
+        if (gm2.scalar_type() != means2d_dtype) gm2 = gm2.to(means2d_dtype);
+        const int task = torch::autograd::get_current_graph_task_id();
+        {
+            std::lock_guard<std::recursive_mutex> lk(g.lock);
+            for (auto it = g.pending.begin(); it != g.pending.end();)       // K7 results of an EARLIER pass no hub collected
+                it = it->second.task < task ? g.pending.erase(it) : std::next(it);
+            if (hub_runs && recs.defined()) {
+                PendingView pv;
+                pv.recs = recs; pv.radii = radii; pv.st = st; pv.s = s; pv.keep = std::move(keep); pv.task = task;
+                g.pending[j] = std::move(pv);
+            }
+        }
+        variable_list res(7);
+        res[0] = gm2;
+        if (hub_runs) res[1] = g.one;      // (a defined gradient for the token: see Group / viewgroup._Hub.forward)
+        return res;
+    }
+    std::string name() const override { return "GdrRenderGroupView"; }
+};
+
+// ---------------------------------------------------------------------------------------------------------------------
+// forward of one view: ONE native call (rasterizer.forward_raw + forward_view_native)
+// ---------------------------------------------------------------------------------------------------------------------
+struct ForwardResult { std::vector<Tensor> outs; std::shared_ptr<ViewState> st; };   // outs: (color, radii, depth, alpha) / (color, radii, allmap)
+
+static ForwardResult forward_view(Group& g, const Settings& set, const gdr_view_opts& opts, bool defer_d, const gdr_same_as* same) {
+    const int path = g.path;
+    const at::Device dev = g.dev;
+    const int32_t N = g.N, H = set.s.image_height, W = set.s.image_width;
+    c10::OptionalDeviceGuard guard;
+    if (dev.is_cuda()) guard.reset_device(dev);
+    const auto f32o = at::TensorOptions().dtype(at::kFloat).device(dev);
+    ForwardResult r;
+    Tensor color = at::empty({3, H, W}, f32o), radii = at::empty({N}, f32o.dtype(at::kInt));
+    Tensor depth, alpha, allmap;
+    gdr_outputs out3{};
+    gsr_outputs outs{};
+    const void* out_ptr;
+    if (path == 0) {
+        depth = at::empty({1, H, W}, f32o); alpha = at::empty({1, H, W}, f32o);
+        out3.color = color.data_ptr<float>(); out3.depth = depth.data_ptr<float>(); out3.alpha = alpha.data_ptr<float>();
+        out3.radii = N ? radii.data_ptr<int32_t>() : nullptr;
+        out_ptr = &out3;
+    } else {
+        allmap = at::empty({7, H, W}, f32o);
+        outs.color = color.data_ptr<float>(); outs.allmap = allmap.data_ptr<float>(); outs.radii = N ? radii.data_ptr<int32_t>() : nullptr;
+        out_ptr = &outs;
+    }
+    const gdr_inputs inp = inputs_struct(g);
+    auto st = std::make_shared<ViewState>();
+    st->N = N; st->M = g.M; st->H = H; st->W = W;
+    void* stream = current_stream(dev);
+    gdr_view_plan plan{};
+    uint64_t exact = 0;
+    bool ok = false;
+    for (int attempt = 0; attempt < 4 && !ok; ++attempt) {
+        check(g_abi.view_plan_for(N, H, W, path, exact, &opts, &plan), "gdr_view_plan_for");
+        if (!defer_d && !exact) plan.have_binning = 0;      // upstream's flow: the count is read back before anything is sized
+        st->ws = at::empty({(int64_t)std::max<uint64_t>(plan.bytes, 256)}, f32o.dtype(at::kByte));
+        const int rc = g_abi.forward_view[path](&set.s, &inp, &plan, st->ws.data_ptr(), &opts, same, out_ptr, &st->vs, stream);
+        if (rc == GDR_OK) { ok = true; break; }
+        if (rc != GDR_ERR_WORKSPACE) check(rc, path ? "gsr_forward_view" : "gdr_forward_view");
+        exact = std::max<uint64_t>(1, st->vs.D);
+    }
+    if (!ok) throw std::runtime_error("gdr_forward_view: the duplicate count kept growing between calls");
+    if (same && st->vs.differ)
+        throw GroupMismatch("this call's opacities / scales / rotations have the autograd provenance of an earlier call's but "
+                            "different values");
+    if (path == 0) r.outs = {color, radii, depth, alpha};
+    else r.outs = {color, radii, allmap};
+    r.st = st;
+    return r;
+}
+
+static void fill_same(gdr_same_as& same, const std::vector<std::pair<Tensor, Tensor>>& pairs) {
+    std::memset(&same, 0, sizeof(same));
+    same.n = (int32_t)pairs.size();
+    for (size_t k = 0; k < pairs.size(); ++k) {
+        same.a[k] = pairs[k].first.data_ptr(); same.b[k] = pairs[k].second.data_ptr();
+        same.n_bytes[k] = (uint64_t)pairs[k].first.numel() * 4;
+    }
+}
+
+// ---- a view rendered twice (viewgroup._reuse_should_probe / _reuse_probe) ---------------------------------------------------
+static bool reuse_should_probe(Group& g, int j, bool reuse_forward) {
+    if (!reuse_forward || j == 0 || g.cache.empty()) return false;
+    std::lock_guard<std::mutex> lk(g_lock);
+    if (g_reuse_hist.size() > 256) g_reuse_hist.clear();
+    auto& hist = g_reuse_hist[g.shape];
+    auto it = hist.find(j);
+    if (it == hist.end() || it->second.matched) return true;
+    if (++it->second.since >= 32) { it->second.since = 0; return true; }
+    return false;
+}
+
+static const CacheEntry* reuse_probe(Group& g, int j, const Settings& now, const std::vector<std::pair<Tensor, Tensor>>& pairs) {
+    std::vector<const CacheEntry*> cands;
+    const size_t first = g.cache.size() > GDR_REUSE_MAX ? g.cache.size() - GDR_REUSE_MAX : 0;
+    for (size_t i = first; i < g.cache.size(); ++i) {
+        const CacheEntry& e = g.cache[i];
+        bool usable = true;
+        for (size_t o = 0; o < e.outs.size(); ++o) usable = usable && (int64_t)e.outs[o]._version() == e.out_versions[o];   // outputs edited in place
+        // a candidate built from the very same tensor (same memory) is only equal if that tensor was not written since
+        for (int q = 0; q < 4; ++q) usable = usable && (e.s->src[q].first != now.src[q].first || e.s->src[q].second == now.src[q].second);
+        if (usable) cands.push_back(&e);
+    }
+    const at::Device dev = g.dev;
+    c10::OptionalDeviceGuard guard;
+    if (dev.is_cuda()) guard.reset_device(dev);
+    gdr_same_as same;
+    fill_same(same, pairs);
+    Tensor scratch;
+    {
+        std::lock_guard<std::mutex> lk(g_lock);
+        auto it = g_scratch.find(dev.index());
+        if (it == g_scratch.end())
+            it = g_scratch.emplace(dev.index(), at::zeros({GDR_REUSE_MAX + 1}, at::TensorOptions().dtype(at::kInt).device(dev))).first;
+        scratch = it->second;
+    }
+    std::vector<gdr_settings> c_arr(std::max<size_t>(1, cands.size()));
+    for (size_t i = 0; i < cands.size(); ++i) c_arr[i] = cands[i]->s->s;
+    int32_t match = -1;
+    uint32_t differ = 0;
+    check(g_abi.view_reuse_probe(&now.s, (int32_t)cands.size(), c_arr.data(), pairs.empty() ? nullptr : &same,
+                                 (uint32_t*)scratch.data_ptr<int32_t>(), &match, &differ, current_stream(dev)), "gdr_view_reuse_probe");
+    if (differ) throw GroupMismatch("render group: equal provenance, different values");
+    const CacheEntry* hit = match >= 0 ? cands[(size_t)match] : nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_lock);
+        g_probes += 1; g_hits += hit ? 1 : 0;
+        g_reuse_hist[g.shape][j] = ReuseHist{hit != nullptr, 0};
+    }
+    return hit;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// viewgroup.grouped_call
+// ---------------------------------------------------------------------------------------------------------------------
+static py::object grouped_call(int path, const Tensor& means3D, const Tensor& means2D, const Tensor& sh, const Tensor& opacities,
+                               const Tensor& scales, const Tensor& rotations, const py::object& rs, const py::tuple& opts_t,
+                               bool defer_d, bool reuse_forward, uint32_t in_flags) {
+    if (!g_abi.ready) throw std::runtime_error("compiled boundary: init(lib_path) was not called");
+    const at::Device dev = means3D.device();
+    const std::array<Tensor, 5> tensors{means3D, sh, opacities, scales, rotations};
+    gdr_view_opts opts{opts_t[0].cast<int32_t>(), opts_t[1].cast<int32_t>(), opts_t[2].cast<int32_t>(),
+                       opts_t[3].cast<int32_t>(), opts_t[4].cast<int32_t>(), opts_t[5].cast<int32_t>()};
+    std::shared_ptr<Settings> set;
+    {
+        at::NoGradGuard ng;
+        set = make_settings(rs, dev);
+    }
+    // ---- find / open the group (viewgroup._find_group): one group = one image size, SH degree and scale modifier
+    KeyBuilder kb;
+    Hold hold;
+    kb.pod<int32_t>(path); kb.pod<int32_t>(set->s.image_height); kb.pod<int32_t>(set->s.image_width);
+    kb.pod<int32_t>(set->s.sh_degree); kb.pod<float>(set->s.scale_modifier); kb.pod<uint32_t>(in_flags);
+    for (const auto& t : tensors) signature(kb, t, hold);
+    std::shared_ptr<Group> grp;
+    bool is_new = false;
+    {
+        std::lock_guard<std::mutex> lk(g_lock);
+        auto it = g_groups.find(kb.s);
+        if (it != g_groups.end()) grp = it->second.lock();
+        if (!grp || grp->n_views >= kMaxViewsPerGroup || grp->closed) {
+            grp = std::make_shared<Group>();
+            grp->path = path; grp->key = kb.s; grp->hold = std::move(hold); grp->orig = tensors; grp->dev = dev; grp->in_flags = in_flags;
+            is_new = true;
+            for (auto i2 = g_groups.begin(); i2 != g_groups.end();)      // dead groups: their addresses may be reused
+                i2 = i2->second.expired() ? g_groups.erase(i2) : std::next(i2);
+            g_groups[kb.s] = grp;
+        }
+    }
+    Group& g = *grp;
+    try {
+        std::vector<std::pair<Tensor, Tensor>> pairs;
+        const CacheEntry* hit = nullptr;
+        CacheEntry hit_copy;
+        int j;
+        {
+            std::lock_guard<std::recursive_mutex> lk(g.lock);
+            at::NoGradGuard ng;
+            if (is_new) {
+                for (int k = 0; k < 5; ++k) g.f32[k] = f32_on(tensors[k], dev);
+                g.N = (int32_t)means3D.size(0); g.M = (int32_t)sh.size(1);
+                if (g.f32[2].numel() != g.N) throw std::runtime_error("opacities must have N elements");
+                int nbits = 0;
+                for (int64_t v = g.N; v; v >>= 1) ++nbits;
+                g.shape = std::to_string(path) + ":" + std::to_string(set->s.image_height) + "x" + std::to_string(set->s.image_width) + ":" +
+                          std::to_string(set->s.sh_degree) + ":" + std::to_string(nbits);
+                // the hub: aliases of the caller's tensors whose grad_fn is the hub node, + the token (a one-element device
+                // tensor the view nodes return a gradient for: a node whose incoming gradients are all undefined is queued to
+                // the CPU worker — two thread hops per pass)
+                auto hub = std::shared_ptr<HubNode>(new HubNode(), torch::autograd::deleteNode);
+                hub->grp = grp;
+                hub->set_next_edges(torch::autograd::collect_next_edges(tensors[0], tensors[1], tensors[2], tensors[3], tensors[4]));
+                for (int k = 0; k < 5; ++k) {
+                    hub->versions[k] = (int64_t)tensors[k]._version();
+                    hub->in_dtypes[k] = tensors[k].scalar_type();
+                    hub->in_shapes[k] = tensors[k].sizes().vec();
+                    Tensor alias = tensors[k].detach();
+                    torch::autograd::create_gradient_edge(alias, hub);
+                    g.hub_out[k] = alias;
+                }
+                g.token = at::zeros({1}, at::TensorOptions().dtype(at::kFloat).device(dev));
+                torch::autograd::create_gradient_edge(g.token, hub);
+                g.one = at::ones({1}, at::TensorOptions().dtype(at::kFloat).device(dev));
+                g.hub_node = hub.get();
+            } else {
+                // viewgroup._same_as_pairs: the (tensor, group's tensor) pairs whose equality the key asserts but that are not the
+                // very same memory — compared on the device next to K1
+                for (int k = 0; k < 5; ++k) {
+                    if (tensors[k].unsafeGetTensorImpl() == g.orig[k].unsafeGetTensorImpl()) continue;
+                    Tensor t32 = f32_on(tensors[k], dev);
+                    if (t32.sizes() != g.f32[k].sizes()) throw GroupMismatch("render group: equal provenance but different shapes");
+                    if (t32.data_ptr() != g.f32[k].data_ptr()) pairs.emplace_back(t32, g.f32[k]);
+                }
+                if (pairs.size() > GDR_SAME_AS_MAX) throw GroupMismatch("render group: more same_as pairs than gdr_same_as holds");
+            }
+            j = g.n_views++;
+            if (!is_new && reuse_should_probe(g, j, reuse_forward)) {
+                hit = reuse_probe(g, j, *set, pairs);
+                pairs.clear();              // (compared next to the settings: the forward need not compare them again)
+                if (hit) { hit_copy = *hit; hit = &hit_copy; }
+            }
+        }
+        // ---- the view's forward (viewgroup._GroupView.forward)
+        std::vector<Tensor> outs;
+        std::shared_ptr<ViewState> st;
+        std::shared_ptr<Settings> used = set;
+        {
+            at::NoGradGuard ng;
+            if (!hit) {
+                gdr_same_as same;
+                if (!pairs.empty()) fill_same(same, pairs);
+                ForwardResult fr = forward_view(g, *set, opts, defer_d, pairs.empty() ? nullptr : &same);
+                outs = std::move(fr.outs); st = fr.st;
+                if (reuse_forward) {
+                    CacheEntry e;
+                    e.s = set; e.st = st;
+                    for (const auto& t : outs) { Tensor a = t.detach(); e.out_versions.push_back((int64_t)a._version()); e.outs.push_back(a); }
+                    std::lock_guard<std::recursive_mutex> lk(g.lock);
+                    g.cache.push_back(std::move(e));
+                    if (g.cache.size() > GDR_REUSE_MAX) g.cache.erase(g.cache.begin(), g.cache.end() - GDR_REUSE_MAX);
+                }
+            } else {
+                for (const auto& t : hit->outs) outs.push_back(t.clone());
+                st = hit->st; used = hit->s;
+            }
+        }
+        auto node = std::shared_ptr<ViewNode>(new ViewNode(), torch::autograd::deleteNode);
+        node->grp = grp; node->j = j; node->st = st; node->s = used; node->radii = outs[1];
+        node->pace_state = pace();
+        node->means2d_shape = means2D.sizes().vec(); node->means2d_dtype = means2D.scalar_type();
+        edge_list edges = torch::autograd::collect_next_edges(means2D);
+        edges.emplace_back(g.token.grad_fn(), g.token.output_nr());
+        for (int k = 0; k < 5; ++k) edges.emplace_back(g.hub_out[k].grad_fn(), g.hub_out[k].output_nr());
+        node->set_next_edges(std::move(edges));
+        py::tuple result(outs.size());
+        for (size_t o = 0; o < outs.size(); ++o) {
+            if (o != 1) torch::autograd::create_gradient_edge(outs[o], node);     // (radii: not differentiable)
+            result[o] = py::cast(outs[o]);
+        }
+        return std::move(result);
+    } catch (const GroupMismatch&) {
+        // equal provenance, different values (a source edited in place outside autograd's view): this call is an ordinary
+        // node on its own tensors, as the reference's would be; the group takes no further calls
+        std::lock_guard<std::recursive_mutex> lk(g.lock);
+        g.closed = true;
+        g.cache.clear();
+        return py::none();
+    }
+}
+
+static py::bytes signature_key(const Tensor& t) {       // tests: the provenance key of one tensor
+    KeyBuilder kb;
+    Hold hold;
+    signature(kb, t, hold);
+    return py::bytes(kb.s);
+}
+
+}  // namespace gdrb
+
+PYBIND11_MODULE(_gdr_boundary, m) {
+    using namespace gdrb;
+    m.doc() = "compiled host boundary of the per-view render path (generativedensification_amd/csrc/boundary.cpp)";
+    m.def("init", &init, "dlopen the C-ABI library and resolve the entry points");
+    m.def("grouped_call", &grouped_call);
+    m.def("signature_key", &signature_key);
+    py::class_<Pace, std::shared_ptr<Pace>>(m, "PaceState")
+        .def_property("calls_since_backward", [](const Pace& p) { return p.calls_since_backward.load(); },
+                      [](Pace& p, int v) { p.calls_since_backward = v; })
+        .def_property("solo_passes", [](const Pace& p) { return p.solo_passes.load(); }, [](Pace& p, int v) { p.solo_passes = v; });
+    m.def("pace", &pace);
+    m.def("note_forward", &note_forward);
+    m.def("note_backward", [](py::object p) { note_backward(p.is_none() ? nullptr : p.cast<std::shared_ptr<Pace>>()); },
+          py::arg("p") = py::none());
+    m.def("reuse_stats", []() { std::lock_guard<std::mutex> lk(g_lock); return py::make_tuple(g_probes, g_hits); });
+    m.def("reuse_stats_reset", []() { std::lock_guard<std::mutex> lk(g_lock); g_probes = g_hits = 0; });
+    m.def("reuse_hist_clear", []() { std::lock_guard<std::mutex> lk(g_lock); g_reuse_hist.clear(); });
+    m.def("live_group_views", []() {      // calls taken by every live group (tests, diagnostics)
+        std::lock_guard<std::mutex> lk(g_lock);
+        std::vector<int> n;
+        for (auto& kv : g_groups)
+            if (auto g = kv.second.lock()) n.push_back(g->n_views);
+        return n;
+    });
+    m.def("backward_host_ns", [](bool reset) {
+        auto r = py::make_tuple((int64_t)g_bwd_ns.load(), (int64_t)g_bwd_calls.load());
+        if (reset) { g_bwd_ns = 0; g_bwd_calls = 0; }
+        return r;
+    }, py::arg("reset") = false);
+    m.attr("ABI_VERSION") = GDR_ABI_VERSION;
+}

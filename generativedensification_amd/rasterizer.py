@@ -279,6 +279,14 @@ def _view_opts():
                          int(K.FORCE_GLOBAL_SORT), int(K.FORCE_RADIX_PARTITION), int(not K.LAUNCH_HINTS))
 
 
+def view_opts_tuple():
+    """_view_opts() as the six ints the compiled boundary takes."""
+    return (-1 if K.SEG_LEN is None else max(0, int(K.SEG_LEN)) // 256 * 256,
+            -1 if K.DEEP_MAX_BUSY is None else max(0, int(K.DEEP_MAX_BUSY)),
+            -1 if K.DEEP_MIN_MEAN is None else max(0, int(K.DEEP_MIN_MEAN)),
+            int(K.FORCE_GLOBAL_SORT), int(K.FORCE_RADIX_PARTITION), int(not K.LAUNCH_HINTS))
+
+
 def forward_view_native(call, s, inp, N, H, W, surfel, out, same_as, dev, stream):
     """ONE native call per view (include/gdr.h gdr_forward_view / gsr_forward_view, round 4): the library carves one
     allocation, runs K1, binning and K6 sized by the device counter, reads the duplicate count back through its pooled

@@ -161,29 +161,46 @@ class _PaceState:
 _TLS = threading.local()
 
 
-def pace() -> _PaceState:
-    """The calling thread's counters."""
+def _py_pace() -> _PaceState:
     st = getattr(_TLS, "st", None)
     if st is None:
         st = _TLS.st = _PaceState()
     return st
 
 
-def note_forward() -> _PaceState:
-    """Called by every differentiable forward call of the boundary (grouped or not)."""
-    p = pace()
+def _py_note_forward() -> _PaceState:
+    p = _py_pace()
     p.calls_since_backward += 1
     return p
 
 
-def note_backward(p: _PaceState = None):
-    """Called by every backward entry of the boundary (grouped or not) with the forward thread's state: closes the count of
-    forward calls of this pass."""
-    p = p if p is not None else pace()
+def _py_note_backward(p: _PaceState = None):
+    p = p if p is not None else _py_pace()
     if p.calls_since_backward == 0:
         return                      # a later node of the same pass
     p.solo_passes = p.solo_passes + 1 if p.calls_since_backward == 1 else 0
     p.calls_since_backward = 0
+
+
+# With the compiled boundary (csrc/boundary.cpp) the counters live there — its view nodes count without the GIL — and the
+# Python nodes of the fallback paths share them: ONE set of counters per host thread whichever path a call takes.
+_B = L.boundary() if GROUP_VIEWS else None
+
+
+def pace():
+    """The calling thread's counters (calls_since_backward, solo_passes)."""
+    return _B.pace() if _B is not None else _py_pace()
+
+
+def note_forward():
+    """Called by every differentiable forward call of the boundary (grouped or not)."""
+    return _B.note_forward() if _B is not None else _py_note_forward()
+
+
+def note_backward(p=None):
+    """Called by every backward entry of the boundary (grouped or not) with the forward thread's state: closes the count of
+    forward calls of this pass."""
+    return _B.note_backward(p) if _B is not None else _py_note_backward(p)
 
 
 def _hashable(v):
@@ -246,6 +263,13 @@ class _Group:
         self.shape = None         # key of the reuse history (_REUSE_HIST)
 
 
+def live_group_views() -> list:
+    """Calls taken by every live render group, over both host paths (tests, diagnostics)."""
+    with _LOCK:
+        n = [g.n_views for g in (r() for r in _GROUPS.values()) if g is not None]
+    return n + (list(_B.live_group_views()) if _B is not None else [])
+
+
 def _observed(t: torch.Tensor) -> bool:
     """A non-leaf input somebody watches: in a group the later calls' activation tensors receive no gradient."""
     return t.grad_fn is not None and (t.retains_grad or bool(t._backward_hooks))
@@ -305,8 +329,47 @@ def _same_as_pairs(grp, tensors, R):
 # a caller that never repeats a view, so WHICH calls probe is learned per scene shape and call index: an index probes when
 # it is new, when its last probe matched, and every 32nd time otherwise.
 REUSE_FORWARD = os.environ.get("GDR_REUSE_FORWARD", "1") != "0"
-_REUSE_HIST: dict = {}            # (path, H, W, sh_degree, bucket of N) -> {call index: [last probe matched, calls since]}
-_REUSE_STATS = {"probes": 0, "hits": 0}      # (tests, diagnostics)
+COMPILED = True      # False: the Python nodes below serve although the compiled boundary is loaded (tests compare the two)
+class _ReuseHist(dict):
+    """(path, H, W, sh_degree, bucket of N) -> {call index: [last probe matched, calls since]}; clear() also clears the
+    compiled boundary's copy."""
+
+    def clear(self):
+        dict.clear(self)
+        if _B is not None:
+            _B.reuse_hist_clear()
+
+
+class _ReuseStats:
+    """{"probes", "hits"} over BOTH host paths (tests, diagnostics): a mapping, not a dict — dict(stats) reads through here."""
+
+    def __init__(self):
+        self._d = {"probes": 0, "hits": 0}
+
+    def _compiled(self):
+        return dict(zip(("probes", "hits"), _B.reuse_stats())) if _B is not None else {"probes": 0, "hits": 0}
+
+    def keys(self):
+        return self._d.keys()
+
+    def __iter__(self):
+        return iter(self._d)
+
+    def __getitem__(self, k):
+        return self._d[k] + self._compiled()[k]
+
+    def __setitem__(self, k, v):       # (only the Python path writes here: `+=` goes through __getitem__, so subtract the other half)
+        self._d[k] = v - self._compiled()[k]
+
+    def update(self, **kw):
+        if _B is not None and all(v == 0 for v in kw.values()):
+            _B.reuse_stats_reset()
+        for k, v in kw.items():
+            self[k] = v
+
+
+_REUSE_HIST = _ReuseHist()
+_REUSE_STATS = _ReuseStats()      # (tests, diagnostics)
 _SCRATCH: dict = {}               # device -> the probe's device words
 
 
@@ -369,7 +432,11 @@ def _reuse_probe(grp, j, raster_settings, same_as, R):
 
 # ---- what differs between the two boundaries ---------------------------------------------------------------------------
 class _Path3D:
-    name, floats, scale_cols, n_out = "3dgs", 16, 3, 4
+    name, floats, scale_cols, n_out, index = "3dgs", 16, 3, 4, 0
+
+    @staticmethod
+    def in_flags(R):       # gdr_inputs.flags of a grouped call (parity switch R1 only: the activations are the caller's)
+        return 0 if R.DEPTH_TO_MEAN else L.GDR_IN_NO_DEPTH_TO_MEAN
 
     @staticmethod
     def supports(sh, raster_settings):
@@ -423,7 +490,11 @@ class _Path3D:
 
 
 class _PathSurfel:
-    name, floats, scale_cols, n_out = "surfel", L.GSR_GRAD_FLOATS, 2, 3
+    name, floats, scale_cols, n_out, index = "surfel", L.GSR_GRAD_FLOATS, 2, 3, 1
+
+    @staticmethod
+    def in_flags(R):
+        return 0
 
     @staticmethod
     def supports(sh, raster_settings):
@@ -630,6 +701,10 @@ def grouped_call(path, means3D, means2D, sh, opacities, scales, rotations, raste
     group's although its provenance matches: the caller falls back)."""
     from . import rasterizer as R
     R._require_hip(means3D, "means3D")
+    if _B is not None and COMPILED:
+        # the whole of what follows in C++ (csrc/boundary.cpp): same groups, same nodes, same native calls
+        return _B.grouped_call(path.index, means3D, means2D, sh, opacities, scales, rotations, raster_settings,
+                               R.view_opts_tuple(), R.K.DEFER_D, REUSE_FORWARD, path.in_flags(R))
     dev = means3D.device
     tensors = (means3D, sh, opacities, scales, rotations)
     grp, new = _find_group(path, tensors, dev, raster_settings)

@@ -45,11 +45,15 @@ for _ in range(10): step()
 torch.cuda.synchronize()
 import gc; gc.disable()
 for k in T: T[k] = 0.0
+B = VG._B if getattr(VG, "COMPILED", False) else None     # the compiled boundary's nodes time themselves (csrc/boundary.cpp)
+if B is not None: B.backward_host_ns(True)
 K = 50
 t = time.perf_counter()
 for _ in range(K): step()
 torch.cuda.synchronize()
 wall = time.perf_counter() - t
+if B is not None: T["our_bwd"] += B.backward_host_ns(True)[0] * 1e-9
+print("host boundary:", "compiled (csrc/boundary.cpp)" if B is not None else "python + ctypes")
 print(f"N={N}: step {wall / K * 1e6:.0f} us | per view: caller activations {T['act'] / K / 4 * 1e6:.0f}, OUR forward call {T['call'] / K / 4 * 1e6:.0f}, "
       f"caller loss {T['loss'] / K / 4 * 1e6:.0f}, backward() {T['bwd'] / K / 4 * 1e6:.0f} of which our backward functions {T['our_bwd'] / K / 4 * 1e6:.0f}")
 pr = cProfile.Profile()

@@ -49,5 +49,5 @@ for k in range(1201):
     if k % 300 == 0:
         torch.cuda.synchronize()
         print(k, "cuda MB", round(torch.cuda.memory_allocated() / 2**20, 1), "reserved", round(torch.cuda.memory_reserved() / 2**20, 1),
-              "rss MB", resource.getrusage(resource.RUSAGE_SELF).ru_maxrss // 1024, "groups", len(VG._GROUPS),
+              "rss MB", resource.getrusage(resource.RUSAGE_SELF).ru_maxrss // 1024, "groups", len(VG.live_group_views()),
               "rb pool", {n: len(v) for n, v in R._CountReadback._pool.items()}, "reuse", dict(VG._REUSE_STATS), "hist", len(VG._REUSE_HIST))

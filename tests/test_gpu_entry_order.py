@@ -82,8 +82,7 @@ for step in range(2):                                # training steps under bf16
             return ((torch.stack([f["image"] for f in fr]) - tg[:VS]) ** 2).mean()
         image_loss, grad = vjp(fn, torch.zeros(N, 4, device=dev, requires_grad=True) + 0)
         losses = torch.stack([view_loss(o, tg[j]) for j, o in enumerate(outs)])
-        live = [g() for g in G._GROUPS.values()]
-        n_views = max((g.n_views for g in live if g is not None), default=0)
+        n_views = max(G.live_group_views(), default=0)
         losses.sum().backward()
     torch.cuda.synchronize()
     prof = L.profile_collect(reset=True)

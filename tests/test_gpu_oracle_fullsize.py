@@ -433,8 +433,7 @@ def test_bench_step_at_c4_size_vs_oracle(oracle_built):
         losses2.append(view_loss(out, tg_d[j]))
         carriers.append(ssp_j)
     lv2 = torch.stack(losses2)
-    live = [g() for g in VG._GROUPS.values()]
-    assert any(g is not None and g.n_views == V for g in live), "the four calls did not form one render group"
+    assert V in VG.live_group_views(), "the four calls did not form one render group"
     np.testing.assert_allclose(lv2.detach().cpu().numpy(), l32, rtol=2e-5)
     grads2 = torch.autograd.grad(lv2.sum(), list(leaves2.values()) + carriers)
     g_hip2 = {k: g.cpu().numpy() for k, g in zip(list(leaves2), grads2[:len(leaves2)])}
@@ -492,8 +491,7 @@ def test_ten_views_at_c2_size_chunked_launches_vs_oracle(oracle_built):
         losses2.append(view_loss(out, tg_d[j]))
         carriers.append(ssp_j)
     lv2 = torch.stack(losses2)
-    live = [g() for g in VG._GROUPS.values()]
-    assert any(g is not None and g.n_views == V for g in live), "the ten calls did not form one render group"
+    assert V in VG.live_group_views(), "the ten calls did not form one render group"
     np.testing.assert_allclose(lv2.detach().cpu().numpy(), l32, rtol=2e-5)
     try:
         grads2 = torch.autograd.grad(lv2.sum(), list(leaves2.values()) + carriers)
@@ -615,8 +613,7 @@ def test_surfel_render_views_backward_vs_oracle(oracle_built, size):
             means3D=leaves2["centers"], means2D=ssp2[v], shs=leaves2["shs"], opacities=torch.sigmoid(leaves2["opacity"]),
             scales=torch.exp(leaves2["scales"]), rotations=torch.nn.functional.normalize(leaves2["rotations"]))
         total2 = total2 + (color * gc[v].to(dev)).sum() + (allmap * ga[v].to(dev)).sum()
-    live = [g_() for g_ in VG._GROUPS.values()]
-    assert any(g_ is not None and g_.path.name == "surfel" and g_.n_views == V for g_ in live), "no surfel render group formed"
+    assert V in VG.live_group_views(), "no surfel render group formed"
     grads2 = torch.autograd.grad(total2, list(leaves2.values()) + ssp2)
     g_grp = {k: x.cpu().numpy() for k, x in zip(list(leaves2), grads2[:len(leaves2)])}
     g_grp["ssp"] = sum(x.cpu().numpy() for x in grads2[len(leaves2):])       # (the oracle's one carrier = the sum over the views)
