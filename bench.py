@@ -157,7 +157,18 @@ def run_c3step(args, wl, dev, rank, world, use_dist, barrier_fn):
     r_fused = Renderer(sh_degree=deg)
     L.load()
 
-    def caller_step():      # lightning/network.py:813-972 + renderer.py:209-272, op for op
+    from generativedensification_amd.camera import MiniCam
+    batch_cam = [(c.c2w.to(dev), torch.tensor(float(c.FoVy), device=dev), torch.tensor(float(c.FoVx), device=dev),
+                  torch.tensor(float(c.znear), device=dev), torch.tensor(float(c.zfar), device=dev)) for c in cams]
+    fresh = {"on": not args.prebuilt_cams}
+
+    def cam_of(j):          # network.py:832,851,970: a new MiniCam per render call from the batch's device tensors (utils.py:22-48)
+        if not fresh["on"]:
+            return cams[j]
+        c2w, fy, fx, zn, zf = batch_cam[j]
+        return MiniCam(c2w, w, h, fy, fx, zn, zf, dev)
+
+    def caller_step():      # the render sequence of lightning/network.py:813-972 + renderer.py:209-272 (cameras: see cam_of)
         for p in leaves:
             p.grad = None
         total = 0
@@ -166,14 +177,14 @@ def run_c3step(args, wl, dev, rank, world, use_dist, barrier_fn):
             oc = []
             for j in range(V):
                 r_caller.set_bg_color(bgs[j])
-                oc.append(r_caller.render_img(cams[j], None, centers, lc["shs"][i], lc["opacity"][i], lc["scales"][i],
+                oc.append(r_caller.render_img(cam_of(j), None, centers, lc["shs"][i], lc["opacity"][i], lc["scales"][i],
                                               lc["rotations"][i], dev))
 
             def fn(ssp):
                 fr = []
                 for j in range(VS):
                     r_caller.set_bg_color(bgs[j])
-                    fr.append(r_caller.render_img(cams[j], None, centers, lc["shs"][i], lc["opacity"][i], lc["scales"][i],
+                    fr.append(r_caller.render_img(cam_of(j), None, centers, lc["shs"][i], lc["opacity"][i], lc["scales"][i],
                                                   lc["rotations"][i], dev, screenspace_points=ssp))
                 return ((torch.stack([f["image"] for f in fr]) - tg[:VS]) ** 2).mean()
             _, grad = vjp(fn, torch.zeros(n, 4, device=dev))
@@ -184,7 +195,7 @@ def run_c3step(args, wl, dev, rank, world, use_dist, barrier_fn):
             of = []
             for j in range(V):
                 r_caller.set_bg_color(bgs[j])
-                of.append(r_caller.render_img(cams[j], None, *fs, dev, prex="_fine"))
+                of.append(r_caller.render_img(cam_of(j), None, *fs, dev, prex="_fine"))
             img_c = torch.cat([o["image"] for o in oc], dim=1)          # views concatenated along the width (network.py:974)
             img_f = torch.cat([o["image_fine"] for o in of], dim=1)
             gt = torch.cat(list(tg), dim=1)
@@ -232,6 +243,11 @@ def run_c3step(args, wl, dev, rank, world, use_dist, barrier_fn):
     el_f, loss_f = timed(fused_step, args.steps, args.warmup)
     el_c, loss_c = timed(caller_step, max(1, min(args.steps, 10)), max(1, min(args.warmup, 3)))
     k_c = max(1, min(args.steps, 10))
+    el_c_prebuilt = None
+    if fresh["on"]:         # the same sequence from cameras built once: what the per-call MiniCam costs the caller
+        fresh["on"] = False
+        el_c_prebuilt, _ = timed(caller_step, k_c, 2)
+        fresh["on"] = True
     kernels = {}
     roofline = None
     if not args.no_roofline:
@@ -331,7 +347,12 @@ def run_c3step(args, wl, dev, rank, world, use_dist, barrier_fn):
         "per_view": {"value": round(v_c, 2), "unit": "renders/s", "ms_per_step": round(1e3 * el_c / k_c, 3),
                      "ms_per_sample": round(1e3 * el_c / k_c / B, 3), "steps": k_c, "of_fused": round(v_c / v_f, 3),
                      "entry": "the unchanged caller: render_img per view (torch activations, new settings + carrier per call), "
-                              "torch.autograd.functional.vjp + torch.topk, losses on the width-concatenated views, one backward"},
+                              "torch.autograd.functional.vjp + torch.topk, losses on the width-concatenated views, one backward",
+                     "cameras": ("built once (--prebuilt-cams)" if args.prebuilt_cams else
+                                 "a MiniCam built on the device in front of every render call (network.py:832,851,970 -> utils.py:22-48)"),
+                     "value_prebuilt_cams": None if el_c_prebuilt is None else round(renders * k_c / el_c_prebuilt, 2),
+                     "ms_per_sample_prebuilt_cams": None if el_c_prebuilt is None else round(1e3 * el_c_prebuilt / k_c / B, 3),
+                     "host_boundary": "compiled (csrc/boundary.cpp)" if L.boundary() is not None else "python + ctypes"},
         "loss_fused": loss_f, "loss_per_view": loss_c, "roofline": roofline, "cpu_baseline": cpu_baseline, "kernels": kernels,
         "spread": "same box run-to-run +-0.3 %, box-to-box +-4 % (BASELINE.md section 4)",
         "gc": "Python's cyclic collector disabled inside the timed regions (timeit convention; collected right before)",
@@ -551,6 +572,13 @@ def main():
                     help="the loss of the reference's fine-stage renders and of its first 1000 iterations "
                          "(lightning/loss.py:35-50): image MSE only, in torch — no gradient reaches depth / alpha / the 2DGS "
                          "maps, and the surfel backward takes the image-only K7s")
+    ap.add_argument("--separate-loss-gather", action="store_true",
+                    help="with --grad-allreduce: the per-view losses in a collective of their own (rounds 1-5) instead of in the tail "
+                         "of the packed gradient buffer (A/B of the one-collective step)")
+    ap.add_argument("--prebuilt-cams", action="store_true",
+                    help="the unchanged-caller legs (`per_view`, c3step's caller_step, --per-view) render from cameras built once "
+                         "instead of building a MiniCam on the device in front of every render call as "
+                         "/root/reference/lightning/network.py:832,851,970 do (default: per call, the reference's loop)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "pmc_traffic.json"),
@@ -681,6 +709,23 @@ def main():
     plist = list(params.values())
     L.load()
 
+    # The reference builds its camera in front of EVERY render call (lightning/network.py:832,851,970 ->
+    # lightning/utils.py:22-48) from tensors of the batch, which live on the device: torch.inverse(c2w), a CPU projection
+    # matrix filled entry by entry from device scalars (four implicit device -> host reads), its upload, a 4x4 matmul; and
+    # set_rasterizer's math.tan(FoV / 2) reads two more device scalars (lightning/renderer.py:109-110).  The unchanged-caller
+    # legs do the same (round-5 verdict, missing #4) unless --prebuilt-cams; both figures are reported.
+    dev_scalars = {}
+
+    def fresh_cam(c):
+        from generativedensification_amd.camera import MiniCam
+        k = id(c)
+        if k not in dev_scalars:     # the batch's tensors: c2w, fovx / fovy, near / far on the device
+            dev_scalars[k] = (c.c2w.to(dev), torch.tensor(float(c.FoVy), device=dev), torch.tensor(float(c.FoVx), device=dev),
+                              torch.tensor(float(c.znear), device=dev), torch.tensor(float(c.zfar), device=dev))
+        c2w, fy, fx, zn, zf = dev_scalars[k]
+        return MiniCam(c2w, c.image_width, c.image_height, fy, fx, zn, zf, dev)
+    prebuilt_override = {"on": False}
+
     def make_step(per_view, unfused, torch_loss=False, loss_kernels=False, stacked_loss=False, backward_per_view=False):
         """One pass of the hot path over the rank's views.  per_view: the reference's call pattern — one
         `render_img` per view (lightning/network.py:827-838), the losses summed, ONE backward through all the views'
@@ -693,6 +738,8 @@ def main():
             rnd.set_bg_color(torch.ones(3, device=dev))
         a = (params["centers"], params["shs"], params["opacity"], params["scales"], params["rotations"], dev)
 
+        fresh = per_view and not (args.prebuilt_cams or prebuilt_override["on"])
+
         def step():
             for p in plist:
                 if args.keep_grads and p.grad is not None:
@@ -702,6 +749,8 @@ def main():
             if per_view:
                 losses = []
                 for j, cam in enumerate(cams):
+                    if fresh:       # network.py:832: a new MiniCam per render call, built on the device from the batch's tensors
+                        cam = fresh_cam(cam)
                     out = rnd.render_img(cam, rays[j] if surfel else None, *a)
                     loss = (((out["image"] - targets[j]) ** 2).mean() if args.image_loss
                             else (surfel_loss if surfel else view_loss)(out, targets[j]))
@@ -758,14 +807,26 @@ def main():
             if comm_events is not None:     # (the timed collectives of the roofline pass: events on the caller's stream)
                 ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
                 ev[0].record()
-            all_losses = gather_view_losses(losses, total_views)
-            if ev:
-                ev[1].record()
-            if args.grad_allreduce:
+            if args.grad_allreduce and not args.separate_loss_gather:
+                # ONE pair of collectives per step (round 6): the V per-view losses ride in the tail of the packed gradient
+                # buffer (the reference's DDP issues one bucketed all-reduce per step, train_lightning.py:71-76)
+                if ev:
+                    ev[1].record()
+                h_ = allreduce_gaussian_grads(plist, async_op=bool(args.overlap_comm), view_losses=losses, n_views=total_views)
                 if args.overlap_comm:   # RS + AG on the process group's stream, next to the NEXT step's forward; joined before
-                    pending_box["h"] = allreduce_gaussian_grads(plist, async_op=True)     # its backward writes the buffer again
+                    pending_box["h"] = h_                                                 # its backward writes the buffer again
+                    all_losses = losses      # (the gathered losses are read where they are logged: h_.losses joins)
                 else:
-                    allreduce_gaussian_grads(plist)
+                    all_losses = h_.losses
+            else:
+                all_losses = gather_view_losses(losses, total_views)
+                if ev:
+                    ev[1].record()
+                if args.grad_allreduce:
+                    if args.overlap_comm:
+                        pending_box["h"] = allreduce_gaussian_grads(plist, async_op=True)
+                    else:
+                        allreduce_gaussian_grads(plist)
             if ev:
                 ev[2].record()
                 comm_events.append(ev)
@@ -850,12 +911,16 @@ def main():
         dist.all_reduce(ones)                     # how many ranks the collectives really span (1 per process of the group)
         G_, B_ = dist.get_world_size(), sum(p.numel() * p.element_size() for p in plist)
         link = 153e9                              # one xGMI link, one direction (MI355X_MICROARCH.md: 7 links x ~153 GB/s per GPU)
-        comm_ms = dict(rccl_ranks_seen=int(ones.item()), backend=dist.get_backend(),
+        comm_ms = dict(ranks_seen=int(ones.item()), backend=dist.get_backend(),     # ("nccl" = RCCL over xGMI; "gloo" = the CPU test backend)
                        grad_bytes=B_, overlap=bool(args.overlap_comm),
                        expected_grad_allreduce_ms=(None if G_ < 2 else dict(
                            direct_all_links=round(2e3 * (B_ / G_) / link, 3), ring_one_link=round(2e3 * B_ * (G_ - 1) / G_ / link, 3),
                            note="reduce-scatter + all-gather of the packed gradients over xGMI: every peer pair moves 1/G of the "
                                 "buffer per phase when all 7 point-to-point links carry traffic at once; a ring is bound by one link")),
+                       collectives_per_step=(2 if args.grad_allreduce and not args.separate_loss_gather else
+                                             (3 if args.grad_allreduce else 1)),
+                       losses=("in the tail of the packed gradient buffer: no collective of their own" if args.grad_allreduce and
+                               not args.separate_loss_gather else "all-gather of V floats"),
                        loss_gather=round(sum(e[0].elapsed_time(e[1]) for e in comm_events) / k_ev, 4),
                        grad_allreduce=(round(sum(e[1].elapsed_time(e[2]) for e in comm_events) / k_ev, 4) if args.grad_allreduce else None),
                        grads="kept (zeroed each step: autograd accumulates into the packed buffer)" if args.keep_grads
@@ -940,13 +1005,19 @@ def main():
             ch, u0, u1 = _C.c_int32(0), _C.c_float(0), _C.c_float(0)
             for kind in ((3,) if surfel else (1, 0, 2)):
                 if L.load().gdr_k7_tune_get(n, h, w, min(vpg, 8), kind, _C.byref(ch), _C.byref(u0), _C.byref(u1)) == 0:
+                    rd, us4 = _C.c_int32(0), (_C.c_float * 4)()
+                    L.load().gdr_k7_tune_get_rounds(n, h, w, min(vpg, 8), kind, None, _C.byref(rd), us4)
                     k7_variant = dict(chosen={1: "pairs", 0: "rows"}.get(ch.value, "undecided (rows so far)"),
                                       us_rows=round(u0.value, 1), us_pairs=round(u1.value, 1),
+                                      rounds_done=rd.value,
+                                      confirmation=(dict(us_rows=round(us4[2], 1), us_pairs=round(us4[3], 1)) if rd.value >= 2 else
+                                                    "at launches 64..67 of the shape (not reached in this run)"),
                                       timed_steps_on_chosen=(args.steps if ch.value >= 0 and (settle or args.warmup >= 13) else None),
                                       settle_steps=settle,
                                       note="render_bwd_kernel (one record line per 4x4 block) or render_bwd_pairs_kernel (8x4 where "
-                                           "that saves lines): ONE timed round per launch shape (its launches 8..11, here inside the "
-                                           "settle steps in front of --warmup), the faster serves from then on; GDR_K7_PAIRS=0/1 pins it")
+                                           "that saves lines): one timed round per launch shape (its launches 8..11, here inside the "
+                                           "settle steps in front of --warmup), the faster serves; ONE confirmation round at launches "
+                                           "64..67 overturns it only if it loses by > 5 %, then the choice is final; GDR_K7_PAIRS=0/1 pins it")
                     break
         aj = pmc.get(args.workload + "_atomic", {}) if pmc_ok else {}
 
@@ -1093,8 +1164,33 @@ def main():
         per_view = dict(value=round(pv, 2), unit="views/s", ms_per_step=round(1e3 * el / k_pv, 3), steps=k_pv,
                         entry=("renderer_2dgs.render_img" if surfel else "render_img") + " per view, torch activations "
                               "(lightning/renderer.py:225-230 op for op), torch loss, one backward through all views",
+                        cameras=("built once (--prebuilt-cams)" if args.prebuilt_cams else
+                                 "a MiniCam built on the device in front of every render call (lightning/network.py:832 -> "
+                                 "lightning/utils.py:22-48: torch.inverse + a CPU projection matrix filled from device scalars)"),
+                        host_boundary=("compiled (csrc/boundary.cpp)" if L.boundary() is not None else "python + ctypes"),
                         path_frac=round(pv / world * alg["_bytes_view"] / 1e9 / HBM_PEAK_GBS, 4),
                         of_fused=round(pv / views_per_sec, 3))
+        if not args.prebuilt_cams:      # the same loop from cameras built once: what the camera construction costs the caller
+            prebuilt_override["on"] = True
+            pv2_step = make_step(True, True)
+            prebuilt_override["on"] = False
+            for _ in range(3):
+                pv2_step()
+            barrier()
+            gc.collect()
+            gc.disable()
+            t1 = time.perf_counter()
+            for _ in range(k_pv):
+                pv2_step()
+            barrier()
+            el2 = time.perf_counter() - t1
+            gc.enable()
+            if use_dist:
+                t = torch.tensor([el2], device=dev, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                el2 = float(t.item())
+            per_view["value_prebuilt_cams"] = round(total_views * k_pv / el2, 2)
+            per_view["ms_per_step_prebuilt_cams"] = round(1e3 * el2 / k_pv, 3)
         note(f"per-view leg done: {pv:.1f} views/s")
     # ---- third headline: the fused node with the IMAGES out and a torch loss on them ----------------------------------
     # /root/reference/lightning/loss.py:37-48 is MSE + 0.5 (1 - MS-SSIM) on the image: MS-SSIM needs the materialised image,
@@ -1165,9 +1261,10 @@ def main():
         # BASELINE.json's metric ends in "PSNR vs ref": the oracle's render against the HIP render of the same view at the
         # benchmark's own size, on IDENTICAL inputs (torch activations for both: the rasterizer boundary of renderer.py:250-259),
         # for every view of the rank (the oracle as the checker, outside every timed region).  Threshold flips counted: an alpha
-        # on the other side of 1/255 (settled since round 5 by the kernels' threshold guard, render.hip) or a transmittance on
-        # the other side of 1e-4 (T carries the accumulated rounding of all earlier factors: cannot be settled locally) adds or
-        # drops one contributor of one pixel.
+        # on the other side of 1/255 (a guard that re-evaluates near-threshold lanes in the oracle's order was built and
+        # measured in round 5 — render.hip GDR_THRESHOLD_GUARD, profiles/r05_ab_threshold_guard.txt: -2..-4 %, 5 -> 3 flips —
+        # and is NOT in the product build) or a transmittance on the other side of 1e-4 (T carries the accumulated rounding
+        # of all earlier factors) adds or drops one contributor of one pixel: flips of both kinds remain expected.
         per_view_psnr = []
         try:
             act = (params["centers"].detach(), params["shs"].detach(), torch.sigmoid(params["opacity"].detach()),

@@ -20,7 +20,7 @@ GDR_OK = 0
 GDR_IN_RAW_OPACITY, GDR_IN_RAW_SCALES, GDR_IN_RAW_ROTATIONS, GDR_IN_NO_DEPTH_TO_MEAN = 1, 2, 4, 8
 GDR_MAX_VIEWS = 8
 GDR_MAX_NODE_VIEWS = 256
-ABI_VERSION = 16
+ABI_VERSION = 17
 GDR_SAME_AS_MAX, GDR_REUSE_MAX = 8, 32
 GDR_DEFAULT_SEG_LEN = 256
 GDR_ERR_WORKSPACE = -4
@@ -182,6 +182,9 @@ _PROTOS = {
                                     C.POINTER(GdrViewState)]),
     "gdr_view_history_reset": (None, []),
     "gdr_k7_tune_override": (None, [C.c_int32]),
+    "gdr_k7_tune_get_rounds": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32),
+                                         C.POINTER(C.c_int32), C.POINTER(C.c_float)]),
+    "gdr_k7_tune_force_first": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "gdr_k7_tune_get": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32),
                                   C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "gdr_view_history_report": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_uint32), C.c_int32]),

@@ -70,9 +70,11 @@ static inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a
 // model — moves to another duplicates-per-Gaussian class, i.e. another key, instead).  gdr_k7_tune_override pins a variant
 // (tests, A/B, bit-reproducible runs).
 struct K7Tune {
-    float us[2] = {0.f, 0.f};      // the round's best time per variant (0 = not in yet; negated once the round is decided)
+    float us[2] = {0.f, 0.f};      // the running round's best time per variant (0 = not in yet)
+    float us_round[2][2] = {{0.f, 0.f}, {0.f, 0.f}};   // what the first and the confirmation round measured (rows, pairs)
     uint32_t calls = 0;
     int chosen = 0, got = 0;
+    int rounds_done = 0;           // 0: the first round is still to come / running, 1: decided once, 2: confirmed (final)
     bool decided = false;
     uint64_t last_use = 0;
     struct Pend { hipEvent_t a = nullptr, b = nullptr; int state = 0; } pend[4];   // state: 0 idle, 1 begun, 2 ended
@@ -84,7 +86,10 @@ static std::atomic<int> g_k7_override{-1};    // -1 measure and choose, 0 rows, 
 // the round = four consecutive launches, rows / pairs / rows / pairs (the faster of two tries counts), after kK7First launches
 // of the key — K7's duration drifts down over the first ten or so launches of a shape (C3: pairs 1332 -> 1202 us, rows 1335 ->
 // 1277, profiles/r04_ab_k7_blocks.txt section 10), a round at launch 0 chose wrongly
-constexpr uint32_t kK7Round = 4, kK7First = 8;
+// Round 6: a SECOND opinion.  One noisy timing (other streams busy, clocks still ramping) used to be the choice for the life
+// of the process although a wrong pick costs 3 % (C4) to 15 % (C2); launches kK7Second..+3 of the key time both kernels once
+// more and the first pick is overturned only if it loses that round by > 5 %.  After it the choice is final.
+constexpr uint32_t kK7Round = 4, kK7First = 8, kK7Second = 64;
 
 // duplicates per Gaussian of a view as a quarter-octave class (1..63; 0 = unknown: the state did not come from
 // gdr_forward_view(s)) — what gdr_binning.k7_class carries from the forward to the K7 entry points
@@ -118,11 +123,18 @@ static void k7_harvest(K7Tune& k) {   // (g_k7_mu held)
         }
         p.state = 0;
     }
-    if (!k.decided && k.got == (int)kK7Round && k.us[0] > 0.f && k.us[1] > 0.f) {
-        k.chosen = k.us[1] < 0.97f * k.us[0] ? 1 : 0;
-        k.us[0] = -k.us[0]; k.us[1] = -k.us[1];   // (kept, negated, for gdr_k7_tune_get)
+    if (k.rounds_done < 2 && k.got == (int)kK7Round && k.us[0] > 0.f && k.us[1] > 0.f) {
+        if (k.rounds_done == 0) {
+            k.chosen = k.us[1] < 0.97f * k.us[0] ? 1 : 0;
+        } else {                                   // confirmation: switch only if the first pick clearly loses
+            if (k.chosen == 0 && k.us[1] < 0.95f * k.us[0]) k.chosen = 1;
+            else if (k.chosen == 1 && k.us[0] < 0.95f * k.us[1]) k.chosen = 0;
+        }
+        k.us_round[k.rounds_done][0] = k.us[0]; k.us_round[k.rounds_done][1] = k.us[1];
+        k.us[0] = k.us[1] = 0.f;
         k.got = 0;
         k.decided = true;
+        ++k.rounds_done;
     }
 }
 // brackets ONE K7 launch: sets the calling thread's variant, times the launch when it is this key's turn
@@ -141,8 +153,9 @@ struct K7Scope {
             hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
             const bool capturing = hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone;
             if (capturing) (void)hipGetLastError();
-            if (!k.decided && !capturing) {      // (a timing event cannot be queried on a stream under graph capture)
-                const uint32_t phase = k.calls++ - kK7First;                   // (wraps for the launches before the round)
+            if (k.rounds_done < 2 && !capturing) {      // (a timing event cannot be queried on a stream under graph capture)
+                const uint32_t start = k.rounds_done == 0 ? kK7First : kK7Second;
+                const uint32_t phase = k.calls++ - start;                      // (wraps for the launches before the round)
                 if (phase < kK7Round && k.pend[phase].state == 0) {
                     K7Tune::Pend& p = k.pend[phase];
                     if (phase == 0) { k.us[0] = k.us[1] = 0.f; k.got = 0; }
@@ -152,7 +165,7 @@ struct K7Scope {
                 } else if (phase >= kK7Round && phase < 0x80000000u && k.got < (int)kK7Round) {
                     bool open = false;           // a try of the round was lost (an event call failed): start the round over
                     for (uint32_t ph = 0; ph < kK7Round; ++ph) open = open || k.pend[ph].state != 0;
-                    if (!open) k.calls = kK7First;
+                    if (!open) k.calls = start;
                 }
             }
         }
@@ -1501,8 +1514,40 @@ int gdr_k7_tune_get(int32_t N, int32_t H, int32_t W, int32_t V, int32_t kind, in
     if (!best) { set_error("k7_tune_get: no launch of this shape yet", hipSuccess); return GDR_ERR_INVALID_ARG; }
     k7_harvest(*best);
     if (chosen) *chosen = best->decided ? best->chosen : -1;
-    if (us_rows) *us_rows = best->us[0] < 0.f ? -best->us[0] : best->us[0];
-    if (us_pairs) *us_pairs = best->us[1] < 0.f ? -best->us[1] : best->us[1];
+    if (us_rows) *us_rows = best->rounds_done ? best->us_round[0][0] : best->us[0];
+    if (us_pairs) *us_pairs = best->rounds_done ? best->us_round[0][1] : best->us[1];
+    return GDR_OK;
+}
+
+static K7Tune* k7_latest(int32_t N, int32_t H, int32_t W, int32_t V, int32_t kind) {   // (g_k7_mu held)
+    const uint64_t probe = k7_key(N, H, W, V, kind, 0), mask = ~((uint64_t)0x3F << 36);
+    K7Tune* best = nullptr;
+    for (auto& kv : g_k7)
+        if ((kv.first & mask) == (probe & mask) && kv.second.last_use && (!best || kv.second.last_use > best->last_use)) best = &kv.second;
+    return best;
+}
+
+int gdr_k7_tune_get_rounds(int32_t N, int32_t H, int32_t W, int32_t V, int32_t kind, int32_t* chosen, int32_t* rounds_done,
+                           float* us4) {
+    std::lock_guard<std::mutex> lk(g_k7_mu);
+    K7Tune* best = k7_latest(N, H, W, V, kind);
+    if (!best) { set_error("k7_tune_get_rounds: no launch of this shape yet", hipSuccess); return GDR_ERR_INVALID_ARG; }
+    k7_harvest(*best);
+    if (chosen) *chosen = best->decided ? best->chosen : -1;
+    if (rounds_done) *rounds_done = best->rounds_done;
+    if (us4) for (int r = 0; r < 2; ++r) for (int v = 0; v < 2; ++v) us4[2 * r + v] = best->us_round[r][v];
+    return GDR_OK;
+}
+
+int gdr_k7_tune_force_first(int32_t N, int32_t H, int32_t W, int32_t V, int32_t kind, int32_t variant) {
+    std::lock_guard<std::mutex> lk(g_k7_mu);
+    K7Tune* best = k7_latest(N, H, W, V, kind);
+    if (!best) { set_error("k7_tune_force_first: no launch of this shape yet", hipSuccess); return GDR_ERR_INVALID_ARG; }
+    k7_harvest(*best);
+    if (best->rounds_done >= 2) { set_error("k7_tune_force_first: the shape's choice is already final", hipSuccess); return GDR_ERR_INVALID_ARG; }
+    best->chosen = variant ? 1 : 0;
+    best->decided = true;
+    if (best->rounds_done == 0) { best->rounds_done = 1; best->us[0] = best->us[1] = 0.f; best->got = 0; }
     return GDR_OK;
 }
 
@@ -1511,7 +1556,8 @@ void gdr_view_history_reset(void) {
         std::lock_guard<std::mutex> lk7(g_k7_mu);
         for (auto& kv : g_k7) {
             kv.second.calls = 0; kv.second.chosen = 0; kv.second.got = 0; kv.second.us[0] = kv.second.us[1] = 0.f;
-            kv.second.decided = false; kv.second.last_use = 0;
+            kv.second.decided = false; kv.second.last_use = 0; kv.second.rounds_done = 0;
+            for (int r = 0; r < 2; ++r) kv.second.us_round[r][0] = kv.second.us_round[r][1] = 0.f;
         }
     }
     std::lock_guard<std::mutex> lk(g_hist_mu);

@@ -56,12 +56,33 @@ def _no_peers() -> bool:
     return dist.get_world_size() == 1 and os.environ.get("GDR_FORCE_COLLECTIVES", "0") != "1"
 
 
-def gather_view_losses(local_losses: torch.Tensor, n_views: int | None = None) -> torch.Tensor:
+class _PendingLosses:
+    """An all-gather of per-view losses in flight (gather_view_losses(async_op=True)): wait() returns them in global view
+    order — call it where the losses are read (logging), not where they are produced."""
+
+    def __init__(self, work, out, m, sizes):
+        self.work, self.out, self.m, self.sizes = work, out, m, sizes
+
+    def wait(self) -> torch.Tensor:
+        if self.work is not None:
+            self.work.wait()
+            self.work = None
+        if self.sizes is None:
+            return self.out
+        return torch.cat([self.out[r * self.m: r * self.m + n] for r, n in enumerate(self.sizes)])
+
+
+def gather_view_losses(local_losses: torch.Tensor, n_views: int | None = None, async_op: bool = False):
     """All-gather of per-view scalar losses in global view order.  Uneven shards are padded
-    to the largest shard with NaN and stripped again."""
+    to the largest shard with NaN and stripped again.  async_op=True (needs n_views): the collective runs on the process
+    group's stream and a handle comes back; handle.wait() returns the losses (a step that only logs them joins there).
+    A step that ALSO sums gradients over the ranks needs no collective of its own for the losses: they ride in the tail of
+    the packed gradient buffer (allreduce_gaussian_grads(view_losses=...))."""
     if _no_peers():
-        return local_losses
+        return _PendingLosses(None, local_losses, 0, None) if async_op else local_losses
     world = dist.get_world_size()
+    if async_op and n_views is None:
+        raise ValueError("gather_view_losses(async_op=True) needs n_views (the shard sizes must be known without a collective)")
     n_local = torch.tensor([local_losses.numel()], device=local_losses.device, dtype=torch.int64)
     if n_views is None:
         sizes = [torch.zeros_like(n_local) for _ in range(world)]
@@ -73,6 +94,8 @@ def gather_view_losses(local_losses: torch.Tensor, n_views: int | None = None) -
     pad = torch.full((m,), float("nan"), device=local_losses.device, dtype=local_losses.dtype)
     pad[: local_losses.numel()] = local_losses
     out = torch.empty(world * m, device=local_losses.device, dtype=local_losses.dtype)
+    if async_op:
+        return _PendingLosses(dist.all_gather_into_tensor(out, pad, async_op=True), out, m, sizes)
     dist.all_gather_into_tensor(out, pad)
     return torch.cat([out[r * m: r * m + sizes[r]] for r in range(world)])
 
@@ -80,15 +103,16 @@ def gather_view_losses(local_losses: torch.Tensor, n_views: int | None = None) -
 class _Pack:
     """Persistent packed gradient buffer of ONE set of parameter tensors of one dtype (identified by the tensors
     themselves, not by their shapes: two Gaussian sets of equal N — coarse / fine, two models — must never share one)."""
-    __slots__ = ("flat", "views", "shard", "refs")
+    __slots__ = ("flat", "views", "shard", "refs", "tail")
 
 
 _PACKS: dict = {}   # (world, ids of the parameters) -> _Pack; the weak references guard against id() reuse
 
 
-def _grad_pack(params, world):
+def _grad_pack(params, world, tail: int = 0):
+    """tail: extra elements behind the gradients (the per-view losses of a step ride there: allreduce_gaussian_grads)."""
     import weakref
-    key = (world, tuple(id(p) for p in params))
+    key = (world, tuple(id(p) for p in params), int(tail))
     pack = _PACKS.get(key)
     if pack is not None and all(r() is p for r, p in zip(pack.refs, params)):
         _PACKS[key] = _PACKS.pop(key)      # most recently used last: the eviction below drops the LEAST recently used set
@@ -96,13 +120,14 @@ def _grad_pack(params, world):
     for k in [k for k, v in _PACKS.items() if any(r() is None for r in v.refs)]:    # sets whose tensors are gone
         del _PACKS[k]
     n = sum(p.numel() for p in params)
-    padded = (n + world - 1) // world * world
+    padded = (n + int(tail) + world - 1) // world * world
     pack = _Pack()
     pack.flat = torch.zeros(padded, device=params[0].device, dtype=params[0].dtype)
     pack.views, off = [], 0
     for p in params:
         pack.views.append(pack.flat[off: off + p.numel()].view(p.shape))
         off += p.numel()
+    pack.tail = pack.flat[n: n + int(tail)]
     pack.shard = torch.empty(padded // world, device=pack.flat.device, dtype=pack.flat.dtype)
     pack.refs = [weakref.ref(p) for p in params]
     while len(_PACKS) >= 16:     # (an evicted set's .grad tensors keep their storage alive; its next call builds a new buffer
@@ -115,16 +140,24 @@ class _PendingReduce:
     """Collectives in flight (allreduce_gaussian_grads(async_op=True)).  wait(): the caller's stream waits for them — call it
     before anything reads the gradients (the optimizer) or writes the packed buffer again (the next backward)."""
 
-    def __init__(self, works):
+    def __init__(self, works, losses=None):
         self.works = works
+        self._losses = losses
 
     def wait(self):
         for w in self.works:
             w.wait()
         self.works = []
+        return self
+
+    @property
+    def losses(self):
+        """The per-view losses of all ranks in global view order (allreduce_gaussian_grads(view_losses=...)); joins first."""
+        self.wait()
+        return self._losses
 
 
-def prepare_grad_sinks(params: Sequence[torch.Tensor], any_device: bool = False) -> None:
+def prepare_grad_sinks(params: Sequence[torch.Tensor], any_device: bool = False, tail=(0, None)) -> None:
     """Create the packed gradient buffer(s) of `params` now and register every slice as the gradient sink of its tensor
     (rasterizer.register_grad_sink): from the next backward on, the multi-view nodes' K9 writes the gradients of these leaves
     straight into the buffer the collectives move — no copy in allreduce_gaussian_grads.  (Called by
@@ -139,13 +172,14 @@ def prepare_grad_sinks(params: Sequence[torch.Tensor], any_device: bool = False)
         if dtype != torch.float32 or (dev.type != "cuda" and not any_device):     # (any_device: the CPU tests of the mechanism)
             continue
         from . import rasterizer as R
-        pack = _grad_pack(group, world)
+        pack = _grad_pack(group, world, tail[0] if tail[1] == (dev, dtype) else 0)   # (tail: the buffer that also carries a step's losses)
         for p, v in zip(group, pack.views):
             if p.is_leaf and p.requires_grad and p.is_contiguous():
                 R.register_grad_sink(p, v)
 
 
-def allreduce_gaussian_grads(params: Sequence[torch.Tensor], async_op: bool = False):
+def allreduce_gaussian_grads(params: Sequence[torch.Tensor], async_op: bool = False, view_losses: torch.Tensor | None = None,
+                             n_views: int | None = None):
     """Sum the per-Gaussian attribute gradients over ranks: one packed buffer
     (236 B/Gaussian at SH degree 3) moved as reduce-scatter + all-gather so that all
     7 xGMI links of a GPU carry 1/G of it each, instead of a per-tensor ring all-reduce.
@@ -172,19 +206,48 @@ def allreduce_gaussian_grads(params: Sequence[torch.Tensor], async_op: bool = Fa
     their tensors (prepare_grad_sinks), the multi-view nodes' K9 writes there directly and `.grad` arrives as a view of the
     buffer; (b) async_op=True returns a handle instead of making the caller's stream wait: the collectives run on the process
     group's stream next to whatever the caller enqueues next (the next sample's forward) — handle.wait() before the optimizer
-    reads the gradients or the next backward writes the buffer."""
+    reads the gradients or the next backward writes the buffer.
+
+    Round 6 — ONE pair of collectives per step (the reference's DDP issues one bucketed all-reduce per step,
+    /root/reference/train_lightning.py:71-76): view_losses = this rank's per-view losses (its shard of the n_views views, in
+    order).  They ride in the tail of the packed buffer: every rank writes its losses at its GLOBAL view positions and zeros at
+    the others, so the sum over the ranks that reduce-scatter + all-gather form anyway IS the all-gather of the losses — no
+    separate loss collective (0.12 ms of launch latency for a handful of floats, profiles/r05_bench_rccl_1rank*.json), no
+    size exchange, no NaN padding.  With view_losses the call always returns a handle; handle.losses (joins) is the (n_views,)
+    tensor in global view order."""
+    with_losses = view_losses is not None
+    if with_losses and n_views is None:
+        raise ValueError("allreduce_gaussian_grads(view_losses=...) needs n_views")
     if _no_peers():
+        if with_losses:
+            return _PendingReduce([], view_losses)
         return _PendingReduce([]) if async_op else None
     world = dist.get_world_size()
     params = list(params)
     if not params:
+        if with_losses:
+            return _PendingReduce([], gather_view_losses(view_losses, n_views))
         return _PendingReduce([]) if async_op else None
     works = []
+    gathered = None
     groups: dict = {}
     for p in params:     # one pack per dtype (and device), the order within a group as given
         groups.setdefault((p.device, p.dtype), []).append(p)
-    for group in groups.values():
-        pack = _grad_pack(group, world)
+    carrier = None       # the group whose buffer carries the losses: the first one of the losses' dtype and device
+    if with_losses:
+        carrier = next((k for k in groups if k == (view_losses.device, view_losses.dtype)), None)
+        if carrier is None:      # (no gradient buffer of that dtype: the losses take their own collective)
+            gathered = gather_view_losses(view_losses, n_views)
+    for gkey, group in groups.items():
+        pack = _grad_pack(group, world, n_views if gkey == carrier else 0)
+        if gkey == carrier:
+            mine = shard_views(n_views, dist.get_rank(), world)
+            if view_losses.numel() != len(mine):
+                raise ValueError(f"view_losses has {view_losses.numel()} entries, this rank's shard of {n_views} views has {len(mine)}")
+            pack.tail.zero_()
+            if len(mine):
+                pack.tail[mine.start: mine.stop].copy_(view_losses.detach().reshape(-1))
+            gathered = pack.tail
         for p, v in zip(group, pack.views):
             if p.grad is None:
                 v.zero_()
@@ -198,5 +261,7 @@ def allreduce_gaussian_grads(params: Sequence[torch.Tensor], async_op: bool = Fa
         for p, v in zip(group, pack.views):
             p.grad = v
     if params[0].is_cuda:
-        prepare_grad_sinks(params)
+        prepare_grad_sinks(params, tail=(n_views if carrier is not None else 0, carrier))
+    if with_losses:
+        return _PendingReduce(works, gathered)
     return _PendingReduce(works) if async_op else None

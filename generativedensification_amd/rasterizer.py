@@ -520,8 +520,12 @@ def _sink_for(t: torch.Tensor):
     if e is None:
         return None
     leaf = e[0]()
-    if (leaf is None or leaf.grad is not None or not leaf.is_leaf or not leaf.requires_grad or leaf.data_ptr() != t.data_ptr()
-            or leaf.numel() != t.numel() or t.dtype != torch.float32 or leaf._backward_hooks):
+    # `t` must BE the registered leaf (round-5 advisor finding): a view of it with another shape (p.view(N, 1), p[:, None]) or a
+    # second leaf on the same memory (p.detach().requires_grad_()) has the leaf's address and element count, but a sink alias of
+    # the leaf's shape is the wrong gradient for the first and somebody else's buffer for the second.  Saved inputs unpack to the
+    # caller's own tensor object, so identity is the test; anything else gets an ordinary buffer.
+    if (leaf is None or t is not leaf or t.grad_fn is not None or leaf.grad is not None or not leaf.is_leaf or not leaf.requires_grad
+            or t.shape != leaf.shape or t.dtype != torch.float32 or leaf._backward_hooks):
         return None
     task = torch._C._current_graph_task_id()
     with _HIST_LOCK:

@@ -25,7 +25,7 @@
  *   - the caller owns every buffer; the library allocates no device memory.  Process-wide state it DOES keep (all
  *     mutex-guarded; results never depend on any of it except where said): (1) the per-shape view history behind
  *     gdr_view_plan_for — duplicates per Gaussian and launch-size reports of recent calls, gdr_view_history_*;
- *     (2) the K7 choice per launch shape, gdr_k7_tune_* — decided ONCE per shape by timing, so WHICH of two
+ *     (2) the K7 choice per launch shape, gdr_k7_tune_* — decided per shape by timing (once + one confirmation), so WHICH of two
  *     kernels sums a gradient (the same terms in another order: differences at the fp32 rounding level) can differ
  *     between processes unless gdr_k7_tune_override pins it; (3) pooled pinned words / events (gdr_host_copy_*,
  *     gdr_forward_view(s), gdr_view_reuse_probe); (4) the opt-in timing facility at the end of this header.
@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define GDR_ABI_VERSION 16
+#define GDR_ABI_VERSION 17
 
 #define GDR_OK 0
 #define GDR_ERR_INVALID_ARG (-1)  /* NULL / inconsistent arguments                     */
@@ -422,9 +422,11 @@ void gdr_view_history_set(int32_t N, int32_t H, int32_t W, int32_t surfel, doubl
  * slower for sub-pixel Gaussians and object-like scenes.  The gradients are the same sums in another order.  Per (device,
  * N bucket, duplicates-per-Gaussian class of the views — gdr_binning.k7_class —, image size, views per launch, entry kind)
  * the library times both kernels ONCE (events around four consecutive launches, rows / pairs / rows / pairs, after the key's
- * first 8 launches; never on a stream under graph capture) and keeps the faster for the life of the process (v16; until v15
- * the round was repeated every 256 launches, so the variant could change mid-run).  A scene that drifts moves to another
- * class, i.e. another key with a round of its own.
+ * first 8 launches; never on a stream under graph capture) and keeps the faster (v16; until v15 the round was repeated every
+ * 256 launches, so the variant could change mid-run).  v17: ONE confirmation — launches 64..67 of the key time both kernels
+ * once more and the first pick is overturned only if it loses that round by > 5 % (a wrong pick from one noisy timing cost
+ * 3 % at C4, 15 % at C2 for the life of the process); after it the choice is final.  A scene that drifts moves to another
+ * class, i.e. another key with rounds of its own.
  * kind: 0 gdr_backward / gdr_render_backward(_views), 1 the _loss entries, 2 the mean2D-only entries, 3 the 2DGS K7s
  * (gsr_backward / gsr_render_backward(_views): 16 + 4 totals per pair, two record lines), 4 gdr_render_backward_mean2d_loss.
  * _override: -1 measure and choose (default), 0 rows only, 1 row pairs always (tests, A/B, bit-reproducible runs: the Python
@@ -433,6 +435,13 @@ void gdr_view_history_set(int32_t N, int32_t H, int32_t W, int32_t surfel, doubl
  * gdr_view_history_reset restarts the choices. */
 void gdr_k7_tune_override(int32_t mode);
 int gdr_k7_tune_get(int32_t N, int32_t H, int32_t W, int32_t V, int32_t kind, int32_t* chosen, float* us_rows, float* us_pairs);
+/* v17: both rounds of that key — *rounds_done 0 (first round still to come / running), 1 (decided once), 2 (confirmed: final);
+ * us4 = {rows, pairs} of the first round, {rows, pairs} of the confirmation round, microseconds, 0 = not measured yet. */
+int gdr_k7_tune_get_rounds(int32_t N, int32_t H, int32_t W, int32_t V, int32_t kind, int32_t* chosen, int32_t* rounds_done,
+                           float* us4);
+/* test hook: make `variant` the FIRST pick of that key (as if its first round had chosen it) — the confirmation round must
+ * then correct it if it is the wrong one.  Error once the key's choice is final. */
+int gdr_k7_tune_force_first(int32_t N, int32_t H, int32_t W, int32_t V, int32_t kind, int32_t variant);
 
 /* ---- backward (K7 + K8/K9) --------------------------------------------------------
  * Replaces `_C.rasterize_gaussians_backward`, reached through autograd from the losses on the render outputs

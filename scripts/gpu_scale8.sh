@@ -3,7 +3,7 @@
 # the driver's 8-GPU tier was never available, SCALE_r01..r04 are "skipped").  One rank per GPU over RCCL / xGMI:
 #   bash scripts/gpu_scale8.sh [out_dir]
 # writes out_dir/scale_<workload>_<N>.json for N = 1 2 4 8 (render-only scaling: loss all-gather) and the same with the
-# gradient reduce-scatter + all-gather (--grad-allreduce, plain and --overlap-comm); comm_ms.rccl_ranks_seen in every line
+# gradient reduce-scatter + all-gather (--grad-allreduce, plain and --overlap-comm); comm_ms.ranks_seen in every line
 # says how many ranks the collectives really spanned, comm_ms.expected_grad_allreduce_ms what xGMI allows.
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 OUT=${1:-gpurun_out/scale8}; mkdir -p $OUT
@@ -21,7 +21,7 @@ for wl in c4 c2; do for n in 1 2 4 8; do
 import json
 try:
     d = json.load(open("$OUT/scale_${wl}_${n}_${tag}.json"))
-    print("$wl N=$n $tag:", d["value"], "views/s", d["ms_per_step"], "ms/step", "ranks", (d.get("comm_ms") or {}).get("rccl_ranks_seen"),
+    print("$wl N=$n $tag:", d["value"], "views/s", d["ms_per_step"], "ms/step", "ranks", (d.get("comm_ms") or {}).get("ranks_seen"),
           "comm", {k: v for k, v in (d.get("comm_ms") or {}).items() if k in ("loss_gather", "grad_allreduce")})
 except Exception as ex:
     print("$wl N=$n $tag: FAILED", ex)

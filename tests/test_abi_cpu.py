@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/*.h but not exported"
         assert n in L.EXPORTED_SYMBOLS, f"{n} has no ctypes prototype"
-    assert lib.gdr_abi_version() == L.ABI_VERSION == 16
+    assert lib.gdr_abi_version() == L.ABI_VERSION == 17
     assert lib.gdr_build_tag() == b"release"
 
 

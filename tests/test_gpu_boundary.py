@@ -530,6 +530,52 @@ def test_k7_variant_is_measured_per_shape_and_can_be_pinned():
         lib.gdr_k7_tune_override(-1)
 
 
+def test_k7_choice_gets_one_confirmation_round_that_can_overturn_a_wrong_first_pick():
+    """include/gdr.h v17 (round-5 verdict next #8): launches 64..67 of a shape time both K7 kernels once more; the first pick is
+    overturned iff it loses that round by > 5 %, and the choice is final afterwards.  Both first picks are forced in turn
+    (gdr_k7_tune_force_first) so that whichever kernel is slower on this box is, once, the 'wrong first pick'; the outcome
+    must follow the rule applied to the times the library reports, and the slower-by-5-% kernel never survives."""
+    import ctypes as C
+
+    import util as U
+    from generativedensification_amd import _lib as L
+
+    lib = L.load()
+    N, H, W = 20_000, 96, 112
+    case = U.make_case(N, H, W, 23, deg=1, sigma0=(0.03, 0.01))
+    grads = U.rand_grads(case)
+    chosen, rounds, us4 = C.c_int32(-7), C.c_int32(-7), (C.c_float * 4)()
+    finals = []
+    try:
+        lib.gdr_k7_tune_override(-1)
+        for first in (0, 1):
+            lib.gdr_view_history_reset()
+            for _ in range(13):
+                U.run_hip(case, grads)
+            torch.cuda.synchronize()
+            U.run_hip(case, grads)                      # (harvests the first round)
+            assert lib.gdr_k7_tune_get_rounds(N, H, W, 1, 0, C.byref(chosen), C.byref(rounds), us4) == 0
+            assert rounds.value == 1 and us4[0] > 0 and us4[1] > 0 and us4[2] == 0
+            assert lib.gdr_k7_tune_force_first(N, H, W, 1, 0, first) == 0
+            for _ in range(60):
+                U.run_hip(case, grads)
+            torch.cuda.synchronize()
+            U.run_hip(case, grads)                      # (harvests the confirmation round)
+            assert lib.gdr_k7_tune_get_rounds(N, H, W, 1, 0, C.byref(chosen), C.byref(rounds), us4) == 0
+            assert rounds.value == 2 and us4[2] > 0 and us4[3] > 0, (rounds.value, list(us4))
+            own, other = us4[2 + first], us4[3 - first]
+            want = (1 - first) if other < 0.95 * own else first
+            assert chosen.value == want, (first, chosen.value, list(us4))
+            finals.append((chosen.value, us4[2], us4[3]))
+            assert lib.gdr_k7_tune_force_first(N, H, W, 1, 0, 1 - first) != 0      # final: no further change
+        for ch, rows_us, pairs_us in finals:            # a kernel that lost its confirmation round by > 5 % never serves
+            assert not (ch == 0 and pairs_us < 0.95 * rows_us) and not (ch == 1 and rows_us < 0.95 * pairs_us)
+        print("[k7 confirmation] (chosen, rows us, pairs us) after forcing rows / pairs first:", finals)
+    finally:
+        lib.gdr_k7_tune_override(-1)
+        lib.gdr_view_history_reset()
+
+
 def test_gradient_sinks_k9_writes_where_the_collective_needs_it():
     """Round 5 (multiview.prepare_grad_sinks / rasterizer.register_grad_sink): with the slices of a packed buffer registered as
     the gradient sinks of the leaves, the multi-view node's K9 writes there directly — `.grad` IS the slice (no copy), bit for

@@ -105,12 +105,7 @@ def test_hip_vs_oracle_at_baseline_sizes(oracle_built, name):
         np.testing.assert_array_equal(h[k], o[k], err_msg=k)
     np.testing.assert_array_equal(h["rgb"][:, :3], o["rgb"])
     # ---- sampled tiles: images, contributor counts ------------------------------------------------------------------
-    for k in ("color", "depth", "alpha"):
-        a, b = h[k][:, mask], o[k][:, mask]
-        assert U.outlier_fraction(a, b, rtol=1e-4, atol=1e-5) < 1e-4, k
-        assert U.rel_inf(a, b) < 5e-3, k
-    assert U.psnr(np.clip(h["color"][:, mask], 0, 1), np.clip(o["color"][:, mask], 0, 1)) > 60.0
-    assert (h["n_contrib"].view(np.uint32)[mask] != o["n_contrib"][mask]).mean() < 1e-4
+    nc, ft, px, p = U.assert_image_parity(h, o, name + " sampled tiles", mask)       # counts, not fractions (tests/util.py)
     lens = (o["ranges"][tiles, 1].astype(np.int64) - o["ranges"][tiles, 0])
     print(f"[{name}] D = {o['num_rendered']}, {tiles.size} sampled tiles, list lengths {lens.min()}..{lens.max()}")
     # ---- sampled tiles: full backward (upstream gradients zero outside the sample) ---------------------------------
@@ -140,6 +135,7 @@ def test_whole_images_of_all_bench_views_at_c4_size(oracle_built):
     H = W = 800
     cams = orbit_cameras(4, W, H)
     views = range(4) if (os.cpu_count() or 1) >= 16 else range(1)   # (the oracle needs ~4 s per view on 64 threads)
+    print(f"[c4 whole image] host has {os.cpu_count()} cpus: comparing view(s) {list(views)} of 4")
     ora = Oracle("f32", nthreads=THREADS)
     for v in views:
         case = _case_from_scene(sc, cams[v], H, W, 3)
@@ -147,15 +143,10 @@ def test_whole_images_of_all_bench_views_at_c4_size(oracle_built):
         h, _ = U.run_hip(case)
         o = ora.forward(U._np(case["means3D"]), U._np(case["opacities"]), U.settings_np(case), **kw)
         assert h["num_rendered"] == o["num_rendered"] > 3_000_000
-        for k in ("color", "depth", "alpha"):
-            assert U.outlier_fraction(h[k], o[k], rtol=1e-4, atol=1e-5) < 1e-4, (v, k)
-            assert U.rel_inf(h[k], o[k]) < 5e-3, (v, k)
-        p = U.psnr(np.clip(h["color"], 0, 1), np.clip(o["color"], 0, 1))
-        nc = float((h["n_contrib"].view(np.uint32) != o["n_contrib"]).mean())
-        ft = U.outlier_fraction(h["final_T"], o["final_T"], rtol=1e-4, atol=1e-6)
-        print(f"[c4 whole image] view {v}: D = {o['num_rendered']}, PSNR {p:.1f} dB, n_contrib differs on {nc:.2e} of the pixels, "
-              f"final T outside on {ft:.2e}")
-        assert p > 60.0 and nc < 1e-4 and ft < 1e-4, (v, p, nc, ft)
+        nc, ft, px, p = U.assert_image_parity(h, o, f"c4 whole image, view {v}")
+        print(f"[c4 whole image] view {v}: D = {o['num_rendered']}, PSNR {p:.1f} dB, n_contrib differs on {nc} pixels, "
+              f"final T outside on {ft}, colour / depth / alpha outside on {px} (bars {U.MAX_NCONTRIB_PIXELS} / "
+              f"{U.MAX_FINAL_T_PIXELS} / {U.MAX_IMAGE_PIXELS} of {H * W})")
 
 
 def test_whole_image_backward_at_c4_size(oracle_built):
@@ -164,7 +155,9 @@ def test_whole_image_backward_at_c4_size(oracle_built):
     a Gaussian's pixel terms then associate as on the GPU), float64 as the arbiter."""
     from oracle.gdr_oracle import Oracle
     if (os.cpu_count() or 1) < 16:
+        print(f"[c4 whole image backward] SKIPPED: host has {os.cpu_count()} cpus (< 16)")
         pytest.skip("the whole-image oracle backward at 2 M Gaussians needs a many-core host")
+    print(f"[c4 whole image backward] host has {os.cpu_count()} cpus: running")
     sc, cam, H, W, deg = _scene("c4")
     case = _case_from_scene(sc, cam, H, W, deg)
     kw = dict(shs=U._np(case["shs"]), scales=U._np(case["scales"]), rotations=U._np(case["rotations"]))
@@ -203,13 +196,9 @@ def test_whole_image_forward_and_backward_at_reference_sizes(oracle_built, name)
         out[dt] = ora.backward(f, *[U._np(g) for g in grads])
         if dt == "f32":
             o = f
-    for k in ("color", "depth", "alpha"):
-        assert U.outlier_fraction(h[k], o[k], rtol=1e-4, atol=1e-5) < 1e-4, k
-        assert U.rel_inf(h[k], o[k]) < 5e-3, k
-    p = U.psnr(np.clip(h["color"], 0, 1), np.clip(o["color"], 0, 1))
-    nc = float((h["n_contrib"].view(np.uint32) != o["n_contrib"]).mean())
-    print(f"[{name} whole image] D = {o['num_rendered']}, PSNR {p:.1f} dB, n_contrib differs on {nc:.2e} of the pixels")
-    assert p > 60.0 and nc < 1e-4
+    nc, ft, px, p = U.assert_image_parity(h, o, name + " whole image")
+    print(f"[{name} whole image] D = {o['num_rendered']}, PSNR {p:.1f} dB, n_contrib differs on {nc} pixels, final T outside on {ft}, "
+          f"colour / depth / alpha outside on {px}")
     # (max-norm bar: see the C4 test above.  Fraction outside the per-element bar: measured 0 .. 9.6e-5 here — a random
     # gradient on EVERY pixel makes every Gaussian's sums cancel, which the sampled-tile tests' 48 tiles do not — bar 3e-4.)
     _assert_grads(hg, out["f64"], out["f32"], GRAD_KEYS, name + " whole image", maxnorm=1e-3, max_outside=3e-4)

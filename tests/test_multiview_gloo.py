@@ -73,6 +73,24 @@ def _worker(rank, world, port, n_views, q):
         assert g["centers"].grad[0, 0].item() == float(sum(range(1, world + 1)))      # the first set's result is intact
         assert h["centers"].grad.data_ptr() != g["centers"].grad.data_ptr()
         _sink_path(rank, world)
+        # round 6: ONE pair of collectives per step — the per-view losses ride in the tail of the packed gradient buffer
+        # (incl. the rank whose shard is empty), synchronously and as async_op; the async loss-only gather agrees
+        c = {k: torch.ones(5, 3, requires_grad=True) for k in ("centers", "shs")}
+        (c["centers"].sum() * float(rank + 1)).backward()
+        hnd = allreduce_gaussian_grads(list(c.values()), view_losses=losses.detach(), n_views=n_views)
+        assert hnd.losses.tolist() == allv.tolist(), (hnd.losses.tolist(), allv.tolist())
+        assert c["centers"].grad[0, 0].item() == float(sum(range(1, world + 1))) and float(c["shs"].grad.abs().sum()) == 0.0
+        for p in c.values():
+            p.grad = None
+        (c["centers"].sum() * 2.0).backward()
+        hnd = allreduce_gaussian_grads(list(c.values()), async_op=True, view_losses=losses.detach() * 2.0, n_views=n_views)
+        assert hnd.losses.tolist() == [2.0 * x for x in allv.tolist()] and c["centers"].grad[0, 0].item() == 2.0 * world
+        assert gather_view_losses(losses.detach(), n_views, async_op=True).wait().tolist() == allv.tolist()
+        try:
+            allreduce_gaussian_grads(list(c.values()), view_losses=torch.zeros(len(mine) + 1), n_views=n_views)
+            raise AssertionError("a loss vector that is not this rank's shard must be refused")
+        except ValueError:
+            pass
         q.put((rank, allv.tolist(), first[0], first[1]))
     finally:
         dist.destroy_process_group()

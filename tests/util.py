@@ -124,6 +124,40 @@ def outlier_fraction(a, b, rtol=1e-4, atol=1e-4):
     return float((np.abs(a - b) > atol + rtol * np.abs(b)).mean()) if a.size else 0.0
 
 
+# The parity line of the images, held where it IS (round-5 verdict, next #5).  HIP and the f32 oracle evaluate alpha with two
+# valid fp32 programs (v_exp_f32 on a log2e-prescaled conic vs glibc expf), so on a handful of pixels per image one
+# contributor of weight ~1/255 is kept by one and skipped by the other (alpha on the other side of 1/255, or T on the other
+# side of 1e-4): measured per 800x800 image n_contrib differs on 0-1 pixels, final T on 0-2, colour on 0-1.  The bars are
+# COUNTS a little above that — not fractions of the image (1e-4 of 640 000 pixels = 64: a regression that flips 50 pixels
+# per image passed until round 5).
+MAX_NCONTRIB_PIXELS, MAX_FINAL_T_PIXELS, MAX_IMAGE_PIXELS = 4, 8, 4
+
+
+def image_parity_counts(h, o, mask=None):
+    """(pixels whose contributor count differs, pixels whose final T is outside, pixels with colour / depth / alpha outside
+    the per-element bar, PSNR of the clamped colour).  h / o: dicts with color (3,H,W), depth, alpha (1,H,W), n_contrib,
+    final_T (H,W); mask: optional boolean (H,W) restricting the comparison."""
+    m = np.ones(h["n_contrib"].shape, bool) if mask is None else mask
+    nc = int((h["n_contrib"].view(np.uint32)[m] != np.asarray(o["n_contrib"]).view(np.uint32)[m]).sum())
+    a, b = np.asarray(h["final_T"], np.float64)[m], np.asarray(o["final_T"], np.float64)[m]
+    ft = int((np.abs(a - b) > 1e-6 + 1e-4 * np.abs(b)).sum())
+    bad = np.zeros(int(m.sum()), bool)
+    for k in ("color", "depth", "alpha"):
+        x, y = np.asarray(h[k], np.float64)[:, m], np.asarray(o[k], np.float64)[:, m]
+        bad |= (np.abs(x - y) > 1e-5 + 1e-4 * np.abs(y)).any(axis=0)
+    return nc, ft, int(bad.sum()), psnr(np.clip(h["color"][:, m], 0, 1), np.clip(o["color"][:, m], 0, 1))
+
+
+def assert_image_parity(h, o, tag, mask=None):
+    nc, ft, px, p = image_parity_counts(h, o, mask)
+    for k in ("color", "depth", "alpha"):
+        x, y = (h[k], o[k]) if mask is None else (h[k][:, mask], o[k][:, mask])
+        assert rel_inf(x, y) < 5e-3, (tag, k)        # (one contributor of weight 1/255 on a pixel, no more)
+    assert nc <= MAX_NCONTRIB_PIXELS and ft <= MAX_FINAL_T_PIXELS and px <= MAX_IMAGE_PIXELS and p > 60.0, \
+        (tag, dict(n_contrib_pixels=nc, final_T_pixels=ft, image_pixels=px, psnr=p))
+    return nc, ft, px, p
+
+
 def psnr(a, b):
     mse = float(((np.asarray(a, np.float64) - np.asarray(b, np.float64)) ** 2).mean())
     return 10 * math.log10(1.0 / max(mse, 1e-30))
