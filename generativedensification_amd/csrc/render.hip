@@ -75,6 +75,18 @@ __device__ __forceinline__ bool alpha_near_threshold(float alpha) { return fabsf
 #define GDR_WALK_WAVES
 __device__ __forceinline__ bool alpha_near_threshold(float) { return false; }
 #endif
+// occupancy experiments of the measurement builds (round 6): -DGDR_K6_WAVES=n / -DGDR_K7_WAVES=n pin the waves per SIMD of the
+// standard K6 / the row-mode K7 (the compiler then caps their VGPRs at 512 / n); not set in the product build
+#ifdef GDR_K6_WAVES
+#define GDR_K6_OCC __attribute__((amdgpu_waves_per_eu(GDR_K6_WAVES, GDR_K6_WAVES)))
+#else
+#define GDR_K6_OCC
+#endif
+#ifdef GDR_K7_WAVES
+#define GDR_K7_OCC __attribute__((amdgpu_waves_per_eu(GDR_K7_WAVES, GDR_K7_WAVES)))
+#else
+#define GDR_K7_OCC
+#endif
 // ---- measurement builds (round 6: the K7 instruction / time budget, profiles/r06_k7_budget.json) --------------------------
 // -DGDR_K7_STUB=<bits> compiles ONE phase of K7's walk out (or twice in) so that its share of the launch can be MEASURED as
 // a difference of launch times and SQ_INSTS_VALU counts (scripts/gpu_k7_budget.sh).  Results of such a build are WRONG by
@@ -348,7 +360,7 @@ struct FwdView {
 struct FwdViews { FwdView v[GDR_MAX_VIEWS]; };
 
 template <int LOSS>
-__global__ __launch_bounds__(GDR_BLOCK) GDR_WALK_WAVES
+__global__ __launch_bounds__(GDR_BLOCK) GDR_WALK_WAVES GDR_K6_OCC
 void render_fwd_kernel(const FwdViews vs, int V, int interleave, int W, int H, int gx,
                                                                int ntiles) {
     __shared__ SliceLds lds;
@@ -1121,7 +1133,7 @@ __device__ __forceinline__ void render_bwd_body(const BwdViews& vs, int V, int i
 }
 
 template <bool M2_ONLY, bool LOSS = false>
-__global__ __launch_bounds__(GDR_BLOCK) GDR_WALK_WAVES
+__global__ __launch_bounds__(GDR_BLOCK) GDR_WALK_WAVES GDR_K7_OCC
 void render_bwd_kernel(const BwdViews vs, int V, int interleave, int n_extra_max,
                                                                int W, int H, int gx, int ntiles) {
     render_bwd_body<M2_ONLY, LOSS, false>(vs, V, interleave, n_extra_max, W, H, gx, ntiles);

@@ -118,7 +118,7 @@ def _grad_pack(params, world, tail: int = 0):
         _PACKS[key] = _PACKS.pop(key)      # most recently used last: the eviction below drops the LEAST recently used set
         return pack
     for k in [k for k, v in _PACKS.items() if any(r() is None for r in v.refs)]:    # sets whose tensors are gone
-        del _PACKS[k]
+        _drop_pack(_PACKS.pop(k))
     n = sum(p.numel() for p in params)
     padded = (n + int(tail) + world - 1) // world * world
     pack = _Pack()
@@ -131,9 +131,19 @@ def _grad_pack(params, world, tail: int = 0):
     pack.shard = torch.empty(padded // world, device=pack.flat.device, dtype=pack.flat.dtype)
     pack.refs = [weakref.ref(p) for p in params]
     while len(_PACKS) >= 16:     # (an evicted set's .grad tensors keep their storage alive; its next call builds a new buffer
-        _PACKS.pop(next(iter(_PACKS)))   #  and copies once — LRU, so that only sets not reduced for 16 other sets pay that)
+        _drop_pack(_PACKS.pop(next(iter(_PACKS))))   #  and copies once — LRU, so that only sets not reduced for 16 other sets pay that)
     _PACKS[key] = pack
     return pack
+
+
+def _drop_pack(pack):
+    """A packed buffer leaves the cache: its slices must not stay registered as gradient sinks (the registry would keep the
+    whole buffer — 472 MB at 2 M Gaussians — alive until the next registration; round-5 advisor finding)."""
+    try:
+        from . import rasterizer as R
+        R.unregister_grad_sinks(pack.views)
+    except Exception:      # noqa: BLE001 — (the rasterizer module needs the HIP library; the CPU tests of the collectives do not)
+        pass
 
 
 class _PendingReduce:
@@ -179,7 +189,7 @@ def prepare_grad_sinks(params: Sequence[torch.Tensor], any_device: bool = False,
 
 
 def allreduce_gaussian_grads(params: Sequence[torch.Tensor], async_op: bool = False, view_losses: torch.Tensor | None = None,
-                             n_views: int | None = None):
+                             n_views: int | None = None, use_sinks: bool = True):
     """Sum the per-Gaussian attribute gradients over ranks: one packed buffer
     (236 B/Gaussian at SH degree 3) moved as reduce-scatter + all-gather so that all
     7 xGMI links of a GPU carry 1/G of it each, instead of a per-tensor ring all-reduce.
@@ -214,7 +224,13 @@ def allreduce_gaussian_grads(params: Sequence[torch.Tensor], async_op: bool = Fa
     the others, so the sum over the ranks that reduce-scatter + all-gather form anyway IS the all-gather of the losses — no
     separate loss collective (0.12 ms of launch latency for a handful of floats, profiles/r05_bench_rccl_1rank*.json), no
     size exchange, no NaN padding.  With view_losses the call always returns a handle; handle.losses (joins) is the (n_views,)
-    tensor in global view order."""
+    tensor in global view order.
+
+    ALIASING (as DDP's gradient_as_bucket_view): after the call `.grad` of every tensor is a VIEW of the persistent packed
+    buffer, and with use_sinks=True (default) the next backward's K9 writes the new gradients into that same memory — a caller
+    that keeps a reference to an old gradient after `p.grad = None` (manual accumulation, densification statistics) sees it
+    overwritten.  Clone what must survive a step, or pass use_sinks=False (the gradients then arrive in fresh tensors and are
+    copied into the buffer by the next call: one read + write of the buffer per step)."""
     with_losses = view_losses is not None
     if with_losses and n_views is None:
         raise ValueError("allreduce_gaussian_grads(view_losses=...) needs n_views")
@@ -260,7 +276,7 @@ def allreduce_gaussian_grads(params: Sequence[torch.Tensor], async_op: bool = Fa
         works += [w1, w2] if async_op else []
         for p, v in zip(group, pack.views):
             p.grad = v
-    if params[0].is_cuda:
+    if params[0].is_cuda and use_sinks:
         prepare_grad_sinks(params, tail=(n_views if carrier is not None else 0, carrier))
     if with_losses:
         return _PendingReduce(works, gathered)

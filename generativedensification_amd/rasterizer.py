@@ -442,7 +442,7 @@ def _early_records_clear(ctx, pending):
             L.check(lib.gdr_clear_async(C.c_void_p(recs.data_ptr() + v * row), row, C.c_void_p(streams[v].cuda_stream)),
                     "gdr_clear_async")
     ctx.recs = recs
-    ctx.recs_streams = distinct    # (a one-launch K7 on the caller's stream waits for these: _join_record_clears)
+    ctx.recs_streams = distinct    # (whatever K7 mode the backward runs in, it joins these first: _join_record_clears)
 
 
 def _early_records(ctx, dev, V, N, H, W, floats):
@@ -507,9 +507,16 @@ def register_grad_sink(leaf: torch.Tensor, sink: torch.Tensor):
         _GRAD_SINKS[leaf.data_ptr()] = [weakref.ref(leaf), sink, None]
 
 
-def unregister_grad_sinks():
+def unregister_grad_sinks(sinks=None):
+    """Forget every registered sink, or only those whose sink tensor is one of `sinks` (a packed buffer that is being
+    dropped: multiview._grad_pack's eviction) — the registry holds the sink tensors strongly."""
     with _HIST_LOCK:
-        _GRAD_SINKS.clear()
+        if sinks is None:
+            _GRAD_SINKS.clear()
+            return
+        ptrs = {t.data_ptr() for t in sinks}
+        for k in [k for k, e in _GRAD_SINKS.items() if e[1].data_ptr() in ptrs or e[0]() is None]:
+            del _GRAD_SINKS[k]
 
 
 def _sink_for(t: torch.Tensor):
@@ -903,8 +910,8 @@ class _RenderViews(torch.autograd.Function):
                 grads_in.append((gc, gd, ga))
             sets = _kept_settings(ctx, dev, keep2)
             mode = k7_views_mode(H, W, N) if V > 1 else 0
-            if mode:
-                _join_record_clears(ctx)
+            _join_record_clears(ctx)      # (always: the forward chose ONE clear on one stream from the mode it saw; if the mode was
+            #                                switched in between — the A/B tooling does — per-view K7 launches must still wait for it)
             sides = _SideViews(dev, 1 if mode else V, H, W)  # after every torch-side preparation (the side streams wait for this point)
             for lo in range(0, V, L.GDR_MAX_VIEWS):
                 n = min(L.GDR_MAX_VIEWS, V - lo)
@@ -991,8 +998,7 @@ class _RenderViewsLoss(torch.autograd.Function):
             stream = _stream()
             sets = _kept_settings(ctx, dev, keep2)
             mode = k7_views_mode(states[0].H, states[0].W, N) if V > 1 else 0
-            if mode:
-                _join_record_clears(ctx)
+            _join_record_clears(ctx)      # (always: see _RenderViews.backward)
             sides = _SideViews(dev, 1 if mode else V, states[0].H, states[0].W)  # after every torch-side preparation (the side streams wait for this point)
             for lo in range(0, V, L.GDR_MAX_VIEWS):
                 n = min(L.GDR_MAX_VIEWS, V - lo)

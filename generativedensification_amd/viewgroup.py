@@ -642,6 +642,8 @@ class _GroupView(torch.autograd.Function):
                 with grp.lock:
                     grp.cache.append(dict(s=keep_rest[-1], outs=alias, out_versions=tuple(a._version for a in alias), state=st,
                                           keep_rest=keep_rest, set_versions=_settings_versions(raster_settings)))
+                    del grp.cache[:-L.GDR_REUSE_MAX]      # (only the last GDR_REUSE_MAX entries are ever probe candidates: a pass that
+                    #                                        never reaches the hub must not keep 64 views' workspaces alive)
         else:
             outs, st, keep_rest = tuple(t.clone() for t in hit["outs"]), hit["state"], hit["keep_rest"]
         ctx.grp, ctx.j, ctx.raster_settings, ctx.state, ctx.radii = grp, j, raster_settings, st, outs[1]

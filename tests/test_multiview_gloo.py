@@ -183,3 +183,24 @@ def test_single_process_is_a_no_op():
     x = torch.arange(3.0)
     assert gather_view_losses(x) is x
     allreduce_gaussian_grads([torch.ones(2, requires_grad=True)])
+
+
+def test_a_gradient_sink_is_only_handed_to_the_registered_leaf_itself():
+    """Round-5 advisor finding: _sink_for matched a node input to a registered leaf by address and element count.  A view of the
+    leaf with another shape (p.view(N, 1)) then got a leaf-shaped sink alias (autograd: 'invalid gradient shape'), and a second
+    leaf on the same memory (p.detach().requires_grad_()) took p's sink.  The input must BE the leaf."""
+    from generativedensification_amd import rasterizer as R
+    p = torch.ones(6, requires_grad=True)
+    sink = torch.zeros(6)
+    try:
+        R.register_grad_sink(p, sink)
+        assert R._sink_for(p) is sink
+        R._GRAD_SINKS[p.data_ptr()][2] = None                     # (the slot is free again for the next probe)
+        assert R._sink_for(p.view(6, 1)) is None and R._sink_for(p[:, None]) is None and R._sink_for(p.view(2, 3)) is None
+        q = p.detach().requires_grad_()                           # another leaf, same memory
+        assert q.data_ptr() == p.data_ptr() and R._sink_for(q) is None
+        assert R._sink_for(p * 1.0) is None
+        R.unregister_grad_sinks([sink])                           # the targeted form drops exactly this entry
+        assert R._sink_for(p) is None and not R._GRAD_SINKS
+    finally:
+        R.unregister_grad_sinks()
