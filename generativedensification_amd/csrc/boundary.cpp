@@ -337,7 +337,7 @@ static std::unordered_map<std::string, std::weak_ptr<Group>> g_groups;
 static const int kMaxViewsPerGroup = 64;
 
 // reuse history / statistics (viewgroup._REUSE_HIST, _REUSE_STATS)
-struct ReuseHist { bool matched = false; int since = 0; };
+struct ReuseHist { bool matched = false; int since = 0; int period = 32; };   // period: calls between probes after a miss (doubles per miss)
 static std::unordered_map<std::string, std::map<int, ReuseHist>> g_reuse_hist;
 static int64_t g_probes = 0, g_hits = 0;
 static std::unordered_map<int, Tensor> g_scratch;     // device index -> the probe's device words
@@ -608,7 +608,7 @@ static bool reuse_should_probe(Group& g, int j, bool reuse_forward) {
     auto& hist = g_reuse_hist[g.shape];
     auto it = hist.find(j);
     if (it == hist.end() || it->second.matched) return true;
-    if (++it->second.since >= 32) { it->second.since = 0; return true; }
+    if (++it->second.since >= it->second.period) { it->second.since = 0; return true; }
     return false;
 }
 
@@ -647,7 +647,12 @@ static const CacheEntry* reuse_probe(Group& g, int j, const Settings& now, const
     {
         std::lock_guard<std::mutex> lk(g_lock);
         g_probes += 1; g_hits += hit ? 1 : 0;
-        g_reuse_hist[g.shape][j] = ReuseHist{hit != nullptr, 0};
+        // a probe is a BLOCKING call (it drains the caller's stream): an index that keeps missing is asked again after 32, 64, ...
+        // 1024 calls — a caller that never repeats a view pays a handful of probes per index, not one in every 32 calls
+        ReuseHist& h = g_reuse_hist[g.shape][j];
+        h.period = hit ? 32 : (h.matched || h.period < 32 ? 32 : std::min(h.period * 2, 1024));
+        h.matched = hit != nullptr;
+        h.since = 0;
     }
     return hit;
 }

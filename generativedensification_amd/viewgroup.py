@@ -327,7 +327,7 @@ def _same_as_pairs(grp, tensors, R):
 # per call by the reference (MiniCam, `bg.to(device)`), so they are compared on the device — one small blocking native call
 # (gdr_view_reuse_probe, which also carries the group's same_as pairs).  A blocking call per render would tax every call of
 # a caller that never repeats a view, so WHICH calls probe is learned per scene shape and call index: an index probes when
-# it is new, when its last probe matched, and every 32nd time otherwise.
+# it is new, when its last probe matched, and otherwise after 32, 64, ... 1024 calls (doubling per miss: round 6).
 REUSE_FORWARD = os.environ.get("GDR_REUSE_FORWARD", "1") != "0"
 COMPILED = True      # False: the Python nodes below serve although the compiled boundary is loaded (tests compare the two)
 class _ReuseHist(dict):
@@ -388,7 +388,7 @@ def _reuse_should_probe(grp, j):
         if h is None or h[0]:
             return True
         h[1] += 1
-        if h[1] >= 32:
+        if h[1] >= h[2]:
             h[1] = 0
             return True
         return False
@@ -426,7 +426,12 @@ def _reuse_probe(grp, j, raster_settings, same_as, R):
     with _LOCK:
         _REUSE_STATS["probes"] += 1
         _REUSE_STATS["hits"] += hit is not None
-        _REUSE_HIST.setdefault(grp.shape, {})[j] = [hit is not None, 0]
+        # (a probe is a BLOCKING call — it drains the caller's stream —: an index that keeps missing is asked again after 32, 64,
+        # ... 1024 calls; same-box A/B profiles/r06_ab_perview_regress.txt: probing every 32nd call cost a loop that never repeats a
+        # view 4-7 % at C2 / C3 / C5)
+        prev = _REUSE_HIST.setdefault(grp.shape, {}).get(j)
+        period = 32 if (hit is not None or prev is None or prev[0]) else min(prev[2] * 2, 1024)
+        _REUSE_HIST[grp.shape][j] = [hit is not None, 0, period]
     return hit, True
 
 

@@ -5,7 +5,7 @@
 # gpurun_out/final/ (copied into profiles/ afterwards).   bash scripts/gpu_final.sh r03
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 R=$PWD; O=$R/gpurun_out/final; mkdir -p $O
-TAG=${1:-r05}
+TAG=${1:-r06}
 timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?"; tail -2 $O/smoke.log
 timeout 1500 python -m pytest tests -m gpu -q -rP > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -1 $O/pytest_gpu.log
 grep -E "^\[" $O/pytest_gpu.log > $O/${TAG}_fullsize_parity.log
@@ -25,6 +25,12 @@ for wl in c2 c3 c4; do
   timeout 600 python bench.py --workload $wl --steps 10 --warmup 3 --no-cpu-baseline --no-per-view-leg > $O/k7line_$wl.json 2>/dev/null
   python scripts/k7_stalls.py $O/${TAG}_${wl}_pmc_summary.json $O/k7line_$wl.json $O/${TAG}_k7_stalls_$wl.json | cut -c1-400
 done
+python scripts/binning_stalls.py $O/${TAG}_c4_pmc_summary.json $O/k7line_c4.json $O/${TAG}_binning_stalls.json | cut -c1-600
+echo "--- K7 / K6 phase budget from measurement builds (csrc/render.hip GDR_K7_STUB; built here if absent)"
+for st in 1 2 4 8 16 32 3 7 23; do [ -f generativedensification_amd/lib/variants/libgdr_hip_k7stub$st.so ] || make -C generativedensification_amd/csrc variant VTAG=k7stub$st VDEFS=-DGDR_K7_STUB=$st > /dev/null 2>&1; done
+bash scripts/gpu_k7_budget.sh > $O/k7_budget.log 2>&1; cp gpurun_out/k7_budget/k7_budget.json $O/${TAG}_k7_budget.json 2>/dev/null; tail -3 $O/k7_budget.log | cut -c1-300
+for u in valu_rate valu_select; do P=generativedensification_amd/lib/$u; [ -x $P ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 scripts/ubench/$u.hip -o $P 2>/dev/null; timeout 120 $P > $O/${TAG}_$u.txt 2>&1; done
+for k in 20 21 22 23 24 25 26 27; do timeout 15 generativedensification_amd/lib/valu_select $k >> $O/${TAG}_valu_select.txt 2>&1; done
 b() { name=$1; shift; timeout 1200 python bench.py "$@" > $O/${TAG}_bench_$name.json 2> $O/bench_$name.err || tail -3 $O/bench_$name.err
   python - <<PY
 import json
@@ -63,8 +69,14 @@ echo "--- kernel timeline of a C4 step + idle gaps"
 bash scripts/gpu_timeline.sh c4 --no-per-view-leg > /dev/null 2>&1; cp gpurun_out/timeline_c4.txt $O/${TAG}_timeline_c4.txt; head -12 $O/${TAG}_timeline_c4.txt | grep "^step"
 echo "--- the unchanged caller's loop: kernel timeline + GPU-busy fraction (C4 GPU-bound, C2 80 % busy)"
 for wl in c4 c2 c5; do bash scripts/gpu_timeline_pv.sh $wl > /dev/null 2>&1; cp gpurun_out/timeline_pv_$wl.txt $O/${TAG}_timeline_pv_$wl.txt; grep "^step [23]" $O/${TAG}_timeline_pv_$wl.txt; done
-python scripts/host_split.py 2>/dev/null | tail -1 | tee $O/${TAG}_host_split.txt
-python scripts/host_split2.py 2>/dev/null | grep "us per call" | head -16 >> $O/${TAG}_host_split.txt
+echo "--- host time of the unchanged caller's loop: compiled boundary (csrc/boundary.cpp) vs the python + ctypes boundary"
+python scripts/host_split.py 2>/dev/null | grep -E "host boundary|^N=" | tee $O/${TAG}_host_split.txt
+GDR_COMPILED_BOUNDARY=0 python scripts/host_split.py 2>/dev/null | grep -E "host boundary|^N=" | tee -a $O/${TAG}_host_split.txt
+GDR_COMPILED_BOUNDARY=0 python scripts/host_split2.py 2>/dev/null | grep "us per call" | head -16 >> $O/${TAG}_host_split.txt
+echo "--- same box A/B: compiled boundary on / off, forward reuse on / off (unchanged caller, cameras built once)" | tee $O/${TAG}_ab_boundary_reuse.txt
+for wl in c5 c2 c3; do for cb in 1 0; do for rf in 1 0; do
+  GDR_COMPILED_BOUNDARY=$cb GDR_REUSE_FORWARD=$rf timeout 600 python bench.py --workload $wl --per-view --unfused --prebuilt-cams --no-cpu-baseline --no-roofline --steps 10 2>/dev/null | python -c "import json,sys; d=json.load(sys.stdin); print('$wl compiled_boundary=$cb reuse_forward=$rf', d['value'], 'views/s', d['ms_per_step'], 'ms/step')" | tee -a $O/${TAG}_ab_boundary_reuse.txt
+done; done; done
 echo "--- abs-grad entry + device top-k"
 python scripts/absgrad_bench.py 2>/dev/null | tee $O/${TAG}_absgrad.txt
 echo "--- size sweep (every frac must stay <= 1; traffic null off the recorded scene)"
@@ -78,6 +90,7 @@ done
 echo "--- RCCL, one rank, collectives forced: plain / K9 writing into the packed buffer (gradient sinks) / the same with the collectives asynchronous / gradients kept"
 timeout 600 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-roofline --no-per-view-leg 2>/dev/null | tail -1 | tee $O/${TAG}_bench_rccl_1rank_plain.json | cut -c1-120
 timeout 600 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-roofline --no-per-view-leg --force-dist --grad-allreduce 2>/dev/null | tail -1 | tee $O/${TAG}_bench_rccl_1rank.json | cut -c1-200
+timeout 600 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-roofline --no-per-view-leg --force-dist --grad-allreduce --separate-loss-gather 2>/dev/null | tail -1 | tee $O/${TAG}_bench_rccl_1rank_separate_loss_gather.json | cut -c1-200
 timeout 600 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-roofline --no-per-view-leg --force-dist --grad-allreduce --overlap-comm 2>/dev/null | tail -1 | tee $O/${TAG}_bench_rccl_1rank_overlap.json | cut -c1-200
 timeout 600 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-roofline --no-per-view-leg --force-dist --grad-allreduce --keep-grads 2>/dev/null | tail -1 | tee $O/${TAG}_bench_rccl_1rank_keepgrads.json | cut -c1-200
 echo "--- the reference's per-sample sequence through the unchanged caller: phases, forward reuse on / off, kernel timeline"
