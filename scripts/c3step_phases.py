@@ -109,7 +109,7 @@ for reuse in (False, True):
     for _ in range(reps):
         step(sync=False)
     torch.cuda.synchronize()
-    print(f"  unsynchronised step      {1e6 * (time.perf_counter() - t0) / reps:8.0f} us   stats {G._REUSE_STATS}")
+    print(f"  unsynchronised step      {1e6 * (time.perf_counter() - t0) / reps:8.0f} us   stats {dict(G._REUSE_STATS)}")
 
 if "--profile" in sys.argv:
     import cProfile, pstats
