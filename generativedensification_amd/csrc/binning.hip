@@ -967,6 +967,13 @@ hipError_t launch_tile_scatter(const BinViews& vs, int V, int N, int W, int H, h
 }
 
 // per-tile depth sort; input = buffers [in] (tile-partitioned; packed: one word per entry), output = values [in ^ 1]
+// waves per workgroup of the medium class (measurement builds may change it: the forward-phase starvation study of round 6)
+#ifndef GDR_TSORT_MEDIUM_WAVES
+#define GDR_TSORT_MEDIUM_WAVES 8
+#endif
+#ifndef GDR_TSORT_NO_LONG
+#define GDR_TSORT_NO_LONG 0
+#endif
 hipError_t launch_tile_sort_views(const BinViews& vs, int V, int in, int tiles, bool packed, hipStream_t st) {
     if (max_D(vs, V) == 0) return hipSuccess;
     // long lists: 16 waves per workgroup so that the few heavy tiles finish quickly; a two-class scheme (everything
@@ -988,16 +995,18 @@ hipError_t launch_tile_sort_views(const BinViews& vs, int V, int in, int tiles, 
     // runs) — slower for such a list, identical result, so a wrong hint only costs time.
     bool no_long = true;
     for (int v = 0; v < V; ++v) no_long = no_long && vs.v[v].hint_long < 0;
+    if (GDR_TSORT_NO_LONG) no_long = true;
+    constexpr int MW = GDR_TSORT_MEDIUM_WAVES;
     if (packed) {
         if (!no_long)
             GDR_LAUNCH(GDR_K_TILE_SORT_LONG, (tile_sort_kernel<GDR_TSORT_LARGE, GDR_TSORT_MEDIUM, 16, true, true>),
                        dim3(g_long, V), dim3(16 * GDR_WAVE), st, vs, in, tiles);
         if (no_long)
-            GDR_LAUNCH(GDR_K_TILE_SORT_LONG, (tile_sort_kernel<GDR_TSORT_MEDIUM, GDR_TSORT_SMALL, 8, true, true>),
-                       dim3(g_medium, V), dim3(8 * GDR_WAVE), st, vs, in, tiles);
+            GDR_LAUNCH(GDR_K_TILE_SORT_LONG, (tile_sort_kernel<GDR_TSORT_MEDIUM, GDR_TSORT_SMALL, MW, true, true>),
+                       dim3(g_medium, V), dim3(MW * GDR_WAVE), st, vs, in, tiles);
         else
-            GDR_LAUNCH(GDR_K_TILE_SORT_LONG, (tile_sort_kernel<GDR_TSORT_MEDIUM, GDR_TSORT_SMALL, 8, false, true>),
-                       dim3(g_medium, V), dim3(8 * GDR_WAVE), st, vs, in, tiles);
+            GDR_LAUNCH(GDR_K_TILE_SORT_LONG, (tile_sort_kernel<GDR_TSORT_MEDIUM, GDR_TSORT_SMALL, MW, false, true>),
+                       dim3(g_medium, V), dim3(MW * GDR_WAVE), st, vs, in, tiles);
         GDR_LAUNCH(GDR_K_TILE_SORT, (tile_sort_kernel<GDR_TSORT_SMALL, 0, 4, false, true>), dim3(tiles, V), dim3(GDR_BLOCK), st,
                    vs, in, tiles);
         return hipGetLastError();
