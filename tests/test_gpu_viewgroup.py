@@ -459,3 +459,47 @@ def test_an_output_edited_in_place_is_not_handed_out_again():
     np.testing.assert_array_equal(c[0].detach().cpu().numpy(), ref.cpu().numpy())
     np.testing.assert_array_equal(c[3].detach().cpu().numpy(), b[3].detach().cpu().numpy())
     assert G._REUSE_STATS["hits"] == hits              # (a's entry was ruled out: c ran its own forward)
+
+
+def test_two_host_threads_drive_their_own_gaussian_sets_concurrently():
+    """include/gdr.h promises thread safety for distinct workspaces, and the compiled boundary (csrc/boundary.cpp) keeps its
+    group registry, reuse history and pace counters behind mutexes / per thread: two host threads, each running the reference's
+    per-view loop + one backward on its OWN leaves and its own stream, several steps, must each get exactly what the same loop
+    gives alone — images bit for bit, gradients within the per-element bar (the K7 atomics' order is the only freedom)."""
+    import threading
+    dev, base, sets, tg, n = _setup(V=4, n=12_000, B=2, seed=17)
+    want = {}
+    for i in (0, 1):
+        leaves = {k: v.clone().requires_grad_(True) for k, v in base.items()}
+        imgs, losses, _ = _reference_loop(leaves, sets, tg, n, dev, i=i)
+        sum(losses).backward()
+        torch.cuda.synchronize()
+        want[i] = ([x.detach().cpu().numpy() for x in imgs], {k: v.grad.cpu().numpy() for k, v in leaves.items()})
+    got, errors = {}, []
+
+    def worker(i):
+        try:
+            stream = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(stream):
+                for _ in range(6):
+                    leaves = {k: v.clone().requires_grad_(True) for k, v in base.items()}
+                    imgs, losses, _ = _reference_loop(leaves, sets, tg, n, dev, i=i)
+                    sum(losses).backward()
+                stream.synchronize()
+                got[i] = ([x.detach().cpu().numpy() for x in imgs], {k: v.grad.cpu().numpy() for k, v in leaves.items()})
+        except Exception as exc:      # noqa: BLE001
+            errors.append((i, repr(exc)))
+    torch.cuda.synchronize()
+    threads = [threading.Thread(target=worker, args=(i,)) for i in (0, 1)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for i in (0, 1):
+        for a, b in zip(got[i][0], want[i][0]):
+            np.testing.assert_array_equal(a, b)
+        for k in want[i][1]:
+            out, worst, maxn = U.elem_stats(got[i][1][k], want[i][1][k])
+            assert out < U.MAX_OUTSIDE and maxn < 1e-4, (i, k, out, worst, maxn)
+            assert np.abs(got[i][1][k][1 - i]).max() == 0          # the other sample was never rendered by this thread
