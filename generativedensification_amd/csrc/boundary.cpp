@@ -340,7 +340,9 @@ static const int kMaxViewsPerGroup = 64;
 struct ReuseHist { bool matched = false; int since = 0; int period = 32; };   // period: calls between probes after a miss (doubles per miss)
 static std::unordered_map<std::string, std::map<int, ReuseHist>> g_reuse_hist;
 static int64_t g_probes = 0, g_hits = 0;
-static std::unordered_map<int, Tensor> g_scratch;     // device index -> the probe's device words
+// device index -> the probe's device words.  Heap-allocated and never destroyed: a static holding device tensors would be torn
+// down at process exit in an unspecified order relative to torch's caching allocator.
+static std::unordered_map<int, Tensor>& g_scratch = *new std::unordered_map<int, Tensor>();
 
 struct GroupMismatch : std::runtime_error { using std::runtime_error::runtime_error; };
 
