@@ -1052,7 +1052,9 @@ __device__ __forceinline__ void render_bwd_body(const BwdViews& vs, int V, int i
                 const float lim = (top - (int)en.e < last_contributor) ? GDR_ALPHA_MIN : INFINITY;
                 const bool hit = alpha >= lim;
                 const uint64_t hb = __ballot(hit);
+#ifndef GDR_K7_NO_EARLYOUT      /* measurement builds: without the branch the four accumulates of the unrolled walk are one basic block */
                 if (hb == 0ull) return;
+#endif
                 const float a = hit ? alpha : 0.f;
                 const float Gh = hit ? G : 0.f;                       // a lane without a hit contributes nothing below
                 const float r_oma = __builtin_amdgcn_rcpf(1.f - a);  // == 1 when a == 0
